@@ -1,0 +1,229 @@
+// ORACLE / TEST INFRASTRUCTURE — NOT PRODUCT CODE.
+//
+// C-ABI facade over the *reference's own* classes, compiled together with the reference
+// sources where they lie under /root/reference/engine (see oracle/Makefile) into
+// oracle/_ref/libepsilla_ref.so.  Nothing here re-implements the algorithm: every entry
+// point forwards to the reference (`fvec_L2sqr`, `GetDistFunc`, `ANNGraphSegment`,
+// `VecSearchExecutor`, `DBServer`).  It exists so that Python tests (ctypes) can
+//   (a) pin oracle/epsilla_oracle.c against the real reference on the same inputs,
+//   (b) generate the golden fixtures under tests/golden/ (scripts/gen_golden.py),
+//   (c) time the reference CPU path as bench.py's cpu_baseline.kind == "reference".
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+#include <omp.h>
+
+#include <atomic>
+#include <chrono>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "config/config.hpp"
+#include "db/ann_graph_segment.hpp"
+#include "db/db_server.hpp"
+#include "db/execution/vec_search_executor.hpp"
+#include "db/index/distances.hpp"
+#include "db/index/index.hpp"
+#include "db/vector.hpp"
+
+using vectordb::engine::ANNGraphSegment;
+using vectordb::engine::execution::VecSearchExecutor;
+namespace meta = vectordb::engine::meta;
+
+namespace {
+meta::MetricType ToMetric(int m) {
+  // 0 = EUCLIDEAN, 1 = COSINE, 2 = DOT_PRODUCT  (same numbering as include/epsilla_gfx950.h)
+  switch (m) {
+    case 1: return meta::MetricType::COSINE;
+    case 2: return meta::MetricType::DOT_PRODUCT;
+    default: return meta::MetricType::EUCLIDEAN;
+  }
+}
+
+struct RefExecutor {
+  std::shared_ptr<ANNGraphSegment> graph;
+  std::unique_ptr<VecSearchExecutor> exec;
+  size_t dim;  // dist_func_param_ points here (reference passes &vector_dimension_)
+};
+
+std::atomic<uint64_t> g_dist_calls{0};
+vectordb::DenseVecDistFunc<float> g_inner_fn = nullptr;
+float CountingDist(const void* a, const void* b, const void* p) {
+  g_dist_calls.fetch_add(1, std::memory_order_relaxed);
+  return g_inner_fn(a, b, p);
+}
+}  // namespace
+
+extern "C" {
+
+// ---------------------------------------------------------------- distances
+float ref_fvec_L2sqr(const float* x, const float* y, int64_t d) { return vectordb::fvec_L2sqr(x, y, (size_t)d); }
+float ref_fvec_inner_product(const float* x, const float* y, int64_t d) {
+  return vectordb::fvec_inner_product(x, y, (size_t)d);
+}
+// distance as the engine sees it: GetDistFunc(VECTOR_FLOAT, metric)(row, query, &dim)
+float ref_dist(int metric, const float* row, const float* query, int64_t d) {
+  auto f = std::get<vectordb::DenseVecDistFunc<float>>(vectordb::GetDistFunc(meta::FieldType::VECTOR_FLOAT, ToMetric(metric)));
+  size_t dim = (size_t)d;
+  return f(row, query, &dim);
+}
+void ref_dist_batch(int metric, const float* rows, int64_t n, const float* query, int64_t d, float* out) {
+  auto f = std::get<vectordb::DenseVecDistFunc<float>>(vectordb::GetDistFunc(meta::FieldType::VECTOR_FLOAT, ToMetric(metric)));
+  size_t dim = (size_t)d;
+#pragma omp parallel for
+  for (int64_t i = 0; i < n; ++i) out[i] = f(rows + i * d, query, &dim);
+}
+void ref_normalize(float* v, int64_t d) { vectordb::engine::Normalize(v, (size_t)d); }
+
+// ---------------------------------------------------------------- graph segment
+void* ref_graph_build(float* rows, int64_t n, int64_t d, int metric, int threads) {
+  omp_set_num_threads(threads);  // TableMVP::Rebuild does omp_set_num_threads(RebuildThreads) (table_mvp.cpp:96)
+  auto* g = new std::shared_ptr<ANNGraphSegment>(std::make_shared<ANNGraphSegment>(true));
+  (*g)->BuildFromVectorTable(rows, n, d, ToMetric(metric));
+  return g;
+}
+void* ref_graph_from_arrays(int64_t n, const int64_t* off, const int64_t* nbr, int64_t nav) {
+  auto* g = new std::shared_ptr<ANNGraphSegment>(std::make_shared<ANNGraphSegment>(true));
+  (*g)->record_number_ = n;
+  (*g)->offset_table_ = new int64_t[n + 1];
+  memcpy((*g)->offset_table_, off, sizeof(int64_t) * (n + 1));
+  int64_t e = off[n];
+  (*g)->neighbor_list_ = new int64_t[e > 0 ? e : 1];
+  memcpy((*g)->neighbor_list_, nbr, sizeof(int64_t) * e);
+  (*g)->navigation_point_ = nav;
+  return g;
+}
+// file ctor: <dir>/<table_id>/ann_graph_<field_id>.bin
+void* ref_graph_load(const char* dir, int64_t table_id, int64_t field_id) {
+  try {
+    return new std::shared_ptr<ANNGraphSegment>(std::make_shared<ANNGraphSegment>(std::string(dir), table_id, field_id));
+  } catch (...) {
+    return nullptr;
+  }
+}
+int ref_graph_save(void* h, const char* dir, int64_t table_id, int64_t field_id) {
+  auto& g = *static_cast<std::shared_ptr<ANNGraphSegment>*>(h);
+  return g->SaveANNGraph(std::string(dir), table_id, field_id, true).code();
+}
+int64_t ref_graph_n(void* h) { return (*static_cast<std::shared_ptr<ANNGraphSegment>*>(h))->record_number_; }
+int64_t ref_graph_edges(void* h) {
+  auto& g = *static_cast<std::shared_ptr<ANNGraphSegment>*>(h);
+  return g->offset_table_ ? g->offset_table_[g->record_number_] : 0;
+}
+int64_t ref_graph_nav(void* h) { return (*static_cast<std::shared_ptr<ANNGraphSegment>*>(h))->navigation_point_; }
+void ref_graph_copy(void* h, int64_t* off, int64_t* nbr) {
+  auto& g = *static_cast<std::shared_ptr<ANNGraphSegment>*>(h);
+  int64_t n = g->record_number_;
+  memcpy(off, g->offset_table_, sizeof(int64_t) * (n + 1));
+  memcpy(nbr, g->neighbor_list_, sizeof(int64_t) * g->offset_table_[n]);
+}
+void ref_graph_free(void* h) { delete static_cast<std::shared_ptr<ANNGraphSegment>*>(h); }
+
+// ---------------------------------------------------------------- executor (graph search only)
+void* ref_executor_new(void* graph, float* rows, int64_t d, int metric, int T, int64_t L_master, int64_t L_local,
+                       int64_t iters, int count_dists) {
+  auto* e = new RefExecutor;
+  e->graph = *static_cast<std::shared_ptr<ANNGraphSegment>*>(graph);
+  e->dim = (size_t)d;
+  vectordb::DistFunc df = vectordb::GetDistFunc(meta::FieldType::VECTOR_FLOAT, ToMetric(metric));
+  if (count_dists) {
+    g_inner_fn = std::get<vectordb::DenseVecDistFunc<float>>(df);
+    df = (vectordb::DenseVecDistFunc<float>)CountingDist;
+  }
+  e->exec.reset(new VecSearchExecutor(d, e->graph->navigation_point_, e->graph, e->graph->offset_table_,
+                                      e->graph->neighbor_list_, rows, df, &e->dim, T, L_master, L_local, iters, false));
+  return e;
+}
+void ref_executor_init_ids(void* h, int64_t* out) {
+  auto* e = static_cast<RefExecutor*>(h);
+  memcpy(out, e->exec->init_ids_.data(), sizeof(int64_t) * e->exec->init_ids_.size());
+}
+// VecSearchExecutor::SearchImpl on one query; copies the first K entries of the master queue.
+void ref_executor_search_impl(void* h, float* query, int64_t K, int64_t* ids, float* dists) {
+  auto* e = static_cast<RefExecutor*>(h);
+  auto& x = *e->exec;
+  x.SearchImpl(query, K, x.L_master_, x.set_L_, x.init_ids_, x.search_result_, x.L_local_, x.local_queues_starts_,
+               x.local_queues_sizes_, x.is_visited_, x.subsearch_iterations_);
+  const int64_t ms = x.local_queues_starts_[x.num_threads_ - 1];
+  for (int64_t i = 0; i < K; ++i) {
+    ids[i] = x.set_L_[ms + i].id_;
+    dists[i] = x.set_L_[ms + i].distance_;
+  }
+}
+// nq queries with E executors' worth of outer parallelism is done by the caller; this is one
+// executor, sequential over queries (what one pool slot does).  Returns seconds.
+double ref_executor_search_many(void* h, float* queries, int64_t nq, int64_t K, int64_t* ids, float* dists) {
+  auto* e = static_cast<RefExecutor*>(h);
+  auto t0 = std::chrono::steady_clock::now();
+  for (int64_t q = 0; q < nq; ++q) ref_executor_search_impl(h, queries + q * (int64_t)e->dim, K, ids + q * K, dists + q * K);
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+uint64_t ref_dist_calls_reset() { return g_dist_calls.exchange(0); }
+void ref_executor_free(void* h) { delete static_cast<RefExecutor*>(h); }
+
+// ---------------------------------------------------------------- DBServer (JSON level)
+void ref_config(int intra_query_threads, int search_queue_size, int rebuild_threads, int prefilter, int executors) {
+  auto& c = vectordb::globalConfig;
+  if (intra_query_threads > 0) c.setIntraQueryThreads(intra_query_threads);
+  if (search_queue_size > 0) c.setSearchQueueSize(search_queue_size);
+  if (rebuild_threads > 0) c.setRebuildThreads(rebuild_threads);
+  if (prefilter >= 0) c.PreFilter.store(prefilter != 0);
+  if (executors > 0) c.setNumExecutorPerField(executors);
+}
+void* ref_db_new() { return new vectordb::engine::DBServer(); }
+void ref_db_free(void* h) { delete static_cast<vectordb::engine::DBServer*>(h); }
+int ref_db_load(void* h, const char* name, const char* path, int64_t scale, int wal) {
+  std::unordered_map<std::string, std::string> headers;
+  return static_cast<vectordb::engine::DBServer*>(h)->LoadDB(name, path, scale, wal != 0, headers).code();
+}
+int ref_db_create_table(void* h, const char* db, const char* schema_json) {
+  size_t id = 0;
+  return static_cast<vectordb::engine::DBServer*>(h)->CreateTable(db, std::string(schema_json), id).code();
+}
+int ref_db_insert(void* h, const char* db, const char* table, const char* records_json) {
+  vectordb::Json j;
+  if (!j.LoadFromString(records_json)) return -1;
+  std::unordered_map<std::string, std::string> headers;
+  return static_cast<vectordb::engine::DBServer*>(h)->Insert(db, table, j, headers).code();
+}
+int ref_db_delete(void* h, const char* db, const char* table, const char* pk_json, const char* filter) {
+  vectordb::Json j;
+  if (!j.LoadFromString(pk_json)) return -1;
+  return static_cast<vectordb::engine::DBServer*>(h)->Delete(db, table, j, filter).code();
+}
+int ref_db_rebuild(void* h) { return static_cast<vectordb::engine::DBServer*>(h)->Rebuild().code(); }
+int ref_db_swap_executors(void* h) { return static_cast<vectordb::engine::DBServer*>(h)->SwapExecutors().code(); }
+// fields_csv: comma separated response fields.  Result JSON is written into out (NUL terminated,
+// truncated to cap).  Returns the Status code.
+int ref_db_search(void* h, const char* db, const char* table, const char* field, const char* fields_csv, float* q,
+                  int64_t d, int64_t limit, const char* filter, int with_distance, char* out, int64_t cap) {
+  std::string f(field);
+  std::vector<std::string> fields;
+  std::string cur;
+  for (const char* p = fields_csv; *p; ++p) {
+    if (*p == ',') {
+      if (!cur.empty()) fields.push_back(cur);
+      cur.clear();
+    } else {
+      cur.push_back(*p);
+    }
+  }
+  if (!cur.empty()) fields.push_back(cur);
+  vectordb::Json result, facets_cfg, facets;
+  facets_cfg.LoadFromString("[]");
+  auto st = static_cast<vectordb::engine::DBServer*>(h)->Search(db, table, f, fields, d, q, limit, result, filter,
+                                                                 with_distance != 0, facets_cfg, facets);
+  std::string s = st.ok() ? result.DumpToString() : st.message();
+  if (cap > 0) {
+    size_t n = std::min<size_t>(s.size(), (size_t)cap - 1);
+    memcpy(out, s.data(), n);
+    out[n] = 0;
+  }
+  return st.code();
+}
+
+int ref_omp_max_threads() { return omp_get_max_threads(); }
+
+}  // extern "C"

@@ -1,0 +1,2 @@
+// ORACLE BUILD SHIM: included by the reference but unused.
+#pragma once
