@@ -26,7 +26,11 @@
 #include "db/execution/vec_search_executor.hpp"
 #include "db/index/distances.hpp"
 #include "db/index/index.hpp"
+#include "db/index/knn/knn.hpp"
+#include "db/index/nsg/nsg.hpp"
 #include "db/vector.hpp"
+
+namespace vectordb { namespace engine { namespace index { extern unsigned int seed; } } }  // nsg.cpp:19
 
 using vectordb::engine::ANNGraphSegment;
 using vectordb::engine::execution::VecSearchExecutor;
@@ -121,6 +125,50 @@ void ref_graph_copy(void* h, int64_t* off, int64_t* nbr) {
 }
 void ref_graph_free(void* h) { delete static_cast<std::shared_ptr<ANNGraphSegment>*>(h); }
 
+// ---------------------------------------------------------------- build stages, separately
+// NN-Descent kNN graph exactly as BuildFromVectorTable runs it (ann_graph_segment.cpp:208): ids per
+// node in ascending distance, -1 padded to K.
+void ref_knn_graph(float* rows, int64_t n, int64_t d, int64_t K, int metric, int threads, int64_t* out) {
+  omp_set_num_threads(threads);
+  vectordb::engine::index::Graph knng(n);
+  vectordb::engine::index::KNNGraph graph(n, d, K, rows, knng, ToMetric(metric));
+  for (int64_t i = 0; i < n; ++i)
+    for (int64_t j = 0; j < K; ++j) out[i * K + j] = j < (int64_t)knng[i].size() ? knng[i][j] : -1;
+}
+// NsgIndex::Build on a caller-supplied kNN graph (always Metric_Type_L2, ann_graph_segment.cpp:216);
+// the global rand_r seed (nsg.cpp:19) is reset to `seed0` first so runs are reproducible.
+// Returns a graph handle (same type as ref_graph_build).
+void* ref_nsg_from_knn(float* rows, int64_t n, int64_t d, const int64_t* knn, int64_t K, int64_t search_length,
+                       int64_t out_degree, int64_t candidate_pool, int threads, unsigned seed0) {
+  omp_set_num_threads(threads);
+  vectordb::engine::index::seed = seed0;
+  vectordb::engine::index::Graph knng(n);
+  for (int64_t i = 0; i < n; ++i)
+    for (int64_t j = 0; j < K; ++j)
+      if (knn[i * K + j] >= 0) knng[i].push_back(knn[i * K + j]);
+  vectordb::engine::index::BuildParams bp;
+  bp.search_length = search_length;
+  bp.out_degree = out_degree;
+  bp.candidate_pool_size = candidate_pool;
+  vectordb::engine::index::NsgIndex idx(d, n, vectordb::engine::index::NsgIndex::Metric_Type_L2);
+  idx.SetKnnGraph(knng);
+  idx.Build(n, rows, nullptr, bp);
+  auto* g = new std::shared_ptr<ANNGraphSegment>(std::make_shared<ANNGraphSegment>(true));
+  (*g)->record_number_ = n;
+  (*g)->offset_table_ = new int64_t[n + 1];
+  int64_t e = 0;
+  for (int64_t i = 0; i < n; ++i) e += idx.nsg[i].size();
+  (*g)->neighbor_list_ = new int64_t[e > 0 ? e : 1];
+  int64_t o = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    (*g)->offset_table_[i] = o;
+    for (auto v : idx.nsg[i]) (*g)->neighbor_list_[o++] = v;
+  }
+  (*g)->offset_table_[n] = o;
+  (*g)->navigation_point_ = idx.navigation_point;
+  return g;
+}
+
 // ---------------------------------------------------------------- executor (graph search only)
 void* ref_executor_new(void* graph, float* rows, int64_t d, int metric, int T, int64_t L_master, int64_t L_local,
                        int64_t iters, int count_dists) {
@@ -172,7 +220,14 @@ void ref_config(int intra_query_threads, int search_queue_size, int rebuild_thre
   if (prefilter >= 0) c.PreFilter.store(prefilter != 0);
   if (executors > 0) c.setNumExecutorPerField(executors);
 }
-void* ref_db_new() { return new vectordb::engine::DBServer(); }
+// DBServer::is_leader_ is not initialised by the constructor; the reference's own tests call
+// SetLeader(true) before LoadDB whenever they Rebuild (test/engine/db/db_server.cpp:810,946,1088).
+void* ref_db_new() {
+  auto* s = new vectordb::engine::DBServer();
+  s->SetLeader(true);
+  return s;
+}
+void ref_db_set_leader(void* h, int leader) { static_cast<vectordb::engine::DBServer*>(h)->SetLeader(leader != 0); }
 void ref_db_free(void* h) { delete static_cast<vectordb::engine::DBServer*>(h); }
 int ref_db_load(void* h, const char* name, const char* path, int64_t scale, int wal) {
   std::unordered_map<std::string, std::string> headers;
