@@ -1,0 +1,174 @@
+/* epsilla_gfx950.h — C ABI of libepsilla_gfx950.so, the MI355X (gfx950 / CDNA4) implementation of
+ * Epsilla's ANN hot path.  Plain pointers and sizes only; no C++/torch types cross this boundary.
+ *
+ * What each entry point replaces in the reference (paths relative to /root/reference/engine):
+ *
+ *   eps_index_create / destroy      VecSearchExecutor ctor + ExecutorPool slot
+ *                                   (db/execution/vec_search_executor.cpp:29-73, executor_pool.hpp:10-31);
+ *                                   metric selection = GetDistFunc (db/index/index.cpp:10-35)
+ *   eps_index_attach_rows           the executor borrowing TableSegmentMVP::vector_tables_[f]
+ *                                   (db/table_segment_mvp.hpp:85, alloc .cpp:106-111): row-major float[n][dim]
+ *   eps_index_set_deleted           ConcurrentBitset bytes of table_segment->deleted_
+ *                                   (utils/concurrent_bitset.cpp:9-18), read per Search() call (:839)
+ *   eps_index_set_int_filter        the `ID < N`-class post-filter ExprEvaluator::LogicalEvaluate applies to
+ *                                   result candidates (vec_search_executor.cpp:905-927, query/expr/expr_evaluator.cpp:170-258)
+ *   eps_index_build                 ANNGraphSegment::BuildFromVectorTable (db/ann_graph_segment.cpp:201-242)
+ *   eps_index_set_graph / get_graph the public CSR members offset_table_/neighbor_list_/navigation_point_
+ *                                   (db/ann_graph_segment.hpp:44-49) the executor is constructed from
+ *   eps_index_save_graph/load_graph ANNGraphSegment::SaveANNGraph (.cpp:156-199) / file ctor (.cpp:39-98),
+ *                                   byte-identical `ann_graph_<field>.bin`
+ *   eps_index_search                VecSearchExecutor::Search (.cpp:833-935) for a BATCH of queries: mode
+ *                                   selection, SearchImpl (:518-715), BruteForceSearch (:717-768),
+ *                                   PreFilterBruteForceSearch (:770-831), tail merge, post-filter; results are
+ *                                   what the caller reads from search_result_ / distance_ (hpp:51-52)
+ *   eps_normalize_rows              Normalize (db/vector.cpp:60-69) and the insert-time normalisation
+ *                                   (db/table_segment_mvp.cpp:574-587)
+ *   eps_merge_topk                  (new) merges per-shard top-k lists after the RCCL all-gather
+ *
+ * Pointer arguments documented "host or device" are classified with hipPointerGetAttributes; device
+ * pointers are used in place (no copy) on the index's stream.  Every function returns a status code
+ * from the reference's own table (utils/error.hpp:11-41): 0 = OK.  Calls on one handle must not overlap
+ * (same contract as one VecSearchExecutor: one thread per executor instance); different handles are
+ * independent.  The library never falls back to a CPU path: without a usable gfx950 device
+ * eps_index_create fails with EPS_INFRA_UNEXPECTED_ERROR.
+ */
+#ifndef EPSILLA_GFX950_H_
+#define EPSILLA_GFX950_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* status codes: utils/error.hpp:11-41 */
+#define EPS_OK 0
+#define EPS_USER_ERROR 30000
+#define EPS_INFRA_UNEXPECTED_ERROR 40001
+#define EPS_DB_UNEXPECTED_ERROR 50001
+#define EPS_DB_UNSUPPORTED_ERROR 50002
+#define EPS_NOT_IMPLEMENTED_ERROR 50009
+#define EPS_INVALID_PAYLOAD 50400
+
+/* meta::MetricType (db/catalog/meta_types.hpp:44-50) as used by GetDistFunc; "smaller = closer" for all:
+ * EUCLIDEAN -> squared L2, COSINE -> 1 - dot (rows/queries normalised by the caller or eps_normalize_rows),
+ * DOT_PRODUCT -> -dot. */
+#define EPS_METRIC_EUCLIDEAN 0
+#define EPS_METRIC_COSINE 1
+#define EPS_METRIC_DOT_PRODUCT 2
+
+/* search modes */
+#define EPS_MODE_REFERENCE 0 /* VecSearchExecutor::Search's own mode selection (:855-935)          */
+#define EPS_MODE_FLAT 1      /* exact flat scan of [0,n_total) (the BruteForceSearch answer for any n) */
+#define EPS_MODE_GRAPH 2     /* graph traversal + tail even when n_indexed < BruteforceThreshold       */
+
+/* flat-scan engines (EPS_MODE_FLAT, and the flat branches of EPS_MODE_REFERENCE) */
+#define EPS_FLAT_AUTO 0
+#define EPS_FLAT_STREAM 1 /* fp32 streaming scan, HBM-bound; any batch size                            */
+#define EPS_FLAT_MFMA 2   /* fp16-MFMA lower-bound filter over a device-side half mirror + exact fp32
+                             re-rank; returns the same exact answer; for large batches                 */
+
+/* filter comparison operators for eps_index_set_int_filter */
+#define EPS_OP_NONE 0
+#define EPS_OP_LT 1
+#define EPS_OP_LE 2
+#define EPS_OP_EQ 3
+#define EPS_OP_GE 4
+#define EPS_OP_GT 5
+#define EPS_OP_NE 6
+
+typedef struct eps_index eps_index; /* opaque */
+
+/* Search knobs; mirror vectordb::Config (config/config.hpp:17-25) and the executor ctor arguments. */
+typedef struct eps_search_params {
+  int32_t mode;            /* EPS_MODE_*                                                       */
+  int32_t flat_engine;     /* EPS_FLAT_*                                                       */
+  int32_t prefilter;       /* Config::PreFilter: flat scan with the filter applied first        */
+  int32_t intra_threads;   /* Config::IntraQueryThreads (T); the device runs T candidate
+                              expansions of a query concurrently per round (1 = the reference's
+                              deterministic single-thread order)                               */
+  int64_t master_queue;    /* Config::MasterQueueSize (L)                                      */
+  int64_t local_queue;     /* Config::LocalQueueSize (result cap, :872)                        */
+  int64_t sync_interval;   /* Config::GlobalSyncInterval (expansions per worker per round)     */
+} eps_search_params;
+
+/* Build knobs; defaults = NSGConfig(45,50,300,100) (db/ann_graph_segment.cpp:29). */
+typedef struct eps_build_params {
+  int64_t search_length;
+  int64_t out_degree;
+  int64_t candidate_pool_size;
+  int64_t knng;
+  uint32_t seed;      /* rand_r state the NSG stage starts from (nsg.cpp:19 uses 100) */
+  int32_t reserved;
+} eps_build_params;
+
+/* counters of the last eps_index_search call (the reference's commented-out
+ * count_distance_computation_, vec_search_executor.hpp:162, revived) */
+typedef struct eps_search_stats {
+  int64_t dist_evals;       /* distance evaluations, summed over the batch                 */
+  int64_t expansions;       /* graph nodes expanded, summed over the batch                 */
+  int64_t rerank_rows;      /* rows re-ranked in exact fp32 by the MFMA engine             */
+  int64_t overflow_queries; /* queries that fell back from the MFMA filter to the fp32 scan */
+  double kernel_ms;         /* device time of the call measured with hipEvents on its stream */
+  double main_kernel_ms;    /* device time of the dominant kernel only                      */
+  int64_t main_kernel_launches;
+} eps_search_stats;
+
+void eps_default_search_params(eps_search_params* p);
+void eps_default_build_params(eps_build_params* p);
+
+int32_t eps_index_create(int64_t dim, int32_t metric, int32_t device, eps_index** out);
+int32_t eps_index_destroy(eps_index* h);
+const char* eps_index_last_error(const eps_index* h);
+
+/* use an existing HIP stream (hipStream_t passed as void*); NULL = the index's own stream */
+int32_t eps_index_set_stream(eps_index* h, void* hip_stream);
+int32_t eps_index_synchronize(eps_index* h);
+
+/* rows: host or device, row-major float[n][dim].  Host rows are copied to HBM; device rows are
+ * borrowed (caller keeps them alive and immutable for [0,n)).  Replaces any previous attachment. */
+int32_t eps_index_attach_rows(eps_index* h, const float* rows, int64_t n);
+/* rows beyond the current count (the un-indexed tail, :885-900); only for host-attached (owned) stores */
+int32_t eps_index_append_rows(eps_index* h, const float* rows, int64_t n_new);
+int64_t eps_index_row_count(const eps_index* h);
+
+/* global id = local row index * stride + base (hash sharding by row index: stride = #shards, base = rank) */
+int32_t eps_index_set_id_map(eps_index* h, int64_t base, int64_t stride);
+
+/* deleted: host or device bitset, bit (i&7) of byte (i>>3); nbytes >= ceil(n/8); NULL clears */
+int32_t eps_index_set_deleted(eps_index* h, const uint8_t* bits, int64_t nbytes);
+/* integer attribute column: value of row i at column + i*stride_bytes, width_bytes in {1,2,4,8}, signed;
+ * host or device; rows failing `value <op> constant` are filtered. EPS_OP_NONE clears. */
+int32_t eps_index_set_int_filter(eps_index* h, const void* column, int64_t stride_bytes, int32_t width_bytes,
+                                 int32_t op, int64_t constant);
+
+/* graph over rows [0,n): built on the device, or supplied / exported as the reference's CSR */
+int32_t eps_index_build(eps_index* h, int64_t n, const eps_build_params* p);
+int32_t eps_index_set_graph(eps_index* h, int64_t n, const int64_t* offsets, const int64_t* neighbors,
+                            int64_t navigation_point);
+int32_t eps_index_graph_info(const eps_index* h, int64_t* n, int64_t* edges, int64_t* navigation_point);
+int32_t eps_index_get_graph(const eps_index* h, int64_t* offsets, int64_t* neighbors);
+int32_t eps_index_save_graph(eps_index* h, const char* path);
+int32_t eps_index_load_graph(eps_index* h, const char* path);
+
+/* queries: host or device float[nq][dim]; ids_out int64[nq][k], dist_out float[nq][k], counts_out
+ * int32[nq] (host or device, all three the same kind).  Unused slots are id -1 / +inf.
+ * COSINE queries must already be normalised (TableMVP::Search does it, table_mvp.cpp:333-349). */
+int32_t eps_index_search(eps_index* h, const float* queries, int64_t nq, int32_t k, const eps_search_params* p,
+                         int64_t* ids_out, float* dist_out, int32_t* counts_out);
+int32_t eps_index_last_stats(const eps_index* h, eps_search_stats* out);
+
+/* in-place L2 normalisation of float[n][dim] (host or device). only_if_nonzero = 1 reproduces the
+ * insert path (sum > 1e-10), 0 the query path (unconditional). */
+int32_t eps_normalize_rows(float* rows, int64_t n, int64_t dim, int32_t only_if_nonzero, int32_t device,
+                           void* hip_stream);
+
+/* merges `shards` sorted top-k lists per query by (dist,id): dist/ids are [shards][nq][k] device or host
+ * arrays (e.g. the output of an all-gather); out_* are [nq][k]. */
+int32_t eps_merge_topk(const float* dist, const int64_t* ids, int32_t shards, int64_t nq, int32_t k,
+                       float* out_dist, int64_t* out_ids, int32_t device, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EPSILLA_GFX950_H_ */

@@ -1,0 +1,79 @@
+"""CPU checks of the drop-in boundary: the C-ABI library builds/loads and exports exactly what include/*.h
+declares; the product path refuses to run without a GPU (no fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    from vectordb_amd.build import build
+    return build()
+
+
+def test_header_symbols_exported(built):
+    hdr = open(os.path.join(ROOT, "include", "epsilla_gfx950.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(eps_[a-z_0-9]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    lib = ctypes.CDLL(built)
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    from vectordb_amd import _lib
+    assert set(_lib.EXPORTS) == declared
+
+
+def test_defaults_mirror_reference_config(built):
+    from vectordb_amd import _lib
+    L = _lib.load()
+    p = _lib.SearchParams()
+    L.eps_default_search_params(ctypes.byref(p))
+    # config/config.hpp:17-25
+    assert (p.intra_threads, p.master_queue, p.local_queue, p.sync_interval, p.prefilter) == (4, 500, 500, 15, 0)
+    b = _lib.BuildParams()
+    L.eps_default_build_params(ctypes.byref(b))
+    # NSGConfig(45, 50, 300, 100), db/ann_graph_segment.cpp:29
+    assert (b.search_length, b.out_degree, b.candidate_pool_size, b.knng, b.seed) == (45, 50, 300, 100, 100)
+
+
+def test_no_cpu_fallback(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import vectordb_amd
+    with pytest.raises(vectordb_amd.EpsillaError) as e:
+        vectordb_amd.GpuIndex(16)
+    assert e.value.code == 40001
+
+
+def test_product_never_imports_oracle():
+    bad = []
+    for root, _, files in os.walk(os.path.join(ROOT, "vectordb_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
+                txt = open(os.path.join(root, f), errors="ignore").read()
+                if re.search(r"^\s*(from|import)\s+oracle|#include\s+[\"<].*oracle|libepsilla_oracle|libepsilla_ref", txt, re.M):
+                    bad.append(f)
+    assert not bad, bad
+
+
+def test_python_graph_file_roundtrip(tmp_path, oracle):
+    """vectordb_amd.ANNGraphSegment reads/writes the reference's ann_graph_<field>.bin layout."""
+    import numpy as np
+    from vectordb_amd import ANNGraphSegment
+    seg = ANNGraphSegment(skip_sync_disk=False)
+    seg.record_number_ = 3
+    seg.offset_table_ = np.array([0, 2, 3, 5], np.int64)
+    seg.neighbor_list_ = np.array([1, 2, 0, 0, 1], np.int64)
+    seg.navigation_point_ = 2
+    os.makedirs(tmp_path / "5")
+    assert seg.SaveANNGraph(str(tmp_path), 5, 1) == 0
+    off, nbr, nav, fid = oracle.graph_read(str(tmp_path / "5" / "ann_graph_1.bin"))
+    assert nav == 2 and fid == 0 and list(off) == [0, 2, 3, 5] and list(nbr) == [1, 2, 0, 0, 1]
+    seg2 = ANNGraphSegment(str(tmp_path), 5, 1)
+    assert seg2.record_number_ == 3 and seg2.navigation_point_ == 2
+    assert np.array_equal(seg2.offset_table_, off) and np.array_equal(seg2.neighbor_list_, nbr)

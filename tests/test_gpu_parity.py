@@ -1,0 +1,296 @@
+"""Parity tests proper: the HIP path, called through the C ABI (ctypes -> libepsilla_gfx950.so), against the
+CPU oracle on the same seeded inputs and against the golden vectors generated from the compiled reference.
+Run with `-m gpu` on an MI355X."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import assert_topk_match, bitset, data
+from oracle.pyoracle import make_filter
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import vectordb_amd
+    from vectordb_amd.build import build
+    build()
+    return vectordb_amd
+
+
+# ----------------------------------------------------------------------------------------------- flat scan
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("n,d", [(1, 4), (5, 4), (300, 7), (1000, 33), (5000, 128), (3000, 768), (2000, 960), (700, 2)])
+def test_flat_matches_oracle(amd, oracle, metric, n, d):
+    X = data(n, d, 100 + n + d)
+    Q = data(5, d, 200 + n + d) * 1.5 - 0.25
+    if metric == 1:
+        X = np.stack([oracle.normalize_insert(x) for x in X])
+        Q = np.stack([oracle.normalize_query(q) for q in Q])
+    ix = amd.GpuIndex(d, metric)
+    ix.attach_rows(X)
+    for k in (1, 10, 100):
+        ids, dist, cnt = ix.search(Q, k, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
+        for qi, q in enumerate(Q):
+            rid, rd = oracle.topk_flat(metric, X, q, k)
+            m = int(cnt[qi])
+            assert m == len(rid)
+            assert_topk_match(ids[qi, :m], dist[qi, :m], rid, rd, what="flat m%d n%d d%d k%d q%d" % (metric, n, d, k, qi))
+            assert np.all(ids[qi, m:] == -1) and np.all(np.isinf(dist[qi, m:]))
+    ix.close()
+
+
+@pytest.mark.parametrize("nq", [1, 2, 3, 4, 7, 33])
+def test_flat_batch_sizes_and_large_k(amd, oracle, nq):
+    X, Q = data(4000, 64, 1), data(nq, 64, 2)
+    ix = amd.GpuIndex(64, 0)
+    ix.attach_rows(X)
+    for k in (10, 65, 200, 600, 1024):
+        ids, dist, cnt = ix.search(Q, k, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
+        for qi in range(nq):
+            rid, rd = oracle.topk_flat(0, X, Q[qi], k)
+            assert_topk_match(ids[qi], dist[qi], rid, rd, what="nq%d k%d q%d" % (nq, k, qi))
+            assert np.all(np.diff(dist[qi]) >= 0)
+    ix.close()
+
+
+def test_flat_deleted_and_filter(amd, oracle):
+    n, d = 3000, 48
+    X, Q = data(n, d, 3), data(6, d, 4)
+    idcol = np.arange(n, dtype=np.int32)
+    attr = np.zeros((n, 3), np.int32)  # packed attribute rows: the ID lives at byte offset 4, stride 12
+    attr[:, 1] = idcol
+    dele = list(range(0, n, 2))
+    bits = bitset(n, dele)
+    ix = amd.GpuIndex(d, 0)
+    ix.attach_rows(X)
+    ix.set_deleted(bits)
+    for op, val in (("<", 1500), (">=", 2990), ("=", 77), ("!=", 5), ("<=", 2), (">", 10 ** 6)):
+        ix.set_int_filter(attr[:, 1:], op, val, stride=12, width=4)
+        flt, keep = make_filter(deleted=bits, attr=attr[:, 1:].copy(), stride=4, width=4, op=op, value=val)
+        ids, dist, cnt = ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
+        for qi, q in enumerate(Q):
+            rid, rd = oracle.topk_flat(0, X, q, 10, flt=flt)
+            m = int(cnt[qi])
+            assert m == len(rid)
+            assert_topk_match(ids[qi, :m], dist[qi, :m], rid, rd, what="%s %d" % (op, val))
+    # prefilter mode gives the same rows (PreFilterBruteForceSearch, :770-831)
+    ix.set_int_filter(attr[:, 1:], "<", 1500, stride=12, width=4)
+    a = ix.search(Q, 10, mode=amd.MODE_REFERENCE, prefilter=1)
+    b = ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
+    assert np.array_equal(a[0], b[0])
+    ix.close()
+
+
+def test_reference_mode_small_table_caps_at_local_queue(amd, oracle):
+    """n_indexed < 512 -> BruteForceSearch; result_size = min(survivors, limit, L_local) (:862-868)."""
+    X, Q = data(400, 16, 5), data(3, 16, 6)
+    ix = amd.GpuIndex(16, 0)
+    ix.attach_rows(X)
+    ids, dist, cnt = ix.search(Q, 300, mode=amd.MODE_REFERENCE, local_queue=120, master_queue=120)
+    assert list(cnt) == [120, 120, 120]
+    for qi, q in enumerate(Q):
+        oid, od, _ = oracle.search(0, X, 0, None, None, 0, q, 300, L=120)
+        assert_topk_match(ids[qi, :120], dist[qi, :120], oid, od)
+    ix.close()
+
+
+def test_known_answers_through_executor_mirror(amd, oracle):
+    """The reference's own gtest expectations (db_server.cpp:289-292, :514-751, :1407-1630), driven through the
+    VecSearchExecutor mirror class."""
+    cities = [("Berlin", [0.05, 0.61, 0.76, 0.74]), ("London", [0.19, 0.81, 0.75, 0.11]),
+              ("Moscow", [0.36, 0.55, 0.47, 0.94]), ("San Francisco", [0.18, 0.01, 0.85, 0.80]),
+              ("Shanghai", [0.24, 0.18, 0.22, 0.44])]
+    X = np.array([v for _, v in cities], np.float32)
+    q = np.array([0.35, 0.55, 0.47, 0.94], np.float32)
+    want = {"EUCLIDEAN": ["Moscow", "Berlin", "Shanghai", "San Francisco", "London"],
+            "DOT_PRODUCT": ["Moscow", "Berlin", "San Francisco", "London", "Shanghai"],
+            "COSINE": ["Moscow", "Shanghai", "Berlin", "San Francisco", "London"]}
+    seg = amd.ANNGraphSegment()
+    for metric, order in want.items():
+        rows, qq = X.copy(), q.copy()
+        if metric == "COSINE":
+            amd.normalize_rows(rows, only_if_nonzero=True)
+            qq = amd.normalize_rows(qq[None, :].copy(), only_if_nonzero=False)[0]
+        ex = amd.VecSearchExecutor(4, 0, seg, seg.offset_table_, seg.neighbor_list_, rows, amd.GetDistFunc("VECTOR_FLOAT", metric))
+        st, n = ex.Search(qq, 5, 6)
+        assert st == 0 and n == 5
+        assert [cities[i][0] for i in ex.search_result_[:n]] == order
+        if metric == "EUCLIDEAN":
+            assert abs(ex.distance_[0] - 1.0000040e-4) < 1e-8
+            st, n = ex.Search(qq, 5, 6, deleted=np.array([0b1111], np.uint8))
+            assert [cities[i][0] for i in ex.search_result_[:n]] == ["Shanghai"]
+            assert abs(ex.distance_[0] - 0.46149999) < 1e-6
+            st, n = ex.Search(qq, 5, 6, filter_spec=(np.arange(1, 6, dtype=np.int32), "<=", 2))
+            assert sorted(int(i) + 1 for i in ex.search_result_[:n]) == [1, 2]
+        if metric == "DOT_PRODUCT":
+            assert abs(ex.distance_[0] + 1.5329999924) < 1e-6
+
+
+def test_normalize_matches_reference_semantics(amd, oracle):
+    V = data(50, 37, 8) - 0.5
+    V[7] = 0.0
+    a = amd.normalize_rows(V.copy(), only_if_nonzero=True)
+    for i in range(50):
+        assert np.allclose(a[i], oracle.normalize_insert(V[i]), rtol=2e-6, atol=1e-7)
+    assert np.all(a[7] == 0)
+    b = amd.normalize_rows(V[:3].copy(), only_if_nonzero=False)
+    for i in range(3):
+        assert np.allclose(b[i], oracle.normalize_query(V[i]), rtol=2e-6, atol=1e-7)
+
+
+# ----------------------------------------------------------------------------------------------- graph search
+def _golden_graph():
+    z = np.load(os.path.join(G, "graph2000x32.npz"))
+    return z, z["off"].astype(np.int64), z["nbr"].astype(np.int64), int(z["nav"])
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_graph_search_T1_matches_reference_golden(amd, oracle, metric):
+    """Same graph (built by the reference), IntraQueryThreads = 1: the device traversal must return the
+    reference's result; golden = VecSearchExecutor::SearchImpl master queue from the compiled reference."""
+    z, off, nbr, nav = _golden_graph()
+    X, Q = data(2000, 32, 42), data(16, 32, 43)
+    ix = amd.GpuIndex(32, metric)
+    ix.attach_rows(X)
+    ix.set_graph(off, nbr, nav)
+    for k in (10, 100, 500):
+        ids, dist, cnt = ix.search(Q, k, mode=amd.MODE_GRAPH, intra_threads=1)
+        assert np.all(cnt == k)
+        for qi in range(len(Q)):
+            assert_topk_match(ids[qi], dist[qi], z["ids_m%d" % metric][qi][:k], z["dist_m%d" % metric][qi][:k],
+                              what="graph m%d k%d q%d" % (metric, k, qi))
+    # distance evaluations: identical visit sequence => identical count (up to fp ties at the bound)
+    ix.search(Q[:1], 10, mode=amd.MODE_GRAPH, intra_threads=1)
+    ev_gpu = ix.stats()["dist_evals"]
+    init = oracle.prepare_init_ids(off, nbr, nav, 500)
+    _, _, ev_or = oracle.search_impl(metric, X, off, nbr, init, Q[0], T=1, L=500)
+    assert abs(ev_gpu - ev_or) <= max(2, ev_or // 200), (ev_gpu, ev_or)
+    ix.close()
+
+
+def test_graph_search_T4_reaches_exact_answer(amd, oracle):
+    z, off, nbr, nav = _golden_graph()
+    X, Q = data(2000, 32, 42), data(16, 32, 44)
+    ix = amd.GpuIndex(32, 0)
+    ix.attach_rows(X)
+    ix.set_graph(off, nbr, nav)
+    ids, dist, cnt = ix.search(Q, 10, mode=amd.MODE_GRAPH, intra_threads=4)
+    for qi, q in enumerate(Q):
+        rid, rd = oracle.topk_flat(0, X, q, 10)
+        assert_topk_match(ids[qi], dist[qi], rid, rd, what="T4 q%d" % qi)
+    ix.close()
+
+
+def test_search_graph_tail_filter_deleted_golden(amd, oracle):
+    """Full Search(): graph over [0,1000) + brute-force tail [1000,1500) + merge + post-filter + deletes, against
+    the results the reference's DBServer returned (tests/golden/dbserver1500x8.npz)."""
+    z = np.load(os.path.join(G, "dbserver1500x8.npz"))
+    X, Q = data(1500, 8, 15), data(8, 8, 16)
+    off, nbr, nav = z["off"].astype(np.int64), z["nbr"].astype(np.int64), int(z["nav"])
+    idc = np.arange(1500, dtype=np.int32)
+    ix = amd.GpuIndex(8, 0)
+    ix.attach_rows(X)
+    ix.set_graph(off, nbr, nav)
+    for name, spec in (("plain", None), ("lt700", ("<", 700)), ("ge1200", (">=", 1200))):
+        if spec:
+            ix.set_int_filter(idc, spec[0], spec[1])
+        else:
+            ix.set_int_filter(None, None, 0)
+        for limit in (10, 100):
+            ids, dist, cnt = ix.search(Q, limit, mode=amd.MODE_REFERENCE, intra_threads=1)
+            for qi in range(len(Q)):
+                want = z["%s_k%d_ids" % (name, limit)][qi]
+                m = int((want >= 0).sum())
+                assert int(cnt[qi]) == m, (name, limit, qi, cnt[qi], m)
+                assert_topk_match(ids[qi, :m], dist[qi, :m], want[:m], z["%s_k%d_dist" % (name, limit)][qi][:m],
+                                  what="%s k%d q%d" % (name, limit, qi))
+    ix.set_int_filter(None, None, 0)
+    ix.set_deleted(bitset(1500, range(0, 1500, 3)))
+    ids, dist, cnt = ix.search(Q, 10, mode=amd.MODE_REFERENCE, intra_threads=1)
+    for qi in range(len(Q)):
+        want = z["deleted3_k10_ids"][qi]
+        m = int((want >= 0).sum())
+        assert int(cnt[qi]) == m
+        assert_topk_match(ids[qi, :m], dist[qi, :m], want[:m], z["deleted3_k10_dist"][qi][:m])
+    ix.close()
+
+
+def test_known_answer_unit_circle_graph_plus_tail(amd, oracle):
+    """DbServer.QueryDenseVectorDuringRebuild (db_server.cpp:1085-1245) scaled to N=2000: ids 0..499 in order."""
+    N = 2000
+    i = np.arange(N)
+    X = np.stack([np.cos(np.pi * i / N), np.sin(np.pi * i / N)], 1).astype(np.float32)
+    X = np.stack([oracle.normalize_insert(x) for x in X])
+    q = oracle.normalize_query(np.array([1.0, 0.0], np.float32))
+    off, nbr, nav = oracle.build_graph(1, X[:N // 2])
+    ix = amd.GpuIndex(2, 1)
+    ix.attach_rows(X)
+    ix.set_graph(off, nbr, nav)
+    for T in (1, 4):
+        ids, dist, cnt = ix.search(q[None, :], 500, mode=amd.MODE_REFERENCE, intra_threads=T)
+        assert cnt[0] == 500 and np.array_equal(ids[0], np.arange(500))
+    ix.close()
+
+
+def test_graph_file_roundtrip_with_reference_format(amd, oracle, tmp_path):
+    z, off, nbr, nav = _golden_graph()
+    X = data(2000, 32, 42)
+    ix = amd.GpuIndex(32, 0)
+    ix.attach_rows(X)
+    ix.set_graph(off, nbr, nav)
+    p = str(tmp_path / "ann_graph_1.bin")
+    ix.save_graph(p)
+    o2, n2, nav2, fid = oracle.graph_read(p)  # oracle reader was pinned against the reference's loader
+    assert nav2 == nav and np.array_equal(o2, off) and np.array_equal(n2, nbr)
+    ix2 = amd.GpuIndex(32, 0)
+    ix2.attach_rows(X)
+    ix2.load_graph(p)
+    o3, n3, nav3 = ix2.get_graph()
+    assert nav3 == nav and np.array_equal(o3, off) and np.array_equal(n3, nbr)
+
+
+# ----------------------------------------------------------------------------------------------- properties at size
+def test_flat_large_properties(amd):
+    """200k x 128 on-device data: exactness against a float64 numpy scan for a query sample, sortedness,
+    id-map arithmetic, device-pointer I/O (no host copies)."""
+    import torch
+    n, d, nq, k = 200_000, 128, 64, 10
+    g = torch.Generator(device="cuda").manual_seed(42)
+    X = torch.rand((n, d), generator=g, device="cuda", dtype=torch.float32)
+    Qd = torch.rand((nq, d), generator=g, device="cuda", dtype=torch.float32)
+    ix = amd.GpuIndex(d, 0)
+    ix.attach_rows(X)
+    ix.set_id_map(3, 8)
+    ids = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+    dist = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+    cnt = torch.empty((nq,), dtype=torch.int32, device="cuda")
+    ix.search(Qd, k, out=(ids, dist, cnt), mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
+    ix.synchronize()
+    Xh, Qh = X.cpu().numpy().astype(np.float64), Qd.cpu().numpy().astype(np.float64)
+    ids_h, dist_h = ids.cpu().numpy(), dist.cpu().numpy()
+    assert np.all(cnt.cpu().numpy() == k) and np.all(np.diff(dist_h, axis=1) >= 0)
+    for qi in range(0, nq, 7):
+        ex = ((Xh - Qh[qi]) ** 2).sum(1)
+        o = np.argsort(ex, kind="stable")[:k]
+        assert_topk_match((ids_h[qi] - 3) // 8, dist_h[qi], o, ex[o])
+        assert np.all((ids_h[qi] - 3) % 8 == 0)
+    ix.close()
+
+
+def test_merge_topk(amd):
+    rng = np.random.default_rng(0)
+    S, nq, k = 4, 9, 10
+    d = np.sort(rng.random((S, nq, k), dtype=np.float32), axis=2)
+    ids = rng.integers(0, 10 ** 9, (S, nq, k)).astype(np.int64)
+    d[1, :, 7:] = np.inf
+    ids[1, :, 7:] = -1
+    od = np.empty((nq, k), np.float32)
+    oi = np.empty((nq, k), np.int64)
+    amd.merge_topk(d, ids, od, oi)
+    for q in range(nq):
+        pairs = sorted((float(d[s, q, e]), int(ids[s, q, e])) for s in range(S) for e in range(k) if ids[s, q, e] >= 0)[:k]
+        assert [p[1] for p in pairs] == list(oi[q]) and np.allclose([p[0] for p in pairs], od[q])

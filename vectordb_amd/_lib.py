@@ -1,0 +1,99 @@
+"""ctypes binding of libepsilla_gfx950.so (C ABI: include/epsilla_gfx950.h).  The library is the only compute
+path of this package: if it is missing, or no gfx950 device is usable, we fail loudly — there is no CPU
+fallback and nothing under oracle/ is ever imported from here."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libepsilla_gfx950.so")
+
+EPS_OK = 0
+EPS_USER_ERROR = 30000
+EPS_INFRA_UNEXPECTED_ERROR = 40001
+EPS_DB_UNEXPECTED_ERROR = 50001
+EPS_DB_UNSUPPORTED_ERROR = 50002
+EPS_NOT_IMPLEMENTED_ERROR = 50009
+
+METRIC_EUCLIDEAN, METRIC_COSINE, METRIC_DOT_PRODUCT = 0, 1, 2
+MODE_REFERENCE, MODE_FLAT, MODE_GRAPH = 0, 1, 2
+FLAT_AUTO, FLAT_STREAM, FLAT_MFMA = 0, 1, 2
+OPS = {None: 0, "": 0, "<": 1, "<=": 2, "==": 3, "=": 3, ">=": 4, ">": 5, "!=": 6, "<>": 6}
+
+EXPORTS = [
+    "eps_default_search_params", "eps_default_build_params", "eps_index_create", "eps_index_destroy",
+    "eps_index_last_error", "eps_index_set_stream", "eps_index_synchronize", "eps_index_attach_rows",
+    "eps_index_append_rows", "eps_index_row_count", "eps_index_set_id_map", "eps_index_set_deleted",
+    "eps_index_set_int_filter", "eps_index_build", "eps_index_set_graph", "eps_index_graph_info",
+    "eps_index_get_graph", "eps_index_save_graph", "eps_index_load_graph", "eps_index_search",
+    "eps_index_last_stats", "eps_normalize_rows", "eps_merge_topk",
+]
+
+
+class SearchParams(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("flat_engine", C.c_int32), ("prefilter", C.c_int32),
+                ("intra_threads", C.c_int32), ("master_queue", C.c_int64), ("local_queue", C.c_int64),
+                ("sync_interval", C.c_int64)]
+
+
+class BuildParams(C.Structure):
+    _fields_ = [("search_length", C.c_int64), ("out_degree", C.c_int64), ("candidate_pool_size", C.c_int64),
+                ("knng", C.c_int64), ("seed", C.c_uint32), ("reserved", C.c_int32)]
+
+
+class SearchStats(C.Structure):
+    _fields_ = [("dist_evals", C.c_int64), ("expansions", C.c_int64), ("rerank_rows", C.c_int64),
+                ("overflow_queries", C.c_int64), ("kernel_ms", C.c_double), ("main_kernel_ms", C.c_double),
+                ("main_kernel_launches", C.c_int64)]
+
+
+class EpsillaError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("[%d] %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Loads the shared library (no GPU needed for this step) and declares every prototype."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: run `python -m vectordb_amd.build` (hipcc, gfx950). There is no "
+                          "fallback implementation." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int32
+    L.eps_default_search_params.argtypes = [C.POINTER(SearchParams)]
+    L.eps_default_search_params.restype = None
+    L.eps_default_build_params.argtypes = [C.POINTER(BuildParams)]
+    L.eps_default_build_params.restype = None
+    L.eps_index_create.argtypes = [i64, i32, i32, C.POINTER(vp)]
+    L.eps_index_destroy.argtypes = [vp]
+    L.eps_index_last_error.argtypes = [vp]
+    L.eps_index_last_error.restype = C.c_char_p
+    L.eps_index_set_stream.argtypes = [vp, vp]
+    L.eps_index_synchronize.argtypes = [vp]
+    L.eps_index_attach_rows.argtypes = [vp, vp, i64]
+    L.eps_index_append_rows.argtypes = [vp, vp, i64]
+    L.eps_index_row_count.argtypes = [vp]
+    L.eps_index_row_count.restype = i64
+    L.eps_index_set_id_map.argtypes = [vp, i64, i64]
+    L.eps_index_set_deleted.argtypes = [vp, vp, i64]
+    L.eps_index_set_int_filter.argtypes = [vp, vp, i64, i32, i32, i64]
+    L.eps_index_build.argtypes = [vp, i64, C.POINTER(BuildParams)]
+    L.eps_index_set_graph.argtypes = [vp, i64, vp, vp, i64]
+    L.eps_index_graph_info.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
+    L.eps_index_get_graph.argtypes = [vp, vp, vp]
+    L.eps_index_save_graph.argtypes = [vp, C.c_char_p]
+    L.eps_index_load_graph.argtypes = [vp, C.c_char_p]
+    L.eps_index_search.argtypes = [vp, vp, i64, i32, C.POINTER(SearchParams), vp, vp, vp]
+    L.eps_index_last_stats.argtypes = [vp, C.POINTER(SearchStats)]
+    L.eps_normalize_rows.argtypes = [vp, i64, i64, i32, i32, vp]
+    L.eps_merge_topk.argtypes = [vp, vp, i32, i64, i32, vp, vp, i32, vp]
+    for name in EXPORTS:
+        if getattr(L, name).restype is C.c_int:
+            getattr(L, name).restype = i32
+    _lib = L
+    return L

@@ -1,0 +1,220 @@
+// Device-side building blocks shared by every kernel of libepsilla_gfx950 (gfx950 / CDNA4 only).
+//
+//  * Candidate keys.  The reference orders candidates by (distance, id) (db/execution/candidate.hpp:16-22).
+//    On the device a candidate is one u64: order-preserving image of the fp32 distance in the high word,
+//    32-bit local row id in the low word, so one v_cmp_lt_u64 is the reference's operator<.
+//  * WaveTopK: a sorted k-list held in the registers of ONE 64-lane wavefront (entry e lives in register
+//    e/64 of lane e%64).  Insert = ballot/popcount rank + one wave_shr; replaces the reference's
+//    lower_bound + memmove (AddIntoQueue, vec_search_executor.cpp:75-117).
+//  * row_dists: G-lane-per-row fp32 distance evaluation with 16 B/lane coalesced loads and
+//    __shfl_xor reductions; replaces fvec_L2sqr / fvec_inner_product (db/index/distance_simd.cpp:180-214).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace eps {
+
+using u64 = unsigned long long;
+using u32 = unsigned int;
+
+constexpr u64 KEY_EMPTY = ~0ull;
+
+struct FilterSpec {            // `int column <op> constant` + deleted bitset (device pointers)
+  const uint8_t* deleted;      // may be null
+  const uint8_t* column;       // may be null
+  int64_t stride;
+  int32_t width;
+  int32_t op;                  // EPS_OP_*
+  int64_t value;
+};
+
+__device__ __forceinline__ int lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// fp32 -> u32 preserving order (NaN sorts last, -0 is folded into +0 by the callers' `+ 0.0f`)
+__device__ __forceinline__ u32 f2ord(float f) {
+  u32 u = __float_as_uint(f);
+  return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(u32 o) {
+  u32 u = (o & 0x80000000u) ? (o ^ 0x80000000u) : ~o;
+  return __uint_as_float(u);
+}
+__device__ __forceinline__ u64 make_key(float dist, u32 id) { return ((u64)f2ord(dist + 0.0f) << 32) | (u64)id; }
+__device__ __forceinline__ float key_dist(u64 k) { return ord2f((u32)(k >> 32)); }
+__device__ __forceinline__ u32 key_id(u64 k) { return (u32)k; }
+
+__device__ __forceinline__ u64 shfl64(u64 v, int src) {
+  u32 lo = (u32)v, hi = (u32)(v >> 32);
+  lo = __shfl(lo, src);
+  hi = __shfl(hi, src);
+  return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 shfl_up64(u64 v, int d) {
+  u32 lo = (u32)v, hi = (u32)(v >> 32);
+  lo = __shfl_up(lo, d);
+  hi = __shfl_up(hi, d);
+  return ((u64)hi << 32) | lo;
+}
+
+__device__ __forceinline__ bool row_visible(const FilterSpec& f, u32 id) {
+  if (f.deleted && ((f.deleted[id >> 3] >> (id & 7)) & 1)) return false;
+  if (f.op && f.column) {
+    const uint8_t* p = f.column + (int64_t)id * f.stride;
+    int64_t v;
+    switch (f.width) {
+      case 1: v = *(const int8_t*)p; break;
+      case 2: v = *(const int16_t*)p; break;
+      case 8: v = *(const int64_t*)p; break;
+      default: v = *(const int32_t*)p; break;
+    }
+    switch (f.op) {
+      case 1: return v < f.value;
+      case 2: return v <= f.value;
+      case 3: return v == f.value;
+      case 4: return v >= f.value;
+      case 5: return v > f.value;
+      case 6: return v != f.value;
+    }
+  }
+  return true;
+}
+
+// metric epilogue on the raw accumulator (sum of squared differences for L2, dot otherwise)
+__device__ __forceinline__ float finish_dist(int metric, float acc) {
+  return metric == 0 ? acc : (metric == 1 ? 1.0f - acc : -acc);
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int KPL>
+struct WaveTopK {
+  u64 key[KPL];
+
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int r = 0; r < KPL; ++r) key[r] = KEY_EMPTY;
+  }
+  // e-th smallest entry (0-based), wave-uniform
+  __device__ __forceinline__ u64 entry(int e) const {
+    u64 v = KEY_EMPTY;
+#pragma unroll
+    for (int r = 0; r < KPL; ++r) {
+      u64 t = shfl64(key[r], e & 63);
+      if ((e >> 6) == r) v = t;
+    }
+    return v;
+  }
+  // x must be wave-uniform.  Entries beyond KPL*64 fall off the end.
+  __device__ __forceinline__ void insert(u64 x) {
+    const int lane = lane_id();
+    int pos = 0;
+#pragma unroll
+    for (int r = 0; r < KPL; ++r) pos += __popcll(__ballot(key[r] < x));
+#pragma unroll
+    for (int r = KPL - 1; r >= 0; --r) {
+      u64 up = shfl_up64(key[r], 1);
+      u64 carry = r > 0 ? shfl64(key[r - 1], 63) : 0ull;
+      u64 prev = lane == 0 ? carry : up;
+      const int e = r * 64 + lane;
+      key[r] = e > pos ? prev : (e == pos ? x : key[r]);
+    }
+  }
+  // insert unless an identical key (same row, same distance bits) is already present
+  __device__ __forceinline__ void insert_unique(u64 x) {
+    bool dup = false;
+#pragma unroll
+    for (int r = 0; r < KPL; ++r) dup |= (__ballot(key[r] == x) != 0ull);
+    if (!dup) insert(x);
+  }
+  __device__ __forceinline__ void store(u64* dst, int k) const {
+    const int lane = lane_id();
+#pragma unroll
+    for (int r = 0; r < KPL; ++r) {
+      const int e = r * 64 + lane;
+      if (e < k) dst[e] = key[r];
+    }
+  }
+  __device__ __forceinline__ void load(const u64* src, int k) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int r = 0; r < KPL; ++r) {
+      const int e = r * 64 + lane;
+      key[r] = e < k ? src[e] : KEY_EMPTY;
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Geometry of "G lanes per row": G = smallest power of two with G*4 >= dim (VEC4) or G >= dim (scalar),
+// capped at 64.  RPW = 64 / G rows are evaluated by one wavefront at once.
+__host__ __device__ inline int group_lanes(int64_t dim, bool vec4) {
+  int64_t need = vec4 ? (dim + 3) / 4 : dim;
+  int g = 1;
+  while (g < 64 && g < need) g <<= 1;
+  return g;
+}
+
+// Accumulate U rows x NQ queries.  rowp[u] points at the row for this lane's group (already clamped to
+// a valid row); qs = LDS copy of the NQ queries, each dim floats (16-B aligned when VEC4).
+// Returns raw accumulators reduced over the G lanes of the group (valid in every lane of the group).
+template <int U, int NQ, bool VEC4>
+__device__ __forceinline__ void row_dists(const float* const (&rowp)[U], const float* qs, int64_t qstride, int dim,
+                                          int metric, int G, float (&acc)[U][NQ]) {
+  const int t = lane_id() & (G - 1);
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[u][q] = 0.f;
+  if (VEC4) {
+    for (int c = t * 4; c < dim; c += G * 4) {
+      float4 x[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) x[u] = *reinterpret_cast<const float4*>(rowp[u] + c);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const float4 qv = *reinterpret_cast<const float4*>(qs + q * qstride + c);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (metric == 0) {
+            const float a = x[u].x - qv.x, b = x[u].y - qv.y, c2 = x[u].z - qv.z, d2 = x[u].w - qv.w;
+            acc[u][q] = fmaf(a, a, acc[u][q]);
+            acc[u][q] = fmaf(b, b, acc[u][q]);
+            acc[u][q] = fmaf(c2, c2, acc[u][q]);
+            acc[u][q] = fmaf(d2, d2, acc[u][q]);
+          } else {
+            acc[u][q] = fmaf(x[u].x, qv.x, acc[u][q]);
+            acc[u][q] = fmaf(x[u].y, qv.y, acc[u][q]);
+            acc[u][q] = fmaf(x[u].z, qv.z, acc[u][q]);
+            acc[u][q] = fmaf(x[u].w, qv.w, acc[u][q]);
+          }
+        }
+      }
+    }
+  } else {
+    for (int c = t; c < dim; c += G) {
+      float x[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) x[u] = rowp[u][c];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const float qv = qs[q * qstride + c];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (metric == 0) {
+            const float a = x[u] - qv;
+            acc[u][q] = fmaf(a, a, acc[u][q]);
+          } else {
+            acc[u][q] = fmaf(x[u], qv, acc[u][q]);
+          }
+        }
+      }
+    }
+  }
+  for (int o = G >> 1; o > 0; o >>= 1) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) acc[u][q] += __shfl_xor(acc[u][q], o);
+  }
+}
+
+}  // namespace eps

@@ -1,0 +1,357 @@
+// Flat-scan path of libepsilla_gfx950: the device form of VecSearchExecutor::BruteForceSearch /
+// PreFilterBruteForceSearch (reference: engine/db/execution/vec_search_executor.cpp:717-831).
+//
+// The reference computes every distance into a scratch Candidate[N], compacts by deleted/filter and
+// std::sorts all N survivors.  Here one pass streams the contiguous fp32 row store from HBM exactly once
+// per group of NQ queries (16 B/lane coalesced loads, G lanes per row, shuffle reduction) and keeps a
+// k-entry sorted list per wavefront in registers; per-wave lists are merged by a second small kernel.
+// Only candidates that would enter the top-k touch the deleted bitset / filter column, so the
+// algorithmic HBM traffic is N*dim*4 bytes per query group.
+#include "kernels.hpp"
+
+namespace eps {
+
+// ------------------------------------------------------------------------------------------------
+template <int NQ, int KPL>
+__device__ __forceinline__ void offer(WaveTopK<KPL> (&list)[NQ], u64 (&thr)[NQ], int q, u64 key, bool valid,
+                                      const FilterSpec& f, int k, bool unique) {
+  u64 m = __ballot(valid && key < thr[q]);
+  while (m) {
+    const int l = __ffsll((long long)m) - 1;
+    m &= m - 1;
+    const u64 x = shfl64(key, l);
+    if (x < thr[q] && row_visible(f, key_id(x))) {
+      if (unique) list[q].insert_unique(x); else list[q].insert(x);
+      const u64 kth = list[q].entry(k - 1);
+      thr[q] = kth < thr[q] ? kth : thr[q];
+    }
+  }
+}
+
+template <int NQ, int KPL, bool VEC4, int U>
+__global__ __launch_bounds__(256) void flat_scan_kernel(FlatScanArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int dim = a.dim;
+  const int qstride = (dim + 3) & ~3;
+  const int64_t q0 = (int64_t)blockIdx.y * NQ;
+  for (int i = threadIdx.x; i < NQ * qstride; i += 256) {
+    const int q = i / qstride, c = i - q * qstride;
+    const int64_t qq = (q0 + q < a.nq) ? q0 + q : a.nq - 1;
+    smem[i] = c < dim ? a.queries[qq * dim + c] : 0.f;
+  }
+  __syncthreads();
+
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const int G = group_lanes(dim, VEC4);
+  const int RPW = 64 / G;
+  const int g = lane / G;
+  const int t = lane & (G - 1);
+  const int64_t W = (int64_t)gridDim.x * 4;
+  const int64_t w = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t nrows = a.row_end - a.row_begin;
+  const int64_t chunk = (nrows + W - 1) / W;
+  const int64_t begin = a.row_begin + w * chunk;
+  const int64_t end = begin + chunk < a.row_end ? begin + chunk : a.row_end;
+
+  WaveTopK<KPL> list[NQ];
+  u64 thr[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    list[q].init();
+    const int64_t qq = (q0 + q < a.nq) ? q0 + q : a.nq - 1;
+    thr[q] = a.thr_in ? a.thr_in[qq] : KEY_EMPTY;
+  }
+
+  for (int64_t r0 = begin; r0 < end; r0 += RPW * U) {
+    const float* rp[U];
+    int64_t row[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      row[u] = r0 + u * RPW + g;
+      const int64_t rc = row[u] < end ? row[u] : end - 1;
+      rp[u] = a.rows + rc * dim;
+    }
+    float acc[U][NQ];
+    row_dists<U, NQ, VEC4>(rp, smem, qstride, dim, a.metric, G, acc);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool valid = (t == 0) && row[u] < end;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const u64 key = make_key(finish_dist(a.metric, acc[u][q]), (u32)row[u]);
+        offer<NQ, KPL>(list, thr, q, key, valid, a.f, a.k, false);
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+    if (q0 + q < a.nq) list[q].store(a.partial + ((q0 + q) * W + w) * a.k, a.k);
+}
+
+static int pick_kpl(int k) { return k <= 64 ? 1 : k <= 128 ? 2 : k <= 256 ? 4 : k <= 512 ? 8 : 16; }
+static int pick_nq(int64_t nq, int k) {
+  if (k > 128) return 1;
+  return nq >= 3 ? 4 : (nq == 2 ? 2 : 1);
+}
+
+int flat_scan_waves(int64_t nrows, int64_t nq, int dim) {
+  (void)dim;
+  // callers size `partial` with the same k they launch with; NQ depends on k only through k > 128,
+  // which can only increase the number of groups -> fewer blocks in x. Use the smallest NQ for the bound.
+  const int64_t groups_min = (nq + 3) / 4;
+  int64_t gx_rows = (nrows + 127) / 128;  // >= 32 rows per wavefront
+  if (gx_rows < 1) gx_rows = 1;
+  int64_t gx_cap = 2048 / (groups_min > 0 ? groups_min : 1);
+  if (gx_cap < 1) gx_cap = 1;
+  int64_t gx = gx_rows < gx_cap ? gx_rows : gx_cap;
+  return (int)(gx * 4);
+}
+
+template <int NQ, int KPL>
+static void launch_flat_scan_t(const FlatScanArgs& a, bool vec4, hipStream_t s) {
+  const int gx = a.W / 4;
+  const int64_t groups = (a.nq + NQ - 1) / NQ;
+  dim3 grid(gx, (unsigned)groups);
+  const size_t shm = (size_t)NQ * ((a.dim + 3) & ~3) * sizeof(float);
+  if (vec4)
+    hipLaunchKernelGGL((flat_scan_kernel<NQ, KPL, true, 4>), grid, dim3(256), shm, s, a);
+  else
+    hipLaunchKernelGGL((flat_scan_kernel<NQ, KPL, false, 4>), grid, dim3(256), shm, s, a);
+}
+
+void launch_flat_scan(const FlatScanArgs& a, hipStream_t s) {
+  if (a.nq <= 0 || a.row_end <= a.row_begin) return;
+  const bool vec4 = (a.dim % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.rows) & 15) == 0);
+  const int kpl = pick_kpl(a.k);
+  const int nq = pick_nq(a.nq, a.k);
+#define EPS_CASE(NQ_, KPL_) \
+  if (nq == NQ_ && kpl == KPL_) return launch_flat_scan_t<NQ_, KPL_>(a, vec4, s);
+  EPS_CASE(1, 1) EPS_CASE(2, 1) EPS_CASE(4, 1)
+  EPS_CASE(1, 2) EPS_CASE(2, 2) EPS_CASE(4, 2)
+  EPS_CASE(1, 4) EPS_CASE(1, 8) EPS_CASE(1, 16)
+#undef EPS_CASE
+}
+
+// ------------------------------------------------------------------------------------------------
+// merge per-wave lists.  One block per query.
+template <int KPL>
+__global__ __launch_bounds__(256) void merge_lists_kernel(const u64* partial, int lists, int k, u64* run_keys,
+                                                          int merge_run) {
+  __shared__ u64 sh[4][KPL * 64];
+  const int64_t q = blockIdx.x;
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const u64* src = partial + q * (int64_t)lists * k;
+  const int total = lists * k;
+  WaveTopK<KPL> L[1];
+  u64 thr[1];
+  L[0].init();
+  thr[0] = KEY_EMPTY;
+  FilterSpec nof = {nullptr, nullptr, 0, 0, 0, 0};
+  if (merge_run) {
+    thr[0] = run_keys[q * k + (k - 1)];
+    if (wave == 0) L[0].load(run_keys + q * k, k);
+  }
+  const int rounded = (total + 255) & ~255;
+  for (int i = threadIdx.x; i < rounded; i += 256) {
+    const u64 key = i < total ? src[i] : KEY_EMPTY;
+    offer<1, KPL>(L, thr, 0, key, key != KEY_EMPTY, nof, k, false);
+  }
+  L[0].store(&sh[wave][0], k);
+  __syncthreads();
+  if (wave == 0) {
+    for (int w = 1; w < 4; ++w) {
+      for (int e0 = 0; e0 < k; e0 += 64) {
+        const int e = e0 + lane;
+        const u64 key = e < k ? sh[w][e] : KEY_EMPTY;
+        offer<1, KPL>(L, thr, 0, key, key != KEY_EMPTY, nof, k, false);
+      }
+    }
+    L[0].store(run_keys + q * k, k);
+  }
+}
+
+void launch_merge_lists(const u64* partial, int lists, int k, int64_t nq, u64* run_keys, bool merge_run, hipStream_t s) {
+  if (nq <= 0) return;
+  const int kpl = pick_kpl(k);
+#define EPS_CASE(KPL_) \
+  if (kpl == KPL_) {   \
+    hipLaunchKernelGGL((merge_lists_kernel<KPL_>), dim3((unsigned)nq), dim3(256), 0, s, partial, lists, k, run_keys, merge_run ? 1 : 0); \
+    return;            \
+  }
+  EPS_CASE(1) EPS_CASE(2) EPS_CASE(4) EPS_CASE(8) EPS_CASE(16)
+#undef EPS_CASE
+}
+
+// ------------------------------------------------------------------------------------------------
+// exact re-rank of candidate rows gathered by id (fp32, direct form) into the running top-k.
+template <int KPL, bool VEC4>
+__global__ __launch_bounds__(256) void rerank_kernel(RerankArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [qstride] query, then 4 lists
+  const int dim = a.dim;
+  const int qstride = (dim + 3) & ~3;
+  u64* sh = reinterpret_cast<u64*>(smem + qstride);  // qstride*4 bytes is a multiple of 16
+  const int64_t q = blockIdx.x;
+  for (int i = threadIdx.x; i < qstride; i += 256) smem[i] = i < dim ? a.queries[q * dim + i] : 0.f;
+  __syncthreads();
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const int G = group_lanes(dim, VEC4);
+  const int RPW = 64 / G;
+  const int g = lane / G;
+  const int t = lane & (G - 1);
+  constexpr int U = 4;
+  u32 cnt = a.cand_count[q];
+  if (cnt > (u32)a.cap) cnt = (u32)a.cap;
+  const u32* cand = a.cand + q * (int64_t)a.cap;
+
+  WaveTopK<KPL> L[1];
+  u64 thr[1];
+  L[0].init();
+  thr[0] = a.run_keys[q * a.k + (a.k - 1)];
+  if (wave == 0) L[0].load(a.run_keys + q * a.k, a.k);
+
+  for (u32 c0 = wave * RPW * U; c0 < cnt; c0 += 4 * RPW * U) {
+    const float* rp[U];
+    u32 id[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const u32 ci = c0 + u * RPW + g;
+      ok[u] = ci < cnt;
+      id[u] = cand[ok[u] ? ci : cnt - 1];
+      rp[u] = a.rows + (int64_t)id[u] * dim;
+    }
+    float acc[U][1];
+    row_dists<U, 1, VEC4>(rp, smem, qstride, dim, a.metric, G, acc);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const u64 key = make_key(finish_dist(a.metric, acc[u][0]), id[u]);
+      offer<1, KPL>(L, thr, 0, key, ok[u] && t == 0, a.f, a.k, true);
+    }
+  }
+  L[0].store(sh + wave * (KPL * 64), a.k);
+  __syncthreads();
+  if (wave == 0) {
+    FilterSpec nof = {nullptr, nullptr, 0, 0, 0, 0};
+    for (int w = 1; w < 4; ++w) {
+      for (int e0 = 0; e0 < a.k; e0 += 64) {
+        const int e = e0 + lane;
+        const u64 key = e < a.k ? sh[w * (KPL * 64) + e] : KEY_EMPTY;
+        offer<1, KPL>(L, thr, 0, key, key != KEY_EMPTY, nof, a.k, true);
+      }
+    }
+    L[0].store(a.run_keys + q * a.k, a.k);
+  }
+}
+
+void launch_rerank(const RerankArgs& a, hipStream_t s) {
+  if (a.nq <= 0) return;
+  const bool vec4 = (a.dim % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.rows) & 15) == 0);
+  const int kpl = pick_kpl(a.k);
+  const size_t shm = (size_t)((a.dim + 3) & ~3) * sizeof(float) + (size_t)4 * kpl * 64 * sizeof(u64);
+#define EPS_CASE(KPL_)                                                                                   \
+  if (kpl == KPL_) {                                                                                     \
+    if (vec4)                                                                                            \
+      hipLaunchKernelGGL((rerank_kernel<KPL_, true>), dim3((unsigned)a.nq), dim3(256), shm, s, a);      \
+    else                                                                                                 \
+      hipLaunchKernelGGL((rerank_kernel<KPL_, false>), dim3((unsigned)a.nq), dim3(256), shm, s, a);     \
+    return;                                                                                              \
+  }
+  EPS_CASE(1) EPS_CASE(2) EPS_CASE(4) EPS_CASE(8) EPS_CASE(16)
+#undef EPS_CASE
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void finalize_kernel(const u64* run_keys, int64_t nq, int k, int64_t id_base, int64_t id_stride,
+                                int64_t* ids, float* dist, int32_t* counts) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq * k) return;
+  const u64 key = run_keys[i];
+  const bool valid = key != KEY_EMPTY;
+  ids[i] = valid ? (int64_t)key_id(key) * id_stride + id_base : -1;
+  dist[i] = valid ? key_dist(key) : __builtin_inff();
+  if (counts && (i % k) == 0) {
+    int c = 0;
+    for (int e = 0; e < k; ++e) c += run_keys[i + e] != KEY_EMPTY;
+    counts[i / k] = c;
+  }
+}
+void launch_finalize(const u64* run_keys, int64_t nq, int k, int64_t id_base, int64_t id_stride, int64_t* ids,
+                     float* dist, int32_t* counts, hipStream_t s) {
+  const int64_t n = nq * k;
+  if (n <= 0) return;
+  hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, run_keys, nq, k, id_base,
+                     id_stride, ids, dist, counts);
+}
+
+__global__ void fill_u64_kernel(u64* p, int64_t n, u64 v) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+void launch_fill_u64(u64* p, int64_t n, u64 v, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(fill_u64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n, v);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Normalize (db/vector.cpp:60-69; insert path table_segment_mvp.cpp:574-587). One wavefront per row.
+__global__ __launch_bounds__(256) void normalize_kernel(float* rows, int64_t n, int dim, int only_if_nonzero) {
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const int lane = lane_id();
+  float* p = rows + r * dim;
+  float s = 0.f;
+  for (int c = lane; c < dim; c += 64) s = fmaf(p[c], p[c], s);
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (only_if_nonzero && !(s > 1e-10f)) return;
+  const float nrm = sqrtf(s);
+  for (int c = lane; c < dim; c += 64) p[c] = p[c] / nrm;
+}
+void launch_normalize(float* rows, int64_t n, int dim, bool only_if_nonzero, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, rows, n, dim,
+                     only_if_nonzero ? 1 : 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k-way merge of per-shard sorted lists by (dist, id) — what every rank does after the all-gather.
+__global__ void merge_shards_kernel(const float* dist, const int64_t* ids, int shards, int64_t nq, int k,
+                                    float* out_dist, int64_t* out_ids) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  int head[16];
+  for (int s = 0; s < shards; ++s) head[s] = 0;
+  for (int e = 0; e < k; ++e) {
+    int best = -1;
+    float bd = 0.f;
+    int64_t bi = 0;
+    for (int s = 0; s < shards; ++s) {
+      if (head[s] >= k) continue;
+      const int64_t o = ((int64_t)s * nq + q) * k + head[s];
+      const int64_t id = ids[o];
+      if (id < 0) { head[s] = k; continue; }
+      const float d = dist[o];
+      if (best < 0 || d < bd || (d == bd && id < bi)) {
+        best = s; bd = d; bi = id;
+      }
+    }
+    if (best < 0) {
+      out_dist[q * k + e] = __builtin_inff();
+      out_ids[q * k + e] = -1;
+    } else {
+      out_dist[q * k + e] = bd;
+      out_ids[q * k + e] = bi;
+      head[best]++;
+    }
+  }
+}
+void launch_merge_shards(const float* dist, const int64_t* ids, int shards, int64_t nq, int k, float* out_dist,
+                         int64_t* out_ids, hipStream_t s) {
+  if (nq <= 0) return;
+  hipLaunchKernelGGL(merge_shards_kernel, dim3((unsigned)((nq + 127) / 128)), dim3(128), 0, s, dist, ids, shards, nq, k,
+                     out_dist, out_ids);
+}
+
+}  // namespace eps

@@ -1,0 +1,585 @@
+// Host side of libepsilla_gfx950 — see index.hpp.  Compiled with hipcc (host code only here).
+#include "index.hpp"
+
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstring>
+
+namespace eps {
+
+// ------------------------------------------------------------------------------------------------ utils
+DevBuf::~DevBuf() { release(); }
+void DevBuf::release() {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+  cap = 0;
+}
+bool DevBuf::reserve(size_t bytes) {
+  if (bytes <= cap) return true;
+  release();
+  size_t want = bytes + bytes / 8 + 256;
+  if (hipMalloc(&p, want) != hipSuccess) {
+    (void)hipGetLastError();
+    p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      p = nullptr;
+      return false;
+    }
+    want = bytes;
+  }
+  cap = want;
+  return true;
+}
+
+bool is_device_ptr(const void* p) {
+  if (!p) return false;
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+Index::Index(int64_t dim, int metric, int device) : dim_(dim), metric_(metric), device_(device) {}
+
+Index::~Index() {
+  (void)hipSetDevice(device_);
+  if (stream_) (void)hipStreamSynchronize(stream_);
+  if (graph_) graph_free(graph_);
+  if (mirror_) half_mirror_free(mirror_);
+  if (ev0_) (void)hipEventDestroy(ev0_);
+  if (ev1_) (void)hipEventDestroy(ev1_);
+  if (evk0_) (void)hipEventDestroy(evk0_);
+  if (evk1_) (void)hipEventDestroy(evk1_);
+  if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
+}
+
+int32_t Index::hip_fail(hipError_t e, const char* what) {
+  (void)hipGetLastError();
+  return fail(EPS_INFRA_UNEXPECTED_ERROR, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIP_TRY(expr)                                  \
+  do {                                                 \
+    hipError_t e__ = (expr);                           \
+    if (e__ != hipSuccess) return hip_fail(e__, #expr); \
+  } while (0)
+
+int32_t Index::init() {
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    (void)hipGetLastError();
+    return fail(EPS_INFRA_UNEXPECTED_ERROR, "no HIP device available: libepsilla_gfx950 has no CPU fallback");
+  }
+  if (device_ < 0 || device_ >= count) return fail(EPS_USER_ERROR, "device ordinal out of range");
+  HIP_TRY(hipSetDevice(device_));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device_));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(EPS_INFRA_UNEXPECTED_ERROR, std::string("kernels are built for gfx950 only, device is ") + prop.gcnArchName);
+  HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  own_stream_ = true;
+  HIP_TRY(hipEventCreate(&ev0_));
+  HIP_TRY(hipEventCreate(&ev1_));
+  HIP_TRY(hipEventCreate(&evk0_));
+  HIP_TRY(hipEventCreate(&evk1_));
+  return EPS_OK;
+}
+
+int32_t Index::set_stream(void* s) {
+  HIP_TRY(hipSetDevice(device_));
+  if (stream_) HIP_TRY(hipStreamSynchronize(stream_));
+  if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
+  own_stream_ = false;
+  if (s) {
+    stream_ = static_cast<hipStream_t>(s);
+  } else {
+    HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    own_stream_ = true;
+  }
+  return EPS_OK;
+}
+
+int32_t Index::synchronize() {
+  HIP_TRY(hipSetDevice(device_));
+  HIP_TRY(hipStreamSynchronize(stream_));
+  return EPS_OK;
+}
+
+int32_t Index::attach_rows(const float* rows, int64_t n) {
+  if (n < 0 || (n > 0 && !rows)) return fail(EPS_USER_ERROR, "attach_rows: bad arguments");
+  if (n >= (int64_t)1 << 31) return fail(EPS_DB_UNSUPPORTED_ERROR, "attach_rows: more than 2^31-1 rows per index (shard first)");
+  HIP_TRY(hipSetDevice(device_));
+  HIP_TRY(hipStreamSynchronize(stream_));
+  if (is_device_ptr(rows)) {
+    rows_buf_.release();
+    d_rows_ = rows;
+    rows_owned_ = false;
+  } else {
+    const size_t bytes = (size_t)n * dim_ * sizeof(float);
+    if (!rows_buf_.reserve(bytes ? bytes : 16)) return fail(EPS_INFRA_UNEXPECTED_ERROR, "attach_rows: out of device memory");
+    if (bytes) HIP_TRY(hipMemcpyAsync(rows_buf_.p, rows, bytes, hipMemcpyHostToDevice, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    d_rows_ = rows_buf_.as<float>();
+    rows_owned_ = true;
+  }
+  n_rows_ = n;
+  ++rows_version_;
+  return EPS_OK;
+}
+
+int32_t Index::append_rows(const float* rows, int64_t n_new) {
+  if (n_new < 0 || (n_new > 0 && !rows)) return fail(EPS_USER_ERROR, "append_rows: bad arguments");
+  if (n_new == 0) return EPS_OK;
+  if (n_rows_ > 0 && !rows_owned_) return fail(EPS_USER_ERROR, "append_rows: the row store is borrowed device memory; re-attach instead");
+  HIP_TRY(hipSetDevice(device_));
+  HIP_TRY(hipStreamSynchronize(stream_));
+  const size_t old_bytes = (size_t)n_rows_ * dim_ * sizeof(float);
+  const size_t add_bytes = (size_t)n_new * dim_ * sizeof(float);
+  if (old_bytes + add_bytes > rows_buf_.cap) {
+    DevBuf bigger;
+    if (!bigger.reserve((old_bytes + add_bytes) * 3 / 2)) return fail(EPS_INFRA_UNEXPECTED_ERROR, "append_rows: out of device memory");
+    if (old_bytes) HIP_TRY(hipMemcpyAsync(bigger.p, rows_buf_.p, old_bytes, hipMemcpyDeviceToDevice, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    rows_buf_.release();
+    rows_buf_.p = bigger.p;
+    rows_buf_.cap = bigger.cap;
+    bigger.p = nullptr;
+    bigger.cap = 0;
+  }
+  const hipMemcpyKind kind = is_device_ptr(rows) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  HIP_TRY(hipMemcpyAsync(static_cast<char*>(rows_buf_.p) + old_bytes, rows, add_bytes, kind, stream_));
+  HIP_TRY(hipStreamSynchronize(stream_));
+  d_rows_ = rows_buf_.as<float>();
+  rows_owned_ = true;
+  n_rows_ += n_new;
+  ++rows_version_;
+  return EPS_OK;
+}
+
+int32_t Index::set_id_map(int64_t base, int64_t stride) {
+  if (stride <= 0) return fail(EPS_USER_ERROR, "set_id_map: stride must be positive");
+  id_base_ = base;
+  id_stride_ = stride;
+  return EPS_OK;
+}
+
+int32_t Index::set_deleted(const uint8_t* bits, int64_t nbytes) {
+  HIP_TRY(hipSetDevice(device_));
+  if (!bits || nbytes <= 0) {
+    d_deleted_ = nullptr;
+    return EPS_OK;
+  }
+  if (nbytes < (n_rows_ + 7) / 8) return fail(EPS_USER_ERROR, "set_deleted: bitset shorter than ceil(rows/8) bytes");
+  if (is_device_ptr(bits)) {
+    d_deleted_ = bits;
+  } else {
+    if (!deleted_buf_.reserve((size_t)nbytes)) return fail(EPS_INFRA_UNEXPECTED_ERROR, "set_deleted: out of device memory");
+    HIP_TRY(hipMemcpyAsync(deleted_buf_.p, bits, (size_t)nbytes, hipMemcpyHostToDevice, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));  // the host bitset may change right after we return
+    d_deleted_ = deleted_buf_.as<uint8_t>();
+  }
+  return EPS_OK;
+}
+
+int32_t Index::set_int_filter(const void* column, int64_t stride, int32_t width, int32_t op, int64_t constant) {
+  HIP_TRY(hipSetDevice(device_));
+  if (op == EPS_OP_NONE || !column) {
+    f_op_ = 0;
+    d_fcol_ = nullptr;
+    return EPS_OK;
+  }
+  if (op < 0 || op > EPS_OP_NE) return fail(EPS_USER_ERROR, "set_int_filter: unknown operator");
+  if (width != 1 && width != 2 && width != 4 && width != 8) return fail(EPS_USER_ERROR, "set_int_filter: width must be 1, 2, 4 or 8 bytes");
+  if (stride < width) return fail(EPS_USER_ERROR, "set_int_filter: stride smaller than the value width");
+  if (is_device_ptr(column)) {
+    d_fcol_ = static_cast<const uint8_t*>(column);
+  } else {
+    const size_t bytes = (size_t)(n_rows_ > 0 ? (n_rows_ - 1) * stride + width : 0);
+    if (!fcol_buf_.reserve(bytes ? bytes : 16)) return fail(EPS_INFRA_UNEXPECTED_ERROR, "set_int_filter: out of device memory");
+    if (bytes) HIP_TRY(hipMemcpyAsync(fcol_buf_.p, column, bytes, hipMemcpyHostToDevice, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    d_fcol_ = fcol_buf_.as<uint8_t>();
+  }
+  f_stride_ = stride;
+  f_width_ = width;
+  f_op_ = op;
+  f_value_ = constant;
+  return EPS_OK;
+}
+
+FilterSpec Index::filter_spec() const {
+  FilterSpec f;
+  f.deleted = d_deleted_;
+  f.column = f_op_ ? d_fcol_ : nullptr;
+  f.stride = f_stride_;
+  f.width = f_width_;
+  f.op = f_op_;
+  f.value = f_value_;
+  return f;
+}
+
+// ------------------------------------------------------------------------------------------------ graph
+int32_t Index::set_graph(int64_t n, const int64_t* off, const int64_t* nbr, int64_t nav) {
+  if (n < 0 || (n > 0 && (!off || !nbr))) return fail(EPS_USER_ERROR, "set_graph: bad arguments");
+  if (n > n_rows_) return fail(EPS_USER_ERROR, "set_graph: graph has more nodes than attached rows");
+  if (n > 0 && (nav < 0 || nav >= n)) return fail(EPS_USER_ERROR, "set_graph: navigation point out of range");
+  if (n > 0) {
+    if (off[0] != 0) return fail(EPS_USER_ERROR, "set_graph: offsets[0] must be 0");
+    for (int64_t i = 0; i < n; ++i)
+      if (off[i + 1] < off[i]) return fail(EPS_USER_ERROR, "set_graph: offsets must be non-decreasing");
+    const int64_t e = off[n];
+    for (int64_t i = 0; i < e; ++i)
+      if (nbr[i] < 0 || nbr[i] >= n) return fail(EPS_USER_ERROR, "set_graph: neighbor id out of range");
+    h_off_.assign(off, off + n + 1);
+    h_nbr_.assign(nbr, nbr + e);
+  } else {
+    h_off_.assign(1, 0);
+    h_nbr_.clear();
+  }
+  n_indexed_ = n;
+  nav_ = nav;
+  return graph_upload(*this);
+}
+
+int32_t Index::graph_info(int64_t* n, int64_t* edges, int64_t* nav) const {
+  if (n) *n = n_indexed_;
+  if (edges) *edges = n_indexed_ > 0 ? h_off_[n_indexed_] : 0;
+  if (nav) *nav = nav_;
+  return EPS_OK;
+}
+
+int32_t Index::get_graph(int64_t* off, int64_t* nbr) const {
+  if (!off || !nbr) return EPS_USER_ERROR;
+  if (h_off_.empty()) {
+    off[0] = 0;
+    return EPS_OK;
+  }
+  std::memcpy(off, h_off_.data(), sizeof(int64_t) * h_off_.size());
+  if (!h_nbr_.empty()) std::memcpy(nbr, h_nbr_.data(), sizeof(int64_t) * h_nbr_.size());
+  return EPS_OK;
+}
+
+// ann_graph_<field>.bin, byte-compatible with ANNGraphSegment::SaveANNGraph (db/ann_graph_segment.cpp:156-199):
+// i64 n, i64 first_record_id, i64 offsets[n+1], i64 neighbors[E], i64 navigation_point; tmp + fsync + rename.
+int32_t Index::save_graph(const char* path) {
+  if (!path) return fail(EPS_USER_ERROR, "save_graph: null path");
+  const std::string tmp = std::string(path) + ".tmp";
+  FILE* f = std::fopen(tmp.c_str(), "wb");
+  if (!f) return fail(EPS_DB_UNEXPECTED_ERROR, std::string("Cannot open file: ") + path);
+  const int64_t n = n_indexed_, first = 0;
+  std::vector<int64_t> zero(1, 0);
+  const int64_t* off = h_off_.empty() ? zero.data() : h_off_.data();
+  const int64_t e = off[n];
+  bool ok = std::fwrite(&n, 8, 1, f) == 1 && std::fwrite(&first, 8, 1, f) == 1 &&
+            std::fwrite(off, 8, (size_t)n + 1, f) == (size_t)n + 1 &&
+            (e == 0 || std::fwrite(h_nbr_.data(), 8, (size_t)e, f) == (size_t)e) && std::fwrite(&nav_, 8, 1, f) == 1;
+  std::fflush(f);
+  fsync(fileno(f));
+  std::fclose(f);
+  if (!ok) return fail(EPS_DB_UNEXPECTED_ERROR, std::string("Failed to write to file: ") + path);
+  if (std::rename(tmp.c_str(), path) != 0)
+    return fail(EPS_INFRA_UNEXPECTED_ERROR, "Failed to rename temp file: " + tmp + " to " + path);
+  return EPS_OK;
+}
+
+int32_t Index::load_graph(const char* path) {
+  if (!path) return fail(EPS_USER_ERROR, "load_graph: null path");
+  FILE* f = std::fopen(path, "rb");
+  if (!f) return fail(EPS_DB_UNEXPECTED_ERROR, std::string("Cannot open file: ") + path);
+  int64_t hdr[2];
+  std::vector<int64_t> off, nbr;
+  int64_t nav = 0;
+  bool ok = std::fread(hdr, 8, 2, f) == 2 && hdr[0] >= 0;
+  if (ok) {
+    off.resize((size_t)hdr[0] + 1);
+    ok = std::fread(off.data(), 8, off.size(), f) == off.size() && off[hdr[0]] >= 0;
+  }
+  if (ok) {
+    nbr.resize((size_t)off[hdr[0]]);
+    ok = (nbr.empty() || std::fread(nbr.data(), 8, nbr.size(), f) == nbr.size()) && std::fread(&nav, 8, 1, f) == 1;
+  }
+  std::fclose(f);
+  if (!ok) return fail(EPS_DB_UNEXPECTED_ERROR, std::string("Corrupt ANN graph file: ") + path);
+  return set_graph(hdr[0], off.data(), nbr.data(), nav);
+}
+
+int32_t Index::build(int64_t n, const eps_build_params* p) {
+  eps_build_params bp;
+  if (p) bp = *p; else eps_default_build_params(&bp);
+  if (n < 0 || n > n_rows_) return fail(EPS_USER_ERROR, "build: n exceeds the attached rows");
+  HIP_TRY(hipSetDevice(device_));
+  return graph_build(*this, n, bp);
+}
+
+// ------------------------------------------------------------------------------------------------ search
+int32_t Index::flat_stream(const float* dq, int64_t nq, int k, int64_t row_begin, int64_t row_end, u64* run_keys,
+                           bool merge_run) {
+  if (row_end <= row_begin) {
+    if (!merge_run) launch_fill_u64(run_keys, nq * k, KEY_EMPTY, stream_);
+    return EPS_OK;
+  }
+  const int W = flat_scan_waves(row_end - row_begin, nq, (int)dim_);
+  if (!partial_buf_.reserve((size_t)nq * W * k * sizeof(u64))) return fail(EPS_INFRA_UNEXPECTED_ERROR, "search: out of device memory (partial lists)");
+  FlatScanArgs a;
+  a.rows = d_rows_;
+  a.row_begin = row_begin;
+  a.row_end = row_end;
+  a.dim = (int)dim_;
+  a.metric = metric_;
+  a.queries = dq;
+  a.nq = nq;
+  a.k = k;
+  a.f = filter_spec();
+  a.partial = partial_buf_.as<u64>();
+  a.W = W;
+  a.thr_in = nullptr;
+  HIP_TRY(hipEventRecord(evk0_, stream_));
+  launch_flat_scan(a, stream_);
+  HIP_TRY(hipEventRecord(evk1_, stream_));
+  launch_merge_lists(a.partial, W, k, nq, run_keys, merge_run, stream_);
+  HIP_TRY(hipGetLastError());
+  stats_.main_kernel_launches += 1;
+  stats_.dist_evals += nq * (row_end - row_begin);
+  return EPS_OK;
+}
+
+int32_t Index::search(const float* queries, int64_t nq, int32_t k, const eps_search_params* pp, int64_t* ids,
+                      float* dist, int32_t* counts) {
+  eps_search_params p;
+  if (pp) p = *pp; else eps_default_search_params(&p);
+  if (nq < 0 || k <= 0) return fail(EPS_USER_ERROR, "search: nq must be >= 0 and k > 0");
+  if (nq == 0) return EPS_OK;
+  if (!queries || !ids || !dist) return fail(EPS_USER_ERROR, "search: null buffer");
+  if (k > 1024) return fail(EPS_DB_UNSUPPORTED_ERROR, "search: k > 1024 is not supported");
+  if (p.master_queue <= 0 || p.local_queue <= 0 || p.sync_interval <= 0 || p.intra_threads <= 0)
+    return fail(EPS_USER_ERROR, "search: queue sizes, sync interval and thread count must be positive");
+  HIP_TRY(hipSetDevice(device_));
+  std::memset(&stats_, 0, sizeof(stats_));
+
+  const bool q_dev = is_device_ptr(queries);
+  const bool out_dev = is_device_ptr(ids);
+  if (out_dev != is_device_ptr(dist) || (counts && out_dev != is_device_ptr(counts)))
+    return fail(EPS_USER_ERROR, "search: ids_out, dist_out and counts_out must all be host or all be device pointers");
+
+  const float* dq = queries;
+  if (!q_dev) {
+    const size_t qb = (size_t)nq * dim_ * sizeof(float);
+    if (!q_buf_.reserve(qb)) return fail(EPS_INFRA_UNEXPECTED_ERROR, "search: out of device memory (queries)");
+    HIP_TRY(hipMemcpyAsync(q_buf_.p, queries, qb, hipMemcpyHostToDevice, stream_));
+    dq = q_buf_.as<float>();
+  }
+
+  // mode selection of VecSearchExecutor::Search (vec_search_executor.cpp:855-935)
+  int mode = p.mode;
+  int64_t limit = k;
+  bool cap_local = false;
+  if (mode == EPS_MODE_REFERENCE) {
+    if (p.prefilter) {
+      mode = EPS_MODE_FLAT;
+    } else if (n_indexed_ < 512) {  // BruteforceThreshold, vec_search_executor.hpp:28
+      mode = EPS_MODE_FLAT;
+      cap_local = true;  // result_size = min(size, limit, L_local_)  (:864)
+    } else {
+      mode = EPS_MODE_GRAPH;
+    }
+  }
+  if (mode == EPS_MODE_GRAPH && n_indexed_ <= 0) return fail(EPS_USER_ERROR, "search: graph mode requested but no graph is set");
+
+  if (!run_buf_.reserve((size_t)nq * k * sizeof(u64))) return fail(EPS_INFRA_UNEXPECTED_ERROR, "search: out of device memory (results)");
+  u64* run_keys = run_buf_.as<u64>();
+  HIP_TRY(hipEventRecord(ev0_, stream_));
+
+  int keff = k;
+  if (mode == EPS_MODE_FLAT) {
+    if (cap_local && p.local_queue < keff) keff = (int)p.local_queue;
+    if (keff < k) launch_fill_u64(run_keys, nq * k, KEY_EMPTY, stream_);
+    int engine = p.flat_engine;
+    if (engine == EPS_FLAT_AUTO) engine = flat_mfma_supported(*this, nq, keff) ? EPS_FLAT_MFMA : EPS_FLAT_STREAM;
+    if (engine == EPS_FLAT_MFMA && !flat_mfma_supported(*this, nq, keff))
+      return fail(EPS_DB_UNSUPPORTED_ERROR, "search: the MFMA flat engine does not support this shape (see DESIGN.md); use EPS_FLAT_STREAM");
+    int32_t rc;
+    if (keff == k) {
+      rc = engine == EPS_FLAT_MFMA ? flat_mfma_search(*this, dq, nq, k, run_keys)
+                                   : flat_stream(dq, nq, k, 0, n_rows_, run_keys, false);
+    } else {
+      // narrower result (L_local cap): compute into a k_eff-wide list, then widen
+      if (!tmp_buf_.reserve((size_t)nq * keff * sizeof(u64))) return fail(EPS_INFRA_UNEXPECTED_ERROR, "search: out of device memory");
+      u64* narrow = tmp_buf_.as<u64>();
+      rc = engine == EPS_FLAT_MFMA ? flat_mfma_search(*this, dq, nq, keff, narrow)
+                                   : flat_stream(dq, nq, keff, 0, n_rows_, narrow, false);
+      if (rc == EPS_OK)
+        HIP_TRY(hipMemcpy2DAsync(run_keys, (size_t)k * sizeof(u64), narrow, (size_t)keff * sizeof(u64),
+                                 (size_t)keff * sizeof(u64), (size_t)nq, hipMemcpyDeviceToDevice, stream_));
+    }
+    if (rc != EPS_OK) return rc;
+  } else {
+    int64_t evals = 0;
+    int32_t rc = graph_search(*this, dq, nq, k, p, run_keys, &evals);
+    if (rc != EPS_OK) return rc;
+  }
+  (void)limit;
+
+  // results out
+  int64_t* d_ids = ids;
+  float* d_dist = dist;
+  int32_t* d_cnt = counts;
+  if (!out_dev) {
+    if (!ids_buf_.reserve((size_t)nq * k * sizeof(int64_t)) || !dist_buf_.reserve((size_t)nq * k * sizeof(float)) ||
+        !cnt_buf_.reserve((size_t)nq * sizeof(int32_t)))
+      return fail(EPS_INFRA_UNEXPECTED_ERROR, "search: out of device memory (outputs)");
+    d_ids = ids_buf_.as<int64_t>();
+    d_dist = dist_buf_.as<float>();
+    d_cnt = cnt_buf_.as<int32_t>();
+  }
+  launch_finalize(run_keys, nq, k, id_base_, id_stride_, d_ids, d_dist, d_cnt, stream_);
+  HIP_TRY(hipEventRecord(ev1_, stream_));
+  if (!out_dev) {
+    HIP_TRY(hipMemcpyAsync(ids, d_ids, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipMemcpyAsync(dist, d_dist, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    if (counts) HIP_TRY(hipMemcpyAsync(counts, d_cnt, (size_t)nq * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+  }
+  HIP_TRY(hipGetLastError());
+  return EPS_OK;
+}
+
+}  // namespace eps
+
+// ================================================================================================ C ABI
+using eps::Index;
+
+extern "C" {
+
+void eps_default_search_params(eps_search_params* p) {
+  if (!p) return;
+  p->mode = EPS_MODE_REFERENCE;
+  p->flat_engine = EPS_FLAT_AUTO;
+  p->prefilter = 0;         // Config::PreFilter{false}
+  p->intra_threads = 4;     // Config::IntraQueryThreads{4}      (config/config.hpp:18)
+  p->master_queue = 500;    // Config::MasterQueueSize{500}      (:19)
+  p->local_queue = 500;     // Config::LocalQueueSize{500}       (:20)
+  p->sync_interval = 15;    // Config::GlobalSyncInterval{15}    (:21)
+}
+
+void eps_default_build_params(eps_build_params* p) {
+  if (!p) return;
+  p->search_length = 45;  // NSGConfig(45, 50, 300, 100), db/ann_graph_segment.cpp:29
+  p->out_degree = 50;
+  p->candidate_pool_size = 300;
+  p->knng = 100;
+  p->seed = 100;  // nsg.cpp:19
+  p->reserved = 0;
+}
+
+int32_t eps_index_create(int64_t dim, int32_t metric, int32_t device, eps_index** out) {
+  if (!out) return EPS_USER_ERROR;
+  *out = nullptr;
+  if (dim <= 0 || dim > 65536 || metric < 0 || metric > 2) return EPS_USER_ERROR;
+  Index* ix = new Index(dim, metric, device);
+  const int32_t rc = ix->init();
+  if (rc != EPS_OK) {
+    std::fprintf(stderr, "eps_index_create: %s\n", ix->last_error());
+    delete ix;
+    return rc;
+  }
+  *out = reinterpret_cast<eps_index*>(ix);
+  return EPS_OK;
+}
+int32_t eps_index_destroy(eps_index* h) {
+  delete reinterpret_cast<Index*>(h);
+  return EPS_OK;
+}
+const char* eps_index_last_error(const eps_index* h) { return h ? reinterpret_cast<const Index*>(h)->last_error() : "null handle"; }
+#define IX(h) reinterpret_cast<Index*>(h)
+#define CIX(h) reinterpret_cast<const Index*>(h)
+int32_t eps_index_set_stream(eps_index* h, void* s) { return h ? IX(h)->set_stream(s) : EPS_USER_ERROR; }
+int32_t eps_index_synchronize(eps_index* h) { return h ? IX(h)->synchronize() : EPS_USER_ERROR; }
+int32_t eps_index_attach_rows(eps_index* h, const float* rows, int64_t n) { return h ? IX(h)->attach_rows(rows, n) : EPS_USER_ERROR; }
+int32_t eps_index_append_rows(eps_index* h, const float* rows, int64_t n) { return h ? IX(h)->append_rows(rows, n) : EPS_USER_ERROR; }
+int64_t eps_index_row_count(const eps_index* h) { return h ? CIX(h)->row_count() : -1; }
+int32_t eps_index_set_id_map(eps_index* h, int64_t b, int64_t s) { return h ? IX(h)->set_id_map(b, s) : EPS_USER_ERROR; }
+int32_t eps_index_set_deleted(eps_index* h, const uint8_t* bits, int64_t nbytes) { return h ? IX(h)->set_deleted(bits, nbytes) : EPS_USER_ERROR; }
+int32_t eps_index_set_int_filter(eps_index* h, const void* col, int64_t stride, int32_t width, int32_t op, int64_t c) {
+  return h ? IX(h)->set_int_filter(col, stride, width, op, c) : EPS_USER_ERROR;
+}
+int32_t eps_index_build(eps_index* h, int64_t n, const eps_build_params* p) { return h ? IX(h)->build(n, p) : EPS_USER_ERROR; }
+int32_t eps_index_set_graph(eps_index* h, int64_t n, const int64_t* off, const int64_t* nbr, int64_t nav) {
+  return h ? IX(h)->set_graph(n, off, nbr, nav) : EPS_USER_ERROR;
+}
+int32_t eps_index_graph_info(const eps_index* h, int64_t* n, int64_t* e, int64_t* nav) { return h ? CIX(h)->graph_info(n, e, nav) : EPS_USER_ERROR; }
+int32_t eps_index_get_graph(const eps_index* h, int64_t* off, int64_t* nbr) { return h ? CIX(h)->get_graph(off, nbr) : EPS_USER_ERROR; }
+int32_t eps_index_save_graph(eps_index* h, const char* path) { return h ? IX(h)->save_graph(path) : EPS_USER_ERROR; }
+int32_t eps_index_load_graph(eps_index* h, const char* path) { return h ? IX(h)->load_graph(path) : EPS_USER_ERROR; }
+int32_t eps_index_search(eps_index* h, const float* q, int64_t nq, int32_t k, const eps_search_params* p, int64_t* ids,
+                         float* dist, int32_t* counts) {
+  return h ? IX(h)->search(q, nq, k, p, ids, dist, counts) : EPS_USER_ERROR;
+}
+int32_t eps_index_last_stats(const eps_index* h, eps_search_stats* out) {
+  if (!h || !out) return EPS_USER_ERROR;
+  Index* ix = const_cast<Index*>(CIX(h));
+  eps_search_stats s = ix->stats();
+  // event timings are read lazily: the caller may have left the work in flight
+  if (ix->ev0_ && hipEventSynchronize(ix->ev1_) == hipSuccess) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ix->ev0_, ix->ev1_) == hipSuccess) s.kernel_ms = ms;
+    if (s.main_kernel_launches > 0 && hipEventElapsedTime(&ms, ix->evk0_, ix->evk1_) == hipSuccess) s.main_kernel_ms = ms;
+  }
+  (void)hipGetLastError();
+  *out = s;
+  return EPS_OK;
+}
+
+int32_t eps_normalize_rows(float* rows, int64_t n, int64_t dim, int32_t only_if_nonzero, int32_t device, void* stream) {
+  if (n < 0 || dim <= 0 || (n > 0 && !rows)) return EPS_USER_ERROR;
+  if (n == 0) return EPS_OK;
+  if (hipSetDevice(device) != hipSuccess) return EPS_INFRA_UNEXPECTED_ERROR;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (eps::is_device_ptr(rows)) {
+    eps::launch_normalize(rows, n, (int)dim, only_if_nonzero != 0, s);
+    return hipGetLastError() == hipSuccess ? EPS_OK : EPS_INFRA_UNEXPECTED_ERROR;
+  }
+  float* d = nullptr;
+  const size_t bytes = (size_t)n * dim * sizeof(float);
+  if (hipMalloc(&d, bytes) != hipSuccess) return EPS_INFRA_UNEXPECTED_ERROR;
+  bool ok = hipMemcpyAsync(d, rows, bytes, hipMemcpyHostToDevice, s) == hipSuccess;
+  if (ok) eps::launch_normalize(d, n, (int)dim, only_if_nonzero != 0, s);
+  ok = ok && hipMemcpyAsync(rows, d, bytes, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+  (void)hipFree(d);
+  return ok ? EPS_OK : EPS_INFRA_UNEXPECTED_ERROR;
+}
+
+int32_t eps_merge_topk(const float* dist, const int64_t* ids, int32_t shards, int64_t nq, int32_t k, float* out_dist,
+                       int64_t* out_ids, int32_t device, void* stream) {
+  if (!dist || !ids || !out_dist || !out_ids || shards <= 0 || shards > 16 || nq < 0 || k <= 0) return EPS_USER_ERROR;
+  if (nq == 0) return EPS_OK;
+  if (hipSetDevice(device) != hipSuccess) return EPS_INFRA_UNEXPECTED_ERROR;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool dev = eps::is_device_ptr(dist);
+  if (dev != eps::is_device_ptr(ids) || dev != eps::is_device_ptr(out_dist) || dev != eps::is_device_ptr(out_ids)) return EPS_USER_ERROR;
+  if (dev) {
+    eps::launch_merge_shards(dist, ids, shards, nq, k, out_dist, out_ids, s);
+    return hipGetLastError() == hipSuccess ? EPS_OK : EPS_INFRA_UNEXPECTED_ERROR;
+  }
+  const size_t in_n = (size_t)shards * nq * k, out_n = (size_t)nq * k;
+  char* d = nullptr;
+  if (hipMalloc(&d, in_n * 12 + out_n * 12 + 64) != hipSuccess) return EPS_INFRA_UNEXPECTED_ERROR;
+  int64_t* d_ids = reinterpret_cast<int64_t*>(d);
+  int64_t* d_oids = d_ids + in_n;
+  float* d_dist = reinterpret_cast<float*>(d_oids + out_n);
+  float* d_odist = d_dist + in_n;
+  bool ok = hipMemcpyAsync(d_ids, ids, in_n * 8, hipMemcpyHostToDevice, s) == hipSuccess &&
+            hipMemcpyAsync(d_dist, dist, in_n * 4, hipMemcpyHostToDevice, s) == hipSuccess;
+  if (ok) eps::launch_merge_shards(d_dist, d_ids, shards, nq, k, d_odist, d_oids, s);
+  ok = ok && hipMemcpyAsync(out_ids, d_oids, out_n * 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
+       hipMemcpyAsync(out_dist, d_odist, out_n * 4, hipMemcpyDeviceToHost, s) == hipSuccess &&
+       hipStreamSynchronize(s) == hipSuccess;
+  (void)hipFree(d);
+  return ok ? EPS_OK : EPS_INFRA_UNEXPECTED_ERROR;
+}
+
+}  // extern "C"

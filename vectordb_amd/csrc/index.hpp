@@ -1,0 +1,124 @@
+// Host side of libepsilla_gfx950: the per-field index object behind the C ABI (include/epsilla_gfx950.h).
+// It plays the role of one VecSearchExecutor + its ANNGraphSegment (reference:
+// engine/db/execution/vec_search_executor.hpp:30-74, engine/db/ann_graph_segment.hpp:22-55) with the
+// vector table, graph and scratch mirrored in HBM.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/epsilla_gfx950.h"
+#include "kernels.hpp"
+
+namespace eps {
+
+struct DevBuf {  // growable device allocation
+  void* p = nullptr;
+  size_t cap = 0;
+  ~DevBuf();
+  // returns false on allocation failure
+  bool reserve(size_t bytes);
+  void release();
+  template <class T>
+  T* as() const { return static_cast<T*>(p); }
+};
+
+struct HalfMirror;   // fp16 mirror + per-row bounds for the MFMA filter engine (mfma_filter.hip)
+struct GraphDev;     // device CSR + traversal scratch (traverse.hip)
+
+class Index {
+ public:
+  Index(int64_t dim, int metric, int device);
+  ~Index();
+
+  int32_t init();
+  int32_t set_stream(void* s);
+  int32_t synchronize();
+  int32_t attach_rows(const float* rows, int64_t n);
+  int32_t append_rows(const float* rows, int64_t n_new);
+  int32_t set_id_map(int64_t base, int64_t stride);
+  int32_t set_deleted(const uint8_t* bits, int64_t nbytes);
+  int32_t set_int_filter(const void* column, int64_t stride, int32_t width, int32_t op, int64_t constant);
+  int32_t build(int64_t n, const eps_build_params* p);
+  int32_t set_graph(int64_t n, const int64_t* off, const int64_t* nbr, int64_t nav);
+  int32_t graph_info(int64_t* n, int64_t* edges, int64_t* nav) const;
+  int32_t get_graph(int64_t* off, int64_t* nbr) const;
+  int32_t save_graph(const char* path);
+  int32_t load_graph(const char* path);
+  int32_t search(const float* queries, int64_t nq, int32_t k, const eps_search_params* p, int64_t* ids, float* dist,
+                 int32_t* counts);
+
+  int64_t row_count() const { return n_rows_; }
+  const char* last_error() const { return err_.c_str(); }
+  const eps_search_stats& stats() const { return stats_; }
+
+  // ---- used by the engine translation units
+  int32_t fail(int32_t code, const std::string& msg) {
+    err_ = msg;
+    return code;
+  }
+  int32_t hip_fail(hipError_t e, const char* what);
+  FilterSpec filter_spec() const;
+  hipStream_t stream() const { return stream_; }
+
+  int64_t dim_;
+  int metric_;
+  int device_;
+  hipStream_t stream_ = nullptr;
+  bool own_stream_ = false;
+
+  // vector table mirror: row-major float[n_rows_][dim_] (engine/db/table_segment_mvp.cpp:106-111)
+  const float* d_rows_ = nullptr;
+  DevBuf rows_buf_;          // owns the storage when rows were attached from host memory
+  bool rows_owned_ = false;
+  int64_t n_rows_ = 0;
+  int64_t rows_version_ = 0;  // bumped on attach/append (invalidates the fp16 mirror)
+
+  int64_t id_base_ = 0, id_stride_ = 1;
+
+  const uint8_t* d_deleted_ = nullptr;
+  DevBuf deleted_buf_;
+  const uint8_t* d_fcol_ = nullptr;
+  DevBuf fcol_buf_;
+  int64_t f_stride_ = 0;
+  int32_t f_width_ = 0, f_op_ = 0;
+  int64_t f_value_ = 0;
+
+  // graph (reference layout kept on the host for get/save; device form in GraphDev)
+  int64_t n_indexed_ = 0;
+  int64_t nav_ = 0;
+  std::vector<int64_t> h_off_, h_nbr_;
+  GraphDev* graph_ = nullptr;
+
+  HalfMirror* mirror_ = nullptr;
+
+  // scratch
+  DevBuf q_buf_, partial_buf_, run_buf_, ids_buf_, dist_buf_, cnt_buf_, tmp_buf_;
+  hipEvent_t ev0_ = nullptr, ev1_ = nullptr, evk0_ = nullptr, evk1_ = nullptr;
+
+  std::string err_;
+  eps_search_stats stats_{};
+
+ private:
+  int32_t flat_stream(const float* dq, int64_t nq, int k, int64_t row_begin, int64_t row_end, u64* run_keys,
+                      bool merge_run);
+  friend int32_t flat_mfma_search(Index&, const float*, int64_t, int, u64*);
+  friend int32_t graph_search(Index&, const float*, int64_t, int, const eps_search_params&, u64*, int64_t*);
+};
+
+// engines implemented in their own translation units
+int32_t flat_mfma_search(Index& ix, const float* dq, int64_t nq, int k, u64* run_keys);
+bool flat_mfma_supported(const Index& ix, int64_t nq, int k);
+void half_mirror_free(HalfMirror* m);
+int32_t graph_upload(Index& ix);
+void graph_free(GraphDev* g);
+// writes result keys [nq][k] and counts
+int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_search_params& p, u64* run_keys,
+                     int64_t* evals);
+int32_t graph_build(Index& ix, int64_t n, const eps_build_params& p);
+
+bool is_device_ptr(const void* p);
+
+}  // namespace eps

@@ -1,0 +1,57 @@
+// Host-callable launchers for the HIP kernels of libepsilla_gfx950 (definitions in *.hip).
+// All pointers are device pointers unless stated otherwise; all launches are asynchronous on `s`.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_common.hpp"
+
+namespace eps {
+
+// ---------------------------------------------------------------- flat scan (BruteForceSearch, :717-768)
+struct FlatScanArgs {
+  const float* rows;
+  int64_t row_begin, row_end;   // local row range scanned
+  int dim;
+  int metric;
+  const float* queries;         // [nq][dim]
+  int64_t nq;
+  int k;
+  FilterSpec f;
+  u64* partial;                 // [nq][W][k] per-wave sorted lists
+  int W;                        // wavefronts per query = gridDim.x * 4
+  const u64* thr_in;            // optional [nq] initial thresholds (only keys < thr can enter), or null
+};
+// returns W (partial lists per query). `partial` must hold nq * flat_scan_waves(...) * k keys.
+int flat_scan_waves(int64_t nrows, int64_t nq, int dim);
+void launch_flat_scan(const FlatScanArgs& a, hipStream_t s);
+
+// merge `lists` sorted k-lists per query (plus, if merge_run, the existing run_keys[q][k]) into run_keys
+void launch_merge_lists(const u64* partial, int lists, int k, int64_t nq, u64* run_keys, bool merge_run, hipStream_t s);
+
+// exact fp32 re-rank of gathered candidate rows into run_keys (sorted, unique)
+struct RerankArgs {
+  const float* rows;
+  int dim;
+  int metric;
+  const float* queries;     // [nq][dim]
+  int64_t nq;
+  int k;
+  FilterSpec f;
+  const u32* cand;          // [nq][cap] local row ids
+  const u32* cand_count;    // [nq] (may exceed cap: only min(count,cap) are present)
+  int cap;
+  u64* run_keys;            // [nq][k] in/out
+};
+void launch_rerank(const RerankArgs& a, hipStream_t s);
+
+// run_keys -> caller-visible results: ids = local*stride+base (int64), dist fp32, counts int32
+void launch_finalize(const u64* run_keys, int64_t nq, int k, int64_t id_base, int64_t id_stride, int64_t* ids,
+                     float* dist, int32_t* counts, hipStream_t s);
+
+void launch_normalize(float* rows, int64_t n, int dim, bool only_if_nonzero, hipStream_t s);
+void launch_merge_shards(const float* dist, const int64_t* ids, int shards, int64_t nq, int k, float* out_dist,
+                         int64_t* out_ids, hipStream_t s);
+void launch_fill_u64(u64* p, int64_t n, u64 v, hipStream_t s);
+
+}  // namespace eps

@@ -1,0 +1,317 @@
+"""Host-side mirror of the reference's operator surface for the ANN path, over the C ABI.
+
+  GpuIndex           batch-native handle (one per vector field / shard)
+  ANNGraphSegment    same public members and method names as engine/db/ann_graph_segment.hpp:22-55
+  VecSearchExecutor  same constructor argument order and result members as
+                     engine/db/execution/vec_search_executor.hpp:61-74, 51-52
+  GetDistFunc        metric dispatch of engine/db/index/index.cpp:10-35 (returns the metric code the
+                     device kernels take; the arithmetic itself lives in csrc/device_common.hpp)
+
+numpy arrays are host buffers; anything exposing `data_ptr()` (a torch tensor on the GPU) is passed as a
+device pointer and used in place.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib as lib
+from ._lib import (EpsillaError, SearchParams, BuildParams, SearchStats, MODE_REFERENCE, MODE_FLAT, MODE_GRAPH,
+                   FLAT_AUTO, FLAT_STREAM, FLAT_MFMA, METRIC_EUCLIDEAN, METRIC_COSINE, METRIC_DOT_PRODUCT, OPS)
+
+METRICS = {"EUCLIDEAN": 0, "COSINE": 1, "DOT_PRODUCT": 2, "L2": 0, "IP": 2, 0: 0, 1: 1, 2: 2}
+BruteforceThreshold = 512  # vec_search_executor.hpp:28
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if hasattr(a, "data_ptr"):
+        return C.c_void_p(a.data_ptr())
+    return C.c_void_p(a.ctypes.data)
+
+
+def _is_dev(a):
+    return hasattr(a, "data_ptr")
+
+
+def GetDistFunc(field_type="VECTOR_FLOAT", metric_type="EUCLIDEAN"):
+    """index.cpp:10-35: unknown metrics fall back to L2Sqr."""
+    return METRICS.get(metric_type, 0)
+
+
+class GpuIndex:
+    def __init__(self, dim, metric="EUCLIDEAN", device=0):
+        self.L = lib.load()
+        self.dim = int(dim)
+        self.metric = METRICS[metric]
+        self.device = device
+        h = C.c_void_p()
+        rc = self.L.eps_index_create(self.dim, self.metric, device, C.byref(h))
+        if rc != 0:
+            raise EpsillaError(rc, "eps_index_create failed (no gfx950 device? there is no CPU fallback)")
+        self.h = h
+        self._keep = {}
+
+    def _check(self, rc):
+        if rc != 0:
+            raise EpsillaError(rc, self.L.eps_index_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.eps_index_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- data
+    def attach_rows(self, rows):
+        if not _is_dev(rows):
+            rows = np.ascontiguousarray(rows, np.float32)
+        assert rows.shape[1] == self.dim
+        self._keep["rows"] = rows
+        self._check(self.L.eps_index_attach_rows(self.h, _ptr(rows), rows.shape[0]))
+
+    def append_rows(self, rows):
+        if not _is_dev(rows):
+            rows = np.ascontiguousarray(rows, np.float32)
+        self._check(self.L.eps_index_append_rows(self.h, _ptr(rows), rows.shape[0]))
+
+    @property
+    def row_count(self):
+        return self.L.eps_index_row_count(self.h)
+
+    def set_id_map(self, base, stride):
+        self._check(self.L.eps_index_set_id_map(self.h, base, stride))
+
+    def set_deleted(self, bits):
+        if bits is None:
+            self._check(self.L.eps_index_set_deleted(self.h, None, 0))
+            return
+        if not _is_dev(bits):
+            bits = np.ascontiguousarray(bits, np.uint8)
+        self._keep["deleted"] = bits
+        nbytes = bits.numel() if _is_dev(bits) else bits.size
+        self._check(self.L.eps_index_set_deleted(self.h, _ptr(bits), nbytes))
+
+    def set_int_filter(self, column, op, value, stride=None, width=None):
+        if column is None or not OPS[op]:
+            self._check(self.L.eps_index_set_int_filter(self.h, None, 0, 0, 0, 0))
+            return
+        if not _is_dev(column):
+            column = np.ascontiguousarray(column)
+            stride = stride or column.strides[0]
+            width = width or column.dtype.itemsize
+        else:
+            stride = stride or column.element_size()
+            width = width or column.element_size()
+        self._keep["fcol"] = column
+        self._check(self.L.eps_index_set_int_filter(self.h, _ptr(column), stride, width, OPS[op], int(value)))
+
+    def set_stream(self, stream_ptr):
+        self._check(self.L.eps_index_set_stream(self.h, C.c_void_p(stream_ptr) if stream_ptr else None))
+
+    def synchronize(self):
+        self._check(self.L.eps_index_synchronize(self.h))
+
+    # ---- graph
+    def set_graph(self, off, nbr, nav):
+        off = np.ascontiguousarray(off, np.int64)
+        nbr = np.ascontiguousarray(nbr, np.int64)
+        self._check(self.L.eps_index_set_graph(self.h, len(off) - 1, _ptr(off), _ptr(nbr), int(nav)))
+
+    def graph_info(self):
+        n, e, nav = C.c_int64(), C.c_int64(), C.c_int64()
+        self._check(self.L.eps_index_graph_info(self.h, C.byref(n), C.byref(e), C.byref(nav)))
+        return n.value, e.value, nav.value
+
+    def get_graph(self):
+        n, e, nav = self.graph_info()
+        off = np.zeros(n + 1, np.int64)
+        nbr = np.zeros(max(e, 1), np.int64)
+        self._check(self.L.eps_index_get_graph(self.h, _ptr(off), _ptr(nbr)))
+        return off, nbr[:e], nav
+
+    def build(self, n=None, **kw):
+        bp = BuildParams()
+        self.L.eps_default_build_params(C.byref(bp))
+        for k_, v in kw.items():
+            setattr(bp, k_, v)
+        self._check(self.L.eps_index_build(self.h, self.row_count if n is None else n, C.byref(bp)))
+
+    def save_graph(self, path):
+        self._check(self.L.eps_index_save_graph(self.h, path.encode()))
+
+    def load_graph(self, path):
+        self._check(self.L.eps_index_load_graph(self.h, path.encode()))
+
+    # ---- search
+    def params(self, **kw):
+        p = SearchParams()
+        self.L.eps_default_search_params(C.byref(p))
+        for k_, v in kw.items():
+            setattr(p, k_, v)
+        return p
+
+    def search(self, queries, k, out=None, **kw):
+        """Returns (ids int64[nq,k], dist float32[nq,k], counts int32[nq]); numpy for host queries, or the
+        caller-provided device tensors `out=(ids, dist, counts)`."""
+        p = self.params(**kw)
+        if _is_dev(queries):
+            nq = queries.shape[0]
+            assert out is not None, "device queries need device output tensors: out=(ids, dist, counts)"
+            ids, dist, counts = out
+        else:
+            queries = np.ascontiguousarray(queries, np.float32)
+            if queries.ndim == 1:
+                queries = queries[None, :]
+            nq = queries.shape[0]
+            ids = np.empty((nq, k), np.int64)
+            dist = np.empty((nq, k), np.float32)
+            counts = np.empty(nq, np.int32)
+        assert queries.shape[1] == self.dim
+        self._check(self.L.eps_index_search(self.h, _ptr(queries), nq, k, C.byref(p), _ptr(ids), _ptr(dist), _ptr(counts)))
+        return ids, dist, counts
+
+    def stats(self):
+        s = SearchStats()
+        self._check(self.L.eps_index_last_stats(self.h, C.byref(s)))
+        return {f: getattr(s, f) for f, _ in SearchStats._fields_}
+
+
+def normalize_rows(rows, only_if_nonzero=True, device=0, stream=None):
+    """Normalize (db/vector.cpp:60-69) / insert-time normalisation (table_segment_mvp.cpp:574-587), in place."""
+    L = lib.load()
+    n, d = rows.shape
+    rc = L.eps_normalize_rows(_ptr(rows), n, d, int(only_if_nonzero), device, C.c_void_p(stream) if stream else None)
+    if rc != 0:
+        raise EpsillaError(rc, "eps_normalize_rows failed")
+    return rows
+
+
+def merge_topk(dist, ids, out_dist, out_ids, device=0, stream=None):
+    """dist/ids: [shards, nq, k] (all device tensors or all numpy)."""
+    L = lib.load()
+    shards, nq, k = dist.shape
+    rc = L.eps_merge_topk(_ptr(dist), _ptr(ids), shards, nq, k, _ptr(out_dist), _ptr(out_ids), device,
+                          C.c_void_p(stream) if stream else None)
+    if rc != 0:
+        raise EpsillaError(rc, "eps_merge_topk failed")
+    return out_dist, out_ids
+
+
+# ---------------------------------------------------------------------------------------------------------
+class ANNGraphSegment:
+    """engine/db/ann_graph_segment.hpp:22-55.  Public members keep the reference's names."""
+
+    def __init__(self, db_catalog_path=None, table_id=None, field_id=None, skip_sync_disk=True):
+        self.skip_sync_disk_ = skip_sync_disk if db_catalog_path is None else False
+        self.first_record_id_ = 0
+        self.record_number_ = 0
+        self.offset_table_ = np.zeros(1, np.int64)
+        self.neighbor_list_ = np.zeros(0, np.int64)
+        self.navigation_point_ = 0
+        self._index = None
+        if db_catalog_path is not None:  # file ctor, ann_graph_segment.cpp:39-98
+            path = self._path(db_catalog_path, table_id, field_id)
+            if os.path.exists(path):
+                with open(path, "rb") as f:
+                    hdr = np.fromfile(f, np.int64, 2)
+                    self.record_number_, self.first_record_id_ = int(hdr[0]), int(hdr[1])
+                    self.offset_table_ = np.fromfile(f, np.int64, self.record_number_ + 1)
+                    self.neighbor_list_ = np.fromfile(f, np.int64, int(self.offset_table_[-1]))
+                    self.navigation_point_ = int(np.fromfile(f, np.int64, 1)[0])
+            else:
+                os.makedirs(os.path.dirname(path), exist_ok=True)
+                self.SaveANNGraph(db_catalog_path, table_id, field_id)
+
+    @staticmethod
+    def _path(db_catalog_path, table_id, field_id):
+        return os.path.join(db_catalog_path, str(table_id), "ann_graph_%d.bin" % field_id)
+
+    def BuildFromVectorTable(self, vector_column, n, dim, metricType, device=0, **build_kw):
+        """ann_graph_segment.cpp:201-242, on the device: kNN graph -> NSG -> CSR."""
+        ix = GpuIndex(dim, metricType, device)
+        ix.attach_rows(vector_column[:n] if not hasattr(vector_column, "data_ptr") else vector_column)
+        ix.build(n, **build_kw)
+        self.offset_table_, self.neighbor_list_, self.navigation_point_ = ix.get_graph()
+        self.record_number_ = n
+        self._index = ix
+        return self
+
+    def SaveANNGraph(self, db_catalog_path, table_id, field_id, force=False):
+        """ann_graph_segment.cpp:156-199 (tmp + fsync + rename); returns a status code."""
+        if self.skip_sync_disk_ and not force:
+            return 0
+        path = self._path(db_catalog_path, table_id, field_id)
+        tmp = path + ".tmp"
+        try:
+            with open(tmp, "wb") as f:
+                np.array([self.record_number_, self.first_record_id_], np.int64).tofile(f)
+                np.ascontiguousarray(self.offset_table_, np.int64).tofile(f)
+                np.ascontiguousarray(self.neighbor_list_, np.int64).tofile(f)
+                np.array([self.navigation_point_], np.int64).tofile(f)
+                f.flush()
+                os.fsync(f.fileno())
+            os.rename(tmp, path)
+        except OSError:
+            return lib.EPS_DB_UNEXPECTED_ERROR
+        return 0
+
+
+class VecSearchExecutor:
+    """engine/db/execution/vec_search_executor.hpp:30-74.  One query per Search() call like the reference;
+    SearchBatch() is the additive batched entry."""
+
+    def __init__(self, dimension, start_search_point, ann_index, offset_table, neighbor_list, vector_column,
+                 fstdistfunc, dist_func_param=None, num_threads=4, L_master=500, L_local=500,
+                 subsearch_iterations=15, prefilter_enabled=False, device=0):
+        self.ann_index_ = ann_index
+        self.total_indexed_vector_ = int(ann_index.record_number_)
+        self.dimension_ = int(dimension)
+        self.start_search_point_ = int(start_search_point)
+        self.num_threads_, self.L_master_, self.L_local_ = num_threads, L_master, L_local
+        self.subsearch_iterations_, self.prefilter_enabled_ = subsearch_iterations, prefilter_enabled
+        self.brute_force_search_ = self.total_indexed_vector_ < BruteforceThreshold
+        self.search_result_ = np.zeros(L_master, np.int64)
+        self.distance_ = np.zeros(L_master, np.float64)
+        self._ix = GpuIndex(dimension, fstdistfunc, device)
+        self._rows = vector_column
+        self._attached = -1
+        self._graph = (np.asarray(offset_table, np.int64), np.asarray(neighbor_list, np.int64))
+
+    def _sync(self, total_vector, deleted, filter_spec):
+        if total_vector != self._attached:
+            self._ix.attach_rows(self._rows[:total_vector])
+            if self.total_indexed_vector_ > 0:
+                self._ix.set_graph(self._graph[0], self._graph[1], self.start_search_point_)
+            self._attached = total_vector
+        self._ix.set_deleted(deleted)
+        if filter_spec:
+            self._ix.set_int_filter(*filter_spec)
+        else:
+            self._ix.set_int_filter(None, None, 0)
+
+    def SearchBatch(self, queries, total_vector, limit, deleted=None, filter_spec=None):
+        self._sync(total_vector, deleted, filter_spec)
+        ids, dist, counts = self._ix.search(queries, limit, mode=MODE_REFERENCE, prefilter=int(self.prefilter_enabled_),
+                                            intra_threads=self.num_threads_, master_queue=self.L_master_,
+                                            local_queue=self.L_local_, sync_interval=self.subsearch_iterations_)
+        return ids, dist, counts
+
+    def Search(self, query_data, total_vector, limit, deleted=None, filter_spec=None):
+        """Status Search(query, table_segment, limit, filter_nodes, result_size): returns (status, result_size);
+        results land in search_result_ / distance_ (double), vec_search_executor.cpp:833-935."""
+        ids, dist, counts = self.SearchBatch(np.asarray(query_data, np.float32)[None, :], total_vector, limit, deleted,
+                                             filter_spec)
+        n = int(counts[0])
+        if n > len(self.search_result_):
+            self.search_result_ = np.zeros(n, np.int64)
+            self.distance_ = np.zeros(n, np.float64)
+        self.search_result_[:n] = ids[0, :n]
+        self.distance_[:n] = dist[0, :n].astype(np.float64)
+        return 0, n
