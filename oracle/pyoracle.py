@@ -51,7 +51,7 @@ class EoFilter(C.Structure):
 OPS = {None: 0, "": 0, "<": 1, "<=": 2, "==": 3, "=": 3, ">=": 4, ">": 5, "!=": 6, "<>": 6}
 
 
-def make_filter(deleted=None, attr=None, stride=0, width=4, op=None, value=0):
+def make_filter(deleted=None, attr=None, stride=0, width=4, op=None, value=0, offset=0):
     """Returns (EoFilter, keepalive)."""
     f = EoFilter()
     keep = []
@@ -62,7 +62,7 @@ def make_filter(deleted=None, attr=None, stride=0, width=4, op=None, value=0):
     if attr is not None and OPS[op]:
         attr = np.ascontiguousarray(attr)
         keep.append(attr)
-        f.attr = attr.ctypes.data
+        f.attr = attr.ctypes.data + offset
         f.stride = stride or attr.strides[0]
         f.width = width
         f.op = OPS[op]

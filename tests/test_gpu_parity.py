@@ -69,8 +69,8 @@ def test_flat_deleted_and_filter(amd, oracle):
     ix.attach_rows(X)
     ix.set_deleted(bits)
     for op, val in (("<", 1500), (">=", 2990), ("=", 77), ("!=", 5), ("<=", 2), (">", 10 ** 6)):
-        ix.set_int_filter(attr[:, 1:], op, val, stride=12, width=4)
-        flt, keep = make_filter(deleted=bits, attr=attr[:, 1:].copy(), stride=4, width=4, op=op, value=val)
+        ix.set_int_filter(attr, op, val, stride=12, width=4, offset=4)
+        flt, keep = make_filter(deleted=bits, attr=attr, stride=12, width=4, op=op, value=val, offset=4)
         ids, dist, cnt = ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
         for qi, q in enumerate(Q):
             rid, rd = oracle.topk_flat(0, X, q, 10, flt=flt)
@@ -78,7 +78,7 @@ def test_flat_deleted_and_filter(amd, oracle):
             assert m == len(rid)
             assert_topk_match(ids[qi, :m], dist[qi, :m], rid, rd, what="%s %d" % (op, val))
     # prefilter mode gives the same rows (PreFilterBruteForceSearch, :770-831)
-    ix.set_int_filter(attr[:, 1:], "<", 1500, stride=12, width=4)
+    ix.set_int_filter(attr, "<", 1500, stride=12, width=4, offset=4)
     a = ix.search(Q, 10, mode=amd.MODE_REFERENCE, prefilter=1)
     b = ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
     assert np.array_equal(a[0], b[0])
@@ -294,3 +294,78 @@ def test_merge_topk(amd):
     for q in range(nq):
         pairs = sorted((float(d[s, q, e]), int(ids[s, q, e])) for s in range(S) for e in range(k) if ids[s, q, e] >= 0)[:k]
         assert [p[1] for p in pairs] == list(oi[q]) and np.allclose([p[0] for p in pairs], od[q])
+
+
+# ----------------------------------------------------------------------------------------------- MFMA filter engine
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("n,d,nq", [(70_000, 768, 40), (100_000, 128, 130), (66_000, 100, 64), (80_000, 33, 33)])
+def test_mfma_engine_is_exact(amd, oracle, metric, n, d, nq):
+    """fp16-MFMA lower-bound filter + exact fp32 re-rank must return exactly what the fp32 stream scan returns
+    (same rows, same distance bits), and match the CPU oracle on a query sample."""
+    X = data(n, d, 7 + d)
+    Q = data(nq, d, 8 + d)
+    if metric == 1:
+        X = amd.normalize_rows(X, only_if_nonzero=True)
+        Q = amd.normalize_rows(Q, only_if_nonzero=False)
+    ix = amd.GpuIndex(d, metric)
+    ix.attach_rows(X)
+    for k in (1, 10, 100):
+        a = ix.search(Q, k, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA)
+        st = ix.stats()
+        b = ix.search(Q, k, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
+        assert st["overflow_queries"] == 0 and st["rerank_rows"] > 0
+        assert st["rerank_rows"] < 0.02 * n * nq, "filter is not selective: %d" % st["rerank_rows"]
+        assert np.array_equal(a[0], b[0]), "k=%d: %d rows differ" % (k, (a[0] != b[0]).sum())
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    for qi in range(0, nq, 13):
+        rid, rd = oracle.topk_flat(metric, X, Q[qi], 10)
+        ids, dist, cnt = ix.search(Q[qi:qi + 1].repeat(32, 0), 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA)
+        assert_topk_match(ids[5], dist[5], rid, rd, what="mfma vs oracle q%d" % qi)
+    ix.close()
+
+
+def test_mfma_engine_with_deleted_filter_and_ties(amd, oracle):
+    n, d, nq = 90_000, 64, 48
+    rng = np.random.default_rng(3)
+    base = rng.random((300, d), dtype=np.float32)
+    X = base[rng.integers(0, 300, n)]                     # every row has ~300 exact duplicates: massive ties
+    Q = rng.random((nq, d), dtype=np.float32)
+    bits = bitset(n, range(0, n, 3))
+    idc = np.arange(n, dtype=np.int64)
+    ix = amd.GpuIndex(d, 0)
+    ix.attach_rows(X)
+    ix.set_deleted(bits)
+    ix.set_int_filter(idc, ">=", 1000)
+    for k in (10, 64):
+        a = ix.search(Q, k, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA)
+        b = ix.search(Q, k, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    flt, keep = make_filter(deleted=bits, attr=idc, stride=8, width=8, op=">=", value=1000)
+    rid, rd = oracle.topk_flat(0, X, Q[0], 10, flt=flt)
+    assert np.array_equal(a[0][0][:10], rid)               # ties resolve by id exactly as Candidate::operator<
+    ix.close()
+
+
+def test_mfma_engine_adversarial_order_falls_back_exactly(amd):
+    """Rows sorted from far to near: every stage finds better rows than the threshold assumed, the candidate
+    buffers overflow, and the engine must fall back to the exact scan rather than drop results."""
+    import torch
+    n, d, nq = 300_000, 32, 64
+    g = torch.Generator(device="cuda").manual_seed(1)
+    q0 = torch.rand((1, d), generator=g, device="cuda")
+    X = torch.rand((n, d), generator=g, device="cuda")
+    order = torch.argsort(((X - q0) ** 2).sum(1), descending=True)
+    X = X[order].contiguous()
+    Q = (q0 + 0.01 * torch.rand((nq, d), generator=g, device="cuda")).contiguous()
+    ix = amd.GpuIndex(d, 0)
+    ix.attach_rows(X)
+    outs = []
+    for eng in (amd.FLAT_MFMA, amd.FLAT_STREAM):
+        ids = torch.empty((nq, 10), dtype=torch.int64, device="cuda")
+        dist = torch.empty((nq, 10), dtype=torch.float32, device="cuda")
+        cnt = torch.empty((nq,), dtype=torch.int32, device="cuda")
+        ix.search(Q, 10, out=(ids, dist, cnt), mode=amd.MODE_FLAT, flat_engine=eng)
+        ix.synchronize()
+        outs.append((ids.cpu().numpy(), dist.cpu().numpy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    ix.close()

@@ -399,9 +399,7 @@ int32_t Index::search(const float* queries, int64_t nq, int32_t k, const eps_sea
     if (cap_local && p.local_queue < keff) keff = (int)p.local_queue;
     if (keff < k) launch_fill_u64(run_keys, nq * k, KEY_EMPTY, stream_);
     int engine = p.flat_engine;
-    if (engine == EPS_FLAT_AUTO) engine = flat_mfma_supported(*this, nq, keff) ? EPS_FLAT_MFMA : EPS_FLAT_STREAM;
-    if (engine == EPS_FLAT_MFMA && !flat_mfma_supported(*this, nq, keff))
-      return fail(EPS_DB_UNSUPPORTED_ERROR, "search: the MFMA flat engine does not support this shape (see DESIGN.md); use EPS_FLAT_STREAM");
+    if (engine == EPS_FLAT_AUTO) engine = flat_mfma_profitable(*this, nq, keff) ? EPS_FLAT_MFMA : EPS_FLAT_STREAM;
     int32_t rc;
     if (keff == k) {
       rc = engine == EPS_FLAT_MFMA ? flat_mfma_search(*this, dq, nq, k, run_keys)

@@ -110,7 +110,7 @@ class Index {
 
 // engines implemented in their own translation units
 int32_t flat_mfma_search(Index& ix, const float* dq, int64_t nq, int k, u64* run_keys);
-bool flat_mfma_supported(const Index& ix, int64_t nq, int k);
+bool flat_mfma_profitable(const Index& ix, int64_t nq, int k);  // AUTO heuristic
 void half_mirror_free(HalfMirror* m);
 int32_t graph_upload(Index& ix);
 void graph_free(GraphDev* g);

@@ -1,10 +1,471 @@
-// placeholder until the fp16-MFMA filter engine lands (next milestone)
+// Batched flat scan on the matrix cores: the large-batch form of VecSearchExecutor::BruteForceSearch
+// (reference: engine/db/execution/vec_search_executor.cpp:717-768), returning the SAME exact answer as the
+// fp32 streaming scan.
+//
+// Idea: at batch b the flat scan is a GEMM, 2*b*N*d flops over N*d row elements.
+// gfx950 has no fast fp32/xf32 MFMA (fp32-in MFMA runs at the vector rate), so the GEMM runs on an fp16 mirror
+// of the row store with fp32 accumulation and is used only as a LOWER-BOUND FILTER:
+//     key(q,x) = |x|^2 - 2 q.x   (L2; -q.x for IP/COSINE)        exact key, dist = key + const(q)
+//     approx   = base[x] + s*acc,  acc = sum_k qh_k xh_k         what the MFMA tile produces
+//     |key - approx| <= |s| * (|q| * E1[x] + |q - qh| * |xh|)    E1[x] = |x - xh| + gamma*|xh|   (Cauchy-Schwarz +
+//                                                                 fp32 accumulation slack), no distributional assumption
+// A row can only be in the exact top-k if approx - bound <= T, where T is ANY valid upper bound of the k-th best
+// exact key — we use the k-th best exact key found so far.  Rows that pass are re-ranked in exact fp32 by the
+// gather kernel (flat_kernels.hip: rerank_kernel).  The scan is staged so T tightens:
+//     stage 0: exact fp32 stream scan of the first S0 rows            -> running top-k
+//     stage i: MFMA filter over the next, geometrically larger chunk  -> candidates -> exact re-rank -> top-k
+// Expected candidates per query ~ k * sum_i (chunk_i / rows_before_i): a few hundred at N = 10M, k = 10.
+// If a query's candidate buffer overflows (adversarial order/duplicates) the batch falls back to the fp32 scan,
+// so the result is exact in every case.
+//
+// Kernel: 128 rows x 128 queries per workgroup, 4 wavefronts (2x2) x 64x64 outputs each = 2x2 tiles of
+// v_mfma_f32_32x32x16_f16; K-step 64; both operands K-contiguous, staged HBM->LDS by global_load_lds (16 B/lane,
+// double-buffered, next tile in flight under the MFMAs); LDS rows XOR-swizzled on the source address so the
+// ds_read_b128 fragment reads are conflict-free; workgroup->tile map keeps the 8 query tiles of one row tile on
+// one XCD back-to-back so the row tile is fetched from HBM once and re-read from that XCD's L2.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
 #include "index.hpp"
+
 namespace eps {
-struct HalfMirror {};
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 64;
+
+struct HalfMirror {
+  DevBuf xh;       // _Float16 [n_pad][d_pad]
+  DevBuf xn;       // float [n_pad]  |x|^2 (+inf on padding rows)
+  DevBuf zeros;    // float [n_pad]  base for IP / COSINE (+inf on padding rows)
+  DevBuf scal;     // float [4]: E1max, nxh_max, xn_max, overflow flag (as float bits)
+  DevBuf qh;       // _Float16 [b_pad][d_pad]
+  DevBuf qstat;    // float [b_pad][4]: |q|^2, |q|, |q-qh|, unused
+  DevBuf T;        // float [b_pad]
+  DevBuf cand;     // u32 [b][cap]
+  DevBuf cnt;      // u32 [b] + overflow counter at [b]
+  int64_t version = -1;
+  int64_t n = 0, n_pad = 0;
+  int d_pad = 0;
+  bool fp16_range_ok = true;
+  float h_scal[4] = {0, 0, 0, 0};
+};
+
 void half_mirror_free(HalfMirror* m) { delete m; }
-bool flat_mfma_supported(const Index&, int64_t, int) { return false; }
-int32_t flat_mfma_search(Index& ix, const float*, int64_t, int, u64*) {
-  return ix.fail(EPS_NOT_IMPLEMENTED_ERROR, "MFMA flat engine not built");
+
+// ------------------------------------------------------------------------------------------------ mirror build
+__device__ __forceinline__ void atomic_max_pos(float* addr, float v) {  // v >= 0
+  atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
 }
+
+__global__ __launch_bounds__(256) void half_mirror_kernel(const float* rows, int64_t n, int64_t n_pad, int dim, int d_pad,
+                                                          _Float16* xh, float* xn, float* zeros, float* scal, float gamma) {
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n_pad) return;
+  const int lane = lane_id();
+  _Float16* dst = xh + r * d_pad;
+  if (r >= n) {
+    for (int c = lane; c < d_pad; c += 64) dst[c] = (_Float16)0.f;
+    if (lane == 0) {
+      xn[r] = __builtin_inff();
+      zeros[r] = __builtin_inff();
+    }
+    return;
+  }
+  const float* src = rows + r * dim;
+  float s2 = 0.f, e2 = 0.f, h2 = 0.f, mx = 0.f;
+  for (int c = lane; c < d_pad; c += 64) {
+    const float x = c < dim ? src[c] : 0.f;
+    const _Float16 h = (_Float16)x;
+    const float hf = (float)h;
+    dst[c] = h;
+    s2 = fmaf(x, x, s2);
+    const float e = x - hf;
+    e2 = fmaf(e, e, e2);
+    h2 = fmaf(hf, hf, h2);
+    mx = fmaxf(mx, fabsf(x));
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    s2 += __shfl_xor(s2, o);
+    e2 += __shfl_xor(e2, o);
+    h2 += __shfl_xor(h2, o);
+    mx = fmaxf(mx, __shfl_xor(mx, o));
+  }
+  if (lane == 0) {
+    xn[r] = s2;
+    zeros[r] = 0.f;
+    const float nxh = sqrtf(h2) * 1.000001f;
+    const float e1 = sqrtf(e2) * 1.000001f + gamma * nxh;
+    atomic_max_pos(&scal[0], e1);
+    atomic_max_pos(&scal[1], nxh);
+    atomic_max_pos(&scal[2], s2);
+    if (!(mx <= 65504.f)) atomic_max_pos(&scal[3], 1.f);  // also catches NaN
+  }
+}
+
+__global__ __launch_bounds__(256) void query_prep_kernel(const float* q, int64_t nq, int64_t b_pad, int dim, int d_pad,
+                                                         _Float16* qh, float* qstat) {
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= b_pad) return;
+  const int lane = lane_id();
+  _Float16* dst = qh + r * d_pad;
+  if (r >= nq) {
+    for (int c = lane; c < d_pad; c += 64) dst[c] = (_Float16)0.f;
+    if (lane == 0) qstat[r * 4 + 0] = qstat[r * 4 + 1] = qstat[r * 4 + 2] = qstat[r * 4 + 3] = 0.f;
+    return;
+  }
+  const float* src = q + r * dim;
+  float s2 = 0.f, e2 = 0.f;
+  for (int c = lane; c < d_pad; c += 64) {
+    const float x = c < dim ? src[c] : 0.f;
+    const _Float16 h = (_Float16)x;
+    dst[c] = h;
+    s2 = fmaf(x, x, s2);
+    const float e = x - (float)h;
+    e2 = fmaf(e, e, e2);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    s2 += __shfl_xor(s2, o);
+    e2 += __shfl_xor(e2, o);
+  }
+  if (lane == 0) {
+    qstat[r * 4 + 0] = s2;
+    qstat[r * 4 + 1] = sqrtf(s2) * 1.000001f;
+    qstat[r * 4 + 2] = sqrtf(e2) * 1.000001f;
+    qstat[r * 4 + 3] = 0.f;
+  }
+}
+
+// T[j]: pass threshold in approx-key space for query j, from the current k-th best exact distance.
+__global__ void threshold_kernel(const u64* run_keys, int k, int64_t nq, int64_t b_pad, const float* qstat,
+                                 const float* scal, int metric, float* T) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= b_pad) return;
+  if (j >= nq) {
+    T[j] = -__builtin_inff();
+    return;
+  }
+  const u64 kth = run_keys[j * k + (k - 1)];
+  const float FMAX = 3.0e38f;
+  if (kth == KEY_EMPTY) {
+    T[j] = FMAX;  // fewer than k visible rows so far: everything passes (bounded by the candidate cap)
+    return;
+  }
+  const float thr = key_dist(kth);
+  const float qn2 = qstat[j * 4 + 0], nq_ = qstat[j * 4 + 1], eq = qstat[j * 4 + 2];
+  const float e1max = scal[0], nxhmax = scal[1], xnmax = scal[2];
+  const float s = metric == 0 ? 2.f : 1.f;
+  const float c = metric == 0 ? qn2 : (metric == 1 ? 1.f : 0.f);
+  const float margin = s * (nq_ * e1max + eq * nxhmax);
+  const float scale = metric == 0 ? (fabsf(thr) + qn2 + xnmax) : (fabsf(thr) + 1.f + nq_ * nxhmax);
+  float t = (thr - c) + margin + 8e-6f * scale;
+  T[j] = fminf(t, FMAX);
+}
+
+// ------------------------------------------------------------------------------------------------ filter kernel
+struct FilterArgs {
+  const _Float16* xh;   // [n_pad][d_pad]
+  const _Float16* qh;   // [b_pad][d_pad]
+  const float* base;    // [n_pad]
+  const float* T;       // [b_pad]
+  int d_pad;
+  int tiles_q;          // b_pad / BN
+  int64_t tile0;        // first row tile of this stage
+  int64_t ntiles;       // row tiles in this stage
+  int64_t row_hi;       // rows >= row_hi are not reported
+  int64_t nq;
+  float s;              // -2 (L2) or -1
+  u32* cand;
+  u32* cnt;
+  int cap;
+};
+
+__device__ __forceinline__ int swz(int row, int chunk) { return (row << 3) + (chunk ^ ((row >> 1) & 7)); }  // 16-B granule index
+
+__global__ __launch_bounds__(256, 2) void mfma_filter_kernel(FilterArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  // layout: [2 stages][A 16 KB | B 16 KB] then base[128] floats
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware map: block b runs on XCD b%8; the tiles_q query tiles of a row tile are consecutive on one XCD
+  const int64_t bid = blockIdx.x;
+  const int xcd = (int)(bid & 7);
+  const int64_t local = bid >> 3;
+  const int qt = (int)(local % a.tiles_q);
+  const int64_t rt = (local / a.tiles_q) * 8 + xcd;
+  if (rt >= a.ntiles) return;
+  const int64_t row0 = (a.tile0 + rt) * BM;
+  const int64_t q0 = (int64_t)qt * BN;
+  const int ldk = a.d_pad;
+  const int KT = ldk / BK;
+
+  float* base_lds = reinterpret_cast<float*>(lds + 2 * 32768);
+  if (tid < BM) base_lds[tid] = a.base[row0 + tid];
+
+  const _Float16* gA = a.xh + row0 * ldk;
+  const _Float16* gB = a.qh + q0 * ldk;
+
+  // per-thread staging coordinates: 4 granules of A and 4 of B per K-tile
+  int g_row[4], g_chunk[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int s = it * 256 + tid;
+    g_row[it] = s >> 3;
+    g_chunk[it] = (s & 7) ^ ((g_row[it] >> 1) & 7);
+  }
+  auto stage = [&](int kt, int buf) {
+    unsigned char* dA = lds + buf * 32768;
+    unsigned char* dB = dA + 16384;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const _Float16* sa = gA + (int64_t)g_row[it] * ldk + kt * BK + g_chunk[it] * 8;
+      const _Float16* sb = gB + (int64_t)g_row[it] * ldk + kt * BK + g_chunk[it] * 8;
+      const int wbase = (it * 256 + wave * 64) * 16;  // wave-uniform LDS base; hardware adds lane*16
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sa,
+                                       (__attribute__((address_space(3))) void*)(dA + wbase), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sb,
+                                       (__attribute__((address_space(3))) void*)(dB + wbase), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int arow0 = wm * 64 + (lane & 31);
+  const int brow0 = wn * 64 + (lane & 31);
+  const int khalf = lane >> 5;
+
+  stage(0, 0);
+  for (int kt = 0; kt < KT; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < KT) stage(kt + 1, (kt + 1) & 1);
+    const unsigned char* sA = lds + (kt & 1) * 32768;
+    const unsigned char* sB = sA + 16384;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int chunk = kk * 2 + khalf;
+      half8 fa[2], fb[2];
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        fa[f] = *reinterpret_cast<const half8*>(sA + swz(arow0 + f * 32, chunk) * 16);
+        fb[f] = *reinterpret_cast<const half8*>(sB + swz(brow0 + f * 32, chunk) * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // epilogue: approx lower-bound key vs per-query threshold; survivors are appended to the candidate lists
+  float Tj[2];
+  int64_t qj[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    qj[j] = q0 + wn * 64 + j * 32 + (lane & 31);
+    Tj[j] = a.T[qj[j]];
+  }
+  __syncthreads();  // base_lds visible (first barrier of the K loop already ordered it; kept for KT == 0 safety)
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int rbase = wm * 64 + i * 32 + 4 * khalf;
+    float4 bv[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bv[g] = *reinterpret_cast<const float4*>(&base_lds[rbase + 8 * g]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bool any = false;
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float b = (r & 3) == 0 ? bv[r >> 2].x : (r & 3) == 1 ? bv[r >> 2].y : (r & 3) == 2 ? bv[r >> 2].z : bv[r >> 2].w;
+        v[r] = fmaf(acc[i][j][r], a.s, b);
+        any |= (v[r] <= Tj[j]);
+      }
+      if (__any(any)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (v[r] <= Tj[j]) {
+            const int64_t row = row0 + rbase + (r & 3) + 8 * (r >> 2);
+            if (row < a.row_hi && qj[j] < a.nq) {
+              const u32 slot = atomicAdd(&a.cnt[qj[j]], 1u);
+              if (slot < (u32)a.cap) a.cand[qj[j] * (int64_t)a.cap + slot] = (u32)row;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+__global__ void count_overflow_kernel(const u32* cnt, int64_t nq, int cap, u32* overflow) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < nq && cnt[j] > (u32)cap) atomicAdd(overflow, 1u);
+}
+__global__ void sum_counts_kernel(const u32* cnt, int64_t nq, int cap, unsigned long long* total) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < nq) atomicAdd(total, (unsigned long long)(cnt[j] < (u32)cap ? cnt[j] : (u32)cap));
+}
+
+// ------------------------------------------------------------------------------------------------ host
+static int32_t ensure_mirror(Index& ix) {
+  if (!ix.mirror_) ix.mirror_ = new HalfMirror();
+  HalfMirror& m = *ix.mirror_;
+  if (m.version == ix.rows_version_) return EPS_OK;
+  const int64_t n = ix.n_rows_;
+  const int64_t n_pad = (n + BM - 1) / BM * BM;
+  const int d_pad = (int)((ix.dim_ + BK - 1) / BK * BK);
+  if (!m.xh.reserve((size_t)n_pad * d_pad * 2) || !m.xn.reserve((size_t)n_pad * 4) || !m.zeros.reserve((size_t)n_pad * 4) ||
+      !m.scal.reserve(64))
+    return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory for the fp16 mirror");
+  hipStream_t s = ix.stream_;
+  hipError_t er = hipMemsetAsync(m.scal.p, 0, 64, s);
+  if (er != hipSuccess) return ix.hip_fail(er, "memset");
+  // fp32 accumulation slack of the MFMA dot product: <= 4 * d * 2^-24 * |qh||xh| (generous: covers any
+  // internal summation order / truncating adder)
+  const float gamma = 4.0f * (float)d_pad * 5.9604645e-8f;
+  hipLaunchKernelGGL(half_mirror_kernel, dim3((unsigned)((n_pad + 3) / 4)), dim3(256), 0, s, ix.d_rows_, n, n_pad,
+                     (int)ix.dim_, d_pad, m.xh.as<_Float16>(), m.xn.as<float>(), m.zeros.as<float>(), m.scal.as<float>(), gamma);
+  er = hipMemcpyAsync(m.h_scal, m.scal.p, 16, hipMemcpyDeviceToHost, s);
+  if (er == hipSuccess) er = hipStreamSynchronize(s);
+  if (er != hipSuccess) return ix.hip_fail(er, "fp16 mirror build");
+  m.fp16_range_ok = (m.h_scal[3] == 0.f);
+  m.n = n;
+  m.n_pad = n_pad;
+  m.d_pad = d_pad;
+  m.version = ix.rows_version_;
+  return EPS_OK;
+}
+
+bool flat_mfma_profitable(const Index& ix, int64_t nq, int k) {
+  // worth it only when the GEMM is big enough to beat the HBM-bound stream scan
+  if (nq < 32 || ix.n_rows_ < 65536 || k > 128) return false;
+  if (ix.mirror_ && ix.mirror_->version == ix.rows_version_ && !ix.mirror_->fp16_range_ok) return false;
+  return true;
+}
+
+int32_t flat_mfma_search(Index& ix, const float* dq, int64_t nq, int k, u64* run_keys) {
+  int32_t rc = ensure_mirror(ix);
+  if (rc != EPS_OK) return rc;
+  HalfMirror& m = *ix.mirror_;
+  const int64_t n = ix.n_rows_;
+  if (!m.fp16_range_ok) {
+    // values beyond the fp16 range: the filter bound would be vacuous; the exact stream engine takes over
+    return ix.flat_stream(dq, nq, k, 0, n, run_keys, false);
+  }
+  hipStream_t s = ix.stream_;
+  const int64_t b_pad = (nq + BN - 1) / BN * BN;
+  const int cap = std::max(4096, 64 * k);
+  if (!m.qh.reserve((size_t)b_pad * m.d_pad * 2) || !m.qstat.reserve((size_t)b_pad * 16) || !m.T.reserve((size_t)b_pad * 4) ||
+      !m.cand.reserve((size_t)nq * cap * 4) || !m.cnt.reserve((size_t)(nq + 4) * 4 + 16))
+    return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory (scratch)");
+  hipLaunchKernelGGL(query_prep_kernel, dim3((unsigned)((b_pad + 3) / 4)), dim3(256), 0, s, dq, nq, b_pad, (int)ix.dim_,
+                     m.d_pad, m.qh.as<_Float16>(), m.qstat.as<float>());
+
+  // stage boundaries (multiples of BM): S0, 32*S0, 256*S0, n
+  int64_t S0 = std::max<int64_t>(4096, (int64_t)(32 * k + BM - 1) / BM * BM);
+  std::vector<int64_t> bounds;
+  bounds.push_back(std::min(S0, n));
+  for (int64_t bnd : {S0 * 32, S0 * 256}) {
+    if (bnd < n && bnd > bounds.back()) bounds.push_back(bnd);
+  }
+  if (bounds.back() < n) bounds.push_back(n);
+
+  // stage 0: exact scan of the head
+  rc = ix.flat_stream(dq, nq, k, 0, bounds[0], run_keys, false);
+  if (rc != EPS_OK) return rc;
+  ix.stats_.main_kernel_launches = 0;
+
+  u32* cnt = m.cnt.as<u32>();
+  u32* overflow = cnt + nq;                                                    // [1]
+  unsigned long long* total = reinterpret_cast<unsigned long long*>(cnt + nq + 2);  // 8-byte aligned? ensured below
+  if ((reinterpret_cast<uintptr_t>(total) & 7) != 0) total = reinterpret_cast<unsigned long long*>(cnt + nq + 3);
+  hipError_t er = hipMemsetAsync(cnt + nq, 0, 32, s);
+  if (er != hipSuccess) return ix.hip_fail(er, "memset");
+
+  FilterArgs fa;
+  fa.xh = m.xh.as<_Float16>();
+  fa.qh = m.qh.as<_Float16>();
+  fa.base = ix.metric_ == 0 ? m.xn.as<float>() : m.zeros.as<float>();
+  fa.T = m.T.as<float>();
+  fa.d_pad = m.d_pad;
+  fa.tiles_q = (int)(b_pad / BN);
+  fa.nq = nq;
+  fa.s = ix.metric_ == 0 ? -2.f : -1.f;
+  fa.cand = m.cand.as<u32>();
+  fa.cnt = cnt;
+  fa.cap = cap;
+
+  RerankArgs ra;
+  ra.rows = ix.d_rows_;
+  ra.dim = (int)ix.dim_;
+  ra.metric = ix.metric_;
+  ra.queries = dq;
+  ra.nq = nq;
+  ra.k = k;
+  ra.f = ix.filter_spec();
+  ra.cand = fa.cand;
+  ra.cand_count = cnt;
+  ra.cap = cap;
+  ra.run_keys = run_keys;
+
+  const size_t shm = 2 * 32768 + BM * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_filter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    attr_set = true;
+  }
+  bool first = true;
+  for (size_t st = 0; st + 1 < bounds.size(); ++st) {
+    const int64_t lo = bounds[st], hi = bounds[st + 1];
+    hipLaunchKernelGGL(threshold_kernel, dim3((unsigned)((b_pad + 255) / 256)), dim3(256), 0, s, run_keys, k, nq, b_pad,
+                       m.qstat.as<float>(), m.scal.as<float>(), ix.metric_, m.T.as<float>());
+    er = hipMemsetAsync(cnt, 0, (size_t)nq * 4, s);
+    if (er != hipSuccess) return ix.hip_fail(er, "memset");
+    fa.tile0 = lo / BM;
+    fa.ntiles = (hi + BM - 1) / BM - fa.tile0;
+    fa.row_hi = hi;
+    const int64_t blocks = (fa.ntiles + 7) / 8 * 8 * fa.tiles_q;
+    const bool biggest = (st + 2 == bounds.size());
+    if (biggest) (void)hipEventRecord(ix.evk0_, s);
+    hipLaunchKernelGGL(mfma_filter_kernel, dim3((unsigned)blocks), dim3(256), shm, s, fa);
+    if (biggest) (void)hipEventRecord(ix.evk1_, s);
+    hipLaunchKernelGGL(count_overflow_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, cnt, nq, cap, overflow);
+    hipLaunchKernelGGL(sum_counts_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, cnt, nq, cap, total);
+    launch_rerank(ra, s);
+    first = false;
+  }
+  (void)first;
+  er = hipGetLastError();
+  if (er != hipSuccess) return ix.hip_fail(er, "MFMA filter launch");
+  struct {
+    u32 overflow, pad;
+    unsigned long long total;
+  } h = {0, 0, 0};
+  er = hipMemcpyAsync(&h.overflow, overflow, 4, hipMemcpyDeviceToHost, s);
+  if (er == hipSuccess) er = hipMemcpyAsync(&h.total, total, 8, hipMemcpyDeviceToHost, s);
+  if (er == hipSuccess) er = hipStreamSynchronize(s);
+  if (er != hipSuccess) return ix.hip_fail(er, "MFMA filter");
+  ix.stats_.rerank_rows += (int64_t)h.total;
+  ix.stats_.dist_evals += nq * (n - bounds[0]);
+  ix.stats_.main_kernel_launches = 1;
+  if (h.overflow) {
+    ix.stats_.overflow_queries += h.overflow;
+    return ix.flat_stream(dq, nq, k, 0, n, run_keys, false);  // exact fallback for the (rare) overflow case
+  }
+  return EPS_OK;
+}
+
 }  // namespace eps

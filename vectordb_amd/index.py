@@ -98,7 +98,9 @@ class GpuIndex:
         nbytes = bits.numel() if _is_dev(bits) else bits.size
         self._check(self.L.eps_index_set_deleted(self.h, _ptr(bits), nbytes))
 
-    def set_int_filter(self, column, op, value, stride=None, width=None):
+    def set_int_filter(self, column, op, value, stride=None, width=None, offset=0):
+        """column: numpy array / device tensor holding the attribute rows; the value of row i is the signed
+        `width`-byte integer at byte `offset + i*stride` (TableSegmentMVP::attribute_table_ layout)."""
         if column is None or not OPS[op]:
             self._check(self.L.eps_index_set_int_filter(self.h, None, 0, 0, 0, 0))
             return
@@ -110,7 +112,8 @@ class GpuIndex:
             stride = stride or column.element_size()
             width = width or column.element_size()
         self._keep["fcol"] = column
-        self._check(self.L.eps_index_set_int_filter(self.h, _ptr(column), stride, width, OPS[op], int(value)))
+        base = C.c_void_p(_ptr(column).value + offset)
+        self._check(self.L.eps_index_set_int_filter(self.h, base, stride, width, OPS[op], int(value)))
 
     def set_stream(self, stream_ptr):
         self._check(self.L.eps_index_set_stream(self.h, C.c_void_p(stream_ptr) if stream_ptr else None))
