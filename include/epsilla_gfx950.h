@@ -121,7 +121,10 @@ int32_t eps_index_create(int64_t dim, int32_t metric, int32_t device, eps_index*
 int32_t eps_index_destroy(eps_index* h);
 const char* eps_index_last_error(const eps_index* h);
 
-/* use an existing HIP stream (hipStream_t passed as void*); NULL = the index's own stream */
+/* use an existing HIP stream (hipStream_t passed as void*); NULL = the index's own non-blocking stream,
+ * hipStreamLegacy ((void*)1) = the legacy default stream.  Device buffers handed to the index (rows, queries,
+ * outputs, bitsets, columns) must be ready on the index's stream: share the producer's stream or synchronise
+ * the producer before the call. */
 int32_t eps_index_set_stream(eps_index* h, void* hip_stream);
 int32_t eps_index_synchronize(eps_index* h);
 

@@ -262,7 +262,7 @@ def test_flat_large_properties(amd):
     g = torch.Generator(device="cuda").manual_seed(42)
     X = torch.rand((n, d), generator=g, device="cuda", dtype=torch.float32)
     Qd = torch.rand((nq, d), generator=g, device="cuda", dtype=torch.float32)
-    ix = amd.GpuIndex(d, 0)
+    ix = amd.GpuIndex(d, 0).use_torch_stream()
     ix.attach_rows(X)
     ix.set_id_map(3, 8)
     ids = torch.empty((nq, k), dtype=torch.int64, device="cuda")
@@ -314,7 +314,8 @@ def test_mfma_engine_is_exact(amd, oracle, metric, n, d, nq):
         st = ix.stats()
         b = ix.search(Q, k, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
         assert st["overflow_queries"] == 0 and st["rerank_rows"] > 0
-        assert st["rerank_rows"] < 0.02 * n * nq, "filter is not selective: %d" % st["rerank_rows"]
+        # expected candidates ~ k * (rows / rows already ranked) summed over the stages; allow 2x
+        assert st["rerank_rows"] < nq * (2.0 * k * n / 4096 + 64), "filter is not selective: %d" % st["rerank_rows"]
         assert np.array_equal(a[0], b[0]), "k=%d: %d rows differ" % (k, (a[0] != b[0]).sum())
         assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
     for qi in range(0, nq, 13):
@@ -357,7 +358,7 @@ def test_mfma_engine_adversarial_order_falls_back_exactly(amd):
     order = torch.argsort(((X - q0) ** 2).sum(1), descending=True)
     X = X[order].contiguous()
     Q = (q0 + 0.01 * torch.rand((nq, d), generator=g, device="cuda")).contiguous()
-    ix = amd.GpuIndex(d, 0)
+    ix = amd.GpuIndex(d, 0).use_torch_stream()
     ix.attach_rows(X)
     outs = []
     for eng in (amd.FLAT_MFMA, amd.FLAT_STREAM):

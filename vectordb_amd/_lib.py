@@ -60,6 +60,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    try:
+        # torch ships its own HIP runtime; when both live in one process it must be the first one loaded,
+        # otherwise torch finds "no ROCm-capable device".  torch is plumbing here (device memory / streams).
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s is missing: run `python -m vectordb_amd.build` (hipcc, gfx950). There is no "
                           "fallback implementation." % LIB_PATH)

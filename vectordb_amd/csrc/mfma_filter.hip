@@ -25,6 +25,8 @@
 // one XCD back-to-back so the row tile is fetched from HBM once and re-read from that XCD's L2.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -444,6 +446,18 @@ int32_t flat_mfma_search(Index& ix, const float* dq, int64_t nq, int k, u64* run
     if (biggest) (void)hipEventRecord(ix.evk1_, s);
     hipLaunchKernelGGL(count_overflow_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, cnt, nq, cap, overflow);
     hipLaunchKernelGGL(sum_counts_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, cnt, nq, cap, total);
+    if (getenv("EPS_DEBUG")) {
+      std::vector<u32> hc((size_t)nq);
+      std::vector<float> hT((size_t)nq);
+      std::vector<u64> hk((size_t)nq * k);
+      (void)hipMemcpyAsync(hc.data(), cnt, (size_t)nq * 4, hipMemcpyDeviceToHost, s);
+      (void)hipMemcpyAsync(hT.data(), m.T.p, (size_t)nq * 4, hipMemcpyDeviceToHost, s);
+      (void)hipMemcpyAsync(hk.data(), run_keys, (size_t)nq * k * 8, hipMemcpyDeviceToHost, s);
+      (void)hipStreamSynchronize(s);
+      u32 mn = ~0u, mx = 0; double sum = 0; float tmin = 3e38f, tmax = -3e38f; int64_t empt = 0, big = 0;
+      for (int64_t j = 0; j < nq; ++j) { mn = std::min(mn, hc[j]); mx = std::max(mx, hc[j]); sum += hc[j]; tmin = std::min(tmin, hT[j]); tmax = std::max(tmax, hT[j]); empt += hk[j * k + k - 1] == KEY_EMPTY; big += hc[j] > (u32)cap; }
+      fprintf(stderr, "[eps] stage %zu rows [%lld,%lld) tiles %lld blocks %lld: cnt min %u mean %.1f max %u (>cap: %lld), T min %g max %g, empty kth %lld, scal %g %g %g\n", st, (long long)lo, (long long)hi, (long long)fa.ntiles, (long long)blocks, mn, sum / nq, mx, (long long)big, tmin, tmax, (long long)empt, m.h_scal[0], m.h_scal[1], m.h_scal[2]);
+    }
     launch_rerank(ra, s);
     first = false;
   }

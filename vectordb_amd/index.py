@@ -116,7 +116,19 @@ class GpuIndex:
         self._check(self.L.eps_index_set_int_filter(self.h, base, stride, width, OPS[op], int(value)))
 
     def set_stream(self, stream_ptr):
-        self._check(self.L.eps_index_set_stream(self.h, C.c_void_p(stream_ptr) if stream_ptr else None))
+        """stream_ptr: a hipStream_t as an integer (torch: `torch.cuda.current_stream().cuda_stream`).  0 is
+        torch's default stream = HIP's legacy null stream and is passed as hipStreamLegacy; None gives the index
+        its own non-blocking stream again.  Device buffers handed to the index must be ready on ITS stream:
+        share the producer's stream (this call) or synchronise the producer first."""
+        if stream_ptr is None:
+            self._check(self.L.eps_index_set_stream(self.h, None))
+        else:
+            self._check(self.L.eps_index_set_stream(self.h, C.c_void_p(stream_ptr if stream_ptr else 1)))
+
+    def use_torch_stream(self):
+        import torch
+        self.set_stream(torch.cuda.current_stream().cuda_stream)
+        return self
 
     def synchronize(self):
         self._check(self.L.eps_index_synchronize(self.h))
