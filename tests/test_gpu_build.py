@@ -1,0 +1,137 @@
+"""Device graph build (eps_index_build = ANNGraphSegment::BuildFromVectorTable, ann_graph_segment.cpp:201-242).
+The reference's build is randomised (NN-Descent, rand_r), so parity is defined on what the graph must BE
+(out-degree <= 50 (+repair), every node reachable from the navigation node, nav ~ medoid)
+and on what it must DO: searched by the reference's own algorithm it reaches the reference's recall."""
+import numpy as np
+import pytest
+
+from helpers import assert_topk_match, data
+from oracle.pyoracle import Ref, ref_available
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import vectordb_amd
+    from vectordb_amd.build import build
+    build()
+    return vectordb_amd
+
+
+def check_graph(off, nbr, nav, n, R=50):
+    deg = np.diff(off)
+    assert len(off) == n + 1 and off[0] == 0 and off[-1] == len(nbr)
+    assert nbr.min() >= 0 and nbr.max() < n
+    assert deg.min() >= 1
+    src = np.repeat(np.arange(n), deg)
+    assert not np.any(src == nbr), "self loops"
+    # reachability from nav (CheckConnectivity, nsg.cpp:687-775)
+    seen = np.zeros(n, bool)
+    seen[nav] = True
+    frontier = np.array([nav])
+    while len(frontier):
+        nxt = np.unique(np.concatenate([nbr[off[v]:off[v + 1]] for v in frontier]))
+        nxt = nxt[~seen[nxt]]
+        seen[nxt] = True
+        frontier = nxt
+    assert seen.all(), "%d nodes unreachable from nav" % (~seen).sum()
+    return deg
+
+
+def recall_at_k(ids, gt):
+    return np.mean([len(set(a) & set(b)) / float(len(b)) for a, b in zip(ids, gt)])
+
+
+@pytest.mark.parametrize("metric,n,d", [(0, 3000, 32), (1, 2500, 24), (2, 2000, 16), (0, 700, 7)])
+def test_build_small_graph_properties_and_cross_search(amd, oracle, metric, n, d):
+    X = data(n, d, 42)
+    if metric == 1:
+        X = amd.normalize_rows(X, only_if_nonzero=True)
+    Q = data(32, d, 43)
+    if metric == 1:
+        Q = amd.normalize_rows(Q, only_if_nonzero=False)
+    ix = amd.GpuIndex(d, metric)
+    ix.attach_rows(X)
+    ix.build()
+    off, nbr, nav = ix.get_graph()
+    deg = check_graph(off, nbr, nav, n)
+    assert deg.mean() > 8 and np.percentile(deg, 99) <= 50 + 8
+    # nav ~ medoid: closest row to the centroid
+    c = X.mean(0)
+    assert nav == int(np.argmin(((X - c) ** 2).sum(1)))
+    # the device traversal and the CPU oracle (pinned against the reference) agree on the device-built graph
+    ids, dist, cnt = ix.search(Q, 10, mode=amd.MODE_GRAPH, intra_threads=1)
+    L = min(500, n)
+    init = oracle.prepare_init_ids(off, nbr, nav, L)
+    gt = []
+    for qi, q in enumerate(Q):
+        oid, od, _ = oracle.search_impl(metric, X, off, nbr, init, q, T=1, L=L)
+        assert_topk_match(ids[qi], dist[qi], oid[:10], od[:10], what="cross m%d q%d" % (metric, qi))
+        gt.append(oracle.topk_flat(metric, X, q, 10)[0])
+    assert recall_at_k(ids, gt) >= 0.99   # reference: 1.0 on 3000x32 / 20000x64 at L=500
+    ix.close()
+
+
+@pytest.mark.skipif(not ref_available(), reason="needs oracle/_ref (reference compiled verbatim)")
+def test_reference_executor_searches_device_built_graph(amd):
+    """The strongest lever: the REFERENCE's own VecSearchExecutor::SearchImpl run on the graph
+    the device built, loaded through the reference's own file format, vs. the device traversal."""
+    import tempfile, os
+    ref = Ref()
+    n, d = 4000, 32
+    X, Q = data(n, d, 5), data(16, d, 6)
+    ix = amd.GpuIndex(d, 0)
+    ix.attach_rows(X)
+    ix.build()
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "3"))
+    ix.save_graph(os.path.join(tmp, "3", "ann_graph_1.bin"))
+    g = ref.L.ref_graph_load(tmp.encode(), 3, 1)     # ANNGraphSegment(db_catalog_path, table_id, field_id)
+    assert g
+    ex = ref.executor(g, X, metric=0, T=1, L=500)
+    ids, dist, cnt = ix.search(Q, 10, mode=amd.MODE_GRAPH, intra_threads=1)
+    for qi, q in enumerate(Q):
+        rid, rd = ref.search_impl(ex, q, 10)
+        assert_topk_match(ids[qi], dist[qi], rid, rd, what="ref on device graph q%d" % qi)
+    # and the other way round: a graph built by the reference, searched on the device
+    g2 = ref.build_graph(X, metric=0, threads=8)
+    off, nbr, nav = ref.graph_arrays(g2)
+    ix.set_graph(off, nbr, nav)
+    ex2 = ref.executor(g2, X, metric=0, T=1, L=500)
+    ids, dist, cnt = ix.search(Q, 10, mode=amd.MODE_GRAPH, intra_threads=1)
+    for qi, q in enumerate(Q):
+        rid, rd = ref.search_impl(ex2, q, 10)
+        assert_topk_match(ids[qi], dist[qi], rid, rd, what="device on ref graph q%d" % qi)
+    ix.close()
+
+
+def test_build_100k_mfma_knn_path(amd):
+    """n >= 65536 takes the matrix-core kNN path. Graph sanity + recall of the default search (L=500) against the
+    exact flat scan; the reference reaches 0.955 on 100k x 128 uniform data at L=500."""
+    import torch
+    n, d, nq = 100_000, 64, 200
+    g = torch.Generator(device="cuda").manual_seed(42)
+    X = torch.rand((n, d), generator=g, device="cuda")
+    Q = torch.rand((nq, d), generator=g, device="cuda")
+    ix = amd.GpuIndex(d, 0).use_torch_stream()
+    ix.attach_rows(X)
+    ix.build()
+    off, nbr, nav = ix.get_graph()
+    deg = check_graph(off, nbr, nav, n)
+    assert 20 <= deg.mean() <= 51
+    outs = {}
+    for name, kw in (("graph", dict(mode=amd.MODE_GRAPH, intra_threads=4)), ("flat", dict(mode=amd.MODE_FLAT))):
+        ids = torch.empty((nq, 10), dtype=torch.int64, device="cuda")
+        dist = torch.empty((nq, 10), dtype=torch.float32, device="cuda")
+        cnt = torch.empty((nq,), dtype=torch.int32, device="cuda")
+        ix.search(Q, 10, out=(ids, dist, cnt), **kw)
+        ix.synchronize()
+        outs[name] = ids.cpu().numpy()
+        if name == "graph":
+            st = ix.stats()
+            print("evals/query %.0f expansions/query %.0f" % (st["dist_evals"] / nq, st["expansions"] / nq))
+    r = recall_at_k(outs["graph"], outs["flat"])
+    print("recall@10 at L=500 on 100k x 64:", r)
+    assert r >= 0.95
+    ix.close()

@@ -41,7 +41,7 @@ __device__ __forceinline__ float ord2f(u32 o) {
 }
 __device__ __forceinline__ u64 make_key(float dist, u32 id) { return ((u64)f2ord(dist + 0.0f) << 32) | (u64)id; }
 __device__ __forceinline__ float key_dist(u64 k) { return ord2f((u32)(k >> 32)); }
-__device__ __forceinline__ u32 key_id(u64 k) { return (u32)k; }
+__host__ __device__ __forceinline__ u32 key_id(u64 k) { return (u32)k; }
 
 __device__ __forceinline__ u64 shfl64(u64 v, int src) {
   u32 lo = (u32)v, hi = (u32)(v >> 32);

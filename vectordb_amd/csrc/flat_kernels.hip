@@ -134,16 +134,18 @@ void launch_flat_scan(const FlatScanArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// merge per-wave lists.  One block per query.
+// merge the `lists` key slots of each query (per-wave sorted lists, or an unsorted candidate list) into its top-k.
+// One block per query.
 template <int KPL>
 __global__ __launch_bounds__(256) void merge_lists_kernel(const u64* partial, int lists, int k, u64* run_keys,
-                                                          int merge_run) {
+                                                          int merge_run, const u32* counts) {
   __shared__ u64 sh[4][KPL * 64];
   const int64_t q = blockIdx.x;
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
-  const u64* src = partial + q * (int64_t)lists * k;
-  const int total = lists * k;
+  const u64* src = partial + q * (int64_t)lists;   // `lists` = key slots per query
+  int total = lists;
+  if (counts) total = counts[q] < (u32)total ? (int)counts[q] : total;  // variable-length candidate list
   WaveTopK<KPL> L[1];
   u64 thr[1];
   L[0].init();
@@ -172,12 +174,13 @@ __global__ __launch_bounds__(256) void merge_lists_kernel(const u64* partial, in
   }
 }
 
-void launch_merge_lists(const u64* partial, int lists, int k, int64_t nq, u64* run_keys, bool merge_run, hipStream_t s) {
+void launch_merge_lists(const u64* partial, int lists, int k, int64_t nq, u64* run_keys, bool merge_run, hipStream_t s,
+                        const u32* counts) {
   if (nq <= 0) return;
   const int kpl = pick_kpl(k);
 #define EPS_CASE(KPL_) \
   if (kpl == KPL_) {   \
-    hipLaunchKernelGGL((merge_lists_kernel<KPL_>), dim3((unsigned)nq), dim3(256), 0, s, partial, lists, k, run_keys, merge_run ? 1 : 0); \
+    hipLaunchKernelGGL((merge_lists_kernel<KPL_>), dim3((unsigned)nq), dim3(256), 0, s, partial, lists, k, run_keys, merge_run ? 1 : 0, counts); \
     return;            \
   }
   EPS_CASE(1) EPS_CASE(2) EPS_CASE(4) EPS_CASE(8) EPS_CASE(16)

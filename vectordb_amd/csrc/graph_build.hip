@@ -1,7 +1,589 @@
-// placeholder until the device graph build lands (next milestone)
+// Device graph build: ANNGraphSegment::BuildFromVectorTable (reference: engine/db/ann_graph_segment.cpp:201-242)
+//   KNNGraph (NN-Descent, K = 100)  -> NsgIndex::Build (InitNavigationPoint, Link = GetNeighbors + SyncPrune,
+//   InterInsert, CheckConnectivity)  -> CSR  (engine/db/index/knn/knn.hpp:90-135, engine/db/index/nsg/nsg.cpp:45-775)
+//
+// MI355X form:
+//   1. kNN graph = the K nearest rows of every row by one batched flat scan per 1024-row block of "queries"
+//      on the matrix cores (mfma_filter.hip in approx mode: fp16 keys, no re-rank) — the exact object NN-Descent
+//      approximates iteratively under per-node spinlocks.  O(n^2 d) flops, all MFMA.
+//   2. navigation node = row closest to the centroid (exact flat scan with k = 1; the reference searches the
+//      kNN graph from a random start for the same thing, nsg.cpp:101-155).
+//   3. Link: per node, best-first search on the kNN graph from the navigation node with a queue of
+//      search_length (GetNeighbors, nsg.cpp:158-268) = traverse_kernel with an LDS hash as visited set and a
+//      log of every evaluated (dist,id); then SyncPrune/SelectEdge (nsg.cpp:540-580, 655-685): pool = log +
+//      kNN(v), sorted, MRNG rule over the first candidate_pool_size candidates, out_degree edges kept.
+//   4. InterInsert (nsg.cpp:583-653): reverse edges are scattered into per-node candidate lists with atomics and
+//      every node re-runs SelectEdge over (its edges + reverse candidates) when they exceed out_degree.  The
+//      reference does this serially in node order (its omp-for is orphaned, nsg.cpp:531-536); the batched form
+//      applies the same rule to the same candidate sets, so edge sets differ only by processing order.
+//   5. CheckConnectivity (nsg.cpp:687-775): reachability from the navigation node on the host (BFS over the
+//      CSR), every unreached node gets an in-edge from the closest reached node found by a device search.
+// NSG distances are always L2 (ann_graph_segment.cpp:216); the kNN stage uses the field metric (knn.hpp:41-53).
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
 #include "index.hpp"
+#include "traverse_kernel.hpp"
+
 namespace eps {
-int32_t graph_build(Index& ix, int64_t, const eps_build_params&) {
-  return ix.fail(EPS_NOT_IMPLEMENTED_ERROR, "device graph build not built yet");
+
+constexpr int PRUNE_POOL = 4096;   // sorted candidate pool per node (LDS)
+constexpr int LOG_CAP = 3840;      // evaluated nodes logged per search
+constexpr int REV_CAP = 64;        // reverse-edge candidates kept per node
+
+// ------------------------------------------------------------------------------------------------ kNN extraction
+__global__ void knn_extract_kernel(const u64* run_keys, int k1, int64_t q0, int64_t nq, int K, u32* knn_ids) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  const u64* src = run_keys + q * k1;
+  u32* dst = knn_ids + (q0 + q) * K;
+  int o = 0;
+  for (int e = 0; e < k1 && o < K; ++e) {
+    const u64 key = src[e];
+    if (key == KEY_EMPTY) break;
+    const u32 id = key_id(key);
+    if ((int64_t)id == q0 + q) continue;  // self
+    dst[o++] = id;
+  }
+  for (; o < K; ++o) dst[o] = TRV_NONE;
 }
+
+// ------------------------------------------------------------------------------------------------ centroid
+__global__ __launch_bounds__(256) void centroid_kernel(const float* rows, int64_t n, int dim, int64_t rows_per_block,
+                                                       float* acc) {
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
+  for (int c = threadIdx.x; c < dim; c += 256) {
+    float s = 0.f;
+    for (int64_t r = r0; r < r1; ++r) s += rows[r * dim + c];
+    atomicAdd(&acc[c], s);
+  }
+}
+__global__ void scale_kernel(float* v, int dim, float f) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < dim) v[c] *= f;
+}
+__global__ void gather_rows_kernel(const float* rows, const u32* ids, int64_t m, int dim, float* out) {
+  const int64_t i = blockIdx.x;
+  if (i >= m) return;
+  const float* src = rows + (int64_t)ids[i] * dim;
+  for (int c = threadIdx.x; c < dim; c += blockDim.x) out[i * dim + c] = src[c];
+}
+
+// ------------------------------------------------------------------------------------------------ prune (SelectEdge)
+struct PruneArgs {
+  const float* rows;
+  int dim;
+  int64_t v0;             // first node of this launch (node = v0 + blockIdx.x)
+  const u64* log;         // A: [nb][log_cap] plain (dist,id) keys, indexed by blockIdx.x; may be null
+  const u32* log_cnt;
+  int log_cap;
+  const u32* listB;       // B: [n][degB] ids whose distance to v is computed here (kNN lists), TRV_NONE padded; may be null
+  int degB;
+  const u32* idsC;        // C/D: [n][cap] (id, dist) pairs with counts; may be null
+  const float* distC;
+  const u32* cntC;
+  int capC;
+  const u32* idsD;
+  const float* distD;
+  const u32* cntD;
+  int capD;
+  int depth;              // candidates scanned (candidate_pool_size), <= 0: unlimited
+  int R;                  // out_degree
+  u32* out_ids;           // [n][R], TRV_NONE padded
+  float* out_dist;
+  u32* out_deg;
+};
+
+template <bool VEC4>
+__global__ __launch_bounds__(256) void prune_kernel(PruneArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int dim = a.dim;
+  const int qstride = (dim + 3) & ~3;
+  float* sq = reinterpret_cast<float*>(smem_raw);            // [qstride] V[v], later V[p]
+  u64* pool = reinterpret_cast<u64*>(sq + qstride);          // [PRUNE_POOL]
+  u32* kept = reinterpret_cast<u32*>(pool + PRUNE_POOL);     // [R]
+  float* keptd = reinterpret_cast<float*>(kept + a.R);       // [R]
+  int* sh = reinterpret_cast<int*>(keptd + a.R);             // [8]
+  const int tid = threadIdx.x;
+  const int lane = lane_id();
+  const int wave = tid >> 6;
+  const int64_t v = a.v0 + blockIdx.x;
+  const int G = group_lanes(dim, VEC4);
+  const int RPW = 64 / G;
+  const int g = lane / G;
+  const int t = lane & (G - 1);
+  constexpr int U = 4;
+
+  if (tid == 0) sh[0] = 0;
+  for (int i = tid; i < PRUNE_POOL; i += 256) pool[i] = KEY_EMPTY;
+  for (int i = tid; i < qstride; i += 256) sq[i] = i < dim ? a.rows[v * dim + i] : 0.f;
+  __syncthreads();
+  // ---- gather the pool
+  if (a.log) {
+    const u32 cnt = a.log_cnt[blockIdx.x];
+    const u64* src = a.log + (int64_t)blockIdx.x * a.log_cap;
+    for (u32 i = tid; i < cnt; i += 256) {
+      const int slot = atomicAdd(&sh[0], 1);
+      if (slot < PRUNE_POOL) pool[slot] = src[i];
+    }
+  }
+  if (a.idsC) {
+    const u32 cnt = a.cntC[v] < (u32)a.capC ? a.cntC[v] : (u32)a.capC;
+    for (u32 i = tid; i < cnt; i += 256) {
+      const int slot = atomicAdd(&sh[0], 1);
+      if (slot < PRUNE_POOL) pool[slot] = make_key(a.distC[v * a.capC + i], a.idsC[v * a.capC + i]);
+    }
+  }
+  if (a.idsD) {
+    const u32 cnt = a.cntD[v] < (u32)a.capD ? a.cntD[v] : (u32)a.capD;
+    for (u32 i = tid; i < cnt; i += 256) {
+      const int slot = atomicAdd(&sh[0], 1);
+      if (slot < PRUNE_POOL) pool[slot] = make_key(a.distD[v * a.capD + i], a.idsD[v * a.capD + i]);
+    }
+  }
+  __syncthreads();
+  if (a.listB) {  // "avoid lose nearest neighbor in knng" (nsg.cpp:542-557): distances to the kNN list of v
+    const u32* lst = a.listB + v * a.degB;
+    const int base = sh[0];
+    for (int c0 = wave * RPW * U; c0 < a.degB; c0 += 4 * RPW * U) {
+      const float* rp[U];
+      u32 id[U];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int ci = c0 + u * RPW + g;
+        ok[u] = ci < a.degB;
+        id[u] = ok[u] ? lst[ci] : TRV_NONE;
+        ok[u] = ok[u] && id[u] != TRV_NONE;
+        rp[u] = a.rows + (int64_t)(ok[u] ? id[u] : (u32)v) * dim;
+      }
+      float acc[U][1];
+      row_dists<U, 1, VEC4>(rp, sq, qstride, dim, 0, G, acc);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int slot = base + c0 + u * RPW + g;
+        if (t == 0 && c0 + u * RPW + g < a.degB && slot < PRUNE_POOL) pool[slot] = ok[u] ? make_key(acc[u][0], id[u]) : KEY_EMPTY;
+      }
+    }
+    __syncthreads();
+  }
+  // ---- sort by (dist,id)   (std::sort(pool), nsg.cpp:560 — ties by id here)
+  for (int size = 2; size <= PRUNE_POOL; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int i = tid; i < (PRUNE_POOL >> 1); i += 256) {
+        const int lo = ((i / stride) * (stride << 1)) + (i % stride);
+        const int hi = lo + stride;
+        const bool up = ((lo & size) == 0);
+        const u64 x = pool[lo], y = pool[hi];
+        if ((x > y) == up) {
+          pool[lo] = y;
+          pool[hi] = x;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // ---- SelectEdge (nsg.cpp:655-685): walk unique candidates != v in order; keep p iff no kept r has dist(r,p) < dist(v,p)
+  // count unique candidates first (needed for the "fits without pruning" case of InterInsert, nsg.cpp:640-650)
+  if (tid == 0) {
+    sh[1] = 0;  // nk
+    sh[2] = 0;  // cursor
+    sh[3] = 0;  // scanned
+  }
+  __syncthreads();
+  const bool unlimited = a.depth <= 0;
+  int uniq = 0;
+  if (unlimited) {
+    int local = 0;
+    for (int i = tid; i < PRUNE_POOL; i += 256) {
+      const u64 key = pool[i];
+      if (key != KEY_EMPTY && key_id(key) != (u32)v && (i == 0 || pool[i - 1] != key)) ++local;
+    }
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
+    if (lane == 0) sh[8 + wave] = local;
+    __syncthreads();
+    uniq = sh[8] + sh[9] + sh[10] + sh[11];
+  }
+  const bool keep_all = unlimited && uniq <= a.R;
+  while (true) {
+    // thread 0 advances the cursor to the next unique candidate
+    if (tid == 0) {
+      int c = sh[2];
+      int found = -1;
+      while (c < PRUNE_POOL) {
+        const u64 key = pool[c];
+        if (key == KEY_EMPTY) break;
+        const bool dup = (c > 0 && pool[c - 1] == key) || key_id(key) == (u32)v;
+        if (!dup) {
+          found = c;
+          break;
+        }
+        ++c;
+      }
+      sh[2] = c + 1;
+      sh[6] = found;
+      if (found >= 0) sh[3] += 1;
+      sh[7] = 0;  // "some kept r is closer to p than v" flag
+    }
+    __syncthreads();
+    const int cur = sh[6];
+    const int nk = sh[1];
+    if (cur < 0 || nk >= a.R || (!unlimited && sh[3] > a.depth)) break;
+    const u64 pkey = pool[cur];
+    const u32 pid = key_id(pkey);
+    const float pd = key_dist(pkey);
+    if (nk > 0 && !keep_all) {
+      for (int i = tid; i < qstride; i += 256) sq[i] = i < dim ? a.rows[(int64_t)pid * dim + i] : 0.f;
+      __syncthreads();
+      for (int c0 = wave * RPW * U; c0 < nk; c0 += 4 * RPW * U) {
+        const float* rp[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int ci = c0 + u * RPW + g;
+          ok[u] = ci < nk;
+          rp[u] = a.rows + (int64_t)kept[ok[u] ? ci : 0] * dim;
+        }
+        float acc[U][1];
+        row_dists<U, 1, VEC4>(rp, sq, qstride, dim, 0, G, acc);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (ok[u] && t == 0 && acc[u][0] < pd) sh[7] = 1;
+      }
+      __syncthreads();
+    }
+    if (tid == 0 && !sh[7]) {
+      kept[nk] = pid;
+      keptd[nk] = pd;
+      sh[1] = nk + 1;
+    }
+    __syncthreads();
+  }
+  const int nk = sh[1];
+  for (int i = tid; i < a.R; i += 256) {
+    a.out_ids[v * a.R + i] = i < nk ? kept[i] : TRV_NONE;
+    a.out_dist[v * a.R + i] = i < nk ? keptd[i] : 0.f;
+  }
+  if (tid == 0) a.out_deg[v] = (u32)nk;
+}
+
+// reverse edges: for every edge v->u offer v to u (InterInsert, nsg.cpp:583-653)
+__global__ void rev_scatter_kernel(const u32* ids, const float* dist, const u32* deg, int64_t n, int R, u32* rev_ids,
+                                   float* rev_dist, u32* rev_cnt) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * R) return;
+  const int64_t v = i / R;
+  const int j = (int)(i - v * R);
+  if ((u32)j >= deg[v]) return;
+  const u32 u = ids[i];
+  const u32 slot = atomicAdd(&rev_cnt[u], 1u);
+  if (slot < (u32)REV_CAP) {
+    rev_ids[(int64_t)u * REV_CAP + slot] = (u32)v;
+    rev_dist[(int64_t)u * REV_CAP + slot] = dist[i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host
+#define HIPCHK(expr)                                         \
+  do {                                                       \
+    hipError_t e__ = (expr);                                 \
+    if (e__ != hipSuccess) return ix.hip_fail(e__, #expr);   \
+  } while (0)
+
+static size_t prune_lds_bytes(int dim, int R) {
+  return (size_t)((dim + 3) & ~3) * 4 + (size_t)PRUNE_POOL * 8 + (size_t)R * 8 + 64;
+}
+
+int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp) {
+  hipStream_t s = ix.stream_;
+  const int dim = (int)ix.dim_;
+  if (n <= 1) {
+    std::vector<int64_t> off((size_t)n + 1, 0), nbr;
+    return ix.set_graph(n, off.data(), nbr.data(), 0);
+  }
+  const int K = (int)std::min<int64_t>(bp.knng, n - 1);
+  const int R = (int)bp.out_degree;
+  const int Ls = (int)std::min<int64_t>(bp.search_length, n);
+  if (K <= 0 || R <= 0 || Ls <= 0 || K + 1 > 1024 || R > 512)
+    return ix.fail(EPS_USER_ERROR, "build: unsupported parameters (need 0 < knng < 1024, 0 < out_degree <= 512)");
+  const bool vec4 = (dim % 4 == 0) && ((reinterpret_cast<uintptr_t>(ix.d_rows_) & 15) == 0);
+  const bool debug = getenv("EPS_DEBUG") != nullptr;
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  auto lap = [&](const char* what) {
+    if (!debug) return;
+    (void)hipEventRecord(e1, s);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    fprintf(stderr, "[eps build] %-28s %10.2f ms\n", what, ms);
+    (void)hipEventRecord(e0, s);
+  };
+  (void)hipEventRecord(e0, s);
+
+  // ---- 1. kNN graph
+  DevBuf knn, run;
+  const int k1 = K + 1;
+  const int64_t B = 1024;
+  if (!knn.reserve((size_t)n * K * 4) || !run.reserve((size_t)B * k1 * 8)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "build: out of device memory (kNN graph)");
+  const bool use_mfma = n >= 65536;
+  ix.scan_limit_ = n;  // the graph covers rows [0,n) only
+  for (int64_t q0 = 0; q0 < n; q0 += B) {
+    const int64_t nq = std::min(B, n - q0);
+    const float* dq = ix.d_rows_ + q0 * dim;
+    int32_t rc = use_mfma ? flat_mfma_search(ix, dq, nq, k1, run.as<u64>(), true)
+                          : ix.flat_stream(dq, nq, k1, 0, n, run.as<u64>(), false, -1, false);
+    if (rc != EPS_OK) {
+      ix.scan_limit_ = -1;
+      return rc;
+    }
+    hipLaunchKernelGGL(knn_extract_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, run.as<u64>(), k1, q0, nq, K,
+                       knn.as<u32>());
+  }
+  ix.scan_limit_ = -1;
+  lap("kNN graph");
+
+  // ---- 2. navigation node: closest row to the centroid (always L2)
+  DevBuf cen;
+  if (!cen.reserve((size_t)dim * 4 + 64)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "build: out of device memory");
+  HIPCHK(hipMemsetAsync(cen.p, 0, (size_t)dim * 4, s));
+  {
+    const int64_t rpb = std::max<int64_t>(64, (n + 2047) / 2048);
+    hipLaunchKernelGGL(centroid_kernel, dim3((unsigned)((n + rpb - 1) / rpb)), dim3(256), 0, s, ix.d_rows_, n, dim, rpb, cen.as<float>());
+    hipLaunchKernelGGL(scale_kernel, dim3((dim + 255) / 256), dim3(256), 0, s, cen.as<float>(), dim, 1.0f / (float)n);
+  }
+  int32_t rc = ix.flat_stream(cen.as<float>(), 1, 1, 0, n, run.as<u64>(), false, 0, false);
+  if (rc != EPS_OK) return rc;
+  u64 navkey = 0;
+  HIPCHK(hipMemcpyAsync(&navkey, run.p, 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  const int64_t nav = (int64_t)key_id(navkey);
+  lap("navigation node");
+
+  // seeds of every Link search: the first Ls kNN entries of nav (GetNeighbors, nsg.cpp:174-195), then nav+1, ...
+  std::vector<u32> seeds;
+  {
+    std::vector<u32> row((size_t)K);
+    HIPCHK(hipMemcpyAsync(row.data(), knn.as<u32>() + nav * K, (size_t)K * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    std::vector<uint8_t> sel((size_t)n, 0);
+    for (int i = 0; i < K && (int)seeds.size() < Ls; ++i)
+      if (row[i] != TRV_NONE && !sel[row[i]]) {
+        sel[row[i]] = 1;
+        seeds.push_back(row[i]);
+      }
+    int64_t tmp = nav + 1;
+    while ((int)seeds.size() < Ls) {
+      if (tmp >= n) tmp = 0;
+      const int64_t v = tmp++;
+      if (sel[v]) continue;
+      sel[v] = 1;
+      seeds.push_back((u32)v);
+    }
+  }
+  DevBuf d_seeds, logb, logc, counters, nsg_ids, nsg_dist, nsg_deg;
+  const int64_t NB = std::min<int64_t>(n, 16384);
+  if (!d_seeds.reserve((size_t)Ls * 4) || !logb.reserve((size_t)NB * LOG_CAP * 8) || !logc.reserve((size_t)NB * 4) ||
+      !counters.reserve(16) || !nsg_ids.reserve((size_t)n * R * 4) || !nsg_dist.reserve((size_t)n * R * 4) ||
+      !nsg_deg.reserve((size_t)n * 4))
+    return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "build: out of device memory (NSG link)");
+  HIPCHK(hipMemcpyAsync(d_seeds.p, seeds.data(), (size_t)Ls * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemsetAsync(counters.p, 0, 16, s));
+  int Lp2 = 1;
+  while (Lp2 < Ls) Lp2 <<= 1;
+  const size_t trv_shm = traverse_lds_bytes(dim, Lp2, true);
+  const size_t prn_shm = prune_lds_bytes(dim, R);
+  TraverseArgs ta;
+  ta.rows = ix.d_rows_;
+  ta.dim = dim;
+  ta.metric = 0;
+  ta.off = nullptr;
+  ta.nbr = knn.as<u32>();
+  ta.fixed_deg = K;
+  ta.init_ids = d_seeds.as<u32>();
+  ta.L = Ls;
+  ta.Lp2 = Lp2;
+  ta.M = 1;
+  ta.visited = nullptr;
+  ta.words = 0;
+  ta.out_queue = nullptr;
+  ta.counters = counters.as<unsigned long long>();
+  ta.log = logb.as<u64>();
+  ta.log_cnt = logc.as<u32>();
+  ta.log_cap = LOG_CAP;
+  PruneArgs pa;
+  std::memset(&pa, 0, sizeof(pa));
+  pa.rows = ix.d_rows_;
+  pa.dim = dim;
+  pa.log = logb.as<u64>();
+  pa.log_cnt = logc.as<u32>();
+  pa.log_cap = LOG_CAP;
+  pa.listB = knn.as<u32>();
+  pa.degB = K;
+  pa.depth = (int)bp.candidate_pool_size;
+  pa.R = R;
+  pa.out_ids = nsg_ids.as<u32>();
+  pa.out_dist = nsg_dist.as<float>();
+  pa.out_deg = nsg_deg.as<u32>();
+  // ---- 3. Link
+  for (int64_t v0 = 0; v0 < n; v0 += NB) {
+    const int64_t nb = std::min(NB, n - v0);
+    ta.queries = ix.d_rows_ + v0 * dim;
+    if (vec4)
+      hipLaunchKernelGGL((traverse_kernel<true, true, true>), dim3((unsigned)nb), dim3(256), trv_shm, s, ta);
+    else
+      hipLaunchKernelGGL((traverse_kernel<false, true, true>), dim3((unsigned)nb), dim3(256), trv_shm, s, ta);
+    pa.v0 = v0;
+    if (vec4)
+      hipLaunchKernelGGL((prune_kernel<true>), dim3((unsigned)nb), dim3(256), prn_shm, s, pa);
+    else
+      hipLaunchKernelGGL((prune_kernel<false>), dim3((unsigned)nb), dim3(256), prn_shm, s, pa);
+  }
+  HIPCHK(hipGetLastError());
+  lap("Link (search + SelectEdge)");
+
+  // ---- 4. InterInsert
+  DevBuf rev_ids, rev_dist, rev_cnt, out_ids, out_dist, out_deg;
+  if (!rev_ids.reserve((size_t)n * REV_CAP * 4) || !rev_dist.reserve((size_t)n * REV_CAP * 4) || !rev_cnt.reserve((size_t)n * 4) ||
+      !out_ids.reserve((size_t)n * R * 4) || !out_dist.reserve((size_t)n * R * 4) || !out_deg.reserve((size_t)n * 4))
+    return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "build: out of device memory (InterInsert)");
+  HIPCHK(hipMemsetAsync(rev_cnt.p, 0, (size_t)n * 4, s));
+  hipLaunchKernelGGL(rev_scatter_kernel, dim3((unsigned)((n * R + 255) / 256)), dim3(256), 0, s, nsg_ids.as<u32>(),
+                     nsg_dist.as<float>(), nsg_deg.as<u32>(), n, R, rev_ids.as<u32>(), rev_dist.as<float>(), rev_cnt.as<u32>());
+  std::memset(&pa, 0, sizeof(pa));
+  pa.rows = ix.d_rows_;
+  pa.dim = dim;
+  pa.idsC = nsg_ids.as<u32>();
+  pa.distC = nsg_dist.as<float>();
+  pa.cntC = nsg_deg.as<u32>();
+  pa.capC = R;
+  pa.idsD = rev_ids.as<u32>();
+  pa.distD = rev_dist.as<float>();
+  pa.cntD = rev_cnt.as<u32>();
+  pa.capD = REV_CAP;
+  pa.depth = 0;  // SelectEdge(limit = false)
+  pa.R = R;
+  pa.out_ids = out_ids.as<u32>();
+  pa.out_dist = out_dist.as<float>();
+  pa.out_deg = out_deg.as<u32>();
+  for (int64_t v0 = 0; v0 < n; v0 += 1 << 20) {
+    const int64_t nb = std::min<int64_t>(1 << 20, n - v0);
+    pa.v0 = v0;
+    if (vec4)
+      hipLaunchKernelGGL((prune_kernel<true>), dim3((unsigned)nb), dim3(256), prn_shm, s, pa);
+    else
+      hipLaunchKernelGGL((prune_kernel<false>), dim3((unsigned)nb), dim3(256), prn_shm, s, pa);
+  }
+  HIPCHK(hipGetLastError());
+  lap("InterInsert");
+
+  // ---- 5. connectivity on the host
+  std::vector<u32> h_ids((size_t)n * R), h_deg((size_t)n);
+  HIPCHK(hipMemcpyAsync(h_ids.data(), out_ids.p, (size_t)n * R * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(h_deg.data(), out_deg.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  std::vector<uint8_t> reached((size_t)n, 0);
+  {
+    std::vector<u32> stack;
+    stack.push_back((u32)nav);
+    reached[nav] = 1;
+    while (!stack.empty()) {
+      const u32 x = stack.back();
+      stack.pop_back();
+      for (u32 j = 0; j < h_deg[x]; ++j) {
+        const u32 y = h_ids[(size_t)x * R + j];
+        if (!reached[y]) {
+          reached[y] = 1;
+          stack.push_back(y);
+        }
+      }
+    }
+  }
+  std::vector<u32> orphans;
+  for (int64_t i = 0; i < n; ++i)
+    if (!reached[i]) orphans.push_back((u32)i);
+  std::vector<u32> extra_root;  // extra out-edge root -> orphan (FindUnconnectedNode, nsg.cpp:734-775)
+  if (!orphans.empty()) {
+    // search the NSG for every orphan's vector; attach it to the closest REACHED node in the search trace
+    std::vector<u32> nseeds;
+    {
+      std::vector<uint8_t> sel((size_t)n, 0);
+      for (u32 j = 0; j < h_deg[nav] && (int)nseeds.size() < Ls; ++j) {
+        const u32 y = h_ids[(size_t)nav * R + j];
+        if (!sel[y]) {
+          sel[y] = 1;
+          nseeds.push_back(y);
+        }
+      }
+      int64_t tmp = nav + 1;
+      while ((int)nseeds.size() < Ls) {
+        if (tmp >= n) tmp = 0;
+        const int64_t v = tmp++;
+        if (sel[v]) continue;
+        sel[v] = 1;
+        nseeds.push_back((u32)v);
+      }
+    }
+    DevBuf d_orph, d_q;
+    const int64_t m = (int64_t)orphans.size();
+    const int64_t OB = std::min<int64_t>(m, NB);
+    if (!d_orph.reserve((size_t)m * 4) || !d_q.reserve((size_t)OB * dim * 4)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "build: out of device memory (connectivity)");
+    HIPCHK(hipMemcpyAsync(d_orph.p, orphans.data(), (size_t)m * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_seeds.p, nseeds.data(), (size_t)Ls * 4, hipMemcpyHostToDevice, s));
+    ta.nbr = out_ids.as<u32>();
+    ta.fixed_deg = R;
+    std::vector<u64> hlog((size_t)OB * LOG_CAP);
+    std::vector<u32> hcnt((size_t)OB);
+    extra_root.assign((size_t)m, (u32)nav);
+    for (int64_t o0 = 0; o0 < m; o0 += OB) {
+      const int64_t nb = std::min(OB, m - o0);
+      hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)nb), dim3(256), 0, s, ix.d_rows_, d_orph.as<u32>() + o0, nb, dim, d_q.as<float>());
+      ta.queries = d_q.as<float>();
+      if (vec4)
+        hipLaunchKernelGGL((traverse_kernel<true, true, true>), dim3((unsigned)nb), dim3(256), trv_shm, s, ta);
+      else
+        hipLaunchKernelGGL((traverse_kernel<false, true, true>), dim3((unsigned)nb), dim3(256), trv_shm, s, ta);
+      HIPCHK(hipMemcpyAsync(hlog.data(), logb.p, (size_t)nb * LOG_CAP * 8, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipMemcpyAsync(hcnt.data(), logc.p, (size_t)nb * 4, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
+      for (int64_t i = 0; i < nb; ++i) {
+        u64 best = KEY_EMPTY;
+        for (u32 e = 0; e < hcnt[i]; ++e) {
+          const u64 key = hlog[(size_t)i * LOG_CAP + e];
+          if (reached[key_id(key)] && key < best) best = key;
+        }
+        if (best != KEY_EMPTY) extra_root[o0 + i] = key_id(best);
+      }
+    }
+  }
+  lap("connectivity");
+
+  // ---- CSR in the reference's layout (ann_graph_segment.cpp:222-241)
+  std::vector<int64_t> off((size_t)n + 1);
+  std::vector<u32> extra_cnt((size_t)n, 0);
+  for (size_t i = 0; i < orphans.size(); ++i) extra_cnt[extra_root[i]]++;
+  int64_t e = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    off[i] = e;
+    e += h_deg[i] + extra_cnt[i];
+  }
+  off[n] = e;
+  std::vector<int64_t> nbr((size_t)e);
+  std::vector<int64_t> fill((size_t)n);
+  for (int64_t i = 0; i < n; ++i) {
+    for (u32 j = 0; j < h_deg[i]; ++j) nbr[off[i] + j] = h_ids[(size_t)i * R + j];
+    fill[i] = off[i] + h_deg[i];
+  }
+  for (size_t i = 0; i < orphans.size(); ++i) nbr[fill[extra_root[i]]++] = orphans[i];
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (debug) fprintf(stderr, "[eps build] n=%lld edges=%lld avg degree %.1f orphans %zu nav %lld\n", (long long)n, (long long)e, (double)e / n, orphans.size(), (long long)nav);
+  return ix.set_graph(n, off.data(), nbr.data(), nav);
+}
+
 }  // namespace eps

@@ -318,7 +318,7 @@ int32_t Index::build(int64_t n, const eps_build_params* p) {
 
 // ------------------------------------------------------------------------------------------------ search
 int32_t Index::flat_stream(const float* dq, int64_t nq, int k, int64_t row_begin, int64_t row_end, u64* run_keys,
-                           bool merge_run) {
+                           bool merge_run, int metric, bool filtered) {
   if (row_end <= row_begin) {
     if (!merge_run) launch_fill_u64(run_keys, nq * k, KEY_EMPTY, stream_);
     return EPS_OK;
@@ -330,18 +330,19 @@ int32_t Index::flat_stream(const float* dq, int64_t nq, int k, int64_t row_begin
   a.row_begin = row_begin;
   a.row_end = row_end;
   a.dim = (int)dim_;
-  a.metric = metric_;
+  a.metric = metric < 0 ? metric_ : metric;
   a.queries = dq;
   a.nq = nq;
   a.k = k;
   a.f = filter_spec();
+  if (!filtered) a.f = FilterSpec{nullptr, nullptr, 0, 0, 0, 0};
   a.partial = partial_buf_.as<u64>();
   a.W = W;
   a.thr_in = nullptr;
   HIP_TRY(hipEventRecord(evk0_, stream_));
   launch_flat_scan(a, stream_);
   HIP_TRY(hipEventRecord(evk1_, stream_));
-  launch_merge_lists(a.partial, W, k, nq, run_keys, merge_run, stream_);
+  launch_merge_lists(a.partial, W * k, k, nq, run_keys, merge_run, stream_);
   HIP_TRY(hipGetLastError());
   stats_.main_kernel_launches += 1;
   stats_.dist_evals += nq * (row_end - row_begin);

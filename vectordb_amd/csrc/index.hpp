@@ -75,6 +75,7 @@ class Index {
   bool rows_owned_ = false;
   int64_t n_rows_ = 0;
   int64_t rows_version_ = 0;  // bumped on attach/append (invalidates the fp16 mirror)
+  int64_t scan_limit_ = -1;   // >= 0: flat engines scan rows [0, scan_limit_) only (graph build over a prefix)
 
   int64_t id_base_ = 0, id_stride_ = 1;
 
@@ -103,13 +104,15 @@ class Index {
 
  private:
   int32_t flat_stream(const float* dq, int64_t nq, int k, int64_t row_begin, int64_t row_end, u64* run_keys,
-                      bool merge_run);
-  friend int32_t flat_mfma_search(Index&, const float*, int64_t, int, u64*);
+                      bool merge_run, int metric = -1, bool filtered = true);
+  friend int32_t flat_mfma_search(Index&, const float*, int64_t, int, u64*, bool);
+  friend int32_t graph_build(Index&, int64_t, const eps_build_params&);
   friend int32_t graph_search(Index&, const float*, int64_t, int, const eps_search_params&, u64*, int64_t*);
 };
 
 // engines implemented in their own translation units
-int32_t flat_mfma_search(Index& ix, const float* dq, int64_t nq, int k, u64* run_keys);
+// approx = true: no exact re-rank, the top-k is selected on the fp16 keys (kNN-graph construction), filters ignored
+int32_t flat_mfma_search(Index& ix, const float* dq, int64_t nq, int k, u64* run_keys, bool approx = false);
 bool flat_mfma_profitable(const Index& ix, int64_t nq, int k);  // AUTO heuristic
 void half_mirror_free(HalfMirror* m);
 int32_t graph_upload(Index& ix);

@@ -181,6 +181,9 @@ struct FilterArgs {
   int64_t nq;
   float s;              // -2 (L2) or -1
   u32* cand;
+  u64* cand_keys;       // approx mode: (approx dist, row) keys instead of row ids
+  const float* qstat;   // [b_pad][4] (approx mode: |q|^2 to turn keys into distances)
+  int metric;
   u32* cnt;
   int cap;
 };
@@ -272,12 +275,13 @@ __global__ __launch_bounds__(256, 2) void mfma_filter_kernel(FilterArgs a) {
   }
 
   // epilogue: approx lower-bound key vs per-query threshold; survivors are appended to the candidate lists
-  float Tj[2];
+  float Tj[2], cj[2];
   int64_t qj[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     qj[j] = q0 + wn * 64 + j * 32 + (lane & 31);
     Tj[j] = a.T[qj[j]];
+    cj[j] = a.cand_keys ? (a.metric == 0 ? a.qstat[qj[j] * 4] : (a.metric == 1 ? 1.f : 0.f)) : 0.f;
   }
   __syncthreads();  // base_lds visible (first barrier of the K loop already ordered it; kept for KT == 0 safety)
 #pragma unroll
@@ -303,7 +307,15 @@ __global__ __launch_bounds__(256, 2) void mfma_filter_kernel(FilterArgs a) {
             const int64_t row = row0 + rbase + (r & 3) + 8 * (r >> 2);
             if (row < a.row_hi && qj[j] < a.nq) {
               const u32 slot = atomicAdd(&a.cnt[qj[j]], 1u);
-              if (slot < (u32)a.cap) a.cand[qj[j] * (int64_t)a.cap + slot] = (u32)row;
+              if (slot < (u32)a.cap) {
+                if (a.cand_keys) {
+                  float dapx = v[r] + cj[j];
+                  if (a.metric == 0) dapx = fmaxf(dapx, 0.f);
+                  a.cand_keys[qj[j] * (int64_t)a.cap + slot] = make_key(dapx, (u32)row);
+                } else {
+                  a.cand[qj[j] * (int64_t)a.cap + slot] = (u32)row;
+                }
+              }
             }
           }
         }
@@ -358,20 +370,20 @@ bool flat_mfma_profitable(const Index& ix, int64_t nq, int k) {
   return true;
 }
 
-int32_t flat_mfma_search(Index& ix, const float* dq, int64_t nq, int k, u64* run_keys) {
+int32_t flat_mfma_search(Index& ix, const float* dq, int64_t nq, int k, u64* run_keys, bool approx) {
   int32_t rc = ensure_mirror(ix);
   if (rc != EPS_OK) return rc;
   HalfMirror& m = *ix.mirror_;
-  const int64_t n = ix.n_rows_;
+  const int64_t n = ix.scan_limit_ >= 0 ? std::min(ix.scan_limit_, ix.n_rows_) : ix.n_rows_;
   if (!m.fp16_range_ok) {
     // values beyond the fp16 range: the filter bound would be vacuous; the exact stream engine takes over
-    return ix.flat_stream(dq, nq, k, 0, n, run_keys, false);
+    return ix.flat_stream(dq, nq, k, 0, n, run_keys, false, -1, !approx);
   }
   hipStream_t s = ix.stream_;
   const int64_t b_pad = (nq + BN - 1) / BN * BN;
   const int cap = std::max(4096, 64 * k);
   if (!m.qh.reserve((size_t)b_pad * m.d_pad * 2) || !m.qstat.reserve((size_t)b_pad * 16) || !m.T.reserve((size_t)b_pad * 4) ||
-      !m.cand.reserve((size_t)nq * cap * 4) || !m.cnt.reserve((size_t)(nq + 4) * 4 + 16))
+      !m.cand.reserve((size_t)nq * cap * (approx ? 8 : 4)) || !m.cnt.reserve((size_t)(nq + 4) * 4 + 16))
     return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory (scratch)");
   hipLaunchKernelGGL(query_prep_kernel, dim3((unsigned)((b_pad + 3) / 4)), dim3(256), 0, s, dq, nq, b_pad, (int)ix.dim_,
                      m.d_pad, m.qh.as<_Float16>(), m.qstat.as<float>());
@@ -386,7 +398,7 @@ int32_t flat_mfma_search(Index& ix, const float* dq, int64_t nq, int k, u64* run
   if (bounds.back() < n) bounds.push_back(n);
 
   // stage 0: exact scan of the head
-  rc = ix.flat_stream(dq, nq, k, 0, bounds[0], run_keys, false);
+  rc = ix.flat_stream(dq, nq, k, 0, bounds[0], run_keys, false, -1, !approx);
   if (rc != EPS_OK) return rc;
   ix.stats_.main_kernel_launches = 0;
 
@@ -407,6 +419,9 @@ int32_t flat_mfma_search(Index& ix, const float* dq, int64_t nq, int k, u64* run
   fa.nq = nq;
   fa.s = ix.metric_ == 0 ? -2.f : -1.f;
   fa.cand = m.cand.as<u32>();
+  fa.cand_keys = approx ? m.cand.as<u64>() : nullptr;
+  fa.qstat = m.qstat.as<float>();
+  fa.metric = ix.metric_;
   fa.cnt = cnt;
   fa.cap = cap;
 
@@ -458,7 +473,10 @@ int32_t flat_mfma_search(Index& ix, const float* dq, int64_t nq, int k, u64* run
       for (int64_t j = 0; j < nq; ++j) { mn = std::min(mn, hc[j]); mx = std::max(mx, hc[j]); sum += hc[j]; tmin = std::min(tmin, hT[j]); tmax = std::max(tmax, hT[j]); empt += hk[j * k + k - 1] == KEY_EMPTY; big += hc[j] > (u32)cap; }
       fprintf(stderr, "[eps] stage %zu rows [%lld,%lld) tiles %lld blocks %lld: cnt min %u mean %.1f max %u (>cap: %lld), T min %g max %g, empty kth %lld, scal %g %g %g\n", st, (long long)lo, (long long)hi, (long long)fa.ntiles, (long long)blocks, mn, sum / nq, mx, (long long)big, tmin, tmax, (long long)empt, m.h_scal[0], m.h_scal[1], m.h_scal[2]);
     }
-    launch_rerank(ra, s);
+    if (approx)
+      launch_merge_lists(fa.cand_keys, cap, k, nq, run_keys, true, s, cnt);  // select on the fp16 keys
+    else
+      launch_rerank(ra, s);
     first = false;
   }
   (void)first;
@@ -477,7 +495,7 @@ int32_t flat_mfma_search(Index& ix, const float* dq, int64_t nq, int k, u64* run
   ix.stats_.main_kernel_launches = 1;
   if (h.overflow) {
     ix.stats_.overflow_queries += h.overflow;
-    return ix.flat_stream(dq, nq, k, 0, n, run_keys, false);  // exact fallback for the (rare) overflow case
+    if (!approx) return ix.flat_stream(dq, nq, k, 0, n, run_keys, false);  // exact fallback for the (rare) overflow case
   }
   return EPS_OK;
 }

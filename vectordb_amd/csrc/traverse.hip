@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "index.hpp"
+#include "traverse_kernel.hpp"
 
 namespace eps {
 
@@ -77,264 +78,6 @@ static void prepare_init_ids(const Index& ix, int64_t L, std::vector<u32>& out) 
     if (sel[v]) continue;
     sel[v] = 1;
     out.push_back((u32)v);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------ kernel
-struct TraverseArgs {
-  const float* rows;
-  int dim;
-  int metric;
-  const int64_t* off;
-  const u32* nbr;
-  const u32* init_ids;
-  const float* queries;
-  int L;       // queue length
-  int Lp2;     // next power of two >= L
-  int M;       // expansions per round
-  u32* visited;      // [gridDim.x][words]
-  int64_t words;
-  u64* out_queue;    // [nq][L]
-  unsigned long long* counters;  // [0] distance evals, [1] expansions
-};
-
-constexpr int TRV_CHUNK = 256;   // neighbours handled per sub-round
-constexpr int TRV_MAXM = 16;
-
-// queue key: ord(dist) << 32 | id << 1 | checked
-__device__ __forceinline__ u64 qkey(float d, u32 id, u32 checked) { return ((u64)f2ord(d + 0.0f) << 32) | ((u64)id << 1) | checked; }
-
-template <bool VEC4>
-__global__ __launch_bounds__(256) void traverse_kernel(TraverseArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int dim = a.dim;
-  const int qstride = (dim + 3) & ~3;
-  float* sq = reinterpret_cast<float*>(smem_raw);                        // [qstride]
-  u64* queue = reinterpret_cast<u64*>(sq + qstride);                     // [Lp2]
-  u64* newk = queue + a.Lp2;                                              // [TRV_CHUNK] unsorted keys of this sub-round
-  u64* sorted = newk + TRV_CHUNK;                                         // [TRV_CHUNK]
-  u32* work = reinterpret_cast<u32*>(sorted + TRV_CHUNK);                 // [TRV_CHUNK] surviving neighbour ids
-  int* sh = reinterpret_cast<int*>(work + TRV_CHUNK);                     // small scalars
-  // sh[0]=work count, sh[1]=selected count, sh[2]=k (first possibly-unchecked position), sh[3]=valid new count,
-  // sh[4]=r_min, sh[5]=position of the first selected candidate, sh[8..8+M) selected node ids, sh[24..24+M+1) edge prefix, sh[48..52) per-wave counts
-  const int tid = threadIdx.x;
-  const int lane = lane_id();
-  const int wave = tid >> 6;
-  const int64_t q = blockIdx.x;
-  const int L = a.L;
-  const int G = group_lanes(dim, VEC4);
-  const int RPW = 64 / G;
-  const int g = lane / G;
-  const int t = lane & (G - 1);
-  constexpr int U = 4;
-  u32* vis = a.visited + q * a.words;
-  unsigned long long evals = 0, expansions = 0;
-
-  for (int i = tid; i < qstride; i += 256) sq[i] = i < dim ? a.queries[q * dim + i] : 0.f;
-  for (int i = tid; i < a.Lp2; i += 256) queue[i] = KEY_EMPTY;
-  // InitializeSetLPara (:446-485): mark seeds visited, L seed distances, sort
-  for (int i = tid; i < L; i += 256) {
-    const u32 id = a.init_ids[i];
-    atomicOr(&vis[id >> 5], 1u << (id & 31));
-  }
-  __syncthreads();
-  for (int c0 = wave * RPW * U; c0 < L; c0 += 4 * RPW * U) {
-    const float* rp[U];
-    u32 id[U];
-    bool ok[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int ci = c0 + u * RPW + g;
-      ok[u] = ci < L;
-      id[u] = a.init_ids[ok[u] ? ci : L - 1];
-      rp[u] = a.rows + (int64_t)id[u] * dim;
-    }
-    float acc[U][1];
-    row_dists<U, 1, VEC4>(rp, sq, qstride, dim, a.metric, G, acc);
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (ok[u] && t == 0) queue[c0 + u * RPW + g] = qkey(finish_dist(a.metric, acc[u][0]), id[u], 0);
-  }
-  evals += L;
-  __syncthreads();
-  // bitonic sort of queue[0..Lp2)
-  for (int size = 2; size <= a.Lp2; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int i = tid; i < (a.Lp2 >> 1); i += 256) {
-        const int lo = ((i / stride) * (stride << 1)) + (i % stride);
-        const int hi = lo + stride;
-        const bool up = ((lo & size) == 0);
-        const u64 x = queue[lo], y = queue[hi];
-        if ((x > y) == up) {
-          queue[lo] = y;
-          queue[hi] = x;
-        }
-      }
-      __syncthreads();
-    }
-  }
-  if (tid == 0) sh[2] = 0;
-  __syncthreads();
-
-  // ---- rounds
-  while (true) {
-    // 1. select the first M unchecked candidates at positions >= k, mark them checked
-    if (tid == 0) sh[1] = 0;
-    __syncthreads();
-    for (int base = sh[2]; base < L; base += 256) {
-      const int p = base + tid;
-      const bool un = p < L && !(queue[p] & 1ull);
-      const u64 m = __ballot(un);
-      if (lane == 0) sh[48 + wave] = __popcll(m);
-      __syncthreads();
-      int before = sh[1];
-      for (int w2 = 0; w2 < wave; ++w2) before += sh[48 + w2];
-      const int rank = before + __popcll(m & ((1ull << lane) - 1ull));
-      if (un && rank < a.M) {
-        sh[8 + rank] = (int)((queue[p] >> 1) & 0x7FFFFFFFu);
-        queue[p] |= 1ull;
-        if (rank == 0) sh[5] = p;  // everything before the first selected candidate is checked
-      }
-      __syncthreads();
-      if (tid == 0) {
-        int tot = sh[1] + sh[48] + sh[49] + sh[50] + sh[51];
-        sh[1] = tot < a.M ? tot : a.M;
-      }
-      __syncthreads();
-      if (sh[1] >= a.M) break;
-    }
-    const int nsel = sh[1];
-    if (nsel == 0) break;
-    expansions += nsel;
-    if (tid == 0) {
-      sh[2] = sh[5];
-      int acc = 0;
-      for (int i = 0; i < nsel; ++i) {
-        sh[24 + i] = acc;
-        acc += (int)(a.off[sh[8 + i] + 1] - a.off[sh[8 + i]]);
-      }
-      sh[24 + nsel] = acc;
-    }
-    __syncthreads();
-    const int total_edges = sh[24 + nsel];
-
-    for (int e0 = 0; e0 < total_edges; e0 += TRV_CHUNK) {
-      // 2. gather neighbour ids, test-and-set visited, compact survivors
-      if (tid == 0) {
-        sh[0] = 0;
-        sh[3] = 0;
-      }
-      __syncthreads();
-      {
-        const int e = e0 + tid;
-        bool fresh = false;
-        u32 nb = 0;
-        if (e < total_edges) {
-          int i = 0;
-          while (i + 1 < nsel && sh[24 + i + 1] <= e) ++i;
-          nb = a.nbr[a.off[sh[8 + i]] + (e - sh[24 + i])];
-          const u32 bit = 1u << (nb & 31);
-          const u32 old = atomicOr(&vis[nb >> 5], bit);
-          fresh = !(old & bit);
-        }
-        const u64 m = __ballot(fresh);
-        int wbase = 0;
-        if (lane == 0 && m) wbase = atomicAdd(&sh[0], __popcll(m));
-        wbase = __shfl(wbase, 0);
-        if (fresh) work[wbase + __popcll(m & ((1ull << lane) - 1ull))] = nb;
-      }
-      __syncthreads();
-      const int nwork = sh[0];
-      if (nwork == 0) continue;
-      evals += nwork;
-      // 3. distances; drop candidates beyond the current worst-of-queue (dist > bound, :427)
-      const float bound = key_dist(queue[L - 1]);
-      for (int c0 = wave * RPW * U; c0 < nwork; c0 += 4 * RPW * U) {
-        const float* rp[U];
-        u32 id[U];
-        bool ok[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int ci = c0 + u * RPW + g;
-          ok[u] = ci < nwork;
-          id[u] = work[ok[u] ? ci : nwork - 1];
-          rp[u] = a.rows + (int64_t)id[u] * dim;
-        }
-        float acc[U][1];
-        row_dists<U, 1, VEC4>(rp, sq, qstride, dim, a.metric, G, acc);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          if (ok[u] && t == 0) {
-            const float d = finish_dist(a.metric, acc[u][0]);
-            newk[c0 + u * RPW + g] = (d > bound) ? KEY_EMPTY : qkey(d, id[u], 0);
-          }
-        }
-      }
-      __syncthreads();
-      // 4. rank-sort the survivors (nwork <= 256: one thread per key, broadcast LDS reads)
-      if (tid < nwork) {
-        const u64 mine = newk[tid];
-        if (mine != KEY_EMPTY) {
-          int rank = 0;
-          for (int j = 0; j < nwork; ++j) {
-            const u64 o = newk[j];
-            rank += (o < mine) || (o == mine && j < tid);
-          }
-          sorted[rank] = mine;
-          atomicAdd(&sh[3], 1);
-        }
-      }
-      __syncthreads();
-      const int nnew = sh[3];
-      if (nnew == 0) continue;
-      // 5. in-place parallel merge of sorted[0..nnew) into queue[0..L): read phase, barrier, write phase
-      u64 oldv[16];
-      int oldp[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {  // L <= 4096 = 16 * 256; constant trip count keeps oldv/oldp in registers
-        const int p = tid + i * 256;
-        oldp[i] = L;
-        oldv[i] = KEY_EMPTY;
-        if (p < L) {
-          const u64 v = queue[p];
-          int lo = 0, hi = nnew;  // number of new keys ordered before v
-          while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if ((sorted[mid] >> 1) < (v >> 1)) lo = mid + 1; else hi = mid;
-          }
-          oldv[i] = v;
-          oldp[i] = p + lo;
-        }
-      }
-      u64 nv = KEY_EMPTY;
-      int np = L;
-      if (tid < nnew) {
-        nv = sorted[tid];
-        int lo = 0, hi = L;  // number of old keys ordered before nv
-        while (lo < hi) {
-          const int mid = (lo + hi) >> 1;
-          if ((queue[mid] >> 1) < (nv >> 1)) lo = mid + 1; else hi = mid;
-        }
-        np = tid + lo;
-        if (tid == 0) sh[4] = np;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < 16; ++i)
-        if (oldp[i] < L) queue[oldp[i]] = oldv[i];
-      if (np < L) queue[np] = nv;
-      __syncthreads();
-      if (tid == 0 && sh[4] < sh[2]) sh[2] = sh[4];
-      __syncthreads();
-    }
-    // first possibly-unchecked position: everything before the old k was checked and stays so unless a
-    // new candidate landed there (handled via r_min above)
-    __syncthreads();
-  }
-  for (int i = tid; i < L; i += 256) a.out_queue[q * L + i] = queue[i];
-  if (tid == 0) {
-    atomicAdd(&a.counters[0], evals);
-    atomicAdd(&a.counters[1], expansions);
   }
 }
 
@@ -453,13 +196,18 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
 
   const bool vec4 = (ix.dim_ % 4 == 0) && ((reinterpret_cast<uintptr_t>(ix.d_rows_) & 15) == 0);
   const int qstride = ((int)ix.dim_ + 3) & ~3;
-  const size_t shm = (size_t)qstride * 4 + (size_t)Lp2 * 8 + TRV_CHUNK * 8 * 2 + TRV_CHUNK * 4 + 64 * 4;
+  (void)qstride;
+  const size_t shm = traverse_lds_bytes((int)ix.dim_, Lp2, false);
   TraverseArgs a;
   a.rows = ix.d_rows_;
   a.dim = (int)ix.dim_;
   a.metric = ix.metric_;
   a.off = g.off.as<int64_t>();
   a.nbr = g.nbr.as<u32>();
+  a.fixed_deg = 0;
+  a.log = nullptr;
+  a.log_cnt = nullptr;
+  a.log_cap = 0;
   a.init_ids = g.init_ids.as<u32>();
   a.L = (int)L;
   a.Lp2 = Lp2;
@@ -475,9 +223,9 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
     a.queries = dq + q0 * ix.dim_;
     a.out_queue = g.queue.as<u64>() + q0 * L;
     if (vec4)
-      hipLaunchKernelGGL((traverse_kernel<true>), dim3((unsigned)cnt), dim3(256), shm, s, a);
+      hipLaunchKernelGGL((traverse_kernel<true, false, false>), dim3((unsigned)cnt), dim3(256), shm, s, a);
     else
-      hipLaunchKernelGGL((traverse_kernel<false>), dim3((unsigned)cnt), dim3(256), shm, s, a);
+      hipLaunchKernelGGL((traverse_kernel<false, false, false>), dim3((unsigned)cnt), dim3(256), shm, s, a);
     ix.stats_.main_kernel_launches += 1;
   }
   (void)hipEventRecord(ix.evk1_, s);
