@@ -16,6 +16,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(HERE, "libepsilla_oracle.so")
 REF_SO = os.path.join(HERE, "_ref", "libepsilla_ref.so")
+DROPIN_SO = os.path.join(os.path.dirname(HERE), "dropin", "_build", "libepsilla_dropin.so")
 
 i64 = C.c_int64
 fptr = C.POINTER(C.c_float)
@@ -231,11 +232,35 @@ def ref_available():
     return os.path.exists(REF_SO)
 
 
+def dropin_available():
+    return os.path.exists(DROPIN_SO)
+
+
+def build_dropin():
+    subprocess.check_call(["make", "-s", "-C", os.path.dirname(DROPIN_SO).rsplit("/_build", 1)[0], "-j8"])
+
+
 class Ref:
     """The reference itself (compiled verbatim). See oracle/ref_driver.cpp."""
 
     def __init__(self, path=REF_SO):
-        L = self.L = C.CDLL(path)
+        """path may also be dropin/_build/libepsilla_dropin.so (the reference's DBMS layers over the gfx950
+        executor): that build exports only the DBServer-level entry points, so missing low-level symbols are skipped."""
+        real = C.CDLL(path)
+
+        class _Tolerant:
+            def __getattr__(self_inner, name):
+                try:
+                    return getattr(real, name)
+                except AttributeError:
+                    class _Missing:  # accepts restype/argtypes assignments, fails only when called
+                        def __call__(self_m, *a, **k):
+                            raise AttributeError("%s is not exported by %s" % (name, path))
+                    m = _Missing()
+                    object.__setattr__(self_inner, name, m)
+                    return m
+
+        L = self.L = _Tolerant()
         vp = C.c_void_p
         L.ref_fvec_L2sqr.restype = C.c_float
         L.ref_fvec_L2sqr.argtypes = [fptr, fptr, i64]

@@ -13,6 +13,8 @@
 
 #include <atomic>
 #include <chrono>
+#include <cstdio>
+#include <stdexcept>
 #include <cstdint>
 #include <cstring>
 #include <memory>
@@ -24,18 +26,21 @@
 #include "db/ann_graph_segment.hpp"
 #include "db/db_server.hpp"
 #include "db/execution/vec_search_executor.hpp"
-#include "db/index/distances.hpp"
 #include "db/index/index.hpp"
+#include "db/vector.hpp"
+#ifndef EPS_DROPIN  // the drop-in build (dropin/Makefile) has no reference-internal executor/index code to expose
+#include "db/index/distances.hpp"
 #include "db/index/knn/knn.hpp"
 #include "db/index/nsg/nsg.hpp"
-#include "db/vector.hpp"
 
 namespace vectordb { namespace engine { namespace index { extern unsigned int seed; } } }  // nsg.cpp:19
+#endif
 
 using vectordb::engine::ANNGraphSegment;
 using vectordb::engine::execution::VecSearchExecutor;
 namespace meta = vectordb::engine::meta;
 
+#ifndef EPS_DROPIN
 namespace {
 meta::MetricType ToMetric(int m) {
   // 0 = EUCLIDEAN, 1 = COSINE, 2 = DOT_PRODUCT  (same numbering as include/epsilla_gfx950.h)
@@ -211,6 +216,11 @@ double ref_executor_search_many(void* h, float* queries, int64_t nq, int64_t K, 
 uint64_t ref_dist_calls_reset() { return g_dist_calls.exchange(0); }
 void ref_executor_free(void* h) { delete static_cast<RefExecutor*>(h); }
 
+#endif  // !EPS_DROPIN
+#ifdef EPS_DROPIN
+extern "C" {
+#endif
+
 // ---------------------------------------------------------------- DBServer (JSON level)
 void ref_config(int intra_query_threads, int search_queue_size, int rebuild_threads, int prefilter, int executors) {
   auto& c = vectordb::globalConfig;
@@ -248,7 +258,14 @@ int ref_db_delete(void* h, const char* db, const char* table, const char* pk_jso
   if (!j.LoadFromString(pk_json)) return -1;
   return static_cast<vectordb::engine::DBServer*>(h)->Delete(db, table, j, filter).code();
 }
-int ref_db_rebuild(void* h) { return static_cast<vectordb::engine::DBServer*>(h)->Rebuild().code(); }
+int ref_db_rebuild(void* h) {
+  try {
+    return static_cast<vectordb::engine::DBServer*>(h)->Rebuild().code();
+  } catch (const std::exception& e) {
+    fprintf(stderr, "Rebuild failed: %s\n", e.what());
+    return vectordb::INFRA_UNEXPECTED_ERROR;
+  }
+}
 int ref_db_swap_executors(void* h) { return static_cast<vectordb::engine::DBServer*>(h)->SwapExecutors().code(); }
 // fields_csv: comma separated response fields.  Result JSON is written into out (NUL terminated,
 // truncated to cap).  Returns the Status code.
@@ -268,9 +285,16 @@ int ref_db_search(void* h, const char* db, const char* table, const char* field,
   if (!cur.empty()) fields.push_back(cur);
   vectordb::Json result, facets_cfg, facets;
   facets_cfg.LoadFromString("[]");
-  auto st = static_cast<vectordb::engine::DBServer*>(h)->Search(db, table, f, fields, d, q, limit, result, filter,
-                                                                 with_distance != 0, facets_cfg, facets);
-  std::string s = st.ok() ? result.DumpToString() : st.message();
+  vectordb::Status st;
+  std::string s;
+  try {
+    st = static_cast<vectordb::engine::DBServer*>(h)->Search(db, table, f, fields, d, q, limit, result, filter,
+                                                             with_distance != 0, facets_cfg, facets);
+    s = st.ok() ? result.DumpToString() : st.message();
+  } catch (const std::exception& e) {  // the gfx950 executor throws on infrastructure failures (no device)
+    st = vectordb::Status(vectordb::INFRA_UNEXPECTED_ERROR, e.what());
+    s = e.what();
+  }
   if (cap > 0) {
     size_t n = std::min<size_t>(s.size(), (size_t)cap - 1);
     memcpy(out, s.data(), n);

@@ -1,0 +1,170 @@
+"""The drop-in boundary, end to end: the REFERENCE's own DBServer / DBMVP / TableMVP / TableSegmentMVP / filter
+engine / WAL (compiled unmodified from /root/reference by dropin/Makefile) running on THIS repository's
+ANNGraphSegment + VecSearchExecutor + GetDistFunc (include/db/**, dropin/*.cpp -> libepsilla_gfx950.so).
+GPU tests replay the reference's own known-answer gtest cases (engine/test/engine/db/db_server.cpp) through it."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import data
+from oracle.pyoracle import DROPIN_SO, Ref, dropin_available, ref_available
+
+CITY_SCHEMA = {
+    "name": "MyTable",
+    "fields": [
+        {"name": "ID", "dataType": "INT", "primaryKey": True},
+        {"name": "Doc", "dataType": "STRING"},
+        {"name": "EmbeddingEuclidean", "dataType": "VECTOR_FLOAT", "dimensions": 4, "metricType": "EUCLIDEAN"},
+        {"name": "EmbeddingDotProduct", "dataType": "VECTOR_FLOAT", "dimensions": 4, "metricType": "DOT_PRODUCT"},
+        {"name": "EmbeddingCosine", "dataType": "VECTOR_FLOAT", "dimensions": 4, "metricType": "COSINE"},
+    ],
+}
+CITIES = [(1, "Berlin", [0.05, 0.61, 0.76, 0.74]), (2, "London", [0.19, 0.81, 0.75, 0.11]),
+          (3, "Moscow", [0.36, 0.55, 0.47, 0.94]), (4, "San Francisco", [0.18, 0.01, 0.85, 0.80]),
+          (5, "Shanghai", [0.24, 0.18, 0.22, 0.44])]
+Q4 = np.array([0.35, 0.55, 0.47, 0.94], np.float32)
+
+
+def city_records():
+    return [{"ID": i, "Doc": c, "EmbeddingEuclidean": v, "EmbeddingDotProduct": v, "EmbeddingCosine": v} for i, c, v in CITIES]
+
+
+@pytest.fixture(scope="module")
+def dropin():
+    if os.path.isdir("/root/reference/engine"):
+        from vectordb_amd.build import build
+        from oracle.pyoracle import build_dropin
+        build()
+        build_dropin()
+    if not dropin_available():
+        pytest.skip("dropin/_build/libepsilla_dropin.so not built (needs /root/reference; `make -C dropin`)")
+    return Ref(DROPIN_SO)
+
+
+def test_reference_dbms_compiles_and_links_against_dropin_headers(dropin):
+    """CPU: the unmodified reference DBMS layers build against include/db/** and link to libepsilla_gfx950.so;
+    ingest works; a search without a GPU fails loudly (no CPU fallback) instead of answering."""
+    import tempfile
+    import torch
+    db = dropin.db(os.path.join(tempfile.mkdtemp(), "db"))
+    assert db.create_table(CITY_SCHEMA) == 0
+    assert db.insert("MyTable", city_records()) == 0
+    rc, res = db.search("MyTable", "EmbeddingEuclidean", Q4, 6, fields=("ID", "Doc"))
+    if not torch.cuda.is_available():
+        assert rc == 40001 and "gfx950" in res, (rc, res)   # INFRA_UNEXPECTED_ERROR
+    db.close()
+
+
+@pytest.mark.gpu
+def test_gtest_DenseVector_through_dropin(dropin, tmp_path):
+    """DbServer.DenseVector (db_server.cpp:92-319): three metrics, expected orderings :289-292, before and after
+    Rebuild(); duplicate PK ignored."""
+    db = dropin.db(str(tmp_path / "db"))
+    assert db.create_table(CITY_SCHEMA) == 0
+    recs = city_records()
+    assert db.insert("MyTable", recs + [recs[0]]) == 0          # re-inserting PK 1 must be ignored (:308)
+    want = {"EmbeddingEuclidean": ["Moscow", "Berlin", "Shanghai", "San Francisco", "London"],
+            "EmbeddingDotProduct": ["Moscow", "Berlin", "San Francisco", "London", "Shanghai"],
+            "EmbeddingCosine": ["Moscow", "Shanghai", "Berlin", "San Francisco", "London"]}
+    for rebuild in (False, True):
+        if rebuild:
+            assert db.rebuild() == 0
+        for field, order in want.items():
+            rc, res = db.search("MyTable", field, Q4, 6, fields=("ID", "Doc", field))
+            assert rc == 0, res
+            assert [r["Doc"] for r in res] == order
+    rc, res = db.search("MyTable", "EmbeddingEuclidean", Q4, 1)
+    assert abs(res[0]["@distance"] - 1.0000040e-4) < 1e-8            # SURVEY §8c anchors
+    rc, res = db.search("MyTable", "EmbeddingDotProduct", Q4, 1)
+    assert abs(res[0]["@distance"] + 1.5329999924) < 1e-6
+    db.close()
+
+
+@pytest.mark.gpu
+def test_gtest_DeleteByPK_and_Filter_through_dropin(dropin, tmp_path):
+    """DbServer.DeleteByPK (:514-751) and DbServer.DenseVectorFilter (:1407-1630)."""
+    db = dropin.db(str(tmp_path / "db"))
+    assert db.create_table(CITY_SCHEMA) == 0 and db.insert("MyTable", city_records()) == 0
+    rc, res = db.search("MyTable", "EmbeddingEuclidean", Q4, 6, fields=("ID", "Doc"), flt="ID <= 2")
+    assert rc == 0 and sorted(r["ID"] for r in res) == [1, 2]
+    rc, res = db.search("MyTable", "EmbeddingEuclidean", Q4, 6, fields=("ID", "Doc"), flt="Doc = 'Moscow' OR ID = 5")
+    assert rc == 0 and [r["Doc"] for r in res] == ["Moscow", "Shanghai"]      # host-evaluated filter mask
+    assert db.delete("MyTable", [1, 2, 3, 4]) == 0
+    rc, res = db.search("MyTable", "EmbeddingEuclidean", Q4, 6, fields=("ID", "Doc"))
+    assert [r["Doc"] for r in res] == ["Shanghai"] and abs(res[0]["@distance"] - 0.46149999) < 1e-6
+    db.close()
+
+
+@pytest.mark.gpu
+def test_gtest_QueryDenseVectorDuringRebuild_through_dropin(dropin, tmp_path):
+    """DbServer.QueryDenseVectorDuringRebuild (:1085-1245) at its original size: 10 000 unit vectors
+    (cos(pi i/N), sin(pi i/N)), COSINE, query (1,0), limit 500.  Rebuild on a shuffled half -> the 500 smallest
+    inserted ids in order (:1172-1180); insert the rest (graph 5000 + brute-force tail 5000) -> exactly 0..499
+    (:1195-1199); and again after a second rebuild (:1223-1244)."""
+    dropin.L.ref_config(4, 500, 1, 0, 4)
+    db = dropin.db(str(tmp_path / "db"), scale=150000)
+    schema = {"name": "T", "fields": [{"name": "ID", "dataType": "INT", "primaryKey": True},
+                                       {"name": "V", "dataType": "VECTOR_FLOAT", "dimensions": 2, "metricType": "COSINE"}]}
+    assert db.create_table(schema) == 0
+    N = 10000
+    recs = [{"ID": i, "V": [float(np.cos(np.pi * i / N)), float(np.sin(np.pi * i / N))]} for i in range(N)]
+    order = np.random.default_rng(0).permutation(N)
+    first, second = sorted(order[:N // 2].tolist()), sorted(order[N // 2:].tolist())
+    q = np.array([1.0, 0.0], np.float32)
+    assert db.insert("T", [recs[i] for i in order[:N // 2]]) == 0
+    assert db.rebuild() == 0
+    rc, res = db.search("T", "V", q, 500)
+    assert rc == 0 and [r["ID"] for r in res] == first[:500]
+    assert db.insert("T", [recs[i] for i in order[N // 2:]]) == 0
+    rc, res = db.search("T", "V", q, 500)
+    assert rc == 0 and [r["ID"] for r in res] == list(range(500))
+    assert db.rebuild() == 0
+    rc, res = db.search("T", "V", q, 500)
+    assert rc == 0 and [r["ID"] for r in res] == list(range(500))
+    db.close()
+    dropin.L.ref_config(4, 500, 1, 0, 16)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not ref_available(), reason="needs oracle/_ref")
+def test_dropin_matches_reference_dbserver_on_random_data(dropin, tmp_path):
+    """Same JSON in, same JSON out: the reference DBServer on its own CPU executor vs. on the gfx950 executor
+    (flat, graph + tail, int filter, string filter, deletes). Graphs differ (both builds are valid NSGs), results are
+    compared where both are exact (n small enough that the reference search has recall 1)."""
+    ref = Ref()
+    schema = {"name": "T", "fields": [{"name": "ID", "dataType": "INT", "primaryKey": True},
+                                       {"name": "Tag", "dataType": "STRING"},
+                                       {"name": "V", "dataType": "VECTOR_FLOAT", "dimensions": 16, "metricType": "EUCLIDEAN"}]}
+    X = data(1800, 16, 21)
+    recs = [{"ID": int(i), "Tag": "t%d" % (i % 7), "V": [float(x) for x in X[i]]} for i in range(1800)]
+    dbs = []
+    for lib, name in ((ref, "ref"), (dropin, "drop")):
+        lib.L.ref_config(1, 500, 1, 0, 2)
+        db = lib.db(str(tmp_path / name))
+        assert db.create_table(schema) == 0 and db.insert("T", recs[:1200]) == 0
+        dbs.append(db)
+    Q = data(6, 16, 22)
+
+    def both(limit, flt=""):
+        for q in Q:
+            a = dbs[0].search("T", "V", q, limit, fields=("ID", "Tag"), flt=flt)
+            b = dbs[1].search("T", "V", q, limit, fields=("ID", "Tag"), flt=flt)
+            assert a[0] == 0 and b[0] == 0, (a, b)
+            assert [r["ID"] for r in a[1]] == [r["ID"] for r in b[1]], flt
+            assert np.allclose([r["@distance"] for r in a[1]], [r["@distance"] for r in b[1]], rtol=1e-4)
+
+    both(10)                          # no graph yet: BruteForceSearch on both sides
+    both(10, "ID < 300")
+    for db in dbs:
+        assert db.rebuild() == 0 and db.insert("T", recs[1200:]) == 0
+    both(10)                          # graph over 1200 rows + brute-force tail of 600
+    both(50, "ID >= 900")
+    both(10, "Tag = 't3'")
+    for db in dbs:
+        assert db.delete("T", list(range(0, 1800, 5))) == 0
+    both(10)
+    for db in dbs:
+        db.close()
+    ref.L.ref_config(4, 500, 1, 0, 16)
+    dropin.L.ref_config(4, 500, 1, 0, 16)
