@@ -13,6 +13,11 @@ import subprocess
 
 import numpy as np
 
+try:  # when torch shares the process its bundled HIP runtime must load before ours (libepsilla_dropin links it)
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(HERE, "libepsilla_oracle.so")
 REF_SO = os.path.join(HERE, "_ref", "libepsilla_ref.so")

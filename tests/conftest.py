@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:  # torch bundles its own HIP runtime; it must be the first one loaded in a process that also loads ours
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
