@@ -1,0 +1,146 @@
+#!/usr/bin/env python
+"""Secondary measurements for the BASELINE.json configs other than the headline one (bench.py):
+C1 100k x 128 sequential single queries, C2 1M x 768 batch=1 latency (flat vs graph), C4 10M x 768 COSINE + ID filter.
+    python scripts/bench_configs.py [c1] [c2] [c4]   -> JSON lines"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import vectordb_amd as amd  # noqa: E402
+
+
+def gen(n, d, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    X = torch.empty((n, d), device="cuda")
+    for s in range(0, n, 1 << 20):
+        e = min(n, s + (1 << 20))
+        X[s:e] = torch.rand((e - s, d), generator=g, device="cuda")
+    return X
+
+
+def outs(nq, k):
+    return (torch.empty((nq, k), dtype=torch.int64, device="cuda"), torch.empty((nq, k), dtype=torch.float32, device="cuda"),
+            torch.empty((nq,), dtype=torch.int32, device="cuda"))
+
+
+def recall(a, b):
+    return float(np.mean([len(set(x) & set(y)) / float(len(y)) for x, y in zip(a, b)]))
+
+
+def c1():
+    n, d, nq, k = 100_000, 128, 1000, 10
+    rng = np.random.default_rng(42)
+    X, Q = rng.random((n, d), dtype=np.float32), np.random.default_rng(43).random((nq, d), dtype=np.float32)
+    ix = amd.GpuIndex(d, 0)
+    ix.attach_rows(X)
+    ix.search(Q[:1], k, mode=amd.MODE_REFERENCE)
+    t0 = time.perf_counter()
+    lat = []
+    for q in Q:                      # host in / host out per call, as the bindings path does (always BruteForceSearch)
+        t1 = time.perf_counter()
+        ix.search(q[None, :], k, mode=amd.MODE_REFERENCE)
+        lat.append(time.perf_counter() - t1)
+    el = time.perf_counter() - t0
+    print(json.dumps({"config": "C1 100k x 128 L2 k=10, 1000 sequential single queries, host buffers (flat scan)",
+                      "qps": nq / el, "p50_ms": 1e3 * float(np.median(lat)), "p99_ms": 1e3 * float(np.percentile(lat, 99))}))
+
+
+def c2():
+    n, d, k = 1_000_000, 768, 10
+    X = gen(n, d, 42)
+    Q = gen(256, d, 43)
+    ix = amd.GpuIndex(d, 0).use_torch_stream()
+    ix.attach_rows(X)
+    o = outs(1, k)
+    gt = outs(256, k)
+    ix.search(Q, k, out=gt, mode=amd.MODE_FLAT)
+    torch.cuda.synchronize()
+    gti = gt[0].cpu().numpy()
+    # flat, batch = 1
+    lat, kms = [], []
+    for i in range(64):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        ix.search(Q[i:i + 1], k, out=o, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
+        torch.cuda.synchronize()
+        lat.append(time.perf_counter() - t1)
+        kms.append(ix.stats()["main_kernel_ms"])
+    alg = n * d * 4
+    print(json.dumps({"config": "C2 1M x 768 L2 k=10 batch=1, flat stream scan", "p50_ms": 1e3 * float(np.median(lat)),
+                      "p99_ms": 1e3 * float(np.percentile(lat, 99)), "kernel_ms": float(np.median(kms)),
+                      "achieved_GBps": alg / (float(np.median(kms)) * 1e-3) / 1e9, "frac_of_8TBps": alg / (float(np.median(kms)) * 1e-3) / 8e12,
+                      "recall_at_10": 1.0}))
+    # graph
+    t0 = time.perf_counter()
+    ix.build()
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
+    n_, e_, nav = ix.graph_info()
+    print(json.dumps({"config": "C2 graph build 1M x 768 (kNN K=100 on MFMA + NSG)", "build_s": build_s, "avg_degree": e_ / n_}))
+    for T in (1, 4, 16):
+        for L in (500, 2000):
+            lat, ids = [], []
+            ev = 0
+            for i in range(64):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                ix.search(Q[i:i + 1], k, out=o, mode=amd.MODE_GRAPH, intra_threads=T, master_queue=L, local_queue=L)
+                torch.cuda.synchronize()
+                lat.append(time.perf_counter() - t1)
+                ids.append(o[0][0].cpu().numpy().copy())
+                ev += ix.stats()["dist_evals"]
+            print(json.dumps({"config": "C2 1M x 768 L2 k=10 batch=1, graph traversal T=%d L=%d" % (T, L),
+                              "p50_ms": 1e3 * float(np.median(lat)), "p99_ms": 1e3 * float(np.percentile(lat, 99)),
+                              "recall_at_10": recall(ids, gti[:64]), "evals_per_query": ev / 64.0}))
+    # graph, batch = 256 throughput
+    ob = outs(256, k)
+    for T, L in ((1, 500), (4, 500), (4, 2000)):
+        ix.search(Q, k, out=ob, mode=amd.MODE_GRAPH, intra_threads=T, master_queue=L, local_queue=L)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            ix.search(Q, k, out=ob, mode=amd.MODE_GRAPH, intra_threads=T, master_queue=L, local_queue=L)
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t1) / 3
+        st = ix.stats()
+        byt = st["dist_evals"] * (4 * d + 4) + st["expansions"] * (8 + 4 * 44)
+        print(json.dumps({"config": "C2 1M x 768 graph traversal batch=256 T=%d L=%d" % (T, L), "qps": 256 / el,
+                          "recall_at_10": recall(ob[0].cpu().numpy(), gti), "evals_per_query": st["dist_evals"] / 256.0,
+                          "kernel_ms": st["main_kernel_ms"], "achieved_GBps": byt / (st["main_kernel_ms"] * 1e-3) / 1e9}))
+
+
+def c4():
+    n, d, k, b = 10_000_000, 768, 10, 1024
+    X = gen(n, d, 42)
+    amd.normalize_rows(X, only_if_nonzero=True, stream=None)          # COSINE rows are normalised at insert
+    Q = gen(b, d, 43)
+    amd.normalize_rows(Q, only_if_nonzero=False)
+    idc = torch.arange(n, dtype=torch.int32, device="cuda")
+    ix = amd.GpuIndex(d, "COSINE").use_torch_stream()
+    ix.attach_rows(X)
+    o = outs(b, k)
+    for sel in (0.5, 0.1, 0.9):
+        ix.set_int_filter(idc, "<", int(n * sel))
+        ix.search(Q, k, out=o, mode=amd.MODE_FLAT)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            ix.search(Q, k, out=o, mode=amd.MODE_FLAT)
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t1) / 3
+        st = ix.stats()
+        ok = bool((o[0] < int(n * sel)).all().item() and (o[2] == k).all().item())
+        print(json.dumps({"config": "C4 10M x 768 COSINE + filter ID < %d (%.0f%%), k=10, batch=1024, exact filtered top-k" % (int(n * sel), sel * 100),
+                          "qps": b / el, "ms_per_batch": 1e3 * el, "rerank_rows_per_query": st["rerank_rows"] / b,
+                          "overflow_queries": st["overflow_queries"], "all_results_pass_filter": ok}))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["c1", "c2", "c4"]
+    for w in which:
+        {"c1": c1, "c2": c2, "c4": c4}[w]()
