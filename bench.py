@@ -21,6 +21,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# HBM bytes per launch of the dominant kernel from the PMC counters of profiles/r1_pmc_10Mx768_b1024.csv, collected
+# in separate --pmc passes and corrected as MI355X_MICROARCH.md prescribes (gfx950 FETCH_SIZE counts 128-B requests at
+# 64 B: x2; FETCH_SIZE/WRITE_SIZE are in KiB): (2 * 6741727 + 7201) KiB for the 8.95M-row launch = 13.81e9 bytes,
+# against 13.75e9 algorithmic bytes of the fp16 mirror (each row tile is fetched from HBM once).
+TRAFFIC = {"mfma": (2 * 6741727 + 7201) * 1024.0}
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F16_PEAK_TF = 2500.0  # dense bf16/f16 MFMA peak
 
@@ -176,7 +181,7 @@ def main():
         out_d, out_i = step(queries[args.warmup + s])
         st = ix.stats()  # reads the hipEvent pair the library recorded around its dominant kernel on this stream
         main_ms.append(st["main_kernel_ms"])
-        launches.append(st["main_kernel_launches"])
+        launches.append(st["main_kernel_rows"])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -206,17 +211,19 @@ def main():
 
     if rank == 0:
         qps = b * args.steps / elapsed
-        kernel_ms = float(np.mean(main_ms)) if main_ms else 0.0
-        per_launch_ms = kernel_ms / max(1, int(np.mean(launches))) if launches else 0.0
+        kernel_ms = float(np.mean(main_ms)) if main_ms else 0.0   # hipEvent pair around the dominant launch
+        krows = float(np.mean(launches)) if launches else 0.0     # rows that launch covered
         used_mfma = st.get("rerank_rows", 0) > 0
         if used_mfma:
-            flops = 2.0 * b * n * d
-            roof = {"bound": "mfma", "kernel": "mfma_filter_kernel", "achieved": flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms else None,
-                    "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s", "traffic": None}
+            # algorithmic flops of the timed launch: 2 * batch * rows * d, on the fp16 dense MFMA roof
+            flops = 2.0 * b * krows * d
+            roof = {"bound": "mfma", "kernel": "mfma_filter_kernel_v3 (largest of the 3 filter stages: %d of %d rows)" % (krows, n),
+                    "achieved": flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms else None,
+                    "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s", "traffic": TRAFFIC.get("mfma")}
         else:
-            # a flat scan needs N*4*d bytes ONCE per batch; the stream engine re-reads the store once
+            # a flat scan needs rows*4*d bytes ONCE per batch; the stream engine re-reads the store once
             # per group of 4 queries, which this figure deliberately does not credit.
-            alg_bytes = float(n) * 4 * d
+            alg_bytes = krows * 4 * d
             roof = {"bound": "hbm", "kernel": "flat_scan_kernel", "achieved": alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms else None,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
         roof["frac"] = (roof["achieved"] / roof["peak"]) if roof["achieved"] else None

@@ -112,6 +112,7 @@ typedef struct eps_search_stats {
   double kernel_ms;         /* device time of the call measured with hipEvents on its stream */
   double main_kernel_ms;    /* device time of the dominant kernel only                      */
   int64_t main_kernel_launches;
+  int64_t main_kernel_rows; /* rows covered by the launch timed in main_kernel_ms              */
 } eps_search_stats;
 
 void eps_default_search_params(eps_search_params* p);

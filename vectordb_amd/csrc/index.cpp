@@ -345,6 +345,7 @@ int32_t Index::flat_stream(const float* dq, int64_t nq, int k, int64_t row_begin
   launch_merge_lists(a.partial, W * k, k, nq, run_keys, merge_run, stream_);
   HIP_TRY(hipGetLastError());
   stats_.main_kernel_launches += 1;
+  stats_.main_kernel_rows = row_end - row_begin;
   stats_.dist_evals += nq * (row_end - row_begin);
   return EPS_OK;
 }

@@ -37,7 +37,9 @@ namespace eps {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BM = 128, BN = 128, BK = 64;   // v1 tile
+constexpr int BM2 = 256;                      // v2 row tile (256 rows x 128 queries, 8 wavefronts)
+constexpr int ROWPAD = 256;                   // mirror rows are padded to this
 
 struct HalfMirror {
   DevBuf xh;       // _Float16 [n_pad][d_pad]
@@ -186,6 +188,7 @@ struct FilterArgs {
   int metric;
   u32* cnt;
   int cap;
+  int ablate;           // profiling only (EPS_MFMA_ABLATE): bit0 skip staging loads, bit1 skip MFMAs, bit2 skip LDS fragment reads
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (row << 3) + (chunk ^ ((row >> 1) & 7)); }  // 16-B granule index
@@ -251,26 +254,45 @@ __global__ __launch_bounds__(256, 2) void mfma_filter_kernel(FilterArgs a) {
   const int brow0 = wn * 64 + (lane & 31);
   const int khalf = lane >> 5;
 
-  stage(0, 0);
+  const bool ab_noload = a.ablate & 1, ab_nomfma = a.ablate & 2, ab_nolds = a.ablate & 4;
+  if (!ab_noload) stage(0, 0);
   for (int kt = 0; kt < KT; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (kt + 1 < KT) stage(kt + 1, (kt + 1) & 1);
+    if (kt + 1 < KT && !ab_noload) stage(kt + 1, (kt + 1) & 1);
     const unsigned char* sA = lds + (kt & 1) * 32768;
     const unsigned char* sB = sA + 16384;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int chunk = kk * 2 + khalf;
       half8 fa[2], fb[2];
+      if (!ab_nolds) {
 #pragma unroll
-      for (int f = 0; f < 2; ++f) {
-        fa[f] = *reinterpret_cast<const half8*>(sA + swz(arow0 + f * 32, chunk) * 16);
-        fb[f] = *reinterpret_cast<const half8*>(sB + swz(brow0 + f * 32, chunk) * 16);
+        for (int f = 0; f < 2; ++f) {
+          fa[f] = *reinterpret_cast<const half8*>(sA + swz(arow0 + f * 32, chunk) * 16);
+          fb[f] = *reinterpret_cast<const half8*>(sB + swz(brow0 + f * 32, chunk) * 16);
+        }
+      } else {
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            fa[f][e] = (_Float16)(float)(kk + e);
+            fb[f][e] = (_Float16)(float)(lane + e);
+          }
       }
+      if (!ab_nomfma) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          asm volatile("" ::"v"(fa[f]));
+          asm volatile("" ::"v"(fb[f]));
+        }
+      }
     }
   }
 
@@ -324,6 +346,367 @@ __global__ __launch_bounds__(256, 2) void mfma_filter_kernel(FilterArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------ v2 kernel
+// 256 rows x 128 queries per workgroup, 8 wavefronts (4 x 2) x 64x64 outputs, K-step 64, THREE LDS slots of 48 KB:
+// two K-tiles are always in flight (counted s_waitcnt vmcnt(6), raw s_barrier — a __syncthreads() would drain the
+// LDS-DMA queue to zero), so twice the bytes are outstanding per CU compared with v1 while the row tile is twice as
+// tall (170 flop per L2 byte instead of 128).
+__global__ __launch_bounds__(512, 2) void mfma_filter_kernel_v2(FilterArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int SLOT = 49152;  // A 256x128 B + B 128x128 B
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int64_t bid = blockIdx.x;
+  const int xcd = (int)(bid & 7);
+  const int64_t local = bid >> 3;
+  const int qt = (int)(local % a.tiles_q);
+  const int64_t rt = (local / a.tiles_q) * 8 + xcd;
+  if (rt >= a.ntiles) return;
+  const int64_t row0 = (a.tile0 + rt) * BM2;
+  const int64_t q0 = (int64_t)qt * BN;
+  const int ldk = a.d_pad;
+  const int KT = ldk / BK;
+
+  float* base_lds = reinterpret_cast<float*>(lds + 3 * SLOT);
+  if (tid < BM2) base_lds[tid] = a.base[row0 + tid];
+
+  const _Float16* gA = a.xh + row0 * ldk;
+  const _Float16* gB = a.qh + q0 * ldk;
+  // staging: A = 2048 granules (4 per thread), B = 1024 granules (2 per thread)
+  int a_row[4], a_chunk[4], b_row[2], b_chunk[2];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int s = it * 512 + tid;
+    a_row[it] = s >> 3;
+    a_chunk[it] = (s & 7) ^ ((a_row[it] >> 1) & 7);
+  }
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int s = it * 512 + tid;
+    b_row[it] = s >> 3;
+    b_chunk[it] = (s & 7) ^ ((b_row[it] >> 1) & 7);
+  }
+  auto stage = [&](int kt, int slot) {
+    unsigned char* dA = lds + slot * SLOT;
+    unsigned char* dB = dA + 32768;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const _Float16* sa = gA + (int64_t)a_row[it] * ldk + kt * BK + a_chunk[it] * 8;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sa,
+                                       (__attribute__((address_space(3))) void*)(dA + (it * 512 + wave * 64) * 16), 16, 0, 0);
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const _Float16* sb = gB + (int64_t)b_row[it] * ldk + kt * BK + b_chunk[it] * 8;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sb,
+                                       (__attribute__((address_space(3))) void*)(dB + (it * 512 + wave * 64) * 16), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int arow0 = wm * 64 + (lane & 31);
+  const int brow0 = wn * 64 + (lane & 31);
+  const int khalf = lane >> 5;
+
+  stage(0, 0);
+  if (KT > 1) stage(1, 1);
+  int slot = 0;
+  for (int kt = 0; kt < KT; ++kt) {
+    // tile kt has landed once at most the 6 loads of tile kt+1 are still outstanding
+    if (kt + 1 < KT)
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + 2 < KT) {
+      int ns = slot + 2;
+      if (ns >= 3) ns -= 3;
+      stage(kt + 2, ns);  // slot (kt+2)%3 == (kt-1)%3: every wave finished reading it before this barrier
+    }
+    const unsigned char* sA = lds + slot * SLOT;
+    const unsigned char* sB = sA + 32768;
+    // software pipeline over the four K=16 sub-steps: the fragments of sub-step kk+1 are read from LDS while the
+    // MFMAs of sub-step kk run (one wave per SIMD per block: nothing else hides the ds_read latency)
+    half8 fa[2][2], fb[2][2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      fa[0][f] = *reinterpret_cast<const half8*>(sA + swz(arow0 + f * 32, khalf) * 16);
+      fb[0][f] = *reinterpret_cast<const half8*>(sB + swz(brow0 + f * 32, khalf) * 16);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int cur = kk & 1, nxt = cur ^ 1;
+      if (kk < 3) {
+        const int chunk = (kk + 1) * 2 + khalf;
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          fa[nxt][f] = *reinterpret_cast<const half8*>(sA + swz(arow0 + f * 32, chunk) * 16);
+          fb[nxt][f] = *reinterpret_cast<const half8*>(sB + swz(brow0 + f * 32, chunk) * 16);
+        }
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    slot = slot + 1 == 3 ? 0 : slot + 1;
+  }
+
+  float Tj[2], cj[2];
+  int64_t qj[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    qj[j] = q0 + wn * 64 + j * 32 + (lane & 31);
+    Tj[j] = a.T[qj[j]];
+    cj[j] = a.cand_keys ? (a.metric == 0 ? a.qstat[qj[j] * 4] : (a.metric == 1 ? 1.f : 0.f)) : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int rbase = wm * 64 + i * 32 + 4 * khalf;
+    float4 bv[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bv[g] = *reinterpret_cast<const float4*>(&base_lds[rbase + 8 * g]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bool any = false;
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float b = (r & 3) == 0 ? bv[r >> 2].x : (r & 3) == 1 ? bv[r >> 2].y : (r & 3) == 2 ? bv[r >> 2].z : bv[r >> 2].w;
+        v[r] = fmaf(acc[i][j][r], a.s, b);
+        any |= (v[r] <= Tj[j]);
+      }
+      if (__any(any)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (v[r] <= Tj[j]) {
+            const int64_t row = row0 + rbase + (r & 3) + 8 * (r >> 2);
+            if (row < a.row_hi && qj[j] < a.nq) {
+              const u32 slot_c = atomicAdd(&a.cnt[qj[j]], 1u);
+              if (slot_c < (u32)a.cap) {
+                if (a.cand_keys) {
+                  float dapx = v[r] + cj[j];
+                  if (a.metric == 0) dapx = fmaxf(dapx, 0.f);
+                  a.cand_keys[qj[j] * (int64_t)a.cap + slot_c] = make_key(dapx, (u32)row);
+                } else {
+                  a.cand[qj[j] * (int64_t)a.cap + slot_c] = (u32)row;
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------ v3 kernel
+// Persistent form.  Ablation of v1 (profiles/r1_mfma_ablation.txt) showed the filter was bound by per-workgroup
+// latency, not by the matrix cores: a workgroup that lives for one 128x128 tile pays its launch + first-load latency
+// (~6 us) for 12 K-steps of work, and each K-step exposes one L2->LDS round trip.  v3 launches ONE workgroup per CU
+// (8 wavefronts, 2 x 4, each 128 rows x 64 queries = 4 x 2 tiles of v_mfma_f32_32x32x16_f16) that walks a list of
+// 256 x 256 tiles; the (tile, K-step) sequence is one software pipeline — the loads of step s+1 (possibly the next
+// tile's first K-step, plus its |x|^2 column) are issued right after the barrier of step s and land under the 32
+// MFMAs per wavefront of step s; the epilogue of a tile runs under the first loads of the next.  256 flop per L2
+// byte (v1: 128).  Tile order keeps the query tiles of one row tile on one XCD at the same time.
+constexpr int BM3 = 256, BN3 = 256;
+__global__ __launch_bounds__(512, 2) void mfma_filter_kernel_v3(FilterArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int SLOT = 65536;  // A 256 x 128 B | B 256 x 128 B
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int khalf = lane >> 5;
+  float* base_lds = reinterpret_cast<float*>(lds + 2 * SLOT);  // [2][256]
+
+  // work list of this workgroup
+  const int xcd = blockIdx.x & 7;
+  const int local = blockIdx.x >> 3;              // 0 .. gridDim/8-1 workgroups on this XCD
+  const int per_xcd = gridDim.x >> 3;
+  const int QTB = a.tiles_q < per_xcd ? a.tiles_q : per_xcd;
+  const int G = per_xcd / QTB;                    // row tiles in flight per XCD
+  const int qslot = local % QTB;
+  const int rg = local / QTB;
+  if (rg >= G) return;
+  // row tiles of this XCD: rt = xcd + 8*j; this workgroup takes j = rg, rg+G, ...; query tiles qt = qslot, qslot+QTB, ...
+  const int64_t nj = (a.ntiles - xcd + 7) / 8;    // row tiles on this XCD (may be <= 0)
+  const int nqt = (a.tiles_q - qslot + QTB - 1) / QTB;
+  const int64_t my_rows = nj > rg ? (nj - rg + G - 1) / G : 0;
+  const int64_t ntile = my_rows * nqt;
+  if (ntile <= 0) return;
+  const int ldk = a.d_pad;
+  const int KT = ldk / BK;
+
+  int g_off[4];  // element offset of this thread's granule `it` inside a K-step of a 256-row operand tile
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int s = it * 512 + tid;
+    const int row = s >> 3;
+    g_off[it] = row * ldk + ((s & 7) ^ ((row >> 1) & 7)) * 8;
+  }
+  auto tile_rt = [&](int64_t t) { return (int64_t)xcd + 8 * (rg + (t / nqt) * G); };
+  auto tile_qt = [&](int64_t t) { return qslot + (int)(t % nqt) * QTB; };
+  // operand bases of the tile being computed and of the tile whose first K-step is prefetched (one division per tile)
+  const _Float16 *gA_cur, *gB_cur, *gA_nx, *gB_nx;
+  const float* gbase_nx;
+  auto set_next = [&](int64_t t) {
+    const int64_t rt = tile_rt(t);
+    gA_nx = a.xh + (a.tile0 + rt) * BM3 * (int64_t)ldk;
+    gB_nx = a.qh + (int64_t)tile_qt(t) * BN3 * ldk;
+    gbase_nx = a.base + (a.tile0 + rt) * BM3;
+  };
+  // one quarter of a K-step's staging: piece `it` of A and of B
+  auto stage_piece = [&](const _Float16* gA, const _Float16* gB, int kt, int slot, int it) {
+    unsigned char* dA = lds + slot * SLOT;
+    unsigned char* dB = dA + 32768;
+    const int off = g_off[it] + kt * BK;
+    const int wbase = (it * 512 + wave * 64) * 16;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gA + off),
+                                     (__attribute__((address_space(3))) void*)(dA + wbase), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB + off),
+                                     (__attribute__((address_space(3))) void*)(dB + wbase), 16, 0, 0);
+  };
+  auto stage_base = [&](const float* gb, int64_t t) {  // |x|^2 (or 0) column of the tile's 256 rows, wavefronts 0-3
+    if (wave < 4)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + wave * 64 + lane),
+                                       (__attribute__((address_space(3))) void*)(base_lds + (t & 1) * 256 + wave * 64), 4, 0, 0);
+  };
+
+  f32x16 acc[4][2];
+  const int arow0 = wm * 128 + (lane & 31);
+  const int brow0 = wn * 64 + (lane & 31);
+
+  // thresholds of this workgroup's query tile, loaded before any LDS-DMA is in flight (ordinary loads make the
+  // compiler wait vmcnt(0), which would drain the pipeline if done per tile)
+  float Tj[2], cj[2];
+  int64_t qj[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    qj[j] = (int64_t)qslot * BN3 + wn * 64 + j * 32 + (lane & 31);
+    Tj[j] = a.T[qj[j]];
+    cj[j] = a.cand_keys ? (a.metric == 0 ? a.qstat[qj[j] * 4] : (a.metric == 1 ? 1.f : 0.f)) : 0.f;
+  }
+  set_next(0);
+#pragma unroll
+  for (int it = 0; it < 4; ++it) stage_piece(gA_nx, gB_nx, 0, 0, it);
+  stage_base(gbase_nx, 0);
+  int slot = 0;
+  for (int64_t t = 0; t < ntile; ++t) {
+    gA_cur = gA_nx;
+    gB_cur = gB_nx;
+    const int64_t row0 = (a.tile0 + tile_rt(t)) * BM3;
+    const int64_t q0 = (int64_t)tile_qt(t) * BN3;
+    if (t + 1 < ntile) set_next(t + 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int kt = 0; kt < KT; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      // next step of the (tile, K-step) stream; its staging is spread over the four K=16 sub-steps below so that the
+      // DMA issue cost of one wavefront overlaps the MFMAs of the wavefront sharing its SIMD
+      const bool same = kt + 1 < KT;
+      const bool more = same || (t + 1 < ntile);
+      const _Float16* pA = same ? gA_cur : gA_nx;
+      const _Float16* pB = same ? gB_cur : gB_nx;
+      const int nk_ = same ? kt + 1 : 0;
+      const unsigned char* sA = lds + slot * SLOT;
+      const unsigned char* sB = sA + 32768;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int chunk = kk * 2 + khalf;
+        half8 fa[4], fb[2];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) fa[f] = *reinterpret_cast<const half8*>(sA + swz(arow0 + f * 32, chunk) * 16);
+#pragma unroll
+        for (int f = 0; f < 2; ++f) fb[f] = *reinterpret_cast<const half8*>(sB + swz(brow0 + f * 32, chunk) * 16);
+        if (more) {
+          stage_piece(pA, pB, nk_, slot ^ 1, kk);
+          if (kk == 0 && !same) stage_base(gbase_nx, t + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      slot ^= 1;
+    }
+    // ---- epilogue of tile t (the first K-step of tile t+1 is already in flight)
+    const float* bl = base_lds + (t & 1) * 256;  // landed with K-step 0 of this tile (>= KT barriers ago)
+    if (nqt > 1) {  // the query tile changes between tiles: reload its thresholds (ordinary loads: drains the DMA queue once)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        qj[j] = q0 + wn * 64 + j * 32 + (lane & 31);
+        Tj[j] = a.T[qj[j]];
+        cj[j] = a.cand_keys ? (a.metric == 0 ? a.qstat[qj[j] * 4] : (a.metric == 1 ? 1.f : 0.f)) : 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rbase = wm * 128 + i * 32 + 4 * khalf;
+      float4 bv[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) bv[g] = *reinterpret_cast<const float4*>(&bl[rbase + 8 * g]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        bool any = false;
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float b = (r & 3) == 0 ? bv[r >> 2].x : (r & 3) == 1 ? bv[r >> 2].y : (r & 3) == 2 ? bv[r >> 2].z : bv[r >> 2].w;
+          v[r] = fmaf(acc[i][j][r], a.s, b);
+          any |= (v[r] <= Tj[j]);
+        }
+        if (__any(any)) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            if (v[r] <= Tj[j]) {
+              const int64_t row = row0 + rbase + (r & 3) + 8 * (r >> 2);
+              if (row < a.row_hi && qj[j] < a.nq) {
+                const u32 slot_c = atomicAdd(&a.cnt[qj[j]], 1u);
+                if (slot_c < (u32)a.cap) {
+                  if (a.cand_keys) {
+                    float dapx = v[r] + cj[j];
+                    if (a.metric == 0) dapx = fmaxf(dapx, 0.f);
+                    a.cand_keys[qj[j] * (int64_t)a.cap + slot_c] = make_key(dapx, (u32)row);
+                  } else {
+                    a.cand[qj[j] * (int64_t)a.cap + slot_c] = (u32)row;
+                  }
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
 __global__ void count_overflow_kernel(const u32* cnt, int64_t nq, int cap, u32* overflow) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j < nq && cnt[j] > (u32)cap) atomicAdd(overflow, 1u);
@@ -339,7 +722,7 @@ static int32_t ensure_mirror(Index& ix) {
   HalfMirror& m = *ix.mirror_;
   if (m.version == ix.rows_version_) return EPS_OK;
   const int64_t n = ix.n_rows_;
-  const int64_t n_pad = (n + BM - 1) / BM * BM;
+  const int64_t n_pad = (n + ROWPAD - 1) / ROWPAD * ROWPAD;
   const int d_pad = (int)((ix.dim_ + BK - 1) / BK * BK);
   if (!m.xh.reserve((size_t)n_pad * d_pad * 2) || !m.xn.reserve((size_t)n_pad * 4) || !m.zeros.reserve((size_t)n_pad * 4) ||
       !m.scal.reserve(64))
@@ -380,7 +763,7 @@ int32_t flat_mfma_search(Index& ix, const float* dq, int64_t nq, int k, u64* run
     return ix.flat_stream(dq, nq, k, 0, n, run_keys, false, -1, !approx);
   }
   hipStream_t s = ix.stream_;
-  const int64_t b_pad = (nq + BN - 1) / BN * BN;
+  const int64_t b_pad = (nq + BN3 - 1) / BN3 * BN3;
   const int cap = std::max(4096, 64 * k);
   if (!m.qh.reserve((size_t)b_pad * m.d_pad * 2) || !m.qstat.reserve((size_t)b_pad * 16) || !m.T.reserve((size_t)b_pad * 4) ||
       !m.cand.reserve((size_t)nq * cap * (approx ? 8 : 4)) || !m.cnt.reserve((size_t)(nq + 4) * 4 + 16))
@@ -389,7 +772,7 @@ int32_t flat_mfma_search(Index& ix, const float* dq, int64_t nq, int k, u64* run
                      m.d_pad, m.qh.as<_Float16>(), m.qstat.as<float>());
 
   // stage boundaries (multiples of BM): S0, 32*S0, 256*S0, n
-  int64_t S0 = std::max<int64_t>(4096, (int64_t)(32 * k + BM - 1) / BM * BM);
+  int64_t S0 = std::max<int64_t>(4096, (int64_t)(32 * k + ROWPAD - 1) / ROWPAD * ROWPAD);
   std::vector<int64_t> bounds;
   bounds.push_back(std::min(S0, n));
   for (int64_t bnd : {S0 * 32, S0 * 256}) {
@@ -424,6 +807,7 @@ int32_t flat_mfma_search(Index& ix, const float* dq, int64_t nq, int k, u64* run
   fa.metric = ix.metric_;
   fa.cnt = cnt;
   fa.cap = cap;
+  fa.ablate = getenv("EPS_MFMA_ABLATE") ? atoi(getenv("EPS_MFMA_ABLATE")) : 0;
 
   RerankArgs ra;
   ra.rows = ix.d_rows_;
@@ -438,10 +822,21 @@ int32_t flat_mfma_search(Index& ix, const float* dq, int64_t nq, int k, u64* run
   ra.cap = cap;
   ra.run_keys = run_keys;
 
-  const size_t shm = 2 * 32768 + BM * sizeof(float);
+  static const int version = getenv("EPS_MFMA_KERNEL") ? atoi(getenv("EPS_MFMA_KERNEL")) : 3;
+  const int bm = version == 1 ? BM : BM2;  // v2 and v3 use 256-row tiles
+  const size_t shm = version == 1 ? 2 * 32768 + BM * sizeof(float) : version == 2 ? 3 * 49152 + BM2 * sizeof(float) : 2 * 65536 + 2 * 256 * sizeof(float);
+  static int num_cus = 0;
+  if (!num_cus) {
+    hipDeviceProp_t prop;
+    num_cus = hipGetDeviceProperties(&prop, ix.device_) == hipSuccess ? prop.multiProcessorCount : 256;
+    num_cus = num_cus / 8 * 8;
+    if (num_cus < 8) num_cus = 8;
+  }
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_filter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_filter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * 32768 + BM * sizeof(float)));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_filter_kernel_v2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * 49152 + BM2 * sizeof(float)));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_filter_kernel_v3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * 65536 + 2 * 256 * sizeof(float)));
     attr_set = true;
   }
   bool first = true;
@@ -451,13 +846,22 @@ int32_t flat_mfma_search(Index& ix, const float* dq, int64_t nq, int k, u64* run
                        m.qstat.as<float>(), m.scal.as<float>(), ix.metric_, m.T.as<float>());
     er = hipMemsetAsync(cnt, 0, (size_t)nq * 4, s);
     if (er != hipSuccess) return ix.hip_fail(er, "memset");
-    fa.tile0 = lo / BM;
-    fa.ntiles = (hi + BM - 1) / BM - fa.tile0;
+    fa.tile0 = lo / bm;
+    fa.ntiles = (hi + bm - 1) / bm - fa.tile0;
     fa.row_hi = hi;
     const int64_t blocks = (fa.ntiles + 7) / 8 * 8 * fa.tiles_q;
     const bool biggest = (st + 2 == bounds.size());
     if (biggest) (void)hipEventRecord(ix.evk0_, s);
-    hipLaunchKernelGGL(mfma_filter_kernel, dim3((unsigned)blocks), dim3(256), shm, s, fa);
+    if (biggest) ix.stats_.main_kernel_rows = hi - lo;
+    if (version == 1) {
+      hipLaunchKernelGGL(mfma_filter_kernel, dim3((unsigned)blocks), dim3(256), shm, s, fa);
+    } else if (version == 2) {
+      hipLaunchKernelGGL(mfma_filter_kernel_v2, dim3((unsigned)blocks), dim3(512), shm, s, fa);
+    } else {
+      FilterArgs f3 = fa;
+      f3.tiles_q = (int)(b_pad / BN3);
+      hipLaunchKernelGGL(mfma_filter_kernel_v3, dim3((unsigned)num_cus), dim3(512), shm, s, f3);
+    }
     if (biggest) (void)hipEventRecord(ix.evk1_, s);
     hipLaunchKernelGGL(count_overflow_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, cnt, nq, cap, overflow);
     hipLaunchKernelGGL(sum_counts_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, cnt, nq, cap, total);
