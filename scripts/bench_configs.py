@@ -140,7 +140,36 @@ def c4():
                           "overflow_queries": st["overflow_queries"], "all_results_pass_filter": ok}))
 
 
+def c2b():
+    """graph traversal throughput at batch 1024 on 1M x 768 (graph built on the device)"""
+    n, d, k, b = 1_000_000, 768, 10, 1024
+    X = gen(n, d, 42)
+    Q = gen(b, d, 43)
+    ix = amd.GpuIndex(d, 0).use_torch_stream()
+    ix.attach_rows(X)
+    gt = outs(b, k)
+    ix.search(Q, k, out=gt, mode=amd.MODE_FLAT)
+    torch.cuda.synchronize()
+    gti = gt[0].cpu().numpy()
+    ix.build()
+    ob = outs(b, k)
+    for T, L in ((1, 500), (4, 500), (8, 500), (4, 2000)):
+        ix.search(Q, k, out=ob, mode=amd.MODE_GRAPH, intra_threads=T, master_queue=L, local_queue=L)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            ix.search(Q, k, out=ob, mode=amd.MODE_GRAPH, intra_threads=T, master_queue=L, local_queue=L)
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t1) / 3
+        st = ix.stats()
+        byt = st["dist_evals"] * (4 * d + 4) + st["expansions"] * (4 * 52)
+        print(json.dumps({"config": "C2b 1M x 768 graph traversal batch=1024 T=%d L=%d wide=%s" % (T, L, os.environ.get("EPS_TRV_WIDE", "auto")),
+                          "qps": b / el, "recall_at_10": recall(ob[0].cpu().numpy(), gti), "evals_per_query": st["dist_evals"] / float(b),
+                          "kernel_ms": st["main_kernel_ms"], "achieved_GBps": byt / (st["main_kernel_ms"] * 1e-3) / 1e9,
+                          "frac_of_8TBps": byt / (st["main_kernel_ms"] * 1e-3) / 8e12}))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["c1", "c2", "c4"]
     for w in which:
-        {"c1": c1, "c2": c2, "c4": c4}[w]()
+        {"c1": c1, "c2": c2, "c2b": c2b, "c4": c4}[w]()

@@ -370,3 +370,39 @@ def test_mfma_engine_adversarial_order_falls_back_exactly(amd):
         outs.append((ids.cpu().numpy(), dist.cpu().numpy()))
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
     ix.close()
+
+
+def test_graph_search_csr_fallback_for_high_degree_nodes(amd, oracle):
+    """Connectivity repair can give a node any out-degree; above 64 the device keeps the CSR form instead of the
+    fixed-stride adjacency.  Same answer as the oracle either way, duplicates in an adjacency list included."""
+    z, off, nbr, nav = _golden_graph()
+    X, Q = data(2000, 32, 42), data(8, 32, 45)
+    lists = [list(nbr[off[i]:off[i + 1]]) for i in range(2000)]
+    lists[nav] += list(range(100, 190)) + [lists[nav][0]]        # 90 extra edges + one duplicate
+    lists[7] += [3, 3, 3]
+    off2 = np.zeros(2001, np.int64)
+    off2[1:] = np.cumsum([len(l) for l in lists])
+    nbr2 = np.concatenate([np.asarray(l, np.int64) for l in lists])
+    ix = amd.GpuIndex(32, 0)
+    ix.attach_rows(X)
+    ix.set_graph(off2, nbr2, nav)
+    ids, dist, cnt = ix.search(Q, 50, mode=amd.MODE_GRAPH, intra_threads=1)
+    init = oracle.prepare_init_ids(off2, nbr2, nav, 500)
+    for qi, q in enumerate(Q):
+        oid, od, _ = oracle.search_impl(0, X, off2, nbr2, init, q, T=1, L=500)
+        assert_topk_match(ids[qi], dist[qi], oid[:50], od[:50], what="csr q%d" % qi)
+    ix.close()
+
+
+def test_graph_search_large_batch_slices(amd, oracle):
+    """1500 queries in one call (more workgroups than fit at once, visited bitmaps of the whole batch)."""
+    z, off, nbr, nav = _golden_graph()
+    X = data(2000, 32, 42)
+    Q = np.tile(data(16, 32, 43), (94, 1))[:1500]
+    ix = amd.GpuIndex(32, 0)
+    ix.attach_rows(X)
+    ix.set_graph(off, nbr, nav)
+    ids, dist, cnt = ix.search(Q, 10, mode=amd.MODE_GRAPH, intra_threads=1)
+    for qi in range(1500):
+        assert_topk_match(ids[qi], dist[qi], z["ids_m0"][qi % 16][:10], z["dist_m0"][qi % 16][:10], what="q%d" % qi)
+    ix.close()

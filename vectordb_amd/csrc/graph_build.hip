@@ -435,9 +435,9 @@ int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp) {
     const int64_t nb = std::min(NB, n - v0);
     ta.queries = ix.d_rows_ + v0 * dim;
     if (vec4)
-      hipLaunchKernelGGL((traverse_kernel<true, true, true>), dim3((unsigned)nb), dim3(256), trv_shm, s, ta);
+      hipLaunchKernelGGL((traverse_kernel<true, true, true, 4>), dim3((unsigned)nb), dim3(256), trv_shm, s, ta);
     else
-      hipLaunchKernelGGL((traverse_kernel<false, true, true>), dim3((unsigned)nb), dim3(256), trv_shm, s, ta);
+      hipLaunchKernelGGL((traverse_kernel<false, true, true, 4>), dim3((unsigned)nb), dim3(256), trv_shm, s, ta);
     pa.v0 = v0;
     if (vec4)
       hipLaunchKernelGGL((prune_kernel<true>), dim3((unsigned)nb), dim3(256), prn_shm, s, pa);
@@ -545,9 +545,9 @@ int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp) {
       hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)nb), dim3(256), 0, s, ix.d_rows_, d_orph.as<u32>() + o0, nb, dim, d_q.as<float>());
       ta.queries = d_q.as<float>();
       if (vec4)
-        hipLaunchKernelGGL((traverse_kernel<true, true, true>), dim3((unsigned)nb), dim3(256), trv_shm, s, ta);
+        hipLaunchKernelGGL((traverse_kernel<true, true, true, 4>), dim3((unsigned)nb), dim3(256), trv_shm, s, ta);
       else
-        hipLaunchKernelGGL((traverse_kernel<false, true, true>), dim3((unsigned)nb), dim3(256), trv_shm, s, ta);
+        hipLaunchKernelGGL((traverse_kernel<false, true, true, 4>), dim3((unsigned)nb), dim3(256), trv_shm, s, ta);
       HIPCHK(hipMemcpyAsync(hlog.data(), logb.p, (size_t)nb * LOG_CAP * 8, hipMemcpyDeviceToHost, s));
       HIPCHK(hipMemcpyAsync(hcnt.data(), logc.p, (size_t)nb * 4, hipMemcpyDeviceToHost, s));
       HIPCHK(hipStreamSynchronize(s));

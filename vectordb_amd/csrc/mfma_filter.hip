@@ -67,46 +67,77 @@ __device__ __forceinline__ void atomic_max_pos(float* addr, float v) {  // v >= 
 
 __global__ __launch_bounds__(256) void half_mirror_kernel(const float* rows, int64_t n, int64_t n_pad, int dim, int d_pad,
                                                           _Float16* xh, float* xn, float* zeros, float* scal, float gamma) {
-  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= n_pad) return;
+  // one wavefront per row, grid-stride over rows; the four per-index maxima are reduced in registers and
+  // published with ONE atomic per wavefront (an atomic per row serialises 10M rows on four addresses)
   const int lane = lane_id();
-  _Float16* dst = xh + r * d_pad;
-  if (r >= n) {
-    for (int c = lane; c < d_pad; c += 64) dst[c] = (_Float16)0.f;
-    if (lane == 0) {
-      xn[r] = __builtin_inff();
-      zeros[r] = __builtin_inff();
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  float m_e1 = 0.f, m_nxh = 0.f, m_xn = 0.f, m_bad = 0.f;
+  const bool vec = (dim & 3) == 0 && ((reinterpret_cast<uintptr_t>(rows) & 15) == 0);
+  typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+  for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n_pad; r += nwaves) {
+    _Float16* dst = xh + r * d_pad;
+    if (r >= n) {
+      for (int c = lane; c < d_pad; c += 64) dst[c] = (_Float16)0.f;
+      if (lane == 0) {
+        xn[r] = __builtin_inff();
+        zeros[r] = __builtin_inff();
+      }
+      continue;
     }
-    return;
-  }
-  const float* src = rows + r * dim;
-  float s2 = 0.f, e2 = 0.f, h2 = 0.f, mx = 0.f;
-  for (int c = lane; c < d_pad; c += 64) {
-    const float x = c < dim ? src[c] : 0.f;
-    const _Float16 h = (_Float16)x;
-    const float hf = (float)h;
-    dst[c] = h;
-    s2 = fmaf(x, x, s2);
-    const float e = x - hf;
-    e2 = fmaf(e, e, e2);
-    h2 = fmaf(hf, hf, h2);
-    mx = fmaxf(mx, fabsf(x));
-  }
-  for (int o = 32; o > 0; o >>= 1) {
-    s2 += __shfl_xor(s2, o);
-    e2 += __shfl_xor(e2, o);
-    h2 += __shfl_xor(h2, o);
-    mx = fmaxf(mx, __shfl_xor(mx, o));
+    const float* src = rows + r * dim;
+    float s2 = 0.f, e2 = 0.f, h2 = 0.f, mx = 0.f;
+    if (vec) {  // 16 B/lane loads, 8 B/lane stores (d_pad is a multiple of 64, so c + 3 < d_pad)
+      for (int c = lane * 4; c < d_pad; c += 256) {
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < dim) x = *reinterpret_cast<const float4*>(src + c);
+        half4 h;
+        h[0] = (_Float16)x.x; h[1] = (_Float16)x.y; h[2] = (_Float16)x.z; h[3] = (_Float16)x.w;
+        *reinterpret_cast<half4*>(dst + c) = h;
+        const float xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float hf = (float)h[e];
+          s2 = fmaf(xs[e], xs[e], s2);
+          const float er = xs[e] - hf;
+          e2 = fmaf(er, er, e2);
+          h2 = fmaf(hf, hf, h2);
+          mx = fmaxf(mx, fabsf(xs[e]));
+        }
+      }
+    } else {
+      for (int c = lane; c < d_pad; c += 64) {
+        const float x = c < dim ? src[c] : 0.f;
+        const _Float16 h = (_Float16)x;
+        const float hf = (float)h;
+        dst[c] = h;
+        s2 = fmaf(x, x, s2);
+        const float e = x - hf;
+        e2 = fmaf(e, e, e2);
+        h2 = fmaf(hf, hf, h2);
+        mx = fmaxf(mx, fabsf(x));
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      s2 += __shfl_xor(s2, o);
+      e2 += __shfl_xor(e2, o);
+      h2 += __shfl_xor(h2, o);
+      mx = fmaxf(mx, __shfl_xor(mx, o));
+    }
+    if (lane == 0) {
+      xn[r] = s2;
+      zeros[r] = 0.f;
+    }
+    const float nxh = sqrtf(h2) * 1.000001f;
+    m_e1 = fmaxf(m_e1, sqrtf(e2) * 1.000001f + gamma * nxh);
+    m_nxh = fmaxf(m_nxh, nxh);
+    m_xn = fmaxf(m_xn, s2);
+    if (!(mx <= 65504.f) || s2 != s2) m_bad = 1.f;  // beyond the fp16 range, or NaN
   }
   if (lane == 0) {
-    xn[r] = s2;
-    zeros[r] = 0.f;
-    const float nxh = sqrtf(h2) * 1.000001f;
-    const float e1 = sqrtf(e2) * 1.000001f + gamma * nxh;
-    atomic_max_pos(&scal[0], e1);
-    atomic_max_pos(&scal[1], nxh);
-    atomic_max_pos(&scal[2], s2);
-    if (!(mx <= 65504.f)) atomic_max_pos(&scal[3], 1.f);  // also catches NaN
+    atomic_max_pos(&scal[0], m_e1);
+    atomic_max_pos(&scal[1], m_nxh);
+    atomic_max_pos(&scal[2], m_xn);
+    if (m_bad != 0.f) atomic_max_pos(&scal[3], 1.f);
   }
 }
 
@@ -733,7 +764,7 @@ static int32_t ensure_mirror(Index& ix) {
   // fp32 accumulation slack of the MFMA dot product: <= 4 * d * 2^-24 * |qh||xh| (generous: covers any
   // internal summation order / truncating adder)
   const float gamma = 4.0f * (float)d_pad * 5.9604645e-8f;
-  hipLaunchKernelGGL(half_mirror_kernel, dim3((unsigned)((n_pad + 3) / 4)), dim3(256), 0, s, ix.d_rows_, n, n_pad,
+  hipLaunchKernelGGL(half_mirror_kernel, dim3((unsigned)std::min<int64_t>((n_pad + 3) / 4, 8192)), dim3(256), 0, s, ix.d_rows_, n, n_pad,
                      (int)ix.dim_, d_pad, m.xh.as<_Float16>(), m.xn.as<float>(), m.zeros.as<float>(), m.scal.as<float>(), gamma);
   er = hipMemcpyAsync(m.h_scal, m.scal.p, 16, hipMemcpyDeviceToHost, s);
   if (er == hipSuccess) er = hipStreamSynchronize(s);

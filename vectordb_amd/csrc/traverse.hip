@@ -15,6 +15,7 @@
 // reference's single-thread result (see DESIGN.md "traversal equivalence"); M > 1 plays the role of the
 // reference's T workers, whose interleaving is not deterministic in the reference either.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -24,8 +25,9 @@
 namespace eps {
 
 struct GraphDev {
-  DevBuf off;        // int64 [n+1]
-  DevBuf nbr;        // u32 [E]
+  DevBuf off;        // int64 [n+1]            (CSR form, used when max_degree > 64)
+  DevBuf nbr;        // u32 [E]                (CSR) or u32 [n][fixed_deg] padded with 0xFFFFFFFF
+  int fixed_deg = 0; // > 0: fixed-stride adjacency — one dependent load less per expansion than CSR
   DevBuf init_ids;   // u32 [L]
   int64_t init_L = -1;
   int64_t max_degree = 0;
@@ -44,16 +46,34 @@ int32_t graph_upload(Index& ix) {
   const int64_t n = ix.n_indexed_;
   if (n <= 0) return EPS_OK;
   const int64_t e = ix.h_off_[n];
-  if (!g.off.reserve((size_t)(n + 1) * 8) || !g.nbr.reserve((size_t)(e > 0 ? e : 1) * 4))
-    return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "set_graph: out of device memory");
-  std::vector<u32> nb32((size_t)e);
   int64_t maxdeg = 0;
-  for (int64_t i = 0; i < e; ++i) nb32[i] = (u32)ix.h_nbr_[i];
   for (int64_t i = 0; i < n; ++i) maxdeg = std::max(maxdeg, ix.h_off_[i + 1] - ix.h_off_[i]);
   g.max_degree = maxdeg;
-  hipError_t er = hipMemcpyAsync(g.off.p, ix.h_off_.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, ix.stream_);
-  if (er == hipSuccess && e > 0) er = hipMemcpyAsync(g.nbr.p, nb32.data(), (size_t)e * 4, hipMemcpyHostToDevice, ix.stream_);
-  if (er == hipSuccess) er = hipStreamSynchronize(ix.stream_);
+  hipError_t er = hipSuccess;
+  if (maxdeg > 0 && maxdeg <= 64) {
+    // NSG out-degree is <= 50 (+ connectivity repair): store every list at a fixed stride so the traversal
+    // reads neighbours of node v at nbr[v*deg ..] without first fetching offsets ("one coalesced
+    // CSR row read each")
+    const int deg = (int)((maxdeg + 3) / 4 * 4);
+    std::vector<u32> pad((size_t)n * deg, 0xFFFFFFFFu);
+    for (int64_t i = 0; i < n; ++i) {
+      const int64_t b = ix.h_off_[i], c = ix.h_off_[i + 1] - b;
+      for (int64_t j = 0; j < c; ++j) pad[(size_t)i * deg + j] = (u32)ix.h_nbr_[b + j];
+    }
+    if (!g.nbr.reserve(pad.size() * 4)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "set_graph: out of device memory");
+    er = hipMemcpyAsync(g.nbr.p, pad.data(), pad.size() * 4, hipMemcpyHostToDevice, ix.stream_);
+    if (er == hipSuccess) er = hipStreamSynchronize(ix.stream_);
+    g.fixed_deg = deg;
+  } else {
+    std::vector<u32> nb32((size_t)e);
+    for (int64_t i = 0; i < e; ++i) nb32[i] = (u32)ix.h_nbr_[i];
+    if (!g.off.reserve((size_t)(n + 1) * 8) || !g.nbr.reserve((size_t)(e > 0 ? e : 1) * 4))
+      return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "set_graph: out of device memory");
+    er = hipMemcpyAsync(g.off.p, ix.h_off_.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, ix.stream_);
+    if (er == hipSuccess && e > 0) er = hipMemcpyAsync(g.nbr.p, nb32.data(), (size_t)e * 4, hipMemcpyHostToDevice, ix.stream_);
+    if (er == hipSuccess) er = hipStreamSynchronize(ix.stream_);
+    g.fixed_deg = 0;
+  }
   if (er != hipSuccess) return ix.hip_fail(er, "set_graph upload");
   return EPS_OK;
 }
@@ -202,9 +222,9 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
   a.rows = ix.d_rows_;
   a.dim = (int)ix.dim_;
   a.metric = ix.metric_;
-  a.off = g.off.as<int64_t>();
+  a.off = g.fixed_deg > 0 ? nullptr : g.off.as<int64_t>();
   a.nbr = g.nbr.as<u32>();
-  a.fixed_deg = 0;
+  a.fixed_deg = g.fixed_deg;
   a.log = nullptr;
   a.log_cnt = nullptr;
   a.log_cap = 0;
@@ -222,10 +242,17 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
     if (er != hipSuccess) return ix.hip_fail(er, "memset visited");
     a.queries = dq + q0 * ix.dim_;
     a.out_queue = g.queue.as<u64>() + q0 * L;
-    if (vec4)
-      hipLaunchKernelGGL((traverse_kernel<true, false, false>), dim3((unsigned)cnt), dim3(256), shm, s, a);
+    // few queries: 16 wavefronts per query (latency); many queries: 4 per query (throughput, more queries per CU)
+    static const int wide_env = getenv("EPS_TRV_WIDE") ? atoi(getenv("EPS_TRV_WIDE")) : -1;
+    const bool wide = wide_env >= 0 ? wide_env != 0 : nq <= 256;
+    if (vec4 && wide)
+      hipLaunchKernelGGL((traverse_kernel<true, false, false, 16>), dim3((unsigned)cnt), dim3(1024), shm, s, a);
+    else if (vec4)
+      hipLaunchKernelGGL((traverse_kernel<true, false, false, 4>), dim3((unsigned)cnt), dim3(256), shm, s, a);
+    else if (wide)
+      hipLaunchKernelGGL((traverse_kernel<false, false, false, 16>), dim3((unsigned)cnt), dim3(1024), shm, s, a);
     else
-      hipLaunchKernelGGL((traverse_kernel<false, false, false>), dim3((unsigned)cnt), dim3(256), shm, s, a);
+      hipLaunchKernelGGL((traverse_kernel<false, false, false, 4>), dim3((unsigned)cnt), dim3(256), shm, s, a);
     ix.stats_.main_kernel_launches += 1;
   }
   (void)hipEventRecord(ix.evk1_, s);

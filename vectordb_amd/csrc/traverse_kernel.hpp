@@ -60,8 +60,11 @@ __device__ __forceinline__ bool visit(u32* vis, u32* hash, int* hcount, u32 id) 
   }
 }
 
-template <bool VEC4, bool HASHVIS, bool LOG>
-__global__ __launch_bounds__(256) void traverse_kernel(TraverseArgs a) {
+// NW = wavefronts per workgroup (4: many queries in flight; 16: one query spread over a whole CU's worth of waves,
+// so the ~50 candidate rows of an expansion are all in flight at once — single-query latency)
+template <bool VEC4, bool HASHVIS, bool LOG, int NW>
+__global__ __launch_bounds__(NW * 64) void traverse_kernel(TraverseArgs a) {
+  constexpr int NT = NW * 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int dim = a.dim;
   const int qstride = (dim + 3) & ~3;
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(256) void traverse_kernel(TraverseArgs a) {
   int* sh = reinterpret_cast<int*>(work + TRV_CHUNK);                     // small scalars [64]
   u32* hash = reinterpret_cast<u32*>(sh + 64);                            // [TRV_HASH] (HASHVIS only)
   // sh[0]=work count, sh[1]=selected count, sh[2]=k (first possibly-unchecked position), sh[3]=valid new count,
-  // sh[4]=r_min, sh[5]=position of the first selected candidate, sh[6]=hash fill, sh[7]=log fill, sh[8..8+M) selected node ids, sh[24..24+M+1) edge prefix, sh[48..52) per-wave counts
+  // sh[4]=r_min, sh[5]=position of the first selected candidate, sh[6]=hash fill, sh[7]=log fill, sh[8..8+M) selected node ids, sh[24..24+M+1) edge prefix, sh[48..48+NW) per-wave counts
   const int tid = threadIdx.x;
   const int lane = lane_id();
   const int wave = tid >> 6;
@@ -88,18 +91,18 @@ __global__ __launch_bounds__(256) void traverse_kernel(TraverseArgs a) {
   unsigned long long evals = 0, expansions = 0;
   u64* qlog = LOG ? a.log + q * (int64_t)a.log_cap : nullptr;
   if (HASHVIS) {
-    for (int i = tid; i < TRV_HASH; i += 256) hash[i] = TRV_NONE;
+    for (int i = tid; i < TRV_HASH; i += NT) hash[i] = TRV_NONE;
     if (tid == 0) sh[6] = 0;
   }
   if (LOG && tid == 0) sh[7] = 0;
   if (HASHVIS || LOG) __syncthreads();
 
-  for (int i = tid; i < qstride; i += 256) sq[i] = i < dim ? a.queries[q * dim + i] : 0.f;
-  for (int i = tid; i < a.Lp2; i += 256) queue[i] = KEY_EMPTY;
+  for (int i = tid; i < qstride; i += NT) sq[i] = i < dim ? a.queries[q * dim + i] : 0.f;
+  for (int i = tid; i < a.Lp2; i += NT) queue[i] = KEY_EMPTY;
   // InitializeSetLPara (:446-485): mark seeds visited, L seed distances, sort
-  for (int i = tid; i < L; i += 256) visit<HASHVIS>(vis, hash, &sh[6], a.init_ids[i]);
+  for (int i = tid; i < L; i += NT) visit<HASHVIS>(vis, hash, &sh[6], a.init_ids[i]);
   __syncthreads();
-  for (int c0 = wave * RPW * U; c0 < L; c0 += 4 * RPW * U) {
+  for (int c0 = wave * RPW * U; c0 < L; c0 += NW * RPW * U) {
     const float* rp[U];
     u32 id[U];
     bool ok[U];
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(256) void traverse_kernel(TraverseArgs a) {
   // bitonic sort of queue[0..Lp2)
   for (int size = 2; size <= a.Lp2; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int i = tid; i < (a.Lp2 >> 1); i += 256) {
+      for (int i = tid; i < (a.Lp2 >> 1); i += NT) {
         const int lo = ((i / stride) * (stride << 1)) + (i % stride);
         const int hi = lo + stride;
         const bool up = ((lo & size) == 0);
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(256) void traverse_kernel(TraverseArgs a) {
     // 1. select the first M unchecked candidates at positions >= k, mark them checked
     if (tid == 0) sh[1] = 0;
     __syncthreads();
-    for (int base = sh[2]; base < L; base += 256) {
+    for (int base = sh[2]; base < L; base += NT) {
       const int p = base + tid;
       const bool un = p < L && !(queue[p] & 1ull);
       const u64 m = __ballot(un);
@@ -165,7 +168,8 @@ __global__ __launch_bounds__(256) void traverse_kernel(TraverseArgs a) {
       }
       __syncthreads();
       if (tid == 0) {
-        int tot = sh[1] + sh[48] + sh[49] + sh[50] + sh[51];
+        int tot = sh[1];
+        for (int w2 = 0; w2 < NW; ++w2) tot += sh[48 + w2];
         sh[1] = tot < a.M ? tot : a.M;
       }
       __syncthreads();
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(256) void traverse_kernel(TraverseArgs a) {
         const int e = e0 + tid;
         bool fresh = false;
         u32 nb = 0;
-        if (e < total_edges) {
+        if (tid < TRV_CHUNK && e < total_edges) {
           int i = 0;
           while (i + 1 < nsel && sh[24 + i + 1] <= e) ++i;
           const int64_t rowbase = a.fixed_deg > 0 ? (int64_t)sh[8 + i] * a.fixed_deg : a.off[sh[8 + i]];
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(256) void traverse_kernel(TraverseArgs a) {
       evals += nwork;
       // 3. distances; drop candidates beyond the current worst-of-queue (dist > bound, :427)
       const float bound = key_dist(queue[L - 1]);
-      for (int c0 = wave * RPW * U; c0 < nwork; c0 += 4 * RPW * U) {
+      for (int c0 = wave * RPW * U; c0 < nwork; c0 += NW * RPW * U) {
         const float* rp[U];
         u32 id[U];
         bool ok[U];
@@ -259,11 +263,11 @@ __global__ __launch_bounds__(256) void traverse_kernel(TraverseArgs a) {
       const int nnew = sh[3];
       if (nnew == 0) continue;
       // 5. in-place parallel merge of sorted[0..nnew) into queue[0..L): read phase, barrier, write phase
-      u64 oldv[16];
-      int oldp[16];
+      u64 oldv[4096 / NT];
+      int oldp[4096 / NT];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {  // L <= 4096 = 16 * 256; constant trip count keeps oldv/oldp in registers
-        const int p = tid + i * 256;
+      for (int i = 0; i < 4096 / NT; ++i) {  // L <= 4096; constant trip count keeps oldv/oldp in registers
+        const int p = tid + i * NT;
         oldp[i] = L;
         oldv[i] = KEY_EMPTY;
         if (p < L) {
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(256) void traverse_kernel(TraverseArgs a) {
       }
       __syncthreads();
 #pragma unroll
-      for (int i = 0; i < 16; ++i)
+      for (int i = 0; i < 4096 / NT; ++i)
         if (oldp[i] < L) queue[oldp[i]] = oldv[i];
       if (np < L) queue[np] = nv;
       __syncthreads();
@@ -303,7 +307,7 @@ __global__ __launch_bounds__(256) void traverse_kernel(TraverseArgs a) {
     __syncthreads();
   }
   if (a.out_queue)
-    for (int i = tid; i < L; i += 256) a.out_queue[q * L + i] = queue[i];
+    for (int i = tid; i < L; i += NT) a.out_queue[q * L + i] = queue[i];
   if (LOG && tid == 0) a.log_cnt[q] = sh[7] < a.log_cap ? (u32)sh[7] : (u32)a.log_cap;
   if (tid == 0) {
     atomicAdd(&a.counters[0], evals);
