@@ -219,7 +219,8 @@ struct FilterArgs {
   int metric;
   u32* cnt;
   int cap;
-  int ablate;           // profiling only (EPS_MFMA_ABLATE): bit0 skip staging loads, bit1 skip MFMAs, bit2 skip LDS fragment reads
+  int ablate;           // profiling only (EPS_MFMA_ABLATE): v1: bit0 skip staging loads, bit1 skip MFMAs, bit2 skip LDS
+                        // fragment reads; v3: bit3 skip the query-operand DMA, bit4 skip the row-operand DMA
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (row << 3) + (chunk ^ ((row >> 1) & 7)); }  // 16-B granule index
@@ -559,7 +560,9 @@ __global__ __launch_bounds__(512, 2) void mfma_filter_kernel_v2(FilterArgs a) {
 // MFMAs per wavefront of step s; the epilogue of a tile runs under the first loads of the next.  256 flop per L2
 // byte (v1: 128).  Tile order keeps the query tiles of one row tile on one XCD at the same time.
 constexpr int BM3 = 256, BN3 = 256;
+template <bool ABL>  // ABL: profiling build with the EPS_MFMA_ABLATE switches compiled in
 __global__ __launch_bounds__(512, 2) void mfma_filter_kernel_v3(FilterArgs a) {
+  const int ablate = ABL ? a.ablate : 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int SLOT = 65536;  // A 256 x 128 B | B 256 x 128 B
   const int tid = threadIdx.x;
@@ -611,10 +614,12 @@ __global__ __launch_bounds__(512, 2) void mfma_filter_kernel_v3(FilterArgs a) {
     unsigned char* dB = dA + 32768;
     const int off = g_off[it] + kt * BK;
     const int wbase = (it * 512 + wave * 64) * 16;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gA + off),
-                                     (__attribute__((address_space(3))) void*)(dA + wbase), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB + off),
-                                     (__attribute__((address_space(3))) void*)(dB + wbase), 16, 0, 0);
+    if (!(ablate & 16))
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gA + off),
+                                       (__attribute__((address_space(3))) void*)(dA + wbase), 16, 0, 0);
+    if (!(ablate & 8))
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB + off),
+                                       (__attribute__((address_space(3))) void*)(dB + wbase), 16, 0, 0);
   };
   auto stage_base = [&](const float* gb, int64_t t) {  // |x|^2 (or 0) column of the tile's 256 rows, wavefronts 0-3
     if (wave < 4)
@@ -628,12 +633,13 @@ __global__ __launch_bounds__(512, 2) void mfma_filter_kernel_v3(FilterArgs a) {
 
   // thresholds of this workgroup's query tile, loaded before any LDS-DMA is in flight (ordinary loads make the
   // compiler wait vmcnt(0), which would drain the pipeline if done per tile)
-  float Tj[2], cj[2];
+  const float inv_s = 1.0f / a.s;  // s = -2 (L2) or -1: exact
+  float Tq[2], cj[2];   // Tq = T/s: threshold in accumulator space (a row passes iff acc >= Tq)
   int64_t qj[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     qj[j] = (int64_t)qslot * BN3 + wn * 64 + j * 32 + (lane & 31);
-    Tj[j] = a.T[qj[j]];
+    Tq[j] = a.T[qj[j]] * inv_s;
     cj[j] = a.cand_keys ? (a.metric == 0 ? a.qstat[qj[j] * 4] : (a.metric == 1 ? 1.f : 0.f)) : 0.f;
   }
   set_next(0);
@@ -647,16 +653,32 @@ __global__ __launch_bounds__(512, 2) void mfma_filter_kernel_v3(FilterArgs a) {
     const int64_t row0 = (a.tile0 + tile_rt(t)) * BM3;
     const int64_t q0 = (int64_t)tile_qt(t) * BN3;
     if (t + 1 < ntile) set_next(t + 1);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // accumulators start at base/s (= -|x|^2/2 for L2, 0 otherwise; -inf on padding rows), so that the finished
+    // accumulator is (approx key)/s and the epilogue is one max + one compare per 16 outputs.  The |x|^2 column of
+    // this tile was staged with its first K-step; that step has not been waited for yet when t == 0 / a tile starts,
+    // so the init happens after the first barrier of the tile (kt == 0 below).
     for (int kt = 0; kt < KT; ++kt) {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      if (kt == 0) {
+        const float* bl0 = base_lds + (t & 1) * 256;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int rbase = wm * 128 + i * 32 + 4 * khalf;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float4 bv = *reinterpret_cast<const float4*>(&bl0[rbase + 8 * g]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              acc[i][j][4 * g + 0] = bv.x * inv_s;
+              acc[i][j][4 * g + 1] = bv.y * inv_s;
+              acc[i][j][4 * g + 2] = bv.z * inv_s;
+              acc[i][j][4 * g + 3] = bv.w * inv_s;
+            }
+          }
+        }
+      }
       // next step of the (tile, K-step) stream; its staging is spread over the four K=16 sub-steps below so that the
       // DMA issue cost of one wavefront overlaps the MFMAs of the wavefront sharing its SIMD
       const bool same = kt + 1 < KT;
@@ -666,63 +688,71 @@ __global__ __launch_bounds__(512, 2) void mfma_filter_kernel_v3(FilterArgs a) {
       const int nk_ = same ? kt + 1 : 0;
       const unsigned char* sA = lds + slot * SLOT;
       const unsigned char* sB = sA + 32768;
+      // fragments of sub-step kk+1 are read from LDS while the MFMAs of sub-step kk issue (register double buffer)
+      half8 fa[2][4], fb[2][2];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) fa[0][f] = *reinterpret_cast<const half8*>(sA + swz(arow0 + f * 32, khalf) * 16);
+#pragma unroll
+      for (int f = 0; f < 2; ++f) fb[0][f] = *reinterpret_cast<const half8*>(sB + swz(brow0 + f * 32, khalf) * 16);
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        const int chunk = kk * 2 + khalf;
-        half8 fa[4], fb[2];
+        const int cur = kk & 1, nxt = cur ^ 1;
+        if (kk < 3 && !(ablate & 4)) {
+          const int chunk = (kk + 1) * 2 + khalf;
 #pragma unroll
-        for (int f = 0; f < 4; ++f) fa[f] = *reinterpret_cast<const half8*>(sA + swz(arow0 + f * 32, chunk) * 16);
+          for (int f = 0; f < 4; ++f) fa[nxt][f] = *reinterpret_cast<const half8*>(sA + swz(arow0 + f * 32, chunk) * 16);
 #pragma unroll
-        for (int f = 0; f < 2; ++f) fb[f] = *reinterpret_cast<const half8*>(sB + swz(brow0 + f * 32, chunk) * 16);
+          for (int f = 0; f < 2; ++f) fb[nxt][f] = *reinterpret_cast<const half8*>(sB + swz(brow0 + f * 32, chunk) * 16);
+        }
         if (more) {
           stage_piece(pA, pB, nk_, slot ^ 1, kk);
           if (kk == 0 && !same) stage_base(gbase_nx, t + 1);
         }
-        __builtin_amdgcn_sched_barrier(0);
+        if (!(ablate & 2)) {
+          __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+          for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+          __builtin_amdgcn_s_setprio(0);
+        } else {
+#pragma unroll
+          for (int f = 0; f < 4; ++f) asm volatile("" ::"v"(fa[cur][f]));
+#pragma unroll
+          for (int f = 0; f < 2; ++f) asm volatile("" ::"v"(fb[cur][f]));
+        }
       }
       slot ^= 1;
     }
     // ---- epilogue of tile t (the first K-step of tile t+1 is already in flight)
-    const float* bl = base_lds + (t & 1) * 256;  // landed with K-step 0 of this tile (>= KT barriers ago)
     if (nqt > 1) {  // the query tile changes between tiles: reload its thresholds (ordinary loads: drains the DMA queue once)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         qj[j] = q0 + wn * 64 + j * 32 + (lane & 31);
-        Tj[j] = a.T[qj[j]];
+        Tq[j] = a.T[qj[j]] * inv_s;
         cj[j] = a.cand_keys ? (a.metric == 0 ? a.qstat[qj[j] * 4] : (a.metric == 1 ? 1.f : 0.f)) : 0.f;
       }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int rbase = wm * 128 + i * 32 + 4 * khalf;
-      float4 bv[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) bv[g] = *reinterpret_cast<const float4*>(&bl[rbase + 8 * g]);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        bool any = false;
-        float v[16];
+        // pass  <=>  s*acc <= T  <=>  acc >= T/s  (s < 0): one running max over the 16 outputs of this lane
+        float mx = acc[i][j][0];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float b = (r & 3) == 0 ? bv[r >> 2].x : (r & 3) == 1 ? bv[r >> 2].y : (r & 3) == 2 ? bv[r >> 2].z : bv[r >> 2].w;
-          v[r] = fmaf(acc[i][j][r], a.s, b);
-          any |= (v[r] <= Tj[j]);
-        }
-        if (__any(any)) {
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[i][j][r]);
+        if (__any(mx >= Tq[j])) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            if (v[r] <= Tj[j]) {
+            if (acc[i][j][r] >= Tq[j]) {
               const int64_t row = row0 + rbase + (r & 3) + 8 * (r >> 2);
-              if (row < a.row_hi && qj[j] < a.nq) {
+              if (row < a.row_hi && qj[j] < a.nq && !ablate) {
                 const u32 slot_c = atomicAdd(&a.cnt[qj[j]], 1u);
                 if (slot_c < (u32)a.cap) {
                   if (a.cand_keys) {
-                    float dapx = v[r] + cj[j];
+                    float dapx = acc[i][j][r] * a.s + cj[j];
                     if (a.metric == 0) dapx = fmaxf(dapx, 0.f);
                     a.cand_keys[qj[j] * (int64_t)a.cap + slot_c] = make_key(dapx, (u32)row);
                   } else {
@@ -867,7 +897,8 @@ int32_t flat_mfma_search(Index& ix, const float* dq, int64_t nq, int k, u64* run
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_filter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * 32768 + BM * sizeof(float)));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_filter_kernel_v2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * 49152 + BM2 * sizeof(float)));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_filter_kernel_v3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * 65536 + 2 * 256 * sizeof(float)));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_filter_kernel_v3<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * 65536 + 2 * 256 * sizeof(float)));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_filter_kernel_v3<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * 65536 + 2 * 256 * sizeof(float)));
     attr_set = true;
   }
   bool first = true;
@@ -891,7 +922,10 @@ int32_t flat_mfma_search(Index& ix, const float* dq, int64_t nq, int k, u64* run
     } else {
       FilterArgs f3 = fa;
       f3.tiles_q = (int)(b_pad / BN3);
-      hipLaunchKernelGGL(mfma_filter_kernel_v3, dim3((unsigned)num_cus), dim3(512), shm, s, f3);
+      if (f3.ablate)
+        hipLaunchKernelGGL(mfma_filter_kernel_v3<true>, dim3((unsigned)num_cus), dim3(512), shm, s, f3);
+      else
+        hipLaunchKernelGGL(mfma_filter_kernel_v3<false>, dim3((unsigned)num_cus), dim3(512), shm, s, f3);
     }
     if (biggest) (void)hipEventRecord(ix.evk1_, s);
     hipLaunchKernelGGL(count_overflow_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, cnt, nq, cap, overflow);
@@ -930,7 +964,7 @@ int32_t flat_mfma_search(Index& ix, const float* dq, int64_t nq, int k, u64* run
   ix.stats_.main_kernel_launches = 1;
   if (h.overflow) {
     ix.stats_.overflow_queries += h.overflow;
-    if (!approx) return ix.flat_stream(dq, nq, k, 0, n, run_keys, false);  // exact fallback for the (rare) overflow case
+    if (!approx && !fa.ablate) return ix.flat_stream(dq, nq, k, 0, n, run_keys, false);  // exact fallback for the (rare) overflow case
   }
   return EPS_OK;
 }
