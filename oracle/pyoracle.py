@@ -309,6 +309,7 @@ class Ref:
         L.ref_db_swap_executors.argtypes = [vp]
         L.ref_db_search.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, fptr, i64, i64, C.c_char_p,
                                     C.c_int, C.c_char_p, i64]
+        L.ref_db_get.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, i64, i64, C.c_char_p, i64]
 
     def l2sqr(self, x, y):
         return float(self.L.ref_fvec_L2sqr(_f(x), _f(y), len(x)))
@@ -410,6 +411,13 @@ class Ref:
             buf = C.create_string_buffer(cap)
             rc = self.r.L.ref_db_search(self.h, self.name, table.encode(), field.encode(), ",".join(fields).encode(),
                                         _f(q), len(q), limit, flt.encode(), int(with_distance), buf, cap)
+            txt = buf.value.decode()
+            return rc, (json.loads(txt) if rc == 0 else txt)
+
+        def get(self, table, fields=("ID",), pks=None, flt="", skip=0, limit=1000, cap=1 << 24):
+            buf = C.create_string_buffer(cap)
+            rc = self.r.L.ref_db_get(self.h, self.name, table.encode(), ",".join(fields).encode(),
+                                     json.dumps(pks or []).encode(), flt.encode(), skip, limit, buf, cap)
             txt = buf.value.decode()
             return rc, (json.loads(txt) if rc == 0 else txt)
 

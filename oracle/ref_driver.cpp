@@ -303,6 +303,40 @@ int ref_db_search(void* h, const char* db, const char* table, const char* field,
   return st.code();
 }
 
+// DBServer::Project (the "get" path: VecSearchExecutor::SearchByAttribute underneath, no vector arithmetic).
+int ref_db_get(void* h, const char* db, const char* table, const char* fields_csv, const char* pk_json, const char* filter,
+               int64_t skip, int64_t limit, char* out, int64_t cap) {
+  std::vector<std::string> fields;
+  std::string cur;
+  for (const char* p = fields_csv; *p; ++p) {
+    if (*p == ',') {
+      if (!cur.empty()) fields.push_back(cur);
+      cur.clear();
+    } else {
+      cur.push_back(*p);
+    }
+  }
+  if (!cur.empty()) fields.push_back(cur);
+  vectordb::Json pks, result, facets_cfg, facets;
+  pks.LoadFromString(pk_json && *pk_json ? pk_json : "[]");
+  facets_cfg.LoadFromString("[]");
+  vectordb::Status st;
+  std::string s;
+  try {
+    st = static_cast<vectordb::engine::DBServer*>(h)->Project(db, table, fields, pks, filter, skip, limit, result, facets_cfg, facets);
+    s = st.ok() ? result.DumpToString() : st.message();
+  } catch (const std::exception& e) {
+    st = vectordb::Status(vectordb::INFRA_UNEXPECTED_ERROR, e.what());
+    s = e.what();
+  }
+  if (cap > 0) {
+    size_t n = std::min<size_t>(s.size(), (size_t)cap - 1);
+    memcpy(out, s.data(), n);
+    out[n] = 0;
+  }
+  return st.code();
+}
+
 int ref_omp_max_threads() { return omp_get_max_threads(); }
 
 }  // extern "C"

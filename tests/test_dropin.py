@@ -56,6 +56,34 @@ def test_reference_dbms_compiles_and_links_against_dropin_headers(dropin):
     db.close()
 
 
+@pytest.mark.skipif(not ref_available(), reason="needs oracle/_ref")
+def test_search_by_attribute_matches_reference(dropin, tmp_path):
+    """CPU: DBServer::Project -> VecSearchExecutor::SearchByAttribute (vec_search_executor.cpp:937-1033) has no vector
+    arithmetic; the drop-in's host implementation must return what the reference returns: primary-key lists, filters,
+    skip/limit windows, deleted rows."""
+    ref = Ref()
+    schema = {"name": "T", "fields": [{"name": "ID", "dataType": "INT", "primaryKey": True},
+                                       {"name": "Tag", "dataType": "STRING"},
+                                       {"name": "V", "dataType": "VECTOR_FLOAT", "dimensions": 4, "metricType": "EUCLIDEAN"}]}
+    X = data(300, 4, 3)
+    recs = [{"ID": int(i), "Tag": "t%d" % (i % 5), "V": [float(x) for x in X[i]]} for i in range(300)]
+    dbs = []
+    for lib, name in ((ref, "ref"), (dropin, "drop")):
+        db = lib.db(str(tmp_path / name))
+        assert db.create_table(schema) == 0 and db.insert("T", recs) == 0
+        assert db.delete("T", [7, 8, 9, 200]) == 0
+        dbs.append(db)
+    cases = [dict(), dict(flt="ID < 50"), dict(flt="Tag = 't3' AND ID >= 100"), dict(skip=10, limit=25),
+             dict(flt="ID > 5", skip=3, limit=7), dict(pks=[5, 7, 250, 9999, 12]), dict(pks=[250, 5], flt="ID < 100"),
+             dict(limit=0), dict(skip=1000, limit=10)]
+    for kw in cases:
+        a = dbs[0].get("T", fields=("ID", "Tag"), **kw)
+        b = dbs[1].get("T", fields=("ID", "Tag"), **kw)
+        assert a == b, (kw, a, b)
+    for db in dbs:
+        db.close()
+
+
 @pytest.mark.gpu
 def test_gtest_DenseVector_through_dropin(dropin, tmp_path):
     """DbServer.DenseVector (db_server.cpp:92-319): three metrics, expected orderings :289-292, before and after

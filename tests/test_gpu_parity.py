@@ -406,3 +406,67 @@ def test_graph_search_large_batch_slices(amd, oracle):
     for qi in range(1500):
         assert_topk_match(ids[qi], dist[qi], z["ids_m0"][qi % 16][:10], z["dist_m0"][qi % 16][:10], what="q%d" % qi)
     ix.close()
+
+
+# ----------------------------------------------------------------------------------------------- edge cases
+def test_edge_empty_and_tiny_tables(amd, oracle):
+    ix = amd.GpuIndex(8, 0)
+    ix.attach_rows(np.zeros((0, 8), np.float32))
+    ids, dist, cnt = ix.search(data(3, 8, 1), 5)
+    assert list(cnt) == [0, 0, 0] and np.all(ids == -1) and np.all(np.isinf(dist))
+    X = data(3, 8, 2)
+    ix.attach_rows(X)
+    ids, dist, cnt = ix.search(data(2, 8, 3), 10)             # k > n
+    assert list(cnt) == [3, 3] and np.all(ids[:, 3:] == -1)
+    ix.set_deleted(np.array([0b111], np.uint8))               # everything deleted
+    ids, dist, cnt = ix.search(data(2, 8, 3), 10)
+    assert list(cnt) == [0, 0]
+    ix.set_deleted(None)
+    ix.set_int_filter(np.arange(3, dtype=np.int64), ">", 100)  # filter passes nothing
+    assert list(ix.search(data(2, 8, 3), 10)[2]) == [0, 0]
+    ix.close()
+
+
+@pytest.mark.parametrize("d", [1, 3, 5, 2048, 4096, 8192])
+def test_edge_dimensions(amd, oracle, d):
+    n = 300 if d > 1000 else 2000
+    X = data(n, d, d) - 0.5                                     # negative values too
+    Q = data(3, d, d + 1) - 0.5
+    for metric in (0, 2):
+        ix = amd.GpuIndex(d, metric)
+        ix.attach_rows(X)
+        ids, dist, cnt = ix.search(Q, 7, mode=amd.MODE_FLAT)
+        for qi in range(3):
+            rid, rd = oracle.topk_flat(metric, X, Q[qi], 7)
+            assert_topk_match(ids[qi], dist[qi], rid, rd, rtol=2e-4, atol=2e-5, what="d=%d m=%d" % (d, metric))
+        ix.close()
+
+
+def test_edge_nan_query_does_not_hang(amd):
+    """A zero COSINE query normalises to NaN in the reference (vector.cpp:60-69); the scan must still terminate."""
+    X = data(5000, 16, 1)
+    q = amd.normalize_rows(np.zeros((1, 16), np.float32), only_if_nonzero=False)
+    assert np.isnan(q).all()
+    ix = amd.GpuIndex(16, 1)
+    ix.attach_rows(X)
+    ids, dist, cnt = ix.search(q, 5, mode=amd.MODE_FLAT)
+    assert cnt[0] in (0, 5)
+    ix.close()
+
+
+def test_append_rows_and_tail_search(amd, oracle):
+    """Rows inserted after the last rebuild are searched through the brute-force tail (:885-900): graph over the first
+    1000 rows, two appends, result must equal the oracle's Search() on the same graph."""
+    z = np.load(os.path.join(G, "dbserver1500x8.npz"))
+    off, nbr, nav = z["off"].astype(np.int64), z["nbr"].astype(np.int64), int(z["nav"])
+    X, Q = data(1500, 8, 15), data(8, 8, 16)
+    ix = amd.GpuIndex(8, 0)
+    ix.attach_rows(X[:1000])
+    ix.set_graph(off, nbr, nav)
+    ix.append_rows(X[1000:1200])
+    ix.append_rows(X[1200:])
+    assert ix.row_count == 1500
+    ids, dist, cnt = ix.search(Q, 10, mode=amd.MODE_REFERENCE, intra_threads=1)
+    for qi in range(8):
+        assert_topk_match(ids[qi], dist[qi], z["plain_k10_ids"][qi], z["plain_k10_dist"][qi])
+    ix.close()

@@ -90,9 +90,12 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(FlatScanArgs a) {
 }
 
 static int pick_kpl(int k) { return k <= 64 ? 1 : k <= 128 ? 2 : k <= 256 ? 4 : k <= 512 ? 8 : 16; }
-static int pick_nq(int64_t nq, int k) {
+static int pick_nq(int64_t nq, int k, int dim) {
   if (k > 128) return 1;
-  return nq >= 3 ? 4 : (nq == 2 ? 2 : 1);
+  int want = nq >= 3 ? 4 : (nq == 2 ? 2 : 1);
+  // the NQ queries are staged in LDS: keep NQ * dim floats within 64 KB
+  while (want > 1 && (size_t)want * ((dim + 3) & ~3) * sizeof(float) > 65536) want >>= 1;
+  return want;
 }
 
 int flat_scan_waves(int64_t nrows, int64_t nq, int dim) {
@@ -124,7 +127,7 @@ void launch_flat_scan(const FlatScanArgs& a, hipStream_t s) {
   if (a.nq <= 0 || a.row_end <= a.row_begin) return;
   const bool vec4 = (a.dim % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.rows) & 15) == 0);
   const int kpl = pick_kpl(a.k);
-  const int nq = pick_nq(a.nq, a.k);
+  const int nq = pick_nq(a.nq, a.k, a.dim);
 #define EPS_CASE(NQ_, KPL_) \
   if (nq == NQ_ && kpl == KPL_) return launch_flat_scan_t<NQ_, KPL_>(a, vec4, s);
   EPS_CASE(1, 1) EPS_CASE(2, 1) EPS_CASE(4, 1)

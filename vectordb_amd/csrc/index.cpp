@@ -479,7 +479,7 @@ void eps_default_build_params(eps_build_params* p) {
 int32_t eps_index_create(int64_t dim, int32_t metric, int32_t device, eps_index** out) {
   if (!out) return EPS_USER_ERROR;
   *out = nullptr;
-  if (dim <= 0 || dim > 65536 || metric < 0 || metric > 2) return EPS_USER_ERROR;
+  if (dim <= 0 || dim > 8192 || metric < 0 || metric > 2) return EPS_USER_ERROR;  // one query must fit in LDS next to the queues
   Index* ix = new Index(dim, metric, device);
   const int32_t rc = ix->init();
   if (rc != EPS_OK) {
