@@ -8,7 +8,10 @@
 #include "db/execution/vec_search_executor.hpp"
 
 #include <algorithm>
+#include <condition_variable>
+#include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <stdexcept>
@@ -25,8 +28,35 @@ using vectordb::query::expr::ExprEvaluator;
 using vectordb::query::expr::ExprNodePtr;
 using vectordb::query::expr::NodeType;
 
+// One in-flight Search() call waiting to be served by the micro-batcher.
+struct Pending {
+  const float* query;
+  vectordb::engine::TableSegmentMVP* segment;
+  int32_t k;
+  // executor state the batch must agree on
+  const void* graph_owner;
+  int64_t graph_n, start_point;
+  int64_t* off;
+  int64_t* nbr;
+  int T;
+  int64_t L, Lq, I;
+  bool prefilter;
+  // results
+  std::vector<int64_t> ids;
+  std::vector<float> dist;
+  int32_t count = 0;
+  bool done = false;
+  std::string error;
+};
+
 struct DeviceField {
   std::mutex mu;
+  // micro-batcher: concurrent Search() calls of the pool's executors are coalesced into one
+  // eps_index_search with nq > 1 by whichever caller finds the device idle
+  std::mutex qmu;
+  std::condition_variable qcv;
+  std::deque<Pending*> queue;
+  bool busy = false;
   eps_index* h = nullptr;
   const float* column = nullptr;
   int64_t dim = 0;
@@ -122,6 +152,12 @@ Status VecSearchExecutor::Search(const VectorPtr query_data, vectordb::engine::T
   if (!dev_) throw std::runtime_error("no usable gfx950 device (libepsilla_gfx950 has no CPU fallback)");
   if (limit == 0) return Status::OK();
   DeviceField& dev = *dev_;
+  {
+    const int root0 = static_cast<int>(filter_nodes.size()) - 1;
+    const bool unfiltered = root0 < 0 || (filter_nodes[root0]->node_type == NodeType::BoolConst && filter_nodes[root0]->bool_value);
+    static const bool batching = !(getenv("EPS_DROPIN_BATCH") && atoi(getenv("EPS_DROPIN_BATCH")) == 0);
+    if (unfiltered && batching) return SearchBatched(std::get<DenseVectorPtr>(query_data), table_segment, limit, result_size);
+  }
   std::lock_guard<std::mutex> lk(dev.mu);
   auto fail = [&](const char* what) -> Status {
     throw std::runtime_error(std::string("gfx950 executor: ") + what + ": " + eps_index_last_error(dev.h));
@@ -217,6 +253,118 @@ Status VecSearchExecutor::Search(const VectorPtr query_data, vectordb::engine::T
     distance_[i] = dist[i];
   }
   result_size = count;
+  return Status::OK();
+}
+
+
+// ---- micro-batched path for unfiltered queries -------------------------------------------------------------------
+namespace {
+bool SameKey(const Pending& a, const Pending& b) {
+  return a.segment == b.segment && a.k == b.k && a.graph_owner == b.graph_owner && a.graph_n == b.graph_n && a.T == b.T &&
+         a.L == b.L && a.Lq == b.Lq && a.I == b.I && a.prefilter == b.prefilter;
+}
+
+void RunBatch(DeviceField& dev, int64_t dim, std::vector<Pending*>& batch) {
+  std::lock_guard<std::mutex> lk(dev.mu);
+  Pending& h = *batch[0];
+  std::string err;
+  auto fail = [&](const char* what) { err = std::string("gfx950 executor: ") + what + ": " + eps_index_last_error(dev.h); };
+  const int64_t total_vector = h.segment->record_number_;
+  if (total_vector > dev.attached) {
+    const int32_t rc = dev.attached == 0 ? eps_index_attach_rows(dev.h, dev.column, total_vector)
+                                         : eps_index_append_rows(dev.h, dev.column + dev.attached * dim, total_vector - dev.attached);
+    if (rc != EPS_OK) fail("row upload"); else dev.attached = total_vector;
+  }
+  if (err.empty() && (dev.graph_owner != h.graph_owner || dev.graph_n != h.graph_n)) {
+    if (eps_index_set_graph(dev.h, h.graph_n, h.off, h.nbr, h.start_point) != EPS_OK) fail("graph upload");
+    else { dev.graph_owner = h.graph_owner; dev.graph_n = h.graph_n; }
+  }
+  ConcurrentBitset& deleted = *(h.segment->deleted_);
+  if (err.empty() && eps_index_set_int_filter(dev.h, nullptr, 0, 0, EPS_OP_NONE, 0) != EPS_OK) fail("filter reset");
+  if (err.empty() && eps_index_set_deleted(dev.h, deleted.data(), (int64_t)deleted.size()) != EPS_OK) fail("deleted upload");
+  const int64_t nq = (int64_t)batch.size();
+  const int32_t k = h.k;
+  std::vector<float> q((size_t)nq * dim);
+  std::vector<int64_t> ids((size_t)nq * k);
+  std::vector<float> dist((size_t)nq * k);
+  std::vector<int32_t> cnt((size_t)nq);
+  for (int64_t i = 0; i < nq; ++i) std::memcpy(&q[(size_t)i * dim], batch[i]->query, sizeof(float) * dim);
+  if (err.empty()) {
+    eps_search_params p;
+    eps_default_search_params(&p);
+    p.mode = EPS_MODE_REFERENCE;
+    p.prefilter = h.prefilter ? 1 : 0;
+    p.intra_threads = h.T;
+    p.master_queue = h.L;
+    p.local_queue = h.Lq;
+    p.sync_interval = h.I;
+    if (eps_index_search(dev.h, q.data(), nq, k, &p, ids.data(), dist.data(), cnt.data()) != EPS_OK) fail("search");
+  }
+  for (int64_t i = 0; i < nq; ++i) {
+    Pending& r = *batch[i];
+    r.error = err;
+    if (err.empty()) {
+      r.count = cnt[i];
+      r.ids.assign(ids.begin() + i * k, ids.begin() + i * k + cnt[i]);
+      r.dist.assign(dist.begin() + i * k, dist.begin() + i * k + cnt[i]);
+    }
+  }
+}
+}  // namespace
+
+Status VecSearchExecutor::SearchBatched(const float* query, vectordb::engine::TableSegmentMVP* table_segment, size_t limit,
+                                        int64_t& result_size) {
+  DeviceField& dev = *dev_;
+  Pending me;
+  me.query = query;
+  me.segment = table_segment;
+  me.k = (int32_t)std::min<size_t>(limit, 1024);
+  me.graph_owner = ann_index_.get();
+  me.graph_n = total_indexed_vector_;
+  me.start_point = start_search_point_;
+  me.off = offset_table_;
+  me.nbr = neighbor_list_;
+  me.T = num_threads_;
+  me.L = L_master_;
+  me.Lq = L_local_;
+  me.I = subsearch_iterations_;
+  me.prefilter = prefilter_enabled_;
+  std::unique_lock<std::mutex> lk(dev.qmu);
+  dev.queue.push_back(&me);
+  while (!me.done) {
+    if (dev.busy) {  // somebody is driving the device: wait until served, or until the device is free again
+      dev.qcv.wait(lk, [&] { return me.done || !dev.busy; });
+      continue;
+    }
+    dev.busy = true;  // become the leader: serve the head of the queue and everything compatible with it
+    std::vector<Pending*> batch;
+    Pending* head = dev.queue.front();
+    for (auto it = dev.queue.begin(); it != dev.queue.end() && batch.size() < 256;) {
+      if (SameKey(**it, *head)) {
+        batch.push_back(*it);
+        it = dev.queue.erase(it);
+      } else {
+        ++it;
+      }
+    }
+    lk.unlock();
+    RunBatch(dev, dimension_, batch);
+    lk.lock();
+    for (Pending* r : batch) r->done = true;
+    dev.busy = false;
+    dev.qcv.notify_all();
+  }
+  lk.unlock();
+  if (!me.error.empty()) throw std::runtime_error(me.error);
+  if ((size_t)me.count > search_result_.size()) {
+    search_result_.resize(me.count);
+    distance_.resize(me.count);
+  }
+  for (int32_t i = 0; i < me.count; ++i) {
+    search_result_[i] = me.ids[i];
+    distance_[i] = me.dist[i];
+  }
+  result_size = me.count;
   return Status::OK();
 }
 

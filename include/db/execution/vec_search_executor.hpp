@@ -77,6 +77,8 @@ class VecSearchExecutor {
                            std::vector<vectordb::query::expr::ExprNodePtr>& filter_nodes, int64_t& result_size);
 
  private:
+  // unfiltered queries: coalesced with the concurrent calls of the pool's other executors into one device batch
+  Status SearchBatched(const float* query, vectordb::engine::TableSegmentMVP* table_segment, size_t limit, int64_t& result_size);
   std::shared_ptr<DeviceField> dev_;
   int metric_ = 0;
 };

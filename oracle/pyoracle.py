@@ -309,6 +309,8 @@ class Ref:
         L.ref_db_swap_executors.argtypes = [vp]
         L.ref_db_search.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, fptr, i64, i64, C.c_char_p,
                                     C.c_int, C.c_char_p, i64]
+        L.ref_db_search_mt.restype = C.c_double
+        L.ref_db_search_mt.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, fptr, i64, i64, i64, C.c_int, iptr]
         L.ref_db_get.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, i64, i64, C.c_char_p, i64]
 
     def l2sqr(self, x, y):
@@ -413,6 +415,14 @@ class Ref:
                                         _f(q), len(q), limit, flt.encode(), int(with_distance), buf, cap)
             txt = buf.value.decode()
             return rc, (json.loads(txt) if rc == 0 else txt)
+
+        def search_mt(self, table, field, Q, limit, threads):
+            """Q.shape[0] single-vector Search calls from `threads` client threads; returns (seconds, best ids)."""
+            Q = np.ascontiguousarray(Q, np.float32)
+            first = np.empty(Q.shape[0], np.int64)
+            sec = self.r.L.ref_db_search_mt(self.h, self.name, table.encode(), field.encode(), _f(Q), Q.shape[0], Q.shape[1],
+                                            limit, threads, _i(first))
+            return sec, first
 
         def get(self, table, fields=("ID",), pks=None, flt="", skip=0, limit=1000, cap=1 << 24):
             buf = C.create_string_buffer(cap)

@@ -19,6 +19,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -335,6 +336,39 @@ int ref_db_get(void* h, const char* db, const char* table, const char* fields_cs
     out[n] = 0;
   }
   return st.code();
+}
+
+// nq single-vector DBServer::Search calls issued from `threads` client threads (what concurrent REST requests do);
+// first_ids[q] = "ID" of the best hit of query q (or -1).  Returns elapsed seconds, or -1 on error.
+double ref_db_search_mt(void* h, const char* db, const char* table, const char* field, float* queries, int64_t nq, int64_t d,
+                        int64_t limit, int threads, int64_t* first_ids) {
+  auto* srv = static_cast<vectordb::engine::DBServer*>(h);
+  std::atomic<int64_t> next{0};
+  std::atomic<int> bad{0};
+  auto worker = [&]() {
+    std::string f(field);
+    std::vector<std::string> fields{"ID"};
+    for (;;) {
+      const int64_t q = next.fetch_add(1);
+      if (q >= nq) break;
+      vectordb::Json result, facets_cfg, facets;
+      facets_cfg.LoadFromString("[]");
+      try {
+        auto st = srv->Search(db, table, f, fields, d, queries + q * d, limit, result, "", true, facets_cfg, facets);
+        if (!st.ok()) bad++;
+        first_ids[q] = result.GetSize() > 0 ? result.GetArrayElement(0).GetInt("ID") : -1;
+      } catch (const std::exception&) {
+        bad++;
+        first_ids[q] = -1;
+      }
+    }
+  };
+  auto t0 = std::chrono::steady_clock::now();
+  std::vector<std::thread> pool;
+  for (int t = 0; t < threads; ++t) pool.emplace_back(worker);
+  for (auto& t : pool) t.join();
+  const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return bad.load() ? -1.0 : sec;
 }
 
 int ref_omp_max_threads() { return omp_get_max_threads(); }

@@ -196,3 +196,38 @@ def test_dropin_matches_reference_dbserver_on_random_data(dropin, tmp_path):
         db.close()
     ref.L.ref_config(4, 500, 1, 0, 16)
     dropin.L.ref_config(4, 500, 1, 0, 16)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not ref_available(), reason="needs oracle/_ref")
+def test_concurrent_clients_are_micro_batched_and_match_reference(dropin, tmp_path):
+    """16 client threads issuing single-vector DBServer::Search calls (what concurrent REST requests do): the drop-in
+    coalesces them into device batches; every answer must equal the reference DBServer's answer to the same query,
+    before and after a rebuild (flat and graph + tail)."""
+    ref = Ref()
+    schema = {"name": "T", "fields": [{"name": "ID", "dataType": "INT", "primaryKey": True},
+                                       {"name": "V", "dataType": "VECTOR_FLOAT", "dimensions": 24, "metricType": "EUCLIDEAN"}]}
+    X = data(3000, 24, 31)
+    recs = [{"ID": int(i) + 7, "V": [float(x) for x in X[i]]} for i in range(3000)]
+    Q = data(400, 24, 32)
+    dbs = []
+    for lib, name in ((ref, "ref"), (dropin, "drop")):
+        lib.L.ref_config(1, 500, 1, 0, 2)
+        db = lib.db(str(tmp_path / name))
+        assert db.create_table(schema) == 0 and db.insert("T", recs[:2500]) == 0
+        dbs.append(db)
+    for phase in range(2):
+        sec_r, first_r = dbs[0].search_mt("T", "V", Q, 5, 4)
+        sec_d, first_d = dbs[1].search_mt("T", "V", Q, 5, 16)
+        assert sec_r >= 0 and sec_d >= 0
+        assert (first_r == first_d).all(), phase
+        # a filtered request in between takes the unbatched path and must still be served
+        rc, res = dbs[1].search("T", "V", Q[0], 3, fields=("ID",), flt="ID < 100")
+        assert rc == 0 and all(r["ID"] < 100 for r in res)
+        if phase == 0:
+            for db in dbs:
+                assert db.rebuild() == 0 and db.insert("T", recs[2500:]) == 0
+    for db in dbs:
+        db.close()
+    ref.L.ref_config(4, 500, 1, 0, 16)
+    dropin.L.ref_config(4, 500, 1, 0, 16)
