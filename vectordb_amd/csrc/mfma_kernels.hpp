@@ -1,0 +1,830 @@
+// The batched-flat-scan filter kernels (v1, v2, v3) of mfma_filter.hip, in a header so that the kernel lab
+// (scripts/lab/mfma_lab.hip) can time experimental variants beside them.  See mfma_filter.hip for the method.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "device_common.hpp"
+
+namespace eps {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 64;   // v1 tile
+constexpr int BM2 = 256;                      // v2 row tile (256 rows x 128 queries, 8 wavefronts)
+constexpr int ROWPAD = 256;                   // mirror rows are padded to this
+
+// ------------------------------------------------------------------------------------------------ filter kernel
+struct FilterArgs {
+  const _Float16* xh;   // [n_pad][d_pad]
+  const _Float16* qh;   // [b_pad][d_pad]
+  const _Float16* qf;   // fragment-major copy of qh: [b_pad/32][d_pad/16][64 lanes][8] (v5: query operand straight to VGPRs)
+  const float* base;    // [n_pad]
+  const float* base_s;  // [n_pad] base / s (v5: accumulators are initialised straight from it)
+  const float* T;       // [b_pad]
+  int d_pad;
+  int tiles_q;          // b_pad / BN
+  int64_t tile0;        // first row tile of this stage
+  int64_t ntiles;       // row tiles in this stage
+  int64_t row_hi;       // rows >= row_hi are not reported
+  int64_t nq;
+  float s;              // -2 (L2) or -1
+  u32* cand;
+  u64* cand_keys;       // approx mode: (approx dist, row) keys instead of row ids
+  const float* qstat;   // [b_pad][4] (approx mode: |q|^2 to turn keys into distances)
+  int metric;
+  u32* cnt;
+  int cap;
+  int ablate;           // profiling only (EPS_MFMA_ABLATE): v1: bit0 skip staging loads, bit1 skip MFMAs, bit2 skip LDS
+                        // fragment reads; v3: bit3 skip the query-operand DMA, bit4 skip the row-operand DMA
+};
+
+__device__ __forceinline__ int swz(int row, int chunk) { return (row << 3) + (chunk ^ ((row >> 1) & 7)); }  // 16-B granule index
+
+__global__ __launch_bounds__(256, 2) void mfma_filter_kernel(FilterArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  // layout: [2 stages][A 16 KB | B 16 KB] then base[128] floats
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware map: block b runs on XCD b%8; the tiles_q query tiles of a row tile are consecutive on one XCD
+  const int64_t bid = blockIdx.x;
+  const int xcd = (int)(bid & 7);
+  const int64_t local = bid >> 3;
+  const int qt = (int)(local % a.tiles_q);
+  const int64_t rt = (local / a.tiles_q) * 8 + xcd;
+  if (rt >= a.ntiles) return;
+  const int64_t row0 = (a.tile0 + rt) * BM;
+  const int64_t q0 = (int64_t)qt * BN;
+  const int ldk = a.d_pad;
+  const int KT = ldk / BK;
+
+  float* base_lds = reinterpret_cast<float*>(lds + 2 * 32768);
+  if (tid < BM) base_lds[tid] = a.base[row0 + tid];
+
+  const _Float16* gA = a.xh + row0 * ldk;
+  const _Float16* gB = a.qh + q0 * ldk;
+
+  // per-thread staging coordinates: 4 granules of A and 4 of B per K-tile
+  int g_row[4], g_chunk[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int s = it * 256 + tid;
+    g_row[it] = s >> 3;
+    g_chunk[it] = (s & 7) ^ ((g_row[it] >> 1) & 7);
+  }
+  auto stage = [&](int kt, int buf) {
+    unsigned char* dA = lds + buf * 32768;
+    unsigned char* dB = dA + 16384;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const _Float16* sa = gA + (int64_t)g_row[it] * ldk + kt * BK + g_chunk[it] * 8;
+      const _Float16* sb = gB + (int64_t)g_row[it] * ldk + kt * BK + g_chunk[it] * 8;
+      const int wbase = (it * 256 + wave * 64) * 16;  // wave-uniform LDS base; hardware adds lane*16
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sa,
+                                       (__attribute__((address_space(3))) void*)(dA + wbase), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sb,
+                                       (__attribute__((address_space(3))) void*)(dB + wbase), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int arow0 = wm * 64 + (lane & 31);
+  const int brow0 = wn * 64 + (lane & 31);
+  const int khalf = lane >> 5;
+
+  const bool ab_noload = a.ablate & 1, ab_nomfma = a.ablate & 2, ab_nolds = a.ablate & 4;
+  if (!ab_noload) stage(0, 0);
+  for (int kt = 0; kt < KT; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < KT && !ab_noload) stage(kt + 1, (kt + 1) & 1);
+    const unsigned char* sA = lds + (kt & 1) * 32768;
+    const unsigned char* sB = sA + 16384;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int chunk = kk * 2 + khalf;
+      half8 fa[2], fb[2];
+      if (!ab_nolds) {
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          fa[f] = *reinterpret_cast<const half8*>(sA + swz(arow0 + f * 32, chunk) * 16);
+          fb[f] = *reinterpret_cast<const half8*>(sB + swz(brow0 + f * 32, chunk) * 16);
+        }
+      } else {
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            fa[f][e] = (_Float16)(float)(kk + e);
+            fb[f][e] = (_Float16)(float)(lane + e);
+          }
+      }
+      if (!ab_nomfma) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          asm volatile("" ::"v"(fa[f]));
+          asm volatile("" ::"v"(fb[f]));
+        }
+      }
+    }
+  }
+
+  // epilogue: approx lower-bound key vs per-query threshold; survivors are appended to the candidate lists
+  float Tj[2], cj[2];
+  int64_t qj[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    qj[j] = q0 + wn * 64 + j * 32 + (lane & 31);
+    Tj[j] = a.T[qj[j]];
+    cj[j] = a.cand_keys ? (a.metric == 0 ? a.qstat[qj[j] * 4] : (a.metric == 1 ? 1.f : 0.f)) : 0.f;
+  }
+  __syncthreads();  // base_lds visible (first barrier of the K loop already ordered it; kept for KT == 0 safety)
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int rbase = wm * 64 + i * 32 + 4 * khalf;
+    float4 bv[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bv[g] = *reinterpret_cast<const float4*>(&base_lds[rbase + 8 * g]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bool any = false;
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float b = (r & 3) == 0 ? bv[r >> 2].x : (r & 3) == 1 ? bv[r >> 2].y : (r & 3) == 2 ? bv[r >> 2].z : bv[r >> 2].w;
+        v[r] = fmaf(acc[i][j][r], a.s, b);
+        any |= (v[r] <= Tj[j]);
+      }
+      if (__any(any)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (v[r] <= Tj[j]) {
+            const int64_t row = row0 + rbase + (r & 3) + 8 * (r >> 2);
+            if (row < a.row_hi && qj[j] < a.nq) {
+              const u32 slot = atomicAdd(&a.cnt[qj[j]], 1u);
+              if (slot < (u32)a.cap) {
+                if (a.cand_keys) {
+                  float dapx = v[r] + cj[j];
+                  if (a.metric == 0) dapx = fmaxf(dapx, 0.f);
+                  a.cand_keys[qj[j] * (int64_t)a.cap + slot] = make_key(dapx, (u32)row);
+                } else {
+                  a.cand[qj[j] * (int64_t)a.cap + slot] = (u32)row;
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------ v2 kernel
+// 256 rows x 128 queries per workgroup, 8 wavefronts (4 x 2) x 64x64 outputs, K-step 64, THREE LDS slots of 48 KB:
+// two K-tiles are always in flight (counted s_waitcnt vmcnt(6), raw s_barrier — a __syncthreads() would drain the
+// LDS-DMA queue to zero), so twice the bytes are outstanding per CU compared with v1 while the row tile is twice as
+// tall (170 flop per L2 byte instead of 128).
+__global__ __launch_bounds__(512, 2) void mfma_filter_kernel_v2(FilterArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int SLOT = 49152;  // A 256x128 B + B 128x128 B
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int64_t bid = blockIdx.x;
+  const int xcd = (int)(bid & 7);
+  const int64_t local = bid >> 3;
+  const int qt = (int)(local % a.tiles_q);
+  const int64_t rt = (local / a.tiles_q) * 8 + xcd;
+  if (rt >= a.ntiles) return;
+  const int64_t row0 = (a.tile0 + rt) * BM2;
+  const int64_t q0 = (int64_t)qt * BN;
+  const int ldk = a.d_pad;
+  const int KT = ldk / BK;
+
+  float* base_lds = reinterpret_cast<float*>(lds + 3 * SLOT);
+  if (tid < BM2) base_lds[tid] = a.base[row0 + tid];
+
+  const _Float16* gA = a.xh + row0 * ldk;
+  const _Float16* gB = a.qh + q0 * ldk;
+  // staging: A = 2048 granules (4 per thread), B = 1024 granules (2 per thread)
+  int a_row[4], a_chunk[4], b_row[2], b_chunk[2];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int s = it * 512 + tid;
+    a_row[it] = s >> 3;
+    a_chunk[it] = (s & 7) ^ ((a_row[it] >> 1) & 7);
+  }
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int s = it * 512 + tid;
+    b_row[it] = s >> 3;
+    b_chunk[it] = (s & 7) ^ ((b_row[it] >> 1) & 7);
+  }
+  auto stage = [&](int kt, int slot) {
+    unsigned char* dA = lds + slot * SLOT;
+    unsigned char* dB = dA + 32768;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const _Float16* sa = gA + (int64_t)a_row[it] * ldk + kt * BK + a_chunk[it] * 8;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sa,
+                                       (__attribute__((address_space(3))) void*)(dA + (it * 512 + wave * 64) * 16), 16, 0, 0);
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const _Float16* sb = gB + (int64_t)b_row[it] * ldk + kt * BK + b_chunk[it] * 8;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sb,
+                                       (__attribute__((address_space(3))) void*)(dB + (it * 512 + wave * 64) * 16), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int arow0 = wm * 64 + (lane & 31);
+  const int brow0 = wn * 64 + (lane & 31);
+  const int khalf = lane >> 5;
+
+  stage(0, 0);
+  if (KT > 1) stage(1, 1);
+  int slot = 0;
+  for (int kt = 0; kt < KT; ++kt) {
+    // tile kt has landed once at most the 6 loads of tile kt+1 are still outstanding
+    if (kt + 1 < KT)
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + 2 < KT) {
+      int ns = slot + 2;
+      if (ns >= 3) ns -= 3;
+      stage(kt + 2, ns);  // slot (kt+2)%3 == (kt-1)%3: every wave finished reading it before this barrier
+    }
+    const unsigned char* sA = lds + slot * SLOT;
+    const unsigned char* sB = sA + 32768;
+    // software pipeline over the four K=16 sub-steps: the fragments of sub-step kk+1 are read from LDS while the
+    // MFMAs of sub-step kk run (one wave per SIMD per block: nothing else hides the ds_read latency)
+    half8 fa[2][2], fb[2][2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      fa[0][f] = *reinterpret_cast<const half8*>(sA + swz(arow0 + f * 32, khalf) * 16);
+      fb[0][f] = *reinterpret_cast<const half8*>(sB + swz(brow0 + f * 32, khalf) * 16);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int cur = kk & 1, nxt = cur ^ 1;
+      if (kk < 3) {
+        const int chunk = (kk + 1) * 2 + khalf;
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          fa[nxt][f] = *reinterpret_cast<const half8*>(sA + swz(arow0 + f * 32, chunk) * 16);
+          fb[nxt][f] = *reinterpret_cast<const half8*>(sB + swz(brow0 + f * 32, chunk) * 16);
+        }
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    slot = slot + 1 == 3 ? 0 : slot + 1;
+  }
+
+  float Tj[2], cj[2];
+  int64_t qj[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    qj[j] = q0 + wn * 64 + j * 32 + (lane & 31);
+    Tj[j] = a.T[qj[j]];
+    cj[j] = a.cand_keys ? (a.metric == 0 ? a.qstat[qj[j] * 4] : (a.metric == 1 ? 1.f : 0.f)) : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int rbase = wm * 64 + i * 32 + 4 * khalf;
+    float4 bv[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bv[g] = *reinterpret_cast<const float4*>(&base_lds[rbase + 8 * g]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bool any = false;
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float b = (r & 3) == 0 ? bv[r >> 2].x : (r & 3) == 1 ? bv[r >> 2].y : (r & 3) == 2 ? bv[r >> 2].z : bv[r >> 2].w;
+        v[r] = fmaf(acc[i][j][r], a.s, b);
+        any |= (v[r] <= Tj[j]);
+      }
+      if (__any(any)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (v[r] <= Tj[j]) {
+            const int64_t row = row0 + rbase + (r & 3) + 8 * (r >> 2);
+            if (row < a.row_hi && qj[j] < a.nq) {
+              const u32 slot_c = atomicAdd(&a.cnt[qj[j]], 1u);
+              if (slot_c < (u32)a.cap) {
+                if (a.cand_keys) {
+                  float dapx = v[r] + cj[j];
+                  if (a.metric == 0) dapx = fmaxf(dapx, 0.f);
+                  a.cand_keys[qj[j] * (int64_t)a.cap + slot_c] = make_key(dapx, (u32)row);
+                } else {
+                  a.cand[qj[j] * (int64_t)a.cap + slot_c] = (u32)row;
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------ v3 kernel
+// Persistent form.  Ablation of v1 (profiles/r1_mfma_ablation.txt) showed the filter was bound by per-workgroup
+// latency, not by the matrix cores: a workgroup that lives for one 128x128 tile pays its launch + first-load latency
+// (~6 us) for 12 K-steps of work, and each K-step exposes one L2->LDS round trip.  v3 launches ONE workgroup per CU
+// (8 wavefronts, 2 x 4, each 128 rows x 64 queries = 4 x 2 tiles of v_mfma_f32_32x32x16_f16) that walks a list of
+// 256 x 256 tiles; the (tile, K-step) sequence is one software pipeline — the loads of step s+1 (possibly the next
+// tile's first K-step, plus its |x|^2 column) are issued right after the barrier of step s and land under the 32
+// MFMAs per wavefront of step s; the epilogue of a tile runs under the first loads of the next.  256 flop per L2
+// byte (v1: 128).  Tile order keeps the query tiles of one row tile on one XCD at the same time.
+constexpr int BM3 = 256, BN3 = 256;
+template <bool ABL>  // ABL: profiling build with the EPS_MFMA_ABLATE switches compiled in
+__global__ __launch_bounds__(512, 2) void mfma_filter_kernel_v3(FilterArgs a) {
+  const int ablate = ABL ? a.ablate : 0;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int SLOT = 65536;  // A 256 x 128 B | B 256 x 128 B
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int khalf = lane >> 5;
+  float* base_lds = reinterpret_cast<float*>(lds + 2 * SLOT);  // [2][256]
+
+  // work list of this workgroup
+  const int xcd = blockIdx.x & 7;
+  const int local = blockIdx.x >> 3;              // 0 .. gridDim/8-1 workgroups on this XCD
+  const int per_xcd = gridDim.x >> 3;
+  const int QTB = a.tiles_q < per_xcd ? a.tiles_q : per_xcd;
+  const int G = per_xcd / QTB;                    // row tiles in flight per XCD
+  const int qslot = local % QTB;
+  const int rg = local / QTB;
+  if (rg >= G) return;
+  // row tiles of this XCD: rt = xcd + 8*j; this workgroup takes j = rg, rg+G, ...; query tiles qt = qslot, qslot+QTB, ...
+  const int64_t nj = (a.ntiles - xcd + 7) / 8;    // row tiles on this XCD (may be <= 0)
+  const int nqt = (a.tiles_q - qslot + QTB - 1) / QTB;
+  const int64_t my_rows = nj > rg ? (nj - rg + G - 1) / G : 0;
+  const int64_t ntile = my_rows * nqt;
+  if (ntile <= 0) return;
+  const int ldk = a.d_pad;
+  const int KT = ldk / BK;
+
+  int g_off[4];  // element offset of this thread's granule `it` inside a K-step of a 256-row operand tile
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int s = it * 512 + tid;
+    const int row = s >> 3;
+    g_off[it] = row * ldk + ((s & 7) ^ ((row >> 1) & 7)) * 8;
+  }
+  auto tile_rt = [&](int64_t t) { return (int64_t)xcd + 8 * (rg + (t / nqt) * G); };
+  auto tile_qt = [&](int64_t t) { return qslot + (int)(t % nqt) * QTB; };
+  // operand bases of the tile being computed and of the tile whose first K-step is prefetched (one division per tile)
+  const _Float16 *gA_cur, *gB_cur, *gA_nx, *gB_nx;
+  const float* gbase_nx;
+  auto set_next = [&](int64_t t) {
+    const int64_t rt = tile_rt(t);
+    gA_nx = a.xh + (a.tile0 + rt) * BM3 * (int64_t)ldk;
+    gB_nx = a.qh + (int64_t)tile_qt(t) * BN3 * ldk;
+    gbase_nx = a.base + (a.tile0 + rt) * BM3;
+  };
+  // one quarter of a K-step's staging: piece `it` of A and of B
+  auto stage_piece = [&](const _Float16* gA, const _Float16* gB, int kt, int slot, int it) {
+    unsigned char* dA = lds + slot * SLOT;
+    unsigned char* dB = dA + 32768;
+    const int off = g_off[it] + kt * BK;
+    const int wbase = (it * 512 + wave * 64) * 16;
+    if (!(ablate & 16))
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gA + off),
+                                       (__attribute__((address_space(3))) void*)(dA + wbase), 16, 0, 0);
+    if (!(ablate & 8))
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB + off),
+                                       (__attribute__((address_space(3))) void*)(dB + wbase), 16, 0, 0);
+  };
+  auto stage_base = [&](const float* gb, int64_t t) {  // |x|^2 (or 0) column of the tile's 256 rows, wavefronts 0-3
+    if (wave < 4)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + wave * 64 + lane),
+                                       (__attribute__((address_space(3))) void*)(base_lds + (t & 1) * 256 + wave * 64), 4, 0, 0);
+  };
+
+  f32x16 acc[4][2];
+  const int arow0 = wm * 128 + (lane & 31);
+  const int brow0 = wn * 64 + (lane & 31);
+
+  // thresholds of this workgroup's query tile, loaded before any LDS-DMA is in flight (ordinary loads make the
+  // compiler wait vmcnt(0), which would drain the pipeline if done per tile)
+  const float inv_s = 1.0f / a.s;  // s = -2 (L2) or -1: exact
+  float Tq[2], cj[2];   // Tq = T/s: threshold in accumulator space (a row passes iff acc >= Tq)
+  int64_t qj[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    qj[j] = (int64_t)qslot * BN3 + wn * 64 + j * 32 + (lane & 31);
+    Tq[j] = a.T[qj[j]] * inv_s;
+    cj[j] = a.cand_keys ? (a.metric == 0 ? a.qstat[qj[j] * 4] : (a.metric == 1 ? 1.f : 0.f)) : 0.f;
+  }
+  set_next(0);
+#pragma unroll
+  for (int it = 0; it < 4; ++it) stage_piece(gA_nx, gB_nx, 0, 0, it);
+  stage_base(gbase_nx, 0);
+  int slot = 0;
+  for (int64_t t = 0; t < ntile; ++t) {
+    gA_cur = gA_nx;
+    gB_cur = gB_nx;
+    const int64_t row0 = (a.tile0 + tile_rt(t)) * BM3;
+    const int64_t q0 = (int64_t)tile_qt(t) * BN3;
+    if (t + 1 < ntile) set_next(t + 1);
+    // accumulators start at base/s (= -|x|^2/2 for L2, 0 otherwise; -inf on padding rows), so that the finished
+    // accumulator is (approx key)/s and the epilogue is one max + one compare per 16 outputs.  The |x|^2 column of
+    // this tile was staged with its first K-step; that step has not been waited for yet when t == 0 / a tile starts,
+    // so the init happens after the first barrier of the tile (kt == 0 below).
+    for (int kt = 0; kt < KT; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kt == 0) {
+        const float* bl0 = base_lds + (t & 1) * 256;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int rbase = wm * 128 + i * 32 + 4 * khalf;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float4 bv = *reinterpret_cast<const float4*>(&bl0[rbase + 8 * g]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              acc[i][j][4 * g + 0] = bv.x * inv_s;
+              acc[i][j][4 * g + 1] = bv.y * inv_s;
+              acc[i][j][4 * g + 2] = bv.z * inv_s;
+              acc[i][j][4 * g + 3] = bv.w * inv_s;
+            }
+          }
+        }
+      }
+      // next step of the (tile, K-step) stream; its staging is spread over the four K=16 sub-steps below so that the
+      // DMA issue cost of one wavefront overlaps the MFMAs of the wavefront sharing its SIMD
+      const bool same = kt + 1 < KT;
+      const bool more = same || (t + 1 < ntile);
+      const _Float16* pA = same ? gA_cur : gA_nx;
+      const _Float16* pB = same ? gB_cur : gB_nx;
+      const int nk_ = same ? kt + 1 : 0;
+      const unsigned char* sA = lds + slot * SLOT;
+      const unsigned char* sB = sA + 32768;
+      // fragments of sub-step kk+1 are read from LDS while the MFMAs of sub-step kk issue (register double buffer)
+      half8 fa[2][4], fb[2][2];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) fa[0][f] = *reinterpret_cast<const half8*>(sA + swz(arow0 + f * 32, khalf) * 16);
+#pragma unroll
+      for (int f = 0; f < 2; ++f) fb[0][f] = *reinterpret_cast<const half8*>(sB + swz(brow0 + f * 32, khalf) * 16);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int cur = kk & 1, nxt = cur ^ 1;
+        if (kk < 3 && !(ablate & 4)) {
+          const int chunk = (kk + 1) * 2 + khalf;
+#pragma unroll
+          for (int f = 0; f < 4; ++f) fa[nxt][f] = *reinterpret_cast<const half8*>(sA + swz(arow0 + f * 32, chunk) * 16);
+#pragma unroll
+          for (int f = 0; f < 2; ++f) fb[nxt][f] = *reinterpret_cast<const half8*>(sB + swz(brow0 + f * 32, chunk) * 16);
+        }
+        if (more) {
+          stage_piece(pA, pB, nk_, slot ^ 1, kk);
+          if (kk == 0 && !same) stage_base(gbase_nx, t + 1);
+        }
+        if (!(ablate & 2)) {
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+          __builtin_amdgcn_s_setprio(0);
+        } else {
+#pragma unroll
+          for (int f = 0; f < 4; ++f) asm volatile("" ::"v"(fa[cur][f]));
+#pragma unroll
+          for (int f = 0; f < 2; ++f) asm volatile("" ::"v"(fb[cur][f]));
+        }
+      }
+      slot ^= 1;
+    }
+    // ---- epilogue of tile t (the first K-step of tile t+1 is already in flight)
+    if (nqt > 1) {  // the query tile changes between tiles: reload its thresholds (ordinary loads: drains the DMA queue once)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        qj[j] = q0 + wn * 64 + j * 32 + (lane & 31);
+        Tq[j] = a.T[qj[j]] * inv_s;
+        cj[j] = a.cand_keys ? (a.metric == 0 ? a.qstat[qj[j] * 4] : (a.metric == 1 ? 1.f : 0.f)) : 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rbase = wm * 128 + i * 32 + 4 * khalf;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        // pass  <=>  s*acc <= T  <=>  acc >= T/s  (s < 0): one running max over the 16 outputs of this lane
+        float mx = acc[i][j][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[i][j][r]);
+        if (__any(mx >= Tq[j])) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            if (acc[i][j][r] >= Tq[j]) {
+              const int64_t row = row0 + rbase + (r & 3) + 8 * (r >> 2);
+              if (row < a.row_hi && qj[j] < a.nq && !ablate) {
+                const u32 slot_c = atomicAdd(&a.cnt[qj[j]], 1u);
+                if (slot_c < (u32)a.cap) {
+                  if (a.cand_keys) {
+                    float dapx = acc[i][j][r] * a.s + cj[j];
+                    if (a.metric == 0) dapx = fmaxf(dapx, 0.f);
+                    a.cand_keys[qj[j] * (int64_t)a.cap + slot_c] = make_key(dapx, (u32)row);
+                  } else {
+                    a.cand[qj[j] * (int64_t)a.cap + slot_c] = (u32)row;
+                  }
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ v5 kernel
+// 256 x 256 tile per workgroup as v3, but (measured in scripts/lab, profiles/r1_mfma_lab.txt):
+//  * the QUERY operand never touches LDS: it is pre-packed fragment-major (a.qf: one coalesced 1-KiB
+//    global_load_dwordx4 per 32-query x K=16 fragment, L2-resident) and prefetched two K-steps ahead into a 2-deep
+//    register ring; wavefront w owns queries [32w, 32w+32) x all 256 rows = 8 x 1 tiles of v_mfma_f32_32x32x16_f16;
+//  * the ROW operand streams through a 4-slot LDS ring (32 KB per K=64 step) by LDS-DMA with COUNTED waits: two to
+//    three steps are always in flight and the queue never drains at a step boundary (v3: vmcnt(0) every step); a slot is
+//    published one step before it is consumed so the first fragments of a step are read across the barrier;
+//  * fragment reads and fragment loads are hand-issued (inline asm) and waited for by count - hipcc's own waitcnt
+//    insertion drains the queues (vmcnt(0) at the loop head, lgkmcnt(0) after every other fragment group);
+//  * the loop body has no branches: steps past the end re-read the last tile;
+//  * the second wavefront of each SIMD runs at s_setprio 1 so the pair de-phases (one reads while the other multiplies).
+// Requires d_pad % 128 == 0 and d_pad >= 256 (K-steps come in pairs: the register ring is indexed by step parity).
+#define EPS_DS_READ_B128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define EPS_GLOAD_B128(dst, voff, sbase, off) \
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(off))
+__global__ __launch_bounds__(512, 2) void mfma_filter_kernel_v5(FilterArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int ASLOT = 32768;  // 256 rows x 128 B
+  constexpr int RING = 4;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: lets the fragment stream base live in SGPRs
+  const int khalf = lane >> 5;
+  const int l31 = lane & 31;
+  float* base_lds = reinterpret_cast<float*>(lds + RING * ASLOT);  // [2][256]
+
+  const int xcd = blockIdx.x & 7;
+  const int local = blockIdx.x >> 3;
+  const int per_xcd = gridDim.x >> 3;
+  const int QTB = a.tiles_q < per_xcd ? a.tiles_q : per_xcd;
+  const int G = per_xcd / QTB;
+  const int qslot = local % QTB;
+  const int rg = local / QTB;
+  if (rg >= G) return;
+  const int64_t nj = (a.ntiles - xcd + 7) / 8;
+  const int nqt = (a.tiles_q - qslot + QTB - 1) / QTB;
+  const int64_t my_rows = nj > rg ? (nj - rg + G - 1) / G : 0;
+  const int64_t ntile = my_rows * nqt;
+  if (ntile <= 0) return;
+  const int ldk = a.d_pad;
+  const int KT = ldk / 64;      // even and >= 4 (d_pad is a multiple of 128, >= 256)
+
+  int g_off[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int s = it * 512 + tid;
+    const int row = s >> 3;
+    g_off[it] = row * ldk + ((s & 7) ^ ((row >> 1) & 7)) * 8;
+  }
+  auto tile_rt = [&](int64_t t) { return (int64_t)xcd + 8 * (rg + (t / nqt) * G); };
+  auto tile_qt = [&](int64_t t) { return qslot + (int)(t % nqt) * QTB; };
+  auto rows_of = [&](int64_t t) { return a.xh + (a.tile0 + tile_rt(t)) * 256 * (int64_t)ldk; };
+  auto frags_of = [&](int64_t t) { return a.qf + ((int64_t)(tile_qt(t) * 8 + wave) * (ldk / 16)) * 512; };  // + lane * 8
+  const u32 lane16 = lane * 16;
+  auto issue_base = [&](int64_t t) {  // |x|^2 column of tile t -> base_lds[t & 1]
+    const float* pb = a.base_s + (a.tile0 + tile_rt(t)) * 256;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb + (wave & 3) * 64 + lane),
+                                     (__attribute__((address_space(3))) void*)(base_lds + (t & 1) * 256 + (wave & 3) * 64), 4, 0, 0);
+  };
+  auto issue_piece = [&](const _Float16* pA, int kt, int slot, int it) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pA + g_off[it] + kt * 64),
+                                       (__attribute__((address_space(3))) void*)(lds + slot * ASLOT + (it * 512 + wave * 64) * 16), 16, 0, 0);
+  };
+
+  f32x16 acc[8];
+  half8 fb[2][4];
+  half8 fa[2][4];
+  const float inv_s = 1.0f / a.s;
+  int64_t qj = (int64_t)qslot * 256 + wave * 32 + l31;
+  float Tq = a.T[qj] * inv_s;   // threshold in accumulator space: a row passes iff acc >= T/s (s < 0)
+  float cj = a.cand_keys ? (a.metric == 0 ? a.qstat[qj * 4] : (a.metric == 1 ? 1.f : 0.f)) : 0.f;
+
+  int foff[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) foff[kk] = swz(l31, kk * 2 + khalf) * 16;
+
+  // The (tile, K-step) sequence is one pipeline.  During step g every wavefront issues, in this order interleaved with
+  // its MFMAs: 4 LDS-DMA pieces of step g+3 (ring slot (g+3)%4) and the 4 query fragments of step g+2 (into the register
+  // buffer step g is freeing).  Steps past the end re-read the last tile (harmless) so the loop body has no branches.
+  const _Float16* A_t = rows_of(0);
+  const _Float16* A_n = ntile > 1 ? rows_of(1) : A_t;
+  const _Float16* B_t = frags_of(0);
+  const _Float16* B_n = (nqt > 1 && ntile > 1) ? frags_of(1) : B_t;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the threshold load) keep the counted waits below exact
+  issue_base(0);
+  // prologue = the issue groups of the imaginary steps -3, -2, -1
+#pragma unroll
+  for (int it = 0; it < 4; ++it) issue_piece(A_t, 0, 0, it);
+#pragma unroll
+  for (int it = 0; it < 4; ++it) issue_piece(A_t, 1, 1, it);
+  EPS_GLOAD_B128(fb[0][0], lane16, B_t, 0);
+  EPS_GLOAD_B128(fb[0][1], lane16, B_t, 1024);
+  EPS_GLOAD_B128(fb[0][2], lane16, B_t, 2048);
+  EPS_GLOAD_B128(fb[0][3], lane16, B_t, 3072);
+#pragma unroll
+  for (int it = 0; it < 4; ++it) issue_piece(A_t, 2, 2, it);
+  EPS_GLOAD_B128(fb[1][0], lane16, B_t + 2048, 0);
+  EPS_GLOAD_B128(fb[1][1], lane16, B_t + 2048, 1024);
+  EPS_GLOAD_B128(fb[1][2], lane16, B_t + 2048, 2048);
+  EPS_GLOAD_B128(fb[1][3], lane16, B_t + 2048, 3072);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // slots 0 and 1 + fragments of step 0
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  const u32 lds0 = (u32)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+  u32 faddr[4];   // LDS address of this lane's granule of row l31, per K=16 sub-step, in the slot being computed
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) faddr[kk] = lds0 + foff[kk];
+  EPS_DS_READ_B128(fa[0][0], faddr[0], 0);
+  EPS_DS_READ_B128(fa[0][1], faddr[0], 4096);
+  EPS_DS_READ_B128(fa[0][2], faddr[0], 8192);
+  EPS_DS_READ_B128(fa[0][3], faddr[0], 12288);
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);   // static priority for the second wavefront of each SIMD (skews the pair)
+
+  int slot = 0;     // LDS ring slot of the step being computed
+  // Invariant at the top of a step (after the barrier that ended the previous one): the slots of this step and the
+  // next have landed for every wavefront, and every wavefront has finished reading the slot of the previous step,
+  // which this step's DMA (three steps ahead) overwrites.
+  auto step = [&](int kt, auto U) __attribute__((always_inline)) {
+    constexpr int rb = decltype(U)::value;          // register buffer of the query fragments (step parity; KT is even)
+    const int nslot = (slot + 1) & 3;
+    const int dslot = (slot + 3) & 3;
+    const u32 sA = slot * ASLOT, sN = nslot * ASLOT;
+    const _Float16* pA = kt + 3 < KT ? A_t : A_n;
+    const int akt = kt + 3 < KT ? kt + 3 : kt + 3 - KT;
+    const _Float16* pB = (kt + 2 < KT ? B_t : B_n) + (int64_t)((kt + 2 < KT ? kt + 2 : kt + 2 - KT) * 4) * 512;
+    // (kk, half) pairs: 4 row blocks x K=16 each; the fragments of pair p+1 (pair 0 of the next step after the last)
+    // are read while the MFMAs of pair p issue
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int kk = p >> 1, h = p & 1, cur = p & 1, nxt = cur ^ 1;
+      {
+        const int kk1 = ((p + 1) >> 1) & 3, h1 = (p + 1) & 1;
+        const u32 ad = faddr[kk1] + (p < 7 ? sA : sN) + h1 * 16384;
+        EPS_DS_READ_B128(fa[nxt][0], ad, 0);
+        EPS_DS_READ_B128(fa[nxt][1], ad, 4096);
+        EPS_DS_READ_B128(fa[nxt][2], ad, 8192);
+        EPS_DS_READ_B128(fa[nxt][3], ad, 12288);
+        asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          acc[h * 4 + i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][i], fb[rb][kk], acc[h * 4 + i], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (h == 0) {
+        issue_piece(pA, akt, dslot, kk);
+      } else {
+        EPS_GLOAD_B128(fb[rb][kk], lane16, pB + kk * 512, 0);   // due again two steps from now
+      }
+    }
+    slot = nslot;
+    // publish: my pieces of the step after next have landed (the 8 operations issued during this step may stay in flight)
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  for (int64_t t = 0; t < ntile; ++t) {
+    const int64_t row0 = (a.tile0 + tile_rt(t)) * 256;
+    if (nqt > 1 && t > 0) {
+      qj = (int64_t)tile_qt(t) * 256 + wave * 32 + l31;
+      Tq = a.T[qj] * inv_s;
+      cj = a.cand_keys ? (a.metric == 0 ? a.qstat[qj * 4] : (a.metric == 1 ? 1.f : 0.f)) : 0.f;
+    }
+    if (t + 1 < ntile) issue_base(t + 1);   // a whole tile ahead; counted out by the next step's vmcnt(8)
+    {
+      // accumulators start at base/s (= -|x|^2/2 for L2, 0 otherwise; -inf on padding rows): the finished accumulator is
+      // (approx key)/s and a tile's test is one running max + one compare per 16 outputs
+      const float* bl0 = base_lds + (t & 1) * 256;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int rbase = i * 32 + 4 * khalf;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const float4 bv = *reinterpret_cast<const float4*>(&bl0[rbase + 8 * gq]);
+          acc[i][4 * gq + 0] = bv.x;
+          acc[i][4 * gq + 1] = bv.y;
+          acc[i][4 * gq + 2] = bv.z;
+          acc[i][4 * gq + 3] = bv.w;
+        }
+      }
+    }
+    for (int kt = 0; kt < KT; kt += 2) {
+      step(kt, std::integral_constant<int, 0>{});
+      step(kt + 1, std::integral_constant<int, 1>{});
+    }
+    A_t = A_n;
+    B_t = B_n;
+    if (t + 2 < ntile) {
+      A_n = rows_of(t + 2);
+      if (nqt > 1) B_n = frags_of(t + 2);
+    }
+    // ---- epilogue of tile t (the next tile's first steps are already in flight)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int rbase = i * 32 + 4 * khalf;
+      float mx = acc[i][0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[i][r]);
+      if (__any(mx >= Tq)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (acc[i][r] >= Tq) {
+            const int64_t row = row0 + rbase + (r & 3) + 8 * (r >> 2);
+            if (row < a.row_hi && qj < a.nq) {
+              const u32 slot_c = atomicAdd(&a.cnt[qj], 1u);
+              if (slot_c < (u32)a.cap) {
+                if (a.cand_keys) {
+                  float dapx = acc[i][r] * a.s + cj;
+                  if (a.metric == 0) dapx = fmaxf(dapx, 0.f);
+                  a.cand_keys[qj * (int64_t)a.cap + slot_c] = make_key(dapx, (u32)row);
+                } else {
+                  a.cand[qj * (int64_t)a.cap + slot_c] = (u32)row;
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+
+// row-major fp16 queries -> fragment-major
+__global__ void pack_qf_kernel(const _Float16* qh, _Float16* qf, int64_t b_pad, int d_pad) {
+  const int64_t frag = blockIdx.x;               // (qblock, kc)
+  const int KC = d_pad / 16;
+  const int64_t qb = frag / KC;
+  const int kc = (int)(frag % KC);
+  const int lane = threadIdx.x;
+  const half8 v = *reinterpret_cast<const half8*>(qh + (qb * 32 + (lane & 31)) * d_pad + kc * 16 + (lane >> 5) * 8);
+  *reinterpret_cast<half8*>(qf + (frag * 64 + lane) * 8) = v;
+}
+
+
+}  // namespace eps
