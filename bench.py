@@ -217,7 +217,7 @@ def main():
         if used_mfma:
             # algorithmic flops of the timed launch: 2 * batch * rows * d, on the fp16 dense MFMA roof
             flops = 2.0 * b * krows * d
-            roof = {"bound": "mfma", "kernel": "mfma_filter_kernel_v5 (largest of the 3 filter stages: %d of %d rows)" % (krows, n),
+            roof = {"bound": "mfma", "kernel": "mfma_filter_kernel_v7 (largest of the 3 filter stages: %d of %d rows)" % (krows, n),
                     "achieved": flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms else None,
                     "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s", "traffic": TRAFFIC.get("mfma")}
         else:

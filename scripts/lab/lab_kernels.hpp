@@ -4,3 +4,4 @@
 #include <type_traits>
 #include "lab_v5.hpp"
 #include "lab_v6.hpp"
+#include "lab_v7.hpp"

@@ -91,11 +91,23 @@ static void launch_v5p(const FilterArgs& a, int cus, hipStream_t s) {
   (void)once;
   hipLaunchKernelGGL(mfma_filter_kernel_v5, dim3(cus), dim3(512), 4 * 32768 + 2048, s, a);
 }
+static void launch_v7p(const FilterArgs& a, int cus, hipStream_t s) {
+  static bool once = (set_shm(mfma_filter_kernel_v7, 4 * 32768 + 2048), true);
+  (void)once;
+  hipLaunchKernelGGL(mfma_filter_kernel_v7, dim3(cus), dim3(256), 4 * 32768 + 2048, s, a);
+}
 template <int KNOB>
 static void launch_v6(const FilterArgs& a, int cus, hipStream_t s) {
   static bool once = (set_shm(lab_v6<KNOB>, 4 * 32768 + 2048), true);
   (void)once;
   hipLaunchKernelGGL(lab_v6<KNOB>, dim3(cus), dim3(512), 4 * 32768 + 2048, s, a);
+}
+
+template <int KNOB>
+static void launch_v7(const FilterArgs& a, int cus, hipStream_t s) {
+  static bool once = (set_shm(lab_v7<KNOB>, 4 * 32768 + 2048), true);
+  (void)once;
+  hipLaunchKernelGGL(lab_v7<KNOB>, dim3(cus), dim3(256), 4 * 32768 + 2048, s, a);
 }
 
 #include "lab_variants.inc"

@@ -268,10 +268,10 @@ int32_t flat_mfma_search(Index& ix, const float* dq, int64_t nq, int k, u64* run
     return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory (scratch)");
   hipLaunchKernelGGL(query_prep_kernel, dim3((unsigned)((b_pad + 3) / 4)), dim3(256), 0, s, dq, nq, b_pad, (int)ix.dim_,
                      m.d_pad, m.qh.as<_Float16>(), m.qstat.as<float>());
-  // kernel choice: v5 wants K-steps in pairs (d_pad % 128 == 0, >= 256); other shapes stay on v3
-  static const int version_env = getenv("EPS_MFMA_KERNEL") ? atoi(getenv("EPS_MFMA_KERNEL")) : 5;
-  const int version = (version_env == 5 && (m.d_pad % 128 != 0 || m.d_pad < 256)) ? 3 : version_env;
-  if (version == 5) {
+  // kernel choice: v5 / v7 want K-steps in pairs (d_pad % 128 == 0, >= 256); other shapes stay on v3
+  static const int version_env = getenv("EPS_MFMA_KERNEL") ? atoi(getenv("EPS_MFMA_KERNEL")) : 7;
+  const int version = (version_env >= 5 && (m.d_pad % 128 != 0 || m.d_pad < 256)) ? 3 : version_env;
+  if (version >= 5) {
     if (!m.qf.reserve((size_t)b_pad * m.d_pad * 2)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory (scratch)");
     hipLaunchKernelGGL(pack_qf_kernel, dim3((unsigned)((b_pad / 32) * (m.d_pad / 16))), dim3(64), 0, s, m.qh.as<_Float16>(),
                        m.qf.as<_Float16>(), b_pad, m.d_pad);
@@ -333,7 +333,7 @@ int32_t flat_mfma_search(Index& ix, const float* dq, int64_t nq, int k, u64* run
   const int bm = version == 1 ? BM : BM2;  // v2, v3 and v5 use 256-row tiles
   const size_t shm = version == 1 ? 2 * 32768 + BM * sizeof(float)
                      : version == 2 ? 3 * 49152 + BM2 * sizeof(float)
-                     : version == 5 ? 4 * 32768 + 2 * 256 * sizeof(float)
+                     : version >= 5 ? 4 * 32768 + 2 * 256 * sizeof(float)
                                     : 2 * 65536 + 2 * 256 * sizeof(float);
   static int num_cus = 0;
   if (!num_cus) {
@@ -349,6 +349,7 @@ int32_t flat_mfma_search(Index& ix, const float* dq, int64_t nq, int k, u64* run
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_filter_kernel_v3<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * 65536 + 2 * 256 * sizeof(float)));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_filter_kernel_v3<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * 65536 + 2 * 256 * sizeof(float)));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_filter_kernel_v5), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * 32768 + 2 * 256 * sizeof(float)));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_filter_kernel_v7), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * 32768 + 2 * 256 * sizeof(float)));
     attr_set = true;
   }
   bool first = true;
@@ -369,10 +370,11 @@ int32_t flat_mfma_search(Index& ix, const float* dq, int64_t nq, int k, u64* run
       hipLaunchKernelGGL(mfma_filter_kernel, dim3((unsigned)blocks), dim3(256), shm, s, fa);
     } else if (version == 2) {
       hipLaunchKernelGGL(mfma_filter_kernel_v2, dim3((unsigned)blocks), dim3(512), shm, s, fa);
-    } else if (version == 5) {
+    } else if (version >= 5) {
       FilterArgs f5 = fa;
       f5.tiles_q = (int)(b_pad / BN3);
-      hipLaunchKernelGGL(mfma_filter_kernel_v5, dim3((unsigned)num_cus), dim3(512), shm, s, f5);
+      if (version == 5) hipLaunchKernelGGL(mfma_filter_kernel_v5, dim3((unsigned)num_cus), dim3(512), shm, s, f5);
+      else hipLaunchKernelGGL(mfma_filter_kernel_v7, dim3((unsigned)num_cus), dim3(256), shm, s, f5);
     } else {
       FilterArgs f3 = fa;
       f3.tiles_q = (int)(b_pad / BN3);
