@@ -5,3 +5,4 @@
 #include "lab_v5.hpp"
 #include "lab_v6.hpp"
 #include "lab_v7.hpp"
+#include "lab_v8.hpp"

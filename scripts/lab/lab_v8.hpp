@@ -1,3 +1,4 @@
+// v8 candidate (v7 + the last K-step of every tile block-major with the epilogue interleaved): 
 // v7 candidate: 256 x 256 tile, FOUR wavefronts (one per SIMD, up to 512 registers each), wavefront w = all 256 rows x
 // queries [64w, 64w+64) = 8 x 2 tiles of v_mfma_f32_32x32x16_f16.  Same operand transport as v5 (row operand: 4-slot
 // LDS-DMA ring with counted waits; query operand: fragment-major, straight to VGPRs, two steps ahead) but every row
@@ -6,7 +7,7 @@
 namespace eps {
 
 template <int KNOB>
-__global__ __launch_bounds__(256, 1) void lab_v7(FilterArgs a) {
+__global__ __launch_bounds__(256, 1) void lab_v8(FilterArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int ASLOT = 32768;  // 256 rows x 128 B
   constexpr int RING = 4;
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(256, 1) void lab_v7(FilterArgs a) {
 
   f32x16 acc[8][2];
   half8 fb[2][4][2];
-  half8 fa[2][8];
+  half8 F[16];   // row fragments: normal steps use F[(kk & 1) * 8 + pair]; the block-major last step F[(pair & 3) * 4 + kk]
   const float inv_s = 1.0f / a.s;
   int64_t qj[2];
   float Tq[2];
@@ -112,21 +113,22 @@ __global__ __launch_bounds__(256, 1) void lab_v7(FilterArgs a) {
   u32 faddr[4];
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) faddr[kk] = lds0 + foff[kk];
-  EPS_DS_READ_B128(fa[0][0], faddr[0], 0);
-  EPS_DS_READ_B128(fa[0][1], faddr[0], 4096);
-  EPS_DS_READ_B128(fa[0][2], faddr[0], 8192);
-  EPS_DS_READ_B128(fa[0][3], faddr[0], 12288);
-  EPS_DS_READ_B128(fa[0][4], faddr[0], 16384);
-  EPS_DS_READ_B128(fa[0][5], faddr[0], 20480);
-  EPS_DS_READ_B128(fa[0][6], faddr[0], 24576);
-  EPS_DS_READ_B128(fa[0][7], faddr[0], 28672);
+  EPS_DS_READ_B128(F[0], faddr[0], 0);
+  EPS_DS_READ_B128(F[1], faddr[0], 4096);
+  EPS_DS_READ_B128(F[2], faddr[0], 8192);
+  EPS_DS_READ_B128(F[3], faddr[0], 12288);
+  EPS_DS_READ_B128(F[4], faddr[0], 16384);
+  EPS_DS_READ_B128(F[5], faddr[0], 20480);
+  EPS_DS_READ_B128(F[6], faddr[0], 24576);
+  EPS_DS_READ_B128(F[7], faddr[0], 28672);
 
   int slot = 0;
   // One wavefront per SIMD: after every pair of MFMAs (64 cycles of matrix pipe) exactly one other instruction is
   // issued in its shadow - the LDS read of the row fragment that the same pair will need in the NEXT sub-step
   // (8 pairs = 512 cycles ahead, waited for by count: lgkmcnt(7)), and on odd pairs one LDS-DMA piece / fragment load.
-  auto step = [&](int kt, auto U) __attribute__((always_inline)) {
+  auto step = [&](int kt, auto U, auto PRELAST) __attribute__((always_inline)) {
     constexpr int rb = decltype(U)::value;
+    constexpr bool pre_last = decltype(PRELAST)::value;   // the next step is the tile's block-major last step
     const int nslot = (slot + 1) & 3;
     const int dslot = (slot + 3) & 3;
     const u32 sA = slot * ASLOT, sN = nslot * ASLOT;
@@ -135,43 +137,147 @@ __global__ __launch_bounds__(256, 1) void lab_v7(FilterArgs a) {
     const _Float16* pB = (kt + 2 < KT ? B_t : B_n) + (int64_t)((kt + 2 < KT ? kt + 2 : kt + 2 - KT) * 4) * 512;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      const int cur = kk & 1, nxt = cur ^ 1;
-      const u32 ad = faddr[(kk + 1) & 3] + (kk < 3 ? sA : sN);
+      const int cur = (kk & 1) * 8, nxt = ((kk + 1) & 1) * 8;
+      u32 ad[4];
+      if (kk < 3) {
+        ad[0] = faddr[kk + 1] + sA;
+      } else if (!pre_last) {
+        ad[0] = faddr[0] + sN;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ad[q] = faddr[q] + sN;
+      }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        if (!(KNOB & 2)) {
-          acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][i], fb[rb][kk][0], acc[i][0], 0, 0, 0);
-          acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][i], fb[rb][kk][1], acc[i][1], 0, 0, 0);
-        }
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F[cur + i], fb[rb][kk][0], acc[i][0], 0, 0, 0);
+        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F[cur + i], fb[rb][kk][1], acc[i][1], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (!(KNOB & 64)) {
+        if (kk == 3 && pre_last) {   // F[i] <- (pair i >> 2, sub-step i & 3) of the next slot
+          if (i < 4) EPS_DS_READ_B128(F[nxt + i], ad[i & 3], 0);
+          else EPS_DS_READ_B128(F[nxt + i], ad[i & 3], 4096);
+        } else {
           switch (i) {
-            case 0: EPS_DS_READ_B128(fa[nxt][0], ad, 0); break;
-            case 1: EPS_DS_READ_B128(fa[nxt][1], ad, 4096); break;
-            case 2: EPS_DS_READ_B128(fa[nxt][2], ad, 8192); break;
-            case 3: EPS_DS_READ_B128(fa[nxt][3], ad, 12288); break;
-            case 4: EPS_DS_READ_B128(fa[nxt][4], ad, 16384); break;
-            case 5: EPS_DS_READ_B128(fa[nxt][5], ad, 20480); break;
-            case 6: EPS_DS_READ_B128(fa[nxt][6], ad, 24576); break;
-            default: EPS_DS_READ_B128(fa[nxt][7], ad, 28672); break;
+            case 0: EPS_DS_READ_B128(F[nxt + 0], ad[0], 0); break;
+            case 1: EPS_DS_READ_B128(F[nxt + 1], ad[0], 4096); break;
+            case 2: EPS_DS_READ_B128(F[nxt + 2], ad[0], 8192); break;
+            case 3: EPS_DS_READ_B128(F[nxt + 3], ad[0], 12288); break;
+            case 4: EPS_DS_READ_B128(F[nxt + 4], ad[0], 16384); break;
+            case 5: EPS_DS_READ_B128(F[nxt + 5], ad[0], 20480); break;
+            case 6: EPS_DS_READ_B128(F[nxt + 6], ad[0], 24576); break;
+            default: EPS_DS_READ_B128(F[nxt + 7], ad[0], 28672); break;
           }
         }
-        if (i == 1 || i == 3) {          // query fragments of the PREVIOUS sub-step's slot, for two steps from now
-          if (kk > 0 && !(KNOB & 32)) EPS_GLOAD_B128(fb[rb][kk - 1][i >> 1], lane16, pB + (i >> 1) * jstride + (kk - 1) * 512, 0);
+        if (i == 1 || i == 3) {
+          if (kk > 0) EPS_GLOAD_B128(fb[rb][kk - 1][i >> 1], lane16, pB + (i >> 1) * jstride + (kk - 1) * 512, 0);
         } else if (i == 5 || i == 7) {
           issue_piece(pA, akt, dslot, kk * 2 + (i >> 1) - 2);
         }
       }
     }
-    if (!(KNOB & 32)) {
-      EPS_GLOAD_B128(fb[rb][3][0], lane16, pB + 3 * 512, 0);
-      EPS_GLOAD_B128(fb[rb][3][1], lane16, pB + jstride + 3 * 512, 0);
-    }
+    EPS_GLOAD_B128(fb[rb][3][0], lane16, pB + 3 * 512, 0);
+    EPS_GLOAD_B128(fb[rb][3][1], lane16, pB + jstride + 3 * 512, 0);
     slot = nslot;
     asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    if (!(KNOB & 128)) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  // The threshold test of one 32 x 32 output block, in two halves so that each half fits the shadow of two MFMAs.
+  float mxs = 0.f;
+  auto epi = [&](int i, int j, int part, int64_t row0) __attribute__((always_inline)) {
+    if (part == 0) {
+      mxs = acc[i][j][0];
+#pragma unroll
+      for (int r = 1; r < 8; ++r) mxs = fmaxf(mxs, acc[i][j][r]);
+    } else {
+      float mx = mxs;
+#pragma unroll
+      for (int r = 8; r < 16; ++r) mx = fmaxf(mx, acc[i][j][r]);
+      if (__any(mx >= Tq[j])) {
+        const int rbase = i * 32 + 4 * khalf;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (acc[i][j][r] >= Tq[j]) {
+            const int64_t row = row0 + rbase + (r & 3) + 8 * (r >> 2);
+            if (row < a.row_hi && qj[j] < a.nq) {
+              const u32 slot_c = atomicAdd(&a.cnt[qj[j]], 1u);
+              if (slot_c < (u32)a.cap) a.cand[qj[j] * (int64_t)a.cap + slot_c] = (u32)row;
+            }
+          }
+        }
+      }
+    }
+  };
+
+  // Last K-step of a tile (odd parity): block-major - pair i runs its four K=16 sub-steps back to back, so its 32 x 64
+  // outputs are final 256 matrix-pipe cycles before pair i+1's, and their threshold test issues in the shadow of pair
+  // i+1's MFMAs instead of after the tile with the pipe idle.  Fragment ring: pair i reads F[(i & 3) * 4 + kk], loaded two
+  // pairs ahead; pairs 6 and 7 fetch the next step's (pair n, sub-step 0) fragments into F[0..7].
+  auto last_step = [&](int kt, int64_t row0) __attribute__((always_inline)) {
+    constexpr int rb = 1;
+    const int nslot = (slot + 1) & 3;
+    const int dslot = (slot + 3) & 3;
+    const u32 sA = slot * ASLOT, sN = nslot * ASLOT;
+    const _Float16* pA = kt + 3 < KT ? A_t : A_n;
+    const int akt = kt + 3 < KT ? kt + 3 : kt + 3 - KT;
+    const _Float16* pB = (kt + 2 < KT ? B_t : B_n) + (int64_t)((kt + 2 < KT ? kt + 2 : kt + 2 - KT) * 4) * 512;
+    u32 adL[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) adL[q] = faddr[q] + sA;
+    const u32 adN0 = faddr[0] + sN;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F[(i & 3) * 4 + kk], fb[rb][kk][0], acc[i][0], 0, 0, 0);
+        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F[(i & 3) * 4 + kk], fb[rb][kk][1], acc[i][1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i < 6) {
+          switch (i + 2) {
+            case 2: EPS_DS_READ_B128(F[((i + 2) & 3) * 4 + kk], adL[kk], 8192); break;
+            case 3: EPS_DS_READ_B128(F[((i + 2) & 3) * 4 + kk], adL[kk], 12288); break;
+            case 4: EPS_DS_READ_B128(F[((i + 2) & 3) * 4 + kk], adL[kk], 16384); break;
+            case 5: EPS_DS_READ_B128(F[((i + 2) & 3) * 4 + kk], adL[kk], 20480); break;
+            case 6: EPS_DS_READ_B128(F[((i + 2) & 3) * 4 + kk], adL[kk], 24576); break;
+            default: EPS_DS_READ_B128(F[((i + 2) & 3) * 4 + kk], adL[kk], 28672); break;
+          }
+        } else {
+          switch ((i - 6) * 4 + kk) {
+            case 0: EPS_DS_READ_B128(F[0], adN0, 0); break;
+            case 1: EPS_DS_READ_B128(F[1], adN0, 4096); break;
+            case 2: EPS_DS_READ_B128(F[2], adN0, 8192); break;
+            case 3: EPS_DS_READ_B128(F[3], adN0, 12288); break;
+            case 4: EPS_DS_READ_B128(F[4], adN0, 16384); break;
+            case 5: EPS_DS_READ_B128(F[5], adN0, 20480); break;
+            case 6: EPS_DS_READ_B128(F[6], adN0, 24576); break;
+            default: EPS_DS_READ_B128(F[7], adN0, 28672); break;
+          }
+        }
+        if (kk == 1) issue_piece(pA, akt, dslot, i);
+        if (i > 0 && !(KNOB & 8192)) epi(i - 1, kk >> 1, kk & 1, row0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      EPS_GLOAD_B128(fb[rb][kk][0], lane16, pB + kk * 512, 0);
+      EPS_GLOAD_B128(fb[rb][kk][1], lane16, pB + jstride + kk * 512, 0);
+    }
+    if (KNOB & 8192) {
+#pragma unroll
+      for (int i = 0; i < 7; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) epi(i, q >> 1, q & 1, row0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) epi(7, q >> 1, q & 1, row0);
+    slot = nslot;
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
 
@@ -203,41 +309,17 @@ __global__ __launch_bounds__(256, 1) void lab_v7(FilterArgs a) {
         }
       }
     }
-    for (int kt = 0; kt < KT; kt += 2) {
-      step(kt, std::integral_constant<int, 0>{});
-      step(kt + 1, std::integral_constant<int, 1>{});
+    for (int kt = 0; kt < KT - 2; kt += 2) {
+      step(kt, std::integral_constant<int, 0>{}, std::false_type{});
+      step(kt + 1, std::integral_constant<int, 1>{}, std::false_type{});
     }
+    step(KT - 2, std::integral_constant<int, 0>{}, std::true_type{});
+    last_step(KT - 1, row0);
     A_t = A_n;
     B_t = B_n;
     if (t + 2 < ntile) {
       A_n = rows_of(t + 2);
       if (nqt > 1) B_n = frags_of(t + 2);
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int rbase = i * 32 + 4 * khalf;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        float mx = acc[i][j][0];
-        if (!(KNOB & 4096)) {
-#pragma unroll
-          for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[i][j][r]);
-        } else {
-          mx = fmaxf(mx, acc[i][j][7]);   // timing only: every MFMA result stays live through two of its 16 values
-        }
-        if (__any(mx >= Tq[j])) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            if (acc[i][j][r] >= Tq[j]) {
-              const int64_t row = row0 + rbase + (r & 3) + 8 * (r >> 2);
-              if (row < a.row_hi && qj[j] < a.nq) {
-                const u32 slot_c = atomicAdd(&a.cnt[qj[j]], 1u);
-                if (slot_c < (u32)a.cap) a.cand[qj[j] * (int64_t)a.cap + slot_c] = (u32)row;
-              }
-            }
-          }
-        }
-      }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

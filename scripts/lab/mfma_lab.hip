@@ -92,9 +92,9 @@ static void launch_v5p(const FilterArgs& a, int cus, hipStream_t s) {
   hipLaunchKernelGGL(mfma_filter_kernel_v5, dim3(cus), dim3(512), 4 * 32768 + 2048, s, a);
 }
 static void launch_v7p(const FilterArgs& a, int cus, hipStream_t s) {
-  static bool once = (set_shm(mfma_filter_kernel_v7, 4 * 32768 + 2048), true);
+  static bool once = (set_shm(mfma_filter_kernel_v7, 4 * 32768 + 2048 + 4096), true);
   (void)once;
-  hipLaunchKernelGGL(mfma_filter_kernel_v7, dim3(cus), dim3(256), 4 * 32768 + 2048, s, a);
+  hipLaunchKernelGGL(mfma_filter_kernel_v7, dim3(cus), dim3(256), 4 * 32768 + 2048 + 4096, s, a);
 }
 template <int KNOB>
 static void launch_v6(const FilterArgs& a, int cus, hipStream_t s) {
@@ -108,6 +108,13 @@ static void launch_v7(const FilterArgs& a, int cus, hipStream_t s) {
   static bool once = (set_shm(lab_v7<KNOB>, 4 * 32768 + 2048), true);
   (void)once;
   hipLaunchKernelGGL(lab_v7<KNOB>, dim3(cus), dim3(256), 4 * 32768 + 2048, s, a);
+}
+
+template <int KNOB>
+static void launch_v8(const FilterArgs& a, int cus, hipStream_t s) {
+  static bool once = (set_shm(lab_v8<KNOB>, 4 * 32768 + 2048), true);
+  (void)once;
+  hipLaunchKernelGGL(lab_v8<KNOB>, dim3(cus), dim3(256), 4 * 32768 + 2048, s, a);
 }
 
 #include "lab_variants.inc"
@@ -149,6 +156,13 @@ int main(int argc, char** argv) {
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   unsigned long long ref[2] = {0, 0};
+  struct Checked { const Variant* v; unsigned long long hash, cnt; const char* verdict; };
+  std::vector<Checked> checked;
+  auto verdict_of = [&](const Variant& v, const unsigned long long* h) -> const char* {
+    if (!v.exact) return "";
+    if (!ref[1] && !ref[0]) { ref[0] = h[0]; ref[1] = h[1]; return "(reference set)"; }
+    return (h[0] == ref[0] && h[1] == ref[1]) ? "OK" : "MISMATCH";
+  };
   const double flop = 2.0 * (double)n_pad * nq * d;
   for (const Variant& v : kVariants) {
     if (which != "all" && which.find(v.name) == std::string::npos) continue;
@@ -188,22 +202,29 @@ int main(int argc, char** argv) {
         printf("  %d queries differ\n", bad);
       }
     }
-    const int reps = 5;
-    CK(hipEventRecord(e0, 0));
-    for (int r = 0; r < reps; ++r) v.launch(a, cus, 0);
-    CK(hipEventRecord(e1, 0));
-    CK(hipEventSynchronize(e1));
-    CK(hipGetLastError());
-    float ms;
-    CK(hipEventElapsedTime(&ms, e0, e1));
-    ms /= reps;
-    const char* verdict = "";
-    if (v.exact) {
-      if (!ref[1] && !ref[0]) { ref[0] = h[0]; ref[1] = h[1]; verdict = "(reference set)"; }
-      else verdict = (h[0] == ref[0] && h[1] == ref[1]) ? "OK" : "MISMATCH";
+    checked.push_back({&v, h[0], h[1], verdict_of(v, h)});
+  }
+  // timing: several rounds over all variants (clock / thermal state drifts within a process), median per variant
+  const int rounds = 5, reps = 3;
+  std::vector<std::vector<float>> times(checked.size());
+  for (int r = 0; r < rounds; ++r) {
+    for (size_t i = 0; i < checked.size(); ++i) {
+      const Variant& v = *checked[i].v;
+      CK(hipEventRecord(e0, 0));
+      for (int q = 0; q < reps; ++q) v.launch(a, cus, 0);
+      CK(hipEventRecord(e1, 0));
+      CK(hipEventSynchronize(e1));
+      CK(hipGetLastError());
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      times[i].push_back(ms / reps);
     }
-    printf("%-28s %8.3f ms  %7.1f TFLOP/s  cand %llu hash %016llx %s\n", v.name, ms, flop / ms * 1e-9, h[1], h[0], verdict);
-    fflush(stdout);
+  }
+  for (size_t i = 0; i < checked.size(); ++i) {
+    std::sort(times[i].begin(), times[i].end());
+    const float med = times[i][rounds / 2];
+    printf("%-28s median %7.3f ms (min %7.3f max %7.3f)  %7.1f TFLOP/s  cand %llu %s\n", checked[i].v->name, med, times[i][0],
+           times[i][rounds - 1], flop / med * 1e-9, checked[i].cnt, checked[i].verdict);
   }
   return 0;
 }

@@ -203,6 +203,20 @@ __global__ void threshold_kernel(const u64* run_keys, int k, int64_t nq, int64_t
 }
 
 
+// seeds: the k best APPROXIMATE keys of the head rows (in run_keys) -> candidate ids for the exact re-rank; run_keys is
+// reset so that the re-rank leaves exactly the seeds' exact keys in it
+__global__ void seed_to_cand_kernel(u64* run_keys, int k, int64_t nq, u32* cand, int cap, u32* cnt) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  u32 c = 0;
+  for (int e = 0; e < k; ++e) {
+    const u64 key = run_keys[q * k + e];
+    if (key != KEY_EMPTY) cand[q * (int64_t)cap + c++] = key_id(key);
+    run_keys[q * k + e] = KEY_EMPTY;
+  }
+  cnt[q] = c;
+}
+
 __global__ void count_overflow_kernel(const u32* cnt, int64_t nq, int cap, u32* overflow) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j < nq && cnt[j] > (u32)cap) atomicAdd(overflow, 1u);
@@ -264,7 +278,7 @@ int32_t flat_mfma_search(Index& ix, const float* dq, int64_t nq, int k, u64* run
   const int64_t b_pad = (nq + BN3 - 1) / BN3 * BN3;
   const int cap = std::max(4096, 64 * k);
   if (!m.qh.reserve((size_t)b_pad * m.d_pad * 2) || !m.qstat.reserve((size_t)b_pad * 16) || !m.T.reserve((size_t)b_pad * 4) ||
-      !m.cand.reserve((size_t)nq * cap * (approx ? 8 : 4)) || !m.cnt.reserve((size_t)(nq + 4) * 4 + 16))
+      !m.cand.reserve((size_t)nq * cap * 8) || !m.cnt.reserve((size_t)(nq + 4) * 4 + 16))
     return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory (scratch)");
   hipLaunchKernelGGL(query_prep_kernel, dim3((unsigned)((b_pad + 3) / 4)), dim3(256), 0, s, dq, nq, b_pad, (int)ix.dim_,
                      m.d_pad, m.qh.as<_Float16>(), m.qstat.as<float>());
@@ -277,18 +291,37 @@ int32_t flat_mfma_search(Index& ix, const float* dq, int64_t nq, int k, u64* run
                        m.qf.as<_Float16>(), b_pad, m.d_pad);
   }
 
-  // stage boundaries (multiples of BM): S0, 32*S0, 256*S0, n
+  // Staging.  Every MFMA stage needs a valid upper bound T of the final k-th best exact key; it tightens stage by stage.
+  //  * seeded (exact mode, no deleted bitset / attribute filter): the head [0, S0) goes through the SAME MFMA kernel in
+  //    its approx-key mode with T = +inf, the k best approximate keys are re-ranked exactly, and their k-th exact key is
+  //    the first T (any k exact keys bound the k-th best).  The stages then start at row 0; the exact re-rank dedups rows
+  //    it meets twice.  Stage sizes grow by the cube root of n / S0, which minimises the re-ranked rows ~ k * sum(ratios).
+  //  * otherwise: the head is scanned exactly (with the filter) by the stream kernel, stages 32 x and 256 x S0.
   int64_t S0 = std::max<int64_t>(4096, (int64_t)(32 * k + ROWPAD - 1) / ROWPAD * ROWPAD);
+  const FilterSpec fs = ix.filter_spec();
+  static const bool seed_env = !(getenv("EPS_MFMA_SEED") && atoi(getenv("EPS_MFMA_SEED")) == 0);
+  const bool seeded = seed_env && !approx && !fs.deleted && !fs.op && n > 4 * S0;
   std::vector<int64_t> bounds;
-  bounds.push_back(std::min(S0, n));
-  for (int64_t bnd : {S0 * 32, S0 * 256}) {
-    if (bnd < n && bnd > bounds.back()) bounds.push_back(bnd);
+  if (seeded) {
+    bounds.push_back(0);
+    const double r = std::max(4.0, std::cbrt((double)n / (double)S0));
+    for (double f : {r, r * r}) {
+      const int64_t bnd = (int64_t)((double)S0 * f) / ROWPAD * ROWPAD;
+      if (bnd < n && bnd > bounds.back()) bounds.push_back(bnd);
+    }
+  } else {
+    bounds.push_back(std::min(S0, n));
+    for (int64_t bnd : {S0 * 32, S0 * 256}) {
+      if (bnd < n && bnd > bounds.back()) bounds.push_back(bnd);
+    }
   }
   if (bounds.back() < n) bounds.push_back(n);
 
-  // stage 0: exact scan of the head
-  rc = ix.flat_stream(dq, nq, k, 0, bounds[0], run_keys, false, -1, !approx);
-  if (rc != EPS_OK) return rc;
+  if (!seeded) {
+    // stage 0: exact scan of the head
+    rc = ix.flat_stream(dq, nq, k, 0, bounds[0], run_keys, false, -1, !approx);
+    if (rc != EPS_OK) return rc;
+  }
   ix.stats_.main_kernel_launches = 0;
 
   u32* cnt = m.cnt.as<u32>();
@@ -333,7 +366,8 @@ int32_t flat_mfma_search(Index& ix, const float* dq, int64_t nq, int k, u64* run
   const int bm = version == 1 ? BM : BM2;  // v2, v3 and v5 use 256-row tiles
   const size_t shm = version == 1 ? 2 * 32768 + BM * sizeof(float)
                      : version == 2 ? 3 * 49152 + BM2 * sizeof(float)
-                     : version >= 5 ? 4 * 32768 + 2 * 256 * sizeof(float)
+                     : version >= 7 ? 4 * 32768 + 2 * 256 * sizeof(float) + 4096
+                     : version == 5 ? 4 * 32768 + 2 * 256 * sizeof(float)
                                     : 2 * 65536 + 2 * 256 * sizeof(float);
   static int num_cus = 0;
   if (!num_cus) {
@@ -349,8 +383,38 @@ int32_t flat_mfma_search(Index& ix, const float* dq, int64_t nq, int k, u64* run
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_filter_kernel_v3<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * 65536 + 2 * 256 * sizeof(float)));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_filter_kernel_v3<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * 65536 + 2 * 256 * sizeof(float)));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_filter_kernel_v5), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * 32768 + 2 * 256 * sizeof(float)));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_filter_kernel_v7), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * 32768 + 2 * 256 * sizeof(float)));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_filter_kernel_v7), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * 32768 + 2 * 256 * sizeof(float) + 4096));
     attr_set = true;
+  }
+  auto launch_filter = [&](const FilterArgs& f) {
+    if (version == 1) {
+      const int64_t blocks = (f.ntiles + 7) / 8 * 8 * f.tiles_q;
+      hipLaunchKernelGGL(mfma_filter_kernel, dim3((unsigned)blocks), dim3(256), shm, s, f);
+    } else if (version == 2) {
+      const int64_t blocks = (f.ntiles + 7) / 8 * 8 * f.tiles_q;
+      hipLaunchKernelGGL(mfma_filter_kernel_v2, dim3((unsigned)blocks), dim3(512), shm, s, f);
+    } else {
+      FilterArgs f3 = f;
+      f3.tiles_q = (int)(b_pad / BN3);
+      if (version == 5) hipLaunchKernelGGL(mfma_filter_kernel_v5, dim3((unsigned)num_cus), dim3(512), shm, s, f3);
+      else if (version >= 7) hipLaunchKernelGGL(mfma_filter_kernel_v7, dim3((unsigned)num_cus), dim3(256), shm, s, f3);
+      else if (f3.ablate) hipLaunchKernelGGL(mfma_filter_kernel_v3<true>, dim3((unsigned)num_cus), dim3(512), shm, s, f3);
+      else hipLaunchKernelGGL(mfma_filter_kernel_v3<false>, dim3((unsigned)num_cus), dim3(512), shm, s, f3);
+    }
+  };
+  if (seeded) {
+    launch_fill_u64(reinterpret_cast<u64*>(m.T.p), b_pad / 2, 0x7F8000007F800000ull, s);   // T = +inf: every head row is a candidate
+    er = hipMemsetAsync(cnt, 0, (size_t)nq * 4, s);
+    if (er != hipSuccess) return ix.hip_fail(er, "memset");
+    FilterArgs f0 = fa;
+    f0.cand_keys = m.cand.as<u64>();
+    f0.tile0 = 0;
+    f0.ntiles = (S0 + bm - 1) / bm;
+    f0.row_hi = S0;
+    launch_filter(f0);
+    launch_merge_lists(f0.cand_keys, cap, k, nq, run_keys, false, s, cnt);   // k best approximate keys of the head
+    hipLaunchKernelGGL(seed_to_cand_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, run_keys, k, nq, fa.cand, cap, cnt);
+    launch_rerank(ra, s);                                                      // -> their exact keys
   }
   bool first = true;
   for (size_t st = 0; st + 1 < bounds.size(); ++st) {
@@ -362,27 +426,10 @@ int32_t flat_mfma_search(Index& ix, const float* dq, int64_t nq, int k, u64* run
     fa.tile0 = lo / bm;
     fa.ntiles = (hi + bm - 1) / bm - fa.tile0;
     fa.row_hi = hi;
-    const int64_t blocks = (fa.ntiles + 7) / 8 * 8 * fa.tiles_q;
     const bool biggest = (st + 2 == bounds.size());
     if (biggest) (void)hipEventRecord(ix.evk0_, s);
     if (biggest) ix.stats_.main_kernel_rows = hi - lo;
-    if (version == 1) {
-      hipLaunchKernelGGL(mfma_filter_kernel, dim3((unsigned)blocks), dim3(256), shm, s, fa);
-    } else if (version == 2) {
-      hipLaunchKernelGGL(mfma_filter_kernel_v2, dim3((unsigned)blocks), dim3(512), shm, s, fa);
-    } else if (version >= 5) {
-      FilterArgs f5 = fa;
-      f5.tiles_q = (int)(b_pad / BN3);
-      if (version == 5) hipLaunchKernelGGL(mfma_filter_kernel_v5, dim3((unsigned)num_cus), dim3(512), shm, s, f5);
-      else hipLaunchKernelGGL(mfma_filter_kernel_v7, dim3((unsigned)num_cus), dim3(256), shm, s, f5);
-    } else {
-      FilterArgs f3 = fa;
-      f3.tiles_q = (int)(b_pad / BN3);
-      if (f3.ablate)
-        hipLaunchKernelGGL(mfma_filter_kernel_v3<true>, dim3((unsigned)num_cus), dim3(512), shm, s, f3);
-      else
-        hipLaunchKernelGGL(mfma_filter_kernel_v3<false>, dim3((unsigned)num_cus), dim3(512), shm, s, f3);
-    }
+    launch_filter(fa);
     if (biggest) (void)hipEventRecord(ix.evk1_, s);
     hipLaunchKernelGGL(count_overflow_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, cnt, nq, cap, overflow);
     hipLaunchKernelGGL(sum_counts_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, cnt, nq, cap, total);
@@ -396,7 +443,7 @@ int32_t flat_mfma_search(Index& ix, const float* dq, int64_t nq, int k, u64* run
       (void)hipStreamSynchronize(s);
       u32 mn = ~0u, mx = 0; double sum = 0; float tmin = 3e38f, tmax = -3e38f; int64_t empt = 0, big = 0;
       for (int64_t j = 0; j < nq; ++j) { mn = std::min(mn, hc[j]); mx = std::max(mx, hc[j]); sum += hc[j]; tmin = std::min(tmin, hT[j]); tmax = std::max(tmax, hT[j]); empt += hk[j * k + k - 1] == KEY_EMPTY; big += hc[j] > (u32)cap; }
-      fprintf(stderr, "[eps] stage %zu rows [%lld,%lld) tiles %lld blocks %lld: cnt min %u mean %.1f max %u (>cap: %lld), T min %g max %g, empty kth %lld, scal %g %g %g\n", st, (long long)lo, (long long)hi, (long long)fa.ntiles, (long long)blocks, mn, sum / nq, mx, (long long)big, tmin, tmax, (long long)empt, m.h_scal[0], m.h_scal[1], m.h_scal[2]);
+      fprintf(stderr, "[eps] stage %zu rows [%lld,%lld) tiles %lld: cnt min %u mean %.1f max %u (>cap: %lld), T min %g max %g, empty kth %lld, scal %g %g %g\n", st, (long long)lo, (long long)hi, (long long)fa.ntiles, mn, sum / nq, mx, (long long)big, tmin, tmax, (long long)empt, m.h_scal[0], m.h_scal[1], m.h_scal[2]);
     }
     if (approx)
       launch_merge_lists(fa.cand_keys, cap, k, nq, run_keys, true, s, cnt);  // select on the fp16 keys
@@ -416,7 +463,7 @@ int32_t flat_mfma_search(Index& ix, const float* dq, int64_t nq, int k, u64* run
   if (er == hipSuccess) er = hipStreamSynchronize(s);
   if (er != hipSuccess) return ix.hip_fail(er, "MFMA filter");
   ix.stats_.rerank_rows += (int64_t)h.total;
-  ix.stats_.dist_evals += nq * (n - bounds[0]);
+  ix.stats_.dist_evals += nq * (n - bounds[0]) + (seeded ? nq * S0 : 0);
   ix.stats_.main_kernel_launches = 1;
   if (h.overflow) {
     ix.stats_.overflow_queries += h.overflow;

@@ -831,7 +831,6 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int khalf = lane >> 5;
   const int l31 = lane & 31;
   float* base_lds = reinterpret_cast<float*>(lds + RING * ASLOT);  // [2][256]
 
@@ -851,36 +850,28 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
   const int ldk = a.d_pad;
   const int KT = ldk / 64;      // even and >= 4
 
-  int g_off[8];
-#pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int s = it * 256 + tid;
-    const int row = s >> 3;
-    g_off[it] = row * ldk + ((s & 7) ^ ((row >> 1) & 7)) * 8;
-  }
+  // LDS-DMA piece `it` (0..7) of a K-step covers rows [32 it, 32 it + 32) of the tile: lane offsets differ from piece 0's
+  // only by it * 32 rows, which goes into the scalar base - one offset register for all pieces
+  u32 g_off0;
   auto tile_rt = [&](int64_t t) { return (int64_t)xcd + 8 * (rg + (t / nqt) * G); };
   auto tile_qt = [&](int64_t t) { return qslot + (int)(t % nqt) * QTB; };
   auto rows_of = [&](int64_t t) { return a.xh + (a.tile0 + tile_rt(t)) * 256 * (int64_t)ldk; };
   // fragment stream of this wavefront's first 32-query block; the second block follows at + (ldk/16)*512 halfs
   auto frags_of = [&](int64_t t) { return a.qf + ((int64_t)(tile_qt(t) * 8 + wave * 2) * (ldk / 16)) * 512; };
   const int64_t jstride = (int64_t)(ldk / 16) * 512;
-  const u32 lane16 = lane * 16;
+  u32 lane16, lane4;
   const u32 lds_base = (u32)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
-  const u32 lane4 = lane * 4;
   auto issue_base = [&](int64_t t) {  // pre-scaled |x|^2 column of tile t -> base_lds[t & 1] (64 rows per wavefront)
     const float* pb = a.base_s + (a.tile0 + tile_rt(t)) * 256 + wave * 64;
     const u32 m0v = lds_base + RING * ASLOT + (u32)(((t & 1) * 256 + wave * 64) * 4);
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : : "v"(lane4), "s"(pb), "s"(m0v) : "memory");
   };
-  u32 g_off2[8];
-#pragma unroll
-  for (int it = 0; it < 8; ++it) g_off2[it] = (u32)g_off[it] * 2;
   // LDS-DMA, saddr form: 32-bit lane offset + scalar base, M0 = LDS address of lane 0's 16 bytes.  Hand-issued so the
   // compiler neither forms 64-bit VGPR addresses nor tracks these in its waitcnt model (see v5).
   auto issue_piece = [&](const _Float16* pA, int kt, int slot, int it) {
-    const _Float16* sb = pA + kt * 64;
+    const _Float16* sb = pA + kt * 64 + (int64_t)it * 32 * ldk;
     const u32 m0v = lds_base + slot * ASLOT + (it * 256 + wave * 64) * 16;
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(g_off2[it]), "s"(sb), "s"(m0v) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(g_off0), "s"(sb), "s"(m0v) : "memory");
   };
 
   f32x16 acc[8][2];
@@ -888,16 +879,31 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
   half8 fa[2][8];
   const float inv_s = 1.0f / a.s;
   int64_t qj[2];
-  float Tq[2], cj[2];   // Tq = T/s: a row passes iff acc >= Tq (s < 0); cj: approx-mode constant of the query
+  // Tq = T/s: a row passes iff acc >= Tq (s < 0); cj: approx-mode constant of the query.  Per-lane constants of the
+  // query tile: parked in LDS and read back at each epilogue - as registers they would be live across the K loop, get
+  // spilled, and their scratch reload would again drain the VMEM queue (vmcnt(0)) once per tile.
+  float* tq_lds = base_lds + 512 + wave * 256;   // [4][64] per wavefront: Tq0, Tq1, cj0, cj1
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     qj[j] = (int64_t)qslot * 256 + wave * 64 + j * 32 + l31;
-    Tq[j] = a.T[qj[j]] * inv_s;
-    cj[j] = a.cand_keys ? (a.metric == 0 ? a.qstat[qj[j] * 4] : (a.metric == 1 ? 1.f : 0.f)) : 0.f;
+    tq_lds[j * 64 + lane] = a.T[qj[j]] * inv_s;
+    tq_lds[(2 + j) * 64 + lane] = a.cand_keys ? (a.metric == 0 ? a.qstat[qj[j] * 4] : (a.metric == 1 ? 1.f : 0.f)) : 0.f;
   }
-  int foff[4];
+  // Everything derived from the lane id that the K loop keeps in registers is RE-DERIVED at the top of every tile from
+  // v_mbcnt (a dozen VALU instructions): values that live across the tile loop get spilled around the epilogue's
+  // register peak, and a scratch reload makes hipcc wait vmcnt(0) - which drains the LDS-DMA ring once per tile.
+  u32 faddr[4];
+  auto lane_values = [&]() __attribute__((always_inline)) {
+    u32 ln;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+    lane16 = ln * 16;
+    lane4 = ln * 4;
+    const u32 td = (u32)wave * 64 + ln, row = td >> 3;
+    g_off0 = (row * (u32)ldk + ((td & 7) ^ ((row >> 1) & 7)) * 8) * 2;
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) foff[kk] = swz(l31, kk * 2 + khalf) * 16;
+    for (int kk = 0; kk < 4; ++kk) faddr[kk] = lds_base + (u32)swz((int)(ln & 31), kk * 2 + (int)(ln >> 5)) * 16;
+  };
+  lane_values();
 
   const _Float16* A_t = rows_of(0);
   const _Float16* A_n = ntile > 1 ? rows_of(1) : A_t;
@@ -925,10 +931,6 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
   asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // slots 0 and 1 + fragments of step 0
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  const u32 lds0 = lds_base;
-  u32 faddr[4];
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk) faddr[kk] = lds0 + foff[kk];
   EPS_DS_READ_B128(fa[0][0], faddr[0], 0);
   EPS_DS_READ_B128(fa[0][1], faddr[0], 4096);
   EPS_DS_READ_B128(fa[0][2], faddr[0], 8192);
@@ -942,8 +944,9 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
   // One wavefront per SIMD: after every pair of MFMAs (64 cycles of matrix pipe) exactly one other instruction is
   // issued in its shadow - the LDS read of the row fragment that the same pair will need in the NEXT sub-step
   // (8 pairs = 512 cycles ahead, waited for by count: lgkmcnt(7)), and on odd pairs one LDS-DMA piece / fragment load.
-  auto step = [&](int kt, auto U) __attribute__((always_inline)) {
+  auto step = [&](int kt, auto U, auto FIRST) __attribute__((always_inline)) {
     constexpr int rb = decltype(U)::value;
+    constexpr bool first = decltype(FIRST)::value;   // first K-step of a tile: only acc[.][0] holds the base column
     const int nslot = (slot + 1) & 3;
     const int dslot = (slot + 3) & 3;
     const u32 sA = slot * ASLOT, sN = nslot * ASLOT;
@@ -958,7 +961,10 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
       for (int i = 0; i < 8; ++i) {
         asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        {
+        if (first && kk == 0) {   // D != C: the second block's accumulator is born from the first block's initial value
+          acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][i], fb[rb][kk][1], acc[i][0], 0, 0, 0);
+          acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][i], fb[rb][kk][0], acc[i][0], 0, 0, 0);
+        } else {
           acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][i], fb[rb][kk][0], acc[i][0], 0, 0, 0);
           acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][i], fb[rb][kk][1], acc[i][1], 0, 0, 0);
         }
@@ -994,12 +1000,15 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
 
   for (int64_t t = 0; t < ntile; ++t) {
     const int64_t row0 = (a.tile0 + tile_rt(t)) * 256;
+    const int64_t qbase = (int64_t)tile_qt(t) * 256 + wave * 64;   // scalar
+    lane_values();
+    const int kh4 = (int)(lane16 >> 7) & 4;     // = 4 * khalf
     if (nqt > 1 && t > 0) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         qj[j] = (int64_t)tile_qt(t) * 256 + wave * 64 + j * 32 + l31;
-        Tq[j] = a.T[qj[j]] * inv_s;
-        cj[j] = a.cand_keys ? (a.metric == 0 ? a.qstat[qj[j] * 4] : (a.metric == 1 ? 1.f : 0.f)) : 0.f;
+        tq_lds[j * 64 + (lane16 >> 4)] = a.T[qj[j]] * inv_s;
+        tq_lds[(2 + j) * 64 + (lane16 >> 4)] = a.cand_keys ? (a.metric == 0 ? a.qstat[qj[j] * 4] : (a.metric == 1 ? 1.f : 0.f)) : 0.f;
       }
     }
     if (t + 1 < ntile) issue_base(t + 1);
@@ -1007,23 +1016,23 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
       const float* bl0 = base_lds + (t & 1) * 256;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const int rbase = i * 32 + 4 * khalf;
+        const int rbase = i * 32 + kh4;
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
           const float4 bv = *reinterpret_cast<const float4*>(&bl0[rbase + 8 * gq]);
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            acc[i][j][4 * gq + 0] = bv.x;
-            acc[i][j][4 * gq + 1] = bv.y;
-            acc[i][j][4 * gq + 2] = bv.z;
-            acc[i][j][4 * gq + 3] = bv.w;
-          }
+          acc[i][0][4 * gq + 0] = bv.x;
+          acc[i][0][4 * gq + 1] = bv.y;
+          acc[i][0][4 * gq + 2] = bv.z;
+          acc[i][0][4 * gq + 3] = bv.w;
         }
+        __builtin_amdgcn_sched_barrier(0);   // one row block at a time: hoisting all 64 reads costs spills
       }
     }
-    for (int kt = 0; kt < KT; kt += 2) {
-      step(kt, std::integral_constant<int, 0>{});
-      step(kt + 1, std::integral_constant<int, 1>{});
+    step(0, std::integral_constant<int, 0>{}, std::true_type{});
+    step(1, std::integral_constant<int, 1>{}, std::false_type{});
+    for (int kt = 2; kt < KT; kt += 2) {
+      step(kt, std::integral_constant<int, 0>{}, std::false_type{});
+      step(kt + 1, std::integral_constant<int, 1>{}, std::false_type{});
     }
     A_t = A_n;
     B_t = B_n;
@@ -1031,11 +1040,23 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
       A_n = rows_of(t + 2);
       if (nqt > 1) B_n = frags_of(t + 2);
     }
+    // the epilogue derives its lane constants afresh too (nothing lane-dependent is live across the K loop but the
+    // operand offsets the loop itself uses)
+    u32 lne;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lne));
+    const int l31e = (int)(lne & 31), kh4e = (int)(lne >> 5) * 4;
+    float Tq[2], cj[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      Tq[j] = tq_lds[j * 64 + lne];
+      cj[j] = tq_lds[(2 + j) * 64 + lne];
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int rbase = i * 32 + 4 * khalf;
+      const int rbase = i * 32 + kh4e;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
+        __builtin_amdgcn_sched_barrier(0);   // one 32 x 32 block at a time (bounded register pressure)
         float mx = acc[i][j][0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[i][j][r]);
@@ -1044,15 +1065,16 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
           for (int r = 0; r < 16; ++r) {
             if (acc[i][j][r] >= Tq[j]) {
               const int64_t row = row0 + rbase + (r & 3) + 8 * (r >> 2);
-              if (row < a.row_hi && qj[j] < a.nq) {
-                const u32 slot_c = atomicAdd(&a.cnt[qj[j]], 1u);
+              const int64_t qq = qbase + j * 32 + l31e;
+              if (row < a.row_hi && qq < a.nq) {
+                const u32 slot_c = atomicAdd(&a.cnt[qq], 1u);
                 if (slot_c < (u32)a.cap) {
                   if (a.cand_keys) {
                     float dapx = acc[i][j][r] * a.s + cj[j];
                     if (a.metric == 0) dapx = fmaxf(dapx, 0.f);
-                    a.cand_keys[qj[j] * (int64_t)a.cap + slot_c] = make_key(dapx, (u32)row);
+                    a.cand_keys[qq * (int64_t)a.cap + slot_c] = make_key(dapx, (u32)row);
                   } else {
-                    a.cand[qj[j] * (int64_t)a.cap + slot_c] = (u32)row;
+                    a.cand[qq * (int64_t)a.cap + slot_c] = (u32)row;
                   }
                 }
               }
