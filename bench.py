@@ -23,9 +23,10 @@ sys.path.insert(0, ROOT)
 
 # HBM bytes per launch of the dominant kernel from the PMC counters of profiles/r1_pmc_10Mx768_b1024.csv, collected
 # in separate --pmc passes and corrected as MI355X_MICROARCH.md prescribes (gfx950 FETCH_SIZE counts 128-B requests at
-# 64 B: x2; FETCH_SIZE/WRITE_SIZE are in KiB): (2 * 6741727 + 7201) KiB for the 8.95M-row launch = 13.81e9 bytes,
-# against 13.75e9 algorithmic bytes of the fp16 mirror (each row tile is fetched from HBM once).
-TRAFFIC = {"mfma": (2 * 6741727 + 7201) * 1024.0}
+# 64 B: x2; FETCH_SIZE/WRITE_SIZE are in KiB): (2 * 7042014 + 11837) KiB for the 9,257,600-row launch of
+# mfma_filter_kernel_v7 = 14.43e9 bytes, against 14.22e9 algorithmic bytes of the fp16 mirror (each row tile is fetched
+# from HBM once; without the per-tile rendezvous of the workgroups that share a row tile it was 27.4e9).
+TRAFFIC = {"mfma": (2 * 7042014 + 11837) * 1024.0}
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F16_PEAK_TF = 2500.0  # dense bf16/f16 MFMA peak
 

@@ -42,6 +42,7 @@ struct HalfMirror {
   DevBuf xn_s;     // float [n_pad]  -|x|^2/2 (= xn / s for L2; -inf on padding rows): v5 accumulator init
   DevBuf zeros_s;  // float [n_pad]  0 (-inf on padding rows)
   DevBuf qf;       // _Float16 fragment-major copy of qh (v5)
+  DevBuf gsync;    // u32 [64]: v7 group arrival counters
   DevBuf scal;     // float [4]: E1max, nxh_max, xn_max, overflow flag (as float bits)
   DevBuf qh;       // _Float16 [b_pad][d_pad]
   DevBuf qstat;    // float [b_pad][4]: |q|^2, |q|, |q-qh|, unused
@@ -348,6 +349,7 @@ int32_t flat_mfma_search(Index& ix, const float* dq, int64_t nq, int k, u64* run
   fa.metric = ix.metric_;
   fa.cnt = cnt;
   fa.cap = cap;
+  fa.group_sync = nullptr;
   fa.ablate = getenv("EPS_MFMA_ABLATE") ? atoi(getenv("EPS_MFMA_ABLATE")) : 0;
 
   RerankArgs ra;
@@ -386,6 +388,8 @@ int32_t flat_mfma_search(Index& ix, const float* dq, int64_t nq, int k, u64* run
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_filter_kernel_v7), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * 32768 + 2 * 256 * sizeof(float) + 4096));
     attr_set = true;
   }
+  static const bool gsync_env = !(getenv("EPS_MFMA_GROUPSYNC") && atoi(getenv("EPS_MFMA_GROUPSYNC")) == 0);
+  if (!m.gsync.reserve(1024)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory (scratch)");
   auto launch_filter = [&](const FilterArgs& f) {
     if (version == 1) {
       const int64_t blocks = (f.ntiles + 7) / 8 * 8 * f.tiles_q;
@@ -397,7 +401,11 @@ int32_t flat_mfma_search(Index& ix, const float* dq, int64_t nq, int k, u64* run
       FilterArgs f3 = f;
       f3.tiles_q = (int)(b_pad / BN3);
       if (version == 5) hipLaunchKernelGGL(mfma_filter_kernel_v5, dim3((unsigned)num_cus), dim3(512), shm, s, f3);
-      else if (version >= 7) hipLaunchKernelGGL(mfma_filter_kernel_v7, dim3((unsigned)num_cus), dim3(256), shm, s, f3);
+      else if (version >= 7) {
+        f3.group_sync = gsync_env ? m.gsync.as<u32>() : nullptr;
+        if (f3.group_sync) (void)hipMemsetAsync(f3.group_sync, 0, 1024, s);
+        hipLaunchKernelGGL(mfma_filter_kernel_v7, dim3((unsigned)num_cus), dim3(256), shm, s, f3);
+      }
       else if (f3.ablate) hipLaunchKernelGGL(mfma_filter_kernel_v3<true>, dim3((unsigned)num_cus), dim3(512), shm, s, f3);
       else hipLaunchKernelGGL(mfma_filter_kernel_v3<false>, dim3((unsigned)num_cus), dim3(512), shm, s, f3);
     }

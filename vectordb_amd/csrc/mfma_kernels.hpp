@@ -24,6 +24,7 @@ struct FilterArgs {
   const _Float16* qf;   // fragment-major copy of qh: [b_pad/32][d_pad/16][64 lanes][8] (v5: query operand straight to VGPRs)
   const float* base;    // [n_pad]
   const float* base_s;  // [n_pad] base / s (v5: accumulators are initialised straight from it)
+  u32* group_sync;      // v7: one arrival counter per group of workgroups that share row tiles (zeroed per launch), or null
   const float* T;       // [b_pad]
   int d_pad;
   int tiles_q;          // b_pad / BN
@@ -1003,6 +1004,22 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
     const int64_t qbase = (int64_t)tile_qt(t) * 256 + wave * 64;   // scalar
     lane_values();
     const int kh4 = (int)(lane16 >> 7) & 4;     // = 4 * khalf
+    // The QTB workgroups of a group stream the SAME row tiles (each against its own query tile) and only the first to
+    // ask pays the HBM fetch - if the others ask within the few microseconds the lines survive in this XCD's L2.  With
+    // the operands prefetched three steps ahead nothing self-synchronises them any more (measured: FETCH_SIZE 1.9 x
+    // the algorithmic bytes), so they rendezvous at every tile start: arrive, then poll (scalar loads: no VMEM
+    // counter involved) until the whole group has arrived - bounded, so a missing member can only cost time.
+    if (a.group_sync && nqt == 1 && wave == 0) {
+      u32* ctr = a.group_sync + (xcd * G + rg);
+      if (lane16 == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const u32 want = (u32)QTB * (u32)(t + 1);
+      for (int spin = 0; spin < 256; ++spin) {
+        u32 seen;
+        asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(seen) : "s"(ctr) : "memory");
+        if (seen >= want) break;
+        __builtin_amdgcn_s_sleep(8);
+      }
+    }
     if (nqt > 1 && t > 0) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
