@@ -325,6 +325,30 @@ def test_mfma_engine_is_exact(amd, oracle, metric, n, d, nq):
     ix.close()
 
 
+@pytest.mark.parametrize("n,d,nq,metric", [(150_000, 256, 300, 0), (150_000, 384, 1100, 2), (100_000, 1024, 64, 0),
+                                           (70_000, 256, 8448, 0), (20_000, 512, 96, 1)])
+def test_mfma_v7_shapes_are_exact(amd, n, d, nq, metric):
+    """The persistent 4-wavefront kernel over its geometry corners: the minimum K depth (d_pad 256 = 4 K-steps), an odd
+    number of step pairs (384), a deep K (1024), several query tiles incl. a padded last one (300, 1100 queries), more
+    query tiles than workgroups per XCD (8448 queries: every workgroup walks two query tiles and reloads its thresholds),
+    and a table barely above the seeded-staging cut-over.  MFMA engine == fp32 stream engine, bit for bit."""
+    X = data(n, d, 70 + d)
+    Q = data(nq, d, 71 + d)
+    if metric == 1:
+        X = amd.normalize_rows(X, only_if_nonzero=True)
+        Q = amd.normalize_rows(Q, only_if_nonzero=False)
+    ix = amd.GpuIndex(d, metric)
+    ix.attach_rows(X)
+    for k in (10, 64):
+        a = ix.search(Q, k, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA)
+        st = ix.stats()
+        assert st["overflow_queries"] == 0 and st["rerank_rows"] > 0
+        b = ix.search(Q, k, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
+        assert np.array_equal(a[0], b[0]), "k=%d: %d rows differ" % (k, (a[0] != b[0]).sum())
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    ix.close()
+
+
 def test_mfma_engine_with_deleted_filter_and_ties(amd, oracle):
     n, d, nq = 90_000, 64, 48
     rng = np.random.default_rng(3)
