@@ -4,11 +4,15 @@ synthetic i.i.d. U[0,1) fp32 rows generated on the device, inputs resident in HB
 
     python bench.py [--gpus N --steps K --warmup W]       (N > 1 is launched by torch.distributed.run)
 
-One "step" = one batch of `--batch` queries through the hot path (eps_index_search: flat scan or graph
-traversal -> top-k).  With N > 1 the corpus is hash-sharded by row index (row i lives on rank i mod N, each rank
-holds `--rows` rows: weak scaling, the 80M/8-GPU configuration at N = 8), every rank answers the same query
-batch on its shard, and the per-shard top-k lists are merged after ONE RCCL all-gather of [batch,k]
-(dist, id) pairs.  Prints ONE JSON line on rank 0.
+One "step" = one batch of queries through the hot path (eps_index_search: flat scan or graph traversal -> top-k).
+With N > 1 the corpus is hash-sharded by row index (row i lives on rank i mod N), every rank answers the same query
+batch on its shard, and the per-shard top-k lists are merged after ONE RCCL all-gather of [batch,k] (dist, id)
+pairs.  Weak scaling, per-GPU work fixed, in one of two forms (--scale):
+  queries (default): the corpus stays --rows (10M) in total, each rank holds rows/N of it, and the batch grows to
+                     N x --batch - the whole-job queries/s (`value`) grows with N;
+  rows:              every rank holds --rows rows (80M rows at N = 8) and the batch stays --batch - queries/s
+                     stays flat while the corpus grows; `work_rate` (query*rows/s) is the number that scales.
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -45,6 +49,10 @@ def parse():
     ap.add_argument("--engine", default="auto", choices=["auto", "stream", "mfma"])
     ap.add_argument("--recall-queries", type=int, default=32)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--scale", default="queries", choices=["queries", "rows"],
+                    help="N > 1: 'queries' = the --rows corpus is hash-sharded over the N GPUs and the batch grows to "
+                         "N x --batch (per-GPU work fixed, whole-job queries/s grows with N); 'rows' = every GPU holds "
+                         "--rows rows (corpus grows to N x --rows, SURVEY C5) and the batch stays --batch")
     return ap.parse_args()
 
 
@@ -136,6 +144,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     n, d, b, k = args.rows, args.dim, args.batch, args.k
+    if world > 1 and args.scale == "queries":
+        n = args.rows // world          # this rank's shard of the fixed corpus (row i lives on rank i mod world)
+        b = args.batch * world          # every rank answers the whole (larger) batch on its shard
 
     X = gen_rows(torch, n, d, 42 + rank, dev)                  # this rank's shard: global row id = local*world + rank
     gq = torch.Generator(device=dev).manual_seed(43)           # same queries on every rank
@@ -159,7 +170,7 @@ def main():
         m_d = torch.empty((b, k), dtype=torch.float32, device=dev)
         m_i = torch.empty((b, k), dtype=torch.int64, device=dev)
 
-    main_ms, launches = [], []
+    main_ms, launches, kq = [], [], []
 
     def step(q):
         ix.search(q, k, out=(ids, dd, cnt), mode=mode, flat_engine=engine)
@@ -183,6 +194,7 @@ def main():
         st = ix.stats()  # reads the hipEvent pair the library recorded around its dominant kernel on this stream
         main_ms.append(st["main_kernel_ms"])
         launches.append(st["main_kernel_rows"])
+        kq.append(st.get("main_kernel_queries", b) or b)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -217,10 +229,11 @@ def main():
         used_mfma = st.get("rerank_rows", 0) > 0
         if used_mfma:
             # algorithmic flops of the timed launch: 2 * batch * rows * d, on the fp16 dense MFMA roof
-            flops = 2.0 * b * krows * d
-            roof = {"bound": "mfma", "kernel": "mfma_filter_kernel_v7 (largest of the 3 filter stages: %d of %d rows)" % (krows, n),
+            flops = 2.0 * float(np.mean(kq)) * krows * d   # queries x rows of the timed launch (batches > 2048 run in slices)
+            roof = {"bound": "mfma", "kernel": "mfma_filter_kernel_v7 (largest of the 3 filter stages: %d of %d rows x %d of %d queries)" % (krows, n, int(np.mean(kq)), b),
                     "achieved": flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms else None,
-                    "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s", "traffic": TRAFFIC.get("mfma")}
+                    "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
+                    "traffic": TRAFFIC.get("mfma") if (world == 1 and n == 10_000_000 and b == 1024 and d == 768) else None}
         else:
             # a flat scan needs rows*4*d bytes ONCE per batch; the stream engine re-reads the store once
             # per group of 4 queries, which this figure deliberately does not credit.
@@ -228,7 +241,8 @@ def main():
             roof = {"bound": "hbm", "kernel": "flat_scan_kernel", "achieved": alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms else None,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
         roof["frac"] = (roof["achieved"] / roof["peak"]) if roof["achieved"] else None
-        roof["kernel_ms_per_step"] = kernel_ms
+        roof["kernel_ms_per_step"] = kernel_ms * (b / float(np.mean(kq)) if used_mfma and kq else 1.0)   # all slices of a step
+        roof["kernel_ms_per_launch"] = kernel_ms
         res = {
             "metric": "QPS @ recall@10>=0.999, 10Mx768 L2",
             "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -236,7 +250,9 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "recall_at_10": recall,
             "config": {"workload": "%dM x %d L2 flat/ANN search, k=%d, batch=%d per step, %s rows per GPU, %d GPU(s), "
-                                   "rows_total=%d" % (n // 1_000_000, d, k, b, n, world, n * world),
+                                   "rows_total=%d%s" % ((n * world) // 1_000_000, d, k, b, n, world, n * world,
+                                                        "" if world == 1 else (" (corpus hash-sharded over the GPUs, batch = %d x %d: per-GPU work fixed)" % (world, args.batch)
+                                                                               if args.scale == "queries" else " (rows per GPU fixed, same batch: capacity scaling, see work_rate)")),
                        "mode": args.mode, "engine": args.engine, "parallelism": "row-hash-shard x%d + RCCL all-gather top-k" % world},
             "roofline": roof,
             "stats": {"dist_evals_per_query": st["dist_evals"] / float(b), "rerank_rows_per_query": st["rerank_rows"] / float(b),

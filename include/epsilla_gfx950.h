@@ -113,6 +113,7 @@ typedef struct eps_search_stats {
   double main_kernel_ms;    /* device time of the dominant kernel only                      */
   int64_t main_kernel_launches;
   int64_t main_kernel_rows; /* rows covered by the launch timed in main_kernel_ms              */
+  int64_t main_kernel_queries; /* queries covered by that launch (large batches run in slices)  */
 } eps_search_stats;
 
 void eps_default_search_params(eps_search_params* p);

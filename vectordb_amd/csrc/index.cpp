@@ -346,6 +346,7 @@ int32_t Index::flat_stream(const float* dq, int64_t nq, int k, int64_t row_begin
   HIP_TRY(hipGetLastError());
   stats_.main_kernel_launches += 1;
   stats_.main_kernel_rows = row_end - row_begin;
+  stats_.main_kernel_queries = nq;
   stats_.dist_evals += nq * (row_end - row_begin);
   return EPS_OK;
 }
