@@ -134,9 +134,26 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # EPS_BENCH_BACKEND=gloo lets the N > 1 path be exercised with several ranks on ONE GPU (exchange staged through the
+    # host); the real multi-GPU run uses nccl (= RCCL over xGMI)
+    backend = os.environ.get("EPS_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
+
+    def all_gather(dst, src):
+        if backend == "nccl":
+            dist.all_gather_into_tensor(dst, src)
+        else:
+            hs = src.cpu()
+            parts = [torch.empty_like(hs) for _ in range(world)]
+            dist.all_gather(parts, hs)
+            dst.copy_(torch.stack(parts).reshape(dst.shape))
     if rank == 0:
         build()
     if world > 1:
@@ -176,8 +193,8 @@ def main():
         ix.search(q, k, out=(ids, dd, cnt), mode=mode, flat_engine=engine)
         if world > 1:
             # the one exchange step of the path: all-gather of the per-shard top-k, then a k-way merge
-            dist.all_gather_into_tensor(g_d, dd)
-            dist.all_gather_into_tensor(g_i, ids)
+            all_gather(g_d, dd)
+            all_gather(g_i, ids)
             amd.merge_topk(g_d, g_i, m_d, m_i, device=local_rank, stream=torch.cuda.current_stream().cuda_stream)
             return m_d, m_i
         return dd, ids
@@ -200,7 +217,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -215,8 +232,8 @@ def main():
         if world > 1:
             ad = torch.empty((world, k), dtype=torch.float32, device=dev)
             ai = torch.empty((world, k), dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(ad, gd.contiguous())
-            dist.all_gather_into_tensor(ai, gi.contiguous())
+            all_gather(ad, gd.contiguous())
+            all_gather(ai, gi.contiguous())
             o = torch.argsort(ad.flatten(), stable=True)[:k]
             gi = ai.flatten()[o]
         hits += len(set(gi.tolist()) & set(out_i[qi].tolist()))
