@@ -28,6 +28,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <numeric>
 #include <vector>
 
 #include "index.hpp"
@@ -306,8 +307,13 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   if (seeded) {
     bounds.push_back(0);
     const double r = std::max(4.0, std::cbrt((double)n / (double)S0));
+    // stage boundaries on multiples of the rows one "round" of the persistent grid covers (256 workgroups x 256 rows /
+    // query tiles), so the small stages do not end on a mostly idle round
+    const int64_t qt = std::max<int64_t>(1, b_pad / 256);
+    const int64_t unit = 256 * std::max<int64_t>(1, 256 / std::gcd<int64_t>(256, qt));
     for (double f : {r, r * r}) {
-      const int64_t bnd = (int64_t)((double)S0 * f) / ROWPAD * ROWPAD;
+      int64_t bnd = (int64_t)((double)S0 * f) / ROWPAD * ROWPAD;
+      if (bnd >= 2 * unit) bnd = bnd / unit * unit;
       if (bnd < n && bnd > bounds.back()) bounds.push_back(bnd);
     }
   } else {
@@ -350,6 +356,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   fa.cnt = cnt;
   fa.cap = cap;
   fa.group_sync = nullptr;
+  fa.dense = 0;
   fa.ablate = getenv("EPS_MFMA_ABLATE") ? atoi(getenv("EPS_MFMA_ABLATE")) : 0;
 
   RerankArgs ra;
@@ -412,9 +419,11 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   };
   if (seeded) {
     launch_fill_u64(reinterpret_cast<u64*>(m.T.p), b_pad / 2, 0x7F8000007F800000ull, s);   // T = +inf: every head row is a candidate
-    er = hipMemsetAsync(cnt, 0, (size_t)nq * 4, s);
+    const bool dense = version >= 7;   // v7 writes the head's keys densely (slot = row); older kernels append with atomics
+    er = dense ? hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(cnt), (int)S0, (size_t)nq, s) : hipMemsetAsync(cnt, 0, (size_t)nq * 4, s);
     if (er != hipSuccess) return ix.hip_fail(er, "memset");
     FilterArgs f0 = fa;
+    f0.dense = dense ? 1 : 0;
     f0.cand_keys = m.cand.as<u64>();
     f0.tile0 = 0;
     f0.ntiles = (S0 + bm - 1) / bm;

@@ -24,6 +24,7 @@ struct FilterArgs {
   const _Float16* qf;   // fragment-major copy of qh: [b_pad/32][d_pad/16][64 lanes][8] (v5: query operand straight to VGPRs)
   const float* base;    // [n_pad]
   const float* base_s;  // [n_pad] base / s (v5: accumulators are initialised straight from it)
+  int dense;            // v7 seed pass: every row is a candidate - keys go to slot (row - first row), no test, no atomics
   u32* group_sync;      // v7: one arrival counter per group of workgroups that share row tiles (zeroed per launch), or null
   const float* T;       // [b_pad]
   int d_pad;
@@ -1074,6 +1075,21 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         __builtin_amdgcn_sched_barrier(0);   // one 32 x 32 block at a time (bounded register pressure)
+        if (a.dense) {   // seed pass (approx keys of ALL head rows): slot = row index, no compare, no atomic
+          const int64_t qq = qbase + j * 32 + l31e;
+          if (qq < a.nq) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int64_t row = row0 + rbase + (r & 3) + 8 * (r >> 2);
+              float dapx = acc[i][j][r] * a.s + cj[j];
+              const bool nan = dapx != dapx;
+              if (a.metric == 0) dapx = fmaxf(dapx, 0.f);
+              if (row < a.row_hi)
+                a.cand_keys[qq * (int64_t)a.cap + (row - a.tile0 * 256)] = nan ? KEY_EMPTY : make_key(dapx, (u32)row);
+            }
+          }
+          continue;
+        }
         float mx = acc[i][j][0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[i][j][r]);
