@@ -18,11 +18,9 @@
 // If a query's candidate buffer overflows (adversarial order/duplicates) the batch falls back to the fp32 scan,
 // so the result is exact in every case.
 //
-// Kernel: 128 rows x 128 queries per workgroup, 4 wavefronts (2x2) x 64x64 outputs each = 2x2 tiles of
-// v_mfma_f32_32x32x16_f16; K-step 64; both operands K-contiguous, staged HBM->LDS by global_load_lds (16 B/lane,
-// double-buffered, next tile in flight under the MFMAs); LDS rows XOR-swizzled on the source address so the
-// ds_read_b128 fragment reads are conflict-free; workgroup->tile map keeps the 8 query tiles of one row tile on
-// one XCD back-to-back so the row tile is fetched from HBM once and re-read from that XCD's L2.
+// Kernels: mfma_kernels.hpp - v7 (default: persistent, 4 wavefronts x 256 rows x 64 queries per 256 x 256 tile, query
+// fragments straight to VGPRs, 4-slot LDS-DMA ring for the row operand), v5 and v3 for A/B (EPS_MFMA_KERNEL) and as the
+// fallback for d_pad % 128 != 0.  Staging, seeds, re-rank and the overflow fallback are in flat_mfma_search_slice below.
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -285,7 +283,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   hipLaunchKernelGGL(query_prep_kernel, dim3((unsigned)((b_pad + 3) / 4)), dim3(256), 0, s, dq, nq, b_pad, (int)ix.dim_,
                      m.d_pad, m.qh.as<_Float16>(), m.qstat.as<float>());
   // kernel choice: v5 / v7 want K-steps in pairs (d_pad % 128 == 0, >= 256); other shapes stay on v3
-  static const int version_env = getenv("EPS_MFMA_KERNEL") ? atoi(getenv("EPS_MFMA_KERNEL")) : 7;
+  static const int version_env = getenv("EPS_MFMA_KERNEL") ? std::max(3, atoi(getenv("EPS_MFMA_KERNEL"))) : 7;   // 3 | 5 | 7
   const int version = (version_env >= 5 && (m.d_pad % 128 != 0 || m.d_pad < 256)) ? 3 : version_env;
   if (version >= 5) {
     if (!m.qf.reserve((size_t)b_pad * m.d_pad * 2)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory (scratch)");
@@ -346,7 +344,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   fa.base_s = ix.metric_ == 0 ? m.xn_s.as<float>() : m.zeros_s.as<float>();
   fa.T = m.T.as<float>();
   fa.d_pad = m.d_pad;
-  fa.tiles_q = (int)(b_pad / BN);
+  fa.tiles_q = (int)(b_pad / BN3);
   fa.nq = nq;
   fa.s = ix.metric_ == 0 ? -2.f : -1.f;
   fa.cand = m.cand.as<u32>();
@@ -372,10 +370,8 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   ra.cap = cap;
   ra.run_keys = run_keys;
 
-  const int bm = version == 1 ? BM : BM2;  // v2, v3 and v5 use 256-row tiles
-  const size_t shm = version == 1 ? 2 * 32768 + BM * sizeof(float)
-                     : version == 2 ? 3 * 49152 + BM2 * sizeof(float)
-                     : version >= 7 ? 4 * 32768 + 2 * 256 * sizeof(float) + 4096
+  const int bm = BM3;   // every kernel generation works on 256-row tiles
+  const size_t shm = version >= 7 ? 4 * 32768 + 2 * 256 * sizeof(float) + 4096
                      : version == 5 ? 4 * 32768 + 2 * 256 * sizeof(float)
                                     : 2 * 65536 + 2 * 256 * sizeof(float);
   static int num_cus = 0;
@@ -387,8 +383,6 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   }
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_filter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * 32768 + BM * sizeof(float)));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_filter_kernel_v2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * 49152 + BM2 * sizeof(float)));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_filter_kernel_v3<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * 65536 + 2 * 256 * sizeof(float)));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_filter_kernel_v3<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * 65536 + 2 * 256 * sizeof(float)));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_filter_kernel_v5), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * 32768 + 2 * 256 * sizeof(float)));
@@ -398,13 +392,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   static const bool gsync_env = !(getenv("EPS_MFMA_GROUPSYNC") && atoi(getenv("EPS_MFMA_GROUPSYNC")) == 0);
   if (!m.gsync.reserve(1024)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory (scratch)");
   auto launch_filter = [&](const FilterArgs& f) {
-    if (version == 1) {
-      const int64_t blocks = (f.ntiles + 7) / 8 * 8 * f.tiles_q;
-      hipLaunchKernelGGL(mfma_filter_kernel, dim3((unsigned)blocks), dim3(256), shm, s, f);
-    } else if (version == 2) {
-      const int64_t blocks = (f.ntiles + 7) / 8 * 8 * f.tiles_q;
-      hipLaunchKernelGGL(mfma_filter_kernel_v2, dim3((unsigned)blocks), dim3(512), shm, s, f);
-    } else {
+    {
       FilterArgs f3 = f;
       f3.tiles_q = (int)(b_pad / BN3);
       if (version == 5) hipLaunchKernelGGL(mfma_filter_kernel_v5, dim3((unsigned)num_cus), dim3(512), shm, s, f3);

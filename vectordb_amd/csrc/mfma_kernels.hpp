@@ -1,4 +1,4 @@
-// The batched-flat-scan filter kernels (v1, v2, v3) of mfma_filter.hip, in a header so that the kernel lab
+// The batched-flat-scan filter kernels (v3, v5, v7; v1 and v2 live on only in profiles/r1_mfma_ablation.txt) of mfma_filter.hip, in a header so that the kernel lab
 // (scripts/lab/mfma_lab.hip) can time experimental variants beside them.  See mfma_filter.hip for the method.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -13,8 +13,7 @@ namespace eps {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 64;   // v1 tile
-constexpr int BM2 = 256;                      // v2 row tile (256 rows x 128 queries, 8 wavefronts)
+constexpr int BK = 64;                        // K-step of every kernel generation
 constexpr int ROWPAD = 256;                   // mirror rows are padded to this
 
 // ------------------------------------------------------------------------------------------------ filter kernel
@@ -45,331 +44,6 @@ struct FilterArgs {
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (row << 3) + (chunk ^ ((row >> 1) & 7)); }  // 16-B granule index
-
-__global__ __launch_bounds__(256, 2) void mfma_filter_kernel(FilterArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  // layout: [2 stages][A 16 KB | B 16 KB] then base[128] floats
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-
-  // XCD-aware map: block b runs on XCD b%8; the tiles_q query tiles of a row tile are consecutive on one XCD
-  const int64_t bid = blockIdx.x;
-  const int xcd = (int)(bid & 7);
-  const int64_t local = bid >> 3;
-  const int qt = (int)(local % a.tiles_q);
-  const int64_t rt = (local / a.tiles_q) * 8 + xcd;
-  if (rt >= a.ntiles) return;
-  const int64_t row0 = (a.tile0 + rt) * BM;
-  const int64_t q0 = (int64_t)qt * BN;
-  const int ldk = a.d_pad;
-  const int KT = ldk / BK;
-
-  float* base_lds = reinterpret_cast<float*>(lds + 2 * 32768);
-  if (tid < BM) base_lds[tid] = a.base[row0 + tid];
-
-  const _Float16* gA = a.xh + row0 * ldk;
-  const _Float16* gB = a.qh + q0 * ldk;
-
-  // per-thread staging coordinates: 4 granules of A and 4 of B per K-tile
-  int g_row[4], g_chunk[4];
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int s = it * 256 + tid;
-    g_row[it] = s >> 3;
-    g_chunk[it] = (s & 7) ^ ((g_row[it] >> 1) & 7);
-  }
-  auto stage = [&](int kt, int buf) {
-    unsigned char* dA = lds + buf * 32768;
-    unsigned char* dB = dA + 16384;
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const _Float16* sa = gA + (int64_t)g_row[it] * ldk + kt * BK + g_chunk[it] * 8;
-      const _Float16* sb = gB + (int64_t)g_row[it] * ldk + kt * BK + g_chunk[it] * 8;
-      const int wbase = (it * 256 + wave * 64) * 16;  // wave-uniform LDS base; hardware adds lane*16
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sa,
-                                       (__attribute__((address_space(3))) void*)(dA + wbase), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sb,
-                                       (__attribute__((address_space(3))) void*)(dB + wbase), 16, 0, 0);
-    }
-  };
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int arow0 = wm * 64 + (lane & 31);
-  const int brow0 = wn * 64 + (lane & 31);
-  const int khalf = lane >> 5;
-
-  const bool ab_noload = a.ablate & 1, ab_nomfma = a.ablate & 2, ab_nolds = a.ablate & 4;
-  if (!ab_noload) stage(0, 0);
-  for (int kt = 0; kt < KT; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < KT && !ab_noload) stage(kt + 1, (kt + 1) & 1);
-    const unsigned char* sA = lds + (kt & 1) * 32768;
-    const unsigned char* sB = sA + 16384;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const int chunk = kk * 2 + khalf;
-      half8 fa[2], fb[2];
-      if (!ab_nolds) {
-#pragma unroll
-        for (int f = 0; f < 2; ++f) {
-          fa[f] = *reinterpret_cast<const half8*>(sA + swz(arow0 + f * 32, chunk) * 16);
-          fb[f] = *reinterpret_cast<const half8*>(sB + swz(brow0 + f * 32, chunk) * 16);
-        }
-      } else {
-#pragma unroll
-        for (int f = 0; f < 2; ++f)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            fa[f][e] = (_Float16)(float)(kk + e);
-            fb[f][e] = (_Float16)(float)(lane + e);
-          }
-      }
-      if (!ab_nomfma) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-      } else {
-#pragma unroll
-        for (int f = 0; f < 2; ++f) {
-          asm volatile("" ::"v"(fa[f]));
-          asm volatile("" ::"v"(fb[f]));
-        }
-      }
-    }
-  }
-
-  // epilogue: approx lower-bound key vs per-query threshold; survivors are appended to the candidate lists
-  float Tj[2], cj[2];
-  int64_t qj[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    qj[j] = q0 + wn * 64 + j * 32 + (lane & 31);
-    Tj[j] = a.T[qj[j]];
-    cj[j] = a.cand_keys ? (a.metric == 0 ? a.qstat[qj[j] * 4] : (a.metric == 1 ? 1.f : 0.f)) : 0.f;
-  }
-  __syncthreads();  // base_lds visible (first barrier of the K loop already ordered it; kept for KT == 0 safety)
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int rbase = wm * 64 + i * 32 + 4 * khalf;
-    float4 bv[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) bv[g] = *reinterpret_cast<const float4*>(&base_lds[rbase + 8 * g]);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      bool any = false;
-      float v[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float b = (r & 3) == 0 ? bv[r >> 2].x : (r & 3) == 1 ? bv[r >> 2].y : (r & 3) == 2 ? bv[r >> 2].z : bv[r >> 2].w;
-        v[r] = fmaf(acc[i][j][r], a.s, b);
-        any |= (v[r] <= Tj[j]);
-      }
-      if (__any(any)) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          if (v[r] <= Tj[j]) {
-            const int64_t row = row0 + rbase + (r & 3) + 8 * (r >> 2);
-            if (row < a.row_hi && qj[j] < a.nq) {
-              const u32 slot = atomicAdd(&a.cnt[qj[j]], 1u);
-              if (slot < (u32)a.cap) {
-                if (a.cand_keys) {
-                  float dapx = v[r] + cj[j];
-                  if (a.metric == 0) dapx = fmaxf(dapx, 0.f);
-                  a.cand_keys[qj[j] * (int64_t)a.cap + slot] = make_key(dapx, (u32)row);
-                } else {
-                  a.cand[qj[j] * (int64_t)a.cap + slot] = (u32)row;
-                }
-              }
-            }
-          }
-        }
-      }
-    }
-  }
-}
-
-
-// ------------------------------------------------------------------------------------------------ v2 kernel
-// 256 rows x 128 queries per workgroup, 8 wavefronts (4 x 2) x 64x64 outputs, K-step 64, THREE LDS slots of 48 KB:
-// two K-tiles are always in flight (counted s_waitcnt vmcnt(6), raw s_barrier — a __syncthreads() would drain the
-// LDS-DMA queue to zero), so twice the bytes are outstanding per CU compared with v1 while the row tile is twice as
-// tall (170 flop per L2 byte instead of 128).
-__global__ __launch_bounds__(512, 2) void mfma_filter_kernel_v2(FilterArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  constexpr int SLOT = 49152;  // A 256x128 B + B 128x128 B
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-
-  const int64_t bid = blockIdx.x;
-  const int xcd = (int)(bid & 7);
-  const int64_t local = bid >> 3;
-  const int qt = (int)(local % a.tiles_q);
-  const int64_t rt = (local / a.tiles_q) * 8 + xcd;
-  if (rt >= a.ntiles) return;
-  const int64_t row0 = (a.tile0 + rt) * BM2;
-  const int64_t q0 = (int64_t)qt * BN;
-  const int ldk = a.d_pad;
-  const int KT = ldk / BK;
-
-  float* base_lds = reinterpret_cast<float*>(lds + 3 * SLOT);
-  if (tid < BM2) base_lds[tid] = a.base[row0 + tid];
-
-  const _Float16* gA = a.xh + row0 * ldk;
-  const _Float16* gB = a.qh + q0 * ldk;
-  // staging: A = 2048 granules (4 per thread), B = 1024 granules (2 per thread)
-  int a_row[4], a_chunk[4], b_row[2], b_chunk[2];
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int s = it * 512 + tid;
-    a_row[it] = s >> 3;
-    a_chunk[it] = (s & 7) ^ ((a_row[it] >> 1) & 7);
-  }
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int s = it * 512 + tid;
-    b_row[it] = s >> 3;
-    b_chunk[it] = (s & 7) ^ ((b_row[it] >> 1) & 7);
-  }
-  auto stage = [&](int kt, int slot) {
-    unsigned char* dA = lds + slot * SLOT;
-    unsigned char* dB = dA + 32768;
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const _Float16* sa = gA + (int64_t)a_row[it] * ldk + kt * BK + a_chunk[it] * 8;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sa,
-                                       (__attribute__((address_space(3))) void*)(dA + (it * 512 + wave * 64) * 16), 16, 0, 0);
-    }
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const _Float16* sb = gB + (int64_t)b_row[it] * ldk + kt * BK + b_chunk[it] * 8;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sb,
-                                       (__attribute__((address_space(3))) void*)(dB + (it * 512 + wave * 64) * 16), 16, 0, 0);
-    }
-  };
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int arow0 = wm * 64 + (lane & 31);
-  const int brow0 = wn * 64 + (lane & 31);
-  const int khalf = lane >> 5;
-
-  stage(0, 0);
-  if (KT > 1) stage(1, 1);
-  int slot = 0;
-  for (int kt = 0; kt < KT; ++kt) {
-    // tile kt has landed once at most the 6 loads of tile kt+1 are still outstanding
-    if (kt + 1 < KT)
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (kt + 2 < KT) {
-      int ns = slot + 2;
-      if (ns >= 3) ns -= 3;
-      stage(kt + 2, ns);  // slot (kt+2)%3 == (kt-1)%3: every wave finished reading it before this barrier
-    }
-    const unsigned char* sA = lds + slot * SLOT;
-    const unsigned char* sB = sA + 32768;
-    // software pipeline over the four K=16 sub-steps: the fragments of sub-step kk+1 are read from LDS while the
-    // MFMAs of sub-step kk run (one wave per SIMD per block: nothing else hides the ds_read latency)
-    half8 fa[2][2], fb[2][2];
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-      fa[0][f] = *reinterpret_cast<const half8*>(sA + swz(arow0 + f * 32, khalf) * 16);
-      fb[0][f] = *reinterpret_cast<const half8*>(sB + swz(brow0 + f * 32, khalf) * 16);
-    }
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const int cur = kk & 1, nxt = cur ^ 1;
-      if (kk < 3) {
-        const int chunk = (kk + 1) * 2 + khalf;
-#pragma unroll
-        for (int f = 0; f < 2; ++f) {
-          fa[nxt][f] = *reinterpret_cast<const half8*>(sA + swz(arow0 + f * 32, chunk) * 16);
-          fb[nxt][f] = *reinterpret_cast<const half8*>(sB + swz(brow0 + f * 32, chunk) * 16);
-        }
-      }
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-    }
-    slot = slot + 1 == 3 ? 0 : slot + 1;
-  }
-
-  float Tj[2], cj[2];
-  int64_t qj[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    qj[j] = q0 + wn * 64 + j * 32 + (lane & 31);
-    Tj[j] = a.T[qj[j]];
-    cj[j] = a.cand_keys ? (a.metric == 0 ? a.qstat[qj[j] * 4] : (a.metric == 1 ? 1.f : 0.f)) : 0.f;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int rbase = wm * 64 + i * 32 + 4 * khalf;
-    float4 bv[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) bv[g] = *reinterpret_cast<const float4*>(&base_lds[rbase + 8 * g]);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      bool any = false;
-      float v[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float b = (r & 3) == 0 ? bv[r >> 2].x : (r & 3) == 1 ? bv[r >> 2].y : (r & 3) == 2 ? bv[r >> 2].z : bv[r >> 2].w;
-        v[r] = fmaf(acc[i][j][r], a.s, b);
-        any |= (v[r] <= Tj[j]);
-      }
-      if (__any(any)) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          if (v[r] <= Tj[j]) {
-            const int64_t row = row0 + rbase + (r & 3) + 8 * (r >> 2);
-            if (row < a.row_hi && qj[j] < a.nq) {
-              const u32 slot_c = atomicAdd(&a.cnt[qj[j]], 1u);
-              if (slot_c < (u32)a.cap) {
-                if (a.cand_keys) {
-                  float dapx = v[r] + cj[j];
-                  if (a.metric == 0) dapx = fmaxf(dapx, 0.f);
-                  a.cand_keys[qj[j] * (int64_t)a.cap + slot_c] = make_key(dapx, (u32)row);
-                } else {
-                  a.cand[qj[j] * (int64_t)a.cap + slot_c] = (u32)row;
-                }
-              }
-            }
-          }
-        }
-      }
-    }
-  }
-}
-
 
 // ------------------------------------------------------------------------------------------------ v3 kernel
 // Persistent form.  Ablation of v1 (profiles/r1_mfma_ablation.txt) showed the filter was bound by per-workgroup
