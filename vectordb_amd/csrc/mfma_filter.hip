@@ -12,8 +12,9 @@
 // A row can only be in the exact top-k if approx - bound <= T, where T is ANY valid upper bound of the k-th best
 // exact key — we use the k-th best exact key found so far.  Rows that pass are re-ranked in exact fp32 by the
 // gather kernel (flat_kernels.hip: rerank_kernel).  The scan is staged so T tightens:
-//     stage 0: exact fp32 stream scan of the first S0 rows            -> running top-k
-//     stage i: MFMA filter over the next, geometrically larger chunk  -> candidates -> exact re-rank -> top-k
+//     stage 0: the first S0 rows: their k best approximate keys (same kernel, every row a candidate), re-ranked
+//              exactly, give the first T (with a deleted bitset / attribute filter: exact fp32 stream scan instead)
+//     stage i: MFMA filter over a geometrically larger chunk          -> candidates -> exact re-rank -> top-k
 // Expected candidates per query ~ k * sum_i (chunk_i / rows_before_i): a few hundred at N = 10M, k = 10.
 // If a query's candidate buffer overflows (adversarial order/duplicates) the batch falls back to the fp32 scan,
 // so the result is exact in every case.
