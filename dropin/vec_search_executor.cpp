@@ -348,7 +348,11 @@ Status VecSearchExecutor::SearchBatched(const float* query, vectordb::engine::Ta
       }
     }
     lk.unlock();
-    RunBatch(dev, dimension_, batch);
+    try {
+      RunBatch(dev, dimension_, batch);
+    } catch (const std::exception& e) {   // (allocation failure while gathering the batch): the followers must still be released
+      for (Pending* r : batch) r->error = std::string("gfx950 executor: ") + e.what();
+    }
     lk.lock();
     for (Pending* r : batch) r->done = true;
     dev.busy = false;
