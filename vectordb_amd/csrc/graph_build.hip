@@ -3,7 +3,7 @@
 //   InterInsert, CheckConnectivity)  -> CSR  (engine/db/index/knn/knn.hpp:90-135, engine/db/index/nsg/nsg.cpp:45-775)
 //
 // MI355X form:
-//   1. kNN graph = the K nearest rows of every row by one batched flat scan per 1024-row block of "queries"
+//   1. kNN graph = the K nearest rows of every row by one batched flat scan per 2048-row block of "queries"
 //      on the matrix cores (mfma_filter.hip in approx mode: fp16 keys, no re-rank) — the exact object NN-Descent
 //      approximates iteratively under per-node spinlocks.  O(n^2 d) flops, all MFMA.
 //   2. navigation node = row closest to the centroid (exact flat scan with k = 1; the reference searches the
@@ -329,7 +329,7 @@ int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp) {
   // ---- 1. kNN graph
   DevBuf knn, run;
   const int k1 = K + 1;
-  const int64_t B = 1024;
+  static const int64_t B = getenv("EPS_BUILD_BLOCK") ? std::max(256, atoi(getenv("EPS_BUILD_BLOCK"))) : 2048;   // queries per kNN pass
   if (!knn.reserve((size_t)n * K * 4) || !run.reserve((size_t)B * k1 * 8)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "build: out of device memory (kNN graph)");
   const bool use_mfma = n >= 65536;
   ix.scan_limit_ = n;  // the graph covers rows [0,n) only

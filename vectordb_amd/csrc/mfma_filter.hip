@@ -301,10 +301,10 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   int64_t S0 = std::max<int64_t>(4096, (int64_t)(32 * k + ROWPAD - 1) / ROWPAD * ROWPAD);
   const FilterSpec fs = ix.filter_spec();
   static const bool seed_env = !(getenv("EPS_MFMA_SEED") && atoi(getenv("EPS_MFMA_SEED")) == 0);
-  const bool seeded = seed_env && !approx && !fs.deleted && !fs.op && n > 4 * S0;
+  const bool seeded = seed_env && !fs.deleted && !fs.op && n > 4 * S0;
   std::vector<int64_t> bounds;
   if (seeded) {
-    bounds.push_back(0);
+    bounds.push_back(approx ? S0 : 0);   // approx mode keeps the head's approximate keys themselves: no second visit
     const double r = std::max(4.0, std::cbrt((double)n / (double)S0));
     // stage boundaries on multiples of the rows one "round" of the persistent grid covers (256 workgroups x 256 rows /
     // query tiles), so the small stages do not end on a mostly idle round
@@ -419,8 +419,10 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
     f0.row_hi = S0;
     launch_filter(f0);
     launch_merge_lists(f0.cand_keys, cap, k, nq, run_keys, false, s, cnt);   // k best approximate keys of the head
-    hipLaunchKernelGGL(seed_to_cand_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, run_keys, k, nq, fa.cand, cap, cnt);
-    launch_rerank(ra, s);                                                      // -> their exact keys
+    if (!approx) {
+      hipLaunchKernelGGL(seed_to_cand_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, run_keys, k, nq, fa.cand, cap, cnt);
+      launch_rerank(ra, s);                                                    // -> their exact keys
+    }
   }
   bool first = true;
   for (size_t st = 0; st + 1 < bounds.size(); ++st) {
@@ -472,7 +474,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   if (er == hipSuccess) er = hipStreamSynchronize(s);
   if (er != hipSuccess) return ix.hip_fail(er, "MFMA filter");
   ix.stats_.rerank_rows += (int64_t)h.total;
-  ix.stats_.dist_evals += nq * (n - bounds[0]) + (seeded ? nq * S0 : 0);
+  ix.stats_.dist_evals += nq * (n - bounds[0]) + (seeded ? nq * S0 : 0);   // (exact mode visits the head twice)
   ix.stats_.main_kernel_launches = 1;
   if (h.overflow) {
     ix.stats_.overflow_queries += h.overflow;
