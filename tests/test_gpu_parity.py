@@ -349,6 +349,22 @@ def test_mfma_v7_shapes_are_exact(amd, n, d, nq, metric):
     ix.close()
 
 
+@pytest.mark.parametrize("nq", [1, 3, 8, 17, 31])
+def test_small_batches_auto_engine_is_exact(amd, nq):
+    """FLAT_AUTO is a cost decision between two engines that return the same bits: from 8 queries on (or earlier, once
+    the fp16 mirror exists) a big table goes through the MFMA filter.  AUTO == MFMA == stream, for every small batch."""
+    n, d = 120_000, 256
+    X = data(n, d, 90)
+    Q = data(nq, d, 91 + nq)
+    ix = amd.GpuIndex(d, 0)
+    ix.attach_rows(X)
+    ref = ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
+    for eng in (amd.FLAT_AUTO, amd.FLAT_MFMA, amd.FLAT_AUTO):
+        got = ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=eng)
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2])
+    ix.close()
+
+
 def test_mfma_engine_with_deleted_filter_and_ties(amd, oracle):
     n, d, nq = 90_000, 64, 48
     rng = np.random.default_rng(3)

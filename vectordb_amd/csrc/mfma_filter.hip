@@ -260,10 +260,18 @@ static int32_t ensure_mirror(Index& ix) {
 }
 
 bool flat_mfma_profitable(const Index& ix, int64_t nq, int k) {
-  // worth it only when the GEMM is big enough to beat the HBM-bound stream scan
-  if (nq < 32 || ix.n_rows_ < 65536 || k > 128) return false;
-  if (ix.mirror_ && ix.mirror_->version == ix.rows_version_ && !ix.mirror_->fp16_range_ok) return false;
-  return true;
+  // FLAT_AUTO: both engines return the same bits, so this is purely a cost decision (scripts/bench_midbatch.py:
+  // 10M x 768: stream 5.1 / 11.3 / 43.7 ms vs filter 3.5 / 3.6 / 3.8 ms at 1 / 8 / 32 queries - the filter reads the
+  // half-size fp16 mirror once per <= 2048 queries, the stream scan reads the fp32 rows once per 4 queries;
+  // 200k x 128: break-even near 32 queries).
+  if (ix.n_rows_ < 65536 || k > 128) return false;
+  const bool have_mirror = ix.mirror_ && ix.mirror_->version == ix.rows_version_;
+  if (have_mirror && !ix.mirror_->fp16_range_ok) return false;
+  if (nq < 8 && !have_mirror) return false;   // do not spend 50 % more HBM on a mirror for single-query traffic alone
+  const double rows = (double)ix.n_rows_, d = (double)ix.dim_, dp = (double)((ix.dim_ + 127) / 128 * 128);
+  const double stream_s = std::ceil((double)nq / 4.0) * rows * d * 4.0 / 6.0e12 + 0.05e-3;
+  const double filter_s = 0.25e-3 + std::max(rows * dp * 2.0 / 5.0e12, 2.0 * 256.0 * std::ceil((double)nq / 256.0) * rows * dp / 1.2e15);
+  return filter_s < stream_s;
 }
 
 int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u64* run_keys, bool approx) {
