@@ -92,9 +92,9 @@ static void launch_v5p(const FilterArgs& a, int cus, hipStream_t s) {
   hipLaunchKernelGGL(mfma_filter_kernel_v5, dim3(cus), dim3(512), 4 * 32768 + 2048, s, a);
 }
 static void launch_v7p(const FilterArgs& a, int cus, hipStream_t s) {
-  static bool once = (set_shm(mfma_filter_kernel_v7, 4 * 32768 + 2048 + 4096), true);
+  static bool once = (set_shm(mfma_filter_kernel_v7<2>, 4 * 32768 + 2048 + 4096), true);
   (void)once;
-  hipLaunchKernelGGL(mfma_filter_kernel_v7, dim3(cus), dim3(256), 4 * 32768 + 2048 + 4096, s, a);
+  hipLaunchKernelGGL(mfma_filter_kernel_v7<2>, dim3(cus), dim3(256), 4 * 32768 + 2048 + 4096, s, a);
 }
 template <int KNOB>
 static void launch_v6(const FilterArgs& a, int cus, hipStream_t s) {

@@ -349,7 +349,7 @@ def test_mfma_v7_shapes_are_exact(amd, n, d, nq, metric):
     ix.close()
 
 
-@pytest.mark.parametrize("nq", [1, 3, 8, 17, 31])
+@pytest.mark.parametrize("nq", [1, 3, 8, 17, 31, 100, 128, 129])
 def test_small_batches_auto_engine_is_exact(amd, nq):
     """FLAT_AUTO is a cost decision between two engines that return the same bits: from 8 queries on (or earlier, once
     the fp16 mirror exists) a big table goes through the MFMA filter.  AUTO == MFMA == stream, for every small batch."""

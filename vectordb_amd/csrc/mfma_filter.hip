@@ -395,9 +395,11 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_filter_kernel_v3<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * 65536 + 2 * 256 * sizeof(float)));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_filter_kernel_v3<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * 65536 + 2 * 256 * sizeof(float)));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_filter_kernel_v5), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * 32768 + 2 * 256 * sizeof(float)));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_filter_kernel_v7), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * 32768 + 2 * 256 * sizeof(float) + 4096));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_filter_kernel_v7<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * 32768 + 2 * 256 * sizeof(float) + 4096));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_filter_kernel_v7<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * 32768 + 2 * 256 * sizeof(float) + 4096));
     attr_set = true;
   }
+  static const bool narrow_env = !(getenv("EPS_MFMA_NARROW") && atoi(getenv("EPS_MFMA_NARROW")) == 0);
   static const bool gsync_env = !(getenv("EPS_MFMA_GROUPSYNC") && atoi(getenv("EPS_MFMA_GROUPSYNC")) == 0);
   if (!m.gsync.reserve(1024)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory (scratch)");
   auto launch_filter = [&](const FilterArgs& f) {
@@ -408,7 +410,12 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
       else if (version >= 7) {
         f3.group_sync = gsync_env ? m.gsync.as<u32>() : nullptr;
         if (f3.group_sync) (void)hipMemsetAsync(f3.group_sync, 0, 1024, s);
-        hipLaunchKernelGGL(mfma_filter_kernel_v7, dim3((unsigned)num_cus), dim3(256), shm, s, f3);
+        if (nq <= 128 && narrow_env) {   // one 128-query tile: half the padded MFMA work, the pass streams the mirror
+          f3.tiles_q = 1;
+          hipLaunchKernelGGL(mfma_filter_kernel_v7<1>, dim3((unsigned)num_cus), dim3(256), shm, s, f3);
+        } else {
+          hipLaunchKernelGGL(mfma_filter_kernel_v7<2>, dim3((unsigned)num_cus), dim3(256), shm, s, f3);
+        }
       }
       else if (f3.ablate) hipLaunchKernelGGL(mfma_filter_kernel_v3<true>, dim3((unsigned)num_cus), dim3(512), shm, s, f3);
       else hipLaunchKernelGGL(mfma_filter_kernel_v3<false>, dim3((unsigned)num_cus), dim3(512), shm, s, f3);

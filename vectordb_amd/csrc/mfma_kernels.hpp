@@ -500,7 +500,11 @@ __global__ __launch_bounds__(512, 2) void mfma_filter_kernel_v5(FilterArgs a) {
 // after every pair of MFMAs (64 cycles of matrix pipe) exactly one LDS read is issued in their shadow - the fragment the
 // same pair needs in the NEXT K=16 sub-step, 512 cycles ahead, waited for by count (lgkmcnt(7)) - and on odd pairs one
 // LDS-DMA piece (row operand, three steps ahead) or one query-fragment load (two steps ahead).
+// JQ = 32-query blocks per wavefront: 2 -> 256-query tiles (the throughput shape), 1 -> 128-query tiles for batches of
+// <= 128 queries, which halves the (padded) MFMA work and leaves the pass bound by streaming the fp16 mirror.
+template <int JQ>
 __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
+  constexpr int QT = 128 * JQ;   // queries per tile
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int ASLOT = 32768;  // 256 rows x 128 B
   constexpr int RING = 4;
@@ -533,7 +537,7 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
   auto tile_qt = [&](int64_t t) { return qslot + (int)(t % nqt) * QTB; };
   auto rows_of = [&](int64_t t) { return a.xh + (a.tile0 + tile_rt(t)) * 256 * (int64_t)ldk; };
   // fragment stream of this wavefront's first 32-query block; the second block follows at + (ldk/16)*512 halfs
-  auto frags_of = [&](int64_t t) { return a.qf + ((int64_t)(tile_qt(t) * 8 + wave * 2) * (ldk / 16)) * 512; };
+  auto frags_of = [&](int64_t t) { return a.qf + ((int64_t)(tile_qt(t) * (4 * JQ) + wave * JQ) * (ldk / 16)) * 512; };
   const int64_t jstride = (int64_t)(ldk / 16) * 512;
   u32 lane16, lane4;
   const u32 lds_base = (u32)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
@@ -550,18 +554,18 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(g_off0), "s"(sb), "s"(m0v) : "memory");
   };
 
-  f32x16 acc[8][2];
-  half8 fb[2][4][2];
+  f32x16 acc[8][JQ];
+  half8 fb[2][4][JQ];
   half8 fa[2][8];
   const float inv_s = 1.0f / a.s;
-  int64_t qj[2];
+  int64_t qj[JQ];
   // Tq = T/s: a row passes iff acc >= Tq (s < 0); cj: approx-mode constant of the query.  Per-lane constants of the
   // query tile: parked in LDS and read back at each epilogue - as registers they would be live across the K loop, get
   // spilled, and their scratch reload would again drain the VMEM queue (vmcnt(0)) once per tile.
   float* tq_lds = base_lds + 512 + wave * 256;   // [4][64] per wavefront: Tq0, Tq1, cj0, cj1
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    qj[j] = (int64_t)qslot * 256 + wave * 64 + j * 32 + l31;
+  for (int j = 0; j < JQ; ++j) {
+    qj[j] = (int64_t)qslot * QT + wave * (32 * JQ) + j * 32 + l31;
     tq_lds[j * 64 + lane] = a.T[qj[j]] * inv_s;
     tq_lds[(2 + j) * 64 + lane] = a.cand_keys ? (a.metric == 0 ? a.qstat[qj[j] * 4] : (a.metric == 1 ? 1.f : 0.f)) : 0.f;
   }
@@ -595,16 +599,17 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
     EPS_GLOAD_B128(fb[0][kk][0], lane16, B_t + kk * 512, 0);
-    EPS_GLOAD_B128(fb[0][kk][1], lane16, B_t + jstride + kk * 512, 0);
+    if (JQ == 2) EPS_GLOAD_B128(fb[0][kk][JQ - 1], lane16, B_t + jstride + kk * 512, 0);
   }
 #pragma unroll
   for (int it = 0; it < 8; ++it) issue_piece(A_t, 2, 2, it);
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
     EPS_GLOAD_B128(fb[1][kk][0], lane16, B_t + 2048 + kk * 512, 0);
-    EPS_GLOAD_B128(fb[1][kk][1], lane16, B_t + jstride + 2048 + kk * 512, 0);
+    if (JQ == 2) EPS_GLOAD_B128(fb[1][kk][JQ - 1], lane16, B_t + jstride + 2048 + kk * 512, 0);
   }
-  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // slots 0 and 1 + fragments of step 0
+  if (JQ == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // slots 0 and 1 + fragments of step 0
+  else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   EPS_DS_READ_B128(fa[0][0], faddr[0], 0);
@@ -637,12 +642,12 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
       for (int i = 0; i < 8; ++i) {
         asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        if (first && kk == 0) {   // D != C: the second block's accumulator is born from the first block's initial value
-          acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][i], fb[rb][kk][1], acc[i][0], 0, 0, 0);
+        if (JQ == 2 && first && kk == 0) {   // D != C: the second block's accumulator is born from the first block's initial value
+          acc[i][JQ - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][i], fb[rb][kk][JQ - 1], acc[i][0], 0, 0, 0);
           acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][i], fb[rb][kk][0], acc[i][0], 0, 0, 0);
         } else {
           acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][i], fb[rb][kk][0], acc[i][0], 0, 0, 0);
-          acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][i], fb[rb][kk][1], acc[i][1], 0, 0, 0);
+          if (JQ == 2) acc[i][JQ - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][i], fb[rb][kk][JQ - 1], acc[i][JQ - 1], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         {
@@ -658,7 +663,7 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
           }
         }
         if (i == 1 || i == 3) {          // query fragments of the PREVIOUS sub-step's slot, for two steps from now
-          if (kk > 0) EPS_GLOAD_B128(fb[rb][kk - 1][i >> 1], lane16, pB + (i >> 1) * jstride + (kk - 1) * 512, 0);
+          if (kk > 0 && (i >> 1) < JQ) EPS_GLOAD_B128(fb[rb][kk - 1][(i >> 1) % JQ], lane16, pB + (i >> 1) * jstride + (kk - 1) * 512, 0);
         } else if (i == 5 || i == 7) {
           issue_piece(pA, akt, dslot, kk * 2 + (i >> 1) - 2);
         }
@@ -666,17 +671,18 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
     }
     {
       EPS_GLOAD_B128(fb[rb][3][0], lane16, pB + 3 * 512, 0);
-      EPS_GLOAD_B128(fb[rb][3][1], lane16, pB + jstride + 3 * 512, 0);
+      if (JQ == 2) EPS_GLOAD_B128(fb[rb][3][JQ - 1], lane16, pB + jstride + 3 * 512, 0);
     }
     slot = nslot;
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    if (JQ == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // this step's 8 DMA pieces + 4 JQ fragment loads may stay in flight
+    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
 
   for (int64_t t = 0; t < ntile; ++t) {
     const int64_t row0 = (a.tile0 + tile_rt(t)) * 256;
-    const int64_t qbase = (int64_t)tile_qt(t) * 256 + wave * 64;   // scalar
+    const int64_t qbase = (int64_t)tile_qt(t) * QT + wave * (32 * JQ);   // scalar
     lane_values();
     const int kh4 = (int)(lane16 >> 7) & 4;     // = 4 * khalf
     // The QTB workgroups of a group stream the SAME row tiles (each against its own query tile) and only the first to
@@ -697,8 +703,8 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
     }
     if (nqt > 1 && t > 0) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        qj[j] = (int64_t)tile_qt(t) * 256 + wave * 64 + j * 32 + l31;
+      for (int j = 0; j < JQ; ++j) {
+        qj[j] = (int64_t)tile_qt(t) * QT + wave * (32 * JQ) + j * 32 + l31;
         tq_lds[j * 64 + (lane16 >> 4)] = a.T[qj[j]] * inv_s;
         tq_lds[(2 + j) * 64 + (lane16 >> 4)] = a.cand_keys ? (a.metric == 0 ? a.qstat[qj[j] * 4] : (a.metric == 1 ? 1.f : 0.f)) : 0.f;
       }
@@ -737,9 +743,9 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
     u32 lne;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lne));
     const int l31e = (int)(lne & 31), kh4e = (int)(lne >> 5) * 4;
-    float Tq[2], cj[2];
+    float Tq[JQ], cj[JQ];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < JQ; ++j) {
       Tq[j] = tq_lds[j * 64 + lne];
       cj[j] = tq_lds[(2 + j) * 64 + lne];
     }
@@ -747,7 +753,7 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
     for (int i = 0; i < 8; ++i) {
       const int rbase = i * 32 + kh4e;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < JQ; ++j) {
         __builtin_amdgcn_sched_barrier(0);   // one 32 x 32 block at a time (bounded register pressure)
         if (a.dense) {   // seed pass (approx keys of ALL head rows): slot = row index, no compare, no atomic
           const int64_t qq = qbase + j * 32 + l31e;
