@@ -178,10 +178,14 @@ __global__ __launch_bounds__(256) void query_prep_kernel(const float* q, int64_t
 }
 
 // T[j]: pass threshold in approx-key space for query j, from the current k-th best exact distance.
+// Also resets what the stage's filter launch accumulates into (candidate counts, group arrival counters), so a stage is
+// threshold -> filter -> counts -> re-rank without separate memsets.
 __global__ void threshold_kernel(const u64* run_keys, int k, int64_t nq, int64_t b_pad, const float* qstat,
-                                 const float* scal, int metric, float* T) {
+                                 const float* scal, int metric, float* T, u32* cnt, u32* gsync) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= b_pad) return;
+  if (j < nq) cnt[j] = 0;
+  if (gsync && j < 256) gsync[j] = 0;
   if (j >= nq) {
     T[j] = -__builtin_inff();
     return;
@@ -218,13 +222,13 @@ __global__ void seed_to_cand_kernel(u64* run_keys, int k, int64_t nq, u32* cand,
   cnt[q] = c;
 }
 
-__global__ void count_overflow_kernel(const u32* cnt, int64_t nq, int cap, u32* overflow) {
+// per stage: queries whose candidate list overflowed, and the number of rows that will be re-ranked
+__global__ void stage_counts_kernel(const u32* cnt, int64_t nq, int cap, u32* overflow, unsigned long long* total) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < nq && cnt[j] > (u32)cap) atomicAdd(overflow, 1u);
-}
-__global__ void sum_counts_kernel(const u32* cnt, int64_t nq, int cap, unsigned long long* total) {
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < nq) atomicAdd(total, (unsigned long long)(cnt[j] < (u32)cap ? cnt[j] : (u32)cap));
+  if (j >= nq) return;
+  const u32 c = cnt[j];
+  if (c > (u32)cap) atomicAdd(overflow, 1u);
+  atomicAdd(total, (unsigned long long)(c < (u32)cap ? c : (u32)cap));
 }
 
 // ------------------------------------------------------------------------------------------------ host
@@ -409,7 +413,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
       if (version == 5) hipLaunchKernelGGL(mfma_filter_kernel_v5, dim3((unsigned)num_cus), dim3(512), shm, s, f3);
       else if (version >= 7) {
         f3.group_sync = gsync_env ? m.gsync.as<u32>() : nullptr;
-        if (f3.group_sync) (void)hipMemsetAsync(f3.group_sync, 0, 1024, s);
+        if (f3.group_sync && f3.dense) (void)hipMemsetAsync(f3.group_sync, 0, 1024, s);   // (stages: reset by threshold_kernel)
         if (nq <= 128 && narrow_env) {   // one 128-query tile: half the padded MFMA work, the pass streams the mirror
           f3.tiles_q = 1;
           hipLaunchKernelGGL(mfma_filter_kernel_v7<1>, dim3((unsigned)num_cus), dim3(256), shm, s, f3);
@@ -443,9 +447,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   for (size_t st = 0; st + 1 < bounds.size(); ++st) {
     const int64_t lo = bounds[st], hi = bounds[st + 1];
     hipLaunchKernelGGL(threshold_kernel, dim3((unsigned)((b_pad + 255) / 256)), dim3(256), 0, s, run_keys, k, nq, b_pad,
-                       m.qstat.as<float>(), m.scal.as<float>(), ix.metric_, m.T.as<float>());
-    er = hipMemsetAsync(cnt, 0, (size_t)nq * 4, s);
-    if (er != hipSuccess) return ix.hip_fail(er, "memset");
+                       m.qstat.as<float>(), m.scal.as<float>(), ix.metric_, m.T.as<float>(), cnt, m.gsync.as<u32>());
     fa.tile0 = lo / bm;
     fa.ntiles = (hi + bm - 1) / bm - fa.tile0;
     fa.row_hi = hi;
@@ -457,8 +459,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
     }
     launch_filter(fa);
     if (biggest) (void)hipEventRecord(ix.evk1_, s);
-    hipLaunchKernelGGL(count_overflow_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, cnt, nq, cap, overflow);
-    hipLaunchKernelGGL(sum_counts_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, cnt, nq, cap, total);
+    hipLaunchKernelGGL(stage_counts_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, cnt, nq, cap, overflow, total);
     if (getenv("EPS_DEBUG")) {
       std::vector<u32> hc((size_t)nq);
       std::vector<float> hT((size_t)nq);
