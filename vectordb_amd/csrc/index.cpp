@@ -178,6 +178,21 @@ int32_t Index::set_deleted(const uint8_t* bits, int64_t nbytes) {
   if (is_device_ptr(bits)) {
     d_deleted_ = bits;
   } else {
+    // the DBMS hands over its bitset on every call; a table without deletions (the common case) is recognised here, which
+    // skips the upload and keeps the unfiltered fast paths (MFMA-seeded staging) available
+    const int64_t live = (n_rows_ + 7) / 8;
+    bool any = false;
+    int64_t i = 0;
+    for (; i + 8 <= live && !any; i += 8) {
+      uint64_t w;
+      std::memcpy(&w, bits + i, 8);
+      any = w != 0;
+    }
+    for (; i < live && !any; ++i) any = bits[i] != 0;
+    if (!any) {
+      d_deleted_ = nullptr;
+      return EPS_OK;
+    }
     if (!deleted_buf_.reserve((size_t)nbytes)) return fail(EPS_INFRA_UNEXPECTED_ERROR, "set_deleted: out of device memory");
     HIP_TRY(hipMemcpyAsync(deleted_buf_.p, bits, (size_t)nbytes, hipMemcpyHostToDevice, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));  // the host bitset may change right after we return
