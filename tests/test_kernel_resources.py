@@ -1,0 +1,38 @@
+"""The filter kernel's schedule is hand-counted (vmcnt/lgkmcnt waits, one instruction per MFMA shadow): if hipcc starts
+spilling in it, every scratch reload adds a compiler-inserted vmcnt(0) that drains the LDS-DMA ring and the kernel
+silently loses several x.  Compile it (no GPU needed) and pin the resource usage."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")), reason="needs hipcc")
+def test_filter_kernels_do_not_spill(tmp_path):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-I" + os.path.join(ROOT, "include"),
+                        "-c", os.path.join(ROOT, "vectordb_amd", "csrc", "mfma_filter.hip"), "-o", str(tmp_path / "mf.o"),
+                        "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    usage = {}
+    name = None
+    for line in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            usage[name] = {}
+        m = re.search(r"(VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]): (\d+)", line)
+        if m and name:
+            usage[name][m.group(1)] = int(m.group(2))
+    v7 = {k: v for k, v in usage.items() if "mfma_filter_kernel_v7" in k}
+    assert len(v7) == 2, list(usage)
+    for k, u in v7.items():
+        assert u["ScratchSize [bytes/lane]"] == 0, (k, u)
+        assert u["AGPRs"] in (128, 256), (k, u)      # the accumulators live in AGPRs
+    for k, u in usage.items():
+        if "mfma_filter_kernel_v5" in k or "mfma_filter_kernel_v3" in k:
+            assert u["ScratchSize [bytes/lane]"] == 0, (k, u)

@@ -313,7 +313,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   int64_t S0 = std::max<int64_t>(4096, (int64_t)(32 * k + ROWPAD - 1) / ROWPAD * ROWPAD);
   const FilterSpec fs = ix.filter_spec();
   static const bool seed_env = !(getenv("EPS_MFMA_SEED") && atoi(getenv("EPS_MFMA_SEED")) == 0);
-  const bool seeded = seed_env && !fs.deleted && !fs.op && n > 4 * S0;
+  const bool seeded = seed_env && n > 4 * S0;   // with a filter the seeds are the k best VISIBLE head rows
   std::vector<int64_t> bounds;
   if (seeded) {
     bounds.push_back(approx ? S0 : 0);   // approx mode keeps the head's approximate keys themselves: no second visit
@@ -437,7 +437,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
     f0.ntiles = (S0 + bm - 1) / bm;
     f0.row_hi = S0;
     launch_filter(f0);
-    launch_merge_lists(f0.cand_keys, cap, k, nq, run_keys, false, s, cnt);   // k best approximate keys of the head
+    launch_merge_lists(f0.cand_keys, cap, k, nq, run_keys, false, s, cnt, approx ? nullptr : &fs);   // k best approximate keys of the (visible) head
     if (!approx) {
       hipLaunchKernelGGL(seed_to_cand_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, run_keys, k, nq, fa.cand, cap, cnt);
       launch_rerank(ra, s);                                                    // -> their exact keys
