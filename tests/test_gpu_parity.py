@@ -412,6 +412,27 @@ def test_mfma_engine_adversarial_order_falls_back_exactly(amd):
     ix.close()
 
 
+def test_mfma_engine_selective_filter_retries_with_more_slots(amd):
+    """98 % of the rows deleted at random: thresholds come from visible rows only, so ~50 x more rows pass the bound than
+    for an unfiltered search and the first pass overflows; the engine retries with 16 x the candidate slots (still far
+    cheaper than the stream scan) and must return exactly the stream engine's answer."""
+    n, d, nq = 400_000, 64, 96
+    rng = np.random.default_rng(11)
+    X, Q = data(n, d, 120), data(nq, d, 121)
+    dele = rng.random(n) < 0.98
+    ix = amd.GpuIndex(d, 0)
+    ix.attach_rows(X)
+    ix.set_deleted(np.packbits(dele, bitorder="little"))
+    a = ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA)
+    st = ix.stats()
+    b = ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
+    assert st["overflow_queries"] > 0                      # the 4096-slot pass did overflow ...
+    assert st["rerank_rows"] > 4096 * 8                    # ... and the retry re-ranked long lists instead of scanning
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert not dele[a[0][a[0] >= 0]].any()
+    ix.close()
+
+
 def test_graph_search_csr_fallback_for_high_degree_nodes(amd, oracle):
     """Connectivity repair can give a node any out-degree; above 64 the device keeps the CSR form instead of the
     fixed-stride adjacency.  Same answer as the oracle either way, duplicates in an adjacency list included."""

@@ -106,7 +106,7 @@ class Index {
   int32_t flat_stream(const float* dq, int64_t nq, int k, int64_t row_begin, int64_t row_end, u64* run_keys,
                       bool merge_run, int metric = -1, bool filtered = true);
   friend int32_t flat_mfma_search(Index&, const float*, int64_t, int, u64*, bool);
-  friend int32_t flat_mfma_search_slice(Index&, const float*, int64_t, int, u64*, bool);
+  friend int32_t flat_mfma_search_slice(Index&, const float*, int64_t, int, u64*, bool, int);
   friend int32_t graph_build(Index&, int64_t, const eps_build_params&);
   friend int32_t graph_search(Index&, const float*, int64_t, int, const eps_search_params&, u64*, int64_t*);
 };
@@ -114,7 +114,7 @@ class Index {
 // engines implemented in their own translation units
 // approx = true: no exact re-rank, the top-k is selected on the fp16 keys (kNN-graph construction), filters ignored
 int32_t flat_mfma_search(Index& ix, const float* dq, int64_t nq, int k, u64* run_keys, bool approx = false);
-int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u64* run_keys, bool approx);  // <= 2048 queries
+int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u64* run_keys, bool approx, int cap_scale = 1);  // <= 2048 queries
 bool flat_mfma_profitable(const Index& ix, int64_t nq, int k);  // AUTO heuristic
 void half_mirror_free(HalfMirror* m);
 int32_t graph_upload(Index& ix);

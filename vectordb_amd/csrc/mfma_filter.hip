@@ -278,7 +278,7 @@ bool flat_mfma_profitable(const Index& ix, int64_t nq, int k) {
   return filter_s < stream_s;
 }
 
-int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u64* run_keys, bool approx) {
+int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u64* run_keys, bool approx, int cap_scale) {
   int32_t rc = ensure_mirror(ix);
   if (rc != EPS_OK) return rc;
   HalfMirror& m = *ix.mirror_;
@@ -289,7 +289,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   }
   hipStream_t s = ix.stream_;
   const int64_t b_pad = (nq + BN3 - 1) / BN3 * BN3;
-  const int cap = std::max(4096, 64 * k);
+  const int cap = std::max(4096, 64 * k) * cap_scale;   // candidate slots per query and stage
   if (!m.qh.reserve((size_t)b_pad * m.d_pad * 2) || !m.qstat.reserve((size_t)b_pad * 16) || !m.T.reserve((size_t)b_pad * 4) ||
       !m.cand.reserve((size_t)nq * cap * 8) || !m.cnt.reserve((size_t)(nq + 4) * 4 + 16))
     return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory (scratch)");
@@ -494,7 +494,13 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   ix.stats_.main_kernel_launches = 1;
   if (h.overflow) {
     ix.stats_.overflow_queries += h.overflow;
-    if (!approx && !fa.ablate) return ix.flat_stream(dq, nq, k, 0, n, run_keys, false);  // exact fallback for the (rare) overflow case
+    if (!approx && !fa.ablate) {
+      // (selective filters inflate the lists by 1 / pass fraction, adversarial row orders by more): first retry with 16 x
+      // the candidate slots - re-ranking tens of thousands of rows per query is still ~50 x cheaper than the stream scan
+      // of a large batch - then the exact stream engine
+      if (cap_scale == 1 && (size_t)nq * cap * 16 * 8 <= ((size_t)4 << 30)) return flat_mfma_search_slice(ix, dq, nq, k, run_keys, approx, 16);
+      return ix.flat_stream(dq, nq, k, 0, n, run_keys, false);
+    }
   }
   return EPS_OK;
 }
