@@ -43,6 +43,8 @@ struct HalfMirror {
   DevBuf zeros_s;  // float [n_pad]  0 (-inf on padding rows)
   DevBuf qf;       // _Float16 fragment-major copy of qh (v5)
   DevBuf gsync;    // u32 [64]: v7 group arrival counters
+  DevBuf sxh, sbase, sbase_u;   // seed sample: S0 rows spread evenly over [0, n) (fp16 rows, their base / s, their base)
+  int64_t sample_version = -1, sample_n = 0, sample_rows = 0;
   DevBuf scal;     // float [4]: E1max, nxh_max, xn_max, overflow flag (as float bits)
   DevBuf qh;       // _Float16 [b_pad][d_pad]
   DevBuf qstat;    // float [b_pad][4]: |q|^2, |q|, |q-qh|, unused
@@ -208,15 +210,30 @@ __global__ void threshold_kernel(const u64* run_keys, int k, int64_t nq, int64_t
 }
 
 
+// seed sample: S rows spread evenly over [0, n) copied next to each other (a positional filter - "the newest rows" - that
+// hides the whole head of the table still leaves visible seeds)
+__global__ __launch_bounds__(256) void seed_sample_kernel(const _Float16* xh, const float* base_s, const float* base, unsigned long long stride,
+                                                          int d_pad, _Float16* sxh, float* sbase, float* sbase_u) {
+  const int64_t i = blockIdx.x;
+  const int64_t r = (int64_t)(((u64)i * stride) >> 32);   // the same fixed-point map the filter kernel applies to its keys
+  const half8* src = reinterpret_cast<const half8*>(xh + r * d_pad);
+  half8* dst = reinterpret_cast<half8*>(sxh + i * d_pad);
+  for (int c = threadIdx.x; c < d_pad / 8; c += 256) dst[c] = src[c];
+  if (threadIdx.x == 0) {
+    sbase[i] = base_s[r];
+    sbase_u[i] = base[r];
+  }
+}
+
 // seeds: the k best APPROXIMATE keys of the head rows (in run_keys) -> candidate ids for the exact re-rank; run_keys is
 // reset so that the re-rank leaves exactly the seeds' exact keys in it
-__global__ void seed_to_cand_kernel(u64* run_keys, int k, int64_t nq, u32* cand, int cap, u32* cnt) {
+__global__ void seed_to_cand_kernel(u64* run_keys, int k, int64_t nq, u32* cand, int cap, u32* cnt, unsigned long long id_stride) {
   const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= nq) return;
   u32 c = 0;
   for (int e = 0; e < k; ++e) {
     const u64 key = run_keys[q * k + e];
-    if (key != KEY_EMPTY) cand[q * (int64_t)cap + c++] = key_id(key);
+    if (key != KEY_EMPTY) cand[q * (int64_t)cap + c++] = id_stride ? (u32)(((u64)key_id(key) * id_stride) >> 32) : key_id(key);
     run_keys[q * k + e] = KEY_EMPTY;
   }
   cnt[q] = c;
@@ -430,16 +447,33 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
     const bool dense = version >= 7;   // v7 writes the head's keys densely (slot = row); older kernels append with atomics
     er = dense ? hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(cnt), (int)S0, (size_t)nq, s) : hipMemsetAsync(cnt, 0, (size_t)nq * 4, s);
     if (er != hipSuccess) return ix.hip_fail(er, "memset");
+    unsigned long long seed_stride = 0;   // != 0: the seed pass ran over the sample, ids are sample indices
     FilterArgs f0 = fa;
     f0.dense = dense ? 1 : 0;
     f0.cand_keys = m.cand.as<u64>();
+    if (!approx) {   // exact mode: seeds from a sample spread over the whole table (approx mode keeps the head's keys)
+      const unsigned long long sample_stride = (unsigned long long)(((unsigned __int128)n << 32) / (unsigned __int128)S0);   // n / S0 in 32.32
+      if (m.sample_version != ix.rows_version_ || m.sample_n != n || m.sample_rows != S0) {
+        if (!m.sxh.reserve((size_t)S0 * m.d_pad * 2) || !m.sbase.reserve((size_t)S0 * 4) || !m.sbase_u.reserve((size_t)S0 * 4))
+          return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory (seed sample)");
+        hipLaunchKernelGGL(seed_sample_kernel, dim3((unsigned)S0), dim3(256), 0, s, m.xh.as<_Float16>(), fa.base_s, fa.base, sample_stride, m.d_pad,
+                           m.sxh.as<_Float16>(), m.sbase.as<float>(), m.sbase_u.as<float>());
+        m.sample_version = ix.rows_version_;
+        m.sample_n = n;
+        m.sample_rows = S0;
+      }
+      f0.xh = m.sxh.as<_Float16>();
+      f0.base_s = m.sbase.as<float>();
+      f0.base = m.sbase_u.as<float>();
+      seed_stride = sample_stride;
+    }
     f0.tile0 = 0;
     f0.ntiles = (S0 + bm - 1) / bm;
     f0.row_hi = S0;
     launch_filter(f0);
-    launch_merge_lists(f0.cand_keys, cap, k, nq, run_keys, false, s, cnt, approx ? nullptr : &fs);   // k best approximate keys of the (visible) head
+    launch_merge_lists(f0.cand_keys, cap, k, nq, run_keys, false, s, cnt, approx ? nullptr : &fs, seed_stride);   // k best approximate keys of the visible seeds
     if (!approx) {
-      hipLaunchKernelGGL(seed_to_cand_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, run_keys, k, nq, fa.cand, cap, cnt);
+      hipLaunchKernelGGL(seed_to_cand_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, run_keys, k, nq, fa.cand, cap, cnt, seed_stride);
       launch_rerank(ra, s);                                                    // -> their exact keys
     }
   }

@@ -765,7 +765,8 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
               const bool nan = dapx != dapx;
               if (a.metric == 0) dapx = fmaxf(dapx, 0.f);
               if (row < a.row_hi)
-                a.cand_keys[qq * (int64_t)a.cap + (row - a.tile0 * 256)] = nan ? KEY_EMPTY : make_key(dapx, (u32)row);
+                a.cand_keys[qq * (int64_t)a.cap + (row - a.tile0 * 256)] =
+                    nan ? KEY_EMPTY : make_key(dapx, (u32)row);
             }
           }
           continue;
