@@ -79,6 +79,12 @@ __device__ __forceinline__ bool row_visible(const FilterSpec& f, u32 id) {
   return true;
 }
 
+// Seed sample of the MFMA engine: sample entry i is table row i for the first `head` entries (the head of the table), then
+// rows spread evenly over the rest: head + ((i - head) * stride >> 32), stride = (rest rows / rest entries) in 32.32.
+__host__ __device__ __forceinline__ u32 seed_row(u32 i, u32 head, u64 stride) {
+  return i < head ? i : head + (u32)(((u64)(i - head) * stride) >> 32);
+}
+
 // metric epilogue on the raw accumulator (sum of squared differences for L2, dot otherwise)
 __device__ __forceinline__ float finish_dist(int metric, float acc) {
   return metric == 0 ? acc : (metric == 1 ? 1.0f - acc : -acc);

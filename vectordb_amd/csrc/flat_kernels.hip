@@ -141,7 +141,7 @@ void launch_flat_scan(const FlatScanArgs& a, hipStream_t s) {
 // One block per query.
 template <int KPL>
 __global__ __launch_bounds__(256) void merge_lists_kernel(const u64* partial, int lists, int k, u64* run_keys,
-                                                          int merge_run, const u32* counts, FilterSpec vis, u64 id_stride) {
+                                                          int merge_run, const u32* counts, FilterSpec vis, u64 id_stride, u32 id_head) {
   __shared__ u64 sh[4][KPL * 64];
   const int64_t q = blockIdx.x;
   const int lane = lane_id();
@@ -161,8 +161,8 @@ __global__ __launch_bounds__(256) void merge_lists_kernel(const u64* partial, in
   const int rounded = (total + 255) & ~255;
   for (int i = threadIdx.x; i < rounded; i += 256) {
     const u64 key = i < total ? src[i] : KEY_EMPTY;
-    if (id_stride) {   // seed selection over a SAMPLE: entry ids are sample indices, row = (index * id_stride) >> 32
-      const bool ok = key != KEY_EMPTY && row_visible(vis, (u32)(((u64)key_id(key) * id_stride) >> 32));
+    if (id_stride) {   // seed selection over a SAMPLE: entry ids are sample indices (seed_row maps them to rows)
+      const bool ok = key != KEY_EMPTY && row_visible(vis, seed_row(key_id(key), id_head, id_stride));
       offer<1, KPL>(L, thr, 0, key, ok, nof, k, false);
     } else {
       offer<1, KPL>(L, thr, 0, key, key != KEY_EMPTY, vis, k, false);   // vis: only rows the filter lets through
@@ -183,13 +183,13 @@ __global__ __launch_bounds__(256) void merge_lists_kernel(const u64* partial, in
 }
 
 void launch_merge_lists(const u64* partial, int lists, int k, int64_t nq, u64* run_keys, bool merge_run, hipStream_t s,
-                        const u32* counts, const FilterSpec* visible, u64 id_stride) {
+                        const u32* counts, const FilterSpec* visible, u64 id_stride, u32 id_head) {
   const FilterSpec vis = visible ? *visible : FilterSpec{nullptr, nullptr, 0, 0, 0, 0};
   if (nq <= 0) return;
   const int kpl = pick_kpl(k);
 #define EPS_CASE(KPL_) \
   if (kpl == KPL_) {   \
-    hipLaunchKernelGGL((merge_lists_kernel<KPL_>), dim3((unsigned)nq), dim3(256), 0, s, partial, lists, k, run_keys, merge_run ? 1 : 0, counts, vis, id_stride); \
+    hipLaunchKernelGGL((merge_lists_kernel<KPL_>), dim3((unsigned)nq), dim3(256), 0, s, partial, lists, k, run_keys, merge_run ? 1 : 0, counts, vis, id_stride, id_head); \
     return;            \
   }
   EPS_CASE(1) EPS_CASE(2) EPS_CASE(4) EPS_CASE(8) EPS_CASE(16)

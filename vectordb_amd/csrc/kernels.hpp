@@ -29,7 +29,7 @@ void launch_flat_scan(const FlatScanArgs& a, hipStream_t s);
 // merge the `slots` keys of each query (plus, if merge_run, the existing run_keys[q][k]) into run_keys[q][k].
 // counts (optional): per-query number of valid keys at the front of its slots (candidate lists).
 void launch_merge_lists(const u64* keys, int slots, int k, int64_t nq, u64* run_keys, bool merge_run, hipStream_t s,
-                        const u32* counts = nullptr, const FilterSpec* visible = nullptr, u64 id_stride = 0);
+                        const u32* counts = nullptr, const FilterSpec* visible = nullptr, u64 id_stride = 0, u32 id_head = 0);
 
 // exact fp32 re-rank of gathered candidate rows into run_keys (sorted, unique)
 struct RerankArgs {

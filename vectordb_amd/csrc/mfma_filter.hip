@@ -210,12 +210,12 @@ __global__ void threshold_kernel(const u64* run_keys, int k, int64_t nq, int64_t
 }
 
 
-// seed sample: S rows spread evenly over [0, n) copied next to each other (a positional filter - "the newest rows" - that
-// hides the whole head of the table still leaves visible seeds)
+// seed sample: the first S/2 rows of the table plus S/2 rows spread evenly over the rest, copied next to each other (a
+// positional filter - "only the newest rows" or "only the oldest" - leaves at least half of the seeds' share visible)
 __global__ __launch_bounds__(256) void seed_sample_kernel(const _Float16* xh, const float* base_s, const float* base, unsigned long long stride,
-                                                          int d_pad, _Float16* sxh, float* sbase, float* sbase_u) {
+                                                          u32 head, int d_pad, _Float16* sxh, float* sbase, float* sbase_u) {
   const int64_t i = blockIdx.x;
-  const int64_t r = (int64_t)(((u64)i * stride) >> 32);   // the same fixed-point map the filter kernel applies to its keys
+  const int64_t r = seed_row((u32)i, head, stride);
   const half8* src = reinterpret_cast<const half8*>(xh + r * d_pad);
   half8* dst = reinterpret_cast<half8*>(sxh + i * d_pad);
   for (int c = threadIdx.x; c < d_pad / 8; c += 256) dst[c] = src[c];
@@ -227,13 +227,13 @@ __global__ __launch_bounds__(256) void seed_sample_kernel(const _Float16* xh, co
 
 // seeds: the k best APPROXIMATE keys of the head rows (in run_keys) -> candidate ids for the exact re-rank; run_keys is
 // reset so that the re-rank leaves exactly the seeds' exact keys in it
-__global__ void seed_to_cand_kernel(u64* run_keys, int k, int64_t nq, u32* cand, int cap, u32* cnt, unsigned long long id_stride) {
+__global__ void seed_to_cand_kernel(u64* run_keys, int k, int64_t nq, u32* cand, int cap, u32* cnt, unsigned long long id_stride, u32 id_head) {
   const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= nq) return;
   u32 c = 0;
   for (int e = 0; e < k; ++e) {
     const u64 key = run_keys[q * k + e];
-    if (key != KEY_EMPTY) cand[q * (int64_t)cap + c++] = id_stride ? (u32)(((u64)key_id(key) * id_stride) >> 32) : key_id(key);
+    if (key != KEY_EMPTY) cand[q * (int64_t)cap + c++] = id_stride ? seed_row(key_id(key), id_head, id_stride) : key_id(key);
     run_keys[q * k + e] = KEY_EMPTY;
   }
   cnt[q] = c;
@@ -448,15 +448,17 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
     er = dense ? hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(cnt), (int)S0, (size_t)nq, s) : hipMemsetAsync(cnt, 0, (size_t)nq * 4, s);
     if (er != hipSuccess) return ix.hip_fail(er, "memset");
     unsigned long long seed_stride = 0;   // != 0: the seed pass ran over the sample, ids are sample indices
+    u32 seed_head = 0;
     FilterArgs f0 = fa;
     f0.dense = dense ? 1 : 0;
     f0.cand_keys = m.cand.as<u64>();
     if (!approx) {   // exact mode: seeds from a sample spread over the whole table (approx mode keeps the head's keys)
-      const unsigned long long sample_stride = (unsigned long long)(((unsigned __int128)n << 32) / (unsigned __int128)S0);   // n / S0 in 32.32
+      const u32 sample_head = (u32)(S0 / 2);
+      const unsigned long long sample_stride = (unsigned long long)(((unsigned __int128)(n - sample_head) << 32) / (unsigned __int128)(S0 - sample_head));
       if (m.sample_version != ix.rows_version_ || m.sample_n != n || m.sample_rows != S0) {
         if (!m.sxh.reserve((size_t)S0 * m.d_pad * 2) || !m.sbase.reserve((size_t)S0 * 4) || !m.sbase_u.reserve((size_t)S0 * 4))
           return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory (seed sample)");
-        hipLaunchKernelGGL(seed_sample_kernel, dim3((unsigned)S0), dim3(256), 0, s, m.xh.as<_Float16>(), fa.base_s, fa.base, sample_stride, m.d_pad,
+        hipLaunchKernelGGL(seed_sample_kernel, dim3((unsigned)S0), dim3(256), 0, s, m.xh.as<_Float16>(), fa.base_s, fa.base, sample_stride, sample_head, m.d_pad,
                            m.sxh.as<_Float16>(), m.sbase.as<float>(), m.sbase_u.as<float>());
         m.sample_version = ix.rows_version_;
         m.sample_n = n;
@@ -466,14 +468,15 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
       f0.base_s = m.sbase.as<float>();
       f0.base = m.sbase_u.as<float>();
       seed_stride = sample_stride;
+      seed_head = sample_head;
     }
     f0.tile0 = 0;
     f0.ntiles = (S0 + bm - 1) / bm;
     f0.row_hi = S0;
     launch_filter(f0);
-    launch_merge_lists(f0.cand_keys, cap, k, nq, run_keys, false, s, cnt, approx ? nullptr : &fs, seed_stride);   // k best approximate keys of the visible seeds
+    launch_merge_lists(f0.cand_keys, cap, k, nq, run_keys, false, s, cnt, approx ? nullptr : &fs, seed_stride, seed_head);   // k best approximate keys of the visible seeds
     if (!approx) {
-      hipLaunchKernelGGL(seed_to_cand_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, run_keys, k, nq, fa.cand, cap, cnt, seed_stride);
+      hipLaunchKernelGGL(seed_to_cand_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, run_keys, k, nq, fa.cand, cap, cnt, seed_stride, seed_head);
       launch_rerank(ra, s);                                                    // -> their exact keys
     }
   }
