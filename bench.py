@@ -32,7 +32,8 @@ sys.path.insert(0, ROOT)
 # from HBM once; without the per-tile rendezvous of the workgroups that share a row tile it was 27.4e9).
 TRAFFIC = {"mfma": (2 * 7042014 + 11837) * 1024.0}
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-MFMA_F16_PEAK_TF = 2500.0  # dense bf16/f16 MFMA peak
+MFMA_F16_PEAK_TF = 2500.0  # dense bf16/f16 MFMA peak (nominal, 2.4 GHz)
+MFMA_F16_SUSTAINED_TF = 1814.0  # measured: v_mfma_f32_32x32x16_f16 alone, operands toggling like data, 1.82 GHz (scripts/lab/mfma_peak.hip)
 
 
 def parse():
@@ -258,6 +259,9 @@ def main():
             roof = {"bound": "hbm", "kernel": "flat_scan_kernel", "achieved": alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms else None,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
         roof["frac"] = (roof["achieved"] / roof["peak"]) if roof["achieved"] else None
+        if used_mfma and roof["achieved"]:
+            roof["sustained_peak_measured"] = MFMA_F16_SUSTAINED_TF
+            roof["frac_of_sustained"] = roof["achieved"] / MFMA_F16_SUSTAINED_TF
         roof["kernel_ms_per_step"] = kernel_ms * (b / float(np.mean(kq)) if used_mfma and kq else 1.0)   # all slices of a step
         roof["kernel_ms_per_launch"] = kernel_ms
         res = {
