@@ -1,0 +1,34 @@
+"""bench.py's output contract (one JSON line with the driver's keys, `roofline` and `cpu_baseline`), on a small workload."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_json_line_with_the_contract_keys():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--rows", "300000",
+                        "--batch", "256", "--cpu-seconds", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["value"] > 0 and abs(d["value"] - 256 * 1000.0 / d["ms_per_step"]) < 1e-6 * d["value"] + 1e-6
+    assert "workload" in d["config"]
+    roof = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in roof, key
+    assert roof["bound"] in ("hbm", "mfma") and 0 < roof["frac"] < 1
+    cb = d["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in cb, key
+    assert cb["kind"] in ("reference", "port")
+    assert d["recall_at_10"] >= 0.999
