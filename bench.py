@@ -252,6 +252,11 @@ def main():
                     "achieved": flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms else None,
                     "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
                     "traffic": TRAFFIC.get("mfma") if (world == 1 and n == 10_000_000 and b == 1024 and d == 768) else None}
+        elif args.mode == "graph":
+            # E evaluations (a row + its id) and X expansions (offsets + an adjacency list) per launch
+            alg_bytes = st["dist_evals"] * (4.0 * d + 4) + st["expansions"] * (8 + 4 * 50.0)
+            roof = {"bound": "hbm", "kernel": "traverse_kernel (gather: E*(4d+4) + X*(8+4*deg) bytes)",
+                    "achieved": alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
         else:
             # a flat scan needs rows*4*d bytes ONCE per batch; the stream engine re-reads the store once
             # per group of 4 queries, which this figure deliberately does not credit.
