@@ -17,8 +17,9 @@
  *   - std::sort on NSG `Neighbor` (distance-only order, neighbor.hpp:25-28) is unstable on ties in
  *     the reference; here a stable merge sort is used, so results agree on tie-free inputs.
  *   - multi-thread SearchImpl (T > 1) is racy in the reference; here the T workers of a round run
- *     one after another in worker order, which is one of the interleavings the reference allows.
- *     T == 1 is bit-deterministic on both sides.
+ *     either one after another in worker order, or in lockstep (eo_set_schedule(1): step i of every
+ *     worker before step i+1 of any, workers in order within a step — the schedule the device kernel
+ *     implements); both are interleavings the reference allows.  T == 1 is bit-deterministic on both sides.
  *   - filters: only `<int column> <op> <int const>` (what the C-ABI lowers to the device); the
  *     reference's general expression engine (engine/query/expr) stays on the host DBMS.
  */
@@ -343,6 +344,14 @@ static int64_t expand_one(eo_ctx* c, int64_t cand_id, const float* bound, eo_can
  * (start (T-1)*Lq, size L).  `visited` is an n-byte scratch that must be zero on entry; it is zeroed
  * again on exit (the reference's per-query clear()+resize(n), :711-714).
  * On return the master queue set_L[(T-1)*Lq .. +L) is the sorted result.  Returns #distance evals. */
+static int g_lockstep = 0;
+/* selects the interleaving eo_search_impl uses for T > 1 (see the parallel region below); returns the previous value */
+int eo_set_schedule(int lockstep) {
+  const int old = g_lockstep;
+  g_lockstep = lockstep;
+  return old;
+}
+
 int64_t eo_search_impl(int metric, const float* rows, int64_t d, int64_t n, const int64_t* off, const int64_t* nbr,
                        const int64_t* init_ids, const float* q, int T, int64_t L, int64_t Lq, int64_t I, eo_cand* set_L,
                        uint8_t* visited) {
@@ -403,24 +412,57 @@ int64_t eo_search_impl(int metric, const float* rows, int64_t d, int64_t n, cons
       }
     }
     if (!count) break;
-    /* the parallel region (:616-679), workers serialised in worker order */
-    for (int w = 0; w < T; ++w) {
-      eo_cand* queue = set_L + starts[w];
-      int64_t* qsize = &sizes[w];
-      int64_t k_uc = (T - 1 != w) ? 0 : k_master;
-      int64_t it = 0;
-      while (it < I && k_uc < *qsize) {
-        eo_cand* cand = &queue[k_uc];
-        if (!cand->checked) {
-          cand->checked = 1;
-          ++it;
-          int64_t r = expand_one(&c, cand->id, last_dist, queue, qsize, Lq);
-          if (r <= k_uc) k_uc = r; else ++k_uc;
-        } else {
-          ++k_uc;
+    /* the parallel region (:616-679).  The reference's T OpenMP workers race on is_visited and on the live bound;
+     * two deterministic interleavings of it are restated here (both are executions the reference allows):
+     *   schedule 0: the workers run one after another in worker order, each doing all of its <= I expansions;
+     *   schedule 1 ("lockstep"): expansion i of every worker happens before expansion i+1 of any worker, and
+     *     within one step the workers go in worker order (master last).  This is the schedule the device kernel
+     *     implements (all T expansions of a step are in flight at once; conflicts on the visited set are
+     *     resolved in worker order), so GPU-vs-oracle parity at T > 1 is bit-exact under it. */
+    if (!g_lockstep) {
+      for (int w = 0; w < T; ++w) {
+        eo_cand* queue = set_L + starts[w];
+        int64_t* qsize = &sizes[w];
+        int64_t k_uc = (T - 1 != w) ? 0 : k_master;
+        int64_t it = 0;
+        while (it < I && k_uc < *qsize) {
+          eo_cand* cand = &queue[k_uc];
+          if (!cand->checked) {
+            cand->checked = 1;
+            ++it;
+            int64_t r = expand_one(&c, cand->id, last_dist, queue, qsize, Lq);
+            if (r <= k_uc) k_uc = r; else ++k_uc;
+          } else {
+            ++k_uc;
+          }
+          if (T - 1 == w) k_master = k_uc;
         }
-        if (T - 1 == w) k_master = k_uc;
       }
+    } else {
+      int64_t* k_uc = (int64_t*)malloc(sizeof(int64_t) * (size_t)T);
+      int64_t* its = (int64_t*)calloc((size_t)T, sizeof(int64_t));
+      for (int w = 0; w < T; ++w) k_uc[w] = (T - 1 != w) ? 0 : k_master;
+      for (;;) {
+        int any = 0;
+        for (int w = 0; w < T; ++w) {
+          eo_cand* queue = set_L + starts[w];
+          int64_t* qsize = &sizes[w];
+          /* the `else ++k_uc` branch (:671) costs no iteration: skip checked entries */
+          while (its[w] < I && k_uc[w] < *qsize && queue[k_uc[w]].checked) ++k_uc[w];
+          if (T - 1 == w) k_master = k_uc[w];
+          if (!(its[w] < I && k_uc[w] < *qsize)) continue;
+          eo_cand* cand = &queue[k_uc[w]];
+          cand->checked = 1;
+          ++its[w];
+          int64_t r = expand_one(&c, cand->id, last_dist, queue, qsize, Lq);
+          if (r <= k_uc[w]) k_uc[w] = r; else ++k_uc[w];
+          if (T - 1 == w) k_master = k_uc[w];
+          any = 1;
+        }
+        if (!any) break;
+      }
+      free(k_uc);
+      free(its);
     }
     /* MergeAllQueuesToMaster */
     {

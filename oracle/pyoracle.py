@@ -96,6 +96,8 @@ class Oracle:
         L.eo_search_impl.restype = i64
         L.eo_search_impl.argtypes = [C.c_int, fptr, i64, i64, iptr, iptr, iptr, fptr, C.c_int, i64, i64, i64,
                                      C.POINTER(EoCand), u8ptr]
+        L.eo_set_schedule.restype = C.c_int
+        L.eo_set_schedule.argtypes = [C.c_int]
         L.eo_search.restype = i64
         L.eo_search.argtypes = [C.c_int, fptr, i64, i64, i64, iptr, iptr, i64, fptr, i64, C.c_int, i64, i64, i64,
                                 C.c_int, C.POINTER(EoFilter), iptr, C.POINTER(C.c_double), iptr]
@@ -157,8 +159,10 @@ class Oracle:
         self.L.eo_prepare_init_ids(n, _i(off), _i(nbr), nav, L, _i(out))
         return out
 
-    def search_impl(self, metric, rows, off, nbr, init_ids, q, T=1, L=500, Lq=None, I=15):
+    def search_impl(self, metric, rows, off, nbr, init_ids, q, T=1, L=500, Lq=None, I=15, lockstep=False):
+        """lockstep=True: the T > 1 interleaving the device kernel implements (see eo_search_impl)."""
         Lq = L if Lq is None else Lq
+        self.L.eo_set_schedule(int(lockstep))
         rows = np.ascontiguousarray(rows, np.float32)
         n = len(off) - 1
         set_l = (EoCand * ((T - 1) * Lq + L))()
@@ -171,8 +175,9 @@ class Oracle:
         return ids, ds, ev
 
     def search(self, metric, rows, n_indexed, off, nbr, nav, q, limit, T=1, L=500, Lq=None, I=15, prefilter=False,
-               flt=None, n_total=None):
+               flt=None, n_total=None, lockstep=False):
         Lq = L if Lq is None else Lq
+        self.L.eo_set_schedule(int(lockstep))
         rows = np.ascontiguousarray(rows, np.float32)
         n_total = rows.shape[0] if n_total is None else n_total
         cap = max(L, limit, 1)

@@ -2,25 +2,20 @@
 // graph branch of VecSearchExecutor::Search (reference: engine/db/execution/vec_search_executor.cpp:518-715,
 // 873-927; algorithm spec SURVEY.md Appendix A.2/A.4).
 //
-// One workgroup (4 wavefronts) per query, the whole batch in flight at once:
-//   * master queue of L candidates sorted by (dist,id) in LDS, `checked` flag in bit 0 of the key
-//     (Candidate, candidate.hpp:7-23; set_L_, vec_search_executor.hpp:55);
-//   * visited set = per-query bitmap in HBM, test-and-set with one atomicOr per neighbour
-//     (is_visited_, :403-406);
-//   * a round expands the first M unchecked candidates at once: CSR rows gathered, visited-filtered and
-//     compacted through LDS, surviving rows streamed with 16 B/lane loads by all four wavefronts
-//     (ExpandOneCandidate, :384-444), the survivors rank-sorted and merged into the queue in place
-//     (AddIntoQueue :75-117 / MergeTwoQueues :150-217 become one parallel merge).
-// With M = 1 (IntraQueryThreads = 1) the sequence of expansions and the final queue are exactly the
-// reference's single-thread result (see DESIGN.md "traversal equivalence"); M > 1 plays the role of the
-// reference's T workers, whose interleaving is not deterministic in the reference either.
+// The kernel is traverse2_kernel.hpp (one workgroup per visited-set slot walking over the queries of the batch;
+// T workers with local queues in lockstep; queues in LDS or, for large SearchQueueSize, in HBM; visited bitmap
+// with an undo log instead of an O(N) reset per query).  This file holds the host side: device CSR, scratch,
+// PrepareInitIds, the launch, and post_kernel = the epilogue of Search() (tail merge + post-filter walk).
+// With IntraQueryThreads = 1 the sequence of expansions and the final queue are exactly the reference's
+// single-thread result; with T > 1 they are the reference's result under the lockstep interleaving of its
+// workers (deterministic here, racy in the reference), restated by oracle/epsilla_oracle.c for parity.
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
 
 #include "index.hpp"
-#include "traverse_kernel.hpp"
+#include "traverse2_kernel.hpp"
 
 namespace eps {
 
@@ -31,7 +26,12 @@ struct GraphDev {
   DevBuf init_ids;   // u32 [L]
   int64_t init_L = -1;
   int64_t max_degree = 0;
-  DevBuf visited;    // u32 [nq_chunk][words]
+  DevBuf visited;    // u32 [slots][words]: all-zero between searches (the kernel undoes what it sets)
+  int64_t vis_slots = 0, vis_words = 0;
+  bool vis_dirty = true;   // a failed launch may have left bits behind: re-zero before the next search
+  DevBuf vlog;       // u32 [slots][vcap] undo log of the visited set
+  DevBuf qglobal;    // u64 [slots][qtot] queues of large-L searches
+  DevBuf auxglobal;  // int [slots][2*Lq]
   DevBuf queue;      // u64 [nq][L]
   DevBuf counters;   // unsigned long long [2]
   DevBuf tail;       // u64 [nq][k] brute-force tail lists
@@ -118,25 +118,29 @@ struct PostArgs {
 };
 
 __device__ __forceinline__ bool ckey_less(u64 a, u64 b) { return a < b; }  // plain (dist,id) keys
+__device__ __forceinline__ u64 plain_key(u64 v) {  // traversal key -> (dist,id) key
+  return v == KEY_EMPTY ? KEY_EMPTY : ((v & 0xFFFFFFFF00000000ull) | ((v & 0xFFFFFFFFull) >> 1));
+}
 
+// One wavefront per query.  Only the first K slots of the master queue take part in the tail merge (they are staged in
+// LDS); the post-filter walk reads slots >= K straight from the queue in HBM, 64 candidates per step (ballot + prefix).
 __global__ __launch_bounds__(64) void post_kernel(PostArgs a) {
-  extern __shared__ __attribute__((aligned(16))) u64 m[];  // [L] master as plain keys
+  extern __shared__ __attribute__((aligned(16))) u64 m[];  // [K] head of the master queue as plain keys
+  __shared__ int s_cand;
   const int64_t q = blockIdx.x;
   const int L = a.L;
-  for (int i = threadIdx.x; i < L; i += 64) {
-    const u64 v = a.queue[q * L + i];
-    m[i] = v == KEY_EMPTY ? KEY_EMPTY : ((v & 0xFFFFFFFF00000000ull) | ((v & 0xFFFFFFFFull) >> 1));
-  }
+  const int lane = threadIdx.x;
+  const u64* qu = a.queue + q * L;
+  for (int i = lane; i < a.K; i += 64) m[i] = plain_key(qu[i]);
+  if (lane == 0) s_cand = a.cand_num;
   __syncthreads();
-  if (threadIdx.x != 0) return;
-  int cand_num = a.cand_num;
-  if (a.tail) {
+  if (a.tail && lane == 0) {
     const u64* bf = a.tail + q * a.k;
     int n2 = 0;
     while (n2 < a.k && bf[n2] != KEY_EMPTY) ++n2;
     if (n2 > 0) {
       const int n1 = a.K;
-      // lower_bound of bf[0] in m[0..n1)
+      // MergeTwoQueuesInto1stQueueSeqFixed (:150-217) on m[0..n1): lower_bound of bf[0]
       int lo = 0, hi = n1;
       while (lo < hi) {
         const int mid = (lo + hi) >> 1;
@@ -167,30 +171,47 @@ __global__ __launch_bounds__(64) void post_kernel(PostArgs a) {
           }
         }
       }
-      cand_num = a.cand_num_tail;
+      s_cand = a.cand_num_tail;
     }
   }
+  __syncthreads();
+  const int cand_num = s_cand;
   int res = 0;
-  for (int i = 0; i < cand_num && res < a.K; ++i) {
-    const u64 v = m[i];
-    if (v == KEY_EMPTY) continue;
-    if (!row_visible(a.f, key_id(v))) continue;
-    a.run_keys[q * a.k + res] = v;
-    ++res;
+  for (int base = 0; base < cand_num && res < a.K; base += 64) {
+    const int i = base + lane;
+    u64 v = KEY_EMPTY;
+    if (i < cand_num) v = i < a.K ? m[i] : plain_key(qu[i]);
+    const bool ok = v != KEY_EMPTY && row_visible(a.f, key_id(v));
+    const u64 mask = __ballot(ok);
+    const int rank = res + __popcll(mask & ((1ull << lane) - 1ull));
+    if (ok && rank < a.K) a.run_keys[q * a.k + rank] = v;
+    res += __popcll(mask);
   }
-  for (; res < a.k; ++res) a.run_keys[q * a.k + res] = KEY_EMPTY;
+  if (res > a.K) res = a.K;
+  for (int i = res + lane; i < a.k; i += 64) a.run_keys[q * a.k + i] = KEY_EMPTY;
 }
 
 // ------------------------------------------------------------------------------------------------ host
+template <bool VEC4, int NW, bool QG>
+static void launch_trv2(const Trv2Args& a, int slots, size_t shm, hipStream_t s) {
+  // (idempotent and cheap; per call so that no process-wide state is needed)
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(traverse2_kernel<VEC4, NW, QG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+  hipLaunchKernelGGL((traverse2_kernel<VEC4, NW, QG>), dim3((unsigned)slots), dim3(NW * 64), shm, s, a);
+}
+
 int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_search_params& p, u64* run_keys,
                      int64_t* evals_out) {
   GraphDev& g = *ix.graph_;
   const int64_t n = ix.n_indexed_;
   int64_t L = p.master_queue;
   if (L > n) L = n;  // the reference would spin forever in PrepareInitIds when L > n (see prepare_init_ids)
-  if (L > 4096) return ix.fail(EPS_DB_UNSUPPORTED_ERROR, "search: SearchQueueSize > 4096 is not supported by the LDS-resident queue (use the flat engines)");
-  int M = p.intra_threads;
-  if (M > TRV_MAXM) M = TRV_MAXM;
+  if (L > ((int64_t)1 << 20)) return ix.fail(EPS_DB_UNSUPPORTED_ERROR, "search: SearchQueueSize > 1048576 is not supported (use the flat engines)");
+  int64_t Lq = p.local_queue;
+  if (Lq > n) Lq = n;
+  if (Lq > ((int64_t)1 << 20)) Lq = (int64_t)1 << 20;
+  int T = p.intra_threads;
+  if (T > TRV2_MAXT) T = TRV2_MAXT;   // more workers than a workgroup can usefully keep in flight
+  const int I = (int)std::min<int64_t>(p.sync_interval, 1 << 20);
   int Lp2 = 1;
   while (Lp2 < L) Lp2 <<= 1;
   hipStream_t s = ix.stream_;
@@ -204,58 +225,67 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
     if (er != hipSuccess) return ix.hip_fail(er, "init ids upload");
     g.init_L = L;
   }
+  const int dp = g.fixed_deg > 0 ? g.fixed_deg : (int)((std::max<int64_t>(g.max_degree, 1) + 3) / 4 * 4);
+  if ((int64_t)T * dp > 2048) return ix.fail(EPS_DB_UNSUPPORTED_ERROR, "search: IntraQueryThreads x maximum out-degree > 2048 is not supported");
+  const int64_t qtot = (int64_t)(T - 1) * Lq + Lp2;
+  const bool vec4 = (ix.dim_ % 4 == 0) && ((reinterpret_cast<uintptr_t>(ix.d_rows_) & 15) == 0);
+  // queues in LDS when the whole working set of a workgroup stays within 64 KB (several workgroups per CU keep
+  // the row gathers in flight); larger SearchQueueSize: queues in HBM
+  const bool qglobal = traverse2_lds_bytes((int)ix.dim_, T, (int)Lq, qtot, dp, false) > 65536;
+  const size_t shm = traverse2_lds_bytes((int)ix.dim_, T, (int)Lq, qtot, dp, qglobal);
+  // few queries: 16 wavefronts per query (latency); many queries: 4 per query (throughput, more queries per CU)
+  const char* wide_s = getenv("EPS_TRV_WIDE");
+  const bool wide = wide_s ? atoi(wide_s) != 0 : nq <= 256;
+  hipDeviceProp_t prop;
+  er = hipGetDeviceProperties(&prop, ix.device_);
+  if (er != hipSuccess) return ix.hip_fail(er, "device properties");
+  const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  int per_cu = (int)std::min<size_t>(wide ? 2 : 8, (size_t)(160 * 1024) / shm);
+  if (per_cu < 1) per_cu = 1;
   const int64_t words = (n + 31) / 32;
-  // visited bitmaps: process the batch in slices so the scratch stays below ~2 GiB
-  int64_t slice = nq;
-  const int64_t max_bytes = (int64_t)2 << 30;
-  if (slice * words * 4 > max_bytes) slice = std::max<int64_t>(1, max_bytes / (words * 4));
-  if (!g.visited.reserve((size_t)slice * words * 4) || !g.queue.reserve((size_t)nq * L * 8) || !g.counters.reserve(16))
+  int64_t slots = std::min<int64_t>(nq, (int64_t)cus * per_cu);
+  slots = std::min<int64_t>(slots, std::max<int64_t>(1, ((int64_t)4 << 30) / (words * 4)));
+  if (qglobal) slots = std::min<int64_t>(slots, std::max<int64_t>(1, ((int64_t)8 << 30) / (qtot * 8)));
+  const int vcap = (int)std::min<int64_t>((int64_t)1 << 20, std::max<int64_t>(1024, words / 4));
+  // results of the traversal are consumed per slice of queries so that the [slice][L] queue copy stays below 2 GiB
+  const int64_t slice = std::max<int64_t>(1, std::min<int64_t>(nq, ((int64_t)2 << 30) / (L * 8)));
+  if (!g.visited.reserve((size_t)slots * words * 4) || !g.vlog.reserve((size_t)slots * vcap * 4) ||
+      !g.queue.reserve((size_t)slice * L * 8) || !g.counters.reserve(16) ||
+      (qglobal && (!g.qglobal.reserve((size_t)slots * qtot * 8) || !g.auxglobal.reserve((size_t)slots * 2 * Lq * 4))))
     return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "search: out of device memory (traversal scratch)");
+  if (g.vis_dirty || g.vis_slots < slots || g.vis_words != words) {
+    // (re)establish the invariant the kernel maintains: every slot's bitmap is all-zero between searches
+    er = hipMemsetAsync(g.visited.p, 0, g.visited.cap, s);
+    if (er != hipSuccess) return ix.hip_fail(er, "memset visited");
+    g.vis_slots = (int64_t)(g.visited.cap / ((size_t)words * 4));
+    g.vis_words = words;
+  }
+  g.vis_dirty = true;   // until this search has completed
   er = hipMemsetAsync(g.counters.p, 0, 16, s);
   if (er != hipSuccess) return ix.hip_fail(er, "memset");
 
-  const bool vec4 = (ix.dim_ % 4 == 0) && ((reinterpret_cast<uintptr_t>(ix.d_rows_) & 15) == 0);
-  const int qstride = ((int)ix.dim_ + 3) & ~3;
-  (void)qstride;
-  const size_t shm = traverse_lds_bytes((int)ix.dim_, Lp2, false);
-  TraverseArgs a;
+  Trv2Args a;
   a.rows = ix.d_rows_;
   a.dim = (int)ix.dim_;
   a.metric = ix.metric_;
   a.off = g.fixed_deg > 0 ? nullptr : g.off.as<int64_t>();
   a.nbr = g.nbr.as<u32>();
   a.fixed_deg = g.fixed_deg;
-  a.log = nullptr;
-  a.log_cnt = nullptr;
-  a.log_cap = 0;
+  a.dp = dp;
   a.init_ids = g.init_ids.as<u32>();
   a.L = (int)L;
+  a.Lq = (int)Lq;
   a.Lp2 = Lp2;
-  a.M = M;
+  a.T = T;
+  a.I = I;
+  a.qtot = qtot;
+  a.qglobal = qglobal ? g.qglobal.as<u64>() : nullptr;
+  a.auxglobal = qglobal ? g.auxglobal.as<int>() : nullptr;
   a.visited = g.visited.as<u32>();
   a.words = words;
+  a.vlog = g.vlog.as<u32>();
+  a.vcap = vcap;
   a.counters = g.counters.as<unsigned long long>();
-  (void)hipEventRecord(ix.evk0_, s);
-  for (int64_t q0 = 0; q0 < nq; q0 += slice) {
-    const int64_t cnt = std::min(slice, nq - q0);
-    er = hipMemsetAsync(g.visited.p, 0, (size_t)cnt * words * 4, s);  // is_visited.clear()/resize(n), :711-714
-    if (er != hipSuccess) return ix.hip_fail(er, "memset visited");
-    a.queries = dq + q0 * ix.dim_;
-    a.out_queue = g.queue.as<u64>() + q0 * L;
-    // few queries: 16 wavefronts per query (latency); many queries: 4 per query (throughput, more queries per CU)
-    static const int wide_env = getenv("EPS_TRV_WIDE") ? atoi(getenv("EPS_TRV_WIDE")) : -1;
-    const bool wide = wide_env >= 0 ? wide_env != 0 : nq <= 256;
-    if (vec4 && wide)
-      hipLaunchKernelGGL((traverse_kernel<true, false, false, 16>), dim3((unsigned)cnt), dim3(1024), shm, s, a);
-    else if (vec4)
-      hipLaunchKernelGGL((traverse_kernel<true, false, false, 4>), dim3((unsigned)cnt), dim3(256), shm, s, a);
-    else if (wide)
-      hipLaunchKernelGGL((traverse_kernel<false, false, false, 16>), dim3((unsigned)cnt), dim3(1024), shm, s, a);
-    else
-      hipLaunchKernelGGL((traverse_kernel<false, false, false, 4>), dim3((unsigned)cnt), dim3(256), shm, s, a);
-    ix.stats_.main_kernel_launches += 1;
-  }
-  (void)hipEventRecord(ix.evk1_, s);
 
   // brute-force tail over the rows the graph does not cover yet (:885-900)
   const int64_t n_total = ix.n_rows_;
@@ -269,7 +299,6 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
   PostArgs pa;
   pa.queue = g.queue.as<u64>();
   pa.L = (int)L;
-  pa.tail = tail;
   pa.k = k;
   int64_t K = n;
   if (k < K) K = k;
@@ -279,14 +308,34 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
   pa.cand_num_tail = (int)std::min<int64_t>(L, n_total);
   pa.cand_num = (int)std::min<int64_t>(L, n);
   pa.f = ix.filter_spec();
-  pa.run_keys = run_keys;
-  hipLaunchKernelGGL(post_kernel, dim3((unsigned)nq), dim3(64), (size_t)L * 8, s, pa);
+
+  (void)hipEventRecord(ix.evk0_, s);
+  for (int64_t q0 = 0; q0 < nq; q0 += slice) {
+    const int64_t cnt = std::min(slice, nq - q0);
+    a.queries = dq + q0 * ix.dim_;
+    a.nq = cnt;
+    a.out_queue = g.queue.as<u64>();
+    const int sl = (int)std::min<int64_t>(slots, cnt);
+    if (vec4) {
+      if (wide) { if (qglobal) launch_trv2<true, 16, true>(a, sl, shm, s); else launch_trv2<true, 16, false>(a, sl, shm, s); }
+      else      { if (qglobal) launch_trv2<true, 4, true>(a, sl, shm, s);  else launch_trv2<true, 4, false>(a, sl, shm, s); }
+    } else {
+      if (wide) { if (qglobal) launch_trv2<false, 16, true>(a, sl, shm, s); else launch_trv2<false, 16, false>(a, sl, shm, s); }
+      else      { if (qglobal) launch_trv2<false, 4, true>(a, sl, shm, s);  else launch_trv2<false, 4, false>(a, sl, shm, s); }
+    }
+    ix.stats_.main_kernel_launches += 1;
+    if (q0 + cnt >= nq) (void)hipEventRecord(ix.evk1_, s);   // (with several slices the pair spans all traversal launches and the post kernels between them)
+    pa.tail = tail ? tail + q0 * k : nullptr;
+    pa.run_keys = run_keys + q0 * k;
+    hipLaunchKernelGGL(post_kernel, dim3((unsigned)cnt), dim3(64), (size_t)K * 8, s, pa);
+  }
   er = hipGetLastError();
   if (er != hipSuccess) return ix.hip_fail(er, "traversal launch");
   unsigned long long h[2] = {0, 0};
   er = hipMemcpyAsync(h, g.counters.p, 16, hipMemcpyDeviceToHost, s);
   if (er == hipSuccess) er = hipStreamSynchronize(s);
   if (er != hipSuccess) return ix.hip_fail(er, "traversal");
+  g.vis_dirty = false;
   ix.stats_.dist_evals += (int64_t)h[0];
   ix.stats_.expansions += (int64_t)h[1];
   if (evals_out) *evals_out = (int64_t)h[0];

@@ -1,0 +1,567 @@
+// Search-time traversal kernel of libepsilla_gfx950: VecSearchExecutor::SearchImpl (reference:
+// engine/db/execution/vec_search_executor.cpp:518-715) with its T workers, local queues, PickTopMToWorkers
+// (:328-356), ExpandOneCandidate (:384-444), AddIntoQueue (:75-117), the GlobalSyncInterval and
+// MergeAllQueuesToMaster / MergeTwoQueuesInto1stQueueSeqFixed (:297-326, :150-217), for any SearchQueueSize.
+//
+// One workgroup owns one "slot" (visited bitmap + undo log + queue scratch) and walks over the queries
+// q = slot, slot + #slots, ...   Per query:
+//   * queue storage is the reference's set_L_ layout: T-1 worker queues of Lq keys, then the master queue of L
+//     keys (vec_search_executor.cpp:59-68), in LDS when it fits next to the work arrays, otherwise in HBM
+//     (QGLOBAL; L up to 2^20);  a key is ord(dist) << 32 | id << 1 | checked, so (key >> 1) order is
+//     Candidate::operator< (candidate.hpp:16-22);
+//   * the T workers of a round run in LOCKSTEP: step i of every worker before step i+1 of any worker; inside one
+//     step all T expansions are in flight together (T adjacency lists gathered, visited-tested with one atomicOr
+//     each, the surviving rows streamed by every wavefront of the workgroup) and conflicts on the visited set
+//     are resolved in worker order, master last.  This is one of the interleavings the reference's racing
+//     OpenMP workers may produce, it is deterministic, and oracle/epsilla_oracle.c restates it
+//     (eo_set_schedule(1)) - so parity is bit-exact for every T, not only T = 1;
+//   * a worker's <= deg new candidates of a step are inserted into its queue AT ONCE (rank sort + in-place merge,
+//     processed from the tail in register-sized chunks).  Inserting the survivors of one expansion together
+//     yields the same queue, and the same lowest insert position, as the reference's one-by-one AddIntoQueue
+//     (DESIGN.md "traversal equivalence");
+//   * visited set = N-bit bitmap per slot that is kept all-zero BETWEEN queries: the ids whose bit a query set
+//     are appended to an undo log and exactly those words are cleared at the end (the reference's
+//     is_visited.clear()/resize(n), :711-714, is O(N) per query; here it is O(evaluations)).  If the log
+//     overflows the slot's bitmap is cleared wholesale by the workgroup.
+#pragma once
+#include "kernels.hpp"
+
+namespace eps {
+
+struct Trv2Args {
+  const float* rows;
+  int dim;
+  int metric;
+  const int64_t* off;   // CSR offsets, or null when fixed_deg > 0
+  const u32* nbr;       // CSR neighbours, or [n][fixed_deg] lists padded with 0xFFFFFFFF
+  int fixed_deg;
+  int dp;               // edge slots per worker and step (>= the longest adjacency list)
+  const u32* init_ids;  // [L]
+  const float* queries;
+  int64_t nq;
+  int L, Lq, Lp2;       // master queue length, worker queue capacity, next power of two >= L
+  int T, I;             // workers (IntraQueryThreads), expansions per worker and round (GlobalSyncInterval)
+  int64_t qtot;         // keys of queue storage per slot = (T-1)*Lq + Lp2
+  u64* qglobal;         // QGLOBAL: [slots][qtot]
+  int* auxglobal;       // QGLOBAL: [slots][2*Lq] merge scratch
+  u32* visited;         // [slots][words], all-zero on entry and on exit
+  int64_t words;
+  u32* vlog;            // [slots][vcap] undo log
+  int vcap;
+  u64* out_queue;       // [nq][L] final master queues
+  unsigned long long* counters;  // [0] distance evaluations, [1] expansions
+};
+
+constexpr int TRV2_SB = 4096;       // keys of the LDS staging block of the QGLOBAL bitonic sort
+constexpr int TRV2_MAXT = 16;
+constexpr int TRV2_SH = 192;        // ints of scalar scratch
+constexpr u32 TRV2_NONE = 0xFFFFFFFFu;
+
+__device__ __forceinline__ u64 q2key(float d, u32 id) { return ((u64)f2ord(d + 0.0f) << 32) | ((u64)id << 1); }
+
+// number of keys in q[0..n) ordered before x (both compared without the checked bit)
+__device__ __forceinline__ int lower_bound_q(const u64* q, int n, u64 x) {
+  int lo = 0, hi = n;
+  const u64 xs = x >> 1;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if ((q[mid] >> 1) < xs) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// compare-exchange network passes of a bitonic sort over buf[0..n) (n a power of two) for strides
+// stride_hi, stride_hi/2, ..., 1; `gbase` is the global index of buf[0], `size` the bitonic block size.
+template <int NT>
+__device__ __forceinline__ void bitonic_passes(u64* buf, int n, int64_t gbase, int64_t size, int stride_hi) {
+  for (int stride = stride_hi; stride > 0; stride >>= 1) {
+    for (int i = threadIdx.x; i < (n >> 1); i += NT) {
+      const int lo = ((i / stride) * (stride << 1)) + (i % stride);
+      const int hi = lo + stride;
+      const bool up = (((gbase + lo) & size) == 0);
+      const u64 x = buf[lo], y = buf[hi];
+      if ((x > y) == up) {
+        buf[lo] = y;
+        buf[hi] = x;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <bool VEC4, int NW, bool QGLOBAL>
+__global__ __launch_bounds__(NW * 64) void traverse2_kernel(Trv2Args a) {
+  constexpr int NT = NW * 64;
+  constexpr int R = 4;           // queue elements per thread and merge chunk
+  constexpr int C = NT * R;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int dim = a.dim;
+  const int qstride = (dim + 3) & ~3;
+  const int T = a.T, L = a.L, Lq = a.Lq, DP = a.dp;
+  const int ecap = T * DP;
+  float* sq = reinterpret_cast<float*>(smem_raw);                          // [qstride]
+  u64* qlds = reinterpret_cast<u64*>(sq + qstride);                         // queues (or the sort staging block)
+  u64* newk = qlds + (QGLOBAL ? (int64_t)TRV2_SB : a.qtot);                 // [ecap] keys of this step, per worker segment
+  u64* sorted = newk + ecap;                                                // [ecap]
+  u32* eid = reinterpret_cast<u32*>(sorted + ecap);                         // [ecap] neighbour id per edge slot
+  u32* eraw = eid + ecap;                                                   // [ecap] 1 = this slot's atomicOr set the bit
+  u32* work = eraw + ecap;                                                  // [ecap] ids to evaluate, per worker segment
+  int* npos = reinterpret_cast<int*>(work + ecap);                          // [ecap] insert positions
+  int* auxl = npos + ecap;                                                  // !QGLOBAL: [2*Lq] MergeAll scratch (T > 1)
+  int* sh = auxl + ((QGLOBAL || T == 1) ? 0 : 2 * Lq);                      // [TRV2_SH]
+  // sh[0] scratch (first found / pmin), sh[1] unchecked count, sh[2] undo-log fill, sh[3] any worker selected,
+  // sh[4] running prefix, sh[5] non-duplicate count, sh[6] r of MergeAll, sh[7] log overflow
+  int* s_kuc = sh + 16;     // [T] first possibly-unchecked position per queue
+  int* s_size = sh + 32;    // [T] queue sizes
+  int* s_its = sh + 48;     // [T] expansions done this round
+  int* s_sel = sh + 64;     // [T] node selected this step, or -1
+  int* s_deg = sh + 80;     // [T] its degree
+  int* s_wcnt = sh + 96;    // [T] ids to evaluate
+  int* s_nnew = sh + 112;   // [T] keys that passed the bound
+  int* s_wave = sh + 128;   // [NW] per-wave counts
+  int* s_selpos = sh + 144; // [T] queue position of the selected candidate
+
+  const int tid = threadIdx.x;
+  const int lane = lane_id();
+  const int wave = tid >> 6;
+  const int G = group_lanes(dim, VEC4);
+  const int RPW = 64 / G;
+  const int g = lane / G;
+  const int t = lane & (G - 1);
+  constexpr int U = 4;
+  const int64_t slot = blockIdx.x;
+  u32* vis = a.visited + slot * a.words;
+  u32* vlog = a.vlog + slot * (int64_t)a.vcap;
+  u64* qbase = QGLOBAL ? a.qglobal + slot * a.qtot : qlds;
+  int* aux = QGLOBAL ? a.auxglobal + slot * (int64_t)(2 * Lq) : auxl;
+  u64* master = qbase + (int64_t)(T - 1) * Lq;
+  unsigned long long evals = 0, expansions = 0;
+
+  for (int64_t q = slot; q < a.nq; q += gridDim.x) {
+    // ------------------------------------------------------------------ InitializeSetLPara (:446-485)
+    for (int i = tid; i < qstride; i += NT) sq[i] = i < dim ? a.queries[q * dim + i] : 0.f;
+    for (int i = tid; i < TRV2_SH; i += NT) sh[i] = 0;
+    for (int i = L + tid; i < a.Lp2; i += NT) master[i] = KEY_EMPTY;
+    for (int i = tid; i < L; i += NT) {
+      const u32 id = a.init_ids[i];
+      atomicOr(&vis[id >> 5], 1u << (id & 31));
+    }
+    __syncthreads();
+    for (int c0 = wave * RPW * U; c0 < L; c0 += NW * RPW * U) {
+      const float* rp[U];
+      u32 id[U];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int ci = c0 + u * RPW + g;
+        ok[u] = ci < L;
+        id[u] = a.init_ids[ok[u] ? ci : L - 1];
+        rp[u] = a.rows + (int64_t)id[u] * dim;
+      }
+      float acc[U][1];
+      row_dists<U, 1, VEC4>(rp, sq, qstride, dim, a.metric, G, acc);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (ok[u] && t == 0) master[c0 + u * RPW + g] = q2key(finish_dist(a.metric, acc[u][0]), id[u]);
+    }
+    evals += L;
+    __syncthreads();
+    // std::sort(master) (:478): bitonic over Lp2 keys (padding sorts last)
+    if (!QGLOBAL) {
+      for (int64_t size = 2; size <= a.Lp2; size <<= 1) bitonic_passes<NT>(master, a.Lp2, 0, size, (int)(size >> 1));
+    } else {
+      const int nb = a.Lp2 < TRV2_SB ? a.Lp2 : TRV2_SB;   // keys per staging block
+      for (int64_t b0 = 0; b0 < a.Lp2; b0 += nb) {        // every block sorted on its own, directions as in the full network
+        for (int i = tid; i < nb; i += NT) qlds[i] = master[b0 + i];
+        __syncthreads();
+        for (int64_t size = 2; size <= nb; size <<= 1) bitonic_passes<NT>(qlds, nb, b0, size, (int)(size >> 1));
+        for (int i = tid; i < nb; i += NT) master[b0 + i] = qlds[i];
+        __syncthreads();
+      }
+      for (int64_t size = (int64_t)nb << 1; size <= a.Lp2; size <<= 1) {
+        for (int64_t stride = size >> 1; stride >= nb; stride >>= 1) {   // strides that span blocks: in HBM
+          for (int64_t i = tid; i < (a.Lp2 >> 1); i += NT) {
+            const int64_t lo = ((i / stride) * (stride << 1)) + (i % stride);
+            const int64_t hi = lo + stride;
+            const bool up = ((lo & size) == 0);
+            const u64 x = master[lo], y = master[hi];
+            if ((x > y) == up) {
+              master[lo] = y;
+              master[hi] = x;
+            }
+          }
+          __syncthreads();
+        }
+        for (int64_t b0 = 0; b0 < a.Lp2; b0 += nb) {                     // the rest of this size inside each block: in LDS
+          for (int i = tid; i < nb; i += NT) qlds[i] = master[b0 + i];
+          __syncthreads();
+          bitonic_passes<NT>(qlds, nb, b0, size, nb >> 1);
+          for (int i = tid; i < nb; i += NT) master[b0 + i] = qlds[i];
+          __syncthreads();
+        }
+      }
+    }
+    if (tid == 0) s_size[T - 1] = L;
+    __syncthreads();
+
+    // ------------------------------------------------------------------ rounds
+    // round 0 = the reference's one sequential expansion on the master queue (:556-593); every later round =
+    // PickTopMToWorkers, <= I lockstep steps, MergeAllQueuesToMaster (:601-698)
+    for (int round = 0;; ++round) {
+      if (round > 0) {
+        // ---- PickTopMToWorkers (:328-356): the i-th unchecked master candidate at or after k goes to worker i mod T
+        // (copied unchecked, the master copy marked checked); every T-th stays with the master.  The reference stops
+        // when worker 0's queue is full, i.e. after unchecked candidate number (Lq-1)*T.
+        const int kmaster = s_kuc[T - 1];
+        const int imax = (Lq - 1) * T;
+        if (tid == 0) sh[4] = 0;
+        __syncthreads();
+        for (int base = kmaster; base < L; base += NT) {
+          const int p = base + tid;
+          const bool un = p < L && !(master[p] & 1ull);
+          const u64 m = __ballot(un);
+          if (lane == 0) s_wave[wave] = __popcll(m);
+          __syncthreads();
+          int i = sh[4];
+          for (int w2 = 0; w2 < wave; ++w2) i += s_wave[w2];
+          i += __popcll(m & ((1ull << lane) - 1ull));
+          if (un && i <= imax) {
+            const int dest = i % T;
+            if (dest != T - 1) {
+              qbase[(int64_t)dest * Lq + i / T] = master[p];
+              master[p] |= 1ull;
+            }
+          }
+          __syncthreads();
+          if (tid == 0) {
+            int tot = sh[4];
+            for (int w2 = 0; w2 < NW; ++w2) tot += s_wave[w2];
+            sh[4] = tot;
+          }
+          __syncthreads();
+        }
+        const int U_ = sh[4];   // unchecked candidates seen
+        if (U_ == 0) break;     // uniform: no unchecked candidate left -> the search is over (:609-611)
+        if (tid < T) {
+          const int last = (U_ - 1 < imax) ? U_ - 1 : imax;   // highest unchecked index that was distributed
+          if (tid < T - 1) s_size[tid] = last >= tid ? (last - tid) / T + 1 : 0;
+          s_kuc[tid] = tid == T - 1 ? kmaster : 0;
+          s_its[tid] = 0;
+        }
+        __syncthreads();
+      }
+      const int I_round = round == 0 ? 1 : a.I;
+
+      // ---- lockstep steps
+      while (true) {
+        // a. every worker with iterations left takes its first unchecked candidate at or after k_uc (:632-672)
+        if (tid == 0) sh[3] = 0;
+        for (int w = 0; w < T; ++w) {
+          const u64* qw = qbase + (int64_t)w * Lq;
+          const int size = s_size[w];
+          const bool can = s_its[w] < I_round;
+          int found = -1;
+          if (can) {
+            for (int base = s_kuc[w]; base < size; base += NT) {   // uniform trip count
+              __syncthreads();
+              if (tid == 0) sh[0] = 0x7FFFFFFF;
+              __syncthreads();
+              const int p = base + tid;
+              if (p < size && !(qw[p] & 1ull)) atomicMin(&sh[0], p);
+              __syncthreads();
+              if (sh[0] != 0x7FFFFFFF) {
+                found = sh[0];
+                break;
+              }
+            }
+          }
+          __syncthreads();
+          if (tid == 0) {
+            if (found >= 0) {
+              u64* qm = qbase + (int64_t)w * Lq;
+              const u64 key = qm[found];
+              qm[found] = key | 1ull;
+              const u32 node = (u32)((key >> 1) & 0x7FFFFFFFu);
+              s_sel[w] = (int)node;
+              s_selpos[w] = found;
+              s_kuc[w] = found;
+              s_its[w] += 1;
+              s_deg[w] = a.fixed_deg > 0 ? a.fixed_deg : (int)(a.off[node + 1] - a.off[node]);
+              sh[3] = 1;
+            } else {
+              s_sel[w] = -1;
+              s_deg[w] = 0;
+              if (can) s_kuc[w] = size;   // ran off the end of its queue
+            }
+            s_wcnt[w] = 0;
+            s_nnew[w] = 0;
+          }
+        }
+        __syncthreads();
+        if (!sh[3]) break;   // uniform: nobody expanded -> the round is over
+        const float bound = key_dist(master[L - 1]);   // last_dist (:546): worst of the master queue before this step
+
+        // b. gather the T adjacency lists, test-and-set visited
+        int nsel = 0;
+        for (int w = 0; w < T; ++w) nsel += s_sel[w] >= 0;
+        expansions += nsel;
+        for (int e = tid; e < ecap; e += NT) {
+          const int w = e / DP, j = e - w * DP;
+          u32 nb = TRV2_NONE;
+          u32 raw = 0;
+          const int node = s_sel[w];
+          if (node >= 0 && j < s_deg[w]) {
+            const int64_t rowbase = a.fixed_deg > 0 ? (int64_t)node * a.fixed_deg : a.off[node];
+            nb = a.nbr[rowbase + j];
+            if (nb != TRV2_NONE) {
+              const u32 bit = 1u << (nb & 31);
+              raw = (atomicOr(&vis[nb >> 5], bit) & bit) ? 0u : 1u;
+            }
+          }
+          eid[e] = nb;
+          eraw[e] = raw;
+        }
+        __syncthreads();
+        // c. a node met by several workers in the same step belongs to the first of them in worker order (the
+        //    reference's sequential `if (is_visited[nb]) continue; is_visited[nb] = true;`, :403-406, under the
+        //    lockstep schedule); which slot's atomicOr happened to win is irrelevant
+        for (int e = tid; e < ecap; e += NT) {
+          const u32 nb = eid[e];
+          bool mine = false;
+          if (nb != TRV2_NONE) {
+            if (T == 1) {
+              mine = eraw[e] != 0;
+            } else {
+              u32 any = 0;
+              int owner = e;
+              for (int e2 = 0; e2 < ecap; ++e2) {
+                if (eid[e2] == nb) {
+                  any |= eraw[e2];
+                  owner = e2 < owner ? e2 : owner;
+                }
+              }
+              mine = any != 0 && owner == e;
+            }
+          }
+          if (mine) {
+            const int w = e / DP;
+            const int pos = atomicAdd(&s_wcnt[w], 1);
+            work[w * DP + pos] = nb;
+            const int ls = atomicAdd(&sh[2], 1);
+            if (ls < a.vcap) vlog[ls] = nb; else sh[7] = 1;
+          }
+        }
+        __syncthreads();
+        // d. distances of all surviving neighbours (every wavefront, 16 B/lane row loads); candidates beyond the
+        //    bound are dropped (`dist > dist_bound`, :427)
+        int nwork = 0;
+        for (int w = 0; w < T; ++w) nwork += s_wcnt[w];
+        evals += nwork;
+        for (int c0 = wave * RPW * U; c0 < nwork; c0 += NW * RPW * U) {
+          const float* rp[U];
+          u32 id[U];
+          int slotk[U];
+          bool ok[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            int ci = c0 + u * RPW + g;
+            ok[u] = ci < nwork;
+            if (!ok[u]) ci = nwork - 1;
+            int w = 0, base = 0;   // item ci -> (worker, index in its segment)
+            for (; w < T - 1; ++w) {
+              const int c = s_wcnt[w];
+              if (ci < base + c) break;
+              base += c;
+            }
+            slotk[u] = w * DP + (ci - base);
+            id[u] = work[slotk[u]];
+            rp[u] = a.rows + (int64_t)id[u] * dim;
+          }
+          float acc[U][1];
+          row_dists<U, 1, VEC4>(rp, sq, qstride, dim, a.metric, G, acc);
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            if (ok[u] && t == 0) {
+              const float d = finish_dist(a.metric, acc[u][0]);
+              newk[slotk[u]] = (d > bound) ? KEY_EMPTY : q2key(d, id[u]);
+            }
+          }
+        }
+        __syncthreads();
+        // e. rank-sort every worker's survivors inside its segment
+        for (int e = tid; e < ecap; e += NT) {
+          const int w = e / DP, j = e - w * DP;
+          if (j < s_wcnt[w]) {
+            const u64 mine = newk[e];
+            if (mine != KEY_EMPTY) {
+              const int cnt = s_wcnt[w];
+              int rank = 0;
+              for (int j2 = 0; j2 < cnt; ++j2) {
+                const u64 o = newk[w * DP + j2];
+                rank += (o < mine) || (o == mine && j2 < j);
+              }
+              sorted[w * DP + rank] = mine;
+              atomicAdd(&s_nnew[w], 1);
+            }
+          }
+        }
+        __syncthreads();
+        // f. AddIntoQueue for every worker: merge its sorted survivors into its queue in place
+        for (int w = 0; w < T; ++w) {
+          const int nnew = s_nnew[w];
+          if (s_sel[w] < 0) continue;              // uniform
+          const int cap = w == T - 1 ? L : Lq;
+          int r = cap;
+          if (nnew > 0) {
+            u64* qw = qbase + (int64_t)w * Lq;
+            const u64* sw = sorted + w * DP;
+            const int size = s_size[w];
+            for (int j = tid; j < nnew; j += NT) npos[j] = j + lower_bound_q(qw, size, sw[j]);
+            __syncthreads();
+            const int pmin = npos[0];
+            if (pmin < cap) {
+              r = pmin;
+              // old entries at positions >= pmin move right by the number of new keys ordered before them; chunks from
+              // the tail so that nothing unread is overwritten
+              for (int cb = ((size - 1) / C) * C; size > 0 && cb + C > pmin && cb >= 0; cb -= C) {
+                u64 v[R];
+                int dst[R];
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                  const int p = cb + i * NT + tid;
+                  dst[i] = -1;
+                  v[i] = KEY_EMPTY;
+                  if (p >= pmin && p < size) {
+                    v[i] = qw[p];
+                    dst[i] = p + lower_bound_q(sw, nnew, v[i]);
+                  }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < R; ++i)
+                  if (dst[i] >= 0 && dst[i] < cap) qw[dst[i]] = v[i];
+              }
+              __syncthreads();
+              for (int j = tid; j < nnew; j += NT)
+                if (npos[j] < cap) qw[npos[j]] = sw[j];
+            }
+            __syncthreads();
+            if (tid == 0) s_size[w] = size + nnew < cap ? size + nnew : cap;
+          }
+          if (tid == 0) {
+            const int kuc = s_selpos[w];
+            s_kuc[w] = r <= kuc ? r : kuc + 1;   // (:661-665)
+          }
+          __syncthreads();
+        }
+      }  // steps
+
+      if (round == 0 || T == 1) continue;
+      // ---- MergeAllQueuesToMaster (:297-326): worker queues into the fixed-size master, in worker order;
+      // equal (dist,id) = duplicate: the master's copy stays and turns unchecked if the worker's copy is unchecked (:182-213)
+      for (int w = 0; w < T - 1; ++w) {
+        const int nb = s_size[w];
+        if (nb == 0) continue;   // uniform
+        const u64* B = qbase + (int64_t)w * Lq;
+        int* bpos = aux;
+        int* ndp = aux + Lq;
+        // pass 1: where every worker key falls in the master; duplicates
+        for (int j = tid; j < nb; j += NT) {
+          const u64 kb = B[j];
+          const int cnt = lower_bound_q(master, L, kb);
+          bool dup = cnt < L && (master[cnt] >> 1) == (kb >> 1);
+          if (dup && !(kb & 1ull) && (master[cnt] & 1ull)) master[cnt] &= ~1ull;
+          bpos[j] = cnt | (dup ? (int)0x80000000 : 0);
+        }
+        __syncthreads();
+        const int r = bpos[0] & 0x7FFFFFFF;   // lowest insert position (lower_bound of the worker's best key, :158-163)
+        if (r < L) {
+          // pass 2: ndp[j] = non-duplicate worker keys before j
+          if (tid == 0) sh[4] = 0;
+          __syncthreads();
+          for (int base = 0; base < nb; base += NT) {
+            const int j = base + tid;
+            const bool nd = j < nb && bpos[j] >= 0;
+            const u64 m = __ballot(nd);
+            if (lane == 0) s_wave[wave] = __popcll(m);
+            __syncthreads();
+            int i = sh[4];
+            for (int w2 = 0; w2 < wave; ++w2) i += s_wave[w2];
+            i += __popcll(m & ((1ull << lane) - 1ull));
+            if (j < nb) ndp[j] = i;
+            __syncthreads();
+            if (tid == 0) {
+              int tot = sh[4];
+              for (int w2 = 0; w2 < NW; ++w2) tot += s_wave[w2];
+              sh[4] = tot;
+            }
+            __syncthreads();
+          }
+          const int nnd = sh[4];
+          // pass 3: master entries at positions >= r move right by the non-duplicate worker keys ordered before them
+          for (int cb = ((L - 1) / C) * C; cb + C > r && cb >= 0; cb -= C) {
+            u64 v[R];
+            int dst[R];
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+              const int p = cb + i * NT + tid;
+              dst[i] = -1;
+              v[i] = KEY_EMPTY;
+              if (p >= r && p < L) {
+                v[i] = master[p];
+                const int jb = lower_bound_q(B, nb, v[i]);
+                dst[i] = p + (jb == nb ? nnd : ndp[jb]);
+              }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+              if (dst[i] >= 0 && dst[i] < L) master[dst[i]] = v[i];
+          }
+          __syncthreads();
+          // pass 4: the non-duplicate worker keys
+          for (int j = tid; j < nb; j += NT) {
+            const int bp = bpos[j];
+            if (bp >= 0) {
+              const int dst = bp + ndp[j];
+              if (dst < L) master[dst] = B[j];
+            }
+          }
+        }
+        __syncthreads();
+        if (tid == 0) {
+          if (r <= s_kuc[T - 1]) s_kuc[T - 1] = r;   // (:686-689)
+          s_size[w] = 0;
+        }
+        __syncthreads();
+      }
+    }  // rounds
+
+    // ------------------------------------------------------------------ results + visited reset
+    if (a.out_queue)
+      for (int i = tid; i < L; i += NT) a.out_queue[q * L + i] = master[i];
+    const int nlog = sh[2];
+    if (sh[7] || nlog > a.vcap) {
+      for (int64_t i = tid; i < a.words; i += NT) vis[i] = 0;
+    } else {
+      for (int i = tid; i < L; i += NT) vis[a.init_ids[i] >> 5] = 0;
+      for (int i = tid; i < nlog; i += NT) vis[vlog[i] >> 5] = 0;
+    }
+    __threadfence();
+    __syncthreads();
+  }
+  if (tid == 0) {
+    atomicAdd(&a.counters[0], evals);
+    atomicAdd(&a.counters[1], expansions);
+  }
+}
+
+// LDS bytes of one workgroup; qglobal = queues in HBM
+inline size_t traverse2_lds_bytes(int dim, int T, int Lq, int64_t qtot, int dp, bool qglobal) {
+  const int qstride = (dim + 3) & ~3;
+  const size_t ecap = (size_t)T * dp;
+  return (size_t)qstride * 4 + (qglobal ? (size_t)TRV2_SB : (size_t)qtot) * 8 + ecap * (8 + 8 + 4 + 4 + 4 + 4) +
+         ((qglobal || T == 1) ? 0 : (size_t)2 * Lq * 4) + TRV2_SH * 4;
+}
+
+}  // namespace eps
