@@ -507,9 +507,15 @@ int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp) {
   std::vector<u32> orphans;
   for (int64_t i = 0; i < n; ++i)
     if (!reached[i]) orphans.push_back((u32)i);
-  std::vector<u32> extra_root;  // extra out-edge root -> orphan (FindUnconnectedNode, nsg.cpp:734-775)
+  // FindUnconnectedNode (nsg.cpp:734-775): the lowest-id unreached node x gets an in-edge from the closest REACHED node
+  // of a search for V[x]; the DFS then continues through x, so only one node per unreached component receives an
+  // extra edge.  Here the searches of all initially unreached nodes run as one device batch (their 32 closest
+  // evaluated nodes are kept), and the attach + DFS-continue loop runs on the host in id order against the live
+  // `reached` set.
+  constexpr int TRACE_K = 32;
+  std::vector<std::pair<u32, u32>> extra;   // (root, orphan) edges
+  const size_t n_orphans = orphans.size();
   if (!orphans.empty()) {
-    // search the NSG for every orphan's vector; attach it to the closest REACHED node in the search trace
     std::vector<u32> nseeds;
     {
       std::vector<uint8_t> sel((size_t)n, 0);
@@ -529,17 +535,16 @@ int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp) {
         nseeds.push_back((u32)v);
       }
     }
-    DevBuf d_orph, d_q;
+    DevBuf d_orph, d_q, d_top;
     const int64_t m = (int64_t)orphans.size();
     const int64_t OB = std::min<int64_t>(m, NB);
-    if (!d_orph.reserve((size_t)m * 4) || !d_q.reserve((size_t)OB * dim * 4)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "build: out of device memory (connectivity)");
+    if (!d_orph.reserve((size_t)m * 4) || !d_q.reserve((size_t)OB * dim * 4) || !d_top.reserve((size_t)OB * TRACE_K * 8))
+      return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "build: out of device memory (connectivity)");
     HIPCHK(hipMemcpyAsync(d_orph.p, orphans.data(), (size_t)m * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_seeds.p, nseeds.data(), (size_t)Ls * 4, hipMemcpyHostToDevice, s));
     ta.nbr = out_ids.as<u32>();
     ta.fixed_deg = R;
-    std::vector<u64> hlog((size_t)OB * LOG_CAP);
-    std::vector<u32> hcnt((size_t)OB);
-    extra_root.assign((size_t)m, (u32)nav);
+    std::vector<u64> top((size_t)m * TRACE_K);
     for (int64_t o0 = 0; o0 < m; o0 += OB) {
       const int64_t nb = std::min(OB, m - o0);
       hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)nb), dim3(256), 0, s, ix.d_rows_, d_orph.as<u32>() + o0, nb, dim, d_q.as<float>());
@@ -548,16 +553,37 @@ int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp) {
         hipLaunchKernelGGL((traverse_kernel<true, true, true, 4>), dim3((unsigned)nb), dim3(256), trv_shm, s, ta);
       else
         hipLaunchKernelGGL((traverse_kernel<false, true, true, 4>), dim3((unsigned)nb), dim3(256), trv_shm, s, ta);
-      HIPCHK(hipMemcpyAsync(hlog.data(), logb.p, (size_t)nb * LOG_CAP * 8, hipMemcpyDeviceToHost, s));
-      HIPCHK(hipMemcpyAsync(hcnt.data(), logc.p, (size_t)nb * 4, hipMemcpyDeviceToHost, s));
+      // the TRACE_K closest evaluated nodes of every search, ascending
+      launch_merge_lists(logb.as<u64>(), LOG_CAP, TRACE_K, nb, d_top.as<u64>(), false, s, logc.as<u32>());
+      HIPCHK(hipMemcpyAsync(top.data() + (size_t)o0 * TRACE_K, d_top.p, (size_t)nb * TRACE_K * 8, hipMemcpyDeviceToHost, s));
       HIPCHK(hipStreamSynchronize(s));
-      for (int64_t i = 0; i < nb; ++i) {
-        u64 best = KEY_EMPTY;
-        for (u32 e = 0; e < hcnt[i]; ++e) {
-          const u64 key = hlog[(size_t)i * LOG_CAP + e];
-          if (reached[key_id(key)] && key < best) best = key;
+    }
+    std::vector<u32> stack;
+    for (int64_t i = 0; i < m; ++i) {
+      const u32 x = orphans[i];
+      if (reached[x]) continue;   // linked through an earlier orphan's subtree
+      u32 root = (u32)nav;        // (the reference falls back to a random linked node, nsg.cpp:763-771)
+      for (int e = 0; e < TRACE_K; ++e) {
+        const u64 key = top[(size_t)i * TRACE_K + e];
+        if (key == KEY_EMPTY) break;
+        if (reached[key_id(key)]) {
+          root = key_id(key);
+          break;
         }
-        if (best != KEY_EMPTY) extra_root[o0 + i] = key_id(best);
+      }
+      extra.emplace_back(root, x);
+      reached[x] = 1;
+      stack.push_back(x);
+      while (!stack.empty()) {
+        const u32 v = stack.back();
+        stack.pop_back();
+        for (u32 j = 0; j < h_deg[v]; ++j) {
+          const u32 y = h_ids[(size_t)v * R + j];
+          if (!reached[y]) {
+            reached[y] = 1;
+            stack.push_back(y);
+          }
+        }
       }
     }
   }
@@ -566,7 +592,7 @@ int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp) {
   // ---- CSR in the reference's layout (ann_graph_segment.cpp:222-241)
   std::vector<int64_t> off((size_t)n + 1);
   std::vector<u32> extra_cnt((size_t)n, 0);
-  for (size_t i = 0; i < orphans.size(); ++i) extra_cnt[extra_root[i]]++;
+  for (auto& pr : extra) extra_cnt[pr.first]++;
   int64_t e = 0;
   for (int64_t i = 0; i < n; ++i) {
     off[i] = e;
@@ -579,10 +605,15 @@ int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp) {
     for (u32 j = 0; j < h_deg[i]; ++j) nbr[off[i] + j] = h_ids[(size_t)i * R + j];
     fill[i] = off[i] + h_deg[i];
   }
-  for (size_t i = 0; i < orphans.size(); ++i) nbr[fill[extra_root[i]]++] = orphans[i];
+  for (auto& pr : extra) nbr[fill[pr.first]++] = pr.second;
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
-  if (debug) fprintf(stderr, "[eps build] n=%lld edges=%lld avg degree %.1f orphans %zu nav %lld\n", (long long)n, (long long)e, (double)e / n, orphans.size(), (long long)nav);
+  if (debug) {
+    u32 maxdeg = 0;
+    for (int64_t i = 0; i < n; ++i) maxdeg = std::max(maxdeg, h_deg[i] + extra_cnt[i]);
+    fprintf(stderr, "[eps build] n=%lld edges=%lld avg degree %.1f max degree %u, %zu nodes unreached after InterInsert, %zu repair edges, nav %lld\n",
+            (long long)n, (long long)e, (double)e / n, maxdeg, n_orphans, extra.size(), (long long)nav);
+  }
   return ix.set_graph(n, off.data(), nbr.data(), nav);
 }
 

@@ -10,6 +10,7 @@
 // single-thread result; with T > 1 they are the reference's result under the lockstep interleaving of its
 // workers (deterministic here, racy in the reference), restated by oracle/epsilla_oracle.c for parity.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -250,7 +251,7 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
   // results of the traversal are consumed per slice of queries so that the [slice][L] queue copy stays below 2 GiB
   const int64_t slice = std::max<int64_t>(1, std::min<int64_t>(nq, ((int64_t)2 << 30) / (L * 8)));
   if (!g.visited.reserve((size_t)slots * words * 4) || !g.vlog.reserve((size_t)slots * vcap * 4) ||
-      !g.queue.reserve((size_t)slice * L * 8) || !g.counters.reserve(16) ||
+      !g.queue.reserve((size_t)slice * L * 8) || !g.counters.reserve(256) ||
       (qglobal && (!g.qglobal.reserve((size_t)slots * qtot * 8) || !g.auxglobal.reserve((size_t)slots * 2 * Lq * 4))))
     return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "search: out of device memory (traversal scratch)");
   if (g.vis_dirty || g.vis_slots < slots || g.vis_words != words) {
@@ -261,8 +262,9 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
     g.vis_words = words;
   }
   g.vis_dirty = true;   // until this search has completed
-  er = hipMemsetAsync(g.counters.p, 0, 16, s);
+  er = hipMemsetAsync(g.counters.p, 0, 256, s);
   if (er != hipSuccess) return ix.hip_fail(er, "memset");
+  const bool prof = getenv("EPS_TRV_PROF") != nullptr;
 
   Trv2Args a;
   a.rows = ix.d_rows_;
@@ -272,6 +274,7 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
   a.nbr = g.nbr.as<u32>();
   a.fixed_deg = g.fixed_deg;
   a.dp = dp;
+  a.hslots = traverse2_hash_slots(T, dp);
   a.init_ids = g.init_ids.as<u32>();
   a.L = (int)L;
   a.Lq = (int)Lq;
@@ -286,6 +289,7 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
   a.vlog = g.vlog.as<u32>();
   a.vcap = vcap;
   a.counters = g.counters.as<unsigned long long>();
+  a.prof = prof ? g.counters.as<unsigned long long>() + 8 : nullptr;
 
   // brute-force tail over the rows the graph does not cover yet (:885-900)
   const int64_t n_total = ix.n_rows_;
@@ -331,11 +335,20 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
   }
   er = hipGetLastError();
   if (er != hipSuccess) return ix.hip_fail(er, "traversal launch");
-  unsigned long long h[2] = {0, 0};
-  er = hipMemcpyAsync(h, g.counters.p, 16, hipMemcpyDeviceToHost, s);
+  unsigned long long h[24];
+  std::memset(h, 0, sizeof(h));
+  er = hipMemcpyAsync(h, g.counters.p, sizeof(h), hipMemcpyDeviceToHost, s);
   if (er == hipSuccess) er = hipStreamSynchronize(s);
   if (er != hipSuccess) return ix.hip_fail(er, "traversal");
   g.vis_dirty = false;
+  if (prof) {
+    static const char* names[10] = {"seeds+sort", "scatter", "select", "gather+visited", "dedupe", "distances", "rank sort", "queue insert", "merge-all", "results+reset"};
+    unsigned long long tot = 0;
+    for (int i = 0; i < 10; ++i) tot += h[8 + i];
+    fprintf(stderr, "[eps trv] nq=%lld T=%d L=%lld I=%d %s queues, %d wavefronts/query, %lld slots, LDS %zu B: steps/query %.1f rounds/query %.1f expansions/query %.1f evals/query %.1f\n",
+            (long long)nq, T, (long long)L, I, qglobal ? "HBM" : "LDS", wide ? 16 : 4, (long long)slots, shm, (double)h[2] / nq, (double)h[3] / nq, (double)h[1] / nq, (double)h[0] / nq);
+    for (int i = 0; i < 10; ++i) fprintf(stderr, "[eps trv]   %-16s %5.1f %%\n", names[i], tot ? 100.0 * h[8 + i] / tot : 0.0);
+  }
   ix.stats_.dist_evals += (int64_t)h[0];
   ix.stats_.expansions += (int64_t)h[1];
   if (evals_out) *evals_out = (int64_t)h[0];

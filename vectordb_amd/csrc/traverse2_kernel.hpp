@@ -36,6 +36,7 @@ struct Trv2Args {
   const u32* nbr;       // CSR neighbours, or [n][fixed_deg] lists padded with 0xFFFFFFFF
   int fixed_deg;
   int dp;               // edge slots per worker and step (>= the longest adjacency list)
+  int hslots;           // slots of the per-step ownership table: power of two >= 2*T*dp, 0 when T == 1
   const u32* init_ids;  // [L]
   const float* queries;
   int64_t nq;
@@ -49,7 +50,8 @@ struct Trv2Args {
   u32* vlog;            // [slots][vcap] undo log
   int vcap;
   u64* out_queue;       // [nq][L] final master queues
-  unsigned long long* counters;  // [0] distance evaluations, [1] expansions
+  unsigned long long* counters;  // [0] distance evaluations, [1] expansions, [2] steps, [3] rounds
+  unsigned long long* prof;      // optional [16]: shader-clock ticks per phase summed over the workgroups (EPS_TRV_PROF)
 };
 
 constexpr int TRV2_SB = 4096;       // keys of the LDS staging block of the QGLOBAL bitonic sort
@@ -107,7 +109,10 @@ __global__ __launch_bounds__(NW * 64) void traverse2_kernel(Trv2Args a) {
   u32* eraw = eid + ecap;                                                   // [ecap] 1 = this slot's atomicOr set the bit
   u32* work = eraw + ecap;                                                  // [ecap] ids to evaluate, per worker segment
   int* npos = reinterpret_cast<int*>(work + ecap);                          // [ecap] insert positions
-  int* auxl = npos + ecap;                                                  // !QGLOBAL: [2*Lq] MergeAll scratch (T > 1)
+  const int H = a.hslots;                                                   // ownership table slots (power of two; 0 when T == 1)
+  u32* hid = reinterpret_cast<u32*>(npos + ecap);                           // [H] node id, TRV2_NONE = empty
+  int* hmin = reinterpret_cast<int*>(hid + H);                              // [H] lowest edge slot that met the node this step
+  int* auxl = hmin + H;                                                     // !QGLOBAL: [2*Lq] MergeAll scratch (T > 1)
   int* sh = auxl + ((QGLOBAL || T == 1) ? 0 : 2 * Lq);                      // [TRV2_SH]
   // sh[0] scratch (first found / pmin), sh[1] unchecked count, sh[2] undo-log fill, sh[3] any worker selected,
   // sh[4] running prefix, sh[5] non-duplicate count, sh[6] r of MergeAll, sh[7] log overflow
@@ -120,6 +125,7 @@ __global__ __launch_bounds__(NW * 64) void traverse2_kernel(Trv2Args a) {
   int* s_nnew = sh + 112;   // [T] keys that passed the bound
   int* s_wave = sh + 128;   // [NW] per-wave counts
   int* s_selpos = sh + 144; // [T] queue position of the selected candidate
+  int* s_eoff = sh + 160;   // [T+1] first edge slot of every worker in this step
 
   const int tid = threadIdx.x;
   const int lane = lane_id();
@@ -135,12 +141,27 @@ __global__ __launch_bounds__(NW * 64) void traverse2_kernel(Trv2Args a) {
   u64* qbase = QGLOBAL ? a.qglobal + slot * a.qtot : qlds;
   int* aux = QGLOBAL ? a.auxglobal + slot * (int64_t)(2 * Lq) : auxl;
   u64* master = qbase + (int64_t)(T - 1) * Lq;
-  unsigned long long evals = 0, expansions = 0;
+  unsigned long long evals = 0, expansions = 0, steps = 0, rounds = 0;
+  // phase clocks (wave-uniform scalar reads; summed by thread 0): 0 seeds+sort, 1 scatter, 2 select, 3 gather+visited,
+  // 4 dedupe, 5 distances, 6 rank sort, 7 queue insert, 8 merge-all, 9 results+reset
+  unsigned long long pt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const bool prof = a.prof != nullptr;
+  long long tprev = prof ? clock64() : 0;
+#define TRV2_LAP(i)                 \
+  if (prof) {                       \
+    const long long tn = clock64(); \
+    pt[i] += (unsigned long long)(tn - tprev); \
+    tprev = tn;                     \
+  }
 
   for (int64_t q = slot; q < a.nq; q += gridDim.x) {
     // ------------------------------------------------------------------ InitializeSetLPara (:446-485)
     for (int i = tid; i < qstride; i += NT) sq[i] = i < dim ? a.queries[q * dim + i] : 0.f;
     for (int i = tid; i < TRV2_SH; i += NT) sh[i] = 0;
+    for (int i = tid; i < H; i += NT) {
+      hid[i] = TRV2_NONE;
+      hmin[i] = 0x7FFFFFFF;
+    }
     for (int i = L + tid; i < a.Lp2; i += NT) master[i] = KEY_EMPTY;
     for (int i = tid; i < L; i += NT) {
       const u32 id = a.init_ids[i];
@@ -203,6 +224,7 @@ __global__ __launch_bounds__(NW * 64) void traverse2_kernel(Trv2Args a) {
     }
     if (tid == 0) s_size[T - 1] = L;
     __syncthreads();
+    TRV2_LAP(0)
 
     // ------------------------------------------------------------------ rounds
     // round 0 = the reference's one sequential expansion on the master queue (:556-593); every later round =
@@ -251,6 +273,8 @@ __global__ __launch_bounds__(NW * 64) void traverse2_kernel(Trv2Args a) {
         __syncthreads();
       }
       const int I_round = round == 0 ? 1 : a.I;
+      ++rounds;
+      TRV2_LAP(1)
 
       // ---- lockstep steps
       while (true) {
@@ -298,60 +322,107 @@ __global__ __launch_bounds__(NW * 64) void traverse2_kernel(Trv2Args a) {
           }
         }
         __syncthreads();
+        if (tid == 0) {
+          int acc = 0;
+          for (int w = 0; w < T; ++w) {
+            s_eoff[w] = acc;
+            acc += s_deg[w];
+          }
+          s_eoff[T] = acc;
+        }
+        __syncthreads();
+        TRV2_LAP(2)
         if (!sh[3]) break;   // uniform: nobody expanded -> the round is over
+        ++steps;
         const float bound = key_dist(master[L - 1]);   // last_dist (:546): worst of the master queue before this step
 
-        // b. gather the T adjacency lists, test-and-set visited
+        // b. gather the T adjacency lists (laid out one after another: worker w's edges at [eoff[w], eoff[w+1])),
+        //    test-and-set visited
         int nsel = 0;
         for (int w = 0; w < T; ++w) nsel += s_sel[w] >= 0;
         expansions += nsel;
-        for (int e = tid; e < ecap; e += NT) {
-          const int w = e / DP, j = e - w * DP;
-          u32 nb = TRV2_NONE;
-          u32 raw = 0;
+        const int etot = s_eoff[T];
+        for (int e = tid; e < etot; e += NT) {
+          int w = 0;
+          while (w < T - 1 && e >= s_eoff[w + 1]) ++w;
+          const int j = e - s_eoff[w];
           const int node = s_sel[w];
-          if (node >= 0 && j < s_deg[w]) {
-            const int64_t rowbase = a.fixed_deg > 0 ? (int64_t)node * a.fixed_deg : a.off[node];
-            nb = a.nbr[rowbase + j];
-            if (nb != TRV2_NONE) {
-              const u32 bit = 1u << (nb & 31);
-              raw = (atomicOr(&vis[nb >> 5], bit) & bit) ? 0u : 1u;
+          const int64_t rowbase = a.fixed_deg > 0 ? (int64_t)node * a.fixed_deg : a.off[node];
+          const u32 nb = a.nbr[rowbase + j];
+          u32 raw = 0;
+          if (nb != TRV2_NONE) {
+            const u32 bit = 1u << (nb & 31);
+            raw = (atomicOr(&vis[nb >> 5], bit) & bit) ? 0u : 1u;
+            if (raw && T > 1) {   // publish "this node became visited in this step" for the ownership resolution below
+              u32 hs = (nb * 2654435761u) & (u32)(H - 1);
+              while (true) {
+                const u32 old = atomicCAS(&hid[hs], TRV2_NONE, nb);
+                if (old == TRV2_NONE || old == nb) break;
+                hs = (hs + 1) & (u32)(H - 1);
+              }
             }
           }
           eid[e] = nb;
           eraw[e] = raw;
         }
         __syncthreads();
+        TRV2_LAP(3)
         // c. a node met by several workers in the same step belongs to the first of them in worker order (the
         //    reference's sequential `if (is_visited[nb]) continue; is_visited[nb] = true;`, :403-406, under the
-        //    lockstep schedule); which slot's atomicOr happened to win is irrelevant
-        for (int e = tid; e < ecap; e += NT) {
+        //    lockstep schedule); which edge slot's atomicOr happened to win is irrelevant.  Every edge slot whose node
+        //    became visited in this step bids with its index, the lowest index owns the node.
+        if (T > 1) {
+          for (int e = tid; e < etot; e += NT) {
+            const u32 nb = eid[e];
+            if (nb == TRV2_NONE) continue;
+            u32 hs = (nb * 2654435761u) & (u32)(H - 1);
+            while (true) {
+              const u32 v = hid[hs];
+              if (v == nb) {
+                atomicMin(&hmin[hs], e);
+                break;
+              }
+              if (v == TRV2_NONE) break;
+              hs = (hs + 1) & (u32)(H - 1);
+            }
+          }
+          __syncthreads();
+        }
+        for (int e = tid; e < etot; e += NT) {
           const u32 nb = eid[e];
           bool mine = false;
           if (nb != TRV2_NONE) {
             if (T == 1) {
               mine = eraw[e] != 0;
             } else {
-              u32 any = 0;
-              int owner = e;
-              for (int e2 = 0; e2 < ecap; ++e2) {
-                if (eid[e2] == nb) {
-                  any |= eraw[e2];
-                  owner = e2 < owner ? e2 : owner;
+              u32 hs = (nb * 2654435761u) & (u32)(H - 1);
+              while (true) {
+                const u32 v = hid[hs];
+                if (v == nb) {
+                  mine = hmin[hs] == e;
+                  break;
                 }
+                if (v == TRV2_NONE) break;
+                hs = (hs + 1) & (u32)(H - 1);
               }
-              mine = any != 0 && owner == e;
             }
           }
           if (mine) {
-            const int w = e / DP;
+            int w = 0;
+            while (w < T - 1 && e >= s_eoff[w + 1]) ++w;
             const int pos = atomicAdd(&s_wcnt[w], 1);
-            work[w * DP + pos] = nb;
+            work[s_eoff[w] + pos] = nb;
             const int ls = atomicAdd(&sh[2], 1);
             if (ls < a.vcap) vlog[ls] = nb; else sh[7] = 1;
           }
         }
         __syncthreads();
+        if (T > 1)   // leave the ownership table empty for the next step
+          for (int i = tid; i < H; i += NT) {
+            hid[i] = TRV2_NONE;
+            hmin[i] = 0x7FFFFFFF;
+          }
+        TRV2_LAP(4)
         // d. distances of all surviving neighbours (every wavefront, 16 B/lane row loads); candidates beyond the
         //    bound are dropped (`dist > dist_bound`, :427)
         int nwork = 0;
@@ -373,7 +444,7 @@ __global__ __launch_bounds__(NW * 64) void traverse2_kernel(Trv2Args a) {
               if (ci < base + c) break;
               base += c;
             }
-            slotk[u] = w * DP + (ci - base);
+            slotk[u] = s_eoff[w] + (ci - base);
             id[u] = work[slotk[u]];
             rp[u] = a.rows + (int64_t)id[u] * dim;
           }
@@ -388,24 +459,29 @@ __global__ __launch_bounds__(NW * 64) void traverse2_kernel(Trv2Args a) {
           }
         }
         __syncthreads();
+        TRV2_LAP(5)
         // e. rank-sort every worker's survivors inside its segment
-        for (int e = tid; e < ecap; e += NT) {
-          const int w = e / DP, j = e - w * DP;
+        for (int e = tid; e < etot; e += NT) {
+          int w = 0;
+          while (w < T - 1 && e >= s_eoff[w + 1]) ++w;
+          const int j = e - s_eoff[w];
           if (j < s_wcnt[w]) {
             const u64 mine = newk[e];
             if (mine != KEY_EMPTY) {
               const int cnt = s_wcnt[w];
+              const u64* seg = newk + s_eoff[w];
               int rank = 0;
               for (int j2 = 0; j2 < cnt; ++j2) {
-                const u64 o = newk[w * DP + j2];
+                const u64 o = seg[j2];
                 rank += (o < mine) || (o == mine && j2 < j);
               }
-              sorted[w * DP + rank] = mine;
+              sorted[s_eoff[w] + rank] = mine;
               atomicAdd(&s_nnew[w], 1);
             }
           }
         }
         __syncthreads();
+        TRV2_LAP(6)
         // f. AddIntoQueue for every worker: merge its sorted survivors into its queue in place
         for (int w = 0; w < T; ++w) {
           const int nnew = s_nnew[w];
@@ -414,7 +490,7 @@ __global__ __launch_bounds__(NW * 64) void traverse2_kernel(Trv2Args a) {
           int r = cap;
           if (nnew > 0) {
             u64* qw = qbase + (int64_t)w * Lq;
-            const u64* sw = sorted + w * DP;
+            const u64* sw = sorted + s_eoff[w];
             const int size = s_size[w];
             for (int j = tid; j < nnew; j += NT) npos[j] = j + lower_bound_q(qw, size, sw[j]);
             __syncthreads();
@@ -454,6 +530,7 @@ __global__ __launch_bounds__(NW * 64) void traverse2_kernel(Trv2Args a) {
           }
           __syncthreads();
         }
+        TRV2_LAP(7)
       }  // steps
 
       if (round == 0 || T == 1) continue;
@@ -535,6 +612,7 @@ __global__ __launch_bounds__(NW * 64) void traverse2_kernel(Trv2Args a) {
         }
         __syncthreads();
       }
+      TRV2_LAP(8)
     }  // rounds
 
     // ------------------------------------------------------------------ results + visited reset
@@ -549,18 +627,30 @@ __global__ __launch_bounds__(NW * 64) void traverse2_kernel(Trv2Args a) {
     }
     __threadfence();
     __syncthreads();
+    TRV2_LAP(9)
   }
+#undef TRV2_LAP
   if (tid == 0) {
     atomicAdd(&a.counters[0], evals);
     atomicAdd(&a.counters[1], expansions);
+    atomicAdd(&a.counters[2], steps);
+    atomicAdd(&a.counters[3], rounds);
+    if (prof)
+      for (int i = 0; i < 10; ++i) atomicAdd(&a.prof[i], pt[i]);
   }
 }
 
 // LDS bytes of one workgroup; qglobal = queues in HBM
+inline int traverse2_hash_slots(int T, int dp) {
+  if (T <= 1) return 0;
+  int h = 64;
+  while (h < 2 * T * dp) h <<= 1;
+  return h;
+}
 inline size_t traverse2_lds_bytes(int dim, int T, int Lq, int64_t qtot, int dp, bool qglobal) {
   const int qstride = (dim + 3) & ~3;
   const size_t ecap = (size_t)T * dp;
-  return (size_t)qstride * 4 + (qglobal ? (size_t)TRV2_SB : (size_t)qtot) * 8 + ecap * (8 + 8 + 4 + 4 + 4 + 4) +
+  return (size_t)qstride * 4 + (qglobal ? (size_t)TRV2_SB : (size_t)qtot) * 8 + ecap * (8 + 8 + 4 + 4 + 4 + 4) + (size_t)traverse2_hash_slots(T, dp) * 8 +
          ((qglobal || T == 1) ? 0 : (size_t)2 * Lq * 4) + TRV2_SH * 4;
 }
 
