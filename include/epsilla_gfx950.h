@@ -162,6 +162,10 @@ int32_t eps_index_load_graph(eps_index* h, const char* path);
 int32_t eps_index_search(eps_index* h, const float* queries, int64_t nq, int32_t k, const eps_search_params* p,
                          int64_t* ids_out, float* dist_out, int32_t* counts_out);
 int32_t eps_index_last_stats(const eps_index* h, eps_search_stats* out);
+/* main-kernel milliseconds (hipEvent pairs recorded on the index's stream) of the most recent search calls, oldest
+ * first, at most min(cap, 64); synchronises the stream.  Returns the number written.  Lets a caller time a run of
+ * searches without a host sync inside it. */
+int32_t eps_index_kernel_times(eps_index* h, double* ms_out, int32_t cap);
 
 /* in-place L2 normalisation of float[n][dim] (host or device). only_if_nonzero = 1 reproduces the
  * insert path (sum > 1e-10), 0 the query path (unconditional). */
@@ -172,6 +176,11 @@ int32_t eps_normalize_rows(float* rows, int64_t n, int64_t dim, int32_t only_if_
  * arrays (e.g. the output of an all-gather); out_* are [nq][k]. */
 int32_t eps_merge_topk(const float* dist, const int64_t* ids, int32_t shards, int64_t nq, int32_t k,
                        float* out_dist, int64_t* out_ids, int32_t device, void* hip_stream);
+
+/* the same merge over ONE gathered device buffer ("one ncclAllGather over a packed buffer"): shard s
+ * contributed shard_stride_bytes bytes holding int64 ids[nq][k] at offset 0 and float dist[nq][k] at dist_offset_bytes. */
+int32_t eps_merge_topk_packed(const void* gathered, int64_t shard_stride_bytes, int64_t dist_offset_bytes, int32_t shards,
+                              int64_t nq, int32_t k, float* out_dist, int64_t* out_ids, int32_t device, void* hip_stream);
 
 #ifdef __cplusplus
 }

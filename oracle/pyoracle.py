@@ -301,6 +301,14 @@ class Ref:
         L.ref_executor_search_impl.argtypes = [vp, fptr, i64, iptr, fptr]
         L.ref_executor_search_many.restype = C.c_double
         L.ref_executor_search_many.argtypes = [vp, fptr, i64, i64, iptr, fptr]
+        L.ref_alloc_rows.restype = C.c_void_p
+        L.ref_alloc_rows.argtypes = [i64, i64, C.c_int]
+        L.ref_free_rows.argtypes = [C.c_void_p]
+        dptr = C.POINTER(C.c_double)
+        L.ref_bruteforce_many.restype = C.c_double
+        L.ref_bruteforce_many.argtypes = [C.c_void_p, i64, i64, C.c_int, C.c_int, fptr, i64, i64, iptr, fptr, dptr]
+        L.ref_pool_search.restype = C.c_double
+        L.ref_pool_search.argtypes = [vp, C.c_void_p, i64, C.c_int, C.c_int, C.c_int, i64, i64, fptr, i64, i64, iptr, fptr, dptr]
         L.ref_dist_calls_reset.restype = C.c_uint64
         L.ref_executor_free.argtypes = [vp]
         L.ref_config.argtypes = [C.c_int] * 5
@@ -390,6 +398,41 @@ class Ref:
         ds = np.empty((Q.shape[0], K), np.float32)
         sec = self.L.ref_executor_search_many(ex, _f(Q), Q.shape[0], K, _i(ids), _f(ds))
         return ids, ds, sec
+
+    # ---- CPU baseline legs (bench.py)
+    def alloc_rows(self, n, d, threads):
+        """page-aligned float[n][d] first-touched by `threads` OpenMP threads (NUMA-local to the later scans);
+        returns (numpy view, raw pointer); release with free_rows(pointer)."""
+        p = self.L.ref_alloc_rows(n, d, threads)
+        if not p:
+            raise MemoryError("ref_alloc_rows(%d, %d)" % (n, d))
+        arr = np.ctypeslib.as_array(C.cast(p, fptr), shape=(n * d,)).reshape(n, d)
+        return arr, p
+
+    def free_rows(self, p):
+        self.L.ref_free_rows(p)
+
+    def bruteforce_many(self, rows_ptr, n, d, Q, k, metric=0, threads=1):
+        """the reference's BruteForceSearch (:717-768) per query; returns ids, dists, per-query seconds"""
+        Q = np.ascontiguousarray(Q, np.float32)
+        nq = Q.shape[0]
+        ids = np.empty((nq, k), np.int64)
+        ds = np.empty((nq, k), np.float32)
+        sec = np.empty(nq, np.float64)
+        self.L.ref_bruteforce_many(rows_ptr, n, d, metric, threads, _f(Q), nq, k, _i(ids), _f(ds),
+                                   sec.ctypes.data_as(C.POINTER(C.c_double)))
+        return ids, ds, sec
+
+    def pool_search(self, g, rows_ptr, d, Q, K, E, T, L, I=15, metric=0):
+        """E executors x T OpenMP workers (the reference's ExecutorPool concurrency); returns ids, dists, latencies, wall s"""
+        Q = np.ascontiguousarray(Q, np.float32)
+        nq = Q.shape[0]
+        ids = np.empty((nq, K), np.int64)
+        ds = np.empty((nq, K), np.float32)
+        lat = np.empty(nq, np.float64)
+        wall = self.L.ref_pool_search(g, rows_ptr, d, metric, E, T, L, I, _f(Q), nq, K, _i(ids), _f(ds),
+                                      lat.ctypes.data_as(C.POINTER(C.c_double)))
+        return ids, ds, lat, wall
 
     # ---- DBServer level
     class DB:

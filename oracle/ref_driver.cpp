@@ -33,6 +33,8 @@
 #include "db/index/distances.hpp"
 #include "db/index/knn/knn.hpp"
 #include "db/index/nsg/nsg.hpp"
+#include "query/expr/expr_evaluator.hpp"
+#include "utils/concurrent_bitset.hpp"
 
 namespace vectordb { namespace engine { namespace index { extern unsigned int seed; } } }  // nsg.cpp:19
 #endif
@@ -216,6 +218,92 @@ double ref_executor_search_many(void* h, float* queries, int64_t nq, int64_t K, 
 }
 uint64_t ref_dist_calls_reset() { return g_dist_calls.exchange(0); }
 void ref_executor_free(void* h) { delete static_cast<RefExecutor*>(h); }
+
+// ---------------------------------------------------------------- CPU baseline legs (bench.py cpu_baseline)
+// Row buffer for the baseline legs: page-aligned, first-touched by the same static OpenMP schedule the reference's
+// `#pragma omp parallel for` over rows uses (vec_search_executor.cpp:729), so that on a multi-socket host every
+// thread later streams rows from its own NUMA node.
+float* ref_alloc_rows(int64_t n, int64_t d, int threads) {
+  float* p = nullptr;
+  if (posix_memalign(reinterpret_cast<void**>(&p), 4096, sizeof(float) * (size_t)n * (size_t)d) != 0) return nullptr;
+  omp_set_num_threads(threads);
+#pragma omp parallel for
+  for (int64_t i = 0; i < n; ++i) memset(p + i * d, 0, sizeof(float) * (size_t)d);
+  return p;
+}
+void ref_free_rows(float* p) { free(p); }
+
+// The reference's own BruteForceSearch (vec_search_executor.cpp:717-768: omp-parallel distances into Candidate[n],
+// serial compaction, std::sort of all n survivors) for nq queries, one after another, with `threads` OpenMP threads.
+// Writes the first k (id, dist) of every query and the per-query seconds; returns the total seconds.
+double ref_bruteforce_many(float* rows, int64_t n, int64_t d, int metric, int threads, float* queries, int64_t nq, int64_t k,
+                           int64_t* ids, float* dists, double* per_query_s) {
+  auto g = std::make_shared<ANNGraphSegment>(true);   // record_number_ = 0 < BruteforceThreshold: no PrepareInitIds
+  size_t dim = (size_t)d;
+  vectordb::DistFunc df = vectordb::GetDistFunc(meta::FieldType::VECTOR_FLOAT, ToMetric(metric));
+  VecSearchExecutor ex(d, 0, g, nullptr, nullptr, rows, df, &dim, threads, 500, 500, 15, false);
+  vectordb::ConcurrentBitset deleted(n);
+  std::vector<vectordb::query::expr::ExprNodePtr> nodes;
+  std::unordered_map<std::string, size_t> offs;
+  int64_t prim = 0, nvar = 0;
+  std::vector<vectordb::engine::VariableLenAttrColumnContainer> var;
+  vectordb::query::expr::ExprEvaluator ev(nodes, offs, prim, nvar, nullptr, var);
+  double total = 0;
+  for (int64_t q = 0; q < nq; ++q) {
+    omp_set_num_threads(threads);
+    auto t0 = std::chrono::steady_clock::now();
+    ex.BruteForceSearch(queries + q * d, 0, n, deleted, ev, nullptr, -1);
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    total += sec;
+    if (per_query_s) per_query_s[q] = sec;
+    for (int64_t i = 0; i < k; ++i) {
+      const bool ok = i < (int64_t)ex.brute_force_queue_.size();
+      ids[q * k + i] = ok ? ex.brute_force_queue_[i].id_ : -1;
+      dists[q * k + i] = ok ? ex.brute_force_queue_[i].distance_ : 0.f;
+    }
+  }
+  return total;
+}
+
+// The reference's concurrency model for graph search (executor_pool.hpp:10-46 + SearchImpl's OpenMP team): E executors,
+// each driven by its own request thread and spawning T OpenMP workers per query; queries are handed out from a shared
+// counter.  Writes the first K master-queue entries and the latency of every query; returns the wall seconds.
+double ref_pool_search(void* graph, float* rows, int64_t d, int metric, int E, int T, int64_t L, int64_t iters, float* queries,
+                       int64_t nq, int64_t K, int64_t* ids, float* dists, double* latency_s) {
+  auto& g = *static_cast<std::shared_ptr<ANNGraphSegment>*>(graph);
+  std::vector<std::unique_ptr<RefExecutor>> pool;
+  for (int e = 0; e < E; ++e) {
+    auto r = std::make_unique<RefExecutor>();
+    r->graph = g;
+    r->dim = (size_t)d;
+    vectordb::DistFunc df = vectordb::GetDistFunc(meta::FieldType::VECTOR_FLOAT, ToMetric(metric));
+    r->exec.reset(new VecSearchExecutor(d, g->navigation_point_, g, g->offset_table_, g->neighbor_list_, rows, df, &r->dim, T, L, L,
+                                        iters, false));
+    pool.push_back(std::move(r));
+  }
+  std::atomic<int64_t> next{0};
+  auto worker = [&](int e) {
+    auto& x = *pool[e]->exec;
+    for (;;) {
+      const int64_t q = next.fetch_add(1);
+      if (q >= nq) break;
+      auto t0 = std::chrono::steady_clock::now();
+      x.SearchImpl(queries + q * d, K, x.L_master_, x.set_L_, x.init_ids_, x.search_result_, x.L_local_, x.local_queues_starts_,
+                   x.local_queues_sizes_, x.is_visited_, x.subsearch_iterations_);
+      const int64_t ms = x.local_queues_starts_[x.num_threads_ - 1];
+      for (int64_t i = 0; i < K; ++i) {
+        ids[q * K + i] = x.set_L_[ms + i].id_;
+        dists[q * K + i] = x.set_L_[ms + i].distance_;
+      }
+      if (latency_s) latency_s[q] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+  };
+  auto t0 = std::chrono::steady_clock::now();
+  std::vector<std::thread> th;
+  for (int e = 0; e < E; ++e) th.emplace_back(worker, e);
+  for (auto& t : th) t.join();
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
 
 #endif  // !EPS_DROPIN
 #ifdef EPS_DROPIN

@@ -32,3 +32,22 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
         assert key in cb, key
     assert cb["kind"] in ("reference", "port")
     assert d["recall_at_10"] >= 0.999
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu_merge_equals_unsharded_scan():
+    """The N > 1 path of bench.py end to end with product code on both sides: two ranks (gloo, both on this GPU), each
+    with its own shard (rows i = local*2 + rank), ONE all-gather of the packed per-shard top-k, eps_merge_topk_packed;
+    recall is measured against the merged exact stream scans of the shards, so anything short of 1.0 is a sharding /
+    id-map / merge bug."""
+    env = dict(os.environ, EPS_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--rows", "150000", "--batch", "96", "--cpu-seconds", "0"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert "rows_total=300000" in d["config"]["workload"]
+    assert d["recall_at_10"] == 1.0 and d["recall_check"]["ground_truth_vs_torch_fp32_scan"] == 1.0

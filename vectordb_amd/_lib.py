@@ -25,7 +25,7 @@ EXPORTS = [
     "eps_index_append_rows", "eps_index_row_count", "eps_index_set_id_map", "eps_index_set_deleted",
     "eps_index_set_int_filter", "eps_index_build", "eps_index_set_graph", "eps_index_graph_info",
     "eps_index_get_graph", "eps_index_save_graph", "eps_index_load_graph", "eps_index_search",
-    "eps_index_last_stats", "eps_normalize_rows", "eps_merge_topk",
+    "eps_index_last_stats", "eps_index_kernel_times", "eps_normalize_rows", "eps_merge_topk", "eps_merge_topk_packed",
 ]
 
 
@@ -99,6 +99,8 @@ def load():
     L.eps_index_last_stats.argtypes = [vp, C.POINTER(SearchStats)]
     L.eps_normalize_rows.argtypes = [vp, i64, i64, i32, i32, vp]
     L.eps_merge_topk.argtypes = [vp, vp, i32, i64, i32, vp, vp, i32, vp]
+    L.eps_index_kernel_times.argtypes = [vp, C.POINTER(C.c_double), i32]
+    L.eps_merge_topk_packed.argtypes = [vp, i64, i64, i32, i64, i32, vp, vp, i32, vp]
     for name in EXPORTS:
         if getattr(L, name).restype is C.c_int:
             getattr(L, name).restype = i32

@@ -329,8 +329,9 @@ void launch_normalize(float* rows, int64_t n, int dim, bool only_if_nonzero, hip
 
 // ------------------------------------------------------------------------------------------------
 // k-way merge of per-shard sorted lists by (dist, id) — what every rank does after the all-gather.
+// shard s's lists start `stride_bytes` after shard s-1's (0 = densely packed [shards][nq][k] arrays)
 __global__ void merge_shards_kernel(const float* dist, const int64_t* ids, int shards, int64_t nq, int k,
-                                    float* out_dist, int64_t* out_ids) {
+                                    float* out_dist, int64_t* out_ids, int64_t stride_bytes) {
   const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= nq) return;
   int head[16];
@@ -341,10 +342,10 @@ __global__ void merge_shards_kernel(const float* dist, const int64_t* ids, int s
     int64_t bi = 0;
     for (int s = 0; s < shards; ++s) {
       if (head[s] >= k) continue;
-      const int64_t o = ((int64_t)s * nq + q) * k + head[s];
-      const int64_t id = ids[o];
+      const int64_t o = q * k + head[s];
+      const int64_t id = *reinterpret_cast<const int64_t*>(reinterpret_cast<const char*>(ids + o) + (stride_bytes ? stride_bytes : nq * k * 8) * s);
       if (id < 0) { head[s] = k; continue; }
-      const float d = dist[o];
+      const float d = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(dist + o) + (stride_bytes ? stride_bytes : nq * k * 4) * s);
       if (best < 0 || d < bd || (d == bd && id < bi)) {
         best = s; bd = d; bi = id;
       }
@@ -360,10 +361,10 @@ __global__ void merge_shards_kernel(const float* dist, const int64_t* ids, int s
   }
 }
 void launch_merge_shards(const float* dist, const int64_t* ids, int shards, int64_t nq, int k, float* out_dist,
-                         int64_t* out_ids, hipStream_t s) {
+                         int64_t* out_ids, hipStream_t s, int64_t stride_bytes) {
   if (nq <= 0) return;
   hipLaunchKernelGGL(merge_shards_kernel, dim3((unsigned)((nq + 127) / 128)), dim3(128), 0, s, dist, ids, shards, nq, k,
-                     out_dist, out_ids);
+                     out_dist, out_ids, stride_bytes);
 }
 
 }  // namespace eps

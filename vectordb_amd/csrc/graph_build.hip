@@ -312,9 +312,16 @@ int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp) {
     return ix.fail(EPS_USER_ERROR, "build: unsupported parameters (need 0 < knng < 1024, 0 < out_degree <= 512)");
   const bool vec4 = (dim % 4 == 0) && ((reinterpret_cast<uintptr_t>(ix.d_rows_) & 15) == 0);
   const bool debug = getenv("EPS_DEBUG") != nullptr;
-  hipEvent_t e0, e1;
-  HIPCHK(hipEventCreate(&e0));
-  HIPCHK(hipEventCreate(&e1));
+  struct EventPair {   // released on every return path
+    hipEvent_t a = nullptr, b = nullptr;
+    ~EventPair() {
+      if (a) (void)hipEventDestroy(a);
+      if (b) (void)hipEventDestroy(b);
+    }
+  } evp;
+  HIPCHK(hipEventCreate(&evp.a));
+  HIPCHK(hipEventCreate(&evp.b));
+  hipEvent_t e0 = evp.a, e1 = evp.b;
   auto lap = [&](const char* what) {
     if (!debug) return;
     (void)hipEventRecord(e1, s);
@@ -558,20 +565,33 @@ int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp) {
       HIPCHK(hipMemcpyAsync(top.data() + (size_t)o0 * TRACE_K, d_top.p, (size_t)nb * TRACE_K * 8, hipMemcpyDeviceToHost, s));
       HIPCHK(hipStreamSynchronize(s));
     }
+    // Out-degree stays <= 64 (the reference has no cap: on hub-prone data its repair edges pile up on a few nodes -
+    // 291 edges on one node at 1M x 768): a saturated node passes the orphan on to the next closest reached node of the
+    // trace, so every adjacency list keeps the fixed 256-byte stride the traversal kernel reads with one row fetch.
+    const u32 deg_cap = (u32)std::max(64, R + 1);
+    std::vector<u32> live_extra((size_t)n, 0);
     std::vector<u32> stack;
+    uint64_t lcg = bp.seed ? bp.seed : 100;
     for (int64_t i = 0; i < m; ++i) {
       const u32 x = orphans[i];
       if (reached[x]) continue;   // linked through an earlier orphan's subtree
-      u32 root = (u32)nav;        // (the reference falls back to a random linked node, nsg.cpp:763-771)
+      int64_t root = -1;
       for (int e = 0; e < TRACE_K; ++e) {
         const u64 key = top[(size_t)i * TRACE_K + e];
         if (key == KEY_EMPTY) break;
-        if (reached[key_id(key)]) {
-          root = key_id(key);
+        const u32 c = key_id(key);
+        if (reached[c] && h_deg[c] + live_extra[c] < deg_cap) {
+          root = c;
           break;
         }
       }
-      extra.emplace_back(root, x);
+      while (root < 0) {          // a random linked node (nsg.cpp:763-771), here one that still has room
+        lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+        const u32 c = (u32)((lcg >> 33) % (uint64_t)n);
+        if (reached[c] && h_deg[c] + live_extra[c] < deg_cap) root = c;
+      }
+      live_extra[root]++;
+      extra.emplace_back((u32)root, x);
       reached[x] = 1;
       stack.push_back(x);
       while (!stack.empty()) {
@@ -606,8 +626,6 @@ int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp) {
     fill[i] = off[i] + h_deg[i];
   }
   for (auto& pr : extra) nbr[fill[pr.first]++] = pr.second;
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
   if (debug) {
     u32 maxdeg = 0;
     for (int64_t i = 0; i < n; ++i) maxdeg = std::max(maxdeg, h_deg[i] + extra_cnt[i]);

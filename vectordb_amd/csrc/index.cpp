@@ -3,8 +3,10 @@
 
 #include <unistd.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <new>
 
 namespace eps {
 
@@ -52,8 +54,9 @@ Index::~Index() {
   if (mirror_) half_mirror_free(mirror_);
   if (ev0_) (void)hipEventDestroy(ev0_);
   if (ev1_) (void)hipEventDestroy(ev1_);
-  if (evk0_) (void)hipEventDestroy(evk0_);
-  if (evk1_) (void)hipEventDestroy(evk1_);
+  for (auto& pr : kring_)
+    for (auto& e : pr)
+      if (e) (void)hipEventDestroy(e);
   if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -85,8 +88,10 @@ int32_t Index::init() {
   own_stream_ = true;
   HIP_TRY(hipEventCreate(&ev0_));
   HIP_TRY(hipEventCreate(&ev1_));
-  HIP_TRY(hipEventCreate(&evk0_));
-  HIP_TRY(hipEventCreate(&evk1_));
+  for (auto& pr : kring_)
+    for (auto& e : pr) HIP_TRY(hipEventCreate(&e));
+  evk0_ = kring_[0][0];
+  evk1_ = kring_[0][1];
   return EPS_OK;
 }
 
@@ -129,6 +134,24 @@ int32_t Index::attach_rows(const float* rows, int64_t n) {
   }
   n_rows_ = n;
   ++rows_version_;
+  // state that was sized for the previous table does not carry over: a graph over more rows than are attached now, a
+  // deleted bitset or an attribute column of the old length
+  if (n_indexed_ > n) {
+    n_indexed_ = 0;
+    nav_ = 0;
+    h_off_.assign(1, 0);
+    h_nbr_.clear();
+    (void)graph_upload(*this);
+  }
+  if (deleted_bytes_ < (n + 7) / 8) {
+    d_deleted_ = nullptr;
+    deleted_bytes_ = 0;
+  }
+  if (fcol_rows_ < n) {
+    f_op_ = 0;
+    d_fcol_ = nullptr;
+    fcol_rows_ = 0;
+  }
   return EPS_OK;
 }
 
@@ -158,7 +181,7 @@ int32_t Index::append_rows(const float* rows, int64_t n_new) {
   rows_owned_ = true;
   n_rows_ += n_new;
   ++rows_version_;
-  return EPS_OK;
+  return EPS_OK;   // (a bitset / attribute column that is now too short is rejected by search(), see there)
 }
 
 int32_t Index::set_id_map(int64_t base, int64_t stride) {
@@ -172,9 +195,11 @@ int32_t Index::set_deleted(const uint8_t* bits, int64_t nbytes) {
   HIP_TRY(hipSetDevice(device_));
   if (!bits || nbytes <= 0) {
     d_deleted_ = nullptr;
+    deleted_bytes_ = 0;
     return EPS_OK;
   }
   if (nbytes < (n_rows_ + 7) / 8) return fail(EPS_USER_ERROR, "set_deleted: bitset shorter than ceil(rows/8) bytes");
+  deleted_bytes_ = nbytes;
   if (is_device_ptr(bits)) {
     d_deleted_ = bits;
   } else {
@@ -189,7 +214,7 @@ int32_t Index::set_deleted(const uint8_t* bits, int64_t nbytes) {
       any = w != 0;
     }
     for (; i < live && !any; ++i) any = bits[i] != 0;
-    if (!any) {
+    if (!any && n_rows_ > 0) {   // (before any rows are attached nothing can be concluded from the live prefix)
       d_deleted_ = nullptr;
       return EPS_OK;
     }
@@ -206,6 +231,7 @@ int32_t Index::set_int_filter(const void* column, int64_t stride, int32_t width,
   if (op == EPS_OP_NONE || !column) {
     f_op_ = 0;
     d_fcol_ = nullptr;
+    fcol_rows_ = 0;
     return EPS_OK;
   }
   if (op < 0 || op > EPS_OP_NE) return fail(EPS_USER_ERROR, "set_int_filter: unknown operator");
@@ -224,6 +250,7 @@ int32_t Index::set_int_filter(const void* column, int64_t stride, int32_t width,
   f_width_ = width;
   f_op_ = op;
   f_value_ = constant;
+  fcol_rows_ = n_rows_;
   return EPS_OK;
 }
 
@@ -240,7 +267,7 @@ FilterSpec Index::filter_spec() const {
 
 // ------------------------------------------------------------------------------------------------ graph
 int32_t Index::set_graph(int64_t n, const int64_t* off, const int64_t* nbr, int64_t nav) {
-  if (n < 0 || (n > 0 && (!off || !nbr))) return fail(EPS_USER_ERROR, "set_graph: bad arguments");
+  if (n < 0 || (n > 0 && (!off || (!nbr && off[n] > 0)))) return fail(EPS_USER_ERROR, "set_graph: bad arguments");
   if (n > n_rows_) return fail(EPS_USER_ERROR, "set_graph: graph has more nodes than attached rows");
   if (n > 0 && (nav < 0 || nav >= n)) return fail(EPS_USER_ERROR, "set_graph: navigation point out of range");
   if (n > 0) {
@@ -309,10 +336,13 @@ int32_t Index::load_graph(const char* path) {
   int64_t hdr[2];
   std::vector<int64_t> off, nbr;
   int64_t nav = 0;
-  bool ok = std::fread(hdr, 8, 2, f) == 2 && hdr[0] >= 0;
+  std::fseek(f, 0, SEEK_END);
+  const int64_t fsize = (int64_t)std::ftell(f);   // header values are untrusted: bound them by the file size
+  std::fseek(f, 0, SEEK_SET);
+  bool ok = std::fread(hdr, 8, 2, f) == 2 && hdr[0] >= 0 && hdr[0] <= (fsize - 32) / 8;
   if (ok) {
     off.resize((size_t)hdr[0] + 1);
-    ok = std::fread(off.data(), 8, off.size(), f) == off.size() && off[hdr[0]] >= 0;
+    ok = std::fread(off.data(), 8, off.size(), f) == off.size() && off[hdr[0]] >= 0 && off[hdr[0]] <= (fsize - 24 - 8 * (hdr[0] + 1)) / 8;
   }
   if (ok) {
     nbr.resize((size_t)off[hdr[0]]);
@@ -378,6 +408,17 @@ int32_t Index::search(const float* queries, int64_t nq, int32_t k, const eps_sea
     return fail(EPS_USER_ERROR, "search: queue sizes, sync interval and thread count must be positive");
   HIP_TRY(hipSetDevice(device_));
   std::memset(&stats_, 0, sizeof(stats_));
+  if (d_deleted_ && deleted_bytes_ < (n_rows_ + 7) / 8)
+    return fail(EPS_USER_ERROR, "search: the deleted bitset is shorter than the table (rows were appended): call set_deleted again");
+  if (f_op_ && d_fcol_ && fcol_rows_ < n_rows_)
+    return fail(EPS_USER_ERROR, "search: the filter column is shorter than the table (rows were appended): call set_int_filter again");
+  kring_seq_ += 1;
+  {
+    const int slot = (int)(kring_seq_ % KRING);
+    evk0_ = kring_[slot][0];
+    evk1_ = kring_[slot][1];
+    kring_valid_[slot] = false;
+  }
 
   const bool q_dev = is_device_ptr(queries);
   const bool out_dev = is_device_ptr(ids);
@@ -461,7 +502,27 @@ int32_t Index::search(const float* queries, int64_t nq, int32_t k, const eps_sea
     HIP_TRY(hipStreamSynchronize(stream_));
   }
   HIP_TRY(hipGetLastError());
+  kring_valid_[kring_seq_ % KRING] = stats_.main_kernel_launches > 0;
   return EPS_OK;
+}
+
+// main-kernel milliseconds of the most recent search calls (oldest first); synchronises the stream
+int Index::kernel_times(double* ms_out, int cap) {
+  if (!ms_out || cap <= 0) return 0;
+  if (hipSetDevice(device_) != hipSuccess || hipStreamSynchronize(stream_) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  int n = 0;
+  const int64_t first = std::max<int64_t>(1, kring_seq_ - std::min<int64_t>(cap, KRING) + 1);
+  for (int64_t q = first; q <= kring_seq_; ++q) {
+    const int slot = (int)(q % KRING);
+    if (!kring_valid_[slot]) continue;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, kring_[slot][0], kring_[slot][1]) == hipSuccess) ms_out[n++] = ms;
+    else (void)hipGetLastError();
+  }
+  return n;
 }
 
 }  // namespace eps
@@ -492,48 +553,79 @@ void eps_default_build_params(eps_build_params* p) {
   p->reserved = 0;
 }
 
+// No C++ exception crosses the C ABI: allocation failures and anything else thrown below map to the reference's
+// status codes (utils/error.hpp:11-41) with the text in eps_index_last_error.
+static int32_t map_exception(Index* ix) {
+  try {
+    throw;
+  } catch (const std::bad_alloc&) {
+    return ix ? ix->fail(EPS_INFRA_UNEXPECTED_ERROR, "out of host memory") : EPS_INFRA_UNEXPECTED_ERROR;
+  } catch (const std::exception& e) {
+    return ix ? ix->fail(EPS_DB_UNEXPECTED_ERROR, std::string("unexpected: ") + e.what()) : EPS_DB_UNEXPECTED_ERROR;
+  } catch (...) {
+    return ix ? ix->fail(EPS_DB_UNEXPECTED_ERROR, "unexpected exception") : EPS_DB_UNEXPECTED_ERROR;
+  }
+}
+#define IX(h) reinterpret_cast<Index*>(h)
+#define CIX(h) reinterpret_cast<const Index*>(h)
+#define GUARD(h, expr)             \
+  do {                             \
+    if (!(h)) return EPS_USER_ERROR; \
+    try {                          \
+      return (expr);               \
+    } catch (...) {                \
+      return map_exception(IX(h)); \
+    }                              \
+  } while (0)
+
 int32_t eps_index_create(int64_t dim, int32_t metric, int32_t device, eps_index** out) {
   if (!out) return EPS_USER_ERROR;
   *out = nullptr;
   if (dim <= 0 || dim > 8192 || metric < 0 || metric > 2) return EPS_USER_ERROR;  // one query must fit in LDS next to the queues
-  Index* ix = new Index(dim, metric, device);
-  const int32_t rc = ix->init();
-  if (rc != EPS_OK) {
-    std::fprintf(stderr, "eps_index_create: %s\n", ix->last_error());
-    delete ix;
-    return rc;
+  try {
+    Index* ix = new Index(dim, metric, device);
+    const int32_t rc = ix->init();
+    if (rc != EPS_OK) {
+      std::fprintf(stderr, "eps_index_create: %s\n", ix->last_error());
+      delete ix;
+      return rc;
+    }
+    *out = reinterpret_cast<eps_index*>(ix);
+    return EPS_OK;
+  } catch (...) {
+    return map_exception(nullptr);
   }
-  *out = reinterpret_cast<eps_index*>(ix);
-  return EPS_OK;
 }
 int32_t eps_index_destroy(eps_index* h) {
-  delete reinterpret_cast<Index*>(h);
-  return EPS_OK;
+  try {
+    delete reinterpret_cast<Index*>(h);
+    return EPS_OK;
+  } catch (...) {
+    return map_exception(nullptr);
+  }
 }
 const char* eps_index_last_error(const eps_index* h) { return h ? reinterpret_cast<const Index*>(h)->last_error() : "null handle"; }
-#define IX(h) reinterpret_cast<Index*>(h)
-#define CIX(h) reinterpret_cast<const Index*>(h)
-int32_t eps_index_set_stream(eps_index* h, void* s) { return h ? IX(h)->set_stream(s) : EPS_USER_ERROR; }
-int32_t eps_index_synchronize(eps_index* h) { return h ? IX(h)->synchronize() : EPS_USER_ERROR; }
-int32_t eps_index_attach_rows(eps_index* h, const float* rows, int64_t n) { return h ? IX(h)->attach_rows(rows, n) : EPS_USER_ERROR; }
-int32_t eps_index_append_rows(eps_index* h, const float* rows, int64_t n) { return h ? IX(h)->append_rows(rows, n) : EPS_USER_ERROR; }
+int32_t eps_index_set_stream(eps_index* h, void* s) { GUARD(h, IX(h)->set_stream(s)); }
+int32_t eps_index_synchronize(eps_index* h) { GUARD(h, IX(h)->synchronize()); }
+int32_t eps_index_attach_rows(eps_index* h, const float* rows, int64_t n) { GUARD(h, IX(h)->attach_rows(rows, n)); }
+int32_t eps_index_append_rows(eps_index* h, const float* rows, int64_t n) { GUARD(h, IX(h)->append_rows(rows, n)); }
 int64_t eps_index_row_count(const eps_index* h) { return h ? CIX(h)->row_count() : -1; }
-int32_t eps_index_set_id_map(eps_index* h, int64_t b, int64_t s) { return h ? IX(h)->set_id_map(b, s) : EPS_USER_ERROR; }
-int32_t eps_index_set_deleted(eps_index* h, const uint8_t* bits, int64_t nbytes) { return h ? IX(h)->set_deleted(bits, nbytes) : EPS_USER_ERROR; }
+int32_t eps_index_set_id_map(eps_index* h, int64_t b, int64_t s) { GUARD(h, IX(h)->set_id_map(b, s)); }
+int32_t eps_index_set_deleted(eps_index* h, const uint8_t* bits, int64_t nbytes) { GUARD(h, IX(h)->set_deleted(bits, nbytes)); }
 int32_t eps_index_set_int_filter(eps_index* h, const void* col, int64_t stride, int32_t width, int32_t op, int64_t c) {
-  return h ? IX(h)->set_int_filter(col, stride, width, op, c) : EPS_USER_ERROR;
+  GUARD(h, IX(h)->set_int_filter(col, stride, width, op, c));
 }
-int32_t eps_index_build(eps_index* h, int64_t n, const eps_build_params* p) { return h ? IX(h)->build(n, p) : EPS_USER_ERROR; }
+int32_t eps_index_build(eps_index* h, int64_t n, const eps_build_params* p) { GUARD(h, IX(h)->build(n, p)); }
 int32_t eps_index_set_graph(eps_index* h, int64_t n, const int64_t* off, const int64_t* nbr, int64_t nav) {
-  return h ? IX(h)->set_graph(n, off, nbr, nav) : EPS_USER_ERROR;
+  GUARD(h, IX(h)->set_graph(n, off, nbr, nav));
 }
 int32_t eps_index_graph_info(const eps_index* h, int64_t* n, int64_t* e, int64_t* nav) { return h ? CIX(h)->graph_info(n, e, nav) : EPS_USER_ERROR; }
 int32_t eps_index_get_graph(const eps_index* h, int64_t* off, int64_t* nbr) { return h ? CIX(h)->get_graph(off, nbr) : EPS_USER_ERROR; }
-int32_t eps_index_save_graph(eps_index* h, const char* path) { return h ? IX(h)->save_graph(path) : EPS_USER_ERROR; }
-int32_t eps_index_load_graph(eps_index* h, const char* path) { return h ? IX(h)->load_graph(path) : EPS_USER_ERROR; }
+int32_t eps_index_save_graph(eps_index* h, const char* path) { GUARD(h, IX(h)->save_graph(path)); }
+int32_t eps_index_load_graph(eps_index* h, const char* path) { GUARD(h, IX(h)->load_graph(path)); }
 int32_t eps_index_search(eps_index* h, const float* q, int64_t nq, int32_t k, const eps_search_params* p, int64_t* ids,
                          float* dist, int32_t* counts) {
-  return h ? IX(h)->search(q, nq, k, p, ids, dist, counts) : EPS_USER_ERROR;
+  GUARD(h, IX(h)->search(q, nq, k, p, ids, dist, counts));
 }
 int32_t eps_index_last_stats(const eps_index* h, eps_search_stats* out) {
   if (!h || !out) return EPS_USER_ERROR;
@@ -549,6 +641,7 @@ int32_t eps_index_last_stats(const eps_index* h, eps_search_stats* out) {
   *out = s;
   return EPS_OK;
 }
+int32_t eps_index_kernel_times(eps_index* h, double* ms_out, int32_t cap) { return h ? IX(h)->kernel_times(ms_out, cap) : 0; }
 
 int32_t eps_normalize_rows(float* rows, int64_t n, int64_t dim, int32_t only_if_nonzero, int32_t device, void* stream) {
   if (n < 0 || dim <= 0 || (n > 0 && !rows)) return EPS_USER_ERROR;
@@ -596,6 +689,22 @@ int32_t eps_merge_topk(const float* dist, const int64_t* ids, int32_t shards, in
        hipStreamSynchronize(s) == hipSuccess;
   (void)hipFree(d);
   return ok ? EPS_OK : EPS_INFRA_UNEXPECTED_ERROR;
+}
+
+// the same merge over ONE gathered buffer: shard s contributed `shard_stride_bytes` bytes holding int64 ids[nq][k] at
+// offset 0 and float dist[nq][k] at `dist_offset_bytes` (what a single all-gather of a packed per-rank buffer delivers)
+int32_t eps_merge_topk_packed(const void* gathered, int64_t shard_stride_bytes, int64_t dist_offset_bytes, int32_t shards, int64_t nq,
+                              int32_t k, float* out_dist, int64_t* out_ids, int32_t device, void* stream) {
+  if (!gathered || !out_dist || !out_ids || shards <= 0 || shards > 16 || nq < 0 || k <= 0) return EPS_USER_ERROR;
+  if (shard_stride_bytes < dist_offset_bytes + nq * k * 4 || dist_offset_bytes < nq * k * 8 || (dist_offset_bytes & 3) || (shard_stride_bytes & 7))
+    return EPS_USER_ERROR;
+  if (nq == 0) return EPS_OK;
+  if (!eps::is_device_ptr(gathered) || !eps::is_device_ptr(out_dist) || !eps::is_device_ptr(out_ids)) return EPS_USER_ERROR;
+  if (hipSetDevice(device) != hipSuccess) return EPS_INFRA_UNEXPECTED_ERROR;
+  const char* base = static_cast<const char*>(gathered);
+  eps::launch_merge_shards(reinterpret_cast<const float*>(base + dist_offset_bytes), reinterpret_cast<const int64_t*>(base), shards, nq, k,
+                           out_dist, out_ids, static_cast<hipStream_t>(stream), shard_stride_bytes);
+  return hipGetLastError() == hipSuccess ? EPS_OK : EPS_INFRA_UNEXPECTED_ERROR;
 }
 
 }  // extern "C"

@@ -97,7 +97,17 @@ class Index {
 
   // scratch
   DevBuf q_buf_, partial_buf_, run_buf_, ids_buf_, dist_buf_, cnt_buf_, tmp_buf_;
-  hipEvent_t ev0_ = nullptr, ev1_ = nullptr, evk0_ = nullptr, evk1_ = nullptr;
+  hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+  // main-kernel event pairs of the last KRING search calls (read back after a run without a sync inside it);
+  // evk0_/evk1_ alias the pair of the call in progress
+  static constexpr int KRING = 64;
+  hipEvent_t kring_[KRING][2] = {};
+  bool kring_valid_[KRING] = {};
+  int64_t kring_seq_ = 0;
+  hipEvent_t evk0_ = nullptr, evk1_ = nullptr;
+  int kernel_times(double* ms_out, int cap);
+  int64_t deleted_bytes_ = 0;   // length of the bitset behind d_deleted_
+  int64_t fcol_rows_ = 0;       // rows the attribute column behind d_fcol_ covers
 
   std::string err_;
   eps_search_stats stats_{};

@@ -230,9 +230,9 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
   if ((int64_t)T * dp > 2048) return ix.fail(EPS_DB_UNSUPPORTED_ERROR, "search: IntraQueryThreads x maximum out-degree > 2048 is not supported");
   const int64_t qtot = (int64_t)(T - 1) * Lq + Lp2;
   const bool vec4 = (ix.dim_ % 4 == 0) && ((reinterpret_cast<uintptr_t>(ix.d_rows_) & 15) == 0);
-  // queues in LDS when the whole working set of a workgroup stays within 64 KB (several workgroups per CU keep
-  // the row gathers in flight); larger SearchQueueSize: queues in HBM
-  const bool qglobal = traverse2_lds_bytes((int)ix.dim_, T, (int)Lq, qtot, dp, false) > 65536;
+  // queues in LDS while a workgroup's working set leaves room for at least two workgroups per CU (the row gathers of
+  // the other one cover this one's queue maintenance); larger SearchQueueSize: queues in HBM
+  const bool qglobal = traverse2_lds_bytes((int)ix.dim_, T, (int)Lq, qtot, dp, false) > 80 * 1024;
   const size_t shm = traverse2_lds_bytes((int)ix.dim_, T, (int)Lq, qtot, dp, qglobal);
   // few queries: 16 wavefronts per query (latency); many queries: 4 per query (throughput, more queries per CU)
   const char* wide_s = getenv("EPS_TRV_WIDE");

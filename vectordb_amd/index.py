@@ -192,10 +192,26 @@ class GpuIndex:
         self._check(self.L.eps_index_search(self.h, _ptr(queries), nq, k, C.byref(p), _ptr(ids), _ptr(dist), _ptr(counts)))
         return ids, dist, counts
 
+    def kernel_times(self, cap=64):
+        """main-kernel ms of the most recent search calls (oldest first); synchronises the index's stream"""
+        buf = (C.c_double * cap)()
+        n = self.L.eps_index_kernel_times(self.h, buf, cap)
+        return [buf[i] for i in range(n)]
+
     def stats(self):
         s = SearchStats()
         self._check(self.L.eps_index_last_stats(self.h, C.byref(s)))
         return {f: getattr(s, f) for f, _ in SearchStats._fields_}
+
+
+def merge_topk_packed(gathered, shard_stride_bytes, dist_offset_bytes, shards, nq, k, out_dist, out_ids, device=0, stream=None):
+    """gathered: one device buffer = the all-gather of every rank's packed [ids int64[nq][k] | dist float[nq][k]]."""
+    L = lib.load()
+    rc = L.eps_merge_topk_packed(_ptr(gathered), shard_stride_bytes, dist_offset_bytes, shards, nq, k, _ptr(out_dist), _ptr(out_ids),
+                                 device, C.c_void_p(stream) if stream else None)
+    if rc != 0:
+        raise EpsillaError(rc, "eps_merge_topk_packed failed")
+    return out_dist, out_ids
 
 
 def normalize_rows(rows, only_if_nonzero=True, device=0, stream=None):
