@@ -369,6 +369,10 @@ def main():
             graph_for_cpu = (off, nbr, nav, gn, ggt)
         ix2.close()
 
+    if args.mode == "graph" and world == 1 and args.cpu_seconds > 0:
+        off, nbr, nav = ix.get_graph()
+        graph_for_cpu = (off, nbr, nav, n, gt)     # the CPU graph leg searches the same device-built graph
+
     if rank == 0:
         qps = b * args.steps / elapsed
         kernel_ms = float(np.mean(main_ms)) if main_ms else 0.0   # hipEvent pair around the dominant launch of every timed step
