@@ -2,9 +2,12 @@
 // Reference behaviour followed: engine/db/execution/vec_search_executor.cpp:29-73 (ctor), :833-935 (Search),
 // :937-1033 (SearchByAttribute).  The distance / traversal / top-k work is eps_index_search on the MI355X; what
 // stays here is glue that needs the DBMS's own types: incremental upload of appended rows, the deleted bitset, and
-// lowering of the parsed filter (ExprNode array) to either the device's `int column <op> const` form or — for
-// anything else (strings, LIKE, IN, AND/OR trees, geo) — a host-evaluated visibility bitset handed to the device,
-// which applies it exactly where the reference applies deleted_/LogicalEvaluate.
+// the filter compiler: the parsed filter (ExprNode array) is lowered to a device predicate program over
+// the packed attribute rows - int / float / bool attributes, constants, arithmetic, comparisons, AND / OR / NOT and
+// @distance, with the reference's evaluation rules (expr_evaluator.cpp:127-258) - which the device applies exactly where
+// the reference applies deleted_ / LogicalEvaluate.  Filters with leaves only the host can evaluate (strings, LIKE, IN,
+// NEARBY) run as in the reference: the device returns the <= L candidates of the post-filter walk (:905-927) and
+// LogicalEvaluate is called on those, O(L) per query, not O(N).
 #include "db/execution/vec_search_executor.hpp"
 
 #include <algorithm>
@@ -25,6 +28,7 @@ namespace engine {
 namespace execution {
 
 using vectordb::query::expr::ExprEvaluator;
+using vectordb::query::expr::ExprNode;
 using vectordb::query::expr::ExprNodePtr;
 using vectordb::query::expr::NodeType;
 
@@ -90,24 +94,115 @@ std::shared_ptr<DeviceField> AcquireField(const float* column, int64_t dim, int 
   return sp;
 }
 
-bool IsIntAttr(NodeType t) { return t == NodeType::Int1Attr || t == NodeType::Int2Attr || t == NodeType::Int4Attr || t == NodeType::Int8Attr; }
-int IntWidth(NodeType t) { return t == NodeType::Int1Attr ? 1 : t == NodeType::Int2Attr ? 2 : t == NodeType::Int4Attr ? 4 : 8; }
-int CmpOp(NodeType t, bool flipped) {
-  switch (t) {
-    case NodeType::LT: return flipped ? EPS_OP_GT : EPS_OP_LT;
-    case NodeType::LTE: return flipped ? EPS_OP_GE : EPS_OP_LE;
-    case NodeType::GT: return flipped ? EPS_OP_LT : EPS_OP_GT;
-    case NodeType::GTE: return flipped ? EPS_OP_LE : EPS_OP_GE;
-    case NodeType::EQ: return EPS_OP_EQ;
-    case NodeType::NE: return EPS_OP_NE;
-    default: return EPS_OP_NONE;
+// ---- filter compiler: ExprNode tree -> eps_filter_op postfix program -------------------------------------------------
+struct Compiler {
+  const std::vector<ExprNodePtr>& nodes;
+  vectordb::engine::TableSegmentMVP* seg;
+  std::vector<eps_filter_op> out;
+  bool host_only = false;   // met a leaf only the host can evaluate
+
+  void Push(int op, int arg = 0, double dval = 0.0) {
+    eps_filter_op o;
+    o.op = op;
+    o.arg = arg;
+    o.ival = 0;
+    o.dval = dval;
+    out.push_back(o);
   }
-}
-bool UsesDistance(const std::vector<ExprNodePtr>& nodes) {
-  for (auto& n : nodes)
-    if (n && n->field_name == "@distance") return true;
-  return false;
-}
+  bool Valid(size_t i) const { return i < nodes.size() && nodes[i]; }
+  int Offset(const std::string& name) {
+    auto it = seg->field_name_mem_offset_map_.find(name);
+    if (it == seg->field_name_mem_offset_map_.end()) {
+      host_only = true;   // (unknown field: let the reference's evaluator decide)
+      return 0;
+    }
+    return (int)it->second;
+  }
+  // NumEvaluate (expr_evaluator.cpp:127-165): `dist` = whether @distance is live at this position
+  void Num(size_t i, bool dist) {
+    if (!Valid(i)) return Push(EPS_FOP_PUSH_CONST, 0, 0.0);
+    const ExprNode& n = *nodes[i];
+    switch (n.node_type) {
+      case NodeType::IntConst: return Push(EPS_FOP_PUSH_CONST, 0, (double)n.int_value);
+      case NodeType::DoubleConst: return Push(EPS_FOP_PUSH_CONST, 0, n.double_value);
+      case NodeType::Int1Attr: return Push(EPS_FOP_PUSH_I8, Offset(n.field_name));
+      case NodeType::Int2Attr: return Push(EPS_FOP_PUSH_I16, Offset(n.field_name));
+      case NodeType::Int4Attr: return Push(EPS_FOP_PUSH_I32, Offset(n.field_name));
+      case NodeType::Int8Attr: return Push(EPS_FOP_PUSH_I64, Offset(n.field_name));
+      case NodeType::DoubleAttr:
+      case NodeType::FloatAttr:
+        if (n.field_name == "@distance") return dist ? Push(EPS_FOP_PUSH_DIST) : Push(EPS_FOP_PUSH_CONST, 0, 0.0);
+        return Push(n.node_type == NodeType::DoubleAttr ? EPS_FOP_PUSH_F64 : EPS_FOP_PUSH_F32, Offset(n.field_name));
+      case NodeType::Add:
+      case NodeType::Subtract:
+      case NodeType::Multiply:
+      case NodeType::Divide:
+      case NodeType::Module:
+        if (n.left != (size_t)-1 && n.right != (size_t)-1) {
+          Num(n.left, dist);
+          Num(n.right, dist);
+          return Push(n.node_type == NodeType::Add ? EPS_FOP_ADD : n.node_type == NodeType::Subtract ? EPS_FOP_SUB
+                      : n.node_type == NodeType::Multiply ? EPS_FOP_MUL : n.node_type == NodeType::Divide ? EPS_FOP_DIV : EPS_FOP_MOD);
+        }
+        return Push(EPS_FOP_PUSH_CONST, 0, 0.0);
+      default:
+        return Push(EPS_FOP_PUSH_CONST, 0, 0.0);   // NumEvaluate's `return 0.0`
+    }
+  }
+  // LogicalEvaluate (:170-258).  Children of AND / OR / NOT and boolean EQ / NE are evaluated WITHOUT the distance
+  // (LogicalEvaluate(child, cand) -> distance 0, :184, :207-208, :217-218).
+  void Logical(size_t i, bool dist) {
+    if (!Valid(i)) return Push(EPS_FOP_PUSH_CONST, 0, 0.0);
+    const ExprNode& n = *nodes[i];
+    switch (n.node_type) {
+      case NodeType::BoolConst: return Push(EPS_FOP_PUSH_CONST, 0, n.bool_value ? 1.0 : 0.0);
+      case NodeType::BoolAttr: return Push(EPS_FOP_PUSH_BOOL, Offset(n.field_name));
+      case NodeType::NOT:
+        Logical(n.left, false);
+        return Push(EPS_FOP_NOT);
+      case NodeType::IN:
+      case NodeType::LIKE:
+      case NodeType::FunctionCall:
+        host_only = true;
+        return Push(EPS_FOP_PUSH_CONST, 0, 0.0);
+      default: break;
+    }
+    if (n.left == (size_t)-1 || n.right == (size_t)-1 || !Valid(n.left) || !Valid(n.right)) return Push(EPS_FOP_PUSH_CONST, 0, 0.0);
+    switch (n.node_type) {
+      case NodeType::EQ:
+      case NodeType::NE: {
+        const auto vt = nodes[n.left]->value_type;
+        if (vt == vectordb::query::expr::ValueType::STRING) {
+          host_only = true;
+          return Push(EPS_FOP_PUSH_CONST, 0, 0.0);
+        }
+        if (vt == vectordb::query::expr::ValueType::BOOL) {
+          Logical(n.left, false);
+          Logical(n.right, false);
+          return Push(n.node_type == NodeType::EQ ? EPS_FOP_EQ_BOOL : EPS_FOP_NE_BOOL);
+        }
+        Num(n.left, dist);
+        Num(n.right, dist);
+        return Push(n.node_type == NodeType::EQ ? EPS_FOP_EQ : EPS_FOP_NE);
+      }
+      case NodeType::AND:
+      case NodeType::OR:
+        Logical(n.left, false);
+        Logical(n.right, false);
+        return Push(n.node_type == NodeType::AND ? EPS_FOP_AND : EPS_FOP_OR);
+      case NodeType::GT:
+      case NodeType::GTE:
+      case NodeType::LT:
+      case NodeType::LTE:
+        Num(n.left, dist);
+        Num(n.right, dist);
+        return Push(n.node_type == NodeType::GT ? EPS_FOP_GT : n.node_type == NodeType::GTE ? EPS_FOP_GE
+                    : n.node_type == NodeType::LT ? EPS_FOP_LT : EPS_FOP_LE);
+      default:
+        return Push(EPS_FOP_PUSH_CONST, 0, 0.0);   // LogicalEvaluate's `return false`
+    }
+  }
+};
 }  // namespace
 
 VecSearchExecutor::VecSearchExecutor(const int64_t dimension, const int64_t start_search_point,
@@ -145,10 +240,10 @@ VecSearchExecutor::~VecSearchExecutor() {}
 Status VecSearchExecutor::Search(const VectorPtr query_data, vectordb::engine::TableSegmentMVP* table_segment,
                                  const size_t limit, std::vector<ExprNodePtr>& filter_nodes, int64_t& result_size) {
   result_size = 0;
+  // TableMVP::Search discards the Status we return (table_mvp.cpp:372), so a failure must not look like "0 results":
+  // throw, as the constructors of the reference's own classes do on I/O failure.
   if (!std::holds_alternative<DenseVectorPtr>(query_data) || !std::holds_alternative<DenseVectorColumnDataContainer>(vector_column_))
-    return Status(NOT_IMPLEMENTED_ERROR, "sparse-vector search is not served by the gfx950 executor");
-  // TableMVP::Search discards the Status we return (table_mvp.cpp:372), so an infrastructure failure must not
-  // look like "0 results": throw, as the constructors of the reference's own classes do on I/O failure.
+    throw std::runtime_error("gfx950 executor: sparse-vector fields are not served by the device executor");
   if (!dev_) throw std::runtime_error("no usable gfx950 device (libepsilla_gfx950 has no CPU fallback)");
   if (limit == 0) return Status::OK();
   DeviceField& dev = *dev_;
@@ -182,53 +277,23 @@ Status VecSearchExecutor::Search(const VectorPtr query_data, vectordb::engine::T
   // ---- filter lowering
   ConcurrentBitset& deleted = *(table_segment->deleted_);
   const int root = static_cast<int>(filter_nodes.size()) - 1;
-  bool device_filter = false, host_mask = false;
-  if (root >= 0) {
-    const ExprNodePtr& r = filter_nodes[root];
-    if (r->node_type == NodeType::BoolConst && r->bool_value) {
-      // always true
-    } else {
-      const int op0 = CmpOp(r->node_type, false);
-      if (op0 != EPS_OP_NONE && r->left < filter_nodes.size() && r->right < filter_nodes.size()) {
-        const ExprNodePtr& a = filter_nodes[r->left];
-        const ExprNodePtr& b = filter_nodes[r->right];
-        const ExprNodePtr* attr = nullptr;
-        const ExprNodePtr* cst = nullptr;
-        bool flipped = false;
-        if (IsIntAttr(a->node_type) && b->node_type == NodeType::IntConst) {
-          attr = &a;
-          cst = &b;
-        } else if (IsIntAttr(b->node_type) && a->node_type == NodeType::IntConst) {
-          attr = &b;
-          cst = &a;
-          flipped = true;
-        }
-        if (attr) {
-          const auto off = table_segment->field_name_mem_offset_map_.find((*attr)->field_name);
-          if (off != table_segment->field_name_mem_offset_map_.end()) {
-            if (eps_index_set_int_filter(dev.h, table_segment->attribute_table_ + off->second, table_segment->primitive_offset_,
-                                         IntWidth((*attr)->node_type), CmpOp(r->node_type, flipped), (*cst)->int_value) != EPS_OK)
-              return fail("filter upload");
-            device_filter = true;
-          }
-        }
-      }
-      if (!device_filter) host_mask = true;
-    }
+  bool host_filter = false;
+  std::vector<eps_filter_op> program;
+  if (root >= 0 && !(filter_nodes[root]->node_type == NodeType::BoolConst && filter_nodes[root]->bool_value)) {
+    Compiler c{filter_nodes, table_segment};
+    c.Logical((size_t)root, true);
+    if (c.host_only || c.out.size() > 64) host_filter = true; else program.swap(c.out);
   }
-  if (!device_filter && eps_index_set_int_filter(dev.h, nullptr, 0, 0, EPS_OP_NONE, 0) != EPS_OK) return fail("filter reset");
-  if (host_mask) {
-    if (UsesDistance(filter_nodes))
-      return Status(NOT_IMPLEMENTED_ERROR, "@distance filters are not lowered to the gfx950 executor yet");
-    ExprEvaluator ev(filter_nodes, table_segment->field_name_mem_offset_map_, table_segment->primitive_offset_,
-                     table_segment->var_len_attr_num_, table_segment->attribute_table_, table_segment->var_len_attr_table_);
-    dev.mask.assign((size_t)(total_vector + 7) / 8, 0);
-    for (int64_t id = 0; id < total_vector; ++id)
-      if (deleted.test(id) || !ev.LogicalEvaluate(root, id)) dev.mask[id >> 3] |= uint8_t(1u << (id & 7));
-    if (eps_index_set_deleted(dev.h, dev.mask.data(), (int64_t)dev.mask.size()) != EPS_OK) return fail("mask upload");
-  } else {
-    if (eps_index_set_deleted(dev.h, deleted.data(), (int64_t)deleted.size()) != EPS_OK) return fail("deleted upload");
+  if (eps_index_set_int_filter(dev.h, nullptr, 0, 0, EPS_OP_NONE, 0) != EPS_OK) return fail("filter reset");
+  if (!program.empty()) {
+    // the attribute rows are handed over as they are: TableSegmentMVP::attribute_table_, primitive_offset_ bytes per row
+    if (eps_index_set_filter_program(dev.h, program.data(), (int32_t)program.size(), table_segment->attribute_table_,
+                                     table_segment->primitive_offset_, total_vector) != EPS_OK)
+      return fail("filter program upload");
+  } else if (eps_index_set_filter_program(dev.h, nullptr, 0, nullptr, 0, 0) != EPS_OK) {
+    return fail("filter reset");
   }
+  if (eps_index_set_deleted(dev.h, deleted.data(), (int64_t)deleted.size()) != EPS_OK) return fail("deleted upload");
 
   eps_search_params p;
   eps_default_search_params(&p);
@@ -238,21 +303,103 @@ Status VecSearchExecutor::Search(const VectorPtr query_data, vectordb::engine::T
   p.master_queue = L_master_;
   p.local_queue = L_local_;
   p.sync_interval = subsearch_iterations_;
-  const int32_t k = (int32_t)std::min<size_t>(limit, 1024);
-  std::vector<int64_t> ids((size_t)k);
-  std::vector<float> dist((size_t)k);
-  int32_t count = 0;
-  if (eps_index_search(dev.h, std::get<DenseVectorPtr>(query_data), 1, k, &p, ids.data(), dist.data(), &count) != EPS_OK)
-    return fail("search");
-  if ((size_t)count > search_result_.size()) {
-    search_result_.resize(count);
-    distance_.resize(count);
+  const bool flat = prefilter_enabled_ || brute_force_search_;
+  auto publish = [&](const int64_t* ids, const float* dist, int64_t count) {
+    if ((size_t)count > search_result_.size()) {
+      search_result_.resize(count);
+      distance_.resize(count);
+    }
+    for (int64_t i = 0; i < count; ++i) {
+      search_result_[i] = ids[i];
+      distance_[i] = dist[i];
+    }
+    result_size = count;
+  };
+
+  if (!host_filter) {
+    // result counts of the reference: PreFilter -> min(|res|, limit) (:856-858); small table -> additionally <= L_local (:864);
+    // graph -> min(n_indexed, limit, L_local) (:872)
+    size_t want = limit;
+    if (!prefilter_enabled_) want = std::min<size_t>(want, (size_t)std::max<int64_t>(L_local_, 1));
+    if (flat && want > 1024)
+      throw std::runtime_error("gfx950 executor: more than 1024 results per query from a brute-force search (PreFilter / tables below 512 indexed rows) are not supported");
+    const int32_t k = (int32_t)want;
+    std::vector<int64_t> ids((size_t)k);
+    std::vector<float> dist((size_t)k);
+    int32_t count = 0;
+    if (eps_index_search(dev.h, std::get<DenseVectorPtr>(query_data), 1, k, &p, ids.data(), dist.data(), &count) != EPS_OK)
+      return fail("search");
+    publish(ids.data(), dist.data(), count);
+    return Status::OK();
   }
-  for (int32_t i = 0; i < count; ++i) {
-    search_result_[i] = ids[i];
-    distance_[i] = dist[i];
+
+  // ---- host-evaluated predicate on the candidates of the reference's own walk
+  ExprEvaluator ev(filter_nodes, table_segment->field_name_mem_offset_map_, table_segment->primitive_offset_,
+                   table_segment->var_len_attr_num_, table_segment->attribute_table_, table_segment->var_len_attr_table_);
+  std::vector<int64_t> out_ids;
+  std::vector<float> out_dist;
+  if (!flat) {
+    // graph: walk the <= L_master candidates in order, stop at searchLimit (:905-927)
+    const int64_t K = std::min<int64_t>({total_indexed_vector_, (int64_t)limit, L_local_});
+    const int32_t cap = (int32_t)std::min<int64_t>(std::max<int64_t>(L_master_, K), (int64_t)1 << 20);
+    std::vector<int64_t> ids((size_t)cap);
+    std::vector<float> dist((size_t)cap);
+    int32_t count = 0;
+    if (eps_index_search_walk(dev.h, std::get<DenseVectorPtr>(query_data), 1, (int32_t)std::min<size_t>(limit, (size_t)1 << 20), cap, &p, ids.data(),
+                              dist.data(), &count) != EPS_OK)
+      return fail("search");
+    for (int32_t i = 0; i < count && (int64_t)out_ids.size() < K; ++i)
+      if (ev.LogicalEvaluate(root, ids[i], dist[i])) {
+        out_ids.push_back(ids[i]);
+        out_dist.push_back(dist[i]);
+      }
+    publish(out_ids.data(), out_dist.data(), (int64_t)out_ids.size());
+    return Status::OK();
   }
-  result_size = count;
+  // brute force (:717-831): the answer is the first `want` passing rows in (dist,id) order.  Fetch the closest candidates
+  // in growing portions and stop as soon as enough of them pass; a filter so selective that 1024 candidates do not
+  // suffice falls back to evaluating it on every row, which is what the reference does for every query.
+  size_t want = std::min<size_t>(limit, (size_t)total_vector);
+  if (!prefilter_enabled_) want = std::min<size_t>(want, (size_t)std::max<int64_t>(L_local_, 1));
+  for (int32_t cap = (int32_t)std::min<size_t>(1024, std::max<size_t>(64, 4 * want)); want <= 1024; cap = std::min(1024, cap * 4)) {
+    std::vector<int64_t> ids((size_t)cap);
+    std::vector<float> dist((size_t)cap);
+    int32_t count = 0;
+    if (eps_index_search_walk(dev.h, std::get<DenseVectorPtr>(query_data), 1, (int32_t)want, cap, &p, ids.data(), dist.data(), &count) != EPS_OK)
+      return fail("search");
+    out_ids.clear();
+    out_dist.clear();
+    for (int32_t i = 0; i < count && out_ids.size() < want; ++i)
+      if (prefilter_enabled_ ? ev.LogicalEvaluate(root, ids[i]) : ev.LogicalEvaluate(root, ids[i], dist[i])) {   // (:795 vs :751)
+        out_ids.push_back(ids[i]);
+        out_dist.push_back(dist[i]);
+      }
+    if (out_ids.size() >= want || count < cap) {   // enough passed, or the table has no more visible rows
+      publish(out_ids.data(), out_dist.data(), (int64_t)out_ids.size());
+      return Status::OK();
+    }
+    if (cap >= 1024) break;
+  }
+  if (want > 1024)
+    throw std::runtime_error("gfx950 executor: more than 1024 results per query from a brute-force search are not supported");
+  // selective host-only filter: visibility of every row, evaluated on the host (the reference's own cost, :746-755)
+  bool uses_distance = false;
+  for (auto& n : filter_nodes) uses_distance |= n && n->field_name == "@distance";
+  if (uses_distance && !prefilter_enabled_)
+    throw std::runtime_error("gfx950 executor: a selective filter that combines @distance with string / geo predicates on a brute-force search is not supported");
+  dev.mask.assign((size_t)(total_vector + 7) / 8, 0);
+  for (int64_t id = 0; id < total_vector; ++id)
+    if (deleted.test(id) || !ev.LogicalEvaluate(root, id)) dev.mask[id >> 3] |= uint8_t(1u << (id & 7));
+  if (eps_index_set_deleted(dev.h, dev.mask.data(), (int64_t)dev.mask.size()) != EPS_OK) return fail("mask upload");
+  {
+    const int32_t k = (int32_t)want;
+    std::vector<int64_t> ids((size_t)k);
+    std::vector<float> dist((size_t)k);
+    int32_t count = 0;
+    if (eps_index_search(dev.h, std::get<DenseVectorPtr>(query_data), 1, k, &p, ids.data(), dist.data(), &count) != EPS_OK)
+      return fail("search");
+    publish(ids.data(), dist.data(), count);
+  }
   return Status::OK();
 }
 
@@ -318,7 +465,14 @@ Status VecSearchExecutor::SearchBatched(const float* query, vectordb::engine::Ta
   Pending me;
   me.query = query;
   me.segment = table_segment;
-  me.k = (int32_t)std::min<size_t>(limit, 1024);
+  {
+    // same result-count rules as the unbatched path above
+    size_t want = limit;
+    if (!prefilter_enabled_) want = std::min<size_t>(want, (size_t)std::max<int64_t>(L_local_, 1));
+    if ((prefilter_enabled_ || brute_force_search_) && want > 1024)
+      throw std::runtime_error("gfx950 executor: more than 1024 results per query from a brute-force search (PreFilter / tables below 512 indexed rows) are not supported");
+    me.k = (int32_t)want;
+  }
   me.graph_owner = ann_index_.get();
   me.graph_n = total_indexed_vector_;
   me.start_point = start_search_point_;

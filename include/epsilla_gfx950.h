@@ -77,6 +77,43 @@ extern "C" {
 #define EPS_OP_GT 5
 #define EPS_OP_NE 6
 
+/* Compiled filter: a postfix program over the packed attribute row of a candidate
+ * (TableSegmentMVP::attribute_table_, rows of primitive_offset_ bytes), evaluated on a stack of doubles exactly as
+ * ExprEvaluator::NumEvaluate / LogicalEvaluate do (query/expr/expr_evaluator.cpp:127-258): every number is a double,
+ * comparisons and AND / OR / NOT produce 0 / 1, the row passes iff the final value is non-zero.  PUSH_* take `arg` = byte
+ * offset of the attribute inside the row; PUSH_CONST takes `dval`; PUSH_DIST is the candidate's distance (`@distance`). */
+#define EPS_FOP_PUSH_CONST 1
+#define EPS_FOP_PUSH_DIST 2
+#define EPS_FOP_PUSH_I8 3
+#define EPS_FOP_PUSH_I16 4
+#define EPS_FOP_PUSH_I32 5
+#define EPS_FOP_PUSH_I64 6
+#define EPS_FOP_PUSH_F32 7
+#define EPS_FOP_PUSH_F64 8
+#define EPS_FOP_PUSH_BOOL 9   /* true iff the byte is non-zero (expr_evaluator.cpp:56-59) */
+#define EPS_FOP_ADD 10
+#define EPS_FOP_SUB 11
+#define EPS_FOP_MUL 12
+#define EPS_FOP_DIV 13
+#define EPS_FOP_MOD 14        /* fmod */
+#define EPS_FOP_LT 15
+#define EPS_FOP_LE 16
+#define EPS_FOP_EQ 17
+#define EPS_FOP_NE 18
+#define EPS_FOP_GE 19
+#define EPS_FOP_GT 20
+#define EPS_FOP_AND 21
+#define EPS_FOP_OR 22
+#define EPS_FOP_NOT 23
+#define EPS_FOP_EQ_BOOL 24    /* EQ / NE between boolean operands (:206-209) */
+#define EPS_FOP_NE_BOOL 25
+typedef struct eps_filter_op {
+  int32_t op;
+  int32_t arg;
+  int64_t ival; /* reserved */
+  double dval;
+} eps_filter_op;
+
 typedef struct eps_index eps_index; /* opaque */
 
 /* Search knobs; mirror vectordb::Config (config/config.hpp:17-25) and the executor ctor arguments. */
@@ -147,6 +184,14 @@ int32_t eps_index_set_deleted(eps_index* h, const uint8_t* bits, int64_t nbytes)
 int32_t eps_index_set_int_filter(eps_index* h, const void* column, int64_t stride_bytes, int32_t width_bytes,
                                  int32_t op, int64_t constant);
 
+/* compiled filter program (see eps_filter_op): `rows` = packed attribute rows (host or device), row i at rows + i*stride_bytes,
+ * n_rows of them.  Replaces eps_index_set_int_filter's filter; nops = 0 clears.  A row is visible iff it is not deleted
+ * and the program leaves a non-zero value.  Programs are limited to 64 instructions and a stack depth of 16.  Host rows
+ * are treated as append-only (as TableSegmentMVP::attribute_table_ is): a later call with the same `rows` pointer and
+ * stride uploads only the rows beyond those already handed over. */
+int32_t eps_index_set_filter_program(eps_index* h, const eps_filter_op* ops, int32_t nops, const void* rows, int64_t stride_bytes,
+                                     int64_t n_rows);
+
 /* graph over rows [0,n): built on the device, or supplied / exported as the reference's CSR */
 int32_t eps_index_build(eps_index* h, int64_t n, const eps_build_params* p);
 int32_t eps_index_set_graph(eps_index* h, int64_t n, const int64_t* offsets, const int64_t* neighbors,
@@ -161,6 +206,14 @@ int32_t eps_index_load_graph(eps_index* h, const char* path);
  * COSINE queries must already be normalised (TableMVP::Search does it, table_mvp.cpp:333-349). */
 int32_t eps_index_search(eps_index* h, const float* queries, int64_t nq, int32_t k, const eps_search_params* p,
                          int64_t* ids_out, float* dist_out, int32_t* counts_out);
+/* The candidates the reference's post-filter loop walks (vec_search_executor.cpp:905-927), for filters that only the host
+ * DBMS can evaluate (strings, LIKE, IN, geo): same traversal / flat scan, same tail merge with searchLimit =
+ * min(n_indexed, limit, L_local) (:872-900), deleted rows and device-side filters already removed, in walk order; at most
+ * `cap` per query (cap >= limit).  ids_out [nq][cap], dist_out [nq][cap], counts_out [nq].  The caller applies its
+ * predicate to these <= cap candidates and keeps the first `limit` that pass - O(L) host work as in the reference,
+ * instead of O(N). */
+int32_t eps_index_search_walk(eps_index* h, const float* queries, int64_t nq, int32_t limit, int32_t cap, const eps_search_params* p,
+                              int64_t* ids_out, float* dist_out, int32_t* counts_out);
 int32_t eps_index_last_stats(const eps_index* h, eps_search_stats* out);
 /* main-kernel milliseconds (hipEvent pairs recorded on the index's stream) of the most recent search calls, oldest
  * first, at most min(cap, 64); synchronises the stream.  Returns the number written.  Lets a caller time a run of

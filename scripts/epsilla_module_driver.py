@@ -1,0 +1,82 @@
+#!/usr/bin/env python
+"""Drives an `epsilla` CPython module (the reference's own build under oracle/_ref/pymod, or the gfx950 drop-in build under
+dropin/_build) through the reference's binding API and prints one JSON document.  Run in a fresh process with the
+module directory first on sys.path:
+    python scripts/epsilla_module_driver.py MODULE_DIR DB_PATH cities|batch|c1 [rows] [dim] [queries]
+  cities  the fixture of engine/test/bindings/python/test.py (5 cities, 3 metrics, filter, duplicate PK, delete)
+  batch   rows x dim random table: query() one by one, then (drop-in only) rebuild() and query_batch()
+  c1      BASELINE configs[0]: rows x dim inserted through insert() in 1000-row JSON batches, `queries` query() calls"""
+import json
+import sys
+import time
+
+sys.path.insert(0, sys.argv[1])
+import numpy as np  # noqa: E402
+import epsilla  # noqa: E402
+
+db_path, what = sys.argv[2], sys.argv[3]
+rows = int(sys.argv[4]) if len(sys.argv) > 4 else 2000
+dim = int(sys.argv[5]) if len(sys.argv) > 5 else 32
+nq = int(sys.argv[6]) if len(sys.argv) > 6 else 64
+out = {"module": getattr(epsilla, "backend", "reference"), "file": epsilla.__file__}
+assert epsilla.load_db(db_name="db", db_path=db_path) == 0
+epsilla.use_db(db_name="db")
+
+if what == "cities":
+    epsilla.create_table(table_name="MyTable", table_fields=[
+        {"name": "ID", "dataType": "INT", "primaryKey": True}, {"name": "Doc", "dataType": "STRING"},
+        {"name": "EmbeddingEuclidean", "dataType": "VECTOR_FLOAT", "dimensions": 4, "metricType": "EUCLIDEAN"},
+        {"name": "EmbeddingDotProduct", "dataType": "VECTOR_FLOAT", "dimensions": 4, "metricType": "DOT_PRODUCT"},
+        {"name": "EmbeddingCosine", "dataType": "VECTOR_FLOAT", "dimensions": 4, "metricType": "COSINE"}])
+    cities = [(1, "Berlin", [0.05, 0.61, 0.76, 0.74]), (2, "London", [0.19, 0.81, 0.75, 0.11]), (3, "Moscow", [0.36, 0.55, 0.47, 0.94]),
+              (4, "San Francisco", [0.18, 0.01, 0.85, 0.80]), (5, "Shanghai", [0.24, 0.18, 0.22, 0.44]), (1, "Berlin", [0.05, 0.61, 0.76, 0.74])]
+    epsilla.insert(table_name="MyTable", records=[{"ID": i, "Doc": c, "EmbeddingEuclidean": v, "EmbeddingDotProduct": v, "EmbeddingCosine": v}
+                                                  for i, c, v in cities])
+    out["queries"] = {}
+    for field in ["EmbeddingEuclidean", "EmbeddingDotProduct", "EmbeddingCosine"]:
+        for flt in ("ID < 6", "", "ID >= 3", "Doc = 'Moscow' OR ID = 5", "NOT (ID < 3)"):
+            code, resp = epsilla.query(table_name="MyTable", query_field=field, response_fields=["ID", "Doc", field],
+                                       query_vector=[0.35, 0.55, 0.47, 0.94], filter=flt, limit=6, with_distance=True)
+            out["queries"]["%s|%s" % (field, flt)] = [code, resp]
+    out["delete"] = epsilla.delete(table_name="MyTable", primary_keys=[1, 2, 3, 4])
+    out["after_delete"] = epsilla.query(table_name="MyTable", query_field="EmbeddingEuclidean", response_fields=["ID", "Doc", "EmbeddingEuclidean"],
+                                        query_vector=[0.35, 0.55, 0.47, 0.94], filter="ID < 6", limit=10, with_distance=True)
+    out["drop"] = epsilla.drop_table("MyTable")
+else:
+    rng = np.random.default_rng(42)
+    X = rng.random((rows, dim), dtype=np.float32)
+    Q = np.random.default_rng(43).random((nq, dim), dtype=np.float32)
+    epsilla.create_table(table_name="T", table_fields=[{"name": "ID", "dataType": "INT", "primaryKey": True},
+                                                       {"name": "V", "dataType": "VECTOR_FLOAT", "dimensions": dim, "metricType": "EUCLIDEAN"}])
+    t0 = time.perf_counter()
+    for s in range(0, rows, 1000):
+        assert epsilla.insert(table_name="T", records=[{"ID": int(i), "V": X[i].tolist()} for i in range(s, min(rows, s + 1000))]) == 0
+    out["insert_s"] = time.perf_counter() - t0
+
+    def one_by_one():
+        lat, res = [], []
+        t0 = time.perf_counter()
+        for q in Q:
+            t1 = time.perf_counter()
+            code, resp = epsilla.query(table_name="T", query_field="V", response_fields=["ID"], query_vector=q.tolist(), filter="", limit=10,
+                                       with_distance=True)
+            lat.append(time.perf_counter() - t1)
+            res.append([[r["ID"] for r in resp], [r["@distance"] for r in resp]])
+        return time.perf_counter() - t0, lat, res
+
+    one_by_one() if what == "c1" and nq <= 16 else None
+    sec, lat, res = one_by_one()
+    out["flat"] = {"qps": nq / sec, "p50_ms": 1e3 * float(np.median(lat)), "p99_ms": 1e3 * float(np.percentile(lat, 99)), "results": res}
+    if hasattr(epsilla, "rebuild"):
+        t0 = time.perf_counter()
+        out["rebuild_code"] = epsilla.rebuild()
+        out["rebuild_s"] = time.perf_counter() - t0
+        sec, lat, res = one_by_one()
+        out["graph"] = {"qps": nq / sec, "p50_ms": 1e3 * float(np.median(lat)), "results": res}
+        t0 = time.perf_counter()
+        code, resp = epsilla.query_batch(table_name="T", query_field="V", query_vectors=[q.tolist() for q in Q], response_fields=["ID"], limit=10,
+                                         filter="", with_distance=True)
+        sec = time.perf_counter() - t0
+        out["query_batch"] = {"code": code, "qps": nq / sec, "results": [[[r["ID"] for r in rr], [r["@distance"] for r in rr]] for rr in resp]}
+    epsilla.drop_table("T")
+print("EPSILLA_JSON " + json.dumps(out))

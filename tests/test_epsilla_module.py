@@ -1,0 +1,95 @@
+"""The `epsilla` CPython module (SURVEY 8b "Python-module ABI").  oracle/_ref/pymod/epsilla.so is the reference's own binding
+over the reference engine; dropin/_build/epsilla.so is the SAME binding source (bindings/python/interface.cpp, unmodified)
+over this repository's executor + libepsilla_gfx950.so, plus the additive rebuild() / query_batch().  Each module runs in its
+own process (both are called `epsilla`)."""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_DIR = os.path.join(ROOT, "oracle", "_ref", "pymod")
+GPU_DIR = os.path.join(ROOT, "dropin", "_build")
+DRIVER = os.path.join(ROOT, "scripts", "epsilla_module_driver.py")
+GOLDEN = os.path.join(ROOT, "tests", "golden", "epsilla_module_cities.json")
+
+
+def _run(module_dir, what, *args):
+    db = os.path.join(tempfile.mkdtemp(), "db")
+    r = subprocess.run([sys.executable, DRIVER, module_dir, db, what] + [str(a) for a in args], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = [l for l in r.stdout.splitlines() if l.startswith("EPSILLA_JSON ")][-1]
+    return json.loads(line[len("EPSILLA_JSON "):])
+
+
+def _have(d):
+    return os.path.exists(os.path.join(d, "epsilla.so"))
+
+
+def _same_rows(a, b, rtol=1e-4):
+    assert a[0] == b[0] == 0
+    assert [r["ID"] for r in a[1]] == [r["ID"] for r in b[1]], (a, b)
+    assert [r["Doc"] for r in a[1]] == [r["Doc"] for r in b[1]]
+    assert np.allclose([r["@distance"] for r in a[1]], [r["@distance"] for r in b[1]], rtol=rtol, atol=1e-7)
+
+
+@pytest.mark.ref
+def test_reference_module_reproduces_the_survey_anchors():
+    """the reference's own module on the fixture of engine/test/bindings/python/test.py: squared L2, negative dot, 1 - dot on
+    stored-normalised rows; after delete([1,2,3,4]) only Shanghai is left.  Also refreshes nothing: the committed golden must
+    equal what the reference returns here."""
+    if not _have(REF_DIR):
+        pytest.skip("oracle/_ref/pymod/epsilla.so not built (make -C oracle pymod)")
+    out = _run(REF_DIR, "cities")
+    q = out["queries"]
+    top = q["EmbeddingEuclidean|ID < 6"][1][0]
+    assert top["Doc"] == "Moscow" and abs(top["@distance"] - 1.0000040e-4) < 1e-9
+    assert abs(q["EmbeddingDotProduct|ID < 6"][1][0]["@distance"] + 1.5329999924) < 1e-6
+    assert abs(q["EmbeddingCosine|ID < 6"][1][0]["@distance"] - 2.99e-5) < 1e-6
+    assert [r["Doc"] for r in out["after_delete"][1]] == ["Shanghai"] and abs(out["after_delete"][1][0]["@distance"] - 0.46149999) < 1e-6
+    gold = json.load(open(GOLDEN))
+    for key in gold["queries"]:
+        _same_rows(q[key], gold["queries"][key], rtol=1e-6)
+
+
+@pytest.mark.gpu
+def test_gfx950_module_answers_like_the_reference_module():
+    """same binding source over the MI355X executor: identical rows / order / distances for every metric and filter of the
+    fixture (golden = the reference module's answers), incl. string and OR / NOT filters and the delete."""
+    if not _have(GPU_DIR):
+        pytest.skip("dropin/_build/epsilla.so not built (make -C dropin)")
+    out = _run(GPU_DIR, "cities")
+    assert out["module"] == "gfx950"
+    gold = json.load(open(GOLDEN))
+    for key in gold["queries"]:
+        _same_rows(out["queries"][key], gold["queries"][key])
+    _same_rows(out["after_delete"], gold["after_delete"])
+    assert out["delete"] == gold["delete"] == 0
+    if _have(REF_DIR):   # side by side on this box as well
+        ref = _run(REF_DIR, "cities")
+        for key in ref["queries"]:
+            _same_rows(out["queries"][key], ref["queries"][key])
+
+
+@pytest.mark.gpu
+def test_gfx950_module_rebuild_and_query_batch():
+    """additive entry points: rebuild() builds the graph on the device through the unchanged DBServer::Rebuild; query_batch()
+    returns what N query() calls return.  3000 x 32: the flat answers equal the reference module's, the graph answers (T = 4,
+    L = 500 on 3000 rows: everything is evaluated) equal the flat ones."""
+    if not _have(GPU_DIR):
+        pytest.skip("dropin/_build/epsilla.so not built (make -C dropin)")
+    out = _run(GPU_DIR, "batch", 3000, 32, 48)
+    assert out["rebuild_code"] == 0 and out["query_batch"]["code"] == 0
+    flat, graph, qb = out["flat"]["results"], out["graph"]["results"], out["query_batch"]["results"]
+    for i in range(len(flat)):
+        assert flat[i][0] == graph[i][0] == qb[i][0], i
+        assert np.allclose(flat[i][1], qb[i][1], rtol=1e-5)
+    if _have(REF_DIR):
+        ref = _run(REF_DIR, "batch", 3000, 32, 48)
+        for i in range(len(flat)):
+            assert flat[i][0] == ref["flat"]["results"][i][0], i
+            assert np.allclose(flat[i][1], ref["flat"]["results"][i][1], rtol=1e-4)

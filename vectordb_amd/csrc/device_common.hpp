@@ -19,14 +19,30 @@ using u32 = unsigned int;
 
 constexpr u64 KEY_EMPTY = ~0ull;
 
-struct FilterSpec {            // `int column <op> constant` + deleted bitset (device pointers)
+// One instruction of a compiled filter (eps_filter_op in include/epsilla_gfx950.h): a postfix program over the packed
+// attribute row of a candidate, evaluated on a small stack of doubles exactly as ExprEvaluator::NumEvaluate /
+// LogicalEvaluate do (query/expr/expr_evaluator.cpp:127-258: every number is a double, booleans are 0 / 1).
+struct FilterOp {
+  int32_t op;     // EPS_FOP_*
+  int32_t arg;    // byte offset inside the attribute row (attribute loads)
+  int64_t ival;
+  double dval;    // constant
+};
+
+struct FilterSpec {            // deleted bitset + `int column <op> constant` or a compiled program (device pointers)
   const uint8_t* deleted;      // may be null
   const uint8_t* column;       // may be null
   int64_t stride;
   int32_t width;
   int32_t op;                  // EPS_OP_*
   int64_t value;
+  const FilterOp* prog;        // may be null: compiled filter program over rows of `prog_stride` bytes at `prog_rows`
+  const uint8_t* prog_rows;
+  int64_t prog_stride;
+  int32_t prog_len;
+  int32_t prog_use_dist;       // 0: @distance evaluates to 0 (PreFilterBruteForceSearch, :795)
 };
+__host__ __device__ inline FilterSpec no_filter() { return FilterSpec{nullptr, nullptr, 0, 0, 0, 0, nullptr, nullptr, 0, 0, 0}; }
 
 __device__ __forceinline__ int lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
@@ -56,7 +72,63 @@ __device__ __forceinline__ u64 shfl_up64(u64 v, int d) {
   return ((u64)hi << 32) | lo;
 }
 
-__device__ __forceinline__ bool row_visible(const FilterSpec& f, u32 id) {
+// EPS_FOP_* opcodes (mirrored in include/epsilla_gfx950.h)
+enum : int32_t {
+  FOP_PUSH_CONST = 1, FOP_PUSH_DIST = 2, FOP_PUSH_I8 = 3, FOP_PUSH_I16 = 4, FOP_PUSH_I32 = 5, FOP_PUSH_I64 = 6, FOP_PUSH_F32 = 7,
+  FOP_PUSH_F64 = 8, FOP_PUSH_BOOL = 9, FOP_ADD = 10, FOP_SUB = 11, FOP_MUL = 12, FOP_DIV = 13, FOP_MOD = 14, FOP_LT = 15, FOP_LE = 16,
+  FOP_EQ = 17, FOP_NE = 18, FOP_GE = 19, FOP_GT = 20, FOP_AND = 21, FOP_OR = 22, FOP_NOT = 23, FOP_EQ_BOOL = 24, FOP_NE_BOOL = 25
+};
+
+__device__ inline bool eval_filter_program(const FilterSpec& f, u32 id, float dist) {
+  double st[16];
+  int sp = 0;
+  const uint8_t* row = f.prog_rows + (int64_t)id * f.prog_stride;
+  for (int i = 0; i < f.prog_len; ++i) {
+    const FilterOp o = f.prog[i];
+    if (o.op <= FOP_PUSH_BOOL) {
+      double v = 0.0;
+      switch (o.op) {
+        case FOP_PUSH_CONST: v = o.dval; break;
+        case FOP_PUSH_DIST: v = f.prog_use_dist ? (double)dist : 0.0; break;
+        case FOP_PUSH_I8: v = (double)*(const int8_t*)(row + o.arg); break;
+        case FOP_PUSH_I16: v = (double)*(const int16_t*)(row + o.arg); break;
+        case FOP_PUSH_I32: v = (double)*(const int32_t*)(row + o.arg); break;
+        case FOP_PUSH_I64: v = (double)*(const int64_t*)(row + o.arg); break;
+        case FOP_PUSH_F32: v = (double)*(const float*)(row + o.arg); break;
+        case FOP_PUSH_F64: v = *(const double*)(row + o.arg); break;
+        case FOP_PUSH_BOOL: v = row[o.arg] != 0 ? 1.0 : 0.0; break;   // "true iff byte != 0" (expr_evaluator.cpp:56-59)
+      }
+      if (sp < 16) st[sp++] = v;
+    } else if (o.op == FOP_NOT) {
+      if (sp >= 1) st[sp - 1] = st[sp - 1] != 0.0 ? 0.0 : 1.0;
+    } else if (sp >= 2) {
+      const double b = st[--sp], a = st[sp - 1];
+      double r = 0.0;
+      switch (o.op) {
+        case FOP_ADD: r = a + b; break;
+        case FOP_SUB: r = a - b; break;
+        case FOP_MUL: r = a * b; break;
+        case FOP_DIV: r = a / b; break;
+        case FOP_MOD: r = fmod(a, b); break;
+        case FOP_LT: r = a < b; break;
+        case FOP_LE: r = a <= b; break;
+        case FOP_EQ: r = a == b; break;
+        case FOP_NE: r = a != b; break;
+        case FOP_GE: r = a >= b; break;
+        case FOP_GT: r = a > b; break;
+        case FOP_AND: r = (a != 0.0) && (b != 0.0); break;
+        case FOP_OR: r = (a != 0.0) || (b != 0.0); break;
+        case FOP_EQ_BOOL: r = (a != 0.0) == (b != 0.0); break;
+        case FOP_NE_BOOL: r = (a != 0.0) != (b != 0.0); break;
+      }
+      st[sp - 1] = r;
+    }
+  }
+  return sp >= 1 && st[0] != 0.0;
+}
+
+// deleted_.test(id) || !LogicalEvaluate(root, id, dist)  (vec_search_executor.cpp:751, :911): dist is the candidate's distance
+__device__ __forceinline__ bool row_visible(const FilterSpec& f, u32 id, float dist = 0.f) {
   if (f.deleted && ((f.deleted[id >> 3] >> (id & 7)) & 1)) return false;
   if (f.op && f.column) {
     const uint8_t* p = f.column + (int64_t)id * f.stride;
@@ -76,6 +148,7 @@ __device__ __forceinline__ bool row_visible(const FilterSpec& f, u32 id) {
       case 6: return v != f.value;
     }
   }
+  if (f.prog) return eval_filter_program(f, id, dist);
   return true;
 }
 

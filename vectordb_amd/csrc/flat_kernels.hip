@@ -20,7 +20,7 @@ __device__ __forceinline__ void offer(WaveTopK<KPL> (&list)[NQ], u64 (&thr)[NQ],
     const int l = __ffsll((long long)m) - 1;
     m &= m - 1;
     const u64 x = shfl64(key, l);
-    if (x < thr[q] && row_visible(f, key_id(x))) {
+    if (x < thr[q] && row_visible(f, key_id(x), key_dist(x))) {
       if (unique) list[q].insert_unique(x); else list[q].insert(x);
       const u64 kth = list[q].entry(k - 1);
       thr[q] = kth < thr[q] ? kth : thr[q];
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void merge_lists_kernel(const u64* partial, in
   for (int i = threadIdx.x; i < rounded; i += 256) {
     const u64 key = i < total ? src[i] : KEY_EMPTY;
     if (id_stride) {   // seed selection over a SAMPLE: entry ids are sample indices (seed_row maps them to rows)
-      const bool ok = key != KEY_EMPTY && row_visible(vis, seed_row(key_id(key), id_head, id_stride));
+      const bool ok = key != KEY_EMPTY && row_visible(vis, seed_row(key_id(key), id_head, id_stride), key_dist(key));
       offer<1, KPL>(L, thr, 0, key, ok, nof, k, false);
     } else {
       offer<1, KPL>(L, thr, 0, key, key != KEY_EMPTY, vis, k, false);   // vis: only rows the filter lets through
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void merge_lists_kernel(const u64* partial, in
 
 void launch_merge_lists(const u64* partial, int lists, int k, int64_t nq, u64* run_keys, bool merge_run, hipStream_t s,
                         const u32* counts, const FilterSpec* visible, u64 id_stride, u32 id_head) {
-  const FilterSpec vis = visible ? *visible : FilterSpec{nullptr, nullptr, 0, 0, 0, 0};
+  const FilterSpec vis = visible ? *visible : no_filter();
   if (nq <= 0) return;
   const int kpl = pick_kpl(k);
 #define EPS_CASE(KPL_) \

@@ -254,14 +254,94 @@ int32_t Index::set_int_filter(const void* column, int64_t stride, int32_t width,
   return EPS_OK;
 }
 
+int32_t Index::set_filter_program(const eps_filter_op* ops, int32_t nops, const void* rows, int64_t stride, int64_t n_rows) {
+  HIP_TRY(hipSetDevice(device_));
+  if (nops <= 0 || !ops) {
+    prog_len_ = 0;
+    d_prog_rows_ = nullptr;
+    prog_uses_dist_ = false;
+    return EPS_OK;
+  }
+  if (nops > 64) return fail(EPS_DB_UNSUPPORTED_ERROR, "set_filter_program: more than 64 instructions");
+  if (!rows || stride <= 0 || n_rows < n_rows_) return fail(EPS_USER_ERROR, "set_filter_program: attribute rows missing or shorter than the table");
+  // validate: known opcodes, attribute loads inside a row, stack discipline
+  int sp = 0, maxsp = 0;
+  bool uses_dist = false;
+  for (int i = 0; i < nops; ++i) {
+    const int op = ops[i].op;
+    if (op < EPS_FOP_PUSH_CONST || op > EPS_FOP_NE_BOOL) return fail(EPS_USER_ERROR, "set_filter_program: unknown opcode");
+    if (op <= EPS_FOP_PUSH_BOOL) {
+      static const int width[] = {0, 0, 0, 1, 2, 4, 8, 4, 8, 1};
+      if (op >= EPS_FOP_PUSH_I8 && (ops[i].arg < 0 || ops[i].arg + width[op] > stride))
+        return fail(EPS_USER_ERROR, "set_filter_program: attribute offset outside the row");
+      uses_dist |= op == EPS_FOP_PUSH_DIST;
+      ++sp;
+    } else if (op == EPS_FOP_NOT) {
+      if (sp < 1) return fail(EPS_USER_ERROR, "set_filter_program: stack underflow");
+    } else {
+      if (sp < 2) return fail(EPS_USER_ERROR, "set_filter_program: stack underflow");
+      --sp;
+    }
+    maxsp = std::max(maxsp, sp);
+  }
+  if (sp != 1 || maxsp > 16) return fail(EPS_USER_ERROR, "set_filter_program: the program must leave exactly one value (stack depth <= 16)");
+  HIP_TRY(hipStreamSynchronize(stream_));
+  if (!prog_buf_.reserve((size_t)nops * sizeof(FilterOp))) return fail(EPS_INFRA_UNEXPECTED_ERROR, "set_filter_program: out of device memory");
+  static_assert(sizeof(FilterOp) == sizeof(eps_filter_op), "FilterOp mirrors eps_filter_op");
+  HIP_TRY(hipMemcpyAsync(prog_buf_.p, ops, (size_t)nops * sizeof(FilterOp), hipMemcpyHostToDevice, stream_));
+  if (is_device_ptr(rows)) {
+    d_prog_rows_ = static_cast<const uint8_t*>(rows);
+    prog_rows_host_ = nullptr;
+  } else {
+    // Host attribute rows are append-only in the reference (an update is delete + insert, table_segment_mvp.cpp:476-587), so
+    // rows handed over earlier from the same table are kept and only the new tail crosses PCIe.
+    const size_t bytes = (size_t)n_rows * (size_t)stride;
+    const bool same = prog_rows_host_ == rows && prog_rows_stride_ == stride && prog_rows_uploaded_ <= n_rows && prog_rows_buf_.p;
+    size_t have = same ? (size_t)prog_rows_uploaded_ * (size_t)stride : 0;
+    if (bytes > prog_rows_buf_.cap) {
+      DevBuf bigger;
+      if (!bigger.reserve(bytes + bytes / 2 + 16)) return fail(EPS_INFRA_UNEXPECTED_ERROR, "set_filter_program: out of device memory");
+      if (have) HIP_TRY(hipMemcpyAsync(bigger.p, prog_rows_buf_.p, have, hipMemcpyDeviceToDevice, stream_));
+      HIP_TRY(hipStreamSynchronize(stream_));
+      prog_rows_buf_.release();
+      prog_rows_buf_.p = bigger.p;
+      prog_rows_buf_.cap = bigger.cap;
+      bigger.p = nullptr;
+      bigger.cap = 0;
+    }
+    if (bytes > have)
+      HIP_TRY(hipMemcpyAsync(static_cast<char*>(prog_rows_buf_.p) + have, static_cast<const char*>(rows) + have, bytes - have, hipMemcpyHostToDevice, stream_));
+    d_prog_rows_ = prog_rows_buf_.as<uint8_t>();
+    prog_rows_host_ = rows;
+    prog_rows_stride_ = stride;
+    prog_rows_uploaded_ = n_rows;
+  }
+  HIP_TRY(hipStreamSynchronize(stream_));
+  prog_stride_ = stride;
+  prog_rows_n_ = n_rows;
+  prog_len_ = nops;
+  prog_uses_dist_ = uses_dist;
+  f_op_ = 0;   // replaces the single-comparison filter
+  d_fcol_ = nullptr;
+  fcol_rows_ = 0;
+  return EPS_OK;
+}
+
 FilterSpec Index::filter_spec() const {
-  FilterSpec f;
+  FilterSpec f = no_filter();
   f.deleted = d_deleted_;
   f.column = f_op_ ? d_fcol_ : nullptr;
   f.stride = f_stride_;
   f.width = f_width_;
   f.op = f_op_;
   f.value = f_value_;
+  if (prog_len_ > 0 && d_prog_rows_) {
+    f.prog = prog_buf_.as<FilterOp>();
+    f.prog_rows = d_prog_rows_;
+    f.prog_stride = prog_stride_;
+    f.prog_len = prog_len_;
+    f.prog_use_dist = prefilter_call_ ? 0 : 1;   // PreFilterBruteForceSearch evaluates the filter without a distance (:795)
+  }
   return f;
 }
 
@@ -380,7 +460,7 @@ int32_t Index::flat_stream(const float* dq, int64_t nq, int k, int64_t row_begin
   a.nq = nq;
   a.k = k;
   a.f = filter_spec();
-  if (!filtered) a.f = FilterSpec{nullptr, nullptr, 0, 0, 0, 0};
+  if (!filtered) a.f = no_filter();
   a.partial = partial_buf_.as<u64>();
   a.W = W;
   a.thr_in = nullptr;
@@ -397,13 +477,15 @@ int32_t Index::flat_stream(const float* dq, int64_t nq, int k, int64_t row_begin
 }
 
 int32_t Index::search(const float* queries, int64_t nq, int32_t k, const eps_search_params* pp, int64_t* ids,
-                      float* dist, int32_t* counts) {
+                      float* dist, int32_t* counts, int32_t walk_limit) {
   eps_search_params p;
   if (pp) p = *pp; else eps_default_search_params(&p);
+  walk_limit_ = walk_limit;
+  prefilter_call_ = p.prefilter != 0;
   if (nq < 0 || k <= 0) return fail(EPS_USER_ERROR, "search: nq must be >= 0 and k > 0");
   if (nq == 0) return EPS_OK;
   if (!queries || !ids || !dist) return fail(EPS_USER_ERROR, "search: null buffer");
-  if (k > 1024) return fail(EPS_DB_UNSUPPORTED_ERROR, "search: k > 1024 is not supported");
+  if (k > (1 << 20)) return fail(EPS_DB_UNSUPPORTED_ERROR, "search: k > 1048576 is not supported");
   if (p.master_queue <= 0 || p.local_queue <= 0 || p.sync_interval <= 0 || p.intra_threads <= 0)
     return fail(EPS_USER_ERROR, "search: queue sizes, sync interval and thread count must be positive");
   HIP_TRY(hipSetDevice(device_));
@@ -412,6 +494,8 @@ int32_t Index::search(const float* queries, int64_t nq, int32_t k, const eps_sea
     return fail(EPS_USER_ERROR, "search: the deleted bitset is shorter than the table (rows were appended): call set_deleted again");
   if (f_op_ && d_fcol_ && fcol_rows_ < n_rows_)
     return fail(EPS_USER_ERROR, "search: the filter column is shorter than the table (rows were appended): call set_int_filter again");
+  if (prog_len_ > 0 && prog_rows_n_ < n_rows_)
+    return fail(EPS_USER_ERROR, "search: the filter program's attribute rows are shorter than the table (rows were appended): call set_filter_program again");
   kring_seq_ += 1;
   {
     const int slot = (int)(kring_seq_ % KRING);
@@ -442,12 +526,14 @@ int32_t Index::search(const float* queries, int64_t nq, int32_t k, const eps_sea
       mode = EPS_MODE_FLAT;
     } else if (n_indexed_ < 512) {  // BruteforceThreshold, vec_search_executor.hpp:28
       mode = EPS_MODE_FLAT;
-      cap_local = true;  // result_size = min(size, limit, L_local_)  (:864)
+      cap_local = walk_limit == 0;  // result_size = min(size, limit, L_local_)  (:864); a candidate walk is cut by its caller
     } else {
       mode = EPS_MODE_GRAPH;
     }
   }
   if (mode == EPS_MODE_GRAPH && n_indexed_ <= 0) return fail(EPS_USER_ERROR, "search: graph mode requested but no graph is set");
+  if (mode == EPS_MODE_FLAT && k > 1024)
+    return fail(EPS_DB_UNSUPPORTED_ERROR, "search: more than 1024 results per query from a flat scan are not supported (the per-wavefront top-k lists hold 1024 entries)");
 
   if (!run_buf_.reserve((size_t)nq * k * sizeof(u64))) return fail(EPS_INFRA_UNEXPECTED_ERROR, "search: out of device memory (results)");
   u64* run_keys = run_buf_.as<u64>();
@@ -459,6 +545,9 @@ int32_t Index::search(const float* queries, int64_t nq, int32_t k, const eps_sea
     if (keff < k) launch_fill_u64(run_keys, nq * k, KEY_EMPTY, stream_);
     int engine = p.flat_engine;
     if (engine == EPS_FLAT_AUTO) engine = flat_mfma_profitable(*this, nq, keff) ? EPS_FLAT_MFMA : EPS_FLAT_STREAM;
+    // a filter on @distance needs exact distances wherever it is evaluated; the MFMA engine selects its seeds on
+    // approximate keys, so such searches stay on the exact stream engine
+    if (prog_len_ > 0 && prog_uses_dist_ && !prefilter_call_) engine = EPS_FLAT_STREAM;
     int32_t rc;
     if (keff == k) {
       rc = engine == EPS_FLAT_MFMA ? flat_mfma_search(*this, dq, nq, k, run_keys)
@@ -476,7 +565,7 @@ int32_t Index::search(const float* queries, int64_t nq, int32_t k, const eps_sea
     if (rc != EPS_OK) return rc;
   } else {
     int64_t evals = 0;
-    int32_t rc = graph_search(*this, dq, nq, k, p, run_keys, &evals);
+    int32_t rc = graph_search(*this, dq, nq, k, p, run_keys, &evals, walk_limit);
     if (rc != EPS_OK) return rc;
   }
   (void)limit;
@@ -614,6 +703,14 @@ int32_t eps_index_set_id_map(eps_index* h, int64_t b, int64_t s) { GUARD(h, IX(h
 int32_t eps_index_set_deleted(eps_index* h, const uint8_t* bits, int64_t nbytes) { GUARD(h, IX(h)->set_deleted(bits, nbytes)); }
 int32_t eps_index_set_int_filter(eps_index* h, const void* col, int64_t stride, int32_t width, int32_t op, int64_t c) {
   GUARD(h, IX(h)->set_int_filter(col, stride, width, op, c));
+}
+int32_t eps_index_set_filter_program(eps_index* h, const eps_filter_op* ops, int32_t nops, const void* rows, int64_t stride, int64_t n_rows) {
+  GUARD(h, IX(h)->set_filter_program(ops, nops, rows, stride, n_rows));
+}
+int32_t eps_index_search_walk(eps_index* h, const float* q, int64_t nq, int32_t limit, int32_t cap, const eps_search_params* p, int64_t* ids,
+                              float* dist, int32_t* counts) {
+  if (limit <= 0 || cap < limit) return EPS_USER_ERROR;
+  GUARD(h, IX(h)->search(q, nq, cap, p, ids, dist, counts, limit));
 }
 int32_t eps_index_build(eps_index* h, int64_t n, const eps_build_params* p) { GUARD(h, IX(h)->build(n, p)); }
 int32_t eps_index_set_graph(eps_index* h, int64_t n, const int64_t* off, const int64_t* nbr, int64_t nav) {

@@ -41,14 +41,16 @@ class Index {
   int32_t set_id_map(int64_t base, int64_t stride);
   int32_t set_deleted(const uint8_t* bits, int64_t nbytes);
   int32_t set_int_filter(const void* column, int64_t stride, int32_t width, int32_t op, int64_t constant);
+  int32_t set_filter_program(const eps_filter_op* ops, int32_t nops, const void* rows, int64_t stride, int64_t n_rows);
   int32_t build(int64_t n, const eps_build_params* p);
   int32_t set_graph(int64_t n, const int64_t* off, const int64_t* nbr, int64_t nav);
   int32_t graph_info(int64_t* n, int64_t* edges, int64_t* nav) const;
   int32_t get_graph(int64_t* off, int64_t* nbr) const;
   int32_t save_graph(const char* path);
   int32_t load_graph(const char* path);
+  // walk_limit > 0: candidate-walk form (eps_index_search_walk): k = cap, the tail merge uses searchLimit(walk_limit)
   int32_t search(const float* queries, int64_t nq, int32_t k, const eps_search_params* p, int64_t* ids, float* dist,
-                 int32_t* counts);
+                 int32_t* counts, int32_t walk_limit = 0);
 
   int64_t row_count() const { return n_rows_; }
   const char* last_error() const { return err_.c_str(); }
@@ -86,6 +88,15 @@ class Index {
   int64_t f_stride_ = 0;
   int32_t f_width_ = 0, f_op_ = 0;
   int64_t f_value_ = 0;
+  DevBuf prog_buf_, prog_rows_buf_;   // compiled filter program + (when handed over from the host) the attribute rows
+  const uint8_t* d_prog_rows_ = nullptr;
+  const void* prog_rows_host_ = nullptr;   // host table the cached device copy mirrors (append-only)
+  int64_t prog_rows_stride_ = 0, prog_rows_uploaded_ = 0;
+  int64_t prog_stride_ = 0, prog_rows_n_ = 0;
+  int32_t prog_len_ = 0;
+  bool prog_uses_dist_ = false;
+  int32_t walk_limit_ = 0;            // of the search call in progress
+  bool prefilter_call_ = false;
 
   // graph (reference layout kept on the host for get/save; device form in GraphDev)
   int64_t n_indexed_ = 0;
@@ -118,7 +129,7 @@ class Index {
   friend int32_t flat_mfma_search(Index&, const float*, int64_t, int, u64*, bool);
   friend int32_t flat_mfma_search_slice(Index&, const float*, int64_t, int, u64*, bool, int);
   friend int32_t graph_build(Index&, int64_t, const eps_build_params&);
-  friend int32_t graph_search(Index&, const float*, int64_t, int, const eps_search_params&, u64*, int64_t*);
+  friend int32_t graph_search(Index&, const float*, int64_t, int, const eps_search_params&, u64*, int64_t*, int);
 };
 
 // engines implemented in their own translation units
@@ -131,7 +142,7 @@ int32_t graph_upload(Index& ix);
 void graph_free(GraphDev* g);
 // writes result keys [nq][k] and counts
 int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_search_params& p, u64* run_keys,
-                     int64_t* evals);
+                     int64_t* evals, int walk_limit = 0);
 int32_t graph_build(Index& ix, int64_t n, const eps_build_params& p);
 
 bool is_device_ptr(const void* p);

@@ -109,9 +109,11 @@ static void prepare_init_ids(const Index& ix, int64_t L, std::vector<u32>& out) 
 struct PostArgs {
   const u64* queue;   // [nq][L] traversal keys (id<<1|checked)
   int L;
-  const u64* tail;    // [nq][k] flat-scan keys of the un-indexed tail (plain id), or null
-  int k;              // output width (= limit)
-  int K;              // searchLimit = min(n_indexed, limit, L_local)
+  const u64* tail;    // [nq][tail_k] flat-scan keys of the un-indexed tail (plain id), or null
+  int tail_k;
+  int k;              // output width
+  int K;              // searchLimit = min(n_indexed, limit, L_local): slots that take part in the tail merge
+  int Kout;           // results wanted per query (= K for Search(); the whole walk for eps_index_search_walk)
   int cand_num_tail;  // min(L_master, n_total)
   int cand_num;       // min(L_master, n_indexed)
   FilterSpec f;
@@ -136,9 +138,9 @@ __global__ __launch_bounds__(64) void post_kernel(PostArgs a) {
   if (lane == 0) s_cand = a.cand_num;
   __syncthreads();
   if (a.tail && lane == 0) {
-    const u64* bf = a.tail + q * a.k;
+    const u64* bf = a.tail + q * a.tail_k;
     int n2 = 0;
-    while (n2 < a.k && bf[n2] != KEY_EMPTY) ++n2;
+    while (n2 < a.tail_k && bf[n2] != KEY_EMPTY) ++n2;
     if (n2 > 0) {
       const int n1 = a.K;
       // MergeTwoQueuesInto1stQueueSeqFixed (:150-217) on m[0..n1): lower_bound of bf[0]
@@ -178,17 +180,17 @@ __global__ __launch_bounds__(64) void post_kernel(PostArgs a) {
   __syncthreads();
   const int cand_num = s_cand;
   int res = 0;
-  for (int base = 0; base < cand_num && res < a.K; base += 64) {
+  for (int base = 0; base < cand_num && res < a.Kout; base += 64) {
     const int i = base + lane;
     u64 v = KEY_EMPTY;
     if (i < cand_num) v = i < a.K ? m[i] : plain_key(qu[i]);
-    const bool ok = v != KEY_EMPTY && row_visible(a.f, key_id(v));
+    const bool ok = v != KEY_EMPTY && row_visible(a.f, key_id(v), key_dist(v));
     const u64 mask = __ballot(ok);
     const int rank = res + __popcll(mask & ((1ull << lane) - 1ull));
-    if (ok && rank < a.K) a.run_keys[q * a.k + rank] = v;
+    if (ok && rank < a.Kout) a.run_keys[q * a.k + rank] = v;
     res += __popcll(mask);
   }
-  if (res > a.K) res = a.K;
+  if (res > a.Kout) res = a.Kout;
   for (int i = res + lane; i < a.k; i += 64) a.run_keys[q * a.k + i] = KEY_EMPTY;
 }
 
@@ -201,7 +203,7 @@ static void launch_trv2(const Trv2Args& a, int slots, size_t shm, hipStream_t s)
 }
 
 int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_search_params& p, u64* run_keys,
-                     int64_t* evals_out) {
+                     int64_t* evals_out, int walk_limit) {
   GraphDev& g = *ix.graph_;
   const int64_t n = ix.n_indexed_;
   int64_t L = p.master_queue;
@@ -294,9 +296,11 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
   // brute-force tail over the rows the graph does not cover yet (:885-900)
   const int64_t n_total = ix.n_rows_;
   const u64* tail = nullptr;
+  const int limit = walk_limit > 0 ? walk_limit : k;   // the reference's `limit`
+  const int tail_k = std::min(limit, 1024);            // only min(|tail|, limit) tail entries are ever merged (:890-899)
   if (n_total > n) {
-    if (!g.tail.reserve((size_t)nq * k * 8)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "search: out of device memory");
-    int32_t rc = ix.flat_stream(dq, nq, k, n, n_total, g.tail.as<u64>(), false);
+    if (!g.tail.reserve((size_t)nq * tail_k * 8)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "search: out of device memory");
+    int32_t rc = ix.flat_stream(dq, nq, tail_k, n, n_total, g.tail.as<u64>(), false);
     if (rc != EPS_OK) return rc;
     tail = g.tail.as<u64>();
   }
@@ -304,11 +308,14 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
   pa.queue = g.queue.as<u64>();
   pa.L = (int)L;
   pa.k = k;
+  pa.tail_k = tail_k;
   int64_t K = n;
-  if (k < K) K = k;
+  if (limit < K) K = limit;
   if (p.local_queue < K) K = p.local_queue;
   if (L < K) K = L;
+  if (tail && K > 1024) return ix.fail(EPS_DB_UNSUPPORTED_ERROR, "search: limit > 1024 with an un-indexed tail is not supported");
   pa.K = (int)K;
+  pa.Kout = walk_limit > 0 ? k : (int)K;
   pa.cand_num_tail = (int)std::min<int64_t>(L, n_total);
   pa.cand_num = (int)std::min<int64_t>(L, n);
   pa.f = ix.filter_spec();
@@ -329,7 +336,7 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
     }
     ix.stats_.main_kernel_launches += 1;
     if (q0 + cnt >= nq) (void)hipEventRecord(ix.evk1_, s);   // (with several slices the pair spans all traversal launches and the post kernels between them)
-    pa.tail = tail ? tail + q0 * k : nullptr;
+    pa.tail = tail ? tail + q0 * tail_k : nullptr;
     pa.run_keys = run_keys + q0 * k;
     hipLaunchKernelGGL(post_kernel, dim3((unsigned)cnt), dim3(64), (size_t)K * 8, s, pa);
   }

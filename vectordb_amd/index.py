@@ -115,6 +115,40 @@ class GpuIndex:
         base = C.c_void_p(_ptr(column).value + offset)
         self._check(self.L.eps_index_set_int_filter(self.h, base, stride, width, OPS[op], int(value)))
 
+    def set_filter_program(self, program, rows=None, stride=None):
+        """program: postfix list of ("const", x) | ("dist",) | ("i8"|"i16"|"i32"|"i64"|"f32"|"f64"|"bool", byte_offset) |
+        (operator,) with operators + - * / % < <= = <> >= > and or not =b <>b (see eps_filter_op); rows: the packed
+        attribute rows (numpy structured/2-D uint8 array or device tensor), row i at i*stride bytes.  None / [] clears."""
+        if not program:
+            self._check(self.L.eps_index_set_filter_program(self.h, None, 0, None, 0, 0))
+            return
+        ops = (lib.FilterOp * len(program))()
+        for i, ins in enumerate(program):
+            ops[i].op = lib.FOP[ins[0]]
+            if ins[0] == "const":
+                ops[i].dval = float(ins[1])
+            elif len(ins) > 1:
+                ops[i].arg = int(ins[1])
+        if not _is_dev(rows):
+            rows = np.ascontiguousarray(rows)
+            stride = stride or rows.strides[0]
+        n_rows = rows.shape[0]
+        self._keep["prog_rows"] = rows
+        self._check(self.L.eps_index_set_filter_program(self.h, ops, len(program), _ptr(rows), stride, n_rows))
+
+    def search_walk(self, queries, limit, cap, **kw):
+        """eps_index_search_walk: the <= cap candidates the reference's post-filter loop would walk (host queries)"""
+        p = self.params(**kw)
+        queries = np.ascontiguousarray(queries, np.float32)
+        if queries.ndim == 1:
+            queries = queries[None, :]
+        nq = queries.shape[0]
+        ids = np.empty((nq, cap), np.int64)
+        dist = np.empty((nq, cap), np.float32)
+        counts = np.empty(nq, np.int32)
+        self._check(self.L.eps_index_search_walk(self.h, _ptr(queries), nq, limit, cap, C.byref(p), _ptr(ids), _ptr(dist), _ptr(counts)))
+        return ids, dist, counts
+
     def set_stream(self, stream_ptr):
         """stream_ptr: a hipStream_t as an integer (torch: `torch.cuda.current_stream().cuda_stream`).  0 is
         torch's default stream = HIP's legacy null stream and is passed as hipStreamLegacy; None gives the index
