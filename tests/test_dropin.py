@@ -231,3 +231,104 @@ def test_concurrent_clients_are_micro_batched_and_match_reference(dropin, tmp_pa
         db.close()
     ref.L.ref_config(4, 500, 1, 0, 16)
     dropin.L.ref_config(4, 500, 1, 0, 16)
+
+
+FILTER_SCHEMA = {"name": "T", "fields": [{"name": "ID", "dataType": "INT", "primaryKey": True},
+                                         {"name": "Tag", "dataType": "STRING"},
+                                         {"name": "Price", "dataType": "FLOAT"},
+                                         {"name": "Weight", "dataType": "DOUBLE"},
+                                         {"name": "Small", "dataType": "SMALLINT"},
+                                         {"name": "Big", "dataType": "BIGINT"},
+                                         {"name": "Flag", "dataType": "BOOL"},
+                                         {"name": "V", "dataType": "VECTOR_FLOAT", "dimensions": 8, "metricType": "EUCLIDEAN"}]}
+FILTERS = ["ID >= 100 AND ID < 500", "ID < 50 OR ID > 1700", "NOT (ID < 1000)", "Price < 0.25", "Price * 2 + 1 >= 2.5", "Weight <= 0.1 OR Price > 0.9",
+           "Small % 7 = 3", "Big > 2000000000", "Flag = true", "NOT Flag", "(ID < 300 OR ID > 1500) AND Price < 0.5 AND Small <> 4",
+           "@distance < 0.35", "@distance >= 0.2 AND ID < 1000", "@distance < 0.5 AND Price < 0.5", "ID / 2 = 50.5", "ID - Small > 1700",
+           "Tag = 't3' AND ID >= 100", "Tag <> 't1'", "Tag = 't2' OR @distance < 0.1", "Tag LIKE 't%' AND Price < 0.05", "Tag = 'absent'",
+           "Tag = 't4' AND Price < 0.3 AND @distance < 0.6"]
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not ref_available(), reason="needs oracle/_ref")
+@pytest.mark.parametrize("prefilter,rebuild", [(0, False), (0, True), (1, False)])
+def test_filter_compiler_matches_reference_dbserver(dropin, tmp_path, prefilter, rebuild):
+    """every filter form - int / float / double / bool attributes, arithmetic, AND / OR / NOT, @distance
+    (device predicate program), strings / LIKE and mixes of both (host predicate on the walk candidates) - returns through
+    the drop-in DBServer exactly what the reference DBServer returns, in the three modes of Search(): brute force
+    (no graph yet), graph + post-filter after Rebuild(), and PreFilter."""
+    ref = Ref()
+    n = 1800
+    X = data(n, 8, 21)
+    rng = np.random.default_rng(22)
+    price, weight = rng.random(n), rng.random(n)
+    recs = [{"ID": int(i), "Tag": "t%d" % (i % 5), "Price": float(np.float32(price[i])), "Weight": float(weight[i]), "Small": int(i % 11),
+             "Big": int(i) * 3000000, "Flag": bool(i % 3 == 0), "V": [float(x) for x in X[i]]} for i in range(n)]
+    Q = data(4, 8, 23)
+    out = []
+    for lib, name in ((ref, "ref"), (dropin, "drop")):
+        lib.L.ref_config(1, 500, 1, prefilter, 2)          # IntraQueryThreads = 1: deterministic on both sides
+        db = lib.db(str(tmp_path / name))
+        assert db.create_table(FILTER_SCHEMA) == 0
+        for s in range(0, n, 600):
+            assert db.insert("T", recs[s:s + 600]) == 0
+        assert db.delete("T", [3, 4, 5, 1000, 1001]) == 0
+        if rebuild:
+            assert db.rebuild() == 0
+        res = {}
+        for flt in FILTERS:
+            for qi, q in enumerate(Q):
+                for limit in (10, 200):
+                    res[(flt, qi, limit)] = db.search("T", "V", q, limit, fields=("ID",), flt=flt)
+        out.append(res)
+        db.close()
+        lib.L.ref_config(4, 500, 1, 0, 4)
+    nonempty = 0
+    for key, (rc_r, r) in out[0].items():
+        rc_d, d = out[1][key]
+        assert rc_r == rc_d == 0, (key, rc_r, rc_d, r if rc_r else d)
+        assert [x["ID"] for x in d] == [x["ID"] for x in r], (key, [x["ID"] for x in d][:12], [x["ID"] for x in r][:12])
+        assert np.allclose([x["@distance"] for x in d], [x["@distance"] for x in r], rtol=1e-4, atol=1e-7), key
+        nonempty += len(r) > 0
+    assert nonempty > len(out[0]) * 0.8
+
+
+@pytest.mark.gpu
+def test_filter_program_through_the_c_abi():
+    """eps_index_set_filter_program on packed rows {i32 id; f32 price; u8 flag; pad; f64 w} against numpy: flat (stream and
+    MFMA engines), with @distance, on 70k rows; and the candidate walk (eps_index_search_walk)."""
+    import vectordb_amd as amd
+    n, d = 70_000, 64
+    X, Q = data(n, d, 31), data(9, d, 32)
+    rng = np.random.default_rng(33)
+    rows = np.zeros(n, dtype=np.dtype([("id", "<i4"), ("price", "<f4"), ("flag", "u1"), ("pad", "u1", 7), ("w", "<f8")]))
+    rows["id"], rows["price"], rows["flag"], rows["w"] = np.arange(n), rng.random(n), rng.integers(0, 2, n), rng.random(n)
+    ix = amd.GpuIndex(d, 0)
+    ix.attach_rows(X)
+    exact = ((X[None, :, :].astype(np.float64) - Q[:, None, :]) ** 2).sum(2) if n * len(Q) * d < 1e8 else None
+    dist = np.stack([((X.astype(np.float64) - q) ** 2).sum(1) for q in Q])
+    progs = [
+        ([("i32", 0), ("const", 35000), ("<",), ("f32", 4), ("const", 0.5), ("<",), ("and",)], lambda dd: (rows["id"] < 35000) & (rows["price"] < 0.5)),
+        ([("bool", 8), ("not",), ("f64", 16), ("const", 0.25), (">=",), ("or",)], lambda dd: (rows["flag"] == 0) | (rows["w"] >= 0.25)),
+        ([("i32", 0), ("const", 7), ("%",), ("const", 3), ("=",)], lambda dd: rows["id"] % 7 == 3),
+    ]
+    for prog, ref_mask in progs:
+        ix.set_filter_program(prog, rows)
+        for eng in (amd.FLAT_STREAM, amd.FLAT_MFMA):
+            ids, dd, cnt = ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=eng)
+            m = ref_mask(None)
+            for qi in range(len(Q)):
+                want = np.argsort(np.where(m, dist[qi], np.inf), kind="stable")[:10]
+                assert list(ids[qi]) == list(want), (prog, eng, qi)
+    # @distance: rows closer than the 200-th nearest are filtered out -> the answer starts at rank 200
+    thr = float(np.sort(dist[0])[200])
+    ix.set_filter_program([("dist",), ("const", thr), (">",)], rows)
+    ids, dd, cnt = ix.search(Q[:1], 10, mode=amd.MODE_FLAT)
+    want = np.argsort(dist[0], kind="stable")
+    want = [i for i in want if np.float32(dist[0][i]) > np.float32(thr)][:10]
+    assert set(ids[0]) == set(want)
+    ix.set_filter_program(None)
+    # candidate walk: flat mode returns the cap closest visible rows
+    wi, wd, wc = ix.search_walk(Q[:2], 10, 300, mode=amd.MODE_FLAT)
+    for qi in range(2):
+        assert int(wc[qi]) == 300 and list(wi[qi]) == list(np.argsort(dist[qi], kind="stable")[:300])
+    ix.close()
