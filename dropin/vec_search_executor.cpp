@@ -340,6 +340,23 @@ Status VecSearchExecutor::Search(const VectorPtr query_data, vectordb::engine::T
   std::vector<float> out_dist;
   if (!flat) {
     // graph: walk the <= L_master candidates in order, stop at searchLimit (:905-927)
+    if (total_vector > total_indexed_vector_) {
+      // the reference's BruteForceSearch over the un-indexed tail (:885-889) drops deleted rows and rows failing the filter
+      // (evaluated with the row's distance) BEFORE the merge into the first K slots: the tail rows are judged here, on the
+      // host as in the reference (O(tail)), and handed to the device as invisible
+      bool uses_distance = false;
+      for (auto& n : filter_nodes) uses_distance |= n && n->field_name == "@distance";
+      const float* base = std::get<DenseVectorColumnDataContainer>(vector_column_);
+      auto dfn = std::get<DenseVecDistFunc<float>>(fstdistfunc_);
+      dev.mask.assign(deleted.data(), deleted.data() + deleted.size());
+      if (dev.mask.size() < (size_t)(total_vector + 7) / 8) dev.mask.resize((size_t)(total_vector + 7) / 8, 0);
+      for (int64_t id = total_indexed_vector_; id < total_vector; ++id) {
+        if (deleted.test(id)) continue;
+        const float d = uses_distance ? dfn(base + id * dimension_, std::get<DenseVectorPtr>(query_data), dist_func_param_) : 0.f;
+        if (!ev.LogicalEvaluate(root, id, d)) dev.mask[id >> 3] |= uint8_t(1u << (id & 7));
+      }
+      if (eps_index_set_deleted(dev.h, dev.mask.data(), (int64_t)dev.mask.size()) != EPS_OK) return fail("mask upload");
+    }
     const int64_t K = std::min<int64_t>({total_indexed_vector_, (int64_t)limit, L_local_});
     const int32_t cap = (int32_t)std::min<int64_t>(std::max<int64_t>(L_master_, K), (int64_t)1 << 20);
     std::vector<int64_t> ids((size_t)cap);
@@ -382,14 +399,23 @@ Status VecSearchExecutor::Search(const VectorPtr query_data, vectordb::engine::T
   }
   if (want > 1024)
     throw std::runtime_error("gfx950 executor: more than 1024 results per query from a brute-force search are not supported");
-  // selective host-only filter: visibility of every row, evaluated on the host (the reference's own cost, :746-755)
+  // selective host-only filter: visibility of every row, evaluated on the host - the reference's own cost for every
+  // brute-force query (:746-755); @distance, if the filter reads it, comes from the host distance function as there
   bool uses_distance = false;
   for (auto& n : filter_nodes) uses_distance |= n && n->field_name == "@distance";
-  if (uses_distance && !prefilter_enabled_)
-    throw std::runtime_error("gfx950 executor: a selective filter that combines @distance with string / geo predicates on a brute-force search is not supported");
-  dev.mask.assign((size_t)(total_vector + 7) / 8, 0);
-  for (int64_t id = 0; id < total_vector; ++id)
-    if (deleted.test(id) || !ev.LogicalEvaluate(root, id)) dev.mask[id >> 3] |= uint8_t(1u << (id & 7));
+  {
+    const float* base = std::get<DenseVectorColumnDataContainer>(vector_column_);
+    auto dfn = std::get<DenseVecDistFunc<float>>(fstdistfunc_);
+    dev.mask.assign((size_t)(total_vector + 7) / 8, 0);
+    for (int64_t id = 0; id < total_vector; ++id) {
+      bool pass = !deleted.test(id);
+      if (pass) {
+        if (prefilter_enabled_ || !uses_distance) pass = ev.LogicalEvaluate(root, id);
+        else pass = ev.LogicalEvaluate(root, id, dfn(base + id * dimension_, std::get<DenseVectorPtr>(query_data), dist_func_param_));
+      }
+      if (!pass) dev.mask[id >> 3] |= uint8_t(1u << (id & 7));
+    }
+  }
   if (eps_index_set_deleted(dev.h, dev.mask.data(), (int64_t)dev.mask.size()) != EPS_OK) return fail("mask upload");
   {
     const int32_t k = (int32_t)want;
@@ -427,7 +453,8 @@ void RunBatch(DeviceField& dev, int64_t dim, std::vector<Pending*>& batch) {
     else { dev.graph_owner = h.graph_owner; dev.graph_n = h.graph_n; }
   }
   ConcurrentBitset& deleted = *(h.segment->deleted_);
-  if (err.empty() && eps_index_set_int_filter(dev.h, nullptr, 0, 0, EPS_OP_NONE, 0) != EPS_OK) fail("filter reset");
+  if (err.empty() && (eps_index_set_int_filter(dev.h, nullptr, 0, 0, EPS_OP_NONE, 0) != EPS_OK ||
+                      eps_index_set_filter_program(dev.h, nullptr, 0, nullptr, 0, 0) != EPS_OK)) fail("filter reset");
   if (err.empty() && eps_index_set_deleted(dev.h, deleted.data(), (int64_t)deleted.size()) != EPS_OK) fail("deleted upload");
   const int64_t nq = (int64_t)batch.size();
   const int32_t k = h.k;
