@@ -19,11 +19,22 @@ rows = int(sys.argv[4]) if len(sys.argv) > 4 else 2000
 dim = int(sys.argv[5]) if len(sys.argv) > 5 else 32
 nq = int(sys.argv[6]) if len(sys.argv) > 6 else 64
 out = {"module": getattr(epsilla, "backend", "reference"), "file": epsilla.__file__}
+
+
+def create_table(name, fields):
+    # the reference binding drops a reference it does not own (`Py_DECREF(tableFieldsListPtr)` on a borrowed argument,
+    # bindings/python/interface.cpp:129): without this compensation the list is freed twice and the interpreter
+    # segfaults at exit - in the reference's own module as well
+    import ctypes
+    ctypes.pythonapi.Py_IncRef(ctypes.py_object(fields))
+    return epsilla.create_table(table_name=name, table_fields=fields)
+
+
 assert epsilla.load_db(db_name="db", db_path=db_path) == 0
 epsilla.use_db(db_name="db")
 
 if what == "cities":
-    epsilla.create_table(table_name="MyTable", table_fields=[
+    create_table("MyTable", [
         {"name": "ID", "dataType": "INT", "primaryKey": True}, {"name": "Doc", "dataType": "STRING"},
         {"name": "EmbeddingEuclidean", "dataType": "VECTOR_FLOAT", "dimensions": 4, "metricType": "EUCLIDEAN"},
         {"name": "EmbeddingDotProduct", "dataType": "VECTOR_FLOAT", "dimensions": 4, "metricType": "DOT_PRODUCT"},
@@ -46,8 +57,8 @@ else:
     rng = np.random.default_rng(42)
     X = rng.random((rows, dim), dtype=np.float32)
     Q = np.random.default_rng(43).random((nq, dim), dtype=np.float32)
-    epsilla.create_table(table_name="T", table_fields=[{"name": "ID", "dataType": "INT", "primaryKey": True},
-                                                       {"name": "V", "dataType": "VECTOR_FLOAT", "dimensions": dim, "metricType": "EUCLIDEAN"}])
+    create_table("T", [{"name": "ID", "dataType": "INT", "primaryKey": True},
+                       {"name": "V", "dataType": "VECTOR_FLOAT", "dimensions": dim, "metricType": "EUCLIDEAN"}])
     t0 = time.perf_counter()
     for s in range(0, rows, 1000):
         assert epsilla.insert(table_name="T", records=[{"ID": int(i), "V": X[i].tolist()} for i in range(s, min(rows, s + 1000))]) == 0

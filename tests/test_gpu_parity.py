@@ -553,3 +553,83 @@ def test_append_rows_and_tail_search(amd, oracle):
     for qi in range(8):
         assert_topk_match(ids[qi], dist[qi], z["plain_k10_ids"][qi], z["plain_k10_dist"][qi])
     ix.close()
+
+
+def test_append_extends_the_fp16_mirror_incrementally(amd, oracle):
+    """appended rows are converted into the fp16 mirror on their own (the mirror of the rows already there is
+    kept); results after the append equal the exact stream engine and the oracle, including hits in the appended tail."""
+    n0, n1, d = 70_000, 9_000, 128
+    X, Q = data(n0 + n1, d, 7), data(24, d, 8)
+    X[n0 + 5] = Q[0] + 1e-3      # planted neighbours inside the appended rows
+    X[n0 + n1 - 1] = Q[1] - 2e-3
+    ix = amd.GpuIndex(d, 0)
+    ix.attach_rows(X[:n0])
+    a = ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA)
+    assert ix.stats()["rerank_rows"] > 0
+    ix.append_rows(X[n0:n0 + 4000])
+    ix.append_rows(X[n0 + 4000:])
+    assert ix.row_count == n0 + n1
+    b = ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA)
+    assert ix.stats()["rerank_rows"] > 0
+    c = ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
+    assert np.array_equal(b[0], c[0]) and np.array_equal(b[1], c[1])
+    assert b[0][0][0] == n0 + 5 and b[0][1][0] == n0 + n1 - 1
+    for qi in range(0, len(Q), 5):
+        rid, rd = oracle.topk_flat(0, X, Q[qi], 10)
+        assert_topk_match(b[0][qi], b[1][qi], rid, rd, what="append q%d" % qi)
+    ix.close()
+
+
+def test_attach_rows_revalidates_dependent_state(amd):
+    """re-attaching fewer rows drops a graph that covers more rows than are attached and a bitset / filter column of
+    the old length; appending rows makes a too-short bitset an error instead of an out-of-bounds read."""
+    z, off, nbr, nav = _golden_graph()
+    X = data(2000, 32, 42)
+    ix = amd.GpuIndex(32, 0)
+    ix.attach_rows(X)
+    ix.set_graph(off, nbr, nav)
+    ix.set_deleted(bitset(2000, [1, 2, 3]))
+    ix.attach_rows(X[:900])
+    assert ix.graph_info()[0] == 0
+    with pytest.raises(amd.EpsillaError):
+        ix.search(X[:1], 5, mode=amd.MODE_GRAPH)
+    ids, _, _ = ix.search(X[1:2], 1, mode=amd.MODE_FLAT)   # the old bitset (row 1 deleted) is still long enough and still applies
+    assert ids[0][0] != 1
+    ix.set_deleted(bitset(900, [1]))
+    ix.append_rows(X[900:1000])
+    with pytest.raises(amd.EpsillaError):
+        ix.search(X[:1], 5, mode=amd.MODE_FLAT)
+    ix.set_deleted(None)
+    ids, _, _ = ix.search(X[950:951], 1, mode=amd.MODE_FLAT)
+    assert ids[0][0] == 950
+    # a one-row and an empty build (ADVICE: build() with n == 1 failed)
+    ix1 = amd.GpuIndex(32, 0)
+    ix1.attach_rows(X[:1])
+    ix1.build(1)
+    assert ix1.graph_info()[:2] == (1, 0)
+    ix.close()
+    ix1.close()
+
+
+def test_mfma_filter_is_exact_at_high_dimension_with_cancellation(amd):
+    """the fp32 slack of the filter threshold has to grow with d.  d = 8192, rows and queries all within 1e-3 of one
+    point (distances are ~1e-5 of the squared norms: massive cancellation in |x|^2 - 2 q.x + |q|^2): the MFMA engine must still
+    return exactly what the fp32 stream engine returns."""
+    import torch
+    n, d, nq = 66_000, 8192, 16
+    g = torch.Generator(device="cuda").manual_seed(5)
+    c = torch.rand((1, d), generator=g, device="cuda")
+    X = c + 1e-3 * torch.randn((n, d), generator=g, device="cuda")
+    Qd = c + 1e-3 * torch.randn((nq, d), generator=g, device="cuda")
+    ix = amd.GpuIndex(d, 0).use_torch_stream()
+    ix.attach_rows(X)
+    outs = []
+    for eng in (amd.FLAT_MFMA, amd.FLAT_STREAM):
+        o = (torch.empty((nq, 10), dtype=torch.int64, device="cuda"), torch.empty((nq, 10), dtype=torch.float32, device="cuda"),
+             torch.empty((nq,), dtype=torch.int32, device="cuda"))
+        ix.search(Qd, 10, out=o, mode=amd.MODE_FLAT, flat_engine=eng)
+        ix.synchronize()
+        outs.append((o[0].cpu().numpy(), o[1].cpu().numpy()))
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][1], outs[1][1])
+    ix.close()

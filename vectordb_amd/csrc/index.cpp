@@ -179,8 +179,7 @@ int32_t Index::append_rows(const float* rows, int64_t n_new) {
   HIP_TRY(hipStreamSynchronize(stream_));
   d_rows_ = rows_buf_.as<float>();
   rows_owned_ = true;
-  n_rows_ += n_new;
-  ++rows_version_;
+  n_rows_ += n_new;   // rows_version_ stays: the fp16 mirror is extended by the new rows on the next MFMA search
   return EPS_OK;   // (a bitset / attribute column that is now too short is rejected by search(), see there)
 }
 

@@ -16,12 +16,13 @@
 //              exactly, give the first T (with a deleted bitset / attribute filter: exact fp32 stream scan instead)
 //     stage i: MFMA filter over a geometrically larger chunk          -> candidates -> exact re-rank -> top-k
 // Expected candidates per query ~ k * sum_i (chunk_i / rows_before_i): a few hundred at N = 10M, k = 10.
-// If a query's candidate buffer overflows (adversarial order/duplicates) the batch falls back to the fp32 scan,
-// so the result is exact in every case.
+// If a query's candidate buffer overflows (adversarial order/duplicates) the batch falls back to the fp32 scan.
+// The bound is a worst-case one (no distributional assumption) for the fp16 rounding and the accumulation order of the
+// GEMM; the fp32 rounding of the re-ranked keys it is compared with is covered by a slack that grows with d.
 //
 // Kernels: mfma_kernels.hpp - v7 (default: persistent, 4 wavefronts x 256 rows x 64 queries per 256 x 256 tile, query
-// fragments straight to VGPRs, 4-slot LDS-DMA ring for the row operand), v5 and v3 for A/B (EPS_MFMA_KERNEL) and as the
-// fallback for d_pad % 128 != 0.  Staging, seeds, re-rank and the overflow fallback are in flat_mfma_search_slice below.
+// fragments straight to VGPRs, 4-slot LDS-DMA ring for the row operand) and v3, the fallback for d_pad % 128 != 0 or
+// d_pad < 256 (tests/test_gpu_parity.py::test_mfma_engine_is_exact covers d = 33 and d = 100).  Staging, seeds, re-rank and the overflow fallback are in flat_mfma_search_slice below.
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -55,6 +56,8 @@ struct HalfMirror {
   int64_t n = 0, n_pad = 0;
   int d_pad = 0;
   bool fp16_range_ok = true;
+  int num_cus = 0;             // CUs of this index's device (persistent grid size)
+  int64_t extended_rows = 0;   // rows converted by incremental extensions (test hook)
   float h_scal[4] = {0, 0, 0, 0};
 };
 
@@ -65,7 +68,9 @@ __device__ __forceinline__ void atomic_max_pos(float* addr, float v) {  // v >= 
   atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
 }
 
-__global__ __launch_bounds__(256) void half_mirror_kernel(const float* rows, int64_t n, int64_t n_pad, int dim, int d_pad,
+// rows [row0, n_pad) are (re)written: row0 = 0 builds the mirror, row0 = rows mirrored so far extends it after an append
+// (the per-index maxima in `scal` only ever grow, so they are accumulated across calls)
+__global__ __launch_bounds__(256) void half_mirror_kernel(const float* rows, int64_t row0, int64_t n, int64_t n_pad, int dim, int d_pad,
                                                           _Float16* xh, float* xn, float* zeros, float* xn_s, float* zeros_s, float* scal,
                                                           float gamma) {
   // one wavefront per row, grid-stride over rows; the four per-index maxima are reduced in registers and
@@ -75,7 +80,7 @@ __global__ __launch_bounds__(256) void half_mirror_kernel(const float* rows, int
   float m_e1 = 0.f, m_nxh = 0.f, m_xn = 0.f, m_bad = 0.f;
   const bool vec = (dim & 3) == 0 && ((reinterpret_cast<uintptr_t>(rows) & 15) == 0);
   typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-  for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n_pad; r += nwaves) {
+  for (int64_t r = row0 + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n_pad; r += nwaves) {
     _Float16* dst = xh + r * d_pad;
     if (r >= n) {
       for (int c = lane; c < d_pad; c += 64) dst[c] = (_Float16)0.f;
@@ -183,7 +188,7 @@ __global__ __launch_bounds__(256) void query_prep_kernel(const float* q, int64_t
 // Also resets what the stage's filter launch accumulates into (candidate counts, group arrival counters), so a stage is
 // threshold -> filter -> counts -> re-rank without separate memsets.
 __global__ void threshold_kernel(const u64* run_keys, int k, int64_t nq, int64_t b_pad, const float* qstat,
-                                 const float* scal, int metric, float* T, u32* cnt, u32* gsync) {
+                                 const float* scal, int metric, float* T, u32* cnt, u32* gsync, float slack) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= b_pad) return;
   if (j < nq) cnt[j] = 0;
@@ -205,7 +210,7 @@ __global__ void threshold_kernel(const u64* run_keys, int k, int64_t nq, int64_t
   const float c = metric == 0 ? qn2 : (metric == 1 ? 1.f : 0.f);
   const float margin = s * (nq_ * e1max + eq * nxhmax);
   const float scale = metric == 0 ? (fabsf(thr) + qn2 + xnmax) : (fabsf(thr) + 1.f + nq_ * nxhmax);
-  float t = (thr - c) + margin + 8e-6f * scale;
+  float t = (thr - c) + margin + slack * scale;
   T[j] = fminf(t, FMAX);
 }
 
@@ -249,24 +254,43 @@ __global__ void stage_counts_kernel(const u32* cnt, int64_t nq, int cap, u32* ov
 }
 
 // ------------------------------------------------------------------------------------------------ host
+static bool grow_keep(DevBuf& b, size_t bytes, size_t keep, hipStream_t s) {
+  if (bytes <= b.cap) return true;
+  DevBuf bigger;
+  if (!bigger.reserve(bytes + bytes / 4)) return false;
+  if (keep && b.p && hipMemcpyAsync(bigger.p, b.p, keep, hipMemcpyDeviceToDevice, s) != hipSuccess) return false;
+  if (hipStreamSynchronize(s) != hipSuccess) return false;
+  b.release();
+  b.p = bigger.p;
+  b.cap = bigger.cap;
+  bigger.p = nullptr;
+  bigger.cap = 0;
+  return true;
+}
+
 static int32_t ensure_mirror(Index& ix) {
   if (!ix.mirror_) ix.mirror_ = new HalfMirror();
   HalfMirror& m = *ix.mirror_;
-  if (m.version == ix.rows_version_) return EPS_OK;
   const int64_t n = ix.n_rows_;
+  if (m.version == ix.rows_version_ && m.n == n) return EPS_OK;
+  // appended rows: only the new rows are converted; the 15 GB mirror of a 10M-row table is not rebuilt
+  const bool extend = m.version == ix.rows_version_ && m.n > 0 && m.n < n;
   const int64_t n_pad = (n + ROWPAD - 1) / ROWPAD * ROWPAD;
   const int d_pad = (int)((ix.dim_ + BK - 1) / BK * BK);
-  if (!m.xh.reserve((size_t)n_pad * d_pad * 2) || !m.xn.reserve((size_t)n_pad * 4) || !m.zeros.reserve((size_t)n_pad * 4) ||
-      !m.xn_s.reserve((size_t)n_pad * 4) || !m.zeros_s.reserve((size_t)n_pad * 4) ||
-      !m.scal.reserve(64))
-    return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory for the fp16 mirror");
   hipStream_t s = ix.stream_;
-  hipError_t er = hipMemsetAsync(m.scal.p, 0, 64, s);
+  const size_t keep_rows = extend ? (size_t)m.n : 0;
+  if (!grow_keep(m.xh, (size_t)n_pad * d_pad * 2, keep_rows * d_pad * 2, s) || !grow_keep(m.xn, (size_t)n_pad * 4, keep_rows * 4, s) ||
+      !grow_keep(m.zeros, (size_t)n_pad * 4, keep_rows * 4, s) || !grow_keep(m.xn_s, (size_t)n_pad * 4, keep_rows * 4, s) ||
+      !grow_keep(m.zeros_s, (size_t)n_pad * 4, keep_rows * 4, s) || !m.scal.reserve(64))
+    return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory for the fp16 mirror");
+  hipError_t er = hipSuccess;
+  if (!extend) er = hipMemsetAsync(m.scal.p, 0, 64, s);
   if (er != hipSuccess) return ix.hip_fail(er, "memset");
   // fp32 accumulation slack of the MFMA dot product: <= 4 * d * 2^-24 * |qh||xh| (generous: covers any
   // internal summation order / truncating adder)
   const float gamma = 4.0f * (float)d_pad * 5.9604645e-8f;
-  hipLaunchKernelGGL(half_mirror_kernel, dim3((unsigned)std::min<int64_t>((n_pad + 3) / 4, 8192)), dim3(256), 0, s, ix.d_rows_, n, n_pad,
+  const int64_t row0 = extend ? m.n : 0;
+  hipLaunchKernelGGL(half_mirror_kernel, dim3((unsigned)std::min<int64_t>((n_pad - row0 + 3) / 4, 8192)), dim3(256), 0, s, ix.d_rows_, row0, n, n_pad,
                      (int)ix.dim_, d_pad, m.xh.as<_Float16>(), m.xn.as<float>(), m.zeros.as<float>(), m.xn_s.as<float>(), m.zeros_s.as<float>(),
                      m.scal.as<float>(), gamma);
   er = hipMemcpyAsync(m.h_scal, m.scal.p, 16, hipMemcpyDeviceToHost, s);
@@ -277,6 +301,7 @@ static int32_t ensure_mirror(Index& ix) {
   m.n_pad = n_pad;
   m.d_pad = d_pad;
   m.version = ix.rows_version_;
+  m.extended_rows += extend ? n - row0 : 0;
   return EPS_OK;
 }
 
@@ -313,9 +338,10 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   hipLaunchKernelGGL(query_prep_kernel, dim3((unsigned)((b_pad + 3) / 4)), dim3(256), 0, s, dq, nq, b_pad, (int)ix.dim_,
                      m.d_pad, m.qh.as<_Float16>(), m.qstat.as<float>());
   // kernel choice: v5 / v7 want K-steps in pairs (d_pad % 128 == 0, >= 256); other shapes stay on v3
-  static const int version_env = getenv("EPS_MFMA_KERNEL") ? std::max(3, atoi(getenv("EPS_MFMA_KERNEL"))) : 7;   // 3 | 5 | 7
-  const int version = (version_env >= 5 && (m.d_pad % 128 != 0 || m.d_pad < 256)) ? 3 : version_env;
-  if (version >= 5) {
+  const char* ver_s = getenv("EPS_MFMA_KERNEL");   // 3 | 7 (A/B); v7 needs K-steps in pairs, other shapes stay on v3
+  const int version_env = ver_s && atoi(ver_s) == 3 ? 3 : 7;
+  const int version = (version_env == 7 && (m.d_pad % 128 != 0 || m.d_pad < 256)) ? 3 : version_env;
+  if (version >= 7) {
     if (!m.qf.reserve((size_t)b_pad * m.d_pad * 2)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory (scratch)");
     hipLaunchKernelGGL(pack_qf_kernel, dim3((unsigned)((b_pad / 32) * (m.d_pad / 16))), dim3(64), 0, s, m.qh.as<_Float16>(),
                        m.qf.as<_Float16>(), b_pad, m.d_pad);
@@ -329,7 +355,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   //  * otherwise: the head is scanned exactly (with the filter) by the stream kernel, stages 32 x and 256 x S0.
   int64_t S0 = std::max<int64_t>(4096, (int64_t)(32 * k + ROWPAD - 1) / ROWPAD * ROWPAD);
   const FilterSpec fs = ix.filter_spec();
-  static const bool seed_env = !(getenv("EPS_MFMA_SEED") && atoi(getenv("EPS_MFMA_SEED")) == 0);
+  const bool seed_env = !(getenv("EPS_MFMA_SEED") && atoi(getenv("EPS_MFMA_SEED")) == 0);
   const bool seeded = seed_env && n > 4 * S0;   // with a filter the seeds are the k best VISIBLE head rows
   std::vector<int64_t> bounds;
   if (seeded) {
@@ -385,7 +411,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   fa.cap = cap;
   fa.group_sync = nullptr;
   fa.dense = 0;
-  fa.ablate = getenv("EPS_MFMA_ABLATE") ? atoi(getenv("EPS_MFMA_ABLATE")) : 0;
+  fa.ablate = 0;
 
   RerankArgs ra;
   ra.rows = ix.d_rows_;
@@ -401,34 +427,25 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   ra.run_keys = run_keys;
 
   const int bm = BM3;   // every kernel generation works on 256-row tiles
-  const size_t shm = version >= 7 ? 4 * 32768 + 2 * 256 * sizeof(float) + 4096
-                     : version == 5 ? 4 * 32768 + 2 * 256 * sizeof(float)
-                                    : 2 * 65536 + 2 * 256 * sizeof(float);
-  static int num_cus = 0;
-  if (!num_cus) {
+  const size_t shm = version >= 7 ? 4 * 32768 + 2 * 256 * sizeof(float) + 4096 : 2 * 65536 + 2 * 256 * sizeof(float);
+  if (!m.num_cus) {   // per index (= per device): no process-wide state
     hipDeviceProp_t prop;
-    num_cus = hipGetDeviceProperties(&prop, ix.device_) == hipSuccess ? prop.multiProcessorCount : 256;
-    num_cus = num_cus / 8 * 8;
-    if (num_cus < 8) num_cus = 8;
-  }
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_filter_kernel_v3<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * 65536 + 2 * 256 * sizeof(float)));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_filter_kernel_v3<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * 65536 + 2 * 256 * sizeof(float)));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_filter_kernel_v5), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * 32768 + 2 * 256 * sizeof(float)));
+    m.num_cus = hipGetDeviceProperties(&prop, ix.device_) == hipSuccess ? prop.multiProcessorCount : 256;
+    m.num_cus = m.num_cus / 8 * 8;
+    if (m.num_cus < 8) m.num_cus = 8;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_filter_kernel_v3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * 65536 + 2 * 256 * sizeof(float)));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_filter_kernel_v7<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * 32768 + 2 * 256 * sizeof(float) + 4096));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_filter_kernel_v7<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * 32768 + 2 * 256 * sizeof(float) + 4096));
-    attr_set = true;
   }
-  static const bool narrow_env = !(getenv("EPS_MFMA_NARROW") && atoi(getenv("EPS_MFMA_NARROW")) == 0);
-  static const bool gsync_env = !(getenv("EPS_MFMA_GROUPSYNC") && atoi(getenv("EPS_MFMA_GROUPSYNC")) == 0);
+  const int num_cus = m.num_cus;
+  const bool narrow_env = !(getenv("EPS_MFMA_NARROW") && atoi(getenv("EPS_MFMA_NARROW")) == 0);
+  const bool gsync_env = !(getenv("EPS_MFMA_GROUPSYNC") && atoi(getenv("EPS_MFMA_GROUPSYNC")) == 0);
   if (!m.gsync.reserve(1024)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory (scratch)");
   auto launch_filter = [&](const FilterArgs& f) {
     {
       FilterArgs f3 = f;
       f3.tiles_q = (int)(b_pad / BN3);
-      if (version == 5) hipLaunchKernelGGL(mfma_filter_kernel_v5, dim3((unsigned)num_cus), dim3(512), shm, s, f3);
-      else if (version >= 7) {
+      if (version >= 7) {
         f3.group_sync = gsync_env ? m.gsync.as<u32>() : nullptr;
         if (f3.group_sync && f3.dense) (void)hipMemsetAsync(f3.group_sync, 0, 1024, s);   // (stages: reset by threshold_kernel)
         if (nq <= 128 && narrow_env) {   // one 128-query tile: half the padded MFMA work, the pass streams the mirror
@@ -438,8 +455,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
           hipLaunchKernelGGL(mfma_filter_kernel_v7<2>, dim3((unsigned)num_cus), dim3(256), shm, s, f3);
         }
       }
-      else if (f3.ablate) hipLaunchKernelGGL(mfma_filter_kernel_v3<true>, dim3((unsigned)num_cus), dim3(512), shm, s, f3);
-      else hipLaunchKernelGGL(mfma_filter_kernel_v3<false>, dim3((unsigned)num_cus), dim3(512), shm, s, f3);
+      else hipLaunchKernelGGL(mfma_filter_kernel_v3, dim3((unsigned)num_cus), dim3(512), shm, s, f3);
     }
   };
   if (seeded) {
@@ -455,7 +471,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
     if (!approx) {   // exact mode: seeds from a sample spread over the whole table (approx mode keeps the head's keys)
       const u32 sample_head = (u32)(S0 / 2);
       const unsigned long long sample_stride = (unsigned long long)(((unsigned __int128)(n - sample_head) << 32) / (unsigned __int128)(S0 - sample_head));
-      if (m.sample_version != ix.rows_version_ || m.sample_n != n || m.sample_rows != S0) {
+      if (m.sample_version != ix.rows_version_ || m.sample_n != n || m.sample_rows != S0) {   // (also after an append: n changed)
         if (!m.sxh.reserve((size_t)S0 * m.d_pad * 2) || !m.sbase.reserve((size_t)S0 * 4) || !m.sbase_u.reserve((size_t)S0 * 4))
           return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory (seed sample)");
         hipLaunchKernelGGL(seed_sample_kernel, dim3((unsigned)S0), dim3(256), 0, s, m.xh.as<_Float16>(), fa.base_s, fa.base, sample_stride, sample_head, m.d_pad,
@@ -480,11 +496,15 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
       launch_rerank(ra, s);                                                    // -> their exact keys
     }
   }
+  // fp32 rounding of the keys the threshold compares: |x|^2, |q|^2 and the re-ranked distance are each a 64-lane sum of
+  // d_pad/64 sequential fmas per lane plus a 6-level shuffle tree, i.e. <= (d_pad/64 + 6) * 2^-24 relative to their
+  // magnitude each; doubled for safety.  (A fixed 8e-6 was only enough up to d ~ 1000.)
+  const float rerank_slack = std::max(8e-6f, 2.f * (3.f * ((float)m.d_pad / 64.f + 6.f) + 2.f) * 5.9604645e-8f);
   bool first = true;
   for (size_t st = 0; st + 1 < bounds.size(); ++st) {
     const int64_t lo = bounds[st], hi = bounds[st + 1];
     hipLaunchKernelGGL(threshold_kernel, dim3((unsigned)((b_pad + 255) / 256)), dim3(256), 0, s, run_keys, k, nq, b_pad,
-                       m.qstat.as<float>(), m.scal.as<float>(), ix.metric_, m.T.as<float>(), cnt, m.gsync.as<u32>());
+                       m.qstat.as<float>(), m.scal.as<float>(), ix.metric_, m.T.as<float>(), cnt, m.gsync.as<u32>(), rerank_slack);
     fa.tile0 = lo / bm;
     fa.ntiles = (hi + bm - 1) / bm - fa.tile0;
     fa.row_hi = hi;
@@ -546,7 +566,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
 // each XCD's 4 MB L2 while the row operand streams past; at 4096 / 8192 queries per pass the query fragments thrash L2
 // and the filter drops to 0.37 / 0.27 of the MFMA peak (0.46 in slices; bench.py --rows 1250000 --batch 8192).
 int32_t flat_mfma_search(Index& ix, const float* dq, int64_t nq, int k, u64* run_keys, bool approx) {
-  static const int64_t slice = getenv("EPS_MFMA_MAX_BATCH") ? std::max(256, atoi(getenv("EPS_MFMA_MAX_BATCH"))) : 2048;
+  const int64_t slice = getenv("EPS_MFMA_MAX_BATCH") ? std::max(256, atoi(getenv("EPS_MFMA_MAX_BATCH"))) : 2048;
   if (nq <= slice) return flat_mfma_search_slice(ix, dq, nq, k, run_keys, approx);
   for (int64_t q0 = 0; q0 < nq; q0 += slice) {   // the counters in ix.stats_ accumulate over the slices
     const int32_t rc = flat_mfma_search_slice(ix, dq + q0 * ix.dim_, std::min(slice, nq - q0), k, run_keys + q0 * k, approx);

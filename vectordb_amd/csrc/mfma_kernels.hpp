@@ -55,9 +55,8 @@ __device__ __forceinline__ int swz(int row, int chunk) { return (row << 3) + (ch
 // MFMAs per wavefront of step s; the epilogue of a tile runs under the first loads of the next.  256 flop per L2
 // byte (v1: 128).  Tile order keeps the query tiles of one row tile on one XCD at the same time.
 constexpr int BM3 = 256, BN3 = 256;
-template <bool ABL>  // ABL: profiling build with the EPS_MFMA_ABLATE switches compiled in
 __global__ __launch_bounds__(512, 2) void mfma_filter_kernel_v3(FilterArgs a) {
-  const int ablate = ABL ? a.ablate : 0;
+  constexpr int ablate = 0;   // (the ablation switches of the kernel lab compile away)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int SLOT = 65536;  // A 256 x 128 B | B 256 x 128 B
   const int tid = threadIdx.x;
@@ -263,236 +262,15 @@ __global__ __launch_bounds__(512, 2) void mfma_filter_kernel_v3(FilterArgs a) {
   }
 }
 
-// ------------------------------------------------------------------------------------------------ v5 kernel
-// 256 x 256 tile per workgroup as v3, but (measured in scripts/lab, profiles/r1_mfma_lab.txt):
-//  * the QUERY operand never touches LDS: it is pre-packed fragment-major (a.qf: one coalesced 1-KiB
-//    global_load_dwordx4 per 32-query x K=16 fragment, L2-resident) and prefetched two K-steps ahead into a 2-deep
-//    register ring; wavefront w owns queries [32w, 32w+32) x all 256 rows = 8 x 1 tiles of v_mfma_f32_32x32x16_f16;
-//  * the ROW operand streams through a 4-slot LDS ring (32 KB per K=64 step) by LDS-DMA with COUNTED waits: two to
-//    three steps are always in flight and the queue never drains at a step boundary (v3: vmcnt(0) every step); a slot is
-//    published one step before it is consumed so the first fragments of a step are read across the barrier;
-//  * fragment reads and fragment loads are hand-issued (inline asm) and waited for by count - hipcc's own waitcnt
-//    insertion drains the queues (vmcnt(0) at the loop head, lgkmcnt(0) after every other fragment group);
-//  * the loop body has no branches: steps past the end re-read the last tile;
-//  * the second wavefront of each SIMD runs at s_setprio 1 so the pair de-phases (one reads while the other multiplies).
-// Requires d_pad % 128 == 0 and d_pad >= 256 (K-steps come in pairs: the register ring is indexed by step parity).
+// hand-issued LDS fragment reads and global fragment loads (waited for by count; hipcc's own waitcnt insertion would
+// drain the queues at every use)
 #define EPS_DS_READ_B128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 #define EPS_GLOAD_B128(dst, voff, sbase, off) \
   asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(off))
-__global__ __launch_bounds__(512, 2) void mfma_filter_kernel_v5(FilterArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  constexpr int ASLOT = 32768;  // 256 rows x 128 B
-  constexpr int RING = 4;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: lets the fragment stream base live in SGPRs
-  const int khalf = lane >> 5;
-  const int l31 = lane & 31;
-  float* base_lds = reinterpret_cast<float*>(lds + RING * ASLOT);  // [2][256]
-
-  const int xcd = blockIdx.x & 7;
-  const int local = blockIdx.x >> 3;
-  const int per_xcd = gridDim.x >> 3;
-  const int QTB = a.tiles_q < per_xcd ? a.tiles_q : per_xcd;
-  const int G = per_xcd / QTB;
-  const int qslot = local % QTB;
-  const int rg = local / QTB;
-  if (rg >= G) return;
-  const int64_t nj = (a.ntiles - xcd + 7) / 8;
-  const int nqt = (a.tiles_q - qslot + QTB - 1) / QTB;
-  const int64_t my_rows = nj > rg ? (nj - rg + G - 1) / G : 0;
-  const int64_t ntile = my_rows * nqt;
-  if (ntile <= 0) return;
-  const int ldk = a.d_pad;
-  const int KT = ldk / 64;      // even and >= 4 (d_pad is a multiple of 128, >= 256)
-
-  int g_off[4];
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int s = it * 512 + tid;
-    const int row = s >> 3;
-    g_off[it] = row * ldk + ((s & 7) ^ ((row >> 1) & 7)) * 8;
-  }
-  auto tile_rt = [&](int64_t t) { return (int64_t)xcd + 8 * (rg + (t / nqt) * G); };
-  auto tile_qt = [&](int64_t t) { return qslot + (int)(t % nqt) * QTB; };
-  auto rows_of = [&](int64_t t) { return a.xh + (a.tile0 + tile_rt(t)) * 256 * (int64_t)ldk; };
-  auto frags_of = [&](int64_t t) { return a.qf + ((int64_t)(tile_qt(t) * 8 + wave) * (ldk / 16)) * 512; };  // + lane * 8
-  const u32 lane16 = lane * 16;
-  auto issue_base = [&](int64_t t) {  // |x|^2 column of tile t -> base_lds[t & 1]
-    const float* pb = a.base_s + (a.tile0 + tile_rt(t)) * 256;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb + (wave & 3) * 64 + lane),
-                                     (__attribute__((address_space(3))) void*)(base_lds + (t & 1) * 256 + (wave & 3) * 64), 4, 0, 0);
-  };
-  auto issue_piece = [&](const _Float16* pA, int kt, int slot, int it) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pA + g_off[it] + kt * 64),
-                                       (__attribute__((address_space(3))) void*)(lds + slot * ASLOT + (it * 512 + wave * 64) * 16), 16, 0, 0);
-  };
-
-  f32x16 acc[8];
-  half8 fb[2][4];
-  half8 fa[2][4];
-  const float inv_s = 1.0f / a.s;
-  int64_t qj = (int64_t)qslot * 256 + wave * 32 + l31;
-  float Tq = a.T[qj] * inv_s;   // threshold in accumulator space: a row passes iff acc >= T/s (s < 0)
-  float cj = a.cand_keys ? (a.metric == 0 ? a.qstat[qj * 4] : (a.metric == 1 ? 1.f : 0.f)) : 0.f;
-
-  int foff[4];
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk) foff[kk] = swz(l31, kk * 2 + khalf) * 16;
-
-  // The (tile, K-step) sequence is one pipeline.  During step g every wavefront issues, in this order interleaved with
-  // its MFMAs: 4 LDS-DMA pieces of step g+3 (ring slot (g+3)%4) and the 4 query fragments of step g+2 (into the register
-  // buffer step g is freeing).  Steps past the end re-read the last tile (harmless) so the loop body has no branches.
-  const _Float16* A_t = rows_of(0);
-  const _Float16* A_n = ntile > 1 ? rows_of(1) : A_t;
-  const _Float16* B_t = frags_of(0);
-  const _Float16* B_n = (nqt > 1 && ntile > 1) ? frags_of(1) : B_t;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the threshold load) keep the counted waits below exact
-  issue_base(0);
-  // prologue = the issue groups of the imaginary steps -3, -2, -1
-#pragma unroll
-  for (int it = 0; it < 4; ++it) issue_piece(A_t, 0, 0, it);
-#pragma unroll
-  for (int it = 0; it < 4; ++it) issue_piece(A_t, 1, 1, it);
-  EPS_GLOAD_B128(fb[0][0], lane16, B_t, 0);
-  EPS_GLOAD_B128(fb[0][1], lane16, B_t, 1024);
-  EPS_GLOAD_B128(fb[0][2], lane16, B_t, 2048);
-  EPS_GLOAD_B128(fb[0][3], lane16, B_t, 3072);
-#pragma unroll
-  for (int it = 0; it < 4; ++it) issue_piece(A_t, 2, 2, it);
-  EPS_GLOAD_B128(fb[1][0], lane16, B_t + 2048, 0);
-  EPS_GLOAD_B128(fb[1][1], lane16, B_t + 2048, 1024);
-  EPS_GLOAD_B128(fb[1][2], lane16, B_t + 2048, 2048);
-  EPS_GLOAD_B128(fb[1][3], lane16, B_t + 2048, 3072);
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // slots 0 and 1 + fragments of step 0
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  const u32 lds0 = (u32)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
-  u32 faddr[4];   // LDS address of this lane's granule of row l31, per K=16 sub-step, in the slot being computed
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk) faddr[kk] = lds0 + foff[kk];
-  EPS_DS_READ_B128(fa[0][0], faddr[0], 0);
-  EPS_DS_READ_B128(fa[0][1], faddr[0], 4096);
-  EPS_DS_READ_B128(fa[0][2], faddr[0], 8192);
-  EPS_DS_READ_B128(fa[0][3], faddr[0], 12288);
-  if (wave >= 4) __builtin_amdgcn_s_setprio(1);   // static priority for the second wavefront of each SIMD (skews the pair)
-
-  int slot = 0;     // LDS ring slot of the step being computed
-  // Invariant at the top of a step (after the barrier that ended the previous one): the slots of this step and the
-  // next have landed for every wavefront, and every wavefront has finished reading the slot of the previous step,
-  // which this step's DMA (three steps ahead) overwrites.
-  auto step = [&](int kt, auto U) __attribute__((always_inline)) {
-    constexpr int rb = decltype(U)::value;          // register buffer of the query fragments (step parity; KT is even)
-    const int nslot = (slot + 1) & 3;
-    const int dslot = (slot + 3) & 3;
-    const u32 sA = slot * ASLOT, sN = nslot * ASLOT;
-    const _Float16* pA = kt + 3 < KT ? A_t : A_n;
-    const int akt = kt + 3 < KT ? kt + 3 : kt + 3 - KT;
-    const _Float16* pB = (kt + 2 < KT ? B_t : B_n) + (int64_t)((kt + 2 < KT ? kt + 2 : kt + 2 - KT) * 4) * 512;
-    // (kk, half) pairs: 4 row blocks x K=16 each; the fragments of pair p+1 (pair 0 of the next step after the last)
-    // are read while the MFMAs of pair p issue
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const int kk = p >> 1, h = p & 1, cur = p & 1, nxt = cur ^ 1;
-      {
-        const int kk1 = ((p + 1) >> 1) & 3, h1 = (p + 1) & 1;
-        const u32 ad = faddr[kk1] + (p < 7 ? sA : sN) + h1 * 16384;
-        EPS_DS_READ_B128(fa[nxt][0], ad, 0);
-        EPS_DS_READ_B128(fa[nxt][1], ad, 4096);
-        EPS_DS_READ_B128(fa[nxt][2], ad, 8192);
-        EPS_DS_READ_B128(fa[nxt][3], ad, 12288);
-        asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          acc[h * 4 + i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][i], fb[rb][kk], acc[h * 4 + i], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (h == 0) {
-        issue_piece(pA, akt, dslot, kk);
-      } else {
-        EPS_GLOAD_B128(fb[rb][kk], lane16, pB + kk * 512, 0);   // due again two steps from now
-      }
-    }
-    slot = nslot;
-    // publish: my pieces of the step after next have landed (the 8 operations issued during this step may stay in flight)
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-  };
-
-  for (int64_t t = 0; t < ntile; ++t) {
-    const int64_t row0 = (a.tile0 + tile_rt(t)) * 256;
-    if (nqt > 1 && t > 0) {
-      qj = (int64_t)tile_qt(t) * 256 + wave * 32 + l31;
-      Tq = a.T[qj] * inv_s;
-      cj = a.cand_keys ? (a.metric == 0 ? a.qstat[qj * 4] : (a.metric == 1 ? 1.f : 0.f)) : 0.f;
-    }
-    if (t + 1 < ntile) issue_base(t + 1);   // a whole tile ahead; counted out by the next step's vmcnt(8)
-    {
-      // accumulators start at base/s (= -|x|^2/2 for L2, 0 otherwise; -inf on padding rows): the finished accumulator is
-      // (approx key)/s and a tile's test is one running max + one compare per 16 outputs
-      const float* bl0 = base_lds + (t & 1) * 256;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int rbase = i * 32 + 4 * khalf;
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          const float4 bv = *reinterpret_cast<const float4*>(&bl0[rbase + 8 * gq]);
-          acc[i][4 * gq + 0] = bv.x;
-          acc[i][4 * gq + 1] = bv.y;
-          acc[i][4 * gq + 2] = bv.z;
-          acc[i][4 * gq + 3] = bv.w;
-        }
-      }
-    }
-    for (int kt = 0; kt < KT; kt += 2) {
-      step(kt, std::integral_constant<int, 0>{});
-      step(kt + 1, std::integral_constant<int, 1>{});
-    }
-    A_t = A_n;
-    B_t = B_n;
-    if (t + 2 < ntile) {
-      A_n = rows_of(t + 2);
-      if (nqt > 1) B_n = frags_of(t + 2);
-    }
-    // ---- epilogue of tile t (the next tile's first steps are already in flight)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int rbase = i * 32 + 4 * khalf;
-      float mx = acc[i][0];
-#pragma unroll
-      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[i][r]);
-      if (__any(mx >= Tq)) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          if (acc[i][r] >= Tq) {
-            const int64_t row = row0 + rbase + (r & 3) + 8 * (r >> 2);
-            if (row < a.row_hi && qj < a.nq) {
-              const u32 slot_c = atomicAdd(&a.cnt[qj], 1u);
-              if (slot_c < (u32)a.cap) {
-                if (a.cand_keys) {
-                  float dapx = acc[i][r] * a.s + cj;
-                  if (a.metric == 0) dapx = fmaxf(dapx, 0.f);
-                  a.cand_keys[qj * (int64_t)a.cap + slot_c] = make_key(dapx, (u32)row);
-                } else {
-                  a.cand[qj * (int64_t)a.cap + slot_c] = (u32)row;
-                }
-              }
-            }
-          }
-        }
-      }
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
 
 // ------------------------------------------------------------------------------------------------ v7 kernel
-// v5's operand transport with FOUR wavefronts per workgroup (one per SIMD, 256 VGPRs + 256 AGPRs each): wavefront w =
+// (v5, the 8-wavefront predecessor of this kernel, lives in scripts/lab/lab_v5.hpp.)  Its operand transport - query
+// fragments straight to VGPRs, 4-slot LDS-DMA ring for the row operand, counted waits - with FOUR wavefronts per workgroup (one per SIMD, 256 VGPRs + 256 AGPRs each): wavefront w =
 // all 256 rows x queries [64w, 64w+64) = 8 x 2 tiles of v_mfma_f32_32x32x16_f16, so every row fragment read from LDS
 // feeds two MFMAs (v5: one).  Measured (scripts/lab, profiles/r1_mfma_lab.txt): the LDS read volume, not the schedule,
 // is what costs v5 its clock (GRBM cycles/us drop from 2.07 GHz with MFMAs alone to 1.72 GHz with the fragment reads);
