@@ -68,6 +68,7 @@ struct DeviceField {
   int64_t attached = 0;            // rows already in HBM
   const void* graph_owner = nullptr;  // ANNGraphSegment whose CSR is on the device
   int64_t graph_n = -1;
+  bool sharded = false;            // several GPUs: searches are exact flat scans per shard (a graph over the whole table cannot be split)
   std::vector<uint8_t> mask;       // scratch: deleted | !filter, for filters evaluated on the host
   ~DeviceField() {
     if (h) eps_index_destroy(h);
@@ -89,7 +90,24 @@ std::shared_ptr<DeviceField> AcquireField(const float* column, int64_t dim, int 
   sp->column = column;
   sp->dim = dim;
   sp->metric = metric;
-  if (eps_index_create(dim, metric, 0, &sp->h) != EPS_OK) return nullptr;  // no gfx950 device: Search() reports it
+  // EPS_DEVICES="0,1,2,3": the field's table is hash-sharded over those GPUs of this process (eps_index_create_sharded);
+  // unset or one ordinal: one index on that device
+  std::vector<int32_t> devices;
+  if (const char* env = getenv("EPS_DEVICES")) {
+    for (const char* p = env; *p;) {
+      char* end = nullptr;
+      const long v = strtol(p, &end, 10);
+      if (end == p) break;
+      devices.push_back((int32_t)v);
+      p = *end == ',' ? end + 1 : end;
+    }
+  }
+  if (devices.size() > 1) {
+    if (eps_index_create_sharded(dim, metric, devices.data(), (int32_t)devices.size(), &sp->h) != EPS_OK) return nullptr;
+    sp->sharded = true;
+  } else if (eps_index_create(dim, metric, devices.empty() ? 0 : devices[0], &sp->h) != EPS_OK) {
+    return nullptr;  // no gfx950 device: Search() reports it
+  }
   g_fields[key] = sp;
   return sp;
 }
@@ -267,7 +285,7 @@ Status VecSearchExecutor::Search(const VectorPtr query_data, vectordb::engine::T
     if (rc != EPS_OK) return fail("row upload");
     dev.attached = total_vector;
   }
-  if (dev.graph_owner != ann_index_.get() || dev.graph_n != total_indexed_vector_) {
+  if (!dev.sharded && (dev.graph_owner != ann_index_.get() || dev.graph_n != total_indexed_vector_)) {
     if (eps_index_set_graph(dev.h, total_indexed_vector_, offset_table_, neighbor_list_, start_search_point_) != EPS_OK)
       return fail("graph upload");
     dev.graph_owner = ann_index_.get();
@@ -303,7 +321,7 @@ Status VecSearchExecutor::Search(const VectorPtr query_data, vectordb::engine::T
   p.master_queue = L_master_;
   p.local_queue = L_local_;
   p.sync_interval = subsearch_iterations_;
-  const bool flat = prefilter_enabled_ || brute_force_search_;
+  const bool flat = prefilter_enabled_ || brute_force_search_ || dev.sharded;
   auto publish = [&](const int64_t* ids, const float* dist, int64_t count) {
     if ((size_t)count > search_result_.size()) {
       search_result_.resize(count);
@@ -378,7 +396,7 @@ Status VecSearchExecutor::Search(const VectorPtr query_data, vectordb::engine::T
   // suffice falls back to evaluating it on every row, which is what the reference does for every query.
   size_t want = std::min<size_t>(limit, (size_t)total_vector);
   if (!prefilter_enabled_) want = std::min<size_t>(want, (size_t)std::max<int64_t>(L_local_, 1));
-  for (int32_t cap = (int32_t)std::min<size_t>(1024, std::max<size_t>(64, 4 * want)); want <= 1024; cap = std::min(1024, cap * 4)) {
+  for (int32_t cap = (int32_t)std::min<size_t>(1024, std::max<size_t>(64, 4 * want)); want <= 1024 && !dev.sharded; cap = std::min(1024, cap * 4)) {
     std::vector<int64_t> ids((size_t)cap);
     std::vector<float> dist((size_t)cap);
     int32_t count = 0;
@@ -448,7 +466,7 @@ void RunBatch(DeviceField& dev, int64_t dim, std::vector<Pending*>& batch) {
                                          : eps_index_append_rows(dev.h, dev.column + dev.attached * dim, total_vector - dev.attached);
     if (rc != EPS_OK) fail("row upload"); else dev.attached = total_vector;
   }
-  if (err.empty() && (dev.graph_owner != h.graph_owner || dev.graph_n != h.graph_n)) {
+  if (err.empty() && !dev.sharded && (dev.graph_owner != h.graph_owner || dev.graph_n != h.graph_n)) {
     if (eps_index_set_graph(dev.h, h.graph_n, h.off, h.nbr, h.start_point) != EPS_OK) fail("graph upload");
     else { dev.graph_owner = h.graph_owner; dev.graph_n = h.graph_n; }
   }

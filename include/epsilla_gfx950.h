@@ -157,6 +157,14 @@ void eps_default_search_params(eps_search_params* p);
 void eps_default_build_params(eps_build_params* p);
 
 int32_t eps_index_create(int64_t dim, int32_t metric, int32_t device, eps_index** out);
+/* Hash-sharded index over `shards` GPUs of THIS process: row i of the table lives on shard i mod shards (device
+ * devices[i mod shards]) as local row i / shards; every shard answers the whole batch on its rows, the per-shard top-k lists
+ * are pushed to devices[0] peer to peer (xGMI) and merged there.  The handle works with every eps_index_* entry point below;
+ * rows, queries, bitsets, filter columns and results are HOST buffers (each shard reads its rows with one strided copy);
+ * eps_index_build builds one graph per shard, eps_index_save/load_graph use <path>.shard<s> files; eps_index_set_graph (one
+ * graph over the whole table), device pointers, eps_index_set_stream and eps_index_search_walk are not available.
+ * devices may repeat an ordinal (several shards on one GPU). */
+int32_t eps_index_create_sharded(int64_t dim, int32_t metric, const int32_t* devices, int32_t shards, eps_index** out);
 int32_t eps_index_destroy(eps_index* h);
 const char* eps_index_last_error(const eps_index* h);
 

@@ -1,0 +1,140 @@
+"""In-library hash-sharded index (eps_index_create_sharded, csrc/shard_group.cpp): G per-device indices in one process, row i on
+shard i mod G, per-shard top-k pushed peer-to-peer to shard 0's device and merged there.  On the one-GPU test box the shards
+share device 0 (`devices=[0, 0, 0]`): every code path is the multi-GPU one except that the peer copies stay on one device."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import assert_topk_match, bitset, data
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import vectordb_amd as amd
+    from vectordb_amd.build import build
+    build()
+    return amd
+
+
+@pytest.mark.parametrize("G", [2, 3])
+@pytest.mark.parametrize("metric", [0, 2])
+def test_sharded_flat_equals_single_index(amd, oracle, G, metric):
+    n, d = 20_011, 48
+    X, Q = data(n, d, 3), data(17, d, 4)
+    one = amd.GpuIndex(d, metric)
+    one.attach_rows(X[:15_000])
+    one.append_rows(X[15_000:])
+    grp = amd.GpuIndex(d, metric, devices=[0] * G)
+    grp.attach_rows(X[:15_000])
+    grp.append_rows(X[15_000:15_007])       # appends that do not start on a multiple of G
+    grp.append_rows(X[15_007:])
+    assert grp.row_count == n
+    dele = bitset(n, range(0, n, 7))
+    idc = np.arange(n, dtype=np.int32)
+    for setup in ("plain", "deleted", "filter"):
+        for ix in (one, grp):
+            ix.set_deleted(dele if setup == "deleted" else None)
+            ix.set_int_filter(idc if setup == "filter" else None, ">=" if setup == "filter" else None, 12_345)
+        a = one.search(Q, 10, mode=amd.MODE_FLAT)
+        b = grp.search(Q, 10, mode=amd.MODE_FLAT)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), setup
+    rid, rd = oracle.topk_flat(metric, X, Q[0], 10)
+    one.set_int_filter(None, None, 0)
+    grp.set_int_filter(None, None, 0)
+    b = grp.search(Q[:1], 10, mode=amd.MODE_FLAT)
+    assert_topk_match(b[0][0], b[1][0], rid, rd)
+    one.close()
+    grp.close()
+
+
+def test_sharded_large_batch_mfma_engine_and_program_filter(amd):
+    """each shard big enough for the MFMA filter engine (>= 65 536 rows), 300 queries, compiled filter over strided attribute rows"""
+    n, d, G = 140_000, 64, 2
+    X, Q = data(n, d, 5), data(300, d, 6)
+    rows = np.zeros(n, dtype=np.dtype([("id", "<i4"), ("price", "<f4")]))
+    rows["id"], rows["price"] = np.arange(n), np.random.default_rng(7).random(n)
+    prog = [("i32", 0), ("const", 3), ("%",), ("const", 1), ("=",), ("f32", 4), ("const", 0.7), ("<",), ("and",)]
+    one = amd.GpuIndex(d, 0)
+    grp = amd.GpuIndex(d, 0, devices=[0] * G)
+    for ix in (one, grp):
+        ix.attach_rows(X)
+        ix.set_filter_program(prog, rows)
+    a = one.search(Q, 10, mode=amd.MODE_FLAT)
+    b = grp.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA)
+    assert grp.stats()["rerank_rows"] > 0
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    m = (rows["id"] % 3 == 1) & (rows["price"] < 0.7)
+    assert m[a[0]].all()
+    one.close()
+    grp.close()
+
+
+def test_sharded_build_graph_search_and_graph_files(amd, tmp_path):
+    """one graph per shard (built on the shard's rows), traversal per shard, merged: unique global ids, the same answer after
+    a save / load round trip through per-shard files in the reference's ann_graph format"""
+    n, d, G = 9_000, 32, 3
+    X, Q = data(n, d, 8), data(40, d, 9)
+    grp = amd.GpuIndex(d, 0, devices=[0] * G)
+    grp.attach_rows(X)
+    grp.build(n)
+    gn, ge, _ = grp.graph_info()
+    assert gn == n and ge > 20 * n
+    ids, dist, cnt = grp.search(Q, 10, mode=amd.MODE_GRAPH, intra_threads=4)
+    ex = grp.search(Q, 10, mode=amd.MODE_FLAT)
+    hits = sum(len(set(ids[i]) & set(ex[0][i])) for i in range(len(Q)))
+    assert hits >= 0.98 * 10 * len(Q)
+    assert all(len(set(r)) == 10 and r.min() >= 0 and r.max() < n for r in ids) and np.all(np.diff(dist, axis=1) >= 0)
+    p = str(tmp_path / "ann_graph_1.bin")
+    grp.save_graph(p)
+    assert all(os.path.exists(p + ".shard%d" % s) for s in range(G))
+    grp2 = amd.GpuIndex(d, 0, devices=[0] * G)
+    grp2.attach_rows(X)
+    grp2.load_graph(p)
+    ids2, dist2, _ = grp2.search(Q, 10, mode=amd.MODE_GRAPH, intra_threads=4)
+    assert np.array_equal(ids, ids2) and np.array_equal(dist, dist2)
+    with pytest.raises(amd.EpsillaError):
+        grp.set_graph(np.zeros(2, np.int64), np.zeros(1, np.int64), 0)
+    grp.close()
+    grp2.close()
+
+
+def test_dropin_dbserver_over_a_sharded_executor(tmp_path):
+    """EPS_DEVICES=0,0: the reference DBServer on the drop-in executor with its table hash-sharded over two shards - exact
+    flat answers, device-compiled and host-evaluated filters, deletes; equal to the reference DBServer's own (exact at this size)."""
+    from oracle.pyoracle import DROPIN_SO, Ref, dropin_available, ref_available
+    if not (dropin_available() and ref_available()):
+        pytest.skip("needs dropin/_build and oracle/_ref")
+    os.environ["EPS_DEVICES"] = "0,0"
+    try:
+        ref, drop = Ref(), Ref(DROPIN_SO)
+        schema = {"name": "T", "fields": [{"name": "ID", "dataType": "INT", "primaryKey": True}, {"name": "Tag", "dataType": "STRING"},
+                                           {"name": "Price", "dataType": "FLOAT"},
+                                           {"name": "V", "dataType": "VECTOR_FLOAT", "dimensions": 12, "metricType": "EUCLIDEAN"}]}
+        n = 1501
+        X = data(n, 12, 11)
+        price = np.random.default_rng(12).random(n)
+        recs = [{"ID": int(i), "Tag": "t%d" % (i % 4), "Price": float(np.float32(price[i])), "V": [float(x) for x in X[i]]} for i in range(n)]
+        Q = data(5, 12, 13)
+        outs = []
+        for lib, name in ((ref, "ref"), (drop, "drop")):
+            lib.L.ref_config(1, 500, 1, 0, 2)
+            db = lib.db(str(tmp_path / name))
+            assert db.create_table(schema) == 0 and db.insert("T", recs[:900]) == 0 and db.insert("T", recs[900:]) == 0
+            assert db.delete("T", [0, 1, 2, 700]) == 0
+            res = {}
+            for flt in ("", "ID >= 400 AND Price < 0.5", "Tag = 't2'", "Tag = 't1' OR ID < 100", "@distance < 0.9"):
+                for qi, q in enumerate(Q):
+                    res[(flt, qi)] = db.search("T", "V", q, 20, fields=("ID",), flt=flt)
+            outs.append(res)
+            db.close()
+            lib.L.ref_config(4, 500, 1, 0, 4)
+        for key, (rc, r) in outs[0].items():
+            rc2, d = outs[1][key]
+            assert rc == rc2 == 0, (key, r if rc else d)
+            assert [x["ID"] for x in d] == [x["ID"] for x in r], key
+            assert np.allclose([x["@distance"] for x in d], [x["@distance"] for x in r], rtol=1e-4)
+    finally:
+        os.environ.pop("EPS_DEVICES", None)

@@ -20,7 +20,7 @@ FLAT_AUTO, FLAT_STREAM, FLAT_MFMA = 0, 1, 2
 OPS = {None: 0, "": 0, "<": 1, "<=": 2, "==": 3, "=": 3, ">=": 4, ">": 5, "!=": 6, "<>": 6}
 
 EXPORTS = [
-    "eps_default_search_params", "eps_default_build_params", "eps_index_create", "eps_index_destroy",
+    "eps_default_search_params", "eps_default_build_params", "eps_index_create", "eps_index_create_sharded", "eps_index_destroy",
     "eps_index_last_error", "eps_index_set_stream", "eps_index_synchronize", "eps_index_attach_rows",
     "eps_index_append_rows", "eps_index_row_count", "eps_index_set_id_map", "eps_index_set_deleted",
     "eps_index_set_int_filter", "eps_index_set_filter_program", "eps_index_search_walk", "eps_index_build", "eps_index_set_graph", "eps_index_graph_info",
@@ -85,6 +85,7 @@ def load():
     L.eps_default_build_params.argtypes = [C.POINTER(BuildParams)]
     L.eps_default_build_params.restype = None
     L.eps_index_create.argtypes = [i64, i32, i32, C.POINTER(vp)]
+    L.eps_index_create_sharded.argtypes = [i64, i32, C.POINTER(i32), i32, C.POINTER(vp)]
     L.eps_index_destroy.argtypes = [vp]
     L.eps_index_last_error.argtypes = [vp]
     L.eps_index_last_error.restype = C.c_char_p

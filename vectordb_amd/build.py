@@ -10,7 +10,7 @@ SRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib")
 OBJ = os.path.join(OUT, "obj")
 LIB = os.path.join(OUT, "libepsilla_gfx950.so")
-SOURCES = ["index.cpp", "flat_kernels.hip", "traverse.hip", "mfma_filter.hip", "graph_build.hip"]
+SOURCES = ["index.cpp", "shard_group.cpp", "flat_kernels.hip", "traverse.hip", "mfma_filter.hip", "graph_build.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-I" + os.path.join(os.path.dirname(HERE), "include")]
 

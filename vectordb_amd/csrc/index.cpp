@@ -115,19 +115,23 @@ int32_t Index::synchronize() {
   return EPS_OK;
 }
 
-int32_t Index::attach_rows(const float* rows, int64_t n) {
-  if (n < 0 || (n > 0 && !rows)) return fail(EPS_USER_ERROR, "attach_rows: bad arguments");
+int32_t Index::attach_rows(const float* rows, int64_t n) { return attach_rows_strided(rows, n, dim_); }
+int32_t Index::append_rows(const float* rows, int64_t n_new) { return append_rows_strided(rows, n_new, dim_); }
+
+int32_t Index::attach_rows_strided(const float* rows, int64_t n, int64_t pitch) {
+  if (n < 0 || (n > 0 && !rows) || pitch < dim_) return fail(EPS_USER_ERROR, "attach_rows: bad arguments");
   if (n >= (int64_t)1 << 31) return fail(EPS_DB_UNSUPPORTED_ERROR, "attach_rows: more than 2^31-1 rows per index (shard first)");
   HIP_TRY(hipSetDevice(device_));
   HIP_TRY(hipStreamSynchronize(stream_));
-  if (is_device_ptr(rows)) {
+  if (is_device_ptr(rows) && pitch == dim_) {
     rows_buf_.release();
     d_rows_ = rows;
     rows_owned_ = false;
   } else {
     const size_t bytes = (size_t)n * dim_ * sizeof(float);
     if (!rows_buf_.reserve(bytes ? bytes : 16)) return fail(EPS_INFRA_UNEXPECTED_ERROR, "attach_rows: out of device memory");
-    if (bytes) HIP_TRY(hipMemcpyAsync(rows_buf_.p, rows, bytes, hipMemcpyHostToDevice, stream_));
+    if (bytes && pitch == dim_) HIP_TRY(hipMemcpyAsync(rows_buf_.p, rows, bytes, hipMemcpyDefault, stream_));
+    else if (bytes) HIP_TRY(hipMemcpy2DAsync(rows_buf_.p, (size_t)dim_ * 4, rows, (size_t)pitch * 4, (size_t)dim_ * 4, (size_t)n, hipMemcpyDefault, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
     d_rows_ = rows_buf_.as<float>();
     rows_owned_ = true;
@@ -155,8 +159,8 @@ int32_t Index::attach_rows(const float* rows, int64_t n) {
   return EPS_OK;
 }
 
-int32_t Index::append_rows(const float* rows, int64_t n_new) {
-  if (n_new < 0 || (n_new > 0 && !rows)) return fail(EPS_USER_ERROR, "append_rows: bad arguments");
+int32_t Index::append_rows_strided(const float* rows, int64_t n_new, int64_t pitch) {
+  if (n_new < 0 || (n_new > 0 && !rows) || pitch < dim_) return fail(EPS_USER_ERROR, "append_rows: bad arguments");
   if (n_new == 0) return EPS_OK;
   if (n_rows_ > 0 && !rows_owned_) return fail(EPS_USER_ERROR, "append_rows: the row store is borrowed device memory; re-attach instead");
   HIP_TRY(hipSetDevice(device_));
@@ -174,8 +178,9 @@ int32_t Index::append_rows(const float* rows, int64_t n_new) {
     bigger.p = nullptr;
     bigger.cap = 0;
   }
-  const hipMemcpyKind kind = is_device_ptr(rows) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-  HIP_TRY(hipMemcpyAsync(static_cast<char*>(rows_buf_.p) + old_bytes, rows, add_bytes, kind, stream_));
+  if (pitch == dim_) HIP_TRY(hipMemcpyAsync(static_cast<char*>(rows_buf_.p) + old_bytes, rows, add_bytes, hipMemcpyDefault, stream_));
+  else HIP_TRY(hipMemcpy2DAsync(static_cast<char*>(rows_buf_.p) + old_bytes, (size_t)dim_ * 4, rows, (size_t)pitch * 4, (size_t)dim_ * 4, (size_t)n_new,
+                                hipMemcpyDefault, stream_));
   HIP_TRY(hipStreamSynchronize(stream_));
   d_rows_ = rows_buf_.as<float>();
   rows_owned_ = true;
@@ -594,6 +599,19 @@ int32_t Index::search(const float* queries, int64_t nq, int32_t k, const eps_sea
   return EPS_OK;
 }
 
+int32_t Index::last_stats(eps_search_stats* out) {
+  eps_search_stats s = stats_;
+  // event timings are read lazily: the caller may have left the work in flight
+  if (ev0_ && hipEventSynchronize(ev1_) == hipSuccess) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ev0_, ev1_) == hipSuccess) s.kernel_ms = ms;
+    if (s.main_kernel_launches > 0 && hipEventElapsedTime(&ms, evk0_, evk1_) == hipSuccess) s.main_kernel_ms = ms;
+  }
+  (void)hipGetLastError();
+  *out = s;
+  return EPS_OK;
+}
+
 // main-kernel milliseconds of the most recent search calls (oldest first); synchronises the stream
 int Index::kernel_times(double* ms_out, int cap) {
   if (!ms_out || cap <= 0) return 0;
@@ -617,6 +635,7 @@ int Index::kernel_times(double* ms_out, int cap) {
 
 // ================================================================================================ C ABI
 using eps::Index;
+using eps::IndexBase;
 
 extern "C" {
 
@@ -643,7 +662,7 @@ void eps_default_build_params(eps_build_params* p) {
 
 // No C++ exception crosses the C ABI: allocation failures and anything else thrown below map to the reference's
 // status codes (utils/error.hpp:11-41) with the text in eps_index_last_error.
-static int32_t map_exception(Index* ix) {
+static int32_t map_exception(IndexBase* ix) {
   try {
     throw;
   } catch (const std::bad_alloc&) {
@@ -654,8 +673,8 @@ static int32_t map_exception(Index* ix) {
     return ix ? ix->fail(EPS_DB_UNEXPECTED_ERROR, "unexpected exception") : EPS_DB_UNEXPECTED_ERROR;
   }
 }
-#define IX(h) reinterpret_cast<Index*>(h)
-#define CIX(h) reinterpret_cast<const Index*>(h)
+#define IX(h) reinterpret_cast<IndexBase*>(h)
+#define CIX(h) reinterpret_cast<const IndexBase*>(h)
 #define GUARD(h, expr)             \
   do {                             \
     if (!(h)) return EPS_USER_ERROR; \
@@ -678,7 +697,24 @@ int32_t eps_index_create(int64_t dim, int32_t metric, int32_t device, eps_index*
       delete ix;
       return rc;
     }
-    *out = reinterpret_cast<eps_index*>(ix);
+    *out = reinterpret_cast<eps_index*>(static_cast<IndexBase*>(ix));
+    return EPS_OK;
+  } catch (...) {
+    return map_exception(nullptr);
+  }
+}
+int32_t eps_index_create_sharded(int64_t dim, int32_t metric, const int32_t* devices, int32_t shards, eps_index** out) {
+  if (!out) return EPS_USER_ERROR;
+  *out = nullptr;
+  if (dim <= 0 || dim > 8192 || metric < 0 || metric > 2 || !devices || shards <= 0 || shards > 16) return EPS_USER_ERROR;
+  try {
+    std::string err;
+    IndexBase* g = eps::make_shard_group(dim, metric, devices, shards, &err);
+    if (!g) {
+      std::fprintf(stderr, "eps_index_create_sharded: %s\n", err.c_str());
+      return EPS_INFRA_UNEXPECTED_ERROR;
+    }
+    *out = reinterpret_cast<eps_index*>(g);
     return EPS_OK;
   } catch (...) {
     return map_exception(nullptr);
@@ -686,13 +722,13 @@ int32_t eps_index_create(int64_t dim, int32_t metric, int32_t device, eps_index*
 }
 int32_t eps_index_destroy(eps_index* h) {
   try {
-    delete reinterpret_cast<Index*>(h);
+    delete reinterpret_cast<IndexBase*>(h);
     return EPS_OK;
   } catch (...) {
     return map_exception(nullptr);
   }
 }
-const char* eps_index_last_error(const eps_index* h) { return h ? reinterpret_cast<const Index*>(h)->last_error() : "null handle"; }
+const char* eps_index_last_error(const eps_index* h) { return h ? CIX(h)->last_error() : "null handle"; }
 int32_t eps_index_set_stream(eps_index* h, void* s) { GUARD(h, IX(h)->set_stream(s)); }
 int32_t eps_index_synchronize(eps_index* h) { GUARD(h, IX(h)->synchronize()); }
 int32_t eps_index_attach_rows(eps_index* h, const float* rows, int64_t n) { GUARD(h, IX(h)->attach_rows(rows, n)); }
@@ -725,17 +761,7 @@ int32_t eps_index_search(eps_index* h, const float* q, int64_t nq, int32_t k, co
 }
 int32_t eps_index_last_stats(const eps_index* h, eps_search_stats* out) {
   if (!h || !out) return EPS_USER_ERROR;
-  Index* ix = const_cast<Index*>(CIX(h));
-  eps_search_stats s = ix->stats();
-  // event timings are read lazily: the caller may have left the work in flight
-  if (ix->ev0_ && hipEventSynchronize(ix->ev1_) == hipSuccess) {
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, ix->ev0_, ix->ev1_) == hipSuccess) s.kernel_ms = ms;
-    if (s.main_kernel_launches > 0 && hipEventElapsedTime(&ms, ix->evk0_, ix->evk1_) == hipSuccess) s.main_kernel_ms = ms;
-  }
-  (void)hipGetLastError();
-  *out = s;
-  return EPS_OK;
+  return const_cast<IndexBase*>(CIX(h))->last_stats(out);
 }
 int32_t eps_index_kernel_times(eps_index* h, double* ms_out, int32_t cap) { return h ? IX(h)->kernel_times(ms_out, cap) : 0; }
 

@@ -28,39 +28,69 @@ struct DevBuf {  // growable device allocation
 struct HalfMirror;   // fp16 mirror + per-row bounds for the MFMA filter engine (mfma_filter.hip)
 struct GraphDev;     // device CSR + traversal scratch (traverse.hip)
 
-class Index {
+// What the C ABI dispatches to: one device index, or a group of them over a hash-sharded table (shard_group.cpp).
+class IndexBase {
+ public:
+  virtual ~IndexBase() {}
+  virtual int32_t set_stream(void* s) = 0;
+  virtual int32_t synchronize() = 0;
+  virtual int32_t attach_rows(const float* rows, int64_t n) = 0;
+  virtual int32_t append_rows(const float* rows, int64_t n_new) = 0;
+  virtual int32_t set_id_map(int64_t base, int64_t stride) = 0;
+  virtual int32_t set_deleted(const uint8_t* bits, int64_t nbytes) = 0;
+  virtual int32_t set_int_filter(const void* column, int64_t stride, int32_t width, int32_t op, int64_t constant) = 0;
+  virtual int32_t set_filter_program(const eps_filter_op* ops, int32_t nops, const void* rows, int64_t stride, int64_t n_rows) = 0;
+  virtual int32_t build(int64_t n, const eps_build_params* p) = 0;
+  virtual int32_t set_graph(int64_t n, const int64_t* off, const int64_t* nbr, int64_t nav) = 0;
+  virtual int32_t graph_info(int64_t* n, int64_t* edges, int64_t* nav) const = 0;
+  virtual int32_t get_graph(int64_t* off, int64_t* nbr) const = 0;
+  virtual int32_t save_graph(const char* path) = 0;
+  virtual int32_t load_graph(const char* path) = 0;
+  virtual int32_t search(const float* queries, int64_t nq, int32_t k, const eps_search_params* p, int64_t* ids, float* dist,
+                         int32_t* counts, int32_t walk_limit = 0) = 0;
+  virtual int64_t row_count() const = 0;
+  virtual int32_t last_stats(eps_search_stats* out) = 0;
+  virtual int kernel_times(double* ms_out, int cap) = 0;
+  const char* last_error() const { return err_.c_str(); }
+  int32_t fail(int32_t code, const std::string& msg) {
+    err_ = msg;
+    return code;
+  }
+  std::string err_;
+};
+
+class Index : public IndexBase {
  public:
   Index(int64_t dim, int metric, int device);
   ~Index();
 
   int32_t init();
-  int32_t set_stream(void* s);
-  int32_t synchronize();
-  int32_t attach_rows(const float* rows, int64_t n);
-  int32_t append_rows(const float* rows, int64_t n_new);
-  int32_t set_id_map(int64_t base, int64_t stride);
-  int32_t set_deleted(const uint8_t* bits, int64_t nbytes);
-  int32_t set_int_filter(const void* column, int64_t stride, int32_t width, int32_t op, int64_t constant);
-  int32_t set_filter_program(const eps_filter_op* ops, int32_t nops, const void* rows, int64_t stride, int64_t n_rows);
-  int32_t build(int64_t n, const eps_build_params* p);
-  int32_t set_graph(int64_t n, const int64_t* off, const int64_t* nbr, int64_t nav);
-  int32_t graph_info(int64_t* n, int64_t* edges, int64_t* nav) const;
-  int32_t get_graph(int64_t* off, int64_t* nbr) const;
-  int32_t save_graph(const char* path);
-  int32_t load_graph(const char* path);
+  int32_t set_stream(void* s) override;
+  int32_t synchronize() override;
+  int32_t attach_rows(const float* rows, int64_t n) override;
+  // rows of a strided host table: row i at rows + i*pitch_floats (hash-sharded tables: pitch = shards*dim)
+  int32_t attach_rows_strided(const float* rows, int64_t n, int64_t pitch_floats);
+  int32_t append_rows_strided(const float* rows, int64_t n_new, int64_t pitch_floats);
+  int32_t append_rows(const float* rows, int64_t n_new) override;
+  int32_t set_id_map(int64_t base, int64_t stride) override;
+  int32_t set_deleted(const uint8_t* bits, int64_t nbytes) override;
+  int32_t set_int_filter(const void* column, int64_t stride, int32_t width, int32_t op, int64_t constant) override;
+  int32_t set_filter_program(const eps_filter_op* ops, int32_t nops, const void* rows, int64_t stride, int64_t n_rows) override;
+  int32_t build(int64_t n, const eps_build_params* p) override;
+  int32_t set_graph(int64_t n, const int64_t* off, const int64_t* nbr, int64_t nav) override;
+  int32_t graph_info(int64_t* n, int64_t* edges, int64_t* nav) const override;
+  int32_t get_graph(int64_t* off, int64_t* nbr) const override;
+  int32_t save_graph(const char* path) override;
+  int32_t load_graph(const char* path) override;
+  int32_t last_stats(eps_search_stats* out) override;
   // walk_limit > 0: candidate-walk form (eps_index_search_walk): k = cap, the tail merge uses searchLimit(walk_limit)
   int32_t search(const float* queries, int64_t nq, int32_t k, const eps_search_params* p, int64_t* ids, float* dist,
-                 int32_t* counts, int32_t walk_limit = 0);
+                 int32_t* counts, int32_t walk_limit = 0) override;
 
-  int64_t row_count() const { return n_rows_; }
-  const char* last_error() const { return err_.c_str(); }
+  int64_t row_count() const override { return n_rows_; }
   const eps_search_stats& stats() const { return stats_; }
 
   // ---- used by the engine translation units
-  int32_t fail(int32_t code, const std::string& msg) {
-    err_ = msg;
-    return code;
-  }
   int32_t hip_fail(hipError_t e, const char* what);
   FilterSpec filter_spec() const;
   hipStream_t stream() const { return stream_; }
@@ -116,11 +146,10 @@ class Index {
   bool kring_valid_[KRING] = {};
   int64_t kring_seq_ = 0;
   hipEvent_t evk0_ = nullptr, evk1_ = nullptr;
-  int kernel_times(double* ms_out, int cap);
+  int kernel_times(double* ms_out, int cap) override;
   int64_t deleted_bytes_ = 0;   // length of the bitset behind d_deleted_
   int64_t fcol_rows_ = 0;       // rows the attribute column behind d_fcol_ covers
 
-  std::string err_;
   eps_search_stats stats_{};
 
  private:
@@ -146,5 +175,8 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
 int32_t graph_build(Index& ix, int64_t n, const eps_build_params& p);
 
 bool is_device_ptr(const void* p);
+
+// hash-sharded table over several devices of one process (shard_group.cpp)
+IndexBase* make_shard_group(int64_t dim, int metric, const int32_t* devices, int32_t shards, std::string* err);
 
 }  // namespace eps

@@ -1,0 +1,262 @@
+// Hash-sharded index over several GPUs of ONE process (north_star: "the corpus is hash-sharded across the
+// 8 GPUs of one node with per-shard top-k merged").  The reference DBMS is a single process, so this is the form its
+// drop-in executor uses: G per-device indices (one per shard, each with its own stream and scratch), row i of the table
+// lives on shard i mod G as local row i / G (global id = local*G + shard via the id map), every shard answers the
+// whole query batch on its rows concurrently, the per-shard [nq][k] (id, dist) lists are pushed to shard 0's device over
+// xGMI with hipMemcpyPeerAsync (peer-to-peer, no host hop) and merged there by the same k-way merge kernel the
+// one-process-per-GPU form runs after its RCCL all-gather (bench.py).  There is no other exchange step.
+//
+// All eps_index_* entry points work on the handle eps_index_create_sharded returns.  Host pointers only (a sharded table
+// is ingested from the DBMS's host column; each shard reads its rows with one strided copy, nothing is re-packed).
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <thread>
+#include <vector>
+
+#include "index.hpp"
+
+namespace eps {
+
+namespace {
+
+class ShardGroup : public IndexBase {
+ public:
+  ShardGroup(int64_t dim, int metric) : dim_(dim), metric_(metric) {}
+  ~ShardGroup() override {
+    const int dev0 = shard_.empty() ? 0 : shard_[0]->device_;
+    free_on(dev0, gathered_);
+    free_on(dev0, m_ids_);
+    free_on(dev0, m_dist_);
+  }
+
+  int32_t init(const int32_t* devices, int32_t shards, std::string* err) {
+    for (int s = 0; s < shards; ++s) {
+      std::unique_ptr<Index> ix(new Index(dim_, metric_, devices[s]));
+      const int32_t rc = ix->init();
+      if (rc != EPS_OK) {
+        *err = std::string("shard ") + std::to_string(s) + ": " + ix->last_error();
+        return rc;
+      }
+      ix->set_id_map(s, shards);
+      shard_.push_back(std::move(ix));
+    }
+    // peer access between shard 0's device (where the merge runs) and the others; failure is not fatal (copies are staged)
+    for (int s = 1; s < shards; ++s)
+      if (devices[s] != devices[0]) {
+        (void)hipSetDevice(devices[0]);
+        (void)hipDeviceEnablePeerAccess(devices[s], 0);
+        (void)hipSetDevice(devices[s]);
+        (void)hipDeviceEnablePeerAccess(devices[0], 0);
+        (void)hipGetLastError();
+      }
+    return EPS_OK;
+  }
+
+  int G() const { return (int)shard_.size(); }
+  int64_t rows_of(int s, int64_t n) const { return n > s ? (n - s + G() - 1) / G() : 0; }
+
+  template <class F>
+  int32_t each(F&& f) {   // f(s, Index&) on every shard, concurrently; first error wins
+    std::vector<int32_t> rc((size_t)G(), EPS_OK);
+    std::vector<std::thread> th;
+    for (int s = 0; s < G(); ++s) th.emplace_back([&, s]() {
+      try {
+        rc[s] = f(s, *shard_[s]);
+      } catch (const std::exception& e) {
+        rc[s] = shard_[s]->fail(EPS_DB_UNEXPECTED_ERROR, e.what());
+      }
+    });
+    for (auto& t : th) t.join();
+    for (int s = 0; s < G(); ++s)
+      if (rc[s] != EPS_OK) return fail(rc[s], "shard " + std::to_string(s) + ": " + shard_[s]->last_error());
+    return EPS_OK;
+  }
+
+  int32_t set_stream(void*) override { return fail(EPS_DB_UNSUPPORTED_ERROR, "sharded index: every shard runs on its own stream"); }
+  int32_t synchronize() override {
+    return each([](int, Index& ix) { return ix.synchronize(); });
+  }
+  int32_t attach_rows(const float* rows, int64_t n) override {
+    if (n < 0 || (n > 0 && !rows)) return fail(EPS_USER_ERROR, "attach_rows: bad arguments");
+    if (is_device_ptr(rows)) return fail(EPS_DB_UNSUPPORTED_ERROR, "sharded index: rows are ingested from host memory");
+    const int32_t rc = each([&](int s, Index& ix) { return ix.attach_rows_strided(rows + (int64_t)s * dim_, rows_of(s, n), (int64_t)G() * dim_); });
+    if (rc == EPS_OK) n_rows_ = n;
+    return rc;
+  }
+  int32_t append_rows(const float* rows, int64_t n_new) override {
+    if (n_new < 0 || (n_new > 0 && !rows)) return fail(EPS_USER_ERROR, "append_rows: bad arguments");
+    if (is_device_ptr(rows)) return fail(EPS_DB_UNSUPPORTED_ERROR, "sharded index: rows are ingested from host memory");
+    // global row n_rows_ + j goes to shard (n_rows_ + j) mod G
+    const int64_t n0 = n_rows_;
+    const int32_t rc = each([&](int s, Index& ix) {
+      const int64_t first = ((s - n0) % G() + G()) % G();   // first j with (n0 + j) mod G == s
+      const int64_t cnt = n_new > first ? (n_new - first + G() - 1) / G() : 0;
+      return cnt ? ix.append_rows_strided(rows + first * dim_, cnt, (int64_t)G() * dim_) : EPS_OK;
+    });
+    if (rc == EPS_OK) n_rows_ += n_new;
+    return rc;
+  }
+  int32_t set_id_map(int64_t, int64_t) override { return fail(EPS_DB_UNSUPPORTED_ERROR, "sharded index: the id map is the sharding itself"); }
+  int32_t set_deleted(const uint8_t* bits, int64_t nbytes) override {
+    if (!bits || nbytes <= 0) return each([](int, Index& ix) { return ix.set_deleted(nullptr, 0); });
+    if (is_device_ptr(bits)) return fail(EPS_DB_UNSUPPORTED_ERROR, "sharded index: the deleted bitset comes from host memory");
+    if (nbytes < (n_rows_ + 7) / 8) return fail(EPS_USER_ERROR, "set_deleted: bitset shorter than ceil(rows/8) bytes");
+    return each([&](int s, Index& ix) {   // bit i of the table = bit i / G of shard i mod G
+      const int64_t ns = rows_of(s, n_rows_);
+      std::vector<uint8_t> local((size_t)(ns + 7) / 8, 0);
+      for (int64_t l = 0; l < ns; ++l) {
+        const int64_t i = l * G() + s;
+        if ((bits[i >> 3] >> (i & 7)) & 1) local[l >> 3] |= uint8_t(1u << (l & 7));
+      }
+      return ix.set_deleted(local.empty() ? nullptr : local.data(), (int64_t)local.size());
+    });
+  }
+  int32_t set_int_filter(const void* column, int64_t stride, int32_t width, int32_t op, int64_t constant) override {
+    if (op == EPS_OP_NONE || !column) return each([](int, Index& ix) { return ix.set_int_filter(nullptr, 0, 0, EPS_OP_NONE, 0); });
+    if (is_device_ptr(column)) return fail(EPS_DB_UNSUPPORTED_ERROR, "sharded index: filter columns come from host memory");
+    return each([&](int s, Index& ix) {   // the shard's rows are every G-th row of the column: same memory, G x the stride
+      return ix.set_int_filter(static_cast<const char*>(column) + (int64_t)s * stride, stride * G(), width, op, constant);
+    });
+  }
+  int32_t set_filter_program(const eps_filter_op* ops, int32_t nops, const void* rows, int64_t stride, int64_t n_rows) override {
+    if (nops <= 0 || !ops) return each([](int, Index& ix) { return ix.set_filter_program(nullptr, 0, nullptr, 0, 0); });
+    if (!rows || is_device_ptr(rows)) return fail(EPS_DB_UNSUPPORTED_ERROR, "sharded index: attribute rows come from host memory");
+    return each([&](int s, Index& ix) {
+      return ix.set_filter_program(ops, nops, static_cast<const char*>(rows) + (int64_t)s * stride, stride * G(), rows_of(s, n_rows));
+    });
+  }
+  int32_t build(int64_t n, const eps_build_params* p) override {   // every shard builds the graph of its own rows
+    if (n < 0 || n > n_rows_) return fail(EPS_USER_ERROR, "build: n exceeds the attached rows");
+    return each([&](int s, Index& ix) { return ix.build(rows_of(s, n), p); });
+  }
+  int32_t set_graph(int64_t, const int64_t*, const int64_t*, int64_t) override {
+    return fail(EPS_DB_UNSUPPORTED_ERROR, "sharded index: a graph over the whole table cannot be split; build per shard (eps_index_build) or load per-shard files");
+  }
+  int32_t graph_info(int64_t* n, int64_t* edges, int64_t* nav) const override {
+    int64_t tn = 0, te = 0;
+    for (auto& ix : shard_) {
+      int64_t a = 0, b = 0, c = 0;
+      ix->graph_info(&a, &b, &c);
+      tn += a;
+      te += b;
+    }
+    if (n) *n = tn;
+    if (edges) *edges = te;
+    if (nav) *nav = -1;
+    return EPS_OK;
+  }
+  int32_t get_graph(int64_t*, int64_t*) const override { return EPS_DB_UNSUPPORTED_ERROR; }
+  int32_t save_graph(const char* path) override {   // <path>.shard<s>, each in the reference's ann_graph file format
+    if (!path) return fail(EPS_USER_ERROR, "save_graph: null path");
+    return each([&](int s, Index& ix) { return ix.save_graph((std::string(path) + ".shard" + std::to_string(s)).c_str()); });
+  }
+  int32_t load_graph(const char* path) override {
+    if (!path) return fail(EPS_USER_ERROR, "load_graph: null path");
+    return each([&](int s, Index& ix) { return ix.load_graph((std::string(path) + ".shard" + std::to_string(s)).c_str()); });
+  }
+
+  int32_t search(const float* queries, int64_t nq, int32_t k, const eps_search_params* pp, int64_t* ids, float* dist, int32_t* counts,
+                 int32_t walk_limit) override {
+    if (nq < 0 || k <= 0) return fail(EPS_USER_ERROR, "search: nq must be >= 0 and k > 0");
+    if (nq == 0) return EPS_OK;
+    if (!queries || !ids || !dist) return fail(EPS_USER_ERROR, "search: null buffer");
+    if (is_device_ptr(queries) || is_device_ptr(ids)) return fail(EPS_DB_UNSUPPORTED_ERROR, "sharded index: queries and results live in host memory");
+    if (walk_limit) return fail(EPS_DB_UNSUPPORTED_ERROR, "sharded index: candidate walks are per index");
+    const int dev0 = shard_[0]->device_;
+    const size_t nk = (size_t)nq * k;
+    // per-shard results stay on the shard's device; they are pushed to shard 0's device and merged there
+    if (hipSetDevice(dev0) != hipSuccess) return fail(EPS_INFRA_UNEXPECTED_ERROR, "hipSetDevice");
+    if (nk > cap_) {
+      free_on(dev0, m_ids_);
+      free_on(dev0, m_dist_);
+      free_on(dev0, gathered_);
+      // one gathered buffer: [G][ids int64[nk] | dist f32[nk]] (the layout eps_merge_topk_packed takes)
+      stride_ = (nk * 12 + 7) / 8 * 8;
+      if (hipMalloc(&gathered_, stride_ * G()) != hipSuccess || hipMalloc(&m_ids_, nk * 8) != hipSuccess || hipMalloc(&m_dist_, nk * 4) != hipSuccess)
+        return fail(EPS_INFRA_UNEXPECTED_ERROR, "search: out of device memory (shard merge)");
+      cap_ = nk;
+    }
+    local_ids_.resize((size_t)G());
+    local_dist_.resize((size_t)G());
+    local_cnt_.resize((size_t)G());
+    int32_t rc = each([&](int s, Index& ix) -> int32_t {
+      if (hipSetDevice(ix.device_) != hipSuccess) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "hipSetDevice");
+      if (!local_ids_[s].reserve(nk * 8) || !local_dist_[s].reserve(nk * 4) || !local_cnt_[s].reserve((size_t)nq * 4))
+        return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "search: out of device memory");
+      int32_t r = ix.search(queries, nq, k, pp, local_ids_[s].as<int64_t>(), local_dist_[s].as<float>(), local_cnt_[s].as<int32_t>());
+      if (r != EPS_OK) return r;
+      // the one exchange step: this shard's [nq][k] lists -> shard 0's device, peer to peer over xGMI
+      char* dst = static_cast<char*>(gathered_) + (size_t)s * stride_;
+      hipError_t e = hipMemcpyPeerAsync(dst, dev0, local_ids_[s].p, ix.device_, nk * 8, ix.stream_);
+      if (e == hipSuccess) e = hipMemcpyPeerAsync(dst + nk * 8, dev0, local_dist_[s].p, ix.device_, nk * 4, ix.stream_);
+      if (e == hipSuccess) e = hipStreamSynchronize(ix.stream_);
+      return e == hipSuccess ? EPS_OK : ix.hip_fail(e, "peer copy of the shard's top-k");
+    });
+    if (rc != EPS_OK) return rc;
+    if (hipSetDevice(dev0) != hipSuccess) return fail(EPS_INFRA_UNEXPECTED_ERROR, "hipSetDevice");
+    hipStream_t s0 = shard_[0]->stream_;
+    launch_merge_shards(reinterpret_cast<const float*>(static_cast<char*>(gathered_) + nk * 8), static_cast<const int64_t*>(gathered_), G(), nq, k,
+                        static_cast<float*>(m_dist_), static_cast<int64_t*>(m_ids_), s0, (int64_t)stride_);
+    hipError_t e = hipMemcpyAsync(ids, m_ids_, nk * 8, hipMemcpyDeviceToHost, s0);
+    if (e == hipSuccess) e = hipMemcpyAsync(dist, m_dist_, nk * 4, hipMemcpyDeviceToHost, s0);
+    if (e == hipSuccess) e = hipStreamSynchronize(s0);
+    if (e != hipSuccess) return fail(EPS_INFRA_UNEXPECTED_ERROR, std::string("shard merge: ") + hipGetErrorString(e));
+    if (counts)
+      for (int64_t q = 0; q < nq; ++q) {
+        int32_t c = 0;
+        while (c < k && ids[q * k + c] >= 0) ++c;
+        counts[q] = c;
+      }
+    return EPS_OK;
+  }
+
+  int64_t row_count() const override { return n_rows_; }
+  int32_t last_stats(eps_search_stats* out) override {   // counters summed over the shards, times = the slowest shard
+    eps_search_stats t;
+    std::memset(&t, 0, sizeof(t));
+    for (auto& ix : shard_) {
+      eps_search_stats s;
+      ix->last_stats(&s);
+      t.dist_evals += s.dist_evals;
+      t.expansions += s.expansions;
+      t.rerank_rows += s.rerank_rows;
+      t.overflow_queries += s.overflow_queries;
+      t.kernel_ms = std::max(t.kernel_ms, s.kernel_ms);
+      t.main_kernel_ms = std::max(t.main_kernel_ms, s.main_kernel_ms);
+      t.main_kernel_launches += s.main_kernel_launches;
+      t.main_kernel_rows += s.main_kernel_rows;
+      t.main_kernel_queries = std::max(t.main_kernel_queries, s.main_kernel_queries);
+    }
+    *out = t;
+    return EPS_OK;
+  }
+  int kernel_times(double* ms_out, int cap) override { return shard_[0]->kernel_times(ms_out, cap); }
+
+ private:
+  static void free_on(int dev, void*& p) {
+    if (!p) return;
+    (void)hipSetDevice(dev);
+    (void)hipFree(p);
+    p = nullptr;
+  }
+  int64_t dim_;
+  int metric_;
+  int64_t n_rows_ = 0;
+  std::vector<std::unique_ptr<Index>> shard_;
+  std::vector<DevBuf> local_ids_, local_dist_, local_cnt_;
+  void* gathered_ = nullptr;
+  void* m_ids_ = nullptr;
+  void* m_dist_ = nullptr;
+  size_t cap_ = 0, stride_ = 0;
+};
+
+}  // namespace
+
+IndexBase* make_shard_group(int64_t dim, int metric, const int32_t* devices, int32_t shards, std::string* err) {
+  std::unique_ptr<ShardGroup> g(new ShardGroup(dim, metric));
+  if (g->init(devices, shards, err) != EPS_OK) return nullptr;
+  return g.release();
+}
+
+}  // namespace eps

@@ -41,13 +41,19 @@ def GetDistFunc(field_type="VECTOR_FLOAT", metric_type="EUCLIDEAN"):
 
 
 class GpuIndex:
-    def __init__(self, dim, metric="EUCLIDEAN", device=0):
+    def __init__(self, dim, metric="EUCLIDEAN", device=0, devices=None):
+        """devices = [d0, d1, ...]: a hash-sharded index over those GPUs of this process (eps_index_create_sharded; host buffers
+        only); otherwise one index on `device`."""
         self.L = lib.load()
         self.dim = int(dim)
         self.metric = METRICS[metric]
-        self.device = device
+        self.device = device if devices is None else devices[0]
         h = C.c_void_p()
-        rc = self.L.eps_index_create(self.dim, self.metric, device, C.byref(h))
+        if devices is not None:
+            arr = (C.c_int32 * len(devices))(*devices)
+            rc = self.L.eps_index_create_sharded(self.dim, self.metric, arr, len(devices), C.byref(h))
+        else:
+            rc = self.L.eps_index_create(self.dim, self.metric, device, C.byref(h))
         if rc != 0:
             raise EpsillaError(rc, "eps_index_create failed (no gfx950 device? there is no CPU fallback)")
         self.h = h
