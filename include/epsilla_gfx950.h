@@ -202,6 +202,13 @@ int32_t eps_index_set_filter_program(eps_index* h, const eps_filter_op* ops, int
 
 /* graph over rows [0,n): built on the device, or supplied / exported as the reference's CSR */
 int32_t eps_index_build(eps_index* h, int64_t n, const eps_build_params* p);
+/* One stage of the build on its own: NsgIndex::SyncPrune's sort + SelectEdge (db/index/nsg/nsg.cpp:557-567, 655-685) for
+ * caller-supplied candidate lists.  Node nodes[i] with candidates cands[i][0..cands_per_node) (-1 = none; the node itself is
+ * skipped): candidates sorted by (L2 distance to the node, id), the closest kept, every further one of the first `depth`
+ * (candidate_pool_size; <= 0 = all) kept iff no kept neighbour is closer to it than the node is (MRNG rule), at most out_degree.
+ * out_ids [m][out_degree] (-1 padded), out_deg [m]; host arrays. */
+int32_t eps_index_select_edges(eps_index* h, const int64_t* nodes, int64_t m, const int64_t* cands, int32_t cands_per_node,
+                               int32_t depth, int32_t out_degree, int64_t* out_ids, int32_t* out_deg);
 int32_t eps_index_set_graph(eps_index* h, int64_t n, const int64_t* offsets, const int64_t* neighbors,
                             int64_t navigation_point);
 int32_t eps_index_graph_info(const eps_index* h, int64_t* n, int64_t* edges, int64_t* navigation_point);

@@ -739,6 +739,43 @@ static void select_edge(nsg_t* s, int64_t* cursor, eo_nb* pool, int64_t pool_n, 
   }
 }
 
+/* SyncPrune's sort + SelectEdge on a caller-supplied candidate list (nsg.cpp:557-567, 655-685): distances node->candidate,
+ * stable sort by distance, the node itself skipped if it sorts first, result = [closest] + SelectEdge(limit = depth > 0).
+ * Returns the number of ids written to out (<= out_degree). */
+int64_t eo_select_edge(const float* rows, int64_t d, int64_t node, const int64_t* cands, int64_t m, int64_t depth, int64_t out_degree,
+                       int64_t* out) {
+  nsg_t s;
+  memset(&s, 0, sizeof(s));
+  s.rows = rows;
+  s.d = d;
+  s.out_degree = out_degree;
+  s.cand_pool = depth;
+  eo_nb* pool = (eo_nb*)malloc(sizeof(eo_nb) * (size_t)(m > 0 ? m : 1));
+  int64_t pn = 0;
+  for (int64_t i = 0; i < m; ++i) {
+    if (cands[i] < 0) continue;
+    pool[pn].id = cands[i];
+    pool[pn].dist = eo_fvec_l2sqr(rows + node * d, rows + cands[i] * d, d);
+    pool[pn].flag = 1;
+    ++pn;
+  }
+  int64_t rn = 0;
+  if (pn > 0) {
+    nb_sort(pool, pn);
+    int64_t cursor = 0;
+    if (pool[cursor].id == node) ++cursor;
+    if (cursor < pn) {
+      eo_nb* result = (eo_nb*)malloc(sizeof(eo_nb) * (size_t)(out_degree + 1));
+      result[rn++] = pool[cursor];
+      select_edge(&s, &cursor, pool, pn, result, &rn, depth > 0);
+      for (int64_t i = 0; i < rn; ++i) out[i] = result[i].id;
+      free(result);
+    }
+  }
+  free(pool);
+  return rn;
+}
+
 static int64_t g_nsg_n = 0;
 static ivec* g_nsg = NULL;
 static int64_t g_nsg_nav = 0;

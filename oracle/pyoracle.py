@@ -106,6 +106,8 @@ class Oracle:
         L.eo_knn_exact.argtypes = [C.c_int, fptr, i64, i64, i64, iptr]
         L.eo_nsg_build.restype = i64
         L.eo_nsg_build.argtypes = [fptr, i64, i64, iptr, i64, i64, i64, i64, C.c_uint]
+        L.eo_select_edge.restype = i64
+        L.eo_select_edge.argtypes = [fptr, i64, i64, iptr, i64, i64, i64, iptr]
         L.eo_nsg_fetch.restype = i64
         L.eo_nsg_fetch.argtypes = [iptr, iptr]
         L.eo_graph_file_write.argtypes = [C.c_char_p, i64, i64, iptr, iptr, i64]
@@ -217,6 +219,13 @@ class Oracle:
         nav = self.L.eo_nsg_fetch(_i(off), _i(nbr))
         return off, nbr[:e], nav
 
+    def select_edge(self, rows, node, cands, depth=300, out_degree=50):
+        rows = np.ascontiguousarray(rows, np.float32)
+        cands = np.ascontiguousarray(cands, np.int64)
+        out = np.empty(out_degree, np.int64)
+        m = self.L.eo_select_edge(_f(rows), rows.shape[1], node, _i(cands), len(cands), depth, out_degree, _i(out))
+        return out[:m].copy()
+
     def build_graph(self, metric, rows, K=100, **kw):
         """BuildFromVectorTable (ann_graph_segment.cpp:201-242) with exact kNN in place of NN-Descent."""
         K = min(K, rows.shape[0] - 1)
@@ -295,6 +304,8 @@ class Ref:
         L.ref_knn_graph.argtypes = [fptr, i64, i64, i64, C.c_int, C.c_int, iptr]
         L.ref_nsg_from_knn.restype = vp
         L.ref_nsg_from_knn.argtypes = [fptr, i64, i64, iptr, i64, i64, i64, i64, C.c_int, C.c_uint]
+        L.ref_select_edge.restype = i64
+        L.ref_select_edge.argtypes = [fptr, i64, i64, i64, iptr, i64, i64, i64, iptr]
         L.ref_executor_new.restype = vp
         L.ref_executor_new.argtypes = [vp, fptr, i64, C.c_int, C.c_int, i64, i64, i64, C.c_int]
         L.ref_executor_init_ids.argtypes = [vp, iptr]
@@ -375,6 +386,13 @@ class Ref:
         knn = np.ascontiguousarray(knn, np.int64)
         return self.L.ref_nsg_from_knn(_f(rows), rows.shape[0], rows.shape[1], _i(knn), knn.shape[1], search_length,
                                        out_degree, cand_pool, threads, seed)
+
+    def select_edge(self, rows, node, cands, depth=300, out_degree=50):
+        rows = np.ascontiguousarray(rows, np.float32)
+        cands = np.ascontiguousarray(cands, np.int64)
+        out = np.empty(out_degree, np.int64)
+        m = self.L.ref_select_edge(_f(rows), rows.shape[0], rows.shape[1], node, _i(cands), len(cands), depth, out_degree, _i(out))
+        return out[:m].copy()
 
     def executor(self, g, rows, metric=0, T=1, L=500, Lq=None, I=15, count=False):
         Lq = L if Lq is None else Lq

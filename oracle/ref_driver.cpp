@@ -177,6 +177,41 @@ void* ref_nsg_from_knn(float* rows, int64_t n, int64_t d, const int64_t* knn, in
   return g;
 }
 
+// The reference's own SyncPrune tail (sort + closest) and SelectEdge (nsg.cpp:557-567, 655-685, protected members) on a
+// caller-supplied candidate list: pins eo_select_edge and, through it, the device's prune kernel.
+namespace {
+struct NsgOpen : vectordb::engine::index::NsgIndex {
+  using NsgIndex::NsgIndex;
+  using NsgIndex::SelectEdge;
+};
+}  // namespace
+int64_t ref_select_edge(float* rows, int64_t n, int64_t d, int64_t node, const int64_t* cands, int64_t m, int64_t depth, int64_t out_degree,
+                        int64_t* out) {
+  using vectordb::engine::index::Neighbor;
+  NsgOpen idx(d, n, vectordb::engine::index::NsgIndex::Metric_Type_L2);
+  idx.ori_data_ = rows;
+  idx.ids_ = nullptr;   // (left uninitialised by the constructor, deleted by the destructor)
+  idx.ntotal = n;
+  idx.out_degree = out_degree;
+  idx.candidate_pool_size = depth > 0 ? depth : 0;
+  std::vector<Neighbor> pool;
+  for (int64_t i = 0; i < m; ++i) {
+    if (cands[i] < 0) continue;
+    const float dist = idx.distance_->Compare(rows + node * d, rows + cands[i] * d, d);
+    pool.emplace_back(Neighbor(cands[i], dist, true));
+  }
+  if (pool.empty()) return 0;
+  std::stable_sort(pool.begin(), pool.end());   // (the reference's std::sort is unstable on equal distances; inputs are tie-free)
+  unsigned cursor = 0;
+  if (pool[cursor].id == static_cast<vectordb::engine::index::node_t>(node)) cursor++;
+  if (cursor >= pool.size()) return 0;
+  std::vector<Neighbor> result;
+  result.push_back(pool[cursor]);
+  idx.SelectEdge(cursor, pool, result, depth > 0);
+  for (size_t i = 0; i < result.size(); ++i) out[i] = result[i].id;
+  return (int64_t)result.size();
+}
+
 // ---------------------------------------------------------------- executor (graph search only)
 void* ref_executor_new(void* graph, float* rows, int64_t d, int metric, int T, int64_t L_master, int64_t L_local,
                        int64_t iters, int count_dists) {

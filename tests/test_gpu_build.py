@@ -135,3 +135,34 @@ def test_build_100k_mfma_knn_path(amd):
     print("recall@10 at L=500 on 100k x 64:", r)
     assert r >= 0.95
     ix.close()
+
+
+def test_device_select_edge_equals_oracle_on_identical_pools(amd, oracle):
+    """Like-for-like build parity of the stage that is deterministic given its input: the device prune kernel (sort by (dist,id)
+    + MRNG rule, csrc/graph_build.hip) against the oracle's SelectEdge - itself pinned bit-exactly to the reference's member
+    (test_oracle_vs_ref::test_select_edge_bit_exact) - on identical candidate pools: random pools, and the real pools of a
+    build (exact kNN lists, the pool SyncPrune starts from)."""
+    n, d = 5000, 32
+    X = data(n, d, 17)
+    ix = amd.GpuIndex(d, 0)
+    ix.attach_rows(X)
+    rng = np.random.default_rng(18)
+    nodes = np.arange(0, 600, 3, dtype=np.int64)
+    for cpn, depth, R in ((420, 300, 50), (420, 0, 50), (120, 300, 50), (64, 40, 8)):
+        cands = np.stack([rng.choice(n, size=cpn, replace=False) for _ in nodes]).astype(np.int64)
+        cands[:, 0] = nodes
+        cands[::5, -3:] = -1                                   # ragged lists
+        ids, deg = ix.select_edges(nodes, cands, depth=depth, out_degree=R)
+        for i, v in enumerate(nodes):
+            want = oracle.select_edge(X, int(v), cands[i], depth, R)
+            assert int(deg[i]) == len(want) and list(ids[i][:deg[i]]) == list(want), (cpn, depth, R, int(v))
+    knn = oracle.knn_exact(0, X[:1200], 100)                   # pools as Link sees them: the K = 100 nearest neighbours
+    ix2 = amd.GpuIndex(d, 0)
+    ix2.attach_rows(X[:1200])
+    nodes = np.arange(1200, dtype=np.int64)
+    ids, deg = ix2.select_edges(nodes, knn, depth=300, out_degree=50)
+    for v in range(0, 1200, 7):
+        want = oracle.select_edge(X[:1200], v, knn[v], 300, 50)
+        assert list(ids[v][:deg[v]]) == list(want), v
+    ix.close()
+    ix2.close()

@@ -228,3 +228,17 @@ def test_dbserver_graph_plus_tail_matches_oracle(oracle, ref, tmp_path):
             assert [r["@distance"] for r in res] == [float(x) for x in ds]
     ref.L.ref_config(4, 500, 1, 0, 16)
     db.close()
+
+
+def test_select_edge_bit_exact(oracle, ref):
+    """SyncPrune's sort + SelectEdge (nsg.cpp:557-567, 655-685) on identical candidate pools: the restatement equals the
+    reference's own (protected) member, with and without the candidate_pool_size limit and for small out-degrees."""
+    rng = np.random.default_rng(3)
+    X = rng.random((4000, 24), dtype=np.float32)
+    for node in range(0, 400, 11):
+        cands = rng.choice(4000, size=420, replace=False).astype(np.int64)
+        cands[0] = node
+        for depth, R in ((300, 50), (0, 50), (300, 8), (40, 50)):
+            a = oracle.select_edge(X, node, cands, depth, R)
+            b = ref.select_edge(X, node, cands, depth, R)
+            assert np.array_equal(a, b), (node, depth, R)

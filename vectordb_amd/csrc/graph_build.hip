@@ -78,6 +78,7 @@ struct PruneArgs {
   const float* rows;
   int dim;
   int64_t v0;             // first node of this launch (node = v0 + blockIdx.x)
+  const u32* node_ids;    // optional: node = node_ids[blockIdx.x]; listB and the outputs are then indexed by blockIdx.x
   const u64* log;         // A: [nb][log_cap] plain (dist,id) keys, indexed by blockIdx.x; may be null
   const u32* log_cnt;
   int log_cap;
@@ -111,7 +112,8 @@ __global__ __launch_bounds__(256) void prune_kernel(PruneArgs a) {
   const int tid = threadIdx.x;
   const int lane = lane_id();
   const int wave = tid >> 6;
-  const int64_t v = a.v0 + blockIdx.x;
+  const int64_t v = a.node_ids ? (int64_t)a.node_ids[blockIdx.x] : a.v0 + blockIdx.x;
+  const int64_t vrow = a.node_ids ? (int64_t)blockIdx.x : v;   // row of listB / the outputs
   const int G = group_lanes(dim, VEC4);
   const int RPW = 64 / G;
   const int g = lane / G;
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(256) void prune_kernel(PruneArgs a) {
   }
   __syncthreads();
   if (a.listB) {  // "avoid lose nearest neighbor in knng" (nsg.cpp:542-557): distances to the kNN list of v
-    const u32* lst = a.listB + v * a.degB;
+    const u32* lst = a.listB + vrow * a.degB;
     const int base = sh[0];
     for (int c0 = wave * RPW * U; c0 < a.degB; c0 += 4 * RPW * U) {
       const float* rp[U];
@@ -265,10 +267,10 @@ __global__ __launch_bounds__(256) void prune_kernel(PruneArgs a) {
   }
   const int nk = sh[1];
   for (int i = tid; i < a.R; i += 256) {
-    a.out_ids[v * a.R + i] = i < nk ? kept[i] : TRV_NONE;
-    a.out_dist[v * a.R + i] = i < nk ? keptd[i] : 0.f;
+    a.out_ids[vrow * a.R + i] = i < nk ? kept[i] : TRV_NONE;
+    a.out_dist[vrow * a.R + i] = i < nk ? keptd[i] : 0.f;
   }
-  if (tid == 0) a.out_deg[v] = (u32)nk;
+  if (tid == 0) a.out_deg[vrow] = (u32)nk;
 }
 
 // reverse edges: for every edge v->u offer v to u (InterInsert, nsg.cpp:583-653)
@@ -633,6 +635,63 @@ int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp) {
             (long long)n, (long long)e, (double)e / n, maxdeg, n_orphans, extra.size(), (long long)nav);
   }
   return ix.set_graph(n, off.data(), nbr.data(), nav);
+}
+
+// SyncPrune's sort + SelectEdge (nsg.cpp:557-567, 655-685) for caller-supplied candidate lists: node nodes[i] with
+// candidates cands[i][0..cands_per_node) (-1 = none; the node itself is skipped) -> its <= out_degree pruned out-edges.
+// The stage of the build that is deterministic given its input, exposed so that it can be pinned against the reference's
+// SelectEdge on identical pools (tests/test_gpu_build.py).
+int32_t select_edges(Index& ix, const int64_t* nodes, int64_t m, const int64_t* cands, int32_t cpn, int32_t depth, int32_t R,
+                     int64_t* out_ids, int32_t* out_deg) {
+  if (m <= 0) return EPS_OK;
+  if (!nodes || !cands || !out_ids || !out_deg || cpn <= 0 || cpn > PRUNE_POOL || R <= 0 || R > 512)
+    return ix.fail(EPS_USER_ERROR, "select_edges: bad arguments");
+  hipStream_t s = ix.stream_;
+  const int dim = (int)ix.dim_;
+  std::vector<u32> h_nodes((size_t)m), h_c((size_t)m * cpn);
+  for (int64_t i = 0; i < m; ++i) {
+    if (nodes[i] < 0 || nodes[i] >= ix.n_rows_) return ix.fail(EPS_USER_ERROR, "select_edges: node out of range");
+    h_nodes[i] = (u32)nodes[i];
+    for (int j = 0; j < cpn; ++j) {
+      const int64_t c = cands[i * cpn + j];
+      if (c >= ix.n_rows_) return ix.fail(EPS_USER_ERROR, "select_edges: candidate out of range");
+      h_c[(size_t)i * cpn + j] = c < 0 ? TRV_NONE : (u32)c;
+    }
+  }
+  DevBuf d_nodes, d_c, d_oi, d_od, d_deg;
+  if (!d_nodes.reserve((size_t)m * 4) || !d_c.reserve((size_t)m * cpn * 4) || !d_oi.reserve((size_t)m * R * 4) || !d_od.reserve((size_t)m * R * 4) ||
+      !d_deg.reserve((size_t)m * 4))
+    return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "select_edges: out of device memory");
+  HIPCHK(hipMemcpyAsync(d_nodes.p, h_nodes.data(), (size_t)m * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(d_c.p, h_c.data(), (size_t)m * cpn * 4, hipMemcpyHostToDevice, s));
+  PruneArgs pa;
+  std::memset(&pa, 0, sizeof(pa));
+  pa.rows = ix.d_rows_;
+  pa.dim = dim;
+  pa.node_ids = d_nodes.as<u32>();
+  pa.listB = d_c.as<u32>();
+  pa.degB = cpn;
+  pa.depth = depth;
+  pa.R = R;
+  pa.out_ids = d_oi.as<u32>();
+  pa.out_dist = d_od.as<float>();
+  pa.out_deg = d_deg.as<u32>();
+  const bool vec4 = (dim % 4 == 0) && ((reinterpret_cast<uintptr_t>(ix.d_rows_) & 15) == 0);
+  const size_t shm = prune_lds_bytes(dim, R);
+  if (vec4)
+    hipLaunchKernelGGL((prune_kernel<true>), dim3((unsigned)m), dim3(256), shm, s, pa);
+  else
+    hipLaunchKernelGGL((prune_kernel<false>), dim3((unsigned)m), dim3(256), shm, s, pa);
+  HIPCHK(hipGetLastError());
+  std::vector<u32> h_oi((size_t)m * R), h_deg((size_t)m);
+  HIPCHK(hipMemcpyAsync(h_oi.data(), d_oi.p, (size_t)m * R * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(h_deg.data(), d_deg.p, (size_t)m * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  for (int64_t i = 0; i < m; ++i) {
+    out_deg[i] = (int32_t)h_deg[i];
+    for (int j = 0; j < R; ++j) out_ids[i * R + j] = (u32)j < h_deg[i] ? (int64_t)h_oi[(size_t)i * R + j] : -1;
+  }
+  return EPS_OK;
 }
 
 }  // namespace eps

@@ -747,6 +747,18 @@ int32_t eps_index_search_walk(eps_index* h, const float* q, int64_t nq, int32_t 
   if (limit <= 0 || cap < limit) return EPS_USER_ERROR;
   GUARD(h, IX(h)->search(q, nq, cap, p, ids, dist, counts, limit));
 }
+int32_t eps_index_select_edges(eps_index* h, const int64_t* nodes, int64_t m, const int64_t* cands, int32_t cands_per_node, int32_t depth,
+                               int32_t out_degree, int64_t* out_ids, int32_t* out_deg) {
+  if (!h) return EPS_USER_ERROR;
+  Index* ix = dynamic_cast<Index*>(IX(h));
+  if (!ix) return IX(h)->fail(EPS_DB_UNSUPPORTED_ERROR, "select_edges: single-device indices only");
+  try {
+    if (hipSetDevice(ix->device_) != hipSuccess) return ix->fail(EPS_INFRA_UNEXPECTED_ERROR, "hipSetDevice");
+    return eps::select_edges(*ix, nodes, m, cands, cands_per_node, depth, out_degree, out_ids, out_deg);
+  } catch (...) {
+    return map_exception(ix);
+  }
+}
 int32_t eps_index_build(eps_index* h, int64_t n, const eps_build_params* p) { GUARD(h, IX(h)->build(n, p)); }
 int32_t eps_index_set_graph(eps_index* h, int64_t n, const int64_t* off, const int64_t* nbr, int64_t nav) {
   GUARD(h, IX(h)->set_graph(n, off, nbr, nav));

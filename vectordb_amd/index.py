@@ -198,6 +198,15 @@ class GpuIndex:
             setattr(bp, k_, v)
         self._check(self.L.eps_index_build(self.h, self.row_count if n is None else n, C.byref(bp)))
 
+    def select_edges(self, nodes, cands, depth=300, out_degree=50):
+        """SyncPrune's sort + SelectEdge for given candidate lists (eps_index_select_edges); returns (ids [m][R] -1 padded, deg [m])"""
+        nodes = np.ascontiguousarray(nodes, np.int64)
+        cands = np.ascontiguousarray(cands, np.int64)
+        out = np.empty((len(nodes), out_degree), np.int64)
+        deg = np.empty(len(nodes), np.int32)
+        self._check(self.L.eps_index_select_edges(self.h, _ptr(nodes), len(nodes), _ptr(cands), cands.shape[1], depth, out_degree, _ptr(out), _ptr(deg)))
+        return out, deg
+
     def save_graph(self, path):
         self._check(self.L.eps_index_save_graph(self.h, path.encode()))
 
