@@ -182,6 +182,22 @@ int32_t eps_index_attach_rows(eps_index* h, const float* rows, int64_t n);
 int32_t eps_index_append_rows(eps_index* h, const float* rows, int64_t n_new);
 int64_t eps_index_row_count(const eps_index* h);
 
+/* On-disk table segment of the reference (`<db>/<table_id>/data_mvp.bin`, TableSegmentMVP::SaveTableSegment,
+ * db/table_segment_mvp.cpp:939-1010) read straight into HBM: header (record count, first id), deleted
+ * bitset, packed attribute rows (record_count x primitive_offset bytes), variable-length attributes (skipped), then one
+ * float[record_count][dim] table per dense vector field.  The caller describes the schema-dependent sizes; the index takes
+ * the rows of dense field `field` (its dim must equal the index's), the deleted bitset, and keeps the attribute rows on the
+ * device for eps_index_set_filter_program(ops, nops, NULL, 0, 0).  *n_out = record count. */
+typedef struct eps_table_layout {
+  int64_t primitive_offset;   /* bytes per packed attribute row (TableSegmentMVP::primitive_offset_)            */
+  int32_t var_len_attrs;      /* strings / sparse vectors per record (var_len_attr_num_)                       */
+  int32_t dense_fields;       /* dense vector fields, in schema order (dense_vector_num_)                      */
+  const int64_t* dense_dims;  /* their dimensions (vector_dims_)                                                */
+  int32_t field;              /* which of them to load                                                          */
+  int32_t reserved;
+} eps_table_layout;
+int32_t eps_index_load_table(eps_index* h, const char* data_mvp_path, const eps_table_layout* layout, int64_t* n_out);
+
 /* global id = local row index * stride + base (hash sharding by row index: stride = #shards, base = rank) */
 int32_t eps_index_set_id_map(eps_index* h, int64_t base, int64_t stride);
 

@@ -633,3 +633,52 @@ def test_mfma_filter_is_exact_at_high_dimension_with_cancellation(amd):
     assert np.array_equal(outs[0][0], outs[1][0])
     assert np.array_equal(outs[0][1], outs[1][1])
     ix.close()
+
+
+def test_load_table_segment_file_written_by_the_reference(amd, tmp_path):
+    """SURVEY 8f rank 3: `data_mvp.bin` written by the reference's own TableSegmentMVP::SaveTableSegment (through its DBServer:
+    INT pk, STRING, FLOAT attribute, two dense fields, deletes) is read straight into HBM by eps_index_load_table; flat searches on
+    the loaded field - plain, with the file's deleted bitset, with a filter program over the file's attribute rows - return what the
+    reference DBServer returns."""
+    import glob
+    from oracle.pyoracle import Ref, ref_available
+    if not ref_available():
+        pytest.skip("needs oracle/_ref")
+    ref = Ref()
+    n = 900
+    X8, X16 = data(n, 8, 51), data(n, 16, 52)
+    price = np.random.default_rng(53).random(n)
+    schema = {"name": "T", "fields": [{"name": "ID", "dataType": "INT", "primaryKey": True}, {"name": "Tag", "dataType": "STRING"},
+                                       {"name": "Price", "dataType": "FLOAT"},
+                                       {"name": "A", "dataType": "VECTOR_FLOAT", "dimensions": 8, "metricType": "EUCLIDEAN"},
+                                       {"name": "B", "dataType": "VECTOR_FLOAT", "dimensions": 16, "metricType": "EUCLIDEAN"}]}
+    recs = [{"ID": int(i), "Tag": "tag-%d" % (i * 37 % 101), "Price": float(np.float32(price[i])), "A": [float(x) for x in X8[i]],
+             "B": [float(x) for x in X16[i]]} for i in range(n)]
+    ref.L.ref_config(1, 500, 1, 0, 2)
+    db = ref.db(str(tmp_path / "db"))
+    assert db.create_table(schema) == 0 and db.insert("T", recs) == 0
+    assert db.delete("T", [5, 6, 7, 400]) == 0
+    assert db.rebuild() == 0                      # Rebuild() saves the table segment (db_mvp.cpp / table_mvp.cpp)
+    files = glob.glob(str(tmp_path / "db" / "*" / "data_mvp.bin"))
+    assert len(files) == 1, files
+    Q = data(6, 16, 54)
+    ix = amd.GpuIndex(16, 0)
+    assert ix.load_table(files[0], primitive_offset=8, var_len_attrs=1, dense_dims=[8, 16], field=1) == n
+    for flt, prog in (("", None), ("Price < 0.4 AND ID >= 100", [("f32", 4), ("const", 0.4), ("<",), ("i32", 0), ("const", 100), (">=",), ("and",)])):
+        ix.set_filter_program(prog)               # rows = None: the attribute rows the loader kept
+        ids, dist, cnt = ix.search(Q, 10, mode=amd.MODE_FLAT)
+        for qi, q in enumerate(Q):
+            rc, res = db.search("T", "B", q, 10, fields=("ID",), flt=flt)
+            assert rc == 0
+            assert [r["ID"] for r in res] == list(ids[qi][:cnt[qi]]), (flt, qi)      # ID == row index here
+            assert np.allclose([r["@distance"] for r in res], dist[qi][:cnt[qi]], rtol=1e-4)
+    ix8 = amd.GpuIndex(8, 0)
+    assert ix8.load_table(files[0], primitive_offset=8, var_len_attrs=1, dense_dims=[8, 16], field=0) == n
+    ids, _, _ = ix8.search(X8[10:11], 1, mode=amd.MODE_FLAT)
+    assert ids[0][0] == 10
+    with pytest.raises(amd.EpsillaError):
+        ix8.load_table(files[0], primitive_offset=8, var_len_attrs=3, dense_dims=[8, 16], field=0)   # wrong layout: detected, not read out of bounds
+    db.close()
+    ref.L.ref_config(4, 500, 1, 0, 4)
+    ix.close()
+    ix8.close()

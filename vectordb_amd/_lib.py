@@ -22,7 +22,7 @@ OPS = {None: 0, "": 0, "<": 1, "<=": 2, "==": 3, "=": 3, ">=": 4, ">": 5, "!=": 
 EXPORTS = [
     "eps_default_search_params", "eps_default_build_params", "eps_index_create", "eps_index_create_sharded", "eps_index_destroy",
     "eps_index_last_error", "eps_index_set_stream", "eps_index_synchronize", "eps_index_attach_rows",
-    "eps_index_append_rows", "eps_index_row_count", "eps_index_set_id_map", "eps_index_set_deleted",
+    "eps_index_append_rows", "eps_index_row_count", "eps_index_load_table", "eps_index_set_id_map", "eps_index_set_deleted",
     "eps_index_set_int_filter", "eps_index_set_filter_program", "eps_index_search_walk", "eps_index_select_edges", "eps_index_build", "eps_index_set_graph", "eps_index_graph_info",
     "eps_index_get_graph", "eps_index_save_graph", "eps_index_load_graph", "eps_index_search",
     "eps_index_last_stats", "eps_index_kernel_times", "eps_normalize_rows", "eps_merge_topk", "eps_merge_topk_packed",
@@ -46,6 +46,11 @@ class FilterOp(C.Structure):
 
 FOP = {"const": 1, "dist": 2, "i8": 3, "i16": 4, "i32": 5, "i64": 6, "f32": 7, "f64": 8, "bool": 9, "+": 10, "-": 11, "*": 12, "/": 13,
        "%": 14, "<": 15, "<=": 16, "=": 17, "<>": 18, ">=": 19, ">": 20, "and": 21, "or": 22, "not": 23, "=b": 24, "<>b": 25}
+
+
+class TableLayout(C.Structure):
+    _fields_ = [("primitive_offset", C.c_int64), ("var_len_attrs", C.c_int32), ("dense_fields", C.c_int32),
+                ("dense_dims", C.POINTER(C.c_int64)), ("field", C.c_int32), ("reserved", C.c_int32)]
 
 
 class SearchStats(C.Structure):
@@ -95,6 +100,7 @@ def load():
     L.eps_index_append_rows.argtypes = [vp, vp, i64]
     L.eps_index_row_count.argtypes = [vp]
     L.eps_index_row_count.restype = i64
+    L.eps_index_load_table.argtypes = [vp, C.c_char_p, C.POINTER(TableLayout), C.POINTER(i64)]
     L.eps_index_set_id_map.argtypes = [vp, i64, i64]
     L.eps_index_set_deleted.argtypes = [vp, vp, i64]
     L.eps_index_set_int_filter.argtypes = [vp, vp, i64, i32, i32, i64]

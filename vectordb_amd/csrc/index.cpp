@@ -1,6 +1,9 @@
 // Host side of libepsilla_gfx950 — see index.hpp.  Compiled with hipcc (host code only here).
 #include "index.hpp"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -188,6 +191,89 @@ int32_t Index::append_rows_strided(const float* rows, int64_t n_new, int64_t pit
   return EPS_OK;   // (a bitset / attribute column that is now too short is rejected by search(), see there)
 }
 
+// data_mvp.bin -> HBM (layout: db/table_segment_mvp.cpp:939-1010; the reference's own loader is its constructor, :133-295)
+int32_t Index::load_table(const char* path, const eps_table_layout* lay, int64_t* n_out) {
+  if (!path || !lay || lay->primitive_offset < 0 || lay->var_len_attrs < 0 || lay->dense_fields <= 0 || !lay->dense_dims || lay->field < 0 ||
+      lay->field >= lay->dense_fields)
+    return fail(EPS_USER_ERROR, "load_table: bad arguments");
+  if (lay->dense_dims[lay->field] != dim_) return fail(EPS_USER_ERROR, "load_table: the field's dimension differs from the index's");
+  const int fd = ::open(path, O_RDONLY);
+  if (fd < 0) return fail(EPS_DB_UNEXPECTED_ERROR, std::string("Cannot open file: ") + path);
+  struct stat st;
+  if (fstat(fd, &st) != 0 || st.st_size < 32) {
+    ::close(fd);
+    return fail(EPS_DB_UNEXPECTED_ERROR, std::string("Corrupt table segment file: ") + path);
+  }
+  const size_t fsize = (size_t)st.st_size;
+  void* map = mmap(nullptr, fsize, PROT_READ, MAP_PRIVATE, fd, 0);
+  ::close(fd);
+  if (map == MAP_FAILED) return fail(EPS_DB_UNEXPECTED_ERROR, std::string("Cannot map file: ") + path);
+  struct Unmap {
+    void* p;
+    size_t n;
+    ~Unmap() { munmap(p, n); }
+  } unmap{map, fsize};
+  const char* base = static_cast<const char*>(map);
+  size_t pos = 0;
+  auto need = [&](size_t bytes) { return bytes <= fsize && pos <= fsize - bytes; };
+  auto corrupt = [&]() { return fail(EPS_DB_UNEXPECTED_ERROR, std::string("Corrupt table segment file: ") + path); };
+  if (!need(24)) return corrupt();
+  uint64_t n64;
+  int64_t first_id, bitset_size;
+  std::memcpy(&n64, base + pos, 8);
+  std::memcpy(&first_id, base + pos + 8, 8);
+  std::memcpy(&bitset_size, base + pos + 16, 8);
+  pos += 24;
+  (void)first_id;
+  if (n64 >= ((uint64_t)1 << 31) || bitset_size < 0 || !need((size_t)bitset_size)) return corrupt();
+  const int64_t n = (int64_t)n64;
+  const uint8_t* bits = reinterpret_cast<const uint8_t*>(base + pos);
+  pos += (size_t)bitset_size;
+  const size_t attr_bytes = (size_t)n * (size_t)lay->primitive_offset;
+  if (!need(attr_bytes)) return corrupt();
+  const char* attrs = base + pos;
+  pos += attr_bytes;
+  for (int64_t r = 0; r < n; ++r)            // variable-length attributes: int64 length + payload each
+    for (int a = 0; a < lay->var_len_attrs; ++a) {
+      if (!need(8)) return corrupt();
+      int64_t len;
+      std::memcpy(&len, base + pos, 8);
+      pos += 8;
+      if (len < 0 || !need((size_t)len)) return corrupt();
+      pos += (size_t)len;
+    }
+  const float* field_rows = nullptr;
+  for (int f = 0; f < lay->dense_fields; ++f) {
+    if (lay->dense_dims[f] <= 0) return fail(EPS_USER_ERROR, "load_table: bad dimension");
+    const size_t bytes = (size_t)n * (size_t)lay->dense_dims[f] * sizeof(float);
+    if (!need(bytes)) return corrupt();
+    if (f == lay->field) field_rows = reinterpret_cast<const float*>(base + pos);
+    pos += bytes;
+  }
+  if (!need(8)) return corrupt();            // trailing WAL id
+  int32_t rc = attach_rows(field_rows, n);   // the mapped pages go to HBM directly; no host copy of the table is made
+  if (rc != EPS_OK) return rc;
+  if (bitset_size >= (n + 7) / 8 && n > 0) {
+    rc = set_deleted(bits, bitset_size);
+    if (rc != EPS_OK) return rc;
+  }
+  if (attr_bytes > 0) {   // keep the attribute rows on the device for a later filter program
+    HIP_TRY(hipStreamSynchronize(stream_));
+    if (!prog_rows_buf_.reserve(attr_bytes)) return fail(EPS_INFRA_UNEXPECTED_ERROR, "load_table: out of device memory (attribute rows)");
+    HIP_TRY(hipMemcpyAsync(prog_rows_buf_.p, attrs, attr_bytes, hipMemcpyHostToDevice, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    d_prog_rows_ = prog_rows_buf_.as<uint8_t>();
+    prog_rows_host_ = nullptr;
+    prog_rows_stride_ = lay->primitive_offset;
+    prog_rows_uploaded_ = n;
+    loaded_attr_rows_ = n;
+    loaded_attr_stride_ = lay->primitive_offset;
+    prog_len_ = 0;
+  }
+  if (n_out) *n_out = n;
+  return EPS_OK;
+}
+
 int32_t Index::set_id_map(int64_t base, int64_t stride) {
   if (stride <= 0) return fail(EPS_USER_ERROR, "set_id_map: stride must be positive");
   id_base_ = base;
@@ -267,7 +353,12 @@ int32_t Index::set_filter_program(const eps_filter_op* ops, int32_t nops, const 
     return EPS_OK;
   }
   if (nops > 64) return fail(EPS_DB_UNSUPPORTED_ERROR, "set_filter_program: more than 64 instructions");
-  if (!rows || stride <= 0 || n_rows < n_rows_) return fail(EPS_USER_ERROR, "set_filter_program: attribute rows missing or shorter than the table");
+  const bool use_loaded = !rows && loaded_attr_rows_ > 0 && loaded_attr_rows_ >= n_rows_;   // the rows eps_index_load_table kept
+  if (use_loaded) {
+    stride = loaded_attr_stride_;
+    n_rows = loaded_attr_rows_;
+  }
+  if ((!rows && !use_loaded) || stride <= 0 || n_rows < n_rows_) return fail(EPS_USER_ERROR, "set_filter_program: attribute rows missing or shorter than the table");
   // validate: known opcodes, attribute loads inside a row, stack discipline
   int sp = 0, maxsp = 0;
   bool uses_dist = false;
@@ -293,10 +384,14 @@ int32_t Index::set_filter_program(const eps_filter_op* ops, int32_t nops, const 
   if (!prog_buf_.reserve((size_t)nops * sizeof(FilterOp))) return fail(EPS_INFRA_UNEXPECTED_ERROR, "set_filter_program: out of device memory");
   static_assert(sizeof(FilterOp) == sizeof(eps_filter_op), "FilterOp mirrors eps_filter_op");
   HIP_TRY(hipMemcpyAsync(prog_buf_.p, ops, (size_t)nops * sizeof(FilterOp), hipMemcpyHostToDevice, stream_));
-  if (is_device_ptr(rows)) {
+  if (use_loaded) {
+    d_prog_rows_ = prog_rows_buf_.as<uint8_t>();
+  } else if (is_device_ptr(rows)) {
     d_prog_rows_ = static_cast<const uint8_t*>(rows);
     prog_rows_host_ = nullptr;
+    loaded_attr_rows_ = 0;
   } else {
+    loaded_attr_rows_ = 0;
     // Host attribute rows are append-only in the reference (an update is delete + insert, table_segment_mvp.cpp:476-587), so
     // rows handed over earlier from the same table are kept and only the new tail crosses PCIe.
     const size_t bytes = (size_t)n_rows * (size_t)stride;
@@ -755,6 +850,17 @@ int32_t eps_index_select_edges(eps_index* h, const int64_t* nodes, int64_t m, co
   try {
     if (hipSetDevice(ix->device_) != hipSuccess) return ix->fail(EPS_INFRA_UNEXPECTED_ERROR, "hipSetDevice");
     return eps::select_edges(*ix, nodes, m, cands, cands_per_node, depth, out_degree, out_ids, out_deg);
+  } catch (...) {
+    return map_exception(ix);
+  }
+}
+int32_t eps_index_load_table(eps_index* h, const char* path, const eps_table_layout* layout, int64_t* n_out) {
+  if (!h) return EPS_USER_ERROR;
+  Index* ix = dynamic_cast<Index*>(IX(h));
+  if (!ix) return IX(h)->fail(EPS_DB_UNSUPPORTED_ERROR, "load_table: single-device indices only");
+  try {
+    if (hipSetDevice(ix->device_) != hipSuccess) return ix->fail(EPS_INFRA_UNEXPECTED_ERROR, "hipSetDevice");
+    return ix->load_table(path, layout, n_out);
   } catch (...) {
     return map_exception(ix);
   }

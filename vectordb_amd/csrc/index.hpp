@@ -83,6 +83,7 @@ class Index : public IndexBase {
   int32_t save_graph(const char* path) override;
   int32_t load_graph(const char* path) override;
   int32_t last_stats(eps_search_stats* out) override;
+  int32_t load_table(const char* path, const eps_table_layout* layout, int64_t* n_out);
   // walk_limit > 0: candidate-walk form (eps_index_search_walk): k = cap, the tail merge uses searchLimit(walk_limit)
   int32_t search(const float* queries, int64_t nq, int32_t k, const eps_search_params* p, int64_t* ids, float* dist,
                  int32_t* counts, int32_t walk_limit = 0) override;
@@ -122,6 +123,7 @@ class Index : public IndexBase {
   const uint8_t* d_prog_rows_ = nullptr;
   const void* prog_rows_host_ = nullptr;   // host table the cached device copy mirrors (append-only)
   int64_t prog_rows_stride_ = 0, prog_rows_uploaded_ = 0;
+  int64_t loaded_attr_rows_ = 0, loaded_attr_stride_ = 0;   // attribute rows kept by load_table
   int64_t prog_stride_ = 0, prog_rows_n_ = 0;
   int32_t prog_len_ = 0;
   bool prog_uses_dist_ = false;

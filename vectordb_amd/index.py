@@ -87,6 +87,14 @@ class GpuIndex:
             rows = np.ascontiguousarray(rows, np.float32)
         self._check(self.L.eps_index_append_rows(self.h, _ptr(rows), rows.shape[0]))
 
+    def load_table(self, path, primitive_offset, var_len_attrs, dense_dims, field):
+        """eps_index_load_table: the reference's data_mvp.bin straight into HBM; returns the record count"""
+        dims = (C.c_int64 * len(dense_dims))(*dense_dims)
+        lay = lib.TableLayout(primitive_offset, var_len_attrs, len(dense_dims), dims, field, 0)
+        n = C.c_int64()
+        self._check(self.L.eps_index_load_table(self.h, path.encode(), C.byref(lay), C.byref(n)))
+        return n.value
+
     @property
     def row_count(self):
         return self.L.eps_index_row_count(self.h)
@@ -135,6 +143,9 @@ class GpuIndex:
                 ops[i].dval = float(ins[1])
             elif len(ins) > 1:
                 ops[i].arg = int(ins[1])
+        if rows is None:   # the attribute rows eps_index_load_table kept on the device
+            self._check(self.L.eps_index_set_filter_program(self.h, ops, len(program), None, 0, 0))
+            return
         if not _is_dev(rows):
             rows = np.ascontiguousarray(rows)
             stride = stride or rows.strides[0]
