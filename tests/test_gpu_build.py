@@ -150,6 +150,8 @@ def test_device_select_edge_equals_oracle_on_identical_pools(amd, oracle):
     nodes = np.arange(0, 600, 3, dtype=np.int64)
     for cpn, depth, R in ((420, 300, 50), (420, 0, 50), (120, 300, 50), (64, 40, 8)):
         cands = np.stack([rng.choice(n, size=cpn, replace=False) for _ in nodes]).astype(np.int64)
+        for i, v in enumerate(nodes):                          # the node itself appears exactly once (as in a real pool)
+            cands[i][cands[i] == v] = (v + 1) % n if (v + 1) % n not in cands[i] else -1
         cands[:, 0] = nodes
         cands[::5, -3:] = -1                                   # ragged lists
         ids, deg = ix.select_edges(nodes, cands, depth=depth, out_degree=R)
