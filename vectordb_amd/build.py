@@ -15,6 +15,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", 
          "-I" + os.path.join(os.path.dirname(HERE), "include")]
 
 
+# lab only: extra -D switches for kernel experiments (e.g. EPS_BUILD_DEFS="-DEPS_TRV_U=8"); the product build sets none
+FLAGS += os.environ.get("EPS_BUILD_DEFS", "").split()
+
+
 def _hipcc():
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.sep not in c or os.path.exists(c)):

@@ -36,6 +36,8 @@
 
 namespace eps {
 
+constexpr int EPS_MFMA_MANTISSA_DEFAULT = 10;
+
 struct HalfMirror {
   DevBuf xh;       // _Float16 [n_pad][d_pad]
   DevBuf xn;       // float [n_pad]  |x|^2 (+inf on padding rows)
@@ -57,6 +59,7 @@ struct HalfMirror {
   int d_pad = 0;
   bool fp16_range_ok = true;
   int num_cus = 0;             // CUs of this index's device (persistent grid size)
+  int drop = -1;               // low mantissa bits the mirror and the query operand leave at zero (to_half_drop)
   int64_t extended_rows = 0;   // rows converted by incremental extensions (test hook)
   float h_scal[4] = {0, 0, 0, 0};
 };
@@ -64,6 +67,21 @@ struct HalfMirror {
 void half_mirror_free(HalfMirror* m) { delete m; }
 
 // ------------------------------------------------------------------------------------------------ mirror build
+// fp32 -> fp16 keeping only the top `10 - drop` mantissa bits (round to nearest even at that width).  The MI355X clocks to its
+// power budget and the matrix pipe draws less on operands that toggle fewer bits (scripts/lab/mfma_power.hip: the same MFMA
+// stream runs 7.6 % / 12 % faster at 7 / 5 mantissa bits); the filter only needs a lower bound, and every bound below is
+// computed from the residual |x - xh| of the value actually stored, so the result stays exact for any `drop` - coarser
+// operands just let a few more candidates through to the fp32 re-rank.
+__device__ __forceinline__ _Float16 to_half_drop(float x, int drop) {
+  const _Float16 h = (_Float16)x;
+  if (drop <= 0) return h;
+  unsigned short u = __builtin_bit_cast(unsigned short, h);
+  const unsigned short keep = (unsigned short)~((1u << drop) - 1u);
+  const unsigned short r = (unsigned short)(u + ((1u << (drop - 1)) - 1u) + ((u >> drop) & 1u));   // RNE (carries into the exponent)
+  u = ((r & 0x7C00u) == 0x7C00u && (u & 0x7C00u) != 0x7C00u) ? (unsigned short)(u & keep) : (unsigned short)(r & keep);   // never round up to inf
+  return __builtin_bit_cast(_Float16, u);
+}
+
 __device__ __forceinline__ void atomic_max_pos(float* addr, float v) {  // v >= 0
   atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
 }
@@ -72,7 +90,7 @@ __device__ __forceinline__ void atomic_max_pos(float* addr, float v) {  // v >= 
 // (the per-index maxima in `scal` only ever grow, so they are accumulated across calls)
 __global__ __launch_bounds__(256) void half_mirror_kernel(const float* rows, int64_t row0, int64_t n, int64_t n_pad, int dim, int d_pad,
                                                           _Float16* xh, float* xn, float* zeros, float* xn_s, float* zeros_s, float* scal,
-                                                          float gamma) {
+                                                          float gamma, int drop) {
   // one wavefront per row, grid-stride over rows; the four per-index maxima are reduced in registers and
   // published with ONE atomic per wavefront (an atomic per row serialises 10M rows on four addresses)
   const int lane = lane_id();
@@ -99,7 +117,7 @@ __global__ __launch_bounds__(256) void half_mirror_kernel(const float* rows, int
         float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c < dim) x = *reinterpret_cast<const float4*>(src + c);
         half4 h;
-        h[0] = (_Float16)x.x; h[1] = (_Float16)x.y; h[2] = (_Float16)x.z; h[3] = (_Float16)x.w;
+        h[0] = to_half_drop(x.x, drop); h[1] = to_half_drop(x.y, drop); h[2] = to_half_drop(x.z, drop); h[3] = to_half_drop(x.w, drop);
         *reinterpret_cast<half4*>(dst + c) = h;
         const float xs[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
@@ -115,7 +133,7 @@ __global__ __launch_bounds__(256) void half_mirror_kernel(const float* rows, int
     } else {
       for (int c = lane; c < d_pad; c += 64) {
         const float x = c < dim ? src[c] : 0.f;
-        const _Float16 h = (_Float16)x;
+        const _Float16 h = to_half_drop(x, drop);
         const float hf = (float)h;
         dst[c] = h;
         s2 = fmaf(x, x, s2);
@@ -152,7 +170,7 @@ __global__ __launch_bounds__(256) void half_mirror_kernel(const float* rows, int
 }
 
 __global__ __launch_bounds__(256) void query_prep_kernel(const float* q, int64_t nq, int64_t b_pad, int dim, int d_pad,
-                                                         _Float16* qh, float* qstat) {
+                                                         _Float16* qh, float* qstat, int drop) {
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= b_pad) return;
   const int lane = lane_id();
@@ -166,7 +184,7 @@ __global__ __launch_bounds__(256) void query_prep_kernel(const float* q, int64_t
   float s2 = 0.f, e2 = 0.f;
   for (int c = lane; c < d_pad; c += 64) {
     const float x = c < dim ? src[c] : 0.f;
-    const _Float16 h = (_Float16)x;
+    const _Float16 h = to_half_drop(x, drop);
     dst[c] = h;
     s2 = fmaf(x, x, s2);
     const float e = x - (float)h;
@@ -272,6 +290,11 @@ static int32_t ensure_mirror(Index& ix) {
   if (!ix.mirror_) ix.mirror_ = new HalfMirror();
   HalfMirror& m = *ix.mirror_;
   const int64_t n = ix.n_rows_;
+  if (m.drop < 0) {   // EPS_MFMA_MANTISSA = mantissa bits the fp16 operands keep (10 = plain fp16); fixed per mirror
+    const char* e = getenv("EPS_MFMA_MANTISSA");
+    const int keep = e ? std::min(10, std::max(2, atoi(e))) : EPS_MFMA_MANTISSA_DEFAULT;
+    m.drop = 10 - keep;
+  }
   if (m.version == ix.rows_version_ && m.n == n) return EPS_OK;
   // appended rows: only the new rows are converted; the 15 GB mirror of a 10M-row table is not rebuilt
   const bool extend = m.version == ix.rows_version_ && m.n > 0 && m.n < n;
@@ -292,7 +315,7 @@ static int32_t ensure_mirror(Index& ix) {
   const int64_t row0 = extend ? m.n : 0;
   hipLaunchKernelGGL(half_mirror_kernel, dim3((unsigned)std::min<int64_t>((n_pad - row0 + 3) / 4, 8192)), dim3(256), 0, s, ix.d_rows_, row0, n, n_pad,
                      (int)ix.dim_, d_pad, m.xh.as<_Float16>(), m.xn.as<float>(), m.zeros.as<float>(), m.xn_s.as<float>(), m.zeros_s.as<float>(),
-                     m.scal.as<float>(), gamma);
+                     m.scal.as<float>(), gamma, m.drop);
   er = hipMemcpyAsync(m.h_scal, m.scal.p, 16, hipMemcpyDeviceToHost, s);
   if (er == hipSuccess) er = hipStreamSynchronize(s);
   if (er != hipSuccess) return ix.hip_fail(er, "fp16 mirror build");
@@ -336,7 +359,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
       !m.cand.reserve((size_t)nq * cap * 8) || !m.cnt.reserve((size_t)(nq + 4) * 4 + 16))
     return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory (scratch)");
   hipLaunchKernelGGL(query_prep_kernel, dim3((unsigned)((b_pad + 3) / 4)), dim3(256), 0, s, dq, nq, b_pad, (int)ix.dim_,
-                     m.d_pad, m.qh.as<_Float16>(), m.qstat.as<float>());
+                     m.d_pad, m.qh.as<_Float16>(), m.qstat.as<float>(), m.drop);
   // kernel choice: v5 / v7 want K-steps in pairs (d_pad % 128 == 0, >= 256); other shapes stay on v3
   const char* ver_s = getenv("EPS_MFMA_KERNEL");   // 3 | 7 (A/B); v7 needs K-steps in pairs, other shapes stay on v3
   const int version_env = ver_s && atoi(ver_s) == 3 ? 3 : 7;

@@ -236,14 +236,18 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
   // the other one cover this one's queue maintenance); larger SearchQueueSize: queues in HBM
   const bool qglobal = traverse2_lds_bytes((int)ix.dim_, T, (int)Lq, qtot, dp, false) > 80 * 1024;
   const size_t shm = traverse2_lds_bytes((int)ix.dim_, T, (int)Lq, qtot, dp, qglobal);
-  // few queries: 16 wavefronts per query (latency); many queries: 4 per query (throughput, more queries per CU)
-  const char* wide_s = getenv("EPS_TRV_WIDE");
-  const bool wide = wide_s ? atoi(wide_s) != 0 : nq <= 256;
+  // few queries: 16 wavefronts per query (latency); many queries: fewer per query (throughput, more queries per CU)
+  const char* waves_s = getenv("EPS_TRV_WAVES");
+  int nw = waves_s ? atoi(waves_s) : (nq <= 256 ? 16 : 4);
+  if (const char* wide_s = getenv("EPS_TRV_WIDE")) nw = atoi(wide_s) != 0 ? 16 : 4;   // (older switch)
+  if (nw != 4 && nw != 8 && nw != 16) nw = 4;
+  const bool wide = nw == 16;
   hipDeviceProp_t prop;
   er = hipGetDeviceProperties(&prop, ix.device_);
   if (er != hipSuccess) return ix.hip_fail(er, "device properties");
   const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  int per_cu = (int)std::min<size_t>(wide ? 2 : 8, (size_t)(160 * 1024) / shm);
+  int per_cu = (int)std::min<size_t>((size_t)(32 / nw), (size_t)(160 * 1024) / shm);   // 32 wavefronts per CU at this register use
+  if (const char* pc = getenv("EPS_TRV_PER_CU")) per_cu = std::max(1, atoi(pc));
   if (per_cu < 1) per_cu = 1;
   const int64_t words = (n + 31) / 32;
   int64_t slots = std::min<int64_t>(nq, (int64_t)cus * per_cu);
@@ -327,13 +331,17 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
     a.nq = cnt;
     a.out_queue = g.queue.as<u64>();
     const int sl = (int)std::min<int64_t>(slots, cnt);
+#define EPS_TRV_LAUNCH(V4, NW_)                                        \
+  do {                                                                 \
+    if (qglobal) launch_trv2<V4, NW_, true>(a, sl, shm, s);            \
+    else launch_trv2<V4, NW_, false>(a, sl, shm, s);                   \
+  } while (0)
     if (vec4) {
-      if (wide) { if (qglobal) launch_trv2<true, 16, true>(a, sl, shm, s); else launch_trv2<true, 16, false>(a, sl, shm, s); }
-      else      { if (qglobal) launch_trv2<true, 4, true>(a, sl, shm, s);  else launch_trv2<true, 4, false>(a, sl, shm, s); }
+      if (nw == 16) EPS_TRV_LAUNCH(true, 16); else if (nw == 8) EPS_TRV_LAUNCH(true, 8); else EPS_TRV_LAUNCH(true, 4);
     } else {
-      if (wide) { if (qglobal) launch_trv2<false, 16, true>(a, sl, shm, s); else launch_trv2<false, 16, false>(a, sl, shm, s); }
-      else      { if (qglobal) launch_trv2<false, 4, true>(a, sl, shm, s);  else launch_trv2<false, 4, false>(a, sl, shm, s); }
+      if (nw == 16) EPS_TRV_LAUNCH(false, 16); else if (nw == 8) EPS_TRV_LAUNCH(false, 8); else EPS_TRV_LAUNCH(false, 4);
     }
+#undef EPS_TRV_LAUNCH
     ix.stats_.main_kernel_launches += 1;
     if (q0 + cnt >= nq) (void)hipEventRecord(ix.evk1_, s);   // (with several slices the pair spans all traversal launches and the post kernels between them)
     pa.tail = tail ? tail + q0 * tail_k : nullptr;
@@ -353,7 +361,7 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
     unsigned long long tot = 0;
     for (int i = 0; i < 10; ++i) tot += h[8 + i];
     fprintf(stderr, "[eps trv] nq=%lld T=%d L=%lld I=%d %s queues, %d wavefronts/query, %lld slots, LDS %zu B: steps/query %.1f rounds/query %.1f expansions/query %.1f evals/query %.1f\n",
-            (long long)nq, T, (long long)L, I, qglobal ? "HBM" : "LDS", wide ? 16 : 4, (long long)slots, shm, (double)h[2] / nq, (double)h[3] / nq, (double)h[1] / nq, (double)h[0] / nq);
+            (long long)nq, T, (long long)L, I, qglobal ? "HBM" : "LDS", nw, (long long)slots, shm, (double)h[2] / nq, (double)h[3] / nq, (double)h[1] / nq, (double)h[0] / nq);
     for (int i = 0; i < 10; ++i) fprintf(stderr, "[eps trv]   %-16s %5.1f %%\n", names[i], tot ? 100.0 * h[8 + i] / tot : 0.0);
   }
   ix.stats_.dist_evals += (int64_t)h[0];

@@ -54,6 +54,9 @@ struct Trv2Args {
   unsigned long long* prof;      // optional [16]: shader-clock ticks per phase summed over the workgroups (EPS_TRV_PROF)
 };
 
+#ifndef EPS_TRV_U
+#define EPS_TRV_U 4   // rows in flight per lane group in the distance phases
+#endif
 constexpr int TRV2_SB = 4096;       // keys of the LDS staging block of the QGLOBAL bitonic sort
 constexpr int TRV2_MAXT = 16;
 constexpr int TRV2_SH = 192;        // ints of scalar scratch
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(NW * 64) void traverse2_kernel(Trv2Args a) {
   const int RPW = 64 / G;
   const int g = lane / G;
   const int t = lane & (G - 1);
-  constexpr int U = 4;
+  constexpr int U = EPS_TRV_U;
   const int64_t slot = blockIdx.x;
   u32* vis = a.visited + slot * a.words;
   u32* vlog = a.vlog + slot * (int64_t)a.vcap;
