@@ -228,7 +228,7 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
     if (er != hipSuccess) return ix.hip_fail(er, "init ids upload");
     g.init_L = L;
   }
-  const int dp = g.fixed_deg > 0 ? g.fixed_deg : (int)((std::max<int64_t>(g.max_degree, 1) + 3) / 4 * 4);
+  const int dp = (int)(((g.fixed_deg > 0 ? (int64_t)g.fixed_deg : std::max<int64_t>(g.max_degree, 1)) + 7) / 8 * 8);   // edge slots per worker and step
   if ((int64_t)T * dp > 2048) return ix.fail(EPS_DB_UNSUPPORTED_ERROR, "search: IntraQueryThreads x maximum out-degree > 2048 is not supported");
   const int64_t qtot = (int64_t)(T - 1) * Lq + Lp2;
   const bool vec4 = (ix.dim_ % 4 == 0) && ((reinterpret_cast<uintptr_t>(ix.d_rows_) & 15) == 0);
@@ -241,7 +241,6 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
   int nw = waves_s ? atoi(waves_s) : (nq <= 256 ? 16 : 4);
   if (const char* wide_s = getenv("EPS_TRV_WIDE")) nw = atoi(wide_s) != 0 ? 16 : 4;   // (older switch)
   if (nw != 4 && nw != 8 && nw != 16) nw = 4;
-  const bool wide = nw == 16;
   hipDeviceProp_t prop;
   er = hipGetDeviceProperties(&prop, ix.device_);
   if (er != hipSuccess) return ix.hip_fail(er, "device properties");

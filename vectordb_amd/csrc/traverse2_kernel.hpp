@@ -281,33 +281,29 @@ __global__ __launch_bounds__(NW * 64) void traverse2_kernel(Trv2Args a) {
 
       // ---- lockstep steps
       while (true) {
-        // a. every worker with iterations left takes its first unchecked candidate at or after k_uc (:632-672)
+        // a. every worker with iterations left takes its first unchecked candidate at or after k_uc (:632-672).  One
+        //    wavefront per worker (ballot over 64 queue positions at a time), the workers side by side.
         if (tid == 0) sh[3] = 0;
-        for (int w = 0; w < T; ++w) {
-          const u64* qw = qbase + (int64_t)w * Lq;
+        __syncthreads();
+        for (int w = wave; w < T; w += NW) {
+          u64* qw = qbase + (int64_t)w * Lq;
           const int size = s_size[w];
           const bool can = s_its[w] < I_round;
           int found = -1;
           if (can) {
-            for (int base = s_kuc[w]; base < size; base += NT) {   // uniform trip count
-              __syncthreads();
-              if (tid == 0) sh[0] = 0x7FFFFFFF;
-              __syncthreads();
-              const int p = base + tid;
-              if (p < size && !(qw[p] & 1ull)) atomicMin(&sh[0], p);
-              __syncthreads();
-              if (sh[0] != 0x7FFFFFFF) {
-                found = sh[0];
+            for (int base = s_kuc[w]; base < size; base += 64) {   // wave-uniform
+              const int p = base + lane;
+              const u64 m = __ballot(p < size && !(qw[p] & 1ull));
+              if (m) {
+                found = base + __ffsll((long long)m) - 1;
                 break;
               }
             }
           }
-          __syncthreads();
-          if (tid == 0) {
+          if (lane == 0) {
             if (found >= 0) {
-              u64* qm = qbase + (int64_t)w * Lq;
-              const u64 key = qm[found];
-              qm[found] = key | 1ull;
+              const u64 key = qw[found];
+              qw[found] = key | 1ull;
               const u32 node = (u32)((key >> 1) & 0x7FFFFFFFu);
               s_sel[w] = (int)node;
               s_selpos[w] = found;
@@ -327,9 +323,9 @@ __global__ __launch_bounds__(NW * 64) void traverse2_kernel(Trv2Args a) {
         __syncthreads();
         if (tid == 0) {
           int acc = 0;
-          for (int w = 0; w < T; ++w) {
+          for (int w = 0; w < T; ++w) {   // segments start on multiples of 8 edge slots (the rank sort reads 8 keys at a time)
             s_eoff[w] = acc;
-            acc += s_deg[w];
+            acc += (s_deg[w] + 7) & ~7;
           }
           s_eoff[T] = acc;
         }
@@ -350,8 +346,11 @@ __global__ __launch_bounds__(NW * 64) void traverse2_kernel(Trv2Args a) {
           while (w < T - 1 && e >= s_eoff[w + 1]) ++w;
           const int j = e - s_eoff[w];
           const int node = s_sel[w];
-          const int64_t rowbase = a.fixed_deg > 0 ? (int64_t)node * a.fixed_deg : a.off[node];
-          const u32 nb = a.nbr[rowbase + j];
+          u32 nb = TRV2_NONE;
+          if (j < s_deg[w]) {
+            const int64_t rowbase = a.fixed_deg > 0 ? (int64_t)node * a.fixed_deg : a.off[node];
+            nb = a.nbr[rowbase + j];
+          }
           u32 raw = 0;
           if (nb != TRV2_NONE) {
             const u32 bit = 1u << (nb & 31);
@@ -431,6 +430,10 @@ __global__ __launch_bounds__(NW * 64) void traverse2_kernel(Trv2Args a) {
         int nwork = 0;
         for (int w = 0; w < T; ++w) nwork += s_wcnt[w];
         evals += nwork;
+        if (tid < T) {   // pad every segment's keys to a multiple of 8 with EMPTY (sorts last, never counted)
+          const int c = s_wcnt[tid];
+          for (int p = c; p < ((c + 7) & ~7); ++p) newk[s_eoff[tid] + p] = KEY_EMPTY;
+        }
         for (int c0 = wave * RPW * U; c0 < nwork; c0 += NW * RPW * U) {
           const float* rp[U];
           u32 id[U];
@@ -463,71 +466,94 @@ __global__ __launch_bounds__(NW * 64) void traverse2_kernel(Trv2Args a) {
         }
         __syncthreads();
         TRV2_LAP(5)
-        // e. rank-sort every worker's survivors inside its segment
-        for (int e = tid; e < etot; e += NT) {
+        // e. rank-sort every worker's survivors inside its segment: one thread per key, the segment read 8 keys at a time
+        //    (independent LDS reads in flight).  Valid keys are distinct (a node is evaluated once), dropped ones are EMPTY:
+        //    rank = number of smaller keys.
+        for (int e0 = 0; e0 < etot; e0 += NT) {   // uniform trip count (ballots below)
+          const int e = e0 + tid;
           int w = 0;
-          while (w < T - 1 && e >= s_eoff[w + 1]) ++w;
-          const int j = e - s_eoff[w];
-          if (j < s_wcnt[w]) {
-            const u64 mine = newk[e];
-            if (mine != KEY_EMPTY) {
-              const int cnt = s_wcnt[w];
+          bool placed = false;
+          if (e < etot) {
+            while (w < T - 1 && e >= s_eoff[w + 1]) ++w;
+            const int j = e - s_eoff[w];
+            const int cnt = s_wcnt[w];
+            if (j < cnt) {
               const u64* seg = newk + s_eoff[w];
-              int rank = 0;
-              for (int j2 = 0; j2 < cnt; ++j2) {
-                const u64 o = seg[j2];
-                rank += (o < mine) || (o == mine && j2 < j);
+              const u64 mine = seg[j];
+              if (mine != KEY_EMPTY) {
+                int rank = 0;
+                for (int c0 = 0; c0 < cnt; c0 += 8) {
+                  u64 o[8];
+#pragma unroll
+                  for (int u = 0; u < 8; ++u) o[u] = seg[c0 + u];
+#pragma unroll
+                  for (int u = 0; u < 8; ++u) rank += o[u] < mine ? 1 : 0;
+                }
+                sorted[s_eoff[w] + rank] = mine;
+                placed = true;
               }
-              sorted[s_eoff[w] + rank] = mine;
-              atomicAdd(&s_nnew[w], 1);
             }
+          }
+          for (int ww = 0; ww < T; ++ww) {        // survivors per worker: one LDS atomic per wavefront and worker
+            const u64 m = __ballot(placed && w == ww);
+            if (m && lane == __ffsll((long long)m) - 1) atomicAdd(&s_nnew[ww], __popcll(m));
           }
         }
         __syncthreads();
         TRV2_LAP(6)
-        // f. AddIntoQueue for every worker: merge its sorted survivors into its queue in place
-        for (int w = 0; w < T; ++w) {
-          const int nnew = s_nnew[w];
-          if (s_sel[w] < 0) continue;              // uniform
+        // f. AddIntoQueue for every worker: merge its sorted survivors into its queue in place.  The workers are handled side
+        //    by side, TPW threads each, in the same barrier schedule (the chunk loop runs as long as the longest needs).
+        {
+          const int Tp = T <= 1 ? 1 : (T <= 2 ? 2 : (T <= 4 ? 4 : (T <= 8 ? 8 : 16)));
+          const int TPW = NT / Tp;                 // threads per worker
+          const int CW = TPW * R;                  // queue entries per worker and chunk
+          const int w = tid / TPW;                 // this thread's worker (may be >= T: idle group)
+          const int tg = tid - w * TPW;
+          const bool mine_w = w < T && s_sel[w] >= 0;
+          const int nnew = mine_w ? s_nnew[w] : 0;
           const int cap = w == T - 1 ? L : Lq;
-          int r = cap;
-          if (nnew > 0) {
-            u64* qw = qbase + (int64_t)w * Lq;
-            const u64* sw = sorted + s_eoff[w];
-            const int size = s_size[w];
-            for (int j = tid; j < nnew; j += NT) npos[j] = j + lower_bound_q(qw, size, sw[j]);
-            __syncthreads();
-            const int pmin = npos[0];
-            if (pmin < cap) {
-              r = pmin;
-              // old entries at positions >= pmin move right by the number of new keys ordered before them; chunks from
-              // the tail so that nothing unread is overwritten
-              for (int cb = ((size - 1) / C) * C; size > 0 && cb + C > pmin && cb >= 0; cb -= C) {
-                u64 v[R];
-                int dst[R];
+          const int size = mine_w ? s_size[w] : 0;
+          u64* qw = qbase + (int64_t)(w < T ? w : 0) * Lq;
+          const u64* sw = sorted + (w < T ? s_eoff[w] : 0);
+          int* np = npos + (w < T ? s_eoff[w] : 0);
+          for (int j = tg; j < nnew; j += TPW) np[j] = j + lower_bound_q(qw, size, sw[j]);
+          if (tid == 0) sh[0] = 0;
+          __syncthreads();
+          const int pmin = nnew > 0 ? np[0] : cap;
+          const bool moves = nnew > 0 && pmin < cap && size > 0;
+          const int top = moves ? ((size - 1) / CW) * CW : 0;
+          const int nchunks = moves ? (top / CW - pmin / CW + 1) : 0;
+          if (tg == 0 && nchunks > 0) atomicMax(&sh[0], nchunks);
+          __syncthreads();
+          const int maxchunks = sh[0];
+          // old entries at positions >= pmin move right by the number of new keys ordered before them; chunks from the tail so
+          // that nothing unread is overwritten
+          for (int it = 0; it < maxchunks; ++it) {
+            u64 v[R];
+            int dst[R];
+            const int cb = top - it * CW;
 #pragma unroll
-                for (int i = 0; i < R; ++i) {
-                  const int p = cb + i * NT + tid;
-                  dst[i] = -1;
-                  v[i] = KEY_EMPTY;
-                  if (p >= pmin && p < size) {
-                    v[i] = qw[p];
-                    dst[i] = p + lower_bound_q(sw, nnew, v[i]);
-                  }
-                }
-                __syncthreads();
-#pragma unroll
-                for (int i = 0; i < R; ++i)
-                  if (dst[i] >= 0 && dst[i] < cap) qw[dst[i]] = v[i];
+            for (int i = 0; i < R; ++i) {
+              const int p = cb + i * TPW + tg;
+              dst[i] = -1;
+              v[i] = KEY_EMPTY;
+              if (it < nchunks && p >= pmin && p < size) {
+                v[i] = qw[p];
+                dst[i] = p + lower_bound_q(sw, nnew, v[i]);
               }
-              __syncthreads();
-              for (int j = tid; j < nnew; j += NT)
-                if (npos[j] < cap) qw[npos[j]] = sw[j];
             }
             __syncthreads();
-            if (tid == 0) s_size[w] = size + nnew < cap ? size + nnew : cap;
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+              if (dst[i] >= 0 && dst[i] < cap) qw[dst[i]] = v[i];
           }
-          if (tid == 0) {
+          __syncthreads();
+          if (nnew > 0 && pmin < cap)
+            for (int j = tg; j < nnew; j += TPW)
+              if (np[j] < cap) qw[np[j]] = sw[j];
+          if (mine_w && tg == 0) {
+            if (nnew > 0) s_size[w] = size + nnew < cap ? size + nnew : cap;
+            const int r = (nnew > 0 && pmin < cap) ? pmin : cap;
             const int kuc = s_selpos[w];
             s_kuc[w] = r <= kuc ? r : kuc + 1;   // (:661-665)
           }
