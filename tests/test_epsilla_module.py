@@ -93,3 +93,38 @@ def test_gfx950_module_rebuild_and_query_batch():
         for i in range(len(flat)):
             assert flat[i][0] == ref["flat"]["results"][i][0], i
             assert np.allclose(flat[i][1], ref["flat"]["results"][i][1], rtol=1e-4)
+
+
+def test_gfx950_module_loads_on_cpu_and_refuses_to_search_without_a_gpu():
+    """CPU: the drop-in module imports (the reference binding's 8 methods + rebuild + query_batch), ingests through the unchanged
+    DBServer, and a query fails loudly when no gfx950 device is usable - there is no CPU fallback behind the binding either."""
+    if not _have(GPU_DIR):
+        pytest.skip("dropin/_build/epsilla.so not built (make -C dropin)")
+    import torch
+    code = r'''
+import sys, ctypes
+sys.path.insert(0, %r)
+import epsilla
+names = ["load_db", "unload_db", "use_db", "create_table", "insert", "query", "drop_table", "delete", "rebuild", "query_batch"]
+assert all(hasattr(epsilla, n) for n in names), [n for n in names if not hasattr(epsilla, n)]
+assert epsilla.backend == "gfx950"
+assert epsilla.load_db(db_name="db", db_path=sys.argv[1]) == 0
+epsilla.use_db(db_name="db")
+fields = [{"name": "ID", "dataType": "INT", "primaryKey": True}, {"name": "V", "dataType": "VECTOR_FLOAT", "dimensions": 4, "metricType": "EUCLIDEAN"}]
+ctypes.pythonapi.Py_IncRef(ctypes.py_object(fields))
+epsilla.create_table(table_name="T", table_fields=fields)
+assert epsilla.insert(table_name="T", records=[{"ID": 1, "V": [0.1, 0.2, 0.3, 0.4]}]) == 0
+try:
+    r = epsilla.query(table_name="T", query_field="V", query_vector=[0.1, 0.2, 0.3, 0.4], response_fields=["ID"], limit=1, filter="", with_distance=True)
+    print("ANSWERED", r)
+except BaseException as e:
+    print("REFUSED", e)
+''' % GPU_DIR
+    db = os.path.join(tempfile.mkdtemp(), "db")
+    r = subprocess.run([sys.executable, "-c", code, db], capture_output=True, text=True, timeout=300)
+    out = r.stdout + r.stderr
+    if torch.cuda.is_available():
+        assert "ANSWERED" in out, out[-2000:]
+    else:
+        assert "ANSWERED" not in out and ("REFUSED" in out or r.returncode != 0), out[-2000:]
+        assert "gfx950" in out, out[-2000:]

@@ -192,3 +192,48 @@ def test_reference_side_by_side_100k_x_128(amd, ref, tmp_path):
 def test_reference_side_by_side_1M_x_768(amd, ref, tmp_path):
     """BASELINE configs[1] size: 1M x 768 built on the device, searched by both sides at L = 500 and 4000."""
     _side_by_side(amd, ref, tmp_path, 1_000_000, 768, 12, [500, 4000])
+
+
+def test_traversal_edge_cases(amd, oracle):
+    """SearchQueueSize clamped to the graph size, a table barely above the brute-force threshold, isolated nodes, more workers
+    than the kernel keeps in flight (clamped to 16), GlobalSyncInterval = 1, k beyond LocalQueueSize, post-filter by a compiled
+    program with deletes - all against the oracle."""
+    from helpers import bitset
+    n, d = 600, 16
+    X, Q = data(n, d, 61), data(9, d, 62)
+    off, nbr, nav = oracle.build_graph(0, X, K=30)
+    lists = [list(nbr[off[i]:off[i + 1]]) for i in range(n)]
+    for i in (5, 77, 300):                          # isolated nodes: no out-edges at all
+        lists[i] = []
+    off2 = np.zeros(n + 1, np.int64)
+    off2[1:] = np.cumsum([len(l) for l in lists])
+    nbr2 = np.concatenate([np.asarray(l, np.int64) for l in lists if l])
+    ix = amd.GpuIndex(d, 0)
+    ix.attach_rows(X)
+    ix.set_graph(off2, nbr2, nav)
+    for T, L, I in ((1, 5000, 15), (4, 600, 1), (4, 512, 15), (40, 500, 15)):
+        Le = min(L, n)
+        Te = min(T, 16)
+        ids, dist, cnt = ix.search(Q, 50, mode=amd.MODE_GRAPH, intra_threads=T, master_queue=L, local_queue=L, sync_interval=I)
+        init = oracle.prepare_init_ids(off2, nbr2, nav, Le)
+        for qi, q in enumerate(Q):
+            oid, od, _ = oracle.search_impl(0, X, off2, nbr2, init, q, T=Te, L=Le, I=I, lockstep=True)
+            assert int(cnt[qi]) == 50
+            assert_topk_match(ids[qi], dist[qi], oid[:50], od[:50], what="T%d L%d I%d q%d" % (T, L, I, qi))
+    # result count is capped by LocalQueueSize (:872)
+    ids, dist, cnt = ix.search(Q, 100, mode=amd.MODE_GRAPH, intra_threads=1, master_queue=500, local_queue=30)
+    assert np.all(cnt == 30) and np.all(ids[:, 30:] == -1)
+    # post-filter (program) + deleted rows on the graph path == the oracle's Search() with the same int filter
+    rows = np.zeros(n, dtype=np.dtype([("id", "<i4"), ("x", "<f4")]))
+    rows["id"] = np.arange(n)
+    dele = bitset(n, range(0, n, 4))
+    ix.set_deleted(dele)
+    ix.set_filter_program([("i32", 0), ("const", 250), (">=",)], rows)
+    ids, dist, cnt = ix.search(Q, 10, mode=amd.MODE_REFERENCE, intra_threads=1)
+    from oracle.pyoracle import make_filter
+    flt, keep = make_filter(deleted=dele, attr=np.arange(n, dtype=np.int32), op=">=", value=250)
+    for qi, q in enumerate(Q):
+        oid, od, _ = oracle.search(0, X, n, off2, nbr2, nav, q, 10, T=1, L=500, flt=flt)
+        assert int(cnt[qi]) == len(oid)
+        assert_topk_match(ids[qi, :len(oid)], dist[qi, :len(oid)], oid, od, what="post-filter q%d" % qi)
+    ix.close()
