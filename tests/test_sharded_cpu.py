@@ -2,7 +2,12 @@
 exact top-k with the CPU oracle (checker standing in for eps_index_search), and the REAL sharding logic is
 exercised: hash-sharding by row index, global id = local*G + rank, one all-gather of [nq,k] (dist,id), k-way merge
 by (dist,id) (a numpy restatement of eps_merge_topk, whose device version is checked in test_gpu_parity).  The
-merged answer must equal the unsharded exact answer."""
+merged answer must equal the unsharded exact answer.
+
+The product code of the N > 1 path itself (eps_index_set_id_map, the packed all-gather buffer, eps_merge_topk_packed, the
+in-library shard group) cannot run without a GPU; it is covered on the GPU box with product code on both sides by
+tests/test_bench_contract.py::test_bench_two_ranks_on_one_gpu_merge_equals_unsharded_scan (two gloo ranks on one GPU through
+bench.py) and tests/test_gpu_sharded.py (eps_index_create_sharded with several shards on one device)."""
 import os
 import socket
 import sys
