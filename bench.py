@@ -32,7 +32,10 @@ sys.path.insert(0, ROOT)
 # MI355X_MICROARCH.md prescribes: gfx950 FETCH_SIZE counts 128-B requests at 64 B -> x2; FETCH_SIZE/WRITE_SIZE in KiB):
 #   mfma: profiles/r1_pmc_10Mx768_b1024.csv, (2 * 7042014 + 11837) KiB for the 9,257,600-row launch of
 #         mfma_filter_kernel_v7 = 14.43e9 bytes vs 14.22e9 algorithmic bytes of the fp16 mirror.
-TRAFFIC = {"mfma": (2 * 7042014 + 11837) * 1024.0}
+#   graph: profiles/r2_traverse_10Mx768_pmc.csv, traverse2_kernel T=4 L=500 batch 1024 on the 10M-node device-built graph:
+#         2 * 48440196 KiB = 99.2e9 bytes vs 100.97e9 algorithmic (the x2 calibrated in the same run on flat_scan_kernel,
+#         whose FETCH_SIZE x 2 = rows * dim * 4 exactly).
+TRAFFIC = {"mfma": (2 * 7042014 + 11837) * 1024.0, "graph_T4_L500": 2 * 48440196 * 1024.0}
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F16_PEAK_TF = 2500.0  # dense bf16/f16 MFMA peak (nominal, 2.4 GHz)
 MFMA_F16_SUSTAINED_TF = 1814.0  # measured: v_mfma_f32_32x32x16_f16 alone, operands toggling like data, 1.82 GHz (scripts/lab/mfma_peak.hip)
@@ -402,7 +405,8 @@ def main():
             n_, e_, nav_ = ix.graph_info()
             alg_bytes = st["dist_evals"] * (4.0 * d + 4) + st["expansions"] * (8 + 4.0 * e_ / n_)
             roof = {"bound": "hbm", "kernel": "traverse2_kernel (gather: E*(4d+4) + X*(8+4*deg) bytes, E evaluations and X expansions counted by the kernel)",
-                    "achieved": alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
+                    "achieved": alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "traffic": TRAFFIC.get("graph_T4_L500") if (n == 10_000_000 and b == 1024 and d == 768 and args.T == 4 and args.L == 500 and args.data == "uniform") else None}
         elif used_mfma:
             # algorithmic flops of the timed launch: 2 * batch * rows * d, on the fp16 dense MFMA roof
             flops = 2.0 * kq * krows * d   # queries x rows of the timed launch (batches > 2048 run in slices)
