@@ -45,6 +45,7 @@ struct Pending {
   int T;
   int64_t L, Lq, I;
   bool prefilter;
+  std::vector<eps_filter_op> program;   // compiled device filter (empty = unfiltered); part of the batch key
   // results
   std::vector<int64_t> ids;
   std::vector<float> dist;
@@ -266,10 +267,17 @@ Status VecSearchExecutor::Search(const VectorPtr query_data, vectordb::engine::T
   if (limit == 0) return Status::OK();
   DeviceField& dev = *dev_;
   {
-    const int root0 = static_cast<int>(filter_nodes.size()) - 1;
-    const bool unfiltered = root0 < 0 || (filter_nodes[root0]->node_type == NodeType::BoolConst && filter_nodes[root0]->bool_value);
+    // unfiltered queries and queries whose filter compiles to a device program go through the micro-batcher: concurrent calls
+    // with the same program (the same filter text) share one device batch
     static const bool batching = !(getenv("EPS_DROPIN_BATCH") && atoi(getenv("EPS_DROPIN_BATCH")) == 0);
-    if (unfiltered && batching) return SearchBatched(std::get<DenseVectorPtr>(query_data), table_segment, limit, result_size);
+    if (batching) {
+      const int root0 = static_cast<int>(filter_nodes.size()) - 1;
+      const bool unfiltered = root0 < 0 || (filter_nodes[root0]->node_type == NodeType::BoolConst && filter_nodes[root0]->bool_value);
+      if (unfiltered) return SearchBatched(std::get<DenseVectorPtr>(query_data), table_segment, limit, result_size, nullptr);
+      Compiler c{filter_nodes, table_segment};
+      c.Logical((size_t)root0, true);
+      if (!c.host_only && c.out.size() <= 64) return SearchBatched(std::get<DenseVectorPtr>(query_data), table_segment, limit, result_size, &c.out);
+    }
   }
   std::lock_guard<std::mutex> lk(dev.mu);
   auto fail = [&](const char* what) -> Status {
@@ -452,7 +460,8 @@ Status VecSearchExecutor::Search(const VectorPtr query_data, vectordb::engine::T
 namespace {
 bool SameKey(const Pending& a, const Pending& b) {
   return a.segment == b.segment && a.k == b.k && a.graph_owner == b.graph_owner && a.graph_n == b.graph_n && a.T == b.T &&
-         a.L == b.L && a.Lq == b.Lq && a.I == b.I && a.prefilter == b.prefilter;
+         a.L == b.L && a.Lq == b.Lq && a.I == b.I && a.prefilter == b.prefilter && a.program.size() == b.program.size() &&
+         (a.program.empty() || std::memcmp(a.program.data(), b.program.data(), a.program.size() * sizeof(eps_filter_op)) == 0);
 }
 
 void RunBatch(DeviceField& dev, int64_t dim, std::vector<Pending*>& batch) {
@@ -471,8 +480,13 @@ void RunBatch(DeviceField& dev, int64_t dim, std::vector<Pending*>& batch) {
     else { dev.graph_owner = h.graph_owner; dev.graph_n = h.graph_n; }
   }
   ConcurrentBitset& deleted = *(h.segment->deleted_);
-  if (err.empty() && (eps_index_set_int_filter(dev.h, nullptr, 0, 0, EPS_OP_NONE, 0) != EPS_OK ||
-                      eps_index_set_filter_program(dev.h, nullptr, 0, nullptr, 0, 0) != EPS_OK)) fail("filter reset");
+  if (err.empty() && eps_index_set_int_filter(dev.h, nullptr, 0, 0, EPS_OP_NONE, 0) != EPS_OK) fail("filter reset");
+  if (err.empty()) {
+    const int32_t rc = h.program.empty() ? eps_index_set_filter_program(dev.h, nullptr, 0, nullptr, 0, 0)
+                                         : eps_index_set_filter_program(dev.h, h.program.data(), (int32_t)h.program.size(), h.segment->attribute_table_,
+                                                                        h.segment->primitive_offset_, total_vector);
+    if (rc != EPS_OK) fail("filter program upload");
+  }
   if (err.empty() && eps_index_set_deleted(dev.h, deleted.data(), (int64_t)deleted.size()) != EPS_OK) fail("deleted upload");
   const int64_t nq = (int64_t)batch.size();
   const int32_t k = h.k;
@@ -505,9 +519,10 @@ void RunBatch(DeviceField& dev, int64_t dim, std::vector<Pending*>& batch) {
 }  // namespace
 
 Status VecSearchExecutor::SearchBatched(const float* query, vectordb::engine::TableSegmentMVP* table_segment, size_t limit,
-                                        int64_t& result_size) {
+                                        int64_t& result_size, const std::vector<eps_filter_op>* program) {
   DeviceField& dev = *dev_;
   Pending me;
+  if (program) me.program = *program;
   me.query = query;
   me.segment = table_segment;
   {

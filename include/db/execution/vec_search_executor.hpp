@@ -34,6 +34,8 @@
 #include "utils/json.hpp"
 #include "utils/status.hpp"
 
+struct eps_filter_op;   // include/epsilla_gfx950.h
+
 namespace vectordb {
 namespace engine {
 namespace execution {
@@ -77,8 +79,10 @@ class VecSearchExecutor {
                            std::vector<vectordb::query::expr::ExprNodePtr>& filter_nodes, int64_t& result_size);
 
  private:
-  // unfiltered queries: coalesced with the concurrent calls of the pool's other executors into one device batch
-  Status SearchBatched(const float* query, vectordb::engine::TableSegmentMVP* table_segment, size_t limit, int64_t& result_size);
+  // unfiltered queries and queries with a device-compiled filter: coalesced with the concurrent calls of the pool's other
+  // executors that carry the same filter program into one device batch
+  Status SearchBatched(const float* query, vectordb::engine::TableSegmentMVP* table_segment, size_t limit, int64_t& result_size,
+                       const std::vector<eps_filter_op>* program);
   std::shared_ptr<DeviceField> dev_;
   int metric_ = 0;
 };

@@ -335,6 +335,8 @@ class Ref:
                                     C.c_int, C.c_char_p, i64]
         L.ref_db_search_mt.restype = C.c_double
         L.ref_db_search_mt.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, fptr, i64, i64, i64, C.c_int, iptr]
+        L.ref_db_search_mt_filter.restype = C.c_double
+        L.ref_db_search_mt_filter.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, fptr, i64, i64, i64, C.c_int, C.c_char_p, iptr]
         L.ref_db_get.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, i64, i64, C.c_char_p, i64]
 
     def l2sqr(self, x, y):
@@ -482,12 +484,12 @@ class Ref:
             txt = buf.value.decode()
             return rc, (json.loads(txt) if rc == 0 else txt)
 
-        def search_mt(self, table, field, Q, limit, threads):
+        def search_mt(self, table, field, Q, limit, threads, flt=""):
             """Q.shape[0] single-vector Search calls from `threads` client threads; returns (seconds, best ids)."""
             Q = np.ascontiguousarray(Q, np.float32)
             first = np.empty(Q.shape[0], np.int64)
-            sec = self.r.L.ref_db_search_mt(self.h, self.name, table.encode(), field.encode(), _f(Q), Q.shape[0], Q.shape[1],
-                                            limit, threads, _i(first))
+            sec = self.r.L.ref_db_search_mt_filter(self.h, self.name, table.encode(), field.encode(), _f(Q), Q.shape[0], Q.shape[1],
+                                                   limit, threads, flt.encode(), _i(first))
             return sec, first
 
         def get(self, table, fields=("ID",), pks=None, flt="", skip=0, limit=1000, cap=1 << 24):

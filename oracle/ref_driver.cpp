@@ -463,8 +463,9 @@ int ref_db_get(void* h, const char* db, const char* table, const char* fields_cs
 
 // nq single-vector DBServer::Search calls issued from `threads` client threads (what concurrent REST requests do);
 // first_ids[q] = "ID" of the best hit of query q (or -1).  Returns elapsed seconds, or -1 on error.
-double ref_db_search_mt(void* h, const char* db, const char* table, const char* field, float* queries, int64_t nq, int64_t d,
-                        int64_t limit, int threads, int64_t* first_ids) {
+double ref_db_search_mt_filter(void* h, const char* db, const char* table, const char* field, float* queries, int64_t nq, int64_t d,
+                               int64_t limit, int threads, const char* filter, int64_t* first_ids) {
+  const std::string flt(filter ? filter : "");
   auto* srv = static_cast<vectordb::engine::DBServer*>(h);
   std::atomic<int64_t> next{0};
   std::atomic<int> bad{0};
@@ -477,7 +478,7 @@ double ref_db_search_mt(void* h, const char* db, const char* table, const char* 
       vectordb::Json result, facets_cfg, facets;
       facets_cfg.LoadFromString("[]");
       try {
-        auto st = srv->Search(db, table, f, fields, d, queries + q * d, limit, result, "", true, facets_cfg, facets);
+        auto st = srv->Search(db, table, f, fields, d, queries + q * d, limit, result, flt, true, facets_cfg, facets);
         if (!st.ok()) bad++;
         first_ids[q] = result.GetSize() > 0 ? result.GetArrayElement(0).GetInt("ID") : -1;
       } catch (const std::exception&) {
@@ -492,6 +493,11 @@ double ref_db_search_mt(void* h, const char* db, const char* table, const char* 
   for (auto& t : pool) t.join();
   const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   return bad.load() ? -1.0 : sec;
+}
+
+double ref_db_search_mt(void* h, const char* db, const char* table, const char* field, float* queries, int64_t nq, int64_t d,
+                        int64_t limit, int threads, int64_t* first_ids) {
+  return ref_db_search_mt_filter(h, db, table, field, queries, nq, d, limit, threads, "", first_ids);
 }
 
 int ref_omp_max_threads() { return omp_get_max_threads(); }
