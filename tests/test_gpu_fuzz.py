@@ -56,7 +56,7 @@ def test_auto_engine_equals_stream_engine(amd, c):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", list(range(10)))
+@pytest.mark.parametrize("seed", list(range(24)))
 def test_fuzz_traversal_matches_oracle_lockstep(amd, oracle, seed):
     """Seeded fuzz of the traversal kernel over worker counts, queue sizes (LocalQueueSize != SearchQueueSize included), sync
     intervals, metrics, batch sizes (4- and 16-wavefront variants) and adjacency shapes (fixed stride; CSR with lists beyond 64

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void prune_kernel(PruneArgs a) {
   u64* pool = reinterpret_cast<u64*>(sq + qstride);          // [PRUNE_POOL]
   u32* kept = reinterpret_cast<u32*>(pool + PRUNE_POOL);     // [R]
   float* keptd = reinterpret_cast<float*>(kept + a.R);       // [R]
-  int* sh = reinterpret_cast<int*>(keptd + a.R);             // [8]
+  int* sh = reinterpret_cast<int*>(keptd + a.R);             // [64] scalars, then the staged candidate vectors of the SelectEdge walk
   const int tid = threadIdx.x;
   const int lane = lane_id();
   const int wave = tid >> 6;
@@ -211,57 +211,91 @@ __global__ __launch_bounds__(256) void prune_kernel(PruneArgs a) {
     uniq = sh[8] + sh[9] + sh[10] + sh[11];
   }
   const bool keep_all = unlimited && uniq <= a.R;
+  // The walk is sequential by definition (a candidate is judged against everything kept BEFORE it), but PB candidates are
+  // evaluated per round: their vectors are staged in LDS, every kept row is streamed once against all of them (and the batch's
+  // own rows against the later members of the batch), then one thread resolves the batch in order.  A quarter of the barriers
+  // and of the row traffic of one candidate per round.
+  constexpr int PB = 4;
+  float* sqb = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(sh + 64) + 15) & ~(uintptr_t)15);   // [PB][qstride] candidate vectors (16-B aligned)
+  // sh[16+b] pool position of batch member b, sh[24+b] "a row kept before the batch is closer", sh[32 + b*PB + b2] "batch member b2 (< b)
+  // is closer to member b than v is"
   while (true) {
-    // thread 0 advances the cursor to the next unique candidate
-    if (tid == 0) {
+    if (tid == 0) {   // the next <= PB unique candidates
       int c = sh[2];
-      int found = -1;
-      while (c < PRUNE_POOL) {
+      int nb = 0;
+      while (nb < PB && c < PRUNE_POOL && (unlimited || sh[3] < a.depth)) {
         const u64 key = pool[c];
         if (key == KEY_EMPTY) break;
         const bool dup = (c > 0 && pool[c - 1] == key) || key_id(key) == (u32)v;
         if (!dup) {
-          found = c;
-          break;
+          sh[16 + nb] = c;
+          sh[24 + nb] = 0;
+          for (int b2 = 0; b2 < PB; ++b2) sh[32 + nb * PB + b2] = 0;
+          ++nb;
+          sh[3] += 1;
         }
         ++c;
       }
-      sh[2] = c + 1;
-      sh[6] = found;
-      if (found >= 0) sh[3] += 1;
-      sh[7] = 0;  // "some kept r is closer to p than v" flag
+      sh[2] = c;
+      sh[6] = nb;
     }
     __syncthreads();
-    const int cur = sh[6];
+    const int nb = sh[6];
     const int nk = sh[1];
-    if (cur < 0 || nk >= a.R || (!unlimited && sh[3] > a.depth)) break;
-    const u64 pkey = pool[cur];
-    const u32 pid = key_id(pkey);
-    const float pd = key_dist(pkey);
-    if (nk > 0 && !keep_all) {
-      for (int i = tid; i < qstride; i += 256) sq[i] = i < dim ? a.rows[(int64_t)pid * dim + i] : 0.f;
+    if (nb == 0 || nk >= a.R) break;
+    if (!keep_all && (nk > 0 || nb > 1)) {
+      for (int i = tid; i < PB * qstride; i += 256) {
+        const int b2 = i / qstride, c = i - b2 * qstride;
+        const u32 pid = key_id(pool[sh[16 + (b2 < nb ? b2 : 0)]]);
+        sqb[i] = c < dim ? a.rows[(int64_t)pid * dim + c] : 0.f;
+      }
       __syncthreads();
-      for (int c0 = wave * RPW * U; c0 < nk; c0 += 4 * RPW * U) {
+      float pd[PB];
+#pragma unroll
+      for (int b2 = 0; b2 < PB; ++b2) pd[b2] = b2 < nb ? key_dist(pool[sh[16 + b2]]) : -1.f;
+      const int nrows = nk + nb - 1;   // kept rows, then batch members 0 .. nb-2 (member b is judged against members < b)
+      for (int c0 = wave * RPW * U; c0 < nrows; c0 += 4 * RPW * U) {
         const float* rp[U];
+        int ci[U];
         bool ok[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const int ci = c0 + u * RPW + g;
-          ok[u] = ci < nk;
-          rp[u] = a.rows + (int64_t)kept[ok[u] ? ci : 0] * dim;
+          ci[u] = c0 + u * RPW + g;
+          ok[u] = ci[u] < nrows;
+          const int cc = ok[u] ? ci[u] : 0;
+          const u32 rid = cc < nk ? kept[cc] : key_id(pool[sh[16 + (cc - nk)]]);
+          rp[u] = a.rows + (int64_t)rid * dim;
         }
-        float acc[U][1];
-        row_dists<U, 1, VEC4>(rp, sq, qstride, dim, 0, G, acc);
+        float acc[U][PB];
+        row_dists<U, PB, VEC4>(rp, sqb, qstride, dim, 0, G, acc);
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-          if (ok[u] && t == 0 && acc[u][0] < pd) sh[7] = 1;
+        for (int u = 0; u < U; ++u) {
+          if (!ok[u] || t != 0) continue;
+#pragma unroll
+          for (int b2 = 0; b2 < PB; ++b2) {
+            if (b2 >= nb || !(acc[u][b2] < pd[b2])) continue;
+            if (ci[u] < nk) sh[24 + b2] = 1;
+            else if (ci[u] - nk < b2) sh[32 + b2 * PB + (ci[u] - nk)] = 1;
+          }
+        }
       }
       __syncthreads();
     }
-    if (tid == 0 && !sh[7]) {
-      kept[nk] = pid;
-      keptd[nk] = pd;
-      sh[1] = nk + 1;
+    if (tid == 0) {   // resolve the batch in candidate order
+      int k2 = nk;
+      int accepted[PB];
+      for (int b2 = 0; b2 < nb && k2 < a.R; ++b2) {
+        bool bad = sh[24 + b2] != 0;
+        for (int b3 = 0; b3 < b2 && !bad; ++b3) bad = accepted[b3] && sh[32 + b2 * PB + b3] != 0;
+        accepted[b2] = (keep_all || !bad) ? 1 : 0;
+        if (accepted[b2]) {
+          const u64 pkey = pool[sh[16 + b2]];
+          kept[k2] = key_id(pkey);
+          keptd[k2] = key_dist(pkey);
+          ++k2;
+        }
+      }
+      sh[1] = k2;
     }
     __syncthreads();
   }
@@ -296,8 +330,8 @@ __global__ void rev_scatter_kernel(const u32* ids, const float* dist, const u32*
     if (e__ != hipSuccess) return ix.hip_fail(e__, #expr);   \
   } while (0)
 
-static size_t prune_lds_bytes(int dim, int R) {
-  return (size_t)((dim + 3) & ~3) * 4 + (size_t)PRUNE_POOL * 8 + (size_t)R * 8 + 64;
+static size_t prune_lds_bytes(int dim, int R) {   // v's vector, pool, kept ids + distances, 64 scalars, 4 staged candidate vectors
+  return (size_t)((dim + 3) & ~3) * 4 + (size_t)PRUNE_POOL * 8 + (size_t)R * 8 + 64 * 4 + 16 + (size_t)4 * ((dim + 3) & ~3) * 4;
 }
 
 int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp) {
