@@ -323,13 +323,18 @@ Status VecSearchExecutor::Search(const VectorPtr query_data, vectordb::engine::T
 
   eps_search_params p;
   eps_default_search_params(&p);
+  // EPS_DROPIN_PREFER_EXACT=1 (opt-in, NOT the reference's semantics): answer graph-mode searches with the exact scan - recall 1.0
+  // instead of the graph's, and on one MI355X also the lower latency up to tens of millions of rows; result counts
+  // keep the reference's caps
+  static const bool prefer_exact = getenv("EPS_DROPIN_PREFER_EXACT") && atoi(getenv("EPS_DROPIN_PREFER_EXACT")) != 0;
   p.mode = EPS_MODE_REFERENCE;
   p.prefilter = prefilter_enabled_ ? 1 : 0;
   p.intra_threads = num_threads_;
   p.master_queue = L_master_;
   p.local_queue = L_local_;
   p.sync_interval = subsearch_iterations_;
-  const bool flat = prefilter_enabled_ || brute_force_search_ || dev.sharded;
+  const bool flat = prefilter_enabled_ || brute_force_search_ || dev.sharded || prefer_exact;
+  if (prefer_exact && !prefilter_enabled_ && !brute_force_search_) p.mode = EPS_MODE_FLAT;
   auto publish = [&](const int64_t* ids, const float* dist, int64_t count) {
     if ((size_t)count > search_result_.size()) {
       search_result_.resize(count);
@@ -498,7 +503,8 @@ void RunBatch(DeviceField& dev, int64_t dim, std::vector<Pending*>& batch) {
   if (err.empty()) {
     eps_search_params p;
     eps_default_search_params(&p);
-    p.mode = EPS_MODE_REFERENCE;
+    static const bool prefer_exact = getenv("EPS_DROPIN_PREFER_EXACT") && atoi(getenv("EPS_DROPIN_PREFER_EXACT")) != 0;
+    p.mode = prefer_exact && !h.prefilter ? EPS_MODE_FLAT : EPS_MODE_REFERENCE;
     p.prefilter = h.prefilter ? 1 : 0;
     p.intra_threads = h.T;
     p.master_queue = h.L;
