@@ -30,6 +30,9 @@ def gen(n, d, seed, kind, centres=None):
         e = min(n, s + step)
         if kind == "uniform":
             X[s:e] = torch.rand((e - s, d), generator=g, device="cuda")
+        elif kind == "manifold":   # centres = (A [16, d], noise sigma): intrinsic dimension 16 embedded in d
+            z = torch.rand((e - s, centres.shape[0]), generator=g, device="cuda")
+            X[s:e] = z @ centres + 0.01 * torch.randn((e - s, d), generator=g, device="cuda")
         else:
             a = torch.randint(0, centres.shape[0], (e - s,), generator=g, device="cuda")
             X[s:e] = centres[a] + 0.1 * torch.randn((e - s, d), generator=g, device="cuda")
@@ -51,7 +54,9 @@ def main():
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--k", type=int, default=10)
-    ap.add_argument("--data", default="uniform", choices=["uniform", "clustered"])
+    ap.add_argument("--data", default="uniform", choices=["uniform", "clustered", "manifold"],
+                    help="manifold: a 16-dimensional uniform latent embedded linearly in --dim dimensions + 1 %% noise (low intrinsic dimension, "
+                         "as learned embeddings have; not part of the BASELINE recipe)")
     ap.add_argument("--L", default="500,2000")
     ap.add_argument("--T", default="1,4")
     ap.add_argument("--reps", type=int, default=3)
@@ -63,6 +68,8 @@ def main():
     centres = None
     if args.data == "clustered":
         centres = torch.rand((1000, d), generator=torch.Generator(device="cuda").manual_seed(41), device="cuda")
+    if args.data == "manifold":
+        centres = 0.25 * torch.randn((16, d), generator=torch.Generator(device="cuda").manual_seed(41), device="cuda")
     X = gen(n, d, 42, args.data, centres)
     Q = gen(b, d, 43, args.data, centres)
     ix = amd.GpuIndex(d, 0).use_torch_stream()
