@@ -53,7 +53,9 @@ def parse():
     ap.add_argument("--metric", default="EUCLIDEAN")
     ap.add_argument("--mode", default="flat", choices=["flat", "graph"])
     ap.add_argument("--engine", default="auto", choices=["auto", "stream", "mfma"])
-    ap.add_argument("--data", default="uniform", choices=["uniform", "clustered"], help="clustered: SURVEY 8d secondary set, 1000 Gaussian clusters sigma=0.1")
+    ap.add_argument("--data", default="uniform", choices=["uniform", "clustered", "manifold"],
+                    help="clustered: SURVEY 8d secondary set, 1000 Gaussian clusters sigma=0.1; manifold: a 16-dimensional uniform latent embedded "
+                         "linearly in --dim dimensions + 1 %% noise (low intrinsic dimension, as learned embeddings have; tertiary, not in BASELINE)")
     ap.add_argument("--T", type=int, default=4, help="graph: IntraQueryThreads")
     ap.add_argument("--L", type=int, default=500, help="graph: SearchQueueSize")
     ap.add_argument("--load-graph", default=None)
@@ -74,6 +76,9 @@ def gen_rows(torch, n, d, seed, device, kind="uniform", centres=None):
         e = min(n, s + step)
         if kind == "uniform":
             X[s:e] = torch.rand((e - s, d), generator=g, device=device, dtype=torch.float32)
+        elif kind == "manifold":
+            z = torch.rand((e - s, centres.shape[0]), generator=g, device=device, dtype=torch.float32)
+            X[s:e] = z @ centres + 0.01 * torch.randn((e - s, d), generator=g, device=device, dtype=torch.float32)
         else:
             a = torch.randint(0, centres.shape[0], (e - s,), generator=g, device=device)
             X[s:e] = centres[a] + 0.1 * torch.randn((e - s, d), generator=g, device=device, dtype=torch.float32)
@@ -178,15 +183,16 @@ def cpu_baseline(args, torch, X, Q, gt_ids, graph, budget_s):
         off, nbr, nav, gn, ggt = graph
         g = ref.graph_from_arrays(off, nbr, nav)
         T = 4
+        Lcpu = args.L if args.mode == "graph" else 500
         E = max(1, threads // T)
         nqg = min(len(Qh), 4 * E)
-        ids_g, ds_g, lat, wall = ref.pool_search(g, ptr, d, Qh[:nqg], k, E=E, T=T, L=500)
+        ids_g, ds_g, lat, wall = ref.pool_search(g, ptr, d, Qh[:nqg], k, E=E, T=T, L=Lcpu)
         reps = int(max(0, min(16, (budget_s * 0.3) / max(wall, 1e-3) - 1)))
         if reps > 0:
             nqg2 = min(len(Qh), nqg * (reps + 1))
-            ids_g, ds_g, lat, wall = ref.pool_search(g, ptr, d, Qh[:nqg2], k, E=E, T=T, L=500)
+            ids_g, ds_g, lat, wall = ref.pool_search(g, ptr, d, Qh[:nqg2], k, E=E, T=T, L=Lcpu)
             nqg = nqg2
-        legs.append({"leg": "graph", "what": "reference SearchImpl on the device-built graph of the first %d rows, %d executors x %d OpenMP workers, SearchQueueSize 500" % (gn, E, T),
+        legs.append({"leg": "graph", "what": "reference SearchImpl on the device-built graph of the first %d rows, %d executors x %d OpenMP workers, SearchQueueSize %d" % (gn, E, T, Lcpu),
                      "qps": nqg / wall, "queries": nqg, "p50_ms": 1e3 * float(np.median(lat)), "p99_ms": 1e3 * float(np.percentile(lat, 99)),
                      "recall_at_10": recall_of(ids_g, ggt[:nqg]), "rows": gn})
         ref.L.ref_graph_free(g)
@@ -244,6 +250,8 @@ def main():
     centres = None
     if args.data == "clustered":
         centres = torch.rand((1000, d), generator=torch.Generator(device=dev).manual_seed(41), device=dev)
+    if args.data == "manifold":
+        centres = 0.25 * torch.randn((16, d), generator=torch.Generator(device=dev).manual_seed(41), device=dev)
     X = gen_rows(torch, n, d, 42 + rank, dev, args.data, centres)   # this rank's shard: global row id = local*world + rank
     gq = torch.Generator(device=dev).manual_seed(43)                # same queries on every rank
     if args.data == "uniform":
@@ -434,7 +442,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f32 (exact fp32 distances; the batched scan runs an fp16-MFMA lower-bound filter with fp32 accumulation, survivors re-ranked in fp32)"
                      if args.mode == "flat" else "f32",
-            "data": "synthetic" if args.data == "uniform" else "synthetic (clustered: 1000 Gaussian clusters, sigma 0.1 - SURVEY 8d secondary set)",
+            "data": "synthetic" if args.data == "uniform" else ("synthetic (clustered: 1000 Gaussian clusters, sigma 0.1 - SURVEY 8d secondary set)" if args.data == "clustered"
+                                                                else "synthetic (manifold: 16-dimensional uniform latent embedded in %d dimensions + 1%% noise - tertiary set, not the BASELINE recipe)" % d),
             "recall_at_10": recall,
             "recall_check": {"queries": nrec, "ground_truth": "exact fp32 direct-form stream scan of all rows (EPS_FLAT_STREAM)",
                              "ground_truth_vs_torch_fp32_scan": gt_vs_torch, "torch_queries": ntorch},
