@@ -245,7 +245,7 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
   er = hipGetDeviceProperties(&prop, ix.device_);
   if (er != hipSuccess) return ix.hip_fail(er, "device properties");
   const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  int per_cu = (int)std::min<size_t>((size_t)(32 / nw), (size_t)(160 * 1024) / shm);   // 32 wavefronts per CU at this register use
+  int per_cu = (int)std::min<size_t>((size_t)(16 / nw), (size_t)(160 * 1024) / shm);   // 4 wavefronts per SIMD at this register use (~104 VGPRs)
   if (const char* pc = getenv("EPS_TRV_PER_CU")) per_cu = std::max(1, atoi(pc));
   if (per_cu < 1) per_cu = 1;
   const int64_t words = (n + 31) / 32;
