@@ -92,9 +92,9 @@ static void launch_v5p(const FilterArgs& a, int cus, hipStream_t s) {
   hipLaunchKernelGGL(mfma_filter_kernel_v5, dim3(cus), dim3(512), 4 * 32768 + 2048, s, a);
 }
 static void launch_v7p(const FilterArgs& a, int cus, hipStream_t s) {
-  static bool once = (set_shm(mfma_filter_kernel_v7<2>, 4 * 32768 + 2048 + 4096), true);
+  static bool once = (set_shm(mfma_filter_kernel_v7<2, FM_IDS>, V7_LDS_BYTES), true);
   (void)once;
-  hipLaunchKernelGGL(mfma_filter_kernel_v7<2>, dim3(cus), dim3(256), 4 * 32768 + 2048 + 4096, s, a);
+  hipLaunchKernelGGL(mfma_filter_kernel_v7<2, FM_IDS>, dim3(cus), dim3(256), V7_LDS_BYTES, s, a);
 }
 template <int KNOB>
 static void launch_v6(const FilterArgs& a, int cus, hipStream_t s) {
@@ -150,7 +150,7 @@ int main(int argc, char** argv) {
   CK(hipDeviceSynchronize());
   FilterArgs a{};
   a.xh = xh; a.qh = qh; a.qf = qf; a.base = base; a.base_s = base_s; a.T = T; a.d_pad = d; a.tiles_q = nq / 256; a.tile0 = 0; a.ntiles = n_pad / 256;
-  a.row_hi = n; a.nq = nq; a.s = -2.f; a.cand = cand; a.cand_keys = nullptr; a.qstat = nullptr; a.metric = 0; a.cnt = cnt;
+  a.row_hi = n; a.nq = nq; a.s = -2.f; a.inv_s = -0.5f; a.sync_shift = 0; a.cand = cand; a.cand_keys = nullptr; a.qstat = nullptr; a.metric = 0; a.cnt = cnt;
   a.cap = cap; a.ablate = 0;
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));

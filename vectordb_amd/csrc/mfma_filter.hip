@@ -426,6 +426,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   fa.tiles_q = (int)(b_pad / BN3);
   fa.nq = nq;
   fa.s = ix.metric_ == 0 ? -2.f : -1.f;
+  fa.inv_s = 1.f / fa.s;
   fa.cand = m.cand.as<u32>();
   fa.cand_keys = approx ? m.cand.as<u64>() : nullptr;
   fa.qstat = m.qstat.as<float>();
@@ -433,6 +434,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   fa.cnt = cnt;
   fa.cap = cap;
   fa.group_sync = nullptr;
+  fa.sync_shift = getenv("EPS_MFMA_SYNC_SHIFT") ? std::min(8, std::max(0, atoi(getenv("EPS_MFMA_SYNC_SHIFT")))) : 2;
   fa.dense = 0;
   fa.ablate = 0;
 
@@ -450,15 +452,17 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   ra.run_keys = run_keys;
 
   const int bm = BM3;   // every kernel generation works on 256-row tiles
-  const size_t shm = version >= 7 ? 4 * 32768 + 2 * 256 * sizeof(float) + 4096 : 2 * 65536 + 2 * 256 * sizeof(float);
+  const size_t shm = version >= 7 ? V7_LDS_BYTES : 2 * 65536 + 2 * 256 * sizeof(float);
   if (!m.num_cus) {   // per index (= per device): no process-wide state
     hipDeviceProp_t prop;
     m.num_cus = hipGetDeviceProperties(&prop, ix.device_) == hipSuccess ? prop.multiProcessorCount : 256;
     m.num_cus = m.num_cus / 8 * 8;
     if (m.num_cus < 8) m.num_cus = 8;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_filter_kernel_v3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * 65536 + 2 * 256 * sizeof(float)));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_filter_kernel_v7<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * 32768 + 2 * 256 * sizeof(float) + 4096));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_filter_kernel_v7<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * 32768 + 2 * 256 * sizeof(float) + 4096));
+    for (const void* fn : {reinterpret_cast<const void*>(mfma_filter_kernel_v7<2, FM_IDS>), reinterpret_cast<const void*>(mfma_filter_kernel_v7<2, FM_KEYS>),
+                           reinterpret_cast<const void*>(mfma_filter_kernel_v7<2, FM_DENSE>), reinterpret_cast<const void*>(mfma_filter_kernel_v7<1, FM_IDS>),
+                           reinterpret_cast<const void*>(mfma_filter_kernel_v7<1, FM_KEYS>), reinterpret_cast<const void*>(mfma_filter_kernel_v7<1, FM_DENSE>)})
+      (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)V7_LDS_BYTES);
   }
   const int num_cus = m.num_cus;
   const bool narrow_env = !(getenv("EPS_MFMA_NARROW") && atoi(getenv("EPS_MFMA_NARROW")) == 0);
@@ -471,11 +475,17 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
       if (version >= 7) {
         f3.group_sync = gsync_env ? m.gsync.as<u32>() : nullptr;
         if (f3.group_sync && f3.dense) (void)hipMemsetAsync(f3.group_sync, 0, 1024, s);   // (stages: reset by threshold_kernel)
+        const int mode = f3.dense ? FM_DENSE : (f3.cand_keys ? FM_KEYS : FM_IDS);
+        const dim3 grid((unsigned)num_cus), block(256);
         if (nq <= 128 && narrow_env) {   // one 128-query tile: half the padded MFMA work, the pass streams the mirror
           f3.tiles_q = 1;
-          hipLaunchKernelGGL(mfma_filter_kernel_v7<1>, dim3((unsigned)num_cus), dim3(256), shm, s, f3);
+          if (mode == FM_DENSE) hipLaunchKernelGGL((mfma_filter_kernel_v7<1, FM_DENSE>), grid, block, shm, s, f3);
+          else if (mode == FM_KEYS) hipLaunchKernelGGL((mfma_filter_kernel_v7<1, FM_KEYS>), grid, block, shm, s, f3);
+          else hipLaunchKernelGGL((mfma_filter_kernel_v7<1, FM_IDS>), grid, block, shm, s, f3);
         } else {
-          hipLaunchKernelGGL(mfma_filter_kernel_v7<2>, dim3((unsigned)num_cus), dim3(256), shm, s, f3);
+          if (mode == FM_DENSE) hipLaunchKernelGGL((mfma_filter_kernel_v7<2, FM_DENSE>), grid, block, shm, s, f3);
+          else if (mode == FM_KEYS) hipLaunchKernelGGL((mfma_filter_kernel_v7<2, FM_KEYS>), grid, block, shm, s, f3);
+          else hipLaunchKernelGGL((mfma_filter_kernel_v7<2, FM_IDS>), grid, block, shm, s, f3);
         }
       }
       else hipLaunchKernelGGL(mfma_filter_kernel_v3, dim3((unsigned)num_cus), dim3(512), shm, s, f3);

@@ -25,6 +25,7 @@ struct FilterArgs {
   const float* base_s;  // [n_pad] base / s (v5: accumulators are initialised straight from it)
   int dense;            // v7 seed pass: every row is a candidate - keys go to slot (row - first row), no test, no atomics
   u32* group_sync;      // v7: one arrival counter per group of workgroups that share row tiles (zeroed per launch), or null
+  int sync_shift;       // v7: the group meets before every 2^sync_shift-th tile
   const float* T;       // [b_pad]
   int d_pad;
   int tiles_q;          // b_pad / BN
@@ -33,6 +34,7 @@ struct FilterArgs {
   int64_t row_hi;       // rows >= row_hi are not reported
   int64_t nq;
   float s;              // -2 (L2) or -1
+  float inv_s;          // 1 / s (v7 reads it as a kernel argument: as a value computed in the kernel it is one more VGPR live across the tile loop)
   u32* cand;
   u64* cand_keys;       // approx mode: (approx dist, row) keys instead of row ids
   const float* qstat;   // [b_pad][4] (approx mode: |q|^2 to turn keys into distances)
@@ -42,6 +44,24 @@ struct FilterArgs {
   int ablate;           // profiling only (EPS_MFMA_ABLATE): v1: bit0 skip staging loads, bit1 skip MFMAs, bit2 skip LDS
                         // fragment reads; v3: bit3 skip the query-operand DMA, bit4 skip the row-operand DMA
 };
+
+// max of the 16 accumulators a lane holds of one 32 x 32 block: 8 x v_max3_f32 in ONE asm statement (chained fmaxf costs 10
+// instructions - hipcc canonicalises operands it cannot prove quiet - and separate asm statements get an s_nop each)
+__device__ __forceinline__ float max16f(const f32x16& v) {
+  float d;
+  asm("v_max3_f32 %0, %1, %2, %3\n\t"
+      "v_max3_f32 %0, %0, %4, %5\n\t"
+      "v_max3_f32 %0, %0, %6, %7\n\t"
+      "v_max3_f32 %0, %0, %8, %9\n\t"
+      "v_max3_f32 %0, %0, %10, %11\n\t"
+      "v_max3_f32 %0, %0, %12, %13\n\t"
+      "v_max3_f32 %0, %0, %14, %15\n\t"
+      "v_max_f32 %0, %0, %16"
+      : "=&v"(d)
+      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]),
+        "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]));
+  return d;
+}
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (row << 3) + (chunk ^ ((row >> 1) & 7)); }  // 16-B granule index
 
@@ -280,7 +300,20 @@ __global__ __launch_bounds__(512, 2) void mfma_filter_kernel_v3(FilterArgs a) {
 // LDS-DMA piece (row operand, three steps ahead) or one query-fragment load (two steps ahead).
 // JQ = 32-query blocks per wavefront: 2 -> 256-query tiles (the throughput shape), 1 -> 128-query tiles for batches of
 // <= 128 queries, which halves the (padded) MFMA work and leaves the pass bound by streaming the fp16 mirror.
-template <int JQ>
+// MODE (what a tile's epilogue does with the accumulators; compile-time so that the tile loop carries one path only):
+//   FM_IDS   rows with acc >= T_q are appended to the query's candidate list as row ids           (exact mode, every stage)
+//   FM_KEYS  the same, as (approximate distance, row) keys                                         (approx mode)
+//   FM_DENSE seed pass: the approximate key of EVERY row goes to slot (row - first row): no test, no atomics
+// Appending (r2): a hit used to cost the wavefront one returning global atomic + the vmcnt(0) that waits for it - which also
+// drains the LDS-DMA ring - i.e. ~1 us of a ~21 us tile, and the other three wavefronts wait for it at the next barrier; the
+// main stage of the 10M-row scan sees ~0.3 hits per wavefront and tile.  Hits now go to a per-wavefront LDS list (slot by
+// an LDS atomic: lgkmcnt only) that is flushed to the global lists, all entries at once, when it is half full (and at the
+// end of the kernel); only a hit that finds the list full takes the direct path.
+enum { FM_IDS = 0, FM_KEYS = 1, FM_DENSE = 2 };
+constexpr int V7_CAPW = 128;   // entries of a wavefront's pending-candidate list
+constexpr size_t V7_LDS_BYTES = 4 * 32768 + 2 * 256 * sizeof(float) + 4096 + 64 + 4 * V7_CAPW * (8 + 4);
+
+template <int JQ, int MODE>
 __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
   constexpr int QT = 128 * JQ;   // queries per tile
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -311,17 +344,20 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
   // LDS-DMA piece `it` (0..7) of a K-step covers rows [32 it, 32 it + 32) of the tile: lane offsets differ from piece 0's
   // only by it * 32 rows, which goes into the scalar base - one offset register for all pieces
   u32 g_off0;
-  auto tile_rt = [&](int64_t t) { return (int64_t)xcd + 8 * (rg + (t / nqt) * G); };
-  auto tile_qt = [&](int64_t t) { return qslot + (int)(t % nqt) * QTB; };
-  auto rows_of = [&](int64_t t) { return a.xh + (a.tile0 + tile_rt(t)) * 256 * (int64_t)ldk; };
+  // tile t of this workgroup = (row index ri = t / nqt, query index qi = t % nqt), kept as two counters that are stepped
+  // (a 64-bit division per tile is ~150 scalar instructions on this machine, and the tile loop had two)
+  auto tile_rt = [&](int ri) { return (int64_t)xcd + 8 * (rg + (int64_t)ri * G); };
+  auto tile_qt = [&](int qi) { return qslot + qi * QTB; };
+  auto rows_of = [&](int ri) { return a.xh + (a.tile0 + tile_rt(ri)) * 256 * (int64_t)ldk; };
   // fragment stream of this wavefront's first 32-query block; the second block follows at + (ldk/16)*512 halfs
-  auto frags_of = [&](int64_t t) { return a.qf + ((int64_t)(tile_qt(t) * (4 * JQ) + wave * JQ) * (ldk / 16)) * 512; };
+  auto frags_of = [&](int qi) { return a.qf + ((int64_t)(tile_qt(qi) * (4 * JQ) + wave * JQ) * (ldk / 16)) * 512; };
+  auto advance = [&](int& ri, int& qi) { if (++qi == nqt) { qi = 0; ++ri; } };
   const int64_t jstride = (int64_t)(ldk / 16) * 512;
   u32 lane16, lane4;
   const u32 lds_base = (u32)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
-  auto issue_base = [&](int64_t t) {  // pre-scaled |x|^2 column of tile t -> base_lds[t & 1] (64 rows per wavefront)
-    const float* pb = a.base_s + (a.tile0 + tile_rt(t)) * 256 + wave * 64;
-    const u32 m0v = lds_base + RING * ASLOT + (u32)(((t & 1) * 256 + wave * 64) * 4);
+  auto issue_base = [&](int ri, int par) {  // pre-scaled |x|^2 column of row tile ri -> base_lds[par] (64 rows per wavefront)
+    const float* pb = a.base_s + (a.tile0 + tile_rt(ri)) * 256 + wave * 64;
+    const u32 m0v = lds_base + RING * ASLOT + (u32)((par * 256 + wave * 64) * 4);
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : : "v"(lane4), "s"(pb), "s"(m0v) : "memory");
   };
   // LDS-DMA, saddr form: 32-bit lane offset + scalar base, M0 = LDS address of lane 0's 16 bytes.  Hand-issued so the
@@ -335,7 +371,6 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
   f32x16 acc[8][JQ];
   half8 fb[2][4][JQ];
   half8 fa[2][8];
-  const float inv_s = 1.0f / a.s;
   int64_t qj[JQ];
   // Tq = T/s: a row passes iff acc >= Tq (s < 0); cj: approx-mode constant of the query.  Per-lane constants of the
   // query tile: parked in LDS and read back at each epilogue - as registers they would be live across the K loop, get
@@ -344,8 +379,8 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
 #pragma unroll
   for (int j = 0; j < JQ; ++j) {
     qj[j] = (int64_t)qslot * QT + wave * (32 * JQ) + j * 32 + l31;
-    tq_lds[j * 64 + lane] = a.T[qj[j]] * inv_s;
-    tq_lds[(2 + j) * 64 + lane] = a.cand_keys ? (a.metric == 0 ? a.qstat[qj[j] * 4] : (a.metric == 1 ? 1.f : 0.f)) : 0.f;
+    tq_lds[j * 64 + lane] = a.T[qj[j]] * a.inv_s;
+    tq_lds[(2 + j) * 64 + lane] = MODE != FM_IDS ? (a.metric == 0 ? a.qstat[qj[j] * 4] : (a.metric == 1 ? 1.f : 0.f)) : 0.f;
   }
   // Everything derived from the lane id that the K loop keeps in registers is RE-DERIVED at the top of every tile from
   // v_mbcnt (a dozen VALU instructions): values that live across the tile loop get spilled around the epilogue's
@@ -363,12 +398,42 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
   };
   lane_values();
 
+  int ri_c = 0, qi_c = 0;        // tile t
+  int ri_n = 0, qi_n = 0;        // tile t + 1
+  advance(ri_n, qi_n);
   const _Float16* A_t = rows_of(0);
-  const _Float16* A_n = ntile > 1 ? rows_of(1) : A_t;
+  const _Float16* A_n = ntile > 1 ? rows_of(ri_n) : A_t;
   const _Float16* B_t = frags_of(0);
-  const _Float16* B_n = (nqt > 1 && ntile > 1) ? frags_of(1) : B_t;
+  const _Float16* B_n = (nqt > 1 && ntile > 1) ? frags_of(qi_n) : B_t;
+  // pending-candidate list of this wavefront (see MODE above): counter, (query << 32 | row) entries, approximate keys
+  u32* wcnt = reinterpret_cast<u32*>(lds + RING * ASLOT + 2048 + 4096) + wave * 4;
+  u64* wbuf = reinterpret_cast<u64*>(lds + RING * ASLOT + 2048 + 4096 + 64) + wave * V7_CAPW;
+  float* wkey = reinterpret_cast<float*>(lds + RING * ASLOT + 2048 + 4096 + 64 + 4 * V7_CAPW * 8) + wave * V7_CAPW;
+  if (MODE != FM_DENSE && lane == 0) *wcnt = 0;
+  auto append = [&](int64_t qq, u32 row, float dapx) __attribute__((always_inline)) {   // straight to the global list
+    const u32 slot_c = atomicAdd(&a.cnt[qq], 1u);
+    if (slot_c < (u32)a.cap) {
+      if (MODE == FM_KEYS) a.cand_keys[qq * (int64_t)a.cap + slot_c] = make_key(dapx, row);
+      else a.cand[qq * (int64_t)a.cap + slot_c] = row;
+    }
+  };
+  auto flush = [&]() __attribute__((always_inline)) {
+    u32 ln;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+    u32 n = *reinterpret_cast<volatile u32*>(wcnt);
+    n = n < (u32)V7_CAPW ? n : (u32)V7_CAPW;
+    for (u32 e = ln; e < n; e += 64) {
+      const u64 v = wbuf[e];
+      append((int64_t)(v >> 32), (u32)v, MODE == FM_KEYS ? wkey[e] : 0.f);
+    }
+    if (ln == 0) *reinterpret_cast<volatile u32*>(wcnt) = 0;
+  };
+  const bool rendezvous = a.group_sync && a.tiles_q <= per_xcd;   // (then nqt == 1 for every member of the group)
+  u32* gs_ctr = a.group_sync + (xcd * G + rg);
+  const int64_t sync_mask = ((int64_t)1 << a.sync_shift) - 1;   // the group meets before every 2^sync_shift-th tile
+  if (rendezvous && wave == 0 && lane == 0) __hip_atomic_fetch_add(gs_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  issue_base(0);
+  issue_base(0, 0);
   // prologue = the issue groups of the imaginary steps -3, -2, -1 (16 operations each from -2 on)
 #pragma unroll
   for (int it = 0; it < 8; ++it) issue_piece(A_t, 0, 0, it);
@@ -459,35 +524,40 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
   };
 
   for (int64_t t = 0; t < ntile; ++t) {
-    const int64_t row0 = (a.tile0 + tile_rt(t)) * 256;
-    const int64_t qbase = (int64_t)tile_qt(t) * QT + wave * (32 * JQ);   // scalar
+    const int64_t row0 = (a.tile0 + tile_rt(ri_c)) * 256;
+    const int64_t qbase = (int64_t)tile_qt(qi_c) * QT + wave * (32 * JQ);   // scalar
     lane_values();
     const int kh4 = (int)(lane16 >> 7) & 4;     // = 4 * khalf
     // The QTB workgroups of a group stream the SAME row tiles (each against its own query tile) and only the first to
     // ask pays the HBM fetch - if the others ask within the few microseconds the lines survive in this XCD's L2.  With
     // the operands prefetched three steps ahead nothing self-synchronises them any more (measured: FETCH_SIZE 1.9 x
-    // the algorithmic bytes), so they rendezvous at every tile start: arrive, then poll (scalar loads: no VMEM
-    // counter involved) until the whole group has arrived - bounded, so a missing member can only cost time.
-    if (a.group_sync && nqt == 1 && wave == 0) {
-      u32* ctr = a.group_sync + (xcd * G + rg);
-      if (lane16 == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const u32 want = (u32)QTB * (u32)(t + 1);
-      for (int spin = 0; spin < 256; ++spin) {
+    // the algorithmic bytes), so they rendezvous every few tiles: each member ARRIVES when its K loop of the previous
+    // tile ends (before that tile's epilogue, so the round trip of the atomic hides under it) and here only polls
+    // (scalar loads: no VMEM counter involved) until the whole group has arrived - bounded, so a missing member can
+    // only cost time.
+    if (rendezvous && wave == 0 && (t & sync_mask) == 0) {
+      const u32 want = (u32)QTB * (u32)((t >> a.sync_shift) + 1);
+      for (int spin = 0; spin < 1024; ++spin) {
         u32 seen;
-        asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(seen) : "s"(ctr) : "memory");
+        asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(seen) : "s"(gs_ctr) : "memory");
         if (seen >= want) break;
-        __builtin_amdgcn_s_sleep(8);
+        __builtin_amdgcn_s_sleep(2);
       }
     }
-    if (nqt > 1 && t > 0) {
+    if (nqt > 1 && t > 0) {   // (everything lane-dependent re-derived here as well: nothing of it may live across the K loop)
 #pragma unroll
       for (int j = 0; j < JQ; ++j) {
-        qj[j] = (int64_t)tile_qt(t) * QT + wave * (32 * JQ) + j * 32 + l31;
-        tq_lds[j * 64 + (lane16 >> 4)] = a.T[qj[j]] * inv_s;
-        tq_lds[(2 + j) * 64 + (lane16 >> 4)] = a.cand_keys ? (a.metric == 0 ? a.qstat[qj[j] * 4] : (a.metric == 1 ? 1.f : 0.f)) : 0.f;
+        const int64_t qjt = (int64_t)tile_qt(qi_c) * QT + wave * (32 * JQ) + j * 32 + ((lane16 >> 4) & 31);
+        tq_lds[j * 64 + (lane16 >> 4)] = a.T[qjt] * a.inv_s;
+        float cm;   // (materialised here from a scalar: as an ordinary value hipcc keeps it in a VGPR across the tile loop and spills it)
+        {
+          const int sv = a.metric == 1 ? 0x3f800000 : 0;   // 1.0f : 0.0f
+          asm volatile("v_mov_b32 %0, %1" : "=v"(cm) : "s"(sv));
+        }
+        tq_lds[(2 + j) * 64 + (lane16 >> 4)] = MODE != FM_IDS ? (a.metric == 0 ? a.qstat[qjt * 4] : cm) : 0.f;
       }
     }
-    if (t + 1 < ntile) issue_base(t + 1);
+    if (t + 1 < ntile) issue_base(ri_n, (int)((t + 1) & 1));
     {
       const float* bl0 = base_lds + (t & 1) * 256;
 #pragma unroll
@@ -510,11 +580,15 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
       step(kt, std::integral_constant<int, 0>{}, std::false_type{});
       step(kt + 1, std::integral_constant<int, 1>{}, std::false_type{});
     }
+    if (rendezvous && wave == 0 && t + 1 < ntile && ((t + 1) & sync_mask) == 0 && lane16 == 0) __hip_atomic_fetch_add(gs_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     A_t = A_n;
     B_t = B_n;
+    ri_c = ri_n;
+    qi_c = qi_n;
+    advance(ri_n, qi_n);
     if (t + 2 < ntile) {
-      A_n = rows_of(t + 2);
-      if (nqt > 1) B_n = frags_of(t + 2);
+      A_n = rows_of(ri_n);
+      if (nqt > 1) B_n = frags_of(qi_n);
     }
     // the epilogue derives its lane constants afresh too (nothing lane-dependent is live across the K loop but the
     // operand offsets the loop itself uses)
@@ -525,7 +599,7 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
 #pragma unroll
     for (int j = 0; j < JQ; ++j) {
       Tq[j] = tq_lds[j * 64 + lne];
-      cj[j] = tq_lds[(2 + j) * 64 + lne];
+      cj[j] = MODE == FM_DENSE ? tq_lds[(2 + j) * 64 + lne] : 0.f;   // (FM_KEYS reads it where a row passes: one live register less)
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -533,7 +607,7 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
 #pragma unroll
       for (int j = 0; j < JQ; ++j) {
         __builtin_amdgcn_sched_barrier(0);   // one 32 x 32 block at a time (bounded register pressure)
-        if (a.dense) {   // seed pass (approx keys of ALL head rows): slot = row index, no compare, no atomic
+        if (MODE == FM_DENSE) {   // seed pass (approx keys of ALL head rows): slot = row index, no compare, no atomic
           const int64_t qq = qbase + j * 32 + l31e;
           if (qq < a.nq) {
 #pragma unroll
@@ -549,25 +623,30 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
           }
           continue;
         }
-        float mx = acc[i][j][0];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[i][j][r]);
+        // the block's running max: 8 x v_max3_f32 (fmaxf chains cost 10: hipcc canonicalises the first two operands)
+        const float mx = max16f(acc[i][j]);
         if (__any(mx >= Tq[j])) {
+          // (rare) everything the hit path needs is derived behind this opaque copy of the lane id, or hipcc hoists the
+          // address arithmetic of all 16 blocks into the common path
+          int l31h = l31e, rbh = rbase;
+          asm volatile("" : "+v"(l31h), "+v"(rbh));
+          const int64_t qq = qbase + j * 32 + l31h;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             if (acc[i][j][r] >= Tq[j]) {
-              const int64_t row = row0 + rbase + (r & 3) + 8 * (r >> 2);
-              const int64_t qq = qbase + j * 32 + l31e;
+              const int64_t row = row0 + rbh + (r & 3) + 8 * (r >> 2);
               if (row < a.row_hi && qq < a.nq) {
-                const u32 slot_c = atomicAdd(&a.cnt[qq], 1u);
-                if (slot_c < (u32)a.cap) {
-                  if (a.cand_keys) {
-                    float dapx = acc[i][j][r] * a.s + cj[j];
-                    if (a.metric == 0) dapx = fmaxf(dapx, 0.f);
-                    a.cand_keys[qq * (int64_t)a.cap + slot_c] = make_key(dapx, (u32)row);
-                  } else {
-                    a.cand[qq * (int64_t)a.cap + slot_c] = (u32)row;
-                  }
+                float dapx = 0.f;
+                if (MODE == FM_KEYS) {
+                  dapx = acc[i][j][r] * a.s + tq_lds[(2 + j) * 64 + lne];
+                  if (a.metric == 0) dapx = fmaxf(dapx, 0.f);
+                }
+                const u32 e = atomicAdd(wcnt, 1u);   // LDS: no VMEM counter involved
+                if (e < (u32)V7_CAPW) {
+                  wbuf[e] = ((u64)qq << 32) | (u32)row;
+                  if (MODE == FM_KEYS) wkey[e] = dapx;
+                } else {
+                  append(qq, (u32)row, dapx);
                 }
               }
             }
@@ -575,7 +654,11 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
         }
       }
     }
+    if (MODE != FM_DENSE) {
+      if (*reinterpret_cast<volatile u32*>(wcnt) >= (u32)(V7_CAPW / 2)) flush();
+    }
   }
+  if (MODE != FM_DENSE) flush();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
