@@ -505,6 +505,8 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
             default: EPS_DS_READ_B128(fa[nxt][7], ad, 28672); break;
           }
         }
+        // (all loads of the loop stay in straight-line code: around a branch hipcc gives an asm load's destination a fresh
+        // register and copies it - possibly before the data has landed; r2 tried to stagger the wavefronts' DMA issue that way)
         if (i == 1 || i == 3) {          // query fragments of the PREVIOUS sub-step's slot, for two steps from now
           if (kk > 0 && (i >> 1) < JQ) EPS_GLOAD_B128(fb[rb][kk - 1][(i >> 1) % JQ], lane16, pB + (i >> 1) * jstride + (kk - 1) * 512, 0);
         } else if (i == 5 || i == 7) {
