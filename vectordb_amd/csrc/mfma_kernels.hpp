@@ -398,6 +398,7 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
   };
   lane_values();
 
+  const int64_t a_stride = (int64_t)8 * G * 256 * ldk;   // halfs between consecutive row tiles of this workgroup
   int ri_c = 0, qi_c = 0;        // tile t
   int ri_n = 0, qi_n = 0;        // tile t + 1
   advance(ri_n, qi_n);
@@ -529,7 +530,6 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
     const int64_t row0 = (a.tile0 + tile_rt(ri_c)) * 256;
     const int64_t qbase = (int64_t)tile_qt(qi_c) * QT + wave * (32 * JQ);   // scalar
     lane_values();
-    const int kh4 = (int)(lane16 >> 7) & 4;     // = 4 * khalf
     // The QTB workgroups of a group stream the SAME row tiles (each against its own query tile) and only the first to
     // ask pays the HBM fetch - if the others ask within the few microseconds the lines survive in this XCD's L2.  With
     // the operands prefetched three steps ahead nothing self-synchronises them any more (measured: FETCH_SIZE 1.9 x
@@ -560,7 +560,9 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
       }
     }
     if (t + 1 < ntile) issue_base(ri_n, (int)((t + 1) & 1));
-    {
+    {   // acc[i][0] <- the pre-scaled |x|^2 column of the tile (hipcc reads it from LDS straight into the AGPRs here; moved
+        // into the previous tile's epilogue it goes through VGPRs + 100 v_accvgpr_write instead)
+      const int kh4 = (int)(lane16 >> 7) & 4;     // = 4 * khalf
       const float* bl0 = base_lds + (t & 1) * 256;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -587,10 +589,13 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
     B_t = B_n;
     ri_c = ri_n;
     qi_c = qi_n;
-    advance(ri_n, qi_n);
-    if (t + 2 < ntile) {
-      A_n = rows_of(ri_n);
-      if (nqt > 1) B_n = frags_of(qi_n);
+    {
+      const int ri_before = ri_n;
+      advance(ri_n, qi_n);
+      if (t + 2 < ntile) {
+        if (ri_n != ri_before) A_n += a_stride;   // the next row tile of this workgroup: 8 * G tiles further on
+        if (nqt > 1) B_n = frags_of(qi_n);
+      }
     }
     // the epilogue derives its lane constants afresh too (nothing lane-dependent is live across the K loop but the
     // operand offsets the loop itself uses)
