@@ -106,11 +106,14 @@ def test_reference_executor_searches_device_built_graph(amd):
     ix.close()
 
 
-def test_build_100k_mfma_knn_path(amd):
-    """n >= 65536 takes the matrix-core kNN path. Graph sanity + recall of the default search (L=500) against the
-    exact flat scan; the reference reaches 0.955 on 100k x 128 uniform data at L=500."""
+@pytest.mark.parametrize("n,d,min_recall", [(100_000, 64, 0.95), (70_000, 256, 0.85)])
+def test_build_100k_mfma_knn_path(amd, n, d, min_recall):
+    """n >= 65536 takes the matrix-core kNN path (d = 64: the v3 kernel; d = 256: mfma_filter_kernel_v7 in its key-appending
+    mode, K = 100 hits per query and stage). Graph sanity + recall of the default search (L=500) against the exact flat
+    scan; the reference reaches 0.955 on 100k x 128 uniform data at L=500; uniform 256-d data is harder for
+    any graph (the bound is what an exact-kNN NSG reaches there, not a tuning target)."""
     import torch
-    n, d, nq = 100_000, 64, 200
+    nq = 200
     g = torch.Generator(device="cuda").manual_seed(42)
     X = torch.rand((n, d), generator=g, device="cuda")
     Q = torch.rand((nq, d), generator=g, device="cuda")
@@ -132,8 +135,8 @@ def test_build_100k_mfma_knn_path(amd):
             st = ix.stats()
             print("evals/query %.0f expansions/query %.0f" % (st["dist_evals"] / nq, st["expansions"] / nq))
     r = recall_at_k(outs["graph"], outs["flat"])
-    print("recall@10 at L=500 on 100k x 64:", r)
-    assert r >= 0.95
+    print("recall@10 at L=500 on %d x %d:" % (n, d), r)
+    assert r >= min_recall
     ix.close()
 
 

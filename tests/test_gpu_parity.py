@@ -349,6 +349,32 @@ def test_mfma_v7_shapes_are_exact(amd, n, d, nq, metric):
     ix.close()
 
 
+@pytest.mark.parametrize("env", [{"EPS_MFMA_MAX_BATCH": "16384"}, {"EPS_MFMA_SYNC_SHIFT": "0"}, {"EPS_MFMA_SYNC_SHIFT": "5"},
+                                 {"EPS_MFMA_GROUPSYNC": "0"}, {"EPS_MFMA_SEED": "0"}])
+def test_mfma_v7_tile_walk_variants_are_exact(amd, monkeypatch, env):
+    """The filter kernel's tile walk under its host-side knobs (read per search call): one pass over 8448 queries instead
+    of slices of 2048 (33 query tiles > 32 workgroups per XCD: some workgroups walk two query tiles, step their (row,
+    query) tile counters through a wrap, reload thresholds per tile and do not rendezvous), the group rendezvous before
+    every tile / every 32nd tile / never, and unseeded staging (loose first-stage thresholds: thousands of hits per
+    wavefront, so the pending-hit list in LDS fills, flushes and overflows to the direct path).  k = 200 keeps the lists
+    busy in every stage.  MFMA engine == fp32 stream engine, bit for bit."""
+    for kk, vv in env.items():
+        monkeypatch.setenv(kk, vv)
+    n, d, nq = 70_000, 256, 8448 if "EPS_MFMA_MAX_BATCH" in env else 600
+    X = data(n, d, 170 + d)
+    Q = data(nq, d, 171 + d)
+    ix = amd.GpuIndex(d, 0)
+    ix.attach_rows(X)
+    for k in (10, 200):
+        a = ix.search(Q, k, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA)
+        st = ix.stats()
+        assert st["overflow_queries"] == 0 and st["rerank_rows"] > 0
+        b = ix.search(Q, k, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
+        assert np.array_equal(a[0], b[0]), "k=%d: %d rows differ" % (k, (a[0] != b[0]).sum())
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    ix.close()
+
+
 @pytest.mark.parametrize("nq", [1, 3, 8, 17, 31, 100, 128, 129])
 def test_small_batches_auto_engine_is_exact(amd, nq):
     """FLAT_AUTO is a cost decision between two engines that return the same bits: from 8 queries on (or earlier, once
