@@ -362,9 +362,9 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
   };
   // LDS-DMA, saddr form: 32-bit lane offset + scalar base, M0 = LDS address of lane 0's 16 bytes.  Hand-issued so the
   // compiler neither forms 64-bit VGPR addresses nor tracks these in its waitcnt model (see v5).
-  auto issue_piece = [&](const _Float16* pA, int kt, int slot, int it) {
-    const _Float16* sb = pA + kt * 64 + (int64_t)it * 32 * ldk;
-    const u32 m0v = lds_base + slot * ASLOT + (it * 256 + wave * 64) * 16;
+  auto issue_piece = [&](const _Float16* pA, u32 slot_off, int it) {   // pA: first row of the tile, at the K-step to fetch
+    const _Float16* sb = pA + (int64_t)it * 32 * ldk;
+    const u32 m0v = lds_base + slot_off + (it * 256 + wave * 64) * 16;
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(g_off0), "s"(sb), "s"(m0v) : "memory");
   };
 
@@ -437,16 +437,16 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
   issue_base(0, 0);
   // prologue = the issue groups of the imaginary steps -3, -2, -1 (16 operations each from -2 on)
 #pragma unroll
-  for (int it = 0; it < 8; ++it) issue_piece(A_t, 0, 0, it);
+  for (int it = 0; it < 8; ++it) issue_piece(A_t, 0, it);
 #pragma unroll
-  for (int it = 0; it < 8; ++it) issue_piece(A_t, 1, 1, it);
+  for (int it = 0; it < 8; ++it) issue_piece(A_t + 64, ASLOT, it);
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
     EPS_GLOAD_B128(fb[0][kk][0], lane16, B_t + kk * 512, 0);
     if (JQ == 2) EPS_GLOAD_B128(fb[0][kk][JQ - 1], lane16, B_t + jstride + kk * 512, 0);
   }
 #pragma unroll
-  for (int it = 0; it < 8; ++it) issue_piece(A_t, 2, 2, it);
+  for (int it = 0; it < 8; ++it) issue_piece(A_t + 128, 2 * ASLOT, it);
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
     EPS_GLOAD_B128(fb[1][kk][0], lane16, B_t + 2048 + kk * 512, 0);
@@ -465,19 +465,27 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
   EPS_DS_READ_B128(fa[0][6], faddr[0], 24576);
   EPS_DS_READ_B128(fa[0][7], faddr[0], 28672);
 
-  int slot = 0;
   // One wavefront per SIMD: after every pair of MFMAs (64 cycles of matrix pipe) exactly one other instruction is
   // issued in its shadow - the LDS read of the row fragment that the same pair will need in the NEXT sub-step
   // (8 pairs = 512 cycles ahead, waited for by count: lgkmcnt(7)), and on odd pairs one LDS-DMA piece / fragment load.
-  auto step = [&](int kt, auto U, auto FIRST) __attribute__((always_inline)) {
+  // Prefetch cursors, stepped at the END of every K-step (in the shadow of its last MFMAs): where the LDS-DMA of this
+  // step reads (the K-step three ahead, possibly in the next tile), where its query-fragment loads read (two ahead),
+  // and the ring slots.  Computed at the head of the step (~30 scalar instructions: selects between this tile and the
+  // next, 64-bit address arithmetic) they sat between the barrier and the first MFMA of every step.
+  const _Float16* pA_run = A_t + 3 * 64;          // KT >= 4
+  int akt_run = 3;
+  const _Float16* pB_run = B_t + (int64_t)2 * 2048;
+  int bkt_run = 2;
+  u32 sA_run = 0, sN_run = ASLOT, sD_run = 3 * ASLOT;   // slot being multiplied, the next one, the one being filled (byte offsets)
+  auto step = [&](auto U, auto FIRST) __attribute__((always_inline)) {
     constexpr int rb = decltype(U)::value;
     constexpr bool first = decltype(FIRST)::value;   // first K-step of a tile: only acc[.][0] holds the base column
-    const int nslot = (slot + 1) & 3;
-    const int dslot = (slot + 3) & 3;
-    const u32 sA = slot * ASLOT, sN = nslot * ASLOT;
-    const _Float16* pA = kt + 3 < KT ? A_t : A_n;
-    const int akt = kt + 3 < KT ? kt + 3 : kt + 3 - KT;
-    const _Float16* pB = (kt + 2 < KT ? B_t : B_n) + (int64_t)((kt + 2 < KT ? kt + 2 : kt + 2 - KT) * 4) * 512;
+    const u32 sA = sA_run, sN = sN_run, sD = sD_run;
+    const _Float16* pA = pA_run;
+    const _Float16* pB = pB_run;
+    const _Float16* pA_nx = pA;
+    const _Float16* pB_nx = pB;
+    int akt_nx = akt_run, bkt_nx = bkt_run;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int cur = kk & 1, nxt = cur ^ 1;
@@ -511,7 +519,21 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
         if (i == 1 || i == 3) {          // query fragments of the PREVIOUS sub-step's slot, for two steps from now
           if (kk > 0 && (i >> 1) < JQ) EPS_GLOAD_B128(fb[rb][kk - 1][(i >> 1) % JQ], lane16, pB + (i >> 1) * jstride + (kk - 1) * 512, 0);
         } else if (i == 5 || i == 7) {
-          issue_piece(pA, akt, dslot, kk * 2 + (i >> 1) - 2);
+          issue_piece(pA, sD, kk * 2 + (i >> 1) - 2);
+        }
+        if (kk == 3 && i == 6) {   // the next step's cursors
+          akt_nx = akt_run + 1;
+          pA_nx = pA + 64;
+          if (akt_nx == KT) {
+            akt_nx = 0;
+            pA_nx = A_n;
+          }
+          bkt_nx = bkt_run + 1;
+          pB_nx = pB + 2048;
+          if (bkt_nx == KT) {
+            bkt_nx = 0;
+            pB_nx = B_n;
+          }
         }
       }
     }
@@ -519,7 +541,13 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
       EPS_GLOAD_B128(fb[rb][3][0], lane16, pB + 3 * 512, 0);
       if (JQ == 2) EPS_GLOAD_B128(fb[rb][3][JQ - 1], lane16, pB + jstride + 3 * 512, 0);
     }
-    slot = nslot;
+    pA_run = pA_nx;
+    akt_run = akt_nx;
+    pB_run = pB_nx;
+    bkt_run = bkt_nx;
+    sA_run = sN;
+    sN_run = (sN + ASLOT) & (RING * ASLOT - 1);
+    sD_run = sA;
     if (JQ == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // this step's 8 DMA pieces + 4 JQ fragment loads may stay in flight
     else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -578,11 +606,11 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
         __builtin_amdgcn_sched_barrier(0);   // one row block at a time: hoisting all 64 reads costs spills
       }
     }
-    step(0, std::integral_constant<int, 0>{}, std::true_type{});
-    step(1, std::integral_constant<int, 1>{}, std::false_type{});
+    step(std::integral_constant<int, 0>{}, std::true_type{});
+    step(std::integral_constant<int, 1>{}, std::false_type{});
     for (int kt = 2; kt < KT; kt += 2) {
-      step(kt, std::integral_constant<int, 0>{}, std::false_type{});
-      step(kt + 1, std::integral_constant<int, 1>{}, std::false_type{});
+      step(std::integral_constant<int, 0>{}, std::false_type{});
+      step(std::integral_constant<int, 1>{}, std::false_type{});
     }
     if (rendezvous && wave == 0 && t + 1 < ntile && ((t + 1) & sync_mask) == 0 && lane16 == 0) __hip_atomic_fetch_add(gs_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     A_t = A_n;
