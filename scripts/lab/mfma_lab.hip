@@ -68,9 +68,9 @@ template <typename K>
 static void set_shm(K k, int bytes) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); }
 
 static void launch_v3(const FilterArgs& a, int cus, hipStream_t s) {
-  static bool once = (set_shm(mfma_filter_kernel_v3<false>, 2 * 65536 + 2048), true);
+  static bool once = (set_shm(mfma_filter_kernel_v3, 2 * 65536 + 2048), true);
   (void)once;
-  hipLaunchKernelGGL(mfma_filter_kernel_v3<false>, dim3(cus), dim3(512), 2 * 65536 + 2048, s, a);
+  hipLaunchKernelGGL(mfma_filter_kernel_v3, dim3(cus), dim3(512), 2 * 65536 + 2048, s, a);
 }
 template <int KNOB>
 static void launch_v3k(const FilterArgs& a, int cus, hipStream_t s) {
@@ -86,15 +86,11 @@ static void launch_v5(const FilterArgs& a, int cus, hipStream_t s) {
   hipLaunchKernelGGL(lab_v5<KNOB>, dim3(cus), dim3(512), 4 * 32768 + 2048, s, a);
 }
 
-static void launch_v5p(const FilterArgs& a, int cus, hipStream_t s) {
-  static bool once = (set_shm(mfma_filter_kernel_v5, 4 * 32768 + 2048), true);
-  (void)once;
-  hipLaunchKernelGGL(mfma_filter_kernel_v5, dim3(cus), dim3(512), 4 * 32768 + 2048, s, a);
-}
+static void launch_v5p(const FilterArgs& a, int cus, hipStream_t s) { launch_v5<0>(a, cus, s); }   // (the shipped v5 moved here: lab_v5<0>)
 static void launch_v7p(const FilterArgs& a, int cus, hipStream_t s) {
-  static bool once = (set_shm(mfma_filter_kernel_v7<2, FM_IDS>, V7_LDS_BYTES), true);
+  static bool once = (set_shm(mfma_filter_kernel_v7<2, FM_IDS>, (int)V7_LDS_BYTES), true);
   (void)once;
-  hipLaunchKernelGGL(mfma_filter_kernel_v7<2, FM_IDS>, dim3(cus), dim3(256), V7_LDS_BYTES, s, a);
+  hipLaunchKernelGGL((mfma_filter_kernel_v7<2, FM_IDS>), dim3(cus), dim3(256), V7_LDS_BYTES, s, a);
 }
 template <int KNOB>
 static void launch_v6(const FilterArgs& a, int cus, hipStream_t s) {
