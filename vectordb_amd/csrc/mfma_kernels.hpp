@@ -494,12 +494,13 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
       for (int i = 0; i < 8; ++i) {
         asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+        // An MFMA occupies the pipe for 32 cycles and the next one cannot issue before that, so EACH of the two leaves
+        // ~28 cycles (about five issue slots) in which the wavefront can issue something else for free: the LDS read
+        // goes behind the first, the VMEM instruction of the pair (if any) behind the second.
         if (JQ == 2 && first && kk == 0) {   // D != C: the second block's accumulator is born from the first block's initial value
           acc[i][JQ - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][i], fb[rb][kk][JQ - 1], acc[i][0], 0, 0, 0);
-          acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][i], fb[rb][kk][0], acc[i][0], 0, 0, 0);
         } else {
           acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][i], fb[rb][kk][0], acc[i][0], 0, 0, 0);
-          if (JQ == 2) acc[i][JQ - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][i], fb[rb][kk][JQ - 1], acc[i][JQ - 1], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         {
@@ -514,6 +515,12 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
             default: EPS_DS_READ_B128(fa[nxt][7], ad, 28672); break;
           }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (JQ == 2) {
+          if (first && kk == 0) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][i], fb[rb][kk][0], acc[i][0], 0, 0, 0);
+          else acc[i][JQ - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][i], fb[rb][kk][JQ - 1], acc[i][JQ - 1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         // (all loads of the loop stay in straight-line code: around a branch hipcc gives an asm load's destination a fresh
         // register and copies it - possibly before the data has landed; r2 tried to stagger the wavefronts' DMA issue that way)
         if (i == 1 || i == 3) {          // query fragments of the PREVIOUS sub-step's slot, for two steps from now
