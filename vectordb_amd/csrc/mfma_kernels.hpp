@@ -368,6 +368,18 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(g_off0), "s"(sb), "s"(m0v) : "memory");
   };
 
+  // the same in two halves for the K loop: address + M0 behind one MFMA, the DMA instruction alone behind the next (the MFMA
+  // between them also provides the wait state M0 needs; nothing else in the loop touches M0 - checked in the ISA)
+  auto prep_piece = [&](const _Float16* pA, u32 slot_off, int it) __attribute__((always_inline)) {
+    const _Float16* sb = pA + (int64_t)it * 32 * ldk;
+    const u32 m0v = lds_base + slot_off + (it * 256 + wave * 64) * 16;
+    asm volatile("s_mov_b32 m0, %1" : "+s"(sb) : "s"(m0v) : "memory");
+    return sb;
+  };
+  auto fire_piece = [&](const _Float16* sb) __attribute__((always_inline)) {
+    asm volatile("global_load_lds_dwordx4 %0, %1" : : "v"(g_off0), "s"(sb) : "memory");
+  };
+
   f32x16 acc[8][JQ];
   half8 fb[2][4][JQ];
   half8 fa[2][8];
@@ -477,6 +489,7 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
   const _Float16* pB_run = B_t + (int64_t)2 * 2048;
   int bkt_run = 2;
   u32 sA_run = 0, sN_run = ASLOT, sD_run = 3 * ASLOT;   // slot being multiplied, the next one, the one being filled (byte offsets)
+  u32 ad_run = faddr[1];                                // LDS address of the first sub-step's fragment reads (slot 0)
   auto step = [&](auto U, auto FIRST) __attribute__((always_inline)) {
     constexpr int rb = decltype(U)::value;
     constexpr bool first = decltype(FIRST)::value;   // first K-step of a tile: only acc[.][0] holds the base column
@@ -489,14 +502,18 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int cur = kk & 1, nxt = cur ^ 1;
-      const u32 ad = faddr[(kk + 1) & 3] + (kk < 3 ? sA : sN);
+      const u32 ad = ad_run;      // LDS address of this sub-step's fragment reads (the NEXT sub-step's operands)
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
+        // An MFMA occupies the pipe for 32 cycles and the next one cannot issue before that, so EACH of the two leaves
+        // ~28 cycles (about five issue slots) in which the wavefront can issue something else for free: the LDS read and
+        // the scalar preparation of the pair's VMEM instruction go behind the first, the VMEM instruction itself (every
+        // other pair: one query-fragment load or one LDS-DMA piece) alone behind the second.
+        const bool has_frag = (i == 1 || i == 3) && kk > 0 && (i >> 1) < JQ;   // fragments of the PREVIOUS sub-step's slot, for two steps from now
+        const bool has_dma = (i == 5 || i == 7);
+        const _Float16* vsrc = nullptr;
         asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        // An MFMA occupies the pipe for 32 cycles and the next one cannot issue before that, so EACH of the two leaves
-        // ~28 cycles (about five issue slots) in which the wavefront can issue something else for free: the LDS read
-        // goes behind the first, the VMEM instruction of the pair (if any) behind the second.
         if (JQ == 2 && first && kk == 0) {   // D != C: the second block's accumulator is born from the first block's initial value
           acc[i][JQ - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][i], fb[rb][kk][JQ - 1], acc[i][0], 0, 0, 0);
         } else {
@@ -515,18 +532,16 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
             default: EPS_DS_READ_B128(fa[nxt][7], ad, 28672); break;
           }
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (JQ == 2) {
-          if (first && kk == 0) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][i], fb[rb][kk][0], acc[i][0], 0, 0, 0);
-          else acc[i][JQ - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][i], fb[rb][kk][JQ - 1], acc[i][JQ - 1], 0, 0, 0);
+        if (has_frag) {
+          vsrc = pB + (i >> 1) * jstride + (kk - 1) * 512;
+          asm volatile("" : "+s"(vsrc));
+        } else if (has_dma) {
+          vsrc = prep_piece(pA, sD, kk * 2 + (i >> 1) - 2);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        // (all loads of the loop stay in straight-line code: around a branch hipcc gives an asm load's destination a fresh
-        // register and copies it - possibly before the data has landed; r2 tried to stagger the wavefronts' DMA issue that way)
-        if (i == 1 || i == 3) {          // query fragments of the PREVIOUS sub-step's slot, for two steps from now
-          if (kk > 0 && (i >> 1) < JQ) EPS_GLOAD_B128(fb[rb][kk - 1][(i >> 1) % JQ], lane16, pB + (i >> 1) * jstride + (kk - 1) * 512, 0);
-        } else if (i == 5 || i == 7) {
-          issue_piece(pA, sD, kk * 2 + (i >> 1) - 2);
+        if (i == 7) {   // the next sub-step's read address (kk = 3: the next K-step's first sub-step, in the slot after this one)
+          u32 adn = faddr[(kk + 2) & 3] + (kk < 2 ? sA : sN);
+          asm volatile("" : "+v"(adn));
+          ad_run = adn;
         }
         if (kk == 3 && i == 6) {   // the next step's cursors
           akt_nx = akt_run + 1;
@@ -542,6 +557,16 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
             pB_nx = B_n;
           }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (JQ == 2) {
+          if (first && kk == 0) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][i], fb[rb][kk][0], acc[i][0], 0, 0, 0);
+          else acc[i][JQ - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][i], fb[rb][kk][JQ - 1], acc[i][JQ - 1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // (all loads of the loop stay in straight-line code: around a branch hipcc gives an asm load's destination a fresh
+        // register and copies it - possibly before the data has landed; r2 tried to stagger the wavefronts' DMA issue that way)
+        if (has_frag) EPS_GLOAD_B128(fb[rb][kk - 1][(i >> 1) % JQ], lane16, vsrc, 0);
+        else if (has_dma) fire_piece(vsrc);
       }
     }
     {
@@ -565,6 +590,7 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
     const int64_t row0 = (a.tile0 + tile_rt(ri_c)) * 256;
     const int64_t qbase = (int64_t)tile_qt(qi_c) * QT + wave * (32 * JQ);   // scalar
     lane_values();
+    ad_run = faddr[1] + sA_run;   // (re-derived with the lane values: nothing lane-dependent lives across the epilogue)
     // The QTB workgroups of a group stream the SAME row tiles (each against its own query tile) and only the first to
     // ask pays the HBM fetch - if the others ask within the few microseconds the lines survive in this XCD's L2.  With
     // the operands prefetched three steps ahead nothing self-synchronises them any more (measured: FETCH_SIZE 1.9 x
