@@ -31,11 +31,11 @@ sys.path.insert(0, ROOT)
 # HBM bytes per launch of the dominant kernel from the PMC counters under profiles/ (separate --pmc passes, corrected as
 # MI355X_MICROARCH.md prescribes: gfx950 FETCH_SIZE counts 128-B requests at 64 B -> x2; FETCH_SIZE/WRITE_SIZE in KiB):
 #   mfma: profiles/r2_pmc_10Mx768_b1024.csv, mean of the four 9,262,720-row launches of mfma_filter_kernel_v7<2, FM_IDS>:
-#         (2 * 7358069 + 7466) KiB = 15.08e9 bytes vs 14.23e9 algorithmic bytes of the fp16 mirror (1.06 x; r1: 14.43e9).
+#         (2 * 7340245 + 7460) KiB = 15.04e9 bytes vs 14.23e9 algorithmic bytes of the fp16 mirror (1.06 x; r1: 14.43e9).
 #   graph: profiles/r2_traverse_10Mx768_pmc.csv, traverse2_kernel T=4 L=500 batch 1024 on the 10M-node device-built graph:
 #         2 * 48440196 KiB = 99.2e9 bytes vs 100.97e9 algorithmic (the x2 calibrated in the same run on flat_scan_kernel,
 #         whose FETCH_SIZE x 2 = rows * dim * 4 exactly).
-TRAFFIC = {"mfma": (2 * 7358069 + 7466) * 1024.0, "graph_T4_L500": 2 * 48440196 * 1024.0}
+TRAFFIC = {"mfma": (2 * 7340245 + 7460) * 1024.0, "graph_T4_L500": 2 * 48440196 * 1024.0}
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F16_PEAK_TF = 2500.0  # dense bf16/f16 MFMA peak (nominal, 2.4 GHz)
 MFMA_F16_SUSTAINED_TF = 1814.0  # measured: v_mfma_f32_32x32x16_f16 alone, operands toggling like data, 1.82 GHz (scripts/lab/mfma_peak.hip)
