@@ -296,6 +296,102 @@ def test_filter_compiler_matches_reference_dbserver(dropin, tmp_path, prefilter,
     assert nonempty > len(out[0]) * 0.8
 
 
+def random_filters(seed, count):
+    """Random filter expressions over FILTER_SCHEMA from a small grammar (numeric attributes, constants, + - * / %, the six
+    comparisons, bool and string leaves, @distance, AND / OR / NOT, parentheses), depth-limited; seeded, so the same list on
+    both sides."""
+    rng = np.random.default_rng(seed)
+    nums = ["ID", "Price", "Weight", "Small", "Big"]
+
+    def const(kind):
+        if kind == "ID":
+            return str(int(rng.integers(0, 1800)))
+        if kind == "Small":
+            return str(int(rng.integers(0, 11)))
+        if kind == "Big":      # (integer literals beyond int32 overflow the reference parser's stoi: now and then, both sides must reject them)
+            return str(int(rng.integers(0, 1800 if rng.random() < 0.05 else 700)) * 3000000)
+        return "%.3f" % rng.random()
+
+    def arith(depth):
+        r = rng.random()
+        if depth <= 0 or r < 0.45:
+            a = nums[int(rng.integers(0, len(nums)))]
+            return a, a
+        if r < 0.55:
+            return "@distance", "Price"
+        if r < 0.65:
+            k = nums[int(rng.integers(0, len(nums)))]
+            return const(k), k
+        (l, lk), (r2, _) = arith(depth - 1), arith(depth - 1)
+        op = ["+", "-", "*", "/", "%"][int(rng.integers(0, 5))]
+        if op in "/%":                       # a constant, non-zero right-hand side: no division by zero on either side
+            r2 = str(int(rng.integers(2, 9)))
+        return "(%s %s %s)" % (l, op, r2), lk
+
+    def leaf(depth):
+        r = rng.random()
+        if r < 0.1:
+            return ["Flag = true", "Flag = false", "Flag", "NOT Flag"][int(rng.integers(0, 4))]
+        if r < 0.2:
+            return "Tag %s 't%d'" % (["=", "<>"][int(rng.integers(0, 2))], int(rng.integers(0, 6)))
+        l, lk = arith(depth)
+        op = ["<", "<=", "=", "<>", ">=", ">"][int(rng.integers(0, 6))]
+        rhs = const(lk) if rng.random() < 0.7 else arith(depth - 1)[0]
+        return "%s %s %s" % (l, op, rhs)
+
+    def expr(depth):
+        r = rng.random()
+        if depth <= 0 or r < 0.35:
+            return leaf(2)
+        if r < 0.45:
+            return "NOT (%s)" % expr(depth - 1)
+        return "(%s) %s (%s)" % (expr(depth - 1), ["AND", "OR"][int(rng.integers(0, 2))], expr(depth - 1))
+
+    return [expr(3) for _ in range(count)]
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not ref_available(), reason="needs oracle/_ref")
+@pytest.mark.parametrize("rebuild", [False, True])
+def test_filter_compiler_random_expressions(dropin, tmp_path, rebuild):
+    """f4 fuzz: 80 seeded random filter expressions (tests/test_dropin.py::random_filters) through the drop-in DBServer and the
+    reference DBServer on the same table: same status, same ids in the same order, same distances - in brute-force mode and
+    after Rebuild() (graph walk + post-filter).  Whatever the reference's parser rejects the drop-in must reject too."""
+    ref = Ref()
+    n = 1800
+    X = data(n, 8, 21)
+    rng = np.random.default_rng(22)
+    price, weight = rng.random(n), rng.random(n)
+    recs = [{"ID": int(i), "Tag": "t%d" % (i % 5), "Price": float(np.float32(price[i])), "Weight": float(weight[i]), "Small": int(i % 11),
+             "Big": int(i) * 3000000, "Flag": bool(i % 3 == 0), "V": [float(x) for x in X[i]]} for i in range(n)]
+    Q = data(2, 8, 24)
+    filters = random_filters(int(os.environ.get("EPS_FUZZ_SEED", "1234")), 80)
+    out = []
+    for lib, name in ((ref, "ref"), (dropin, "drop")):
+        lib.L.ref_config(1, 500, 1, 0, 2)
+        db = lib.db(str(tmp_path / name))
+        assert db.create_table(FILTER_SCHEMA) == 0
+        for s in range(0, n, 600):
+            assert db.insert("T", recs[s:s + 600]) == 0
+        assert db.delete("T", [7, 8, 900]) == 0
+        if rebuild:
+            assert db.rebuild() == 0
+        out.append({(flt, qi): db.search("T", "V", q, 40, fields=("ID",), flt=flt) for flt in filters for qi, q in enumerate(Q)})
+        db.close()
+        lib.L.ref_config(4, 500, 1, 0, 4)
+    ok = nonempty = 0
+    for key, (rc_r, r) in out[0].items():
+        rc_d, d = out[1][key]
+        assert (rc_r == 0) == (rc_d == 0), (key, rc_r, rc_d)
+        if rc_r != 0:
+            continue
+        ok += 1
+        assert [x["ID"] for x in d] == [x["ID"] for x in r], (key, [x["ID"] for x in d][:12], [x["ID"] for x in r][:12])
+        assert np.allclose([x["@distance"] for x in d], [x["@distance"] for x in r], rtol=1e-4, atol=1e-7), key
+        nonempty += len(r) > 0
+    assert ok > len(out[0]) * 0.9 and nonempty > ok * 0.5, (ok, nonempty, len(out[0]))
+
+
 @pytest.mark.gpu
 def test_filter_program_through_the_c_abi():
     """eps_index_set_filter_program on packed rows {i32 id; f32 price; u8 flag; pad; f64 w} against numpy: flat (stream and
