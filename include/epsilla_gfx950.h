@@ -225,6 +225,13 @@ int32_t eps_index_build(eps_index* h, int64_t n, const eps_build_params* p);
  * out_ids [m][out_degree] (-1 padded), out_deg [m]; host arrays. */
 int32_t eps_index_select_edges(eps_index* h, const int64_t* nodes, int64_t m, const int64_t* cands, int32_t cands_per_node,
                                int32_t depth, int32_t out_degree, int64_t* out_ids, int32_t* out_deg);
+/* Another stage on its own: NsgIndex::InterInsert (db/index/nsg/nsg.cpp:583-653) over all n = row-count nodes, on caller-supplied
+ * edge lists ids [n][out_degree] with deg[v] valid entries each (what Link leaves).  Every edge v->u offers v to u; u keeps its
+ * own edges plus the offers if they fit into out_degree, otherwise SelectEdge(limit = false) over all of them sorted by (L2
+ * distance, id) - applied once per node to the whole candidate set (the reference applies it incrementally in node order, which
+ * differs where a list overflows: see DESIGN.md 3.4).  out_ids [n][out_degree] (-1 padded), out_deg [n]; host arrays. */
+int32_t eps_index_inter_insert(eps_index* h, const int64_t* ids, const int32_t* deg, int64_t n, int32_t out_degree, int64_t* out_ids,
+                               int32_t* out_deg);
 int32_t eps_index_set_graph(eps_index* h, int64_t n, const int64_t* offsets, const int64_t* neighbors,
                             int64_t navigation_point);
 int32_t eps_index_graph_info(const eps_index* h, int64_t* n, int64_t* edges, int64_t* navigation_point);

@@ -786,6 +786,86 @@ static void free_lists(ivec* l, int64_t n) {
   free(l);
 }
 
+/* InterInsert for every node (nsg.cpp:531-536, 583-653), serial over v (the omp-for is orphaned: one thread runs the loop).
+ * cut: n * out_degree distances, -1 terminated like cut_graph_dist; result: scratch of out_degree + 1 entries. */
+static void inter_insert_all(nsg_t* s, float* cut, eo_nb* result) {
+  const int64_t n = s->n, out_degree = s->out_degree;
+  nbvec wait = {0, 0, 0};
+  for (int64_t v = 0; v < n; ++v) {
+    float* ndp = cut + v * out_degree;
+    for (int64_t i = 0; i < out_degree; ++i) {
+      if (ndp[i] == -1) break;
+      int64_t cn = s->nsg[v].v[i];
+      ivec* nsn = &s->nsg[cn];
+      float* nsd = cut + cn * out_degree;
+      wait.n = 0;
+      int dup = 0;
+      for (int64_t j = 0; j < out_degree; ++j) {
+        if (nsd[j] == -1) break;
+        if (v == nsn->v[j]) {
+          dup = 1;
+          break;
+        }
+        eo_nb e = {nsn->v[j], nsd[j], 0};
+        nbvec_push(&wait, e);
+      }
+      if (dup) continue;
+      eo_nb cur = {v, ndp[i], 0};
+      nbvec_push(&wait, cur);
+      if (wait.n > out_degree) {
+        int64_t start = 0, rn = 0;
+        nb_sort(wait.v, wait.n);
+        result[rn++] = wait.v[start];
+        select_edge(s, &start, wait.v, wait.n, result, &rn, 0);
+        /* overwrites the first rn slots only: neither the id vector nor the -1 terminator is
+         * shortened, so stale tail entries survive (nsg.cpp:632-639) */
+        for (int64_t j = 0; j < rn; ++j) {
+          nsn->v[j] = result[j].id;
+          nsd[j] = result[j].dist;
+        }
+      } else {
+        for (int64_t j = 0; j < out_degree; ++j) {
+          if (nsd[j] == -1) {
+            ivec_push(nsn, cur.id);
+            nsd[j] = cur.dist;
+            if (j + 1 < out_degree) nsd[j + 1] = -1;
+            break;
+          }
+        }
+      }
+    }
+  }
+  free(wait.v);
+}
+
+/* The InterInsert stage alone, on caller-supplied per-node edge lists (ids: n * out_degree, deg[v] valid entries each, as Link
+ * leaves them; distances are computed here as SyncPrune stores them).  out_ids: n * out_degree, -1 padded; out_deg[v]. */
+void eo_inter_insert(const float* rows, int64_t n, int64_t d, const int64_t* ids, const int64_t* deg, int64_t out_degree,
+                     int64_t* out_ids, int64_t* out_deg) {
+  nsg_t s;
+  memset(&s, 0, sizeof(s));
+  s.rows = rows; s.n = n; s.d = d; s.out_degree = out_degree;
+  s.nsg = (ivec*)calloc((size_t)n, sizeof(ivec));
+  float* cut = (float*)malloc(sizeof(float) * (size_t)(n * out_degree > 0 ? n * out_degree : 1));
+  for (int64_t v = 0; v < n; ++v) {
+    for (int64_t i = 0; i < deg[v]; ++i) {
+      const int64_t u = ids[v * out_degree + i];
+      ivec_push(&s.nsg[v], u);
+      cut[v * out_degree + i] = eo_fvec_l2sqr(rows + v * d, rows + u * d, d);
+    }
+    if (deg[v] < out_degree) cut[v * out_degree + deg[v]] = -1;
+  }
+  eo_nb* result = (eo_nb*)malloc(sizeof(eo_nb) * (size_t)(out_degree + 1));
+  inter_insert_all(&s, cut, result);
+  free(result);
+  free(cut);
+  for (int64_t v = 0; v < n; ++v) {
+    out_deg[v] = s.nsg[v].n;
+    for (int64_t i = 0; i < out_degree; ++i) out_ids[v * out_degree + i] = i < s.nsg[v].n ? s.nsg[v].v[i] : -1;
+  }
+  free_lists(s.nsg, n);
+}
+
 /* NsgIndex::Build (nsg.cpp:45-99).  knn: n*K ids, -1 padded.  Result is kept in a static and fetched
  * with eo_nsg_fetch().  Returns the total number of edges.  seed0 = 100 is the reference's initial
  * value of the global rand_r state (nsg.cpp:19). */
@@ -845,53 +925,7 @@ int64_t eo_nsg_build(const float* rows, int64_t n, int64_t d, const int64_t* knn
       if (rn < out_degree) dp[rn] = -1;
     }
     free(full.v);
-    /* InterInsert (nsg.cpp:583-653), serial over v (the omp-for is orphaned, nsg.cpp:531-536) */
-    nbvec wait = {0, 0, 0};
-    for (int64_t v = 0; v < n; ++v) {
-      float* ndp = cut + v * out_degree;
-      for (int64_t i = 0; i < out_degree; ++i) {
-        if (ndp[i] == -1) break;
-        int64_t cn = s.nsg[v].v[i];
-        ivec* nsn = &s.nsg[cn];
-        float* nsd = cut + cn * out_degree;
-        wait.n = 0;
-        int dup = 0;
-        for (int64_t j = 0; j < out_degree; ++j) {
-          if (nsd[j] == -1) break;
-          if (v == nsn->v[j]) {
-            dup = 1;
-            break;
-          }
-          eo_nb e = {nsn->v[j], nsd[j], 0};
-          nbvec_push(&wait, e);
-        }
-        if (dup) continue;
-        eo_nb cur = {v, ndp[i], 0};
-        nbvec_push(&wait, cur);
-        if (wait.n > out_degree) {
-          int64_t start = 0, rn = 0;
-          nb_sort(wait.v, wait.n);
-          result[rn++] = wait.v[start];
-          select_edge(&s, &start, wait.v, wait.n, result, &rn, 0);
-          /* overwrites the first rn slots only: neither the id vector nor the -1 terminator is
-           * shortened, so stale tail entries survive (nsg.cpp:632-639) */
-          for (int64_t j = 0; j < rn; ++j) {
-            nsn->v[j] = result[j].id;
-            nsd[j] = result[j].dist;
-          }
-        } else {
-          for (int64_t j = 0; j < out_degree; ++j) {
-            if (nsd[j] == -1) {
-              ivec_push(nsn, cur.id);
-              nsd[j] = cur.dist;
-              if (j + 1 < out_degree) nsd[j + 1] = -1;
-              break;
-            }
-          }
-        }
-      }
-    }
-    free(wait.v);
+    inter_insert_all(&s, cut, result);
     free(result);
   }
   free(cut);

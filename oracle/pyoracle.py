@@ -108,6 +108,8 @@ class Oracle:
         L.eo_nsg_build.argtypes = [fptr, i64, i64, iptr, i64, i64, i64, i64, C.c_uint]
         L.eo_select_edge.restype = i64
         L.eo_select_edge.argtypes = [fptr, i64, i64, iptr, i64, i64, i64, iptr]
+        L.eo_inter_insert.restype = None
+        L.eo_inter_insert.argtypes = [fptr, i64, i64, iptr, iptr, i64, iptr, iptr]
         L.eo_nsg_fetch.restype = i64
         L.eo_nsg_fetch.argtypes = [iptr, iptr]
         L.eo_graph_file_write.argtypes = [C.c_char_p, i64, i64, iptr, iptr, i64]
@@ -226,6 +228,15 @@ class Oracle:
         m = self.L.eo_select_edge(_f(rows), rows.shape[1], node, _i(cands), len(cands), depth, out_degree, _i(out))
         return out[:m].copy()
 
+    def inter_insert(self, rows, ids, deg, out_degree):
+        """InterInsert over all nodes in order (nsg.cpp:531-536, 583-653) on edge lists ids[n][out_degree] / deg[n]: (ids, deg) after it"""
+        rows = np.ascontiguousarray(rows, np.float32)
+        ids = np.ascontiguousarray(ids, np.int64)
+        deg = np.ascontiguousarray(deg, np.int64)
+        out, od = np.empty_like(ids), np.empty_like(deg)
+        self.L.eo_inter_insert(_f(rows), rows.shape[0], rows.shape[1], _i(ids), _i(deg), out_degree, _i(out), _i(od))
+        return out, od
+
     def build_graph(self, metric, rows, K=100, **kw):
         """BuildFromVectorTable (ann_graph_segment.cpp:201-242) with exact kNN in place of NN-Descent."""
         K = min(K, rows.shape[0] - 1)
@@ -306,6 +317,9 @@ class Ref:
         L.ref_nsg_from_knn.argtypes = [fptr, i64, i64, iptr, i64, i64, i64, i64, C.c_int, C.c_uint]
         L.ref_select_edge.restype = i64
         L.ref_select_edge.argtypes = [fptr, i64, i64, i64, iptr, i64, i64, i64, iptr]
+        if hasattr(L, "ref_inter_insert"):
+            L.ref_inter_insert.restype = None
+            L.ref_inter_insert.argtypes = [fptr, i64, i64, iptr, iptr, i64, iptr, iptr]
         L.ref_executor_new.restype = vp
         L.ref_executor_new.argtypes = [vp, fptr, i64, C.c_int, C.c_int, i64, i64, i64, C.c_int]
         L.ref_executor_init_ids.argtypes = [vp, iptr]
@@ -395,6 +409,14 @@ class Ref:
         out = np.empty(out_degree, np.int64)
         m = self.L.ref_select_edge(_f(rows), rows.shape[0], rows.shape[1], node, _i(cands), len(cands), depth, out_degree, _i(out))
         return out[:m].copy()
+
+    def inter_insert(self, rows, ids, deg, out_degree):
+        rows = np.ascontiguousarray(rows, np.float32)
+        ids = np.ascontiguousarray(ids, np.int64)
+        deg = np.ascontiguousarray(deg, np.int64)
+        out, od = np.empty_like(ids), np.empty_like(deg)
+        self.L.ref_inter_insert(_f(rows), rows.shape[0], rows.shape[1], _i(ids), _i(deg), out_degree, _i(out), _i(od))
+        return out, od
 
     def executor(self, g, rows, metric=0, T=1, L=500, Lq=None, I=15, count=False):
         Lq = L if Lq is None else Lq

@@ -183,8 +183,35 @@ namespace {
 struct NsgOpen : vectordb::engine::index::NsgIndex {
   using NsgIndex::NsgIndex;
   using NsgIndex::SelectEdge;
+  using NsgIndex::InterInsert;
 };
 }  // namespace
+// NsgIndex::InterInsert (nsg.cpp:583-653) for every node in order, as Link() runs it (nsg.cpp:531-536: the omp-for is orphaned),
+// on caller-supplied edge lists (ids: n * out_degree, deg[v] valid each); distances as SyncPrune stores them.
+void ref_inter_insert(float* rows, int64_t n, int64_t d, const int64_t* ids, const int64_t* deg, int64_t out_degree, int64_t* out_ids,
+                      int64_t* out_deg) {
+  NsgOpen idx(d, n, vectordb::engine::index::NsgIndex::Metric_Type_L2);
+  idx.ori_data_ = rows;
+  idx.ids_ = nullptr;
+  idx.ntotal = n;
+  idx.out_degree = out_degree;
+  idx.nsg.assign((size_t)n, {});
+  std::vector<float> cut((size_t)n * out_degree);
+  for (int64_t v = 0; v < n; ++v) {
+    for (int64_t i = 0; i < deg[v]; ++i) {
+      const int64_t u = ids[v * out_degree + i];
+      idx.nsg[v].push_back((vectordb::engine::index::node_t)u);
+      cut[v * out_degree + i] = idx.distance_->Compare(rows + v * d, rows + u * d, d);
+    }
+    if (deg[v] < out_degree) cut[v * out_degree + deg[v]] = -1;
+  }
+  std::vector<std::mutex> mutex_vec((size_t)n);
+  for (unsigned v = 0; v < (unsigned)n; ++v) idx.InterInsert(v, mutex_vec, cut.data());
+  for (int64_t v = 0; v < n; ++v) {
+    out_deg[v] = (int64_t)idx.nsg[v].size();
+    for (int64_t i = 0; i < out_degree; ++i) out_ids[v * out_degree + i] = i < (int64_t)idx.nsg[v].size() ? (int64_t)idx.nsg[v][i] : -1;
+  }
+}
 int64_t ref_select_edge(float* rows, int64_t n, int64_t d, int64_t node, const int64_t* cands, int64_t m, int64_t depth, int64_t out_degree,
                         int64_t* out) {
   using vectordb::engine::index::Neighbor;

@@ -171,3 +171,46 @@ def test_device_select_edge_equals_oracle_on_identical_pools(amd, oracle):
         assert list(ids[v][:deg[v]]) == list(want), v
     ix.close()
     ix2.close()
+
+
+def test_device_inter_insert_against_oracle_on_identical_lists(amd, oracle):
+    """Like-for-like parity of the InterInsert stage on identical edge lists (the oracle's is pinned bit-exactly to the
+    reference's member, test_oracle_vs_ref::test_inter_insert_bit_exact).  The device applies the rule once per node to
+    (own edges + all offered reverse edges); the reference applies it incrementally in node order.  So:
+      * a node whose candidates fit into out_degree keeps exactly (own edges U offers) on both sides - same set;
+      * a node whose candidates overflow gets SelectEdge(limit = false) over the whole sorted candidate set on the device -
+        checked against the oracle's SelectEdge on that set; the reference's incremental result there is a different (order
+        dependent) list of exactly out_degree entries, and the overlap is reported."""
+    n, d = 3000, 16
+    X = data(n, d, 19)
+    knn = oracle.knn_exact(0, X, 30)
+    ix = amd.GpuIndex(d, 0)
+    ix.attach_rows(X)
+    for R in (12, 50):
+        ids0, deg0 = ix.select_edges(np.arange(n, dtype=np.int64), knn, depth=300, out_degree=R)     # Link's output
+        got, gdeg = ix.inter_insert(ids0, deg0, R)
+        want, wdeg = oracle.inter_insert(X, ids0, deg0.astype(np.int64), R)
+        offers = [[] for _ in range(n)]
+        for v in range(n):
+            for u in ids0[v][:deg0[v]]:
+                offers[int(u)].append(v)
+        fit = over = 0
+        overlap = []
+        for v in range(n):
+            own = [int(u) for u in ids0[v][:deg0[v]]]
+            cand = own + [w for w in offers[v] if w not in own]
+            dev = [int(u) for u in got[v][:gdeg[v]]]
+            refl = [int(u) for u in want[v][:wdeg[v]]]
+            if len(cand) <= R:
+                fit += 1
+                assert sorted(dev) == sorted(cand) == sorted(refl), (R, v)
+            elif len(offers[v]) <= 64:                       # (the device keeps at most 64 offers per node)
+                over += 1
+                sel = oracle.select_edge(X, v, np.asarray(cand, np.int64), 0, R)
+                assert dev == list(sel), (R, v, dev, list(sel))
+                assert set(dev) <= set(cand) and len(refl) == R
+                overlap.append(len(set(dev) & set(refl)) / float(len(set(dev) | set(refl))))
+        print("R=%d: %d nodes fit, %d overflow; device vs reference edge-set Jaccard on the overflowing nodes %.3f" % (R, fit, over, np.mean(overlap) if overlap else 1.0))
+        assert fit > 0 and (R == 50 or over > 0)
+    ix.close()
+

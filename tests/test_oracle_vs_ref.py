@@ -242,3 +242,25 @@ def test_select_edge_bit_exact(oracle, ref):
             a = oracle.select_edge(X, node, cands, depth, R)
             b = ref.select_edge(X, node, cands, depth, R)
             assert np.array_equal(a, b), (node, depth, R)
+
+
+def test_inter_insert_bit_exact(oracle, ref):
+    """InterInsert over all nodes in order (nsg.cpp:531-536, 583-653) on identical edge lists: the restatement equals the
+    reference's own (protected) member called node by node - including its quirk that a re-selected list keeps its stale tail
+    (nsg.cpp:632-639) - for out-degrees small enough that most lists overflow and large enough that none does."""
+    rng = np.random.default_rng(5)
+    n, d = 2500, 16
+    X = rng.random((n, d), dtype=np.float32)
+    knn = oracle.knn_exact(0, X, 30)
+    for R in (8, 16, 50):
+        ids = np.full((n, R), -1, np.int64)
+        deg = np.zeros(n, np.int64)
+        for v in range(n):
+            e = oracle.select_edge(X, v, knn[v], 300, R)
+            ids[v, :len(e)] = e
+            deg[v] = len(e)
+        a = oracle.inter_insert(X, ids, deg, R)
+        b = ref.inter_insert(X, ids, deg, R)
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0]), R
+        assert a[1].mean() > deg.mean()
+

@@ -334,6 +334,51 @@ static size_t prune_lds_bytes(int dim, int R) {   // v's vector, pool, kept ids 
   return (size_t)((dim + 3) & ~3) * 4 + (size_t)PRUNE_POOL * 8 + (size_t)R * 8 + 64 * 4 + 16 + (size_t)4 * ((dim + 3) & ~3) * 4;
 }
 
+// InterInsert (nsg.cpp:583-653), batched: every edge v->u offers v (with dist(v,u)) to u; every node then runs SelectEdge(limit =
+// false) over (its own edges + the offers), which keeps everything when the unique candidates fit into out_degree.  ids / dist /
+// deg: [n][R] device lists as Link leaves them.
+static int32_t inter_insert_device(Index& ix, const u32* nsg_ids, const float* nsg_dist, const u32* nsg_deg, int64_t n, int R, DevBuf& out_ids,
+                                   DevBuf& out_dist, DevBuf& out_deg) {
+  hipStream_t s = ix.stream_;
+  const int dim = (int)ix.dim_;
+  const bool vec4 = (dim % 4 == 0) && ((reinterpret_cast<uintptr_t>(ix.d_rows_) & 15) == 0);
+  const size_t prn_shm = prune_lds_bytes(dim, R);
+  DevBuf rev_ids, rev_dist, rev_cnt;
+  if (!rev_ids.reserve((size_t)n * REV_CAP * 4) || !rev_dist.reserve((size_t)n * REV_CAP * 4) || !rev_cnt.reserve((size_t)n * 4) ||
+      !out_ids.reserve((size_t)n * R * 4) || !out_dist.reserve((size_t)n * R * 4) || !out_deg.reserve((size_t)n * 4))
+    return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "build: out of device memory (InterInsert)");
+  HIPCHK(hipMemsetAsync(rev_cnt.p, 0, (size_t)n * 4, s));
+  hipLaunchKernelGGL(rev_scatter_kernel, dim3((unsigned)((n * R + 255) / 256)), dim3(256), 0, s, nsg_ids, nsg_dist, nsg_deg, n, R, rev_ids.as<u32>(),
+                     rev_dist.as<float>(), rev_cnt.as<u32>());
+  PruneArgs pa;
+  std::memset(&pa, 0, sizeof(pa));
+  pa.rows = ix.d_rows_;
+  pa.dim = dim;
+  pa.idsC = nsg_ids;
+  pa.distC = nsg_dist;
+  pa.cntC = nsg_deg;
+  pa.capC = R;
+  pa.idsD = rev_ids.as<u32>();
+  pa.distD = rev_dist.as<float>();
+  pa.cntD = rev_cnt.as<u32>();
+  pa.capD = REV_CAP;
+  pa.depth = 0;  // SelectEdge(limit = false)
+  pa.R = R;
+  pa.out_ids = out_ids.as<u32>();
+  pa.out_dist = out_dist.as<float>();
+  pa.out_deg = out_deg.as<u32>();
+  for (int64_t v0 = 0; v0 < n; v0 += 1 << 20) {
+    const int64_t nb = std::min<int64_t>(1 << 20, n - v0);
+    pa.v0 = v0;
+    if (vec4)
+      hipLaunchKernelGGL((prune_kernel<true>), dim3((unsigned)nb), dim3(256), prn_shm, s, pa);
+    else
+      hipLaunchKernelGGL((prune_kernel<false>), dim3((unsigned)nb), dim3(256), prn_shm, s, pa);
+  }
+  HIPCHK(hipGetLastError());
+  return EPS_OK;
+}
+
 int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp) {
   hipStream_t s = ix.stream_;
   const int dim = (int)ix.dim_;
@@ -491,38 +536,11 @@ int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp) {
   lap("Link (search + SelectEdge)");
 
   // ---- 4. InterInsert
-  DevBuf rev_ids, rev_dist, rev_cnt, out_ids, out_dist, out_deg;
-  if (!rev_ids.reserve((size_t)n * REV_CAP * 4) || !rev_dist.reserve((size_t)n * REV_CAP * 4) || !rev_cnt.reserve((size_t)n * 4) ||
-      !out_ids.reserve((size_t)n * R * 4) || !out_dist.reserve((size_t)n * R * 4) || !out_deg.reserve((size_t)n * 4))
-    return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "build: out of device memory (InterInsert)");
-  HIPCHK(hipMemsetAsync(rev_cnt.p, 0, (size_t)n * 4, s));
-  hipLaunchKernelGGL(rev_scatter_kernel, dim3((unsigned)((n * R + 255) / 256)), dim3(256), 0, s, nsg_ids.as<u32>(),
-                     nsg_dist.as<float>(), nsg_deg.as<u32>(), n, R, rev_ids.as<u32>(), rev_dist.as<float>(), rev_cnt.as<u32>());
-  std::memset(&pa, 0, sizeof(pa));
-  pa.rows = ix.d_rows_;
-  pa.dim = dim;
-  pa.idsC = nsg_ids.as<u32>();
-  pa.distC = nsg_dist.as<float>();
-  pa.cntC = nsg_deg.as<u32>();
-  pa.capC = R;
-  pa.idsD = rev_ids.as<u32>();
-  pa.distD = rev_dist.as<float>();
-  pa.cntD = rev_cnt.as<u32>();
-  pa.capD = REV_CAP;
-  pa.depth = 0;  // SelectEdge(limit = false)
-  pa.R = R;
-  pa.out_ids = out_ids.as<u32>();
-  pa.out_dist = out_dist.as<float>();
-  pa.out_deg = out_deg.as<u32>();
-  for (int64_t v0 = 0; v0 < n; v0 += 1 << 20) {
-    const int64_t nb = std::min<int64_t>(1 << 20, n - v0);
-    pa.v0 = v0;
-    if (vec4)
-      hipLaunchKernelGGL((prune_kernel<true>), dim3((unsigned)nb), dim3(256), prn_shm, s, pa);
-    else
-      hipLaunchKernelGGL((prune_kernel<false>), dim3((unsigned)nb), dim3(256), prn_shm, s, pa);
+  DevBuf out_ids, out_dist, out_deg;
+  {
+    const int32_t rc = inter_insert_device(ix, nsg_ids.as<u32>(), nsg_dist.as<float>(), nsg_deg.as<u32>(), n, R, out_ids, out_dist, out_deg);
+    if (rc != EPS_OK) return rc;
   }
-  HIPCHK(hipGetLastError());
   lap("InterInsert");
 
   // ---- 5. connectivity on the host
@@ -724,6 +742,60 @@ int32_t select_edges(Index& ix, const int64_t* nodes, int64_t m, const int64_t* 
   for (int64_t i = 0; i < m; ++i) {
     out_deg[i] = (int32_t)h_deg[i];
     for (int j = 0; j < R; ++j) out_ids[i * R + j] = (u32)j < h_deg[i] ? (int64_t)h_oi[(size_t)i * R + j] : -1;
+  }
+  return EPS_OK;
+}
+
+// edge distances dist(v, ids[v][j]) for the lists handed to inter_insert() (one wavefront per edge)
+__global__ __launch_bounds__(256) void edge_dist_kernel(const float* rows, int dim, const u32* ids, const u32* deg, int64_t n, int R, float* dist) {
+  const int64_t e = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (e >= n * R) return;
+  const int64_t v = e / R;
+  const int j = (int)(e - v * R);
+  if ((u32)j >= deg[v]) return;
+  const float* a = rows + v * dim;
+  const float* b = rows + (int64_t)ids[e] * dim;
+  float acc = 0.f;
+  for (int c = lane_id(); c < dim; c += 64) {
+    const float t = a[c] - b[c];
+    acc = fmaf(t, t, acc);
+  }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane_id() == 0) dist[e] = acc;
+}
+
+// The InterInsert stage alone on caller-supplied edge lists (like-for-like build parity, tests/test_gpu_build.py):
+// ids [n][R] (deg[v] valid entries each) -> out_ids [n][R] (-1 padded), out_deg.  n must equal the attached row count.
+int32_t inter_insert(Index& ix, const int64_t* ids, const int32_t* deg, int64_t n, int32_t R, int64_t* out_ids, int32_t* out_deg) {
+  if (n <= 0) return EPS_OK;
+  if (!ids || !deg || !out_ids || !out_deg || R <= 0 || R > 512 || n != ix.n_rows_) return ix.fail(EPS_USER_ERROR, "inter_insert: bad arguments");
+  hipStream_t s = ix.stream_;
+  std::vector<u32> h_ids((size_t)n * R, TRV_NONE), h_deg((size_t)n);
+  for (int64_t v = 0; v < n; ++v) {
+    if (deg[v] < 0 || deg[v] > R) return ix.fail(EPS_USER_ERROR, "inter_insert: degree out of range");
+    h_deg[v] = (u32)deg[v];
+    for (int j = 0; j < deg[v]; ++j) {
+      const int64_t u = ids[v * R + j];
+      if (u < 0 || u >= n) return ix.fail(EPS_USER_ERROR, "inter_insert: neighbour out of range");
+      h_ids[(size_t)v * R + j] = (u32)u;
+    }
+  }
+  DevBuf d_ids, d_dist, d_deg, o_ids, o_dist, o_deg;
+  if (!d_ids.reserve((size_t)n * R * 4) || !d_dist.reserve((size_t)n * R * 4) || !d_deg.reserve((size_t)n * 4))
+    return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "inter_insert: out of device memory");
+  HIPCHK(hipMemcpyAsync(d_ids.p, h_ids.data(), (size_t)n * R * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(d_deg.p, h_deg.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(edge_dist_kernel, dim3((unsigned)((n * R + 3) / 4)), dim3(256), 0, s, ix.d_rows_, (int)ix.dim_, d_ids.as<u32>(), d_deg.as<u32>(), n, (int)R,
+                     d_dist.as<float>());
+  const int32_t rc = inter_insert_device(ix, d_ids.as<u32>(), d_dist.as<float>(), d_deg.as<u32>(), n, R, o_ids, o_dist, o_deg);
+  if (rc != EPS_OK) return rc;
+  std::vector<u32> r_ids((size_t)n * R), r_deg((size_t)n);
+  HIPCHK(hipMemcpyAsync(r_ids.data(), o_ids.p, (size_t)n * R * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(r_deg.data(), o_deg.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  for (int64_t v = 0; v < n; ++v) {
+    out_deg[v] = (int32_t)r_deg[v];
+    for (int j = 0; j < R; ++j) out_ids[v * R + j] = (u32)j < r_deg[v] ? (int64_t)r_ids[(size_t)v * R + j] : -1;
   }
   return EPS_OK;
 }

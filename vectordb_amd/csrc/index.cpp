@@ -854,6 +854,18 @@ int32_t eps_index_select_edges(eps_index* h, const int64_t* nodes, int64_t m, co
     return map_exception(ix);
   }
 }
+int32_t eps_index_inter_insert(eps_index* h, const int64_t* ids, const int32_t* deg, int64_t n, int32_t out_degree, int64_t* out_ids,
+                               int32_t* out_deg) {
+  if (!h) return EPS_USER_ERROR;
+  Index* ix = dynamic_cast<Index*>(IX(h));
+  if (!ix) return IX(h)->fail(EPS_DB_UNSUPPORTED_ERROR, "inter_insert: single-device indices only");
+  try {
+    if (hipSetDevice(ix->device_) != hipSuccess) return ix->fail(EPS_INFRA_UNEXPECTED_ERROR, "hipSetDevice");
+    return eps::inter_insert(*ix, ids, deg, n, out_degree, out_ids, out_deg);
+  } catch (...) {
+    return map_exception(ix);
+  }
+}
 int32_t eps_index_load_table(eps_index* h, const char* path, const eps_table_layout* layout, int64_t* n_out) {
   if (!h) return EPS_USER_ERROR;
   Index* ix = dynamic_cast<Index*>(IX(h));

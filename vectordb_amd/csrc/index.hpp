@@ -161,6 +161,7 @@ class Index : public IndexBase {
   friend int32_t flat_mfma_search_slice(Index&, const float*, int64_t, int, u64*, bool, int);
   friend int32_t graph_build(Index&, int64_t, const eps_build_params&);
   friend int32_t select_edges(Index&, const int64_t*, int64_t, const int64_t*, int32_t, int32_t, int32_t, int64_t*, int32_t*);
+  friend int32_t inter_insert(Index&, const int64_t*, const int32_t*, int64_t, int32_t, int64_t*, int32_t*);
   friend int32_t graph_search(Index&, const float*, int64_t, int, const eps_search_params&, u64*, int64_t*, int);
 };
 
@@ -178,6 +179,7 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
 int32_t graph_build(Index& ix, int64_t n, const eps_build_params& p);
 int32_t select_edges(Index& ix, const int64_t* nodes, int64_t m, const int64_t* cands, int32_t cpn, int32_t depth, int32_t R, int64_t* out_ids,
                      int32_t* out_deg);
+int32_t inter_insert(Index& ix, const int64_t* ids, const int32_t* deg, int64_t n, int32_t R, int64_t* out_ids, int32_t* out_deg);
 
 bool is_device_ptr(const void* p);
 

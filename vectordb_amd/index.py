@@ -218,6 +218,15 @@ class GpuIndex:
         self._check(self.L.eps_index_select_edges(self.h, _ptr(nodes), len(nodes), _ptr(cands), cands.shape[1], depth, out_degree, _ptr(out), _ptr(deg)))
         return out, deg
 
+    def inter_insert(self, ids, deg, out_degree):
+        """The InterInsert stage on given edge lists ids [n][R] / deg [n] (eps_index_inter_insert); returns (ids [n][R] -1 padded, deg [n])"""
+        ids = np.ascontiguousarray(ids, np.int64)
+        deg = np.ascontiguousarray(deg, np.int32)
+        out = np.empty_like(ids)
+        od = np.empty(len(deg), np.int32)
+        self._check(self.L.eps_index_inter_insert(self.h, _ptr(ids), _ptr(deg), len(deg), out_degree, _ptr(out), _ptr(od)))
+        return out, od
+
     def save_graph(self, path):
         self._check(self.L.eps_index_save_graph(self.h, path.encode()))
 
