@@ -221,6 +221,7 @@ def main():
     backend = os.environ.get("EPS_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local_rank)   # before the process group: the nccl barrier below runs on the current device
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
