@@ -229,7 +229,8 @@ int32_t eps_index_select_edges(eps_index* h, const int64_t* nodes, int64_t m, co
  * edge lists ids [n][out_degree] with deg[v] valid entries each (what Link leaves).  Every edge v->u offers v to u; u keeps its
  * own edges plus the offers if they fit into out_degree, otherwise SelectEdge(limit = false) over all of them sorted by (L2
  * distance, id) - applied once per node to the whole candidate set (the reference applies it incrementally in node order, which
- * differs where a list overflows: see DESIGN.md 3.4).  out_ids [n][out_degree] (-1 padded), out_deg [n]; host arrays. */
+ * differs where a list overflows: see DESIGN.md 3.4).  Every offer is considered (kept in a CSR by receiving node), so the result
+ * does not depend on the order in which the device produces them.  out_ids [n][out_degree] (-1 padded), out_deg [n]; host arrays. */
 int32_t eps_index_inter_insert(eps_index* h, const int64_t* ids, const int32_t* deg, int64_t n, int32_t out_degree, int64_t* out_ids,
                                int32_t* out_deg);
 int32_t eps_index_set_graph(eps_index* h, int64_t n, const int64_t* offsets, const int64_t* neighbors,

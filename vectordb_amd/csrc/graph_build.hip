@@ -32,7 +32,6 @@ namespace eps {
 
 constexpr int PRUNE_POOL = 4096;   // sorted candidate pool per node (LDS)
 constexpr int LOG_CAP = 3840;      // evaluated nodes logged per search
-constexpr int REV_CAP = 64;        // reverse-edge candidates kept per node
 
 // ------------------------------------------------------------------------------------------------ kNN extraction
 __global__ void knn_extract_kernel(const u64* run_keys, int k1, int64_t q0, int64_t nq, int K, u32* knn_ids) {
@@ -92,6 +91,7 @@ struct PruneArgs {
   const float* distD;
   const u32* cntD;
   int capD;
+  const unsigned long long* offD;   // non-null: D is a CSR - node v's pairs are idsD / distD [offD[v], offD[v+1])
   int depth;              // candidates scanned (candidate_pool_size), <= 0: unlimited
   int R;                  // out_degree
   u32* out_ids;           // [n][R], TRV_NONE padded
@@ -141,10 +141,11 @@ __global__ __launch_bounds__(256) void prune_kernel(PruneArgs a) {
     }
   }
   if (a.idsD) {
-    const u32 cnt = a.cntD[v] < (u32)a.capD ? a.cntD[v] : (u32)a.capD;
+    const int64_t baseD = a.offD ? (int64_t)a.offD[v] : v * a.capD;
+    const u32 cnt = a.offD ? (u32)(a.offD[v + 1] - a.offD[v]) : (a.cntD[v] < (u32)a.capD ? a.cntD[v] : (u32)a.capD);
     for (u32 i = tid; i < cnt; i += 256) {
       const int slot = atomicAdd(&sh[0], 1);
-      if (slot < PRUNE_POOL) pool[slot] = make_key(a.distD[v * a.capD + i], a.idsD[v * a.capD + i]);
+      if (slot < PRUNE_POOL) pool[slot] = make_key(a.distD[baseD + i], a.idsD[baseD + i]);
     }
   }
   __syncthreads();
@@ -307,20 +308,27 @@ __global__ __launch_bounds__(256) void prune_kernel(PruneArgs a) {
   if (tid == 0) a.out_deg[vrow] = (u32)nk;
 }
 
-// reverse edges: for every edge v->u offer v to u (InterInsert, nsg.cpp:583-653)
-__global__ void rev_scatter_kernel(const u32* ids, const float* dist, const u32* deg, int64_t n, int R, u32* rev_ids,
-                                   float* rev_dist, u32* rev_cnt) {
+// reverse edges: for every edge v->u offer v to u (InterInsert, nsg.cpp:583-653).  All offers are kept, in a CSR by receiving
+// node (count, host prefix sum, fill): r2 first kept the first 64 arrivals per node, which is neither deterministic nor what the
+// reference does for hub nodes - it considers every offer.  The order inside a node's segment is arbitrary; the prune kernel
+// sorts its pool by (dist, id), so the result is not.
+__global__ void rev_count_kernel(const u32* ids, const u32* deg, int64_t n, int R, u32* rev_cnt) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n * R) return;
   const int64_t v = i / R;
-  const int j = (int)(i - v * R);
-  if ((u32)j >= deg[v]) return;
+  if ((u32)(i - v * R) >= deg[v]) return;
+  atomicAdd(&rev_cnt[ids[i]], 1u);
+}
+__global__ void rev_fill_kernel(const u32* ids, const float* dist, const u32* deg, int64_t n, int R, const unsigned long long* rev_off, u32* cursor,
+                                u32* rev_ids, float* rev_dist) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * R) return;
+  const int64_t v = i / R;
+  if ((u32)(i - v * R) >= deg[v]) return;
   const u32 u = ids[i];
-  const u32 slot = atomicAdd(&rev_cnt[u], 1u);
-  if (slot < (u32)REV_CAP) {
-    rev_ids[(int64_t)u * REV_CAP + slot] = (u32)v;
-    rev_dist[(int64_t)u * REV_CAP + slot] = dist[i];
-  }
+  const unsigned long long slot = rev_off[u] + atomicAdd(&cursor[u], 1u);
+  rev_ids[slot] = (u32)v;
+  rev_dist[slot] = dist[i];
 }
 
 // ------------------------------------------------------------------------------------------------ host
@@ -343,13 +351,26 @@ static int32_t inter_insert_device(Index& ix, const u32* nsg_ids, const float* n
   const int dim = (int)ix.dim_;
   const bool vec4 = (dim % 4 == 0) && ((reinterpret_cast<uintptr_t>(ix.d_rows_) & 15) == 0);
   const size_t prn_shm = prune_lds_bytes(dim, R);
-  DevBuf rev_ids, rev_dist, rev_cnt;
-  if (!rev_ids.reserve((size_t)n * REV_CAP * 4) || !rev_dist.reserve((size_t)n * REV_CAP * 4) || !rev_cnt.reserve((size_t)n * 4) ||
-      !out_ids.reserve((size_t)n * R * 4) || !out_dist.reserve((size_t)n * R * 4) || !out_deg.reserve((size_t)n * 4))
+  DevBuf rev_ids, rev_dist, rev_cnt, rev_off;
+  if (!rev_cnt.reserve((size_t)n * 4) || !rev_off.reserve((size_t)(n + 1) * 8) || !out_ids.reserve((size_t)n * R * 4) ||
+      !out_dist.reserve((size_t)n * R * 4) || !out_deg.reserve((size_t)n * 4))
     return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "build: out of device memory (InterInsert)");
+  const unsigned blocks = (unsigned)((n * R + 255) / 256);
   HIPCHK(hipMemsetAsync(rev_cnt.p, 0, (size_t)n * 4, s));
-  hipLaunchKernelGGL(rev_scatter_kernel, dim3((unsigned)((n * R + 255) / 256)), dim3(256), 0, s, nsg_ids, nsg_dist, nsg_deg, n, R, rev_ids.as<u32>(),
-                     rev_dist.as<float>(), rev_cnt.as<u32>());
+  hipLaunchKernelGGL(rev_count_kernel, dim3(blocks), dim3(256), 0, s, nsg_ids, nsg_deg, n, R, rev_cnt.as<u32>());
+  std::vector<u32> h_cnt((size_t)n);
+  std::vector<unsigned long long> h_off((size_t)n + 1);
+  HIPCHK(hipMemcpyAsync(h_cnt.data(), rev_cnt.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  h_off[0] = 0;
+  for (int64_t v = 0; v < n; ++v) h_off[(size_t)v + 1] = h_off[(size_t)v] + h_cnt[(size_t)v];
+  const size_t total = (size_t)h_off[(size_t)n];
+  if (!rev_ids.reserve(std::max<size_t>(total, 1) * 4) || !rev_dist.reserve(std::max<size_t>(total, 1) * 4))
+    return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "build: out of device memory (InterInsert)");
+  HIPCHK(hipMemcpyAsync(rev_off.p, h_off.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemsetAsync(rev_cnt.p, 0, (size_t)n * 4, s));   // now the fill cursors
+  hipLaunchKernelGGL(rev_fill_kernel, dim3(blocks), dim3(256), 0, s, nsg_ids, nsg_dist, nsg_deg, n, R, rev_off.as<unsigned long long>(), rev_cnt.as<u32>(),
+                     rev_ids.as<u32>(), rev_dist.as<float>());
   PruneArgs pa;
   std::memset(&pa, 0, sizeof(pa));
   pa.rows = ix.d_rows_;
@@ -360,8 +381,7 @@ static int32_t inter_insert_device(Index& ix, const u32* nsg_ids, const float* n
   pa.capC = R;
   pa.idsD = rev_ids.as<u32>();
   pa.distD = rev_dist.as<float>();
-  pa.cntD = rev_cnt.as<u32>();
-  pa.capD = REV_CAP;
+  pa.offD = rev_off.as<unsigned long long>();
   pa.depth = 0;  // SelectEdge(limit = false)
   pa.R = R;
   pa.out_ids = out_ids.as<u32>();
