@@ -214,3 +214,20 @@ def test_device_inter_insert_against_oracle_on_identical_lists(amd, oracle):
         assert fit > 0 and (R == 50 or over > 0)
     ix.close()
 
+
+@pytest.mark.parametrize("n,d", [(30_000, 32), (80_000, 256)])
+def test_build_is_deterministic(amd, n, d):
+    """Two builds of the same table give the same graph, bit for bit (exact-kNN path and MFMA-kNN path): every stage that
+    collects through atomics (kNN candidate lists, the search log of Link, the reverse offers of InterInsert) sorts or
+    selects by (distance, id) before anything depends on the order."""
+    X = data(n, d, 23)
+    graphs = []
+    for _ in range(2):
+        ix = amd.GpuIndex(d, 0)
+        ix.attach_rows(X)
+        ix.build()
+        graphs.append(ix.get_graph())
+        ix.close()
+    (o1, n1, v1), (o2, n2, v2) = graphs
+    assert v1 == v2 and np.array_equal(o1, o2) and np.array_equal(n1, n2)
+

@@ -31,7 +31,6 @@
 namespace eps {
 
 constexpr int PRUNE_POOL = 4096;   // sorted candidate pool per node (LDS)
-constexpr int LOG_CAP = 3840;      // evaluated nodes logged per search
 
 // ------------------------------------------------------------------------------------------------ kNN extraction
 __global__ void knn_extract_kernel(const u64* run_keys, int k1, int64_t q0, int64_t nq, int K, u32* knn_ids) {
@@ -496,14 +495,20 @@ int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp) {
   }
   DevBuf d_seeds, logb, logc, counters, nsg_ids, nsg_dist, nsg_deg;
   const int64_t NB = std::min<int64_t>(n, 16384);
-  if (!d_seeds.reserve((size_t)Ls * 4) || !logb.reserve((size_t)NB * LOG_CAP * 8) || !logc.reserve((size_t)NB * 4) ||
+  if (!d_seeds.reserve((size_t)Ls * 4) || !logb.reserve((size_t)NB * 2048 * 8) || !logc.reserve((size_t)NB * 4) ||
       !counters.reserve(16) || !nsg_ids.reserve((size_t)n * R * 4) || !nsg_dist.reserve((size_t)n * R * 4) ||
       !nsg_deg.reserve((size_t)n * 4))
     return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "build: out of device memory (NSG link)");
   HIPCHK(hipMemcpyAsync(d_seeds.p, seeds.data(), (size_t)Ls * 4, hipMemcpyHostToDevice, s));
   HIPCHK(hipMemsetAsync(counters.p, 0, 16, s));
-  int Lp2 = 1;
-  while (Lp2 < Ls) Lp2 <<= 1;
+  // The search keeps the Lcap closest evaluated nodes (its queue) but expands only among the first Ls = search_length of them,
+  // which is the reference's search; the queue is what SyncPrune gets as `fullset`: its SelectEdge looks at the first
+  // candidate_pool_size entries of the sorted pool only, so Lcap >= candidate_pool_size loses nothing.
+  int Lp2 = 512;
+  while (Lp2 < Ls || (bp.candidate_pool_size > 0 && Lp2 < bp.candidate_pool_size)) Lp2 <<= 1;
+  if (bp.candidate_pool_size <= 0 || Lp2 > 2048) Lp2 = 2048;   // (unlimited depth: the 2048 closest)
+  if (Lp2 < Ls) return ix.fail(EPS_DB_UNSUPPORTED_ERROR, "build: search_length > 2048 is not supported");
+  const int Lcap = Lp2;
   const size_t trv_shm = traverse_lds_bytes(dim, Lp2, true);
   const size_t prn_shm = prune_lds_bytes(dim, R);
   TraverseArgs ta;
@@ -514,8 +519,10 @@ int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp) {
   ta.nbr = knn.as<u32>();
   ta.fixed_deg = K;
   ta.init_ids = d_seeds.as<u32>();
-  ta.L = Ls;
+  ta.L = Lcap;
   ta.Lp2 = Lp2;
+  ta.nseeds = Ls;
+  ta.Lsel = Ls;
   ta.M = 1;
   ta.visited = nullptr;
   ta.words = 0;
@@ -523,14 +530,14 @@ int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp) {
   ta.counters = counters.as<unsigned long long>();
   ta.log = logb.as<u64>();
   ta.log_cnt = logc.as<u32>();
-  ta.log_cap = LOG_CAP;
+  ta.log_cap = Lcap;
   PruneArgs pa;
   std::memset(&pa, 0, sizeof(pa));
   pa.rows = ix.d_rows_;
   pa.dim = dim;
   pa.log = logb.as<u64>();
   pa.log_cnt = logc.as<u32>();
-  pa.log_cap = LOG_CAP;
+  pa.log_cap = Lcap;
   pa.listB = knn.as<u32>();
   pa.degB = K;
   pa.depth = (int)bp.candidate_pool_size;
@@ -554,6 +561,13 @@ int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp) {
   }
   HIPCHK(hipGetLastError());
   lap("Link (search + SelectEdge)");
+  if (debug) {
+    unsigned long long hcnt[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(hcnt, counters.p, 16, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    fprintf(stderr, "[eps build] Link: %.0f evaluations, %.1f expansions per search; queue of %d kept as the pool\n", (double)hcnt[0] / (double)n,
+            (double)hcnt[1] / (double)n, Lcap);
+  }
 
   // ---- 4. InterInsert
   DevBuf out_ids, out_dist, out_deg;
@@ -635,7 +649,7 @@ int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp) {
       else
         hipLaunchKernelGGL((traverse_kernel<false, true, true, 4>), dim3((unsigned)nb), dim3(256), trv_shm, s, ta);
       // the TRACE_K closest evaluated nodes of every search, ascending
-      launch_merge_lists(logb.as<u64>(), LOG_CAP, TRACE_K, nb, d_top.as<u64>(), false, s, logc.as<u32>());
+      launch_merge_lists(logb.as<u64>(), Lcap, TRACE_K, nb, d_top.as<u64>(), false, s, logc.as<u32>());
       HIPCHK(hipMemcpyAsync(top.data() + (size_t)o0 * TRACE_K, d_top.p, (size_t)nb * TRACE_K * 8, hipMemcpyDeviceToHost, s));
       HIPCHK(hipStreamSynchronize(s));
     }

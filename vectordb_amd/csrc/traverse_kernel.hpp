@@ -18,14 +18,16 @@ struct TraverseArgs {
   const float* queries;
   int L;       // queue length
   int Lp2;     // next power of two >= L
+  int nseeds;  // number of init_ids (0: L)
+  int Lsel;    // candidates are selected for expansion among the first Lsel queue positions only (0: L)
   int M;       // expansions per round
   u32* visited;      // BITMAP mode: [gridDim.x][words] in HBM
   int64_t words;
   u64* out_queue;    // [nq][L] (may be null)
   unsigned long long* counters;  // [0] distance evals, [1] expansions
-  u64* log;          // LOG mode: [nq][log_cap] plain (dist,id) keys of every evaluated node
+  u64* log;          // LOG mode: [nq][log_cap] plain (dist,id) keys: the final queue = the L closest evaluated nodes, ascending
   u32* log_cnt;      // [nq]
-  int log_cap;
+  int log_cap;       // >= L
 };
 
 constexpr int TRV_HASH = 8192;   // LDS visited hash slots (HASHVIS mode), power of two
@@ -38,14 +40,16 @@ constexpr int TRV_MAXM = 16;
 __device__ __forceinline__ u64 qkey(float d, u32 id, u32 checked) { return ((u64)f2ord(d + 0.0f) << 32) | ((u64)id << 1) | checked; }
 
 // test-and-set of the visited set; returns true when `id` was not visited before
+// (HASHVIS: `open` = the table had room for a whole chunk of insertions when the chunk started - decided once per chunk from
+// a count that is stable there, so that WHICH nodes a nearly full table still admits does not depend on thread timing)
 template <bool HASHVIS>
-__device__ __forceinline__ bool visit(u32* vis, u32* hash, int* hcount, u32 id) {
+__device__ __forceinline__ bool visit(u32* vis, u32* hash, int* hcount, u32 id, bool open = true) {
   if (!HASHVIS) {
     const u32 bit = 1u << (id & 31);
     const u32 old = atomicOr(&vis[id >> 5], bit);
     return !(old & bit);
   } else {
-    if (*hcount >= (TRV_HASH * 3) / 4) return false;  // table full: stop discovering (build-time searches only)
+    if (!open) return false;  // table (nearly) full: stop discovering (build-time searches only)
     u32 h = (id * 2654435761u) >> (32 - 13);
     for (int probe = 0; probe < TRV_HASH; ++probe) {
       const u32 old = atomicCAS(&hash[h], TRV_NONE, id);
@@ -100,17 +104,19 @@ __global__ __launch_bounds__(NW * 64) void traverse_kernel(TraverseArgs a) {
   for (int i = tid; i < qstride; i += NT) sq[i] = i < dim ? a.queries[q * dim + i] : 0.f;
   for (int i = tid; i < a.Lp2; i += NT) queue[i] = KEY_EMPTY;
   // InitializeSetLPara (:446-485): mark seeds visited, L seed distances, sort
-  for (int i = tid; i < L; i += NT) visit<HASHVIS>(vis, hash, &sh[6], a.init_ids[i]);
+  const int NS = a.nseeds > 0 ? a.nseeds : L;     // seeds (<= L)
+  const int LS = a.Lsel > 0 ? a.Lsel : L;         // expansion window
+  for (int i = tid; i < NS; i += NT) visit<HASHVIS>(vis, hash, &sh[6], a.init_ids[i]);
   __syncthreads();
-  for (int c0 = wave * RPW * U; c0 < L; c0 += NW * RPW * U) {
+  for (int c0 = wave * RPW * U; c0 < NS; c0 += NW * RPW * U) {
     const float* rp[U];
     u32 id[U];
     bool ok[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int ci = c0 + u * RPW + g;
-      ok[u] = ci < L;
-      id[u] = a.init_ids[ok[u] ? ci : L - 1];
+      ok[u] = ci < NS;
+      id[u] = a.init_ids[ok[u] ? ci : NS - 1];
       rp[u] = a.rows + (int64_t)id[u] * dim;
     }
     float acc[U][1];
@@ -120,13 +126,9 @@ __global__ __launch_bounds__(NW * 64) void traverse_kernel(TraverseArgs a) {
       if (ok[u] && t == 0) {
         const float d = finish_dist(a.metric, acc[u][0]);
         queue[c0 + u * RPW + g] = qkey(d, id[u], 0);
-        if (LOG) {
-          const int slot = atomicAdd(&sh[7], 1);
-          if (slot < a.log_cap) qlog[slot] = make_key(d, id[u]);
-        }
       }
   }
-  evals += L;
+  evals += NS;
   __syncthreads();
   // bitonic sort of queue[0..Lp2)
   for (int size = 2; size <= a.Lp2; size <<= 1) {
@@ -152,9 +154,9 @@ __global__ __launch_bounds__(NW * 64) void traverse_kernel(TraverseArgs a) {
     // 1. select the first M unchecked candidates at positions >= k, mark them checked
     if (tid == 0) sh[1] = 0;
     __syncthreads();
-    for (int base = sh[2]; base < L; base += NT) {
+    for (int base = sh[2]; base < LS; base += NT) {
       const int p = base + tid;
-      const bool un = p < L && !(queue[p] & 1ull);
+      const bool un = p < LS && !(queue[p] & 1ull);
       const u64 m = __ballot(un);
       if (lane == 0) sh[48 + wave] = __popcll(m);
       __syncthreads();
@@ -197,6 +199,7 @@ __global__ __launch_bounds__(NW * 64) void traverse_kernel(TraverseArgs a) {
         sh[3] = 0;
       }
       __syncthreads();
+      const bool hash_open = !HASHVIS || sh[6] + TRV_CHUNK <= (TRV_HASH * 3) / 4;   // (sh[6] is stable here: see visit())
       {
         const int e = e0 + tid;
         bool fresh = false;
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(NW * 64) void traverse_kernel(TraverseArgs a) {
           while (i + 1 < nsel && sh[24 + i + 1] <= e) ++i;
           const int64_t rowbase = a.fixed_deg > 0 ? (int64_t)sh[8 + i] * a.fixed_deg : a.off[sh[8 + i]];
           nb = a.nbr[rowbase + (e - sh[24 + i])];
-          fresh = nb != TRV_NONE && visit<HASHVIS>(vis, hash, &sh[6], nb);
+          fresh = nb != TRV_NONE && visit<HASHVIS>(vis, hash, &sh[6], nb, hash_open);
         }
         const u64 m = __ballot(fresh);
         int wbase = 0;
@@ -218,6 +221,7 @@ __global__ __launch_bounds__(NW * 64) void traverse_kernel(TraverseArgs a) {
       const int nwork = sh[0];
       if (nwork == 0) continue;
       evals += nwork;
+
       // 3. distances; drop candidates beyond the current worst-of-queue (dist > bound, :427)
       const float bound = key_dist(queue[L - 1]);
       for (int c0 = wave * RPW * U; c0 < nwork; c0 += NW * RPW * U) {
@@ -238,10 +242,6 @@ __global__ __launch_bounds__(NW * 64) void traverse_kernel(TraverseArgs a) {
           if (ok[u] && t == 0) {
             const float d = finish_dist(a.metric, acc[u][0]);
             newk[c0 + u * RPW + g] = (d > bound) ? KEY_EMPTY : qkey(d, id[u], 0);
-            if (LOG) {
-              const int slot = atomicAdd(&sh[7], 1);
-              if (slot < a.log_cap) qlog[slot] = make_key(d, id[u]);
-            }
           }
         }
       }
@@ -308,7 +308,23 @@ __global__ __launch_bounds__(NW * 64) void traverse_kernel(TraverseArgs a) {
   }
   if (a.out_queue)
     for (int i = tid; i < L; i += NT) a.out_queue[q * L + i] = queue[i];
-  if (LOG && tid == 0) a.log_cnt[q] = sh[7] < a.log_cap ? (u32)sh[7] : (u32)a.log_cap;
+  if (LOG) {
+    // the log = the final queue: the L closest evaluated nodes in ascending (dist, id) order.  (Until r2 every evaluation was
+    // appended to a global list of 3840 entries, which EVERY Link search of a 768-d table overran - what got logged were the
+    // nodes met first, i.e. the far ones.)  With L >= candidate_pool_size this is all SyncPrune's depth-limited SelectEdge can see.
+    int cnt = 0;
+    for (int i = tid; i < L; i += NT) {
+      const u64 k2 = queue[i];
+      if (k2 != KEY_EMPTY) {
+        qlog[i] = ((k2 >> 32) << 32) | ((k2 >> 1) & 0x7FFFFFFFull);
+        ++cnt;
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if (lane == 0) atomicAdd(&sh[7], cnt);
+    __syncthreads();
+    if (tid == 0) a.log_cnt[q] = (u32)sh[7];
+  }
   if (tid == 0) {
     atomicAdd(&a.counters[0], evals);
     atomicAdd(&a.counters[1], expansions);
