@@ -24,7 +24,8 @@ struct TraverseArgs {
   u32* visited;      // BITMAP mode: [gridDim.x][words] in HBM
   int64_t words;
   u64* out_queue;    // [nq][L] (may be null)
-  unsigned long long* counters;  // [0] distance evals, [1] expansions
+  unsigned long long* counters;  // [0] distance evals, [1] expansions, [2] (counters_n > 2) searches that filled the visited hash
+  int counters_n;
   u64* log;          // LOG mode: [nq][log_cap] plain (dist,id) keys: the final queue = the L closest evaluated nodes, ascending
   u32* log_cnt;      // [nq]
   int log_cap;       // >= L
@@ -328,6 +329,7 @@ __global__ __launch_bounds__(NW * 64) void traverse_kernel(TraverseArgs a) {
   if (tid == 0) {
     atomicAdd(&a.counters[0], evals);
     atomicAdd(&a.counters[1], expansions);
+    if (HASHVIS && a.counters_n > 2 && sh[6] + TRV_CHUNK > (TRV_HASH * 3) / 4) atomicAdd(&a.counters[2], 1ull);   // searches that filled the visited hash
   }
 }
 
