@@ -494,15 +494,23 @@ int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp) {
     }
   }
   DevBuf d_seeds, logb, logc, counters, nsg_ids, nsg_dist, nsg_deg, visb;
-  // visited set of the Link / connectivity searches: an exact n-bit bitmap per search in HBM, zeroed per batch (batches sized
-  // so that the bitmaps stay below 2 GiB) - the reference's has_calculated bitset.  EPS_BUILD_BITMAP=0: an LDS hash of 6144
-  // nodes instead; a search that fills it stops discovering (a third of the searches at 1M x 768: 5.4 k instead of 5.8 k
-  // evaluations each, Link 2.6 % faster, the same recall - kept as the A/B switch).
-  const bool bitmap_vis = !(getenv("EPS_BUILD_BITMAP") && atoi(getenv("EPS_BUILD_BITMAP")) == 0);
+  // visited set of the Link / connectivity searches (the reference's has_calculated bitset, n bits per search):
+  //   default        a hash table of 32768 slots per search in HBM (128 KB: the ~1000 searches in flight keep theirs in L2 /
+  //                  Infinity Cache), reset per batch of 16384 searches; a search that fills 3/4 of it stops discovering -
+  //                  four times the evaluations any search of the 10M x 768 build makes (5.9 k on average)
+  //   EPS_BUILD_VISITED=bitmap   an exact n-bit bitmap per search, zeroed per batch (batches sized to 2 GiB: 1717 searches at
+  //                  10M rows, where the memsets and the HBM atomics cost +20 s of Link: 56 s vs 36 s)
+  //   EPS_BUILD_VISITED=lds      the r1 table of 8192 slots in LDS: a third of the searches at 1M x 768 fill it (5.4 k
+  //                  evaluations instead of 5.8 k); same recall
+  const char* vis_env = getenv("EPS_BUILD_VISITED");
+  const bool bitmap_vis = vis_env && std::strcmp(vis_env, "bitmap") == 0;
+  const bool ghash_vis = !bitmap_vis && !(vis_env && std::strcmp(vis_env, "lds") == 0);
+  constexpr int GHASH_SLOTS = 32768;
   const int64_t vis_words = (n + 31) / 32;
   int64_t NB = std::min<int64_t>(n, 16384);
   if (bitmap_vis) NB = std::max<int64_t>(256, std::min<int64_t>(NB, ((int64_t)2 << 30) / (vis_words * 4)));
   if (bitmap_vis && !visb.reserve((size_t)NB * vis_words * 4)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "build: out of device memory (visited bitmaps)");
+  if (ghash_vis && !visb.reserve((size_t)NB * GHASH_SLOTS * 4)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "build: out of device memory (visited tables)");
   if (!d_seeds.reserve((size_t)Ls * 4) || !logb.reserve((size_t)NB * 2048 * 8) || !logc.reserve((size_t)NB * 4) ||
       !counters.reserve(32) || !nsg_ids.reserve((size_t)n * R * 4) || !nsg_dist.reserve((size_t)n * R * 4) ||
       !nsg_deg.reserve((size_t)n * 4))
@@ -535,6 +543,8 @@ int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp) {
   ta.M = 1;
   ta.visited = bitmap_vis ? visb.as<u32>() : nullptr;
   ta.words = bitmap_vis ? vis_words : 0;
+  ta.ghash = ghash_vis ? visb.as<u32>() : nullptr;
+  ta.hslots = ghash_vis ? GHASH_SLOTS : 0;
   ta.out_queue = nullptr;
   ta.counters = counters.as<unsigned long long>();
   ta.counters_n = 3;
@@ -564,10 +574,16 @@ int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp) {
         hipLaunchKernelGGL((traverse_kernel<true, false, true, 4>), dim3((unsigned)nb), dim3(256), trv_shm_bm, s, ta);
       else
         hipLaunchKernelGGL((traverse_kernel<false, false, true, 4>), dim3((unsigned)nb), dim3(256), trv_shm_bm, s, ta);
-    } else if (vec4) {
-      hipLaunchKernelGGL((traverse_kernel<true, true, true, 4>), dim3((unsigned)nb), dim3(256), trv_shm, s, ta);
     } else {
-      hipLaunchKernelGGL((traverse_kernel<false, true, true, 4>), dim3((unsigned)nb), dim3(256), trv_shm, s, ta);
+      const size_t shm = ghash_vis ? trv_shm_bm : trv_shm;   // (the LDS layout without the table)
+      if (ghash_vis) {
+        hipError_t e = hipMemsetAsync(visb.p, 0xFF, (size_t)nb * GHASH_SLOTS * 4, s);   // TRV_NONE in every slot
+        if (e != hipSuccess) return e;
+      }
+      if (vec4)
+        hipLaunchKernelGGL((traverse_kernel<true, true, true, 4>), dim3((unsigned)nb), dim3(256), shm, s, ta);
+      else
+        hipLaunchKernelGGL((traverse_kernel<false, true, true, 4>), dim3((unsigned)nb), dim3(256), shm, s, ta);
     }
     return hipSuccess;
   };
@@ -587,8 +603,8 @@ int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp) {
     unsigned long long hcnt[3] = {0, 0, 0};
     HIPCHK(hipMemcpyAsync(hcnt, counters.p, 24, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    fprintf(stderr, "[eps build] Link: %.0f evaluations, %.1f expansions per search; queue of %d kept as the pool; %llu searches filled the visited hash (%d)\n",
-            (double)hcnt[0] / (double)n, (double)hcnt[1] / (double)n, Lcap, hcnt[2], (TRV_HASH * 3) / 4);
+    fprintf(stderr, "[eps build] Link: %.0f evaluations, %.1f expansions per search; queue of %d kept as the pool; visited set: %s, %llu searches filled it\n",
+            (double)hcnt[0] / (double)n, (double)hcnt[1] / (double)n, Lcap, bitmap_vis ? "bitmap" : (ghash_vis ? "hash of 32768 in HBM" : "hash of 8192 in LDS"), hcnt[2]);
   }
 
   // ---- 4. InterInsert

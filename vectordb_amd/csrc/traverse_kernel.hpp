@@ -26,6 +26,8 @@ struct TraverseArgs {
   u64* out_queue;    // [nq][L] (may be null)
   unsigned long long* counters;  // [0] distance evals, [1] expansions, [2] (counters_n > 2) searches that filled the visited hash
   int counters_n;
+  u32* ghash;        // HASHVIS: non-null = the visited hash lives in HBM, [gridDim.x][hslots] u32, pre-set to 0xFF bytes by the host
+  int hslots;        //          (power of two); null = TRV_HASH slots in LDS
   u64* log;          // LOG mode: [nq][log_cap] plain (dist,id) keys: the final queue = the L closest evaluated nodes, ascending
   u32* log_cnt;      // [nq]
   int log_cap;       // >= L
@@ -44,22 +46,23 @@ __device__ __forceinline__ u64 qkey(float d, u32 id, u32 checked) { return ((u64
 // (HASHVIS: `open` = the table had room for a whole chunk of insertions when the chunk started - decided once per chunk from
 // a count that is stable there, so that WHICH nodes a nearly full table still admits does not depend on thread timing)
 template <bool HASHVIS>
-__device__ __forceinline__ bool visit(u32* vis, u32* hash, int* hcount, u32 id, bool open = true) {
+__device__ __forceinline__ bool visit(u32* vis, u32* hash, int* hcount, u32 id, bool open = true, int hbits = 13) {
   if (!HASHVIS) {
     const u32 bit = 1u << (id & 31);
     const u32 old = atomicOr(&vis[id >> 5], bit);
     return !(old & bit);
   } else {
     if (!open) return false;  // table (nearly) full: stop discovering (build-time searches only)
-    u32 h = (id * 2654435761u) >> (32 - 13);
-    for (int probe = 0; probe < TRV_HASH; ++probe) {
+    const u32 mask = (1u << hbits) - 1u;
+    u32 h = (id * 2654435761u) >> (32 - hbits);
+    for (u32 probe = 0; probe <= mask; ++probe) {
       const u32 old = atomicCAS(&hash[h], TRV_NONE, id);
       if (old == TRV_NONE) {
         atomicAdd(hcount, 1);
         return true;
       }
       if (old == id) return false;
-      h = (h + 1) & (TRV_HASH - 1);
+      h = (h + 1) & mask;
     }
     return false;
   }
@@ -79,7 +82,9 @@ __global__ __launch_bounds__(NW * 64) void traverse_kernel(TraverseArgs a) {
   u64* sorted = newk + TRV_CHUNK;                                         // [TRV_CHUNK]
   u32* work = reinterpret_cast<u32*>(sorted + TRV_CHUNK);                 // [TRV_CHUNK] surviving neighbour ids
   int* sh = reinterpret_cast<int*>(work + TRV_CHUNK);                     // small scalars [64]
-  u32* hash = reinterpret_cast<u32*>(sh + 64);                            // [TRV_HASH] (HASHVIS only)
+  u32* hash = (HASHVIS && a.ghash) ? a.ghash + (int64_t)blockIdx.x * a.hslots : reinterpret_cast<u32*>(sh + 64);   // [TRV_HASH] in LDS (HASHVIS only) or [hslots] in HBM
+  const int hbits = (HASHVIS && a.ghash) ? 31 - __clz(a.hslots) : 13;
+  const int hlimit = (HASHVIS && a.ghash) ? (a.hslots / 4) * 3 : (TRV_HASH * 3) / 4;
   // sh[0]=work count, sh[1]=selected count, sh[2]=k (first possibly-unchecked position), sh[3]=valid new count,
   // sh[4]=r_min, sh[5]=position of the first selected candidate, sh[6]=hash fill, sh[7]=log fill, sh[8..8+M) selected node ids, sh[24..24+M+1) edge prefix, sh[48..48+NW) per-wave counts
   const int tid = threadIdx.x;
@@ -96,7 +101,8 @@ __global__ __launch_bounds__(NW * 64) void traverse_kernel(TraverseArgs a) {
   unsigned long long evals = 0, expansions = 0;
   u64* qlog = LOG ? a.log + q * (int64_t)a.log_cap : nullptr;
   if (HASHVIS) {
-    for (int i = tid; i < TRV_HASH; i += NT) hash[i] = TRV_NONE;
+    if (!a.ghash)
+      for (int i = tid; i < TRV_HASH; i += NT) hash[i] = TRV_NONE;
     if (tid == 0) sh[6] = 0;
   }
   if (LOG && tid == 0) sh[7] = 0;
@@ -107,7 +113,7 @@ __global__ __launch_bounds__(NW * 64) void traverse_kernel(TraverseArgs a) {
   // InitializeSetLPara (:446-485): mark seeds visited, L seed distances, sort
   const int NS = a.nseeds > 0 ? a.nseeds : L;     // seeds (<= L)
   const int LS = a.Lsel > 0 ? a.Lsel : L;         // expansion window
-  for (int i = tid; i < NS; i += NT) visit<HASHVIS>(vis, hash, &sh[6], a.init_ids[i]);
+  for (int i = tid; i < NS; i += NT) visit<HASHVIS>(vis, hash, &sh[6], a.init_ids[i], true, hbits);
   __syncthreads();
   for (int c0 = wave * RPW * U; c0 < NS; c0 += NW * RPW * U) {
     const float* rp[U];
@@ -200,7 +206,7 @@ __global__ __launch_bounds__(NW * 64) void traverse_kernel(TraverseArgs a) {
         sh[3] = 0;
       }
       __syncthreads();
-      const bool hash_open = !HASHVIS || sh[6] + TRV_CHUNK <= (TRV_HASH * 3) / 4;   // (sh[6] is stable here: see visit())
+      const bool hash_open = !HASHVIS || sh[6] + TRV_CHUNK <= hlimit;   // (sh[6] is stable here: see visit())
       {
         const int e = e0 + tid;
         bool fresh = false;
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(NW * 64) void traverse_kernel(TraverseArgs a) {
           while (i + 1 < nsel && sh[24 + i + 1] <= e) ++i;
           const int64_t rowbase = a.fixed_deg > 0 ? (int64_t)sh[8 + i] * a.fixed_deg : a.off[sh[8 + i]];
           nb = a.nbr[rowbase + (e - sh[24 + i])];
-          fresh = nb != TRV_NONE && visit<HASHVIS>(vis, hash, &sh[6], nb, hash_open);
+          fresh = nb != TRV_NONE && visit<HASHVIS>(vis, hash, &sh[6], nb, hash_open, hbits);
         }
         const u64 m = __ballot(fresh);
         int wbase = 0;
@@ -329,7 +335,7 @@ __global__ __launch_bounds__(NW * 64) void traverse_kernel(TraverseArgs a) {
   if (tid == 0) {
     atomicAdd(&a.counters[0], evals);
     atomicAdd(&a.counters[1], expansions);
-    if (HASHVIS && a.counters_n > 2 && sh[6] + TRV_CHUNK > (TRV_HASH * 3) / 4) atomicAdd(&a.counters[2], 1ull);   // searches that filled the visited hash
+    if (HASHVIS && a.counters_n > 2 && sh[6] + TRV_CHUNK > hlimit) atomicAdd(&a.counters[2], 1ull);   // searches that filled the visited hash
   }
 }
 
