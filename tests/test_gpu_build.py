@@ -231,3 +231,21 @@ def test_build_is_deterministic(amd, n, d):
     (o1, n1, v1), (o2, n2, v2) = graphs
     assert v1 == v2 and np.array_equal(o1, o2) and np.array_equal(n1, n2)
 
+
+def test_build_visited_hash_is_exact(amd, monkeypatch):
+    """The Link / connectivity searches keep their visited set in a 32768-slot hash per search (HBM); it must behave as the exact
+    n-bit bitmap (the reference's has_calculated): the same table built with EPS_BUILD_VISITED=bitmap gives the same graph."""
+    n, d = 80_000, 256
+    X = data(n, d, 29)
+    graphs = []
+    for mode in ("", "bitmap"):
+        if mode:
+            monkeypatch.setenv("EPS_BUILD_VISITED", mode)
+        ix = amd.GpuIndex(d, 0)
+        ix.attach_rows(X)
+        ix.build()
+        graphs.append(ix.get_graph())
+        ix.close()
+    (o1, n1, v1), (o2, n2, v2) = graphs
+    assert v1 == v2 and np.array_equal(o1, o2) and np.array_equal(n1, n2)
+
