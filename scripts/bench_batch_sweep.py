@@ -1,0 +1,36 @@
+"""Throughput of the exact flat scan (FLAT_AUTO) against the batch size at the headline table (JSON lines):
+    python scripts/bench_batch_sweep.py [rows=10000000] [dim=768]"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import vectordb_amd as amd  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+d = int(sys.argv[2]) if len(sys.argv) > 2 else 768
+g = torch.Generator(device="cuda").manual_seed(42)
+X = torch.empty((n, d), device="cuda")
+for s in range(0, n, 1 << 20):
+    e = min(n, s + (1 << 20))
+    X[s:e] = torch.rand((e - s, d), generator=g, device="cuda")
+ix = amd.GpuIndex(d, 0).use_torch_stream()
+ix.attach_rows(X)
+for nq in (1, 8, 32, 128, 256, 512, 1024, 2048, 4096, 8192):
+    Q = torch.rand((nq, d), generator=g, device="cuda")
+    out = (torch.empty((nq, 10), dtype=torch.int64, device="cuda"), torch.empty((nq, 10), device="cuda"), torch.empty((nq,), dtype=torch.int32, device="cuda"))
+    for _ in range(2):
+        ix.search(Q, 10, out=out, mode=amd.MODE_FLAT)
+    torch.cuda.synchronize()
+    reps = 8 if nq <= 2048 else 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ix.search(Q, 10, out=out, mode=amd.MODE_FLAT)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    st = ix.stats()
+    print(json.dumps({"config": "%d x %d L2 exact flat scan (FLAT_AUTO), k=10" % (n, d), "batch": nq, "ms_per_call": ms, "qps": nq / ms * 1e3,
+                      "engine": "mfma filter + re-rank" if st["rerank_rows"] > 0 else "fp32 stream scan", "rerank_rows_per_query": st["rerank_rows"] / float(nq)}), flush=True)
