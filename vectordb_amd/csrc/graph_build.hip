@@ -174,9 +174,16 @@ __global__ __launch_bounds__(256) void prune_kernel(PruneArgs a) {
     __syncthreads();
   }
   // ---- sort by (dist,id)   (std::sort(pool), nsg.cpp:560 — ties by id here)
-  for (int size = 2; size <= PRUNE_POOL; size <<= 1) {
+  // only the occupied prefix of the pool, rounded up to a power of two (everything behind it is KEY_EMPTY): Link's pool is the
+  // 512-entry queue + the kNN list, InterInsert's a few dozen entries - a quarter / a sixtieth of the 4096 slots
+  int P2 = 64;
+  {
+    const int filled = sh[0] + (a.listB ? a.degB : 0);
+    while (P2 < filled && P2 < PRUNE_POOL) P2 <<= 1;
+  }
+  for (int size = 2; size <= P2; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int i = tid; i < (PRUNE_POOL >> 1); i += 256) {
+      for (int i = tid; i < (P2 >> 1); i += 256) {
         const int lo = ((i / stride) * (stride << 1)) + (i % stride);
         const int hi = lo + stride;
         const bool up = ((lo & size) == 0);
@@ -201,7 +208,7 @@ __global__ __launch_bounds__(256) void prune_kernel(PruneArgs a) {
   int uniq = 0;
   if (unlimited) {
     int local = 0;
-    for (int i = tid; i < PRUNE_POOL; i += 256) {
+    for (int i = tid; i < P2; i += 256) {
       const u64 key = pool[i];
       if (key != KEY_EMPTY && key_id(key) != (u32)v && (i == 0 || pool[i - 1] != key)) ++local;
     }
@@ -223,7 +230,7 @@ __global__ __launch_bounds__(256) void prune_kernel(PruneArgs a) {
     if (tid == 0) {   // the next <= PB unique candidates
       int c = sh[2];
       int nb = 0;
-      while (nb < PB && c < PRUNE_POOL && (unlimited || sh[3] < a.depth)) {
+      while (nb < PB && c < P2 && (unlimited || sh[3] < a.depth)) {
         const u64 key = pool[c];
         if (key == KEY_EMPTY) break;
         const bool dup = (c > 0 && pool[c - 1] == key) || key_id(key) == (u32)v;
