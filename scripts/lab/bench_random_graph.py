@@ -36,8 +36,12 @@ for b in batches:
     out = (torch.empty((b, 10), dtype=torch.int64, device="cuda"), torch.empty((b, 10), device="cuda"), torch.empty((b,), dtype=torch.int32, device="cuda"))
     for T in (1, 4):
         for waves in (os.environ.get("WAVES", "4,8").split(",")):
-            os.environ["EPS_TRV_WAVES"] = waves
-            kw = dict(mode=amd.MODE_GRAPH, intra_threads=T, master_queue=500, local_queue=500)
+            if waves == "auto":
+                os.environ.pop("EPS_TRV_WAVES", None)
+            else:
+                os.environ["EPS_TRV_WAVES"] = waves
+            LQ = int(os.environ.get("LQ", "500"))
+            kw = dict(mode=amd.MODE_GRAPH, intra_threads=T, master_queue=LQ, local_queue=LQ)
             ix.search(Q, 10, out=out, **kw)
             ms = []
             for _ in range(3):
@@ -47,5 +51,5 @@ for b in batches:
             st = ix.stats()
             alg = st["dist_evals"] * (4.0 * d + 4) + st["expansions"] * (8 + 4.0 * deg)
             km = float(np.median(ms))
-            print(json.dumps({"rows": n, "batch": b, "T": T, "waves_per_query": int(waves), "per_cu": os.environ.get("EPS_TRV_PER_CU", "auto"),
+            print(json.dumps({"rows": n, "batch": b, "T": T, "waves_per_query": waves, "per_cu": os.environ.get("EPS_TRV_PER_CU", "auto"),
                               "kernel_ms": km, "evals_per_query": st["dist_evals"] / b, "GBps": alg / (km * 1e-3) / 1e9, "frac_of_8TBps": alg / (km * 1e-3) / 8e12}), flush=True)

@@ -234,11 +234,16 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
   const bool vec4 = (ix.dim_ % 4 == 0) && ((reinterpret_cast<uintptr_t>(ix.d_rows_) & 15) == 0);
   // queues in LDS while a workgroup's working set leaves room for at least two workgroups per CU (the row gathers of
   // the other one cover this one's queue maintenance); larger SearchQueueSize: queues in HBM
-  const bool qglobal = traverse2_lds_bytes((int)ix.dim_, T, (int)Lq, qtot, dp, false) > 80 * 1024;
+  // Between 80 and 150 KB the queues still fit the CU's LDS once: one workgroup of 16 wavefronts per CU then beats queues in
+  // HBM with 4 x 4 wavefronts (T = 4, L = 2000 at 10M x 768, batch 1024: 80 ms vs 108 ms); beyond that: queues in HBM.
+  const size_t lds_need = traverse2_lds_bytes((int)ix.dim_, T, (int)Lq, qtot, dp, false);
+  const size_t lds_limit = getenv("EPS_TRV_LDS_KB") ? (size_t)std::max(16, atoi(getenv("EPS_TRV_LDS_KB"))) * 1024 : (size_t)150 * 1024;   // (A/B knob)
+  const bool qglobal = lds_need > lds_limit;
+  const bool one_per_cu = !qglobal && lds_need > (size_t)80 * 1024;
   const size_t shm = traverse2_lds_bytes((int)ix.dim_, T, (int)Lq, qtot, dp, qglobal);
   // few queries: 16 wavefronts per query (latency); many queries: fewer per query (throughput, more queries per CU)
   const char* waves_s = getenv("EPS_TRV_WAVES");
-  int nw = waves_s ? atoi(waves_s) : (nq <= 256 ? 16 : 4);
+  int nw = waves_s ? atoi(waves_s) : ((nq <= 256 || one_per_cu) ? 16 : 4);
   if (const char* wide_s = getenv("EPS_TRV_WIDE")) nw = atoi(wide_s) != 0 ? 16 : 4;   // (older switch)
   if (nw != 4 && nw != 8 && nw != 16) nw = 4;
   hipDeviceProp_t prop;
