@@ -77,3 +77,36 @@ def test_python_graph_file_roundtrip(tmp_path, oracle):
     seg2 = ANNGraphSegment(str(tmp_path), 5, 1)
     assert seg2.record_number_ == 3 and seg2.navigation_point_ == 2
     assert np.array_equal(seg2.offset_table_, off) and np.array_equal(seg2.neighbor_list_, nbr)
+
+
+def test_public_header_is_plain_c_and_struct_layouts_match_ctypes(tmp_path, built):
+    """include/epsilla_gfx950.h is what a cgo / JNI / N-API binding would include: it must compile as C99 without torch or C++,
+    and the ctypes mirrors in vectordb_amd/_lib.py (what the Python side passes by pointer) must have the C sizes and offsets."""
+    import ctypes as C
+    import shutil
+    import subprocess
+    from vectordb_amd import _lib
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("needs gcc")
+    src = tmp_path / "t.c"
+    src.write_text("""
+#include <stdio.h>
+#include <stddef.h>
+#include "epsilla_gfx950.h"
+int main(void) {
+  printf("search %zu build %zu filter_op %zu %zu %zu %zu layout %zu\\n", sizeof(eps_search_params), sizeof(eps_build_params), sizeof(eps_filter_op),
+         offsetof(eps_filter_op, arg), offsetof(eps_filter_op, ival), offsetof(eps_filter_op, dval), sizeof(eps_table_layout));
+  return 0;
+}
+""")
+    exe = tmp_path / "t"
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([str(exe)], capture_output=True, text=True).stdout.split()
+    c = dict(search=int(out[1]), build=int(out[3]), fop=[int(x) for x in out[5:9]], layout=int(out[10]))
+    assert C.sizeof(_lib.SearchParams) == c["search"] and C.sizeof(_lib.BuildParams) == c["build"]
+    assert [C.sizeof(_lib.FilterOp), _lib.FilterOp.arg.offset, _lib.FilterOp.ival.offset, _lib.FilterOp.dval.offset] == c["fop"]
+    assert C.sizeof(_lib.TableLayout) == c["layout"]
+
