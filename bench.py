@@ -39,6 +39,8 @@ TRAFFIC = {"mfma": (2 * 7340245 + 7460) * 1024.0, "graph_T4_L500": 2 * 48440196 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F16_PEAK_TF = 2500.0  # dense bf16/f16 MFMA peak (nominal, 2.4 GHz)
 MFMA_F16_SUSTAINED_TF = 1814.0  # measured: v_mfma_f32_32x32x16_f16 alone, operands toggling like data, 1.82 GHz (scripts/lab/mfma_peak.hip)
+MFMA_I8_PEAK_TOPS = 5000.0      # dense 8-bit MFMA peak: twice the fp16 rate (MI355X_MICROARCH.md lists the FP8 dense peak ~5 P and I8 at ~2x bf16)
+MFMA_I8_SUSTAINED_TOPS = 3424.0  # measured: v_mfma_i32_32x32x32_i8 alone on bytes in [-127, 127], 1.74 GHz (profiles/r3_mfma_peak_i8_vs_fp16.txt)
 
 
 def parse():
@@ -52,7 +54,8 @@ def parse():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--metric", default="EUCLIDEAN")
     ap.add_argument("--mode", default="flat", choices=["flat", "graph"])
-    ap.add_argument("--engine", default="auto", choices=["auto", "stream", "mfma"])
+    ap.add_argument("--engine", default="auto", choices=["auto", "stream", "mfma", "mfma8"],
+                    help="flat scan engine: auto (the library's choice: int8 first pass), stream (fp32), mfma (fp16 filter), mfma8 (int8 filter)")
     ap.add_argument("--data", default="uniform", choices=["uniform", "clustered", "manifold"],
                     help="clustered: SURVEY 8d secondary set, 1000 Gaussian clusters sigma=0.1; manifold: a 16-dimensional uniform latent embedded "
                          "linearly in --dim dimensions + 1 %% noise (low intrinsic dimension, as learned embeddings have; tertiary, not in BASELINE)")
@@ -265,7 +268,7 @@ def main():
     ix.set_stream(stream)
     ix.attach_rows(X)
     ix.set_id_map(rank, world)
-    engine = {"auto": amd.FLAT_AUTO, "stream": amd.FLAT_STREAM, "mfma": amd.FLAT_MFMA}[args.engine]
+    engine = {"auto": amd.FLAT_AUTO, "stream": amd.FLAT_STREAM, "mfma": amd.FLAT_MFMA, "mfma8": amd.FLAT_MFMA_I8}[args.engine]
     mode = amd.MODE_FLAT if args.mode == "flat" else amd.MODE_GRAPH
     skw = dict(mode=mode, flat_engine=engine)
     build_s = None
@@ -419,10 +422,11 @@ def main():
         elif used_mfma:
             # algorithmic flops of the timed launch: 2 * batch * rows * d, on the fp16 dense MFMA roof
             flops = 2.0 * kq * krows * d   # queries x rows of the timed launch (batches > 2048 run in slices)
-            roof = {"bound": "mfma", "kernel": "mfma_filter_kernel_v7 (largest of the filter stages: %d of %d rows x %d of %d queries)" % (krows, n, kq, b),
+            bits = int(st.get("main_kernel_bits", 16))
+            roof = {"bound": "mfma", "kernel": "mfma_filter_kernel_v7<%s> (largest of the filter stages: %d of %d rows x %d of %d queries)" % ("int8" if bits == 8 else "fp16", krows, n, kq, b),
                     "achieved": flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms else None,
-                    "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
-                    "traffic": TRAFFIC.get("mfma") if (n == 10_000_000 and b == 1024 and d == 768) else None}
+                    "peak": MFMA_I8_PEAK_TOPS if bits == 8 else MFMA_F16_PEAK_TF, "unit": "TOP/s" if bits == 8 else "TFLOP/s", "operand_bits": bits,
+                    "traffic": TRAFFIC.get("mfma") if (n == 10_000_000 and b == 1024 and d == 768 and bits == 16) else None}
         else:
             # a flat scan needs rows*4*d bytes ONCE per batch; the stream engine re-reads the store once
             # per group of 4 queries, which this figure deliberately does not credit.
@@ -431,8 +435,10 @@ def main():
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
         roof["frac"] = (roof["achieved"] / roof["peak"]) if roof["achieved"] else None
         if used_mfma and args.mode == "flat" and roof["achieved"]:
-            roof["sustained_peak_measured"] = MFMA_F16_SUSTAINED_TF
-            roof["frac_of_sustained"] = roof["achieved"] / MFMA_F16_SUSTAINED_TF
+            sus = MFMA_I8_SUSTAINED_TOPS if roof.get("operand_bits") == 8 else MFMA_F16_SUSTAINED_TF
+            roof["sustained_peak_measured"] = sus
+            roof["frac_of_sustained"] = roof["achieved"] / sus
+            roof["fp16_equivalent"] = {"what": "the same algorithmic flops against the fp16 dense MFMA peak (the r2 line's roof)", "frac": roof["achieved"] / MFMA_F16_PEAK_TF}
         roof["kernel_ms_per_step"] = kernel_ms * (b / kq if used_mfma and args.mode == "flat" else 1.0)   # all slices of a step
         roof["kernel_ms_per_launch"] = kernel_ms
         roof["timed_launches"] = len(main_ms)

@@ -67,6 +67,11 @@ extern "C" {
 #define EPS_FLAT_STREAM 1 /* fp32 streaming scan, HBM-bound; any batch size                            */
 #define EPS_FLAT_MFMA 2   /* fp16-MFMA lower-bound filter over a device-side half mirror + exact fp32
                              re-rank; returns the same exact answer; for large batches                 */
+#define EPS_FLAT_MFMA_I8 3 /* the same with an int8 mirror as the filter's operand (twice the matrix rate,
+                             half the mirror; the bound is computed from the stored residuals, so the
+                             answer is again the exact one); tables an 8-bit grid cannot serve and batches
+                             whose candidate lists overflow run the fp16 pass.  EPS_FLAT_AUTO picks this
+                             form when it picks the matrix engine.                                     */
 
 /* filter comparison operators for eps_index_set_int_filter */
 #define EPS_OP_NONE 0
@@ -151,6 +156,7 @@ typedef struct eps_search_stats {
   int64_t main_kernel_launches;
   int64_t main_kernel_rows; /* rows covered by the launch timed in main_kernel_ms              */
   int64_t main_kernel_queries; /* queries covered by that launch (large batches run in slices)  */
+  int64_t main_kernel_bits; /* operand width of that launch: 32 (fp32 stream / traversal), 16 or 8 (matrix engine) */
 } eps_search_stats;
 
 void eps_default_search_params(eps_search_params* p);

@@ -1,0 +1,204 @@
+"""The 8-bit first pass of the batched flat scan (EPS_FLAT_MFMA_I8: int8 mirror on ONE grid per index, v_mfma_i32_32x32x32_i8,
+integer thresholds, exact fp32 re-rank).  The contract is the fp16 engine's: the SAME exact answer as the fp32 stream scan
+(`BruteForceSearch`, reference engine/db/execution/vec_search_executor.cpp:717-768), bit for bit, for any data - the filter's
+bound is computed from the residuals of the stored bytes, so coarse operands may only cost re-ranked rows, never results."""
+import numpy as np
+import pytest
+
+from helpers import assert_topk_match, bitset, data
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import vectordb_amd
+    from vectordb_amd.build import build
+    build()
+    return vectordb_amd
+
+
+def same(a, b, what=""):
+    assert np.array_equal(a[0], b[0]), "%s: %d ids differ" % (what, (a[0] != b[0]).sum())
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), what
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("n,d,nq", [(70_000, 768, 40), (100_000, 128, 130), (66_000, 100, 64), (80_000, 33, 33), (150_000, 384, 1100),
+                                    (70_000, 1024, 300)])
+def test_i8_engine_is_exact(amd, oracle, metric, n, d, nq):
+    """int8 filter + fp32 re-rank == fp32 stream scan (same rows, same distance bits) == fp16 engine, and the oracle on a sample.
+    Shapes: K depths of 4 (the minimum: d <= 512 pads to 512 bytes), 6 and 8 K-steps, padded last query tiles, 128-query
+    tiles (nq <= 128) and several 256-query tiles."""
+    X = data(n, d, 7 + d)
+    Q = data(nq, d, 8 + d)
+    if metric == 1:
+        X = amd.normalize_rows(X, only_if_nonzero=True)
+        Q = amd.normalize_rows(Q, only_if_nonzero=False)
+    ix = amd.GpuIndex(d, metric)
+    ix.attach_rows(X)
+    for k in (1, 10, 100):
+        a = ix.search(Q, k, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
+        st = ix.stats()
+        b = ix.search(Q, k, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
+        assert st["main_kernel_bits"] == 8, st           # the 8-bit pass did run (no silent fall-back to fp16)
+        assert st["overflow_queries"] == 0 and st["rerank_rows"] > 0
+        # the looser bound may let more rows through than the fp16 pass, but it has to stay a FILTER
+        assert st["rerank_rows"] < nq * (8.0 * k * n / 4096 + 512), "filter is not selective: %d" % st["rerank_rows"]
+        same(a, b, "k=%d" % k)
+    c = ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA)
+    assert ix.stats()["main_kernel_bits"] == 16
+    same(c, ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8), "fp16 vs int8")
+    for qi in range(0, nq, 13):
+        rid, rd = oracle.topk_flat(metric, X, Q[qi], 10)
+        ids, dist, cnt = ix.search(Q[qi:qi + 1].repeat(32, 0), 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
+        assert_topk_match(ids[5], dist[5], rid, rd, what="int8 vs oracle q%d" % qi)
+    ix.close()
+
+
+@pytest.mark.parametrize("kind", ["gauss", "offset", "heavy_tail", "signed_ip", "tiny", "query_outliers"])
+def test_i8_engine_on_other_distributions(amd, kind):
+    """The grid is one (zero, step) pair per index, so what the values look like decides how tight the bound is - never the
+    answer.  Gaussian rows (grid spans ~10 sigma), rows far from the origin (|x|^2 ~ 1e4 per dimension: the row constant is
+    summed without cancellation), one huge outlier (the grid is stretched 100x: nearly everything passes, lists overflow, the
+    fp16 pass takes over), signed rows under DOT_PRODUCT, values ~1e-3, and queries far outside the table's range (clamped
+    on the grid: their own residual enters the bound)."""
+    rng = np.random.default_rng(5)
+    n, d, nq, metric = 90_000, 256, 200, 0
+    if kind == "gauss":
+        X = rng.standard_normal((n, d), dtype=np.float32)
+        Q = rng.standard_normal((nq, d), dtype=np.float32)
+    elif kind == "offset":
+        X = 100.0 + rng.random((n, d), dtype=np.float32)
+        Q = 100.0 + rng.random((nq, d), dtype=np.float32)
+    elif kind == "heavy_tail":
+        X = rng.random((n, d), dtype=np.float32)
+        X[12345, 7] = 100.0
+        Q = rng.random((nq, d), dtype=np.float32)
+    elif kind == "signed_ip":
+        metric = 2
+        X = rng.standard_normal((n, d), dtype=np.float32)
+        Q = rng.standard_normal((nq, d), dtype=np.float32) * 3.0
+    elif kind == "tiny":
+        X = rng.random((n, d), dtype=np.float32) * 1e-3
+        Q = rng.random((nq, d), dtype=np.float32) * 1e-3
+    else:
+        X = rng.random((n, d), dtype=np.float32)
+        Q = rng.random((nq, d), dtype=np.float32) * 4.0 - 1.5
+    ix = amd.GpuIndex(d, metric)
+    ix.attach_rows(X)
+    a = ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
+    st = ix.stats()
+    b = ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
+    same(a, b, kind)
+    if kind in ("gauss", "signed_ip", "tiny"):
+        assert st["main_kernel_bits"] == 8 and st["overflow_queries"] == 0, st
+    auto = ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_AUTO)
+    same(auto, b, kind + " (auto)")
+    ix.close()
+
+
+def test_i8_engine_declines_tables_it_cannot_serve(amd):
+    """All values equal (no grid), or a non-finite value: the request for the 8-bit pass is served by the fp16 / stream engine,
+    same answer."""
+    n, d, nq = 70_000, 128, 64
+    Q = data(nq, d, 3)
+    X = np.full((n, d), 0.25, np.float32)
+    ix = amd.GpuIndex(d, 0)
+    ix.attach_rows(X)
+    a = ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
+    assert ix.stats()["main_kernel_bits"] != 8
+    same(a, ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM), "constant table")
+    ix.close()
+    X = data(n, d, 4)
+    X[777, 5] = np.inf
+    ix = amd.GpuIndex(d, 0)
+    ix.attach_rows(X)
+    a = ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
+    assert ix.stats()["main_kernel_bits"] != 8
+    b = ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
+    assert np.array_equal(a[0], b[0])
+    ix.close()
+
+
+def test_i8_engine_with_deleted_filter_and_ties(amd, oracle):
+    from oracle.pyoracle import make_filter
+    n, d, nq = 90_000, 64, 48
+    rng = np.random.default_rng(3)
+    base = rng.random((300, d), dtype=np.float32)
+    X = base[rng.integers(0, 300, n)]                     # every row has ~300 exact duplicates: massive ties
+    Q = rng.random((nq, d), dtype=np.float32)
+    bits = bitset(n, range(0, n, 3))
+    idc = np.arange(n, dtype=np.int64)
+    ix = amd.GpuIndex(d, 0)
+    ix.attach_rows(X)
+    ix.set_deleted(bits)
+    ix.set_int_filter(idc, ">=", 1000)
+    for k in (10, 64):
+        a = ix.search(Q, k, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
+        b = ix.search(Q, k, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
+        same(a, b)
+    flt, keep = make_filter(deleted=bits, attr=idc, stride=8, width=8, op=">=", value=1000)
+    rid, rd = oracle.topk_flat(0, X, Q[0], 10, flt=flt)
+    assert np.array_equal(a[0][0][:10], rid)               # ties resolve by id exactly as Candidate::operator<
+    ix.close()
+
+
+def test_i8_engine_adversarial_order_and_selective_filter(amd):
+    """Rows sorted from far to near (every stage's threshold is too optimistic -> lists overflow -> fp16 pass -> stream scan), and
+    99.5 % of the rows deleted (thresholds from visible rows only).  Whatever chain of fall-backs runs, the answer is the scan's."""
+    rng = np.random.default_rng(1)
+    n, d, nq = 300_000, 32, 64
+    q0 = rng.random((1, d), dtype=np.float32)
+    X = rng.random((n, d), dtype=np.float32)
+    X = np.ascontiguousarray(X[np.argsort(-((X - q0) ** 2).sum(1))])
+    Q = (q0 + 0.01 * rng.random((nq, d), dtype=np.float32)).astype(np.float32)
+    ix = amd.GpuIndex(d, 0)
+    ix.attach_rows(X)
+    same(ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8), ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM), "adversarial order")
+    ix.close()
+    n, d, nq = 400_000, 64, 96
+    X, Q = data(n, d, 120), data(nq, d, 121)
+    dele = rng.random(n) < 0.995
+    ix = amd.GpuIndex(d, 0)
+    ix.attach_rows(X)
+    ix.set_deleted(np.packbits(dele, bitorder="little"))
+    a = ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
+    same(a, ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM), "selective filter")
+    assert not dele[a[0][a[0] >= 0]].any()
+    ix.close()
+
+
+def test_i8_mirror_is_extended_by_appended_rows(amd):
+    """Appended rows are quantised on the grid the table already has (values beyond it are clamped; their residual grows, the
+    bound stays valid) - the mirror is not rebuilt, and the answer over old + new rows equals the scan's."""
+    n0, n1, d, nq = 80_000, 30_000, 256, 128
+    X0, X1, Q = data(n0, d, 1), data(n1, d, 2) * 1.2 - 0.1, data(nq, d, 3)
+    ix = amd.GpuIndex(d, 0)
+    ix.attach_rows(X0)
+    ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
+    ix.append_rows(X1)
+    a = ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
+    assert ix.stats()["main_kernel_bits"] == 8
+    b = ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
+    same(a, b, "after append")
+    assert (a[0] >= n0).any()                              # some of the new rows are among the answers
+    ix.close()
+
+
+def test_query_beyond_the_fp16_range_is_not_dropped(amd):
+    """a query component beyond 65504 became +inf in the fp16 operand, and inf * 0 = NaN accumulators
+    silently failed `acc >= T` for rows holding an exact 0 in that column.  Such a batch now runs on an engine that can
+    represent it; the answer is the stream scan's."""
+    n, d, nq = 70_000, 128, 32
+    X = data(n, d, 9)
+    X[::2, 5] = 0.0
+    Q = data(nq, d, 10)
+    Q[3, 5] = 1.0e6
+    Q[7, 0] = -3.0e5
+    ix = amd.GpuIndex(d, 2)
+    ix.attach_rows(X)
+    ref = ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
+    for eng in (amd.FLAT_MFMA, amd.FLAT_MFMA_I8, amd.FLAT_AUTO):
+        same(ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=eng), ref, "engine %d" % eng)
+    ix.close()

@@ -29,7 +29,7 @@ def test_filter_kernels_do_not_spill(tmp_path):
         if m and name:
             usage[name][m.group(1)] = int(m.group(2))
     v7 = {k: v for k, v in usage.items() if "mfma_filter_kernel_v7" in k}
-    assert len(v7) == 6, list(usage)   # {128, 256}-query tiles x {ids, keys, dense} epilogues
+    assert len(v7) == 12, list(usage)   # {128, 256}-query tiles x {ids, keys, dense} epilogues x {fp16, int8} operands
     for k, u in v7.items():
         assert u["ScratchSize [bytes/lane]"] == 0, (k, u)
         assert u["AGPRs"] in (128, 256), (k, u)      # the accumulators live in AGPRs

@@ -16,7 +16,7 @@ EPS_NOT_IMPLEMENTED_ERROR = 50009
 
 METRIC_EUCLIDEAN, METRIC_COSINE, METRIC_DOT_PRODUCT = 0, 1, 2
 MODE_REFERENCE, MODE_FLAT, MODE_GRAPH = 0, 1, 2
-FLAT_AUTO, FLAT_STREAM, FLAT_MFMA = 0, 1, 2
+FLAT_AUTO, FLAT_STREAM, FLAT_MFMA, FLAT_MFMA_I8 = 0, 1, 2, 3
 OPS = {None: 0, "": 0, "<": 1, "<=": 2, "==": 3, "=": 3, ">=": 4, ">": 5, "!=": 6, "<>": 6}
 
 EXPORTS = [
@@ -57,7 +57,7 @@ class SearchStats(C.Structure):
     _fields_ = [("dist_evals", C.c_int64), ("expansions", C.c_int64), ("rerank_rows", C.c_int64),
                 ("overflow_queries", C.c_int64), ("kernel_ms", C.c_double), ("main_kernel_ms", C.c_double),
                 ("main_kernel_launches", C.c_int64), ("main_kernel_rows", C.c_int64),
-                ("main_kernel_queries", C.c_int64)]
+                ("main_kernel_queries", C.c_int64), ("main_kernel_bits", C.c_int64)]
 
 
 class EpsillaError(RuntimeError):

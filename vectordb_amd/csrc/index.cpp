@@ -571,6 +571,7 @@ int32_t Index::flat_stream(const float* dq, int64_t nq, int k, int64_t row_begin
   stats_.main_kernel_launches += 1;
   stats_.main_kernel_rows = row_end - row_begin;
   stats_.main_kernel_queries = nq;
+  stats_.main_kernel_bits = 32;
   stats_.dist_evals += nq * (row_end - row_begin);
   return EPS_OK;
 }
@@ -643,19 +644,22 @@ int32_t Index::search(const float* queries, int64_t nq, int32_t k, const eps_sea
     if (cap_local && p.local_queue < keff) keff = (int)p.local_queue;
     if (keff < k) launch_fill_u64(run_keys, nq * k, KEY_EMPTY, stream_);
     int engine = p.flat_engine;
+    if (engine < EPS_FLAT_AUTO || engine > EPS_FLAT_MFMA_I8) return fail(EPS_USER_ERROR, "search: unknown flat engine");
+    int bits = engine == EPS_FLAT_MFMA ? 16 : (engine == EPS_FLAT_MFMA_I8 ? 8 : 0);   // AUTO: the library picks the operand width too
+    if (engine == EPS_FLAT_MFMA_I8) engine = EPS_FLAT_MFMA;
     if (engine == EPS_FLAT_AUTO) engine = flat_mfma_profitable(*this, nq, keff) ? EPS_FLAT_MFMA : EPS_FLAT_STREAM;
     // a filter on @distance needs exact distances wherever it is evaluated; the MFMA engine selects its seeds on
     // approximate keys, so such searches stay on the exact stream engine
     if (prog_len_ > 0 && prog_uses_dist_ && !prefilter_call_) engine = EPS_FLAT_STREAM;
     int32_t rc;
     if (keff == k) {
-      rc = engine == EPS_FLAT_MFMA ? flat_mfma_search(*this, dq, nq, k, run_keys)
+      rc = engine == EPS_FLAT_MFMA ? flat_mfma_search(*this, dq, nq, k, run_keys, false, bits)
                                    : flat_stream(dq, nq, k, 0, n_rows_, run_keys, false);
     } else {
       // narrower result (L_local cap): compute into a k_eff-wide list, then widen
       if (!tmp_buf_.reserve((size_t)nq * keff * sizeof(u64))) return fail(EPS_INFRA_UNEXPECTED_ERROR, "search: out of device memory");
       u64* narrow = tmp_buf_.as<u64>();
-      rc = engine == EPS_FLAT_MFMA ? flat_mfma_search(*this, dq, nq, keff, narrow)
+      rc = engine == EPS_FLAT_MFMA ? flat_mfma_search(*this, dq, nq, keff, narrow, false, bits)
                                    : flat_stream(dq, nq, keff, 0, n_rows_, narrow, false);
       if (rc == EPS_OK)
         HIP_TRY(hipMemcpy2DAsync(run_keys, (size_t)k * sizeof(u64), narrow, (size_t)keff * sizeof(u64),

@@ -20,6 +20,23 @@
 // The bound is a worst-case one (no distributional assumption) for the fp16 rounding and the accumulation order of the
 // GEMM; the fp32 rounding of the re-ranked keys it is compared with is covered by a slack that grows with d.
 //
+// 8-bit first pass (r3).  The matrix pipe multiplies int8 operands at twice the fp16 rate (v_mfma_i32_32x32x32_i8: measured
+// 3.42 POP/s against 1.75 PFLOP/s for the fp16 instruction in the same loop, profiles/r3_mfma_peak_i8_vs_fp16.txt), and a
+// lower-bound filter may use any operand whose error it can bound.  Rows and queries are quantised on ONE grid per index,
+//     xh = z + sx * xi,  xi = clamp(rint((x - z) / sx), -127, 127),   z = (min + max) / 2,  sx = (max - min) / 254
+// so that the dot product of the quantised vectors is exact integer arithmetic plus per-row and per-query constants:
+//     qh.xh = d z^2 + z sx SX[x] + z sx SQ[q] + sx^2 * sum_k qi_k xi_k          (SX, SQ: sums of the int8 values)
+//     approx(q,x) = R[x] + C[q] - u * dot,   u = |s| sx^2,   R, C: the row / query constants (kernels below)
+//     |key - approx| <= |s| * (|q| * |x - xh| + |q - qh| * |xh|)                 (Cauchy-Schwarz on the stored residuals; no
+//                                                                                 accumulation slack: the int32 sum is exact)
+// A row passes iff  dot + acc0[x] >= Tq[q]  with acc0 = ceil(-R/u) folded into the accumulator's start value and
+// Tq = floor((C - T)/u): one integer max + compare per 16 outputs, as in the fp16 kernel.  On U[0,1) rows at d = 768 the margin is
+// ~2.0 key units (fp16: 0.03) against a spread of 5.5 per sigma of the distance distribution: a few dozen candidates per query
+// in the last stage instead of ~10 - noise for the fp32 re-rank.  The kernel is the v7 kernel with the MFMA instruction and the
+// accumulator type exchanged (mfma_kernels.hpp, V7Op): a K-step moves the same 128 bytes per row, but covers 128 dimensions
+// instead of 64.  Tables the grid does not fit (all values equal, non-finite values, constants beyond int32) and batches whose
+// candidate lists overflow fall back to the fp16 engine.
+//
 // Kernels: mfma_kernels.hpp - v7 (default: persistent, 4 wavefronts x 256 rows x 64 queries per 256 x 256 tile, query
 // fragments straight to VGPRs, 4-slot LDS-DMA ring for the row operand) and v3, the fallback for d_pad % 128 != 0 or
 // d_pad < 256 (tests/test_gpu_parity.py::test_mfma_engine_is_exact covers d = 33 and d = 100).  Staging, seeds, re-rank and the overflow fallback are in flat_mfma_search_slice below.
@@ -54,6 +71,19 @@ struct HalfMirror {
   DevBuf T;        // float [b_pad]
   DevBuf cand;     // u32 [b][cap]
   DevBuf cnt;      // u32 [b] + overflow counter at [b]
+  // 8-bit mirror (first-pass operand of the filter, see above)
+  DevBuf x8;       // int8 [n_pad8][d_pad8]
+  DevBuf acc0;     // int32 [n_pad8]: accumulator start of every row = ceil(-R/u) + 1 (-2^30 on padding rows)
+  DevBuf sx8, sacc0;            // seed sample of the 8-bit mirror
+  int64_t sample8_version = -1, sample8_n = 0, sample8_rows = 0;
+  DevBuf scal8;    // float [8]: max |x - xh|, max |xh|, max |x|^2, bad flag, max |R|, -, min (ordered u32), max (ordered u32)
+  DevBuf q8;       // int8 [b_pad][d_pad8]
+  float h_scal8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float z8 = 0.f, step8 = 0.f;  // the grid
+  int64_t version8 = -1, n8 = 0, n_pad8 = 0;
+  int d_pad8 = 0;
+  bool i8_ok = false;
+  int64_t extended_rows8 = 0;
   int64_t version = -1;
   int64_t n = 0, n_pad = 0;
   int d_pad = 0;
@@ -184,7 +214,10 @@ __global__ __launch_bounds__(256) void query_prep_kernel(const float* q, int64_t
   float s2 = 0.f, e2 = 0.f;
   for (int c = lane; c < d_pad; c += 64) {
     const float x = c < dim ? src[c] : 0.f;
-    const _Float16 h = to_half_drop(x, drop);
+    // A component beyond the fp16 range is stored as +-65504, not +-inf: inf * 0 would make NaN accumulators that fail every
+    // `acc >= T` and silently drop rows from an exact answer.  Clamped, the component's residual enters |q - qh| like any
+    // other rounding error: the bound stays valid (and becomes so loose that the batch ends on the stream engine).
+    const _Float16 h = to_half_drop(fminf(fmaxf(x, -65504.f), 65504.f), drop);
     dst[c] = h;
     s2 = fmaf(x, x, s2);
     const float e = x - (float)h;
@@ -200,6 +233,203 @@ __global__ __launch_bounds__(256) void query_prep_kernel(const float* q, int64_t
     qstat[r * 4 + 2] = sqrtf(e2) * 1.000001f;
     qstat[r * 4 + 3] = 0.f;
   }
+}
+
+// ------------------------------------------------------------------------------------------------ 8-bit mirror
+// value range of the table (ordered-u32 images, so atomicMin / atomicMax work on them): scal8[6] = min, scal8[7] = max
+__global__ __launch_bounds__(256) void minmax_kernel(const float* rows, int64_t count, u32* scal8) {
+  float lo = __builtin_inff(), hi = -__builtin_inff();
+  bool bad = false;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  if ((reinterpret_cast<uintptr_t>(rows) & 15) == 0) {
+    const int64_t c4 = count / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < c4; i += stride) {
+      const float4 v = reinterpret_cast<const float4*>(rows)[i];
+      lo = fminf(fminf(lo, v.x), fminf(fminf(v.y, v.z), v.w));
+      hi = fmaxf(fmaxf(hi, v.x), fmaxf(fmaxf(v.y, v.z), v.w));
+      bad |= !(fabsf(v.x) < 3.0e38f) || !(fabsf(v.y) < 3.0e38f) || !(fabsf(v.z) < 3.0e38f) || !(fabsf(v.w) < 3.0e38f);
+    }
+    for (int64_t i = c4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) {
+      lo = fminf(lo, rows[i]);
+      hi = fmaxf(hi, rows[i]);
+      bad |= !(fabsf(rows[i]) < 3.0e38f);
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) {
+      lo = fminf(lo, rows[i]);
+      hi = fmaxf(hi, rows[i]);
+      bad |= !(fabsf(rows[i]) < 3.0e38f);
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = fminf(lo, __shfl_xor(lo, o));
+    hi = fmaxf(hi, __shfl_xor(hi, o));
+  }
+  if (lane_id() == 0) {
+    if (lo <= hi) {
+      atomicMin(&scal8[6], f2ord(lo + 0.0f));
+      atomicMax(&scal8[7], f2ord(hi + 0.0f));
+    }
+  }
+  if (__any(bad) && lane_id() == 0) atomicMax(&scal8[3], __float_as_uint(1.f));   // inf / NaN somewhere: the grid would be meaningless
+}
+
+__device__ __forceinline__ int quant8(float x, float z, float inv_step) {
+  float t = rintf((x - z) * inv_step);
+  t = fminf(fmaxf(t, -127.f), 127.f);   // (rows appended after the grid was fixed may lie outside it: clamped, the residual grows, the bound stays valid)
+  return (int)t;
+}
+
+// rows [row0, n_pad) are (re)written, as in half_mirror_kernel.  metric 0: R = |x|^2 - 2 z sx SX - d z^2 = sum (x_k - z)^2 + 2 z (x_k - xh_k)
+// (summed in this form: no cancellation for tables far from the origin); otherwise R = -z sx SX.  u = |s| sx^2.
+__global__ __launch_bounds__(256) void quant_mirror_kernel(const float* rows, int64_t row0, int64_t n, int64_t n_pad, int dim, int d_pad8, float z, float step,
+                                                           float inv_step, float inv_u, int metric, signed char* x8, int* acc0, float* scal8) {
+  const int lane = lane_id();
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  float m_e1 = 0.f, m_nxh = 0.f, m_xn = 0.f, m_bad = 0.f, m_r = 0.f;
+  const bool vec = (dim & 3) == 0 && ((reinterpret_cast<uintptr_t>(rows) & 15) == 0);
+  for (int64_t r = row0 + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n_pad; r += nwaves) {
+    signed char* dst = x8 + r * d_pad8;
+    if (r >= n) {
+      for (int c = lane * 4; c < d_pad8; c += 256) *reinterpret_cast<u32*>(dst + c) = 0u;
+      if (lane == 0) acc0[r] = -(1 << 30);
+      continue;
+    }
+    const float* src = rows + r * dim;
+    float s2 = 0.f, e2 = 0.f, h2 = 0.f, rr = 0.f;
+    int sx_sum = 0;
+    for (int c = lane * 4; c < d_pad8; c += 256) {   // d_pad8 is a multiple of 256
+      float xs[4] = {0.f, 0.f, 0.f, 0.f};
+      if (vec) {
+        if (c < dim) {
+          const float4 v = *reinterpret_cast<const float4*>(src + c);
+          xs[0] = v.x; xs[1] = v.y; xs[2] = v.z; xs[3] = v.w;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xs[e] = c + e < dim ? src[c + e] : 0.f;
+      }
+      u32 packed = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (c + e < dim) {
+          const int xi = quant8(xs[e], z, inv_step);
+          const float dx = xs[e] - z;
+          const float res = fmaf(-step, (float)xi, dx);     // x - xh
+          const float xh = fmaf(step, (float)xi, z);
+          packed |= (u32)(xi & 255) << (8 * e);
+          sx_sum += xi;
+          s2 = fmaf(xs[e], xs[e], s2);
+          e2 = fmaf(res, res, e2);
+          h2 = fmaf(xh, xh, h2);
+          rr += fmaf(dx, dx, 2.f * z * res);
+        }
+      }
+      *reinterpret_cast<u32*>(dst + c) = packed;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      s2 += __shfl_xor(s2, o);
+      e2 += __shfl_xor(e2, o);
+      h2 += __shfl_xor(h2, o);
+      rr += __shfl_xor(rr, o);
+      sx_sum += __shfl_xor(sx_sum, o);
+    }
+    const float R = metric == 0 ? rr : -z * step * (float)sx_sum;
+    const float a0 = ceilf(-R * inv_u) + 1.f;
+    if (!(fabsf(a0) < 536870912.f)) m_bad = 1.f;   // |acc0| must stay below 2^29 (the dot product adds < 2^27)
+    if (lane == 0) acc0[r] = (int)fminf(fmaxf(a0, -536870912.f), 536870912.f);
+    m_e1 = fmaxf(m_e1, sqrtf(e2) * 1.00001f);
+    m_nxh = fmaxf(m_nxh, sqrtf(h2) * 1.00001f);
+    m_xn = fmaxf(m_xn, s2);
+    m_r = fmaxf(m_r, fabsf(R));
+    if (s2 != s2 || !(s2 < 3.0e38f)) m_bad = 1.f;
+  }
+  if (lane == 0) {
+    atomic_max_pos(&scal8[0], m_e1);
+    atomic_max_pos(&scal8[1], m_nxh);
+    atomic_max_pos(&scal8[2], m_xn);
+    if (m_bad != 0.f) atomic_max_pos(&scal8[3], 1.f);
+    atomic_max_pos(&scal8[4], m_r);
+  }
+}
+
+// queries on the table's grid.  qstat[r] = |q|^2, |q|, |q - qh|, C[q] + const(q) (the constant that turns u-scaled accumulators
+// into approximate distances: dist ~ a.s * acc + qstat[3])
+__global__ __launch_bounds__(256) void query_prep8_kernel(const float* q, int64_t nq, int64_t b_pad, int dim, int d_pad8, float z, float step, float inv_step,
+                                                          int metric, signed char* q8, float* qstat) {
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= b_pad) return;
+  const int lane = lane_id();
+  signed char* dst = q8 + r * d_pad8;
+  if (r >= nq) {
+    for (int c = lane * 4; c < d_pad8; c += 256) *reinterpret_cast<u32*>(dst + c) = 0u;
+    if (lane == 0) qstat[r * 4 + 0] = qstat[r * 4 + 1] = qstat[r * 4 + 2] = qstat[r * 4 + 3] = 0.f;
+    return;
+  }
+  const float* src = q + r * dim;
+  float s2 = 0.f, e2 = 0.f;
+  int sq_sum = 0;
+  for (int c = lane * 4; c < d_pad8; c += 256) {
+    u32 packed = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (c + e < dim) {
+        const float x = src[c + e];
+        const int qi = quant8(x, z, inv_step);
+        const float res = fmaf(-step, (float)qi, x - z);
+        packed |= (u32)(qi & 255) << (8 * e);
+        sq_sum += qi;
+        s2 = fmaf(x, x, s2);
+        e2 = fmaf(res, res, e2);
+      }
+    }
+    *reinterpret_cast<u32*>(dst + c) = packed;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    s2 += __shfl_xor(s2, o);
+    e2 += __shfl_xor(e2, o);
+    sq_sum += __shfl_xor(sq_sum, o);
+  }
+  if (lane == 0) {
+    const float sabs = metric == 0 ? 2.f : 1.f;
+    const float C = -(float)dim * z * z - sabs * z * step * (float)sq_sum;
+    const float c = metric == 0 ? s2 : (metric == 1 ? 1.f : 0.f);
+    qstat[r * 4 + 0] = s2;
+    qstat[r * 4 + 1] = sqrtf(s2) * 1.000001f;
+    qstat[r * 4 + 2] = sqrtf(e2) * 1.00001f;
+    qstat[r * 4 + 3] = C + c;
+  }
+}
+
+// the 8-bit form of threshold_kernel: T[j] = int32 threshold in accumulator units (a row passes iff dot + acc0 >= T[j])
+__global__ void threshold8_kernel(const u64* run_keys, int k, int64_t nq, int64_t b_pad, const float* qstat, const float* scal8, int metric,
+                                  float u, int* T, u32* cnt, u32* gsync, float slack) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= b_pad) return;
+  if (j < nq) cnt[j] = 0;
+  if (gsync && j < 256) gsync[j] = 0;
+  if (j >= nq) {
+    T[j] = 0x7FFFFFFF;
+    return;
+  }
+  const u64 kth = run_keys[j * k + (k - 1)];
+  if (kth == KEY_EMPTY) {
+    T[j] = -(1 << 30);   // fewer than k visible rows so far: everything passes (bounded by the candidate cap)
+    return;
+  }
+  const float thr = key_dist(kth);
+  const float qn2 = qstat[j * 4 + 0], nq_ = qstat[j * 4 + 1], eq = qstat[j * 4 + 2];
+  const float e1max = scal8[0], nxhmax = scal8[1], xnmax = scal8[2], rmax = scal8[4];
+  const float s = metric == 0 ? 2.f : 1.f;
+  const float c = metric == 0 ? qn2 : (metric == 1 ? 1.f : 0.f);
+  const float Cq = qstat[j * 4 + 3] - c;
+  const float margin = s * (nq_ * e1max + eq * nxhmax);
+  // fp32 evaluation of the re-ranked keys, of R and of C (each a d-term sum of the magnitude below), and of the two divisions by u
+  const float scale = (metric == 0 ? (fabsf(thr) + qn2 + xnmax) : (fabsf(thr) + 1.f + nq_ * nxhmax)) + fabsf(Cq) + rmax;
+  const float t = (thr - c) + margin + slack * scale + 4.f * u;
+  float v = floorf((Cq - t) / u) - 2.f;
+  v = fminf(fmaxf(v, -1073741824.f), 1073741824.f);
+  T[j] = v >= 1073741824.f ? 0x7FFFFFFF : (int)v;
 }
 
 // T[j]: pass threshold in approx-key space for query j, from the current k-th best exact distance.
@@ -235,8 +465,8 @@ __global__ void threshold_kernel(const u64* run_keys, int k, int64_t nq, int64_t
 
 // seed sample: the first S/2 rows of the table plus S/2 rows spread evenly over the rest, copied next to each other (a
 // positional filter - "only the newest rows" or "only the oldest" - leaves at least half of the seeds' share visible)
-__global__ __launch_bounds__(256) void seed_sample_kernel(const _Float16* xh, const float* base_s, const float* base, unsigned long long stride,
-                                                          u32 head, int d_pad, _Float16* sxh, float* sbase, float* sbase_u) {
+__global__ __launch_bounds__(256) void seed_sample_kernel(const _Float16* xh, const u32* base_s, const u32* base, unsigned long long stride,
+                                                          u32 head, int d_pad, _Float16* sxh, u32* sbase, u32* sbase_u) {   // (base columns: raw words - fp32 or int32)
   const int64_t i = blockIdx.x;
   const int64_t r = seed_row((u32)i, head, stride);
   const half8* src = reinterpret_cast<const half8*>(xh + r * d_pad);
@@ -328,6 +558,67 @@ static int32_t ensure_mirror(Index& ix) {
   return EPS_OK;
 }
 
+static float host_ord2f(u32 o) {
+  const u32 u = (o & 0x80000000u) ? (o ^ 0x80000000u) : ~o;
+  float f;
+  std::memcpy(&f, &u, 4);
+  return f;
+}
+
+// the 8-bit mirror: grid from the table's value range on the first build, kept when rows are appended
+static int32_t ensure_mirror8(Index& ix) {
+  if (!ix.mirror_) ix.mirror_ = new HalfMirror();
+  HalfMirror& m = *ix.mirror_;
+  const int64_t n = ix.n_rows_;
+  if (m.version8 == ix.rows_version_ && m.n8 == n) return EPS_OK;
+  const bool extend = m.version8 == ix.rows_version_ && m.n8 > 0 && m.n8 < n && m.i8_ok;
+  const int64_t n_pad = (n + ROWPAD - 1) / ROWPAD * ROWPAD;
+  const int d_pad8 = std::max(512, (int)((ix.dim_ + 255) / 256 * 256));   // K-steps of 128 bytes, in pairs, at least four
+  hipStream_t s = ix.stream_;
+  const size_t keep_rows = extend ? (size_t)m.n8 : 0;
+  if (!grow_keep(m.x8, (size_t)n_pad * d_pad8, keep_rows * d_pad8, s) || !grow_keep(m.acc0, (size_t)n_pad * 4, keep_rows * 4, s) || !m.scal8.reserve(64))
+    return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory for the 8-bit mirror");
+  hipError_t er = hipSuccess;
+  if (!extend) {
+    er = hipMemsetAsync(m.scal8.p, 0, 32, s);
+    if (er == hipSuccess) er = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(m.scal8.as<u32>() + 6), (int)0xFFFFFFFFu, 1, s);
+    if (er != hipSuccess) return ix.hip_fail(er, "memset");
+    const int64_t count = n * ix.dim_;
+    hipLaunchKernelGGL(minmax_kernel, dim3((unsigned)std::min<int64_t>((count + 1023) / 1024, 4096)), dim3(256), 0, s, ix.d_rows_, count, m.scal8.as<u32>());
+    er = hipMemcpyAsync(m.h_scal8, m.scal8.p, 32, hipMemcpyDeviceToHost, s);
+    if (er == hipSuccess) er = hipStreamSynchronize(s);
+    if (er != hipSuccess) return ix.hip_fail(er, "8-bit mirror: value range");
+    u32 omin, omax;
+    std::memcpy(&omin, &m.h_scal8[6], 4);
+    std::memcpy(&omax, &m.h_scal8[7], 4);
+    const float lo = host_ord2f(omin), hi = host_ord2f(omax);
+    m.i8_ok = m.h_scal8[3] == 0.f && omin <= omax && hi > lo && std::isfinite(lo) && std::isfinite(hi) && std::isfinite(hi - lo);
+    m.z8 = m.i8_ok ? 0.5f * lo + 0.5f * hi : 0.f;
+    m.step8 = m.i8_ok ? (hi - lo) / 254.f : 1.f;
+    if (m.i8_ok && !(m.step8 > 0.f && std::isfinite(1.f / (m.step8 * m.step8)))) m.i8_ok = false;
+  }
+  if (m.i8_ok) {
+    const float u = (ix.metric_ == 0 ? 2.f : 1.f) * m.step8 * m.step8;
+    const int64_t row0 = extend ? m.n8 : 0;
+    hipLaunchKernelGGL(quant_mirror_kernel, dim3((unsigned)std::min<int64_t>((n_pad - row0 + 3) / 4, 8192)), dim3(256), 0, s, ix.d_rows_, row0, n, n_pad,
+                       (int)ix.dim_, d_pad8, m.z8, m.step8, 1.f / m.step8, 1.f / u, ix.metric_, m.x8.as<signed char>(), m.acc0.as<int>(), m.scal8.as<float>());
+    er = hipMemcpyAsync(m.h_scal8, m.scal8.p, 32, hipMemcpyDeviceToHost, s);
+    if (er == hipSuccess) er = hipStreamSynchronize(s);
+    if (er != hipSuccess) return ix.hip_fail(er, "8-bit mirror build");
+    if (m.h_scal8[3] != 0.f) m.i8_ok = false;   // a row constant beyond int32 (or a non-finite value): the fp16 engine serves this table
+    m.extended_rows8 += extend ? n - row0 : 0;
+  }
+  if (!m.i8_ok) {   // nothing of it is used: give the memory back
+    m.x8.release();
+    m.acc0.release();
+  }
+  m.n8 = n;
+  m.n_pad8 = n_pad;
+  m.d_pad8 = d_pad8;
+  m.version8 = ix.rows_version_;
+  return EPS_OK;
+}
+
 bool flat_mfma_profitable(const Index& ix, int64_t nq, int k) {
   // FLAT_AUTO: both engines return the same bits, so this is purely a cost decision (scripts/bench_midbatch.py:
   // 10M x 768: stream 5.1 / 11.3 / 43.7 ms vs filter 3.5 / 3.6 / 3.8 ms at 1 / 8 / 32 queries - the filter reads the
@@ -343,31 +634,47 @@ bool flat_mfma_profitable(const Index& ix, int64_t nq, int k) {
   return filter_s < stream_s;
 }
 
-int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u64* run_keys, bool approx, int cap_scale) {
-  int32_t rc = ensure_mirror(ix);
-  if (rc != EPS_OK) return rc;
+int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u64* run_keys, bool approx, int cap_scale, int bits) {
+  // operand width of the filter pass: 8 = int8 mirror (when the table fits its grid), 16 = fp16 mirror
+  bool i8 = bits == 8;
+  int32_t rc = EPS_OK;
+  if (i8) {
+    rc = ensure_mirror8(ix);
+    if (rc != EPS_OK) return rc;
+    if (!ix.mirror_->i8_ok) i8 = false;
+  }
+  if (!i8) {
+    rc = ensure_mirror(ix);
+    if (rc != EPS_OK) return rc;
+  }
   HalfMirror& m = *ix.mirror_;
   const int64_t n = ix.scan_limit_ >= 0 ? std::min(ix.scan_limit_, ix.n_rows_) : ix.n_rows_;
-  if (!m.fp16_range_ok) {
+  if (!i8 && !m.fp16_range_ok) {
     // values beyond the fp16 range: the filter bound would be vacuous; the exact stream engine takes over
     return ix.flat_stream(dq, nq, k, 0, n, run_keys, false, -1, !approx);
   }
   hipStream_t s = ix.stream_;
   const int64_t b_pad = (nq + BN3 - 1) / BN3 * BN3;
   const int cap = std::max(4096, 64 * k) * cap_scale;   // candidate slots per query and stage
-  if (!m.qh.reserve((size_t)b_pad * m.d_pad * 2) || !m.qstat.reserve((size_t)b_pad * 16) || !m.T.reserve((size_t)b_pad * 4) ||
-      !m.cand.reserve((size_t)nq * cap * 8) || !m.cnt.reserve((size_t)(nq + 4) * 4 + 16))
+  const int d_pad_h = i8 ? m.d_pad8 / 2 : m.d_pad;      // row pitch of the operand in 2-byte units (what the kernels count in)
+  const float u8 = (ix.metric_ == 0 ? 2.f : 1.f) * m.step8 * m.step8;   // key units per accumulator unit of the 8-bit pass
+  if (!m.qstat.reserve((size_t)b_pad * 16) || !m.T.reserve((size_t)b_pad * 4) || !m.cand.reserve((size_t)nq * cap * 8) ||
+      !m.cnt.reserve((size_t)(nq + 4) * 4 + 16) || !(i8 ? m.q8.reserve((size_t)b_pad * m.d_pad8) : m.qh.reserve((size_t)b_pad * m.d_pad * 2)))
     return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory (scratch)");
-  hipLaunchKernelGGL(query_prep_kernel, dim3((unsigned)((b_pad + 3) / 4)), dim3(256), 0, s, dq, nq, b_pad, (int)ix.dim_,
-                     m.d_pad, m.qh.as<_Float16>(), m.qstat.as<float>(), m.drop);
+  if (i8)
+    hipLaunchKernelGGL(query_prep8_kernel, dim3((unsigned)((b_pad + 3) / 4)), dim3(256), 0, s, dq, nq, b_pad, (int)ix.dim_, m.d_pad8, m.z8, m.step8,
+                       1.f / m.step8, ix.metric_, m.q8.as<signed char>(), m.qstat.as<float>());
+  else
+    hipLaunchKernelGGL(query_prep_kernel, dim3((unsigned)((b_pad + 3) / 4)), dim3(256), 0, s, dq, nq, b_pad, (int)ix.dim_,
+                       m.d_pad, m.qh.as<_Float16>(), m.qstat.as<float>(), m.drop);
+  const _Float16* q_op = i8 ? reinterpret_cast<const _Float16*>(m.q8.p) : m.qh.as<_Float16>();   // the query operand, row-major
   // kernel choice: v5 / v7 want K-steps in pairs (d_pad % 128 == 0, >= 256); other shapes stay on v3
   const char* ver_s = getenv("EPS_MFMA_KERNEL");   // 3 | 7 (A/B); v7 needs K-steps in pairs, other shapes stay on v3
-  const int version_env = ver_s && atoi(ver_s) == 3 ? 3 : 7;
-  const int version = (version_env == 7 && (m.d_pad % 128 != 0 || m.d_pad < 256)) ? 3 : version_env;
+  const int version_env = (ver_s && atoi(ver_s) == 3 && !i8) ? 3 : 7;
+  const int version = (version_env == 7 && (d_pad_h % 128 != 0 || d_pad_h < 256)) ? 3 : version_env;   // (the 8-bit mirror is padded for v7)
   if (version >= 7) {
-    if (!m.qf.reserve((size_t)b_pad * m.d_pad * 2)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory (scratch)");
-    hipLaunchKernelGGL(pack_qf_kernel, dim3((unsigned)((b_pad / 32) * (m.d_pad / 16))), dim3(64), 0, s, m.qh.as<_Float16>(),
-                       m.qf.as<_Float16>(), b_pad, m.d_pad);
+    if (!m.qf.reserve((size_t)b_pad * d_pad_h * 2)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory (scratch)");
+    hipLaunchKernelGGL(pack_qf_kernel, dim3((unsigned)((b_pad / 32) * (d_pad_h / 16))), dim3(64), 0, s, q_op, m.qf.as<_Float16>(), b_pad, d_pad_h);
   }
 
   // Staging.  Every MFMA stage needs a valid upper bound T of the final k-th best exact key; it tightens stage by stage.
@@ -416,16 +723,16 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   if (er != hipSuccess) return ix.hip_fail(er, "memset");
 
   FilterArgs fa;
-  fa.xh = m.xh.as<_Float16>();
-  fa.qh = m.qh.as<_Float16>();
+  fa.xh = i8 ? reinterpret_cast<const _Float16*>(m.x8.p) : m.xh.as<_Float16>();
+  fa.qh = q_op;
   fa.qf = m.qf.as<_Float16>();
-  fa.base = ix.metric_ == 0 ? m.xn.as<float>() : m.zeros.as<float>();
-  fa.base_s = ix.metric_ == 0 ? m.xn_s.as<float>() : m.zeros_s.as<float>();
+  fa.base = i8 ? m.acc0.as<float>() : (ix.metric_ == 0 ? m.xn.as<float>() : m.zeros.as<float>());   // (8-bit: int32 words, only ever moved)
+  fa.base_s = i8 ? m.acc0.as<float>() : (ix.metric_ == 0 ? m.xn_s.as<float>() : m.zeros_s.as<float>());
   fa.T = m.T.as<float>();
-  fa.d_pad = m.d_pad;
+  fa.d_pad = d_pad_h;
   fa.tiles_q = (int)(b_pad / BN3);
   fa.nq = nq;
-  fa.s = ix.metric_ == 0 ? -2.f : -1.f;
+  fa.s = i8 ? -u8 : (ix.metric_ == 0 ? -2.f : -1.f);
   fa.inv_s = 1.f / fa.s;
   fa.cand = m.cand.as<u32>();
   fa.cand_keys = approx ? m.cand.as<u64>() : nullptr;
@@ -461,7 +768,10 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_filter_kernel_v3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * 65536 + 2 * 256 * sizeof(float)));
     for (const void* fn : {reinterpret_cast<const void*>(mfma_filter_kernel_v7<2, FM_IDS>), reinterpret_cast<const void*>(mfma_filter_kernel_v7<2, FM_KEYS>),
                            reinterpret_cast<const void*>(mfma_filter_kernel_v7<2, FM_DENSE>), reinterpret_cast<const void*>(mfma_filter_kernel_v7<1, FM_IDS>),
-                           reinterpret_cast<const void*>(mfma_filter_kernel_v7<1, FM_KEYS>), reinterpret_cast<const void*>(mfma_filter_kernel_v7<1, FM_DENSE>)})
+                           reinterpret_cast<const void*>(mfma_filter_kernel_v7<1, FM_KEYS>), reinterpret_cast<const void*>(mfma_filter_kernel_v7<1, FM_DENSE>),
+                           reinterpret_cast<const void*>(mfma_filter_kernel_v7<2, FM_IDS, true>), reinterpret_cast<const void*>(mfma_filter_kernel_v7<2, FM_KEYS, true>),
+                           reinterpret_cast<const void*>(mfma_filter_kernel_v7<2, FM_DENSE, true>), reinterpret_cast<const void*>(mfma_filter_kernel_v7<1, FM_IDS, true>),
+                           reinterpret_cast<const void*>(mfma_filter_kernel_v7<1, FM_KEYS, true>), reinterpret_cast<const void*>(mfma_filter_kernel_v7<1, FM_DENSE, true>)})
       (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)V7_LDS_BYTES);
   }
   const int num_cus = m.num_cus;
@@ -477,16 +787,19 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
         if (f3.group_sync && f3.dense) (void)hipMemsetAsync(f3.group_sync, 0, 1024, s);   // (stages: reset by threshold_kernel)
         const int mode = f3.dense ? FM_DENSE : (f3.cand_keys ? FM_KEYS : FM_IDS);
         const dim3 grid((unsigned)num_cus), block(256);
+#define EPS_V7_LAUNCH(JQ_, I8_)                                                                                             \
+  do {                                                                                                                      \
+    if (mode == FM_DENSE) hipLaunchKernelGGL((mfma_filter_kernel_v7<JQ_, FM_DENSE, I8_>), grid, block, shm, s, f3);         \
+    else if (mode == FM_KEYS) hipLaunchKernelGGL((mfma_filter_kernel_v7<JQ_, FM_KEYS, I8_>), grid, block, shm, s, f3);      \
+    else hipLaunchKernelGGL((mfma_filter_kernel_v7<JQ_, FM_IDS, I8_>), grid, block, shm, s, f3);                            \
+  } while (0)
         if (nq <= 128 && narrow_env) {   // one 128-query tile: half the padded MFMA work, the pass streams the mirror
           f3.tiles_q = 1;
-          if (mode == FM_DENSE) hipLaunchKernelGGL((mfma_filter_kernel_v7<1, FM_DENSE>), grid, block, shm, s, f3);
-          else if (mode == FM_KEYS) hipLaunchKernelGGL((mfma_filter_kernel_v7<1, FM_KEYS>), grid, block, shm, s, f3);
-          else hipLaunchKernelGGL((mfma_filter_kernel_v7<1, FM_IDS>), grid, block, shm, s, f3);
+          if (i8) EPS_V7_LAUNCH(1, true); else EPS_V7_LAUNCH(1, false);
         } else {
-          if (mode == FM_DENSE) hipLaunchKernelGGL((mfma_filter_kernel_v7<2, FM_DENSE>), grid, block, shm, s, f3);
-          else if (mode == FM_KEYS) hipLaunchKernelGGL((mfma_filter_kernel_v7<2, FM_KEYS>), grid, block, shm, s, f3);
-          else hipLaunchKernelGGL((mfma_filter_kernel_v7<2, FM_IDS>), grid, block, shm, s, f3);
+          if (i8) EPS_V7_LAUNCH(2, true); else EPS_V7_LAUNCH(2, false);
         }
+#undef EPS_V7_LAUNCH
       }
       else hipLaunchKernelGGL(mfma_filter_kernel_v3, dim3((unsigned)num_cus), dim3(512), shm, s, f3);
     }
@@ -504,18 +817,25 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
     if (!approx) {   // exact mode: seeds from a sample spread over the whole table (approx mode keeps the head's keys)
       const u32 sample_head = (u32)(S0 / 2);
       const unsigned long long sample_stride = (unsigned long long)(((unsigned __int128)(n - sample_head) << 32) / (unsigned __int128)(S0 - sample_head));
-      if (m.sample_version != ix.rows_version_ || m.sample_n != n || m.sample_rows != S0) {   // (also after an append: n changed)
-        if (!m.sxh.reserve((size_t)S0 * m.d_pad * 2) || !m.sbase.reserve((size_t)S0 * 4) || !m.sbase_u.reserve((size_t)S0 * 4))
+      // (one sample per operand width)
+      int64_t& smp_version = i8 ? m.sample8_version : m.sample_version;
+      int64_t& smp_n = i8 ? m.sample8_n : m.sample_n;
+      int64_t& smp_rows = i8 ? m.sample8_rows : m.sample_rows;
+      DevBuf& smp_x = i8 ? m.sx8 : m.sxh;
+      DevBuf& smp_base = i8 ? m.sacc0 : m.sbase;
+      DevBuf& smp_base_u = i8 ? m.sacc0 : m.sbase_u;
+      if (smp_version != ix.rows_version_ || smp_n != n || smp_rows != S0) {   // (also after an append: n changed)
+        if (!smp_x.reserve((size_t)S0 * d_pad_h * 2) || !smp_base.reserve((size_t)S0 * 4) || !smp_base_u.reserve((size_t)S0 * 4))
           return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory (seed sample)");
-        hipLaunchKernelGGL(seed_sample_kernel, dim3((unsigned)S0), dim3(256), 0, s, m.xh.as<_Float16>(), fa.base_s, fa.base, sample_stride, sample_head, m.d_pad,
-                           m.sxh.as<_Float16>(), m.sbase.as<float>(), m.sbase_u.as<float>());
-        m.sample_version = ix.rows_version_;
-        m.sample_n = n;
-        m.sample_rows = S0;
+        hipLaunchKernelGGL(seed_sample_kernel, dim3((unsigned)S0), dim3(256), 0, s, fa.xh, reinterpret_cast<const u32*>(fa.base_s), reinterpret_cast<const u32*>(fa.base),
+                           sample_stride, sample_head, d_pad_h, smp_x.as<_Float16>(), smp_base.as<u32>(), smp_base_u.as<u32>());
+        smp_version = ix.rows_version_;
+        smp_n = n;
+        smp_rows = S0;
       }
-      f0.xh = m.sxh.as<_Float16>();
-      f0.base_s = m.sbase.as<float>();
-      f0.base = m.sbase_u.as<float>();
+      f0.xh = smp_x.as<_Float16>();
+      f0.base_s = smp_base.as<float>();
+      f0.base = smp_base_u.as<float>();
       seed_stride = sample_stride;
       seed_head = sample_head;
     }
@@ -532,12 +852,16 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   // fp32 rounding of the keys the threshold compares: |x|^2, |q|^2 and the re-ranked distance are each a 64-lane sum of
   // d_pad/64 sequential fmas per lane plus a 6-level shuffle tree, i.e. <= (d_pad/64 + 6) * 2^-24 relative to their
   // magnitude each; doubled for safety.  (A fixed 8e-6 was only enough up to d ~ 1000.)
-  const float rerank_slack = std::max(8e-6f, 2.f * (3.f * ((float)m.d_pad / 64.f + 6.f) + 2.f) * 5.9604645e-8f);
+  const float rerank_slack = std::max(8e-6f, 2.f * (3.f * ((float)((ix.dim_ + 63) / 64 * 64) / 64.f + 6.f) + 2.f) * 5.9604645e-8f);
   bool first = true;
   for (size_t st = 0; st + 1 < bounds.size(); ++st) {
     const int64_t lo = bounds[st], hi = bounds[st + 1];
-    hipLaunchKernelGGL(threshold_kernel, dim3((unsigned)((b_pad + 255) / 256)), dim3(256), 0, s, run_keys, k, nq, b_pad,
-                       m.qstat.as<float>(), m.scal.as<float>(), ix.metric_, m.T.as<float>(), cnt, m.gsync.as<u32>(), rerank_slack);
+    if (i8)
+      hipLaunchKernelGGL(threshold8_kernel, dim3((unsigned)((b_pad + 255) / 256)), dim3(256), 0, s, run_keys, k, nq, b_pad, m.qstat.as<float>(),
+                         m.scal8.as<float>(), ix.metric_, u8, m.T.as<int>(), cnt, m.gsync.as<u32>(), rerank_slack);
+    else
+      hipLaunchKernelGGL(threshold_kernel, dim3((unsigned)((b_pad + 255) / 256)), dim3(256), 0, s, run_keys, k, nq, b_pad,
+                         m.qstat.as<float>(), m.scal.as<float>(), ix.metric_, m.T.as<float>(), cnt, m.gsync.as<u32>(), rerank_slack);
     fa.tile0 = lo / bm;
     fa.ntiles = (hi + bm - 1) / bm - fa.tile0;
     fa.row_hi = hi;
@@ -546,6 +870,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
     if (biggest) {
       ix.stats_.main_kernel_rows = hi - lo;
       ix.stats_.main_kernel_queries = nq;
+      ix.stats_.main_kernel_bits = i8 ? 8 : 16;
     }
     launch_filter(fa);
     if (biggest) (void)hipEventRecord(ix.evk1_, s);
@@ -588,7 +913,8 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
       // (selective filters inflate the lists by 1 / pass fraction, adversarial row orders by more): first retry with 16 x
       // the candidate slots - re-ranking tens of thousands of rows per query is still ~50 x cheaper than the stream scan
       // of a large batch - then the exact stream engine
-      if (cap_scale == 1 && (size_t)nq * cap * 16 * 8 <= ((size_t)4 << 30)) return flat_mfma_search_slice(ix, dq, nq, k, run_keys, approx, 16);
+      if (i8) return flat_mfma_search_slice(ix, dq, nq, k, run_keys, approx, 1, 16);   // the looser 8-bit bound let too much through: fp16 pass
+      if (cap_scale == 1 && (size_t)nq * cap * 16 * 8 <= ((size_t)4 << 30)) return flat_mfma_search_slice(ix, dq, nq, k, run_keys, approx, 16, 16);
       return ix.flat_stream(dq, nq, k, 0, n, run_keys, false);
     }
   }
@@ -598,11 +924,15 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
 // Batches beyond 2048 queries run as slices of 2048: the kernel keeps one slice's fp16 query tile set (3 MB) resident in
 // each XCD's 4 MB L2 while the row operand streams past; at 4096 / 8192 queries per pass the query fragments thrash L2
 // and the filter drops to 0.37 / 0.27 of the MFMA peak (0.46 in slices; bench.py --rows 1250000 --batch 8192).
-int32_t flat_mfma_search(Index& ix, const float* dq, int64_t nq, int k, u64* run_keys, bool approx) {
+int32_t flat_mfma_search(Index& ix, const float* dq, int64_t nq, int k, u64* run_keys, bool approx, int bits) {
+  if (bits != 8 && bits != 16) {   // the library's choice: 8-bit first pass unless switched off (EPS_MFMA_BITS=16, A/B) - tables it cannot serve fall back by themselves
+    const char* e = getenv("EPS_MFMA_BITS");
+    bits = (e && atoi(e) == 16) ? 16 : 8;
+  }
   const int64_t slice = getenv("EPS_MFMA_MAX_BATCH") ? std::max(256, atoi(getenv("EPS_MFMA_MAX_BATCH"))) : 2048;
-  if (nq <= slice) return flat_mfma_search_slice(ix, dq, nq, k, run_keys, approx);
+  if (nq <= slice) return flat_mfma_search_slice(ix, dq, nq, k, run_keys, approx, 1, bits);
   for (int64_t q0 = 0; q0 < nq; q0 += slice) {   // the counters in ix.stats_ accumulate over the slices
-    const int32_t rc = flat_mfma_search_slice(ix, dq + q0 * ix.dim_, std::min(slice, nq - q0), k, run_keys + q0 * k, approx);
+    const int32_t rc = flat_mfma_search_slice(ix, dq + q0 * ix.dim_, std::min(slice, nq - q0), k, run_keys + q0 * k, approx, 1, bits);
     if (rc != EPS_OK) return rc;
   }
   return EPS_OK;

@@ -12,6 +12,8 @@ namespace eps {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 64;                        // K-step of every kernel generation
 constexpr int ROWPAD = 256;                   // mirror rows are padded to this
@@ -62,6 +64,42 @@ __device__ __forceinline__ float max16f(const f32x16& v) {
         "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]));
   return d;
 }
+
+__device__ __forceinline__ int max16i(const i32x16& v) {   // the same for the 8-bit kernel's integer accumulators
+  int d;
+  asm("v_max3_i32 %0, %1, %2, %3\n\t"
+      "v_max3_i32 %0, %0, %4, %5\n\t"
+      "v_max3_i32 %0, %0, %6, %7\n\t"
+      "v_max3_i32 %0, %0, %8, %9\n\t"
+      "v_max3_i32 %0, %0, %10, %11\n\t"
+      "v_max3_i32 %0, %0, %12, %13\n\t"
+      "v_max3_i32 %0, %0, %14, %15\n\t"
+      "v_max_i32 %0, %0, %16"
+      : "=&v"(d)
+      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]),
+        "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]));
+  return d;
+}
+
+// operand / accumulator types and the MFMA of the two operand widths of the v7 kernel.  The 8-bit form multiplies int8 rows by
+// int8 queries into int32 (v_mfma_i32_32x32x32_i8: the same 16 bytes per lane and the same 32 cycles as the fp16 instruction, twice
+// the K) - its instruction stream, LDS layout and DMA pieces are byte for byte those of the fp16 kernel, a K-step covers 128 bytes of
+// a row either way.
+template <bool I8> struct V7Op;
+template <> struct V7Op<false> {
+  typedef half8 frag;
+  typedef f32x16 accv;
+  typedef float scalar;
+  static __device__ __forceinline__ accv mfma(const frag& a, const frag& b, const accv& c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ scalar max16(const accv& v) { return max16f(v); }
+};
+template <> struct V7Op<true> {
+  typedef i32x4 frag;
+  typedef i32x16 accv;
+  typedef int scalar;
+  static __device__ __forceinline__ accv mfma(const frag& a, const frag& b, const accv& c) { return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ scalar max16(const accv& v) { return max16i(v); }
+};
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (row << 3) + (chunk ^ ((row >> 1) & 7)); }  // 16-B granule index
 
@@ -313,8 +351,15 @@ enum { FM_IDS = 0, FM_KEYS = 1, FM_DENSE = 2 };
 constexpr int V7_CAPW = 128;   // entries of a wavefront's pending-candidate list
 constexpr size_t V7_LDS_BYTES = 4 * 32768 + 2 * 256 * sizeof(float) + 4096 + 64 + 4 * V7_CAPW * (8 + 4);
 
-template <int JQ, int MODE>
+// I8 (8-bit operands): a.xh / a.qf hold int8 [..][2 * d_pad] (d_pad counts 2-byte units in both forms), a.base_s the int32 accumulator
+// start of every row, a.T the int32 pass thresholds (a row passes iff its accumulator >= T), a.s the (negative) key units per
+// accumulator unit, a.qstat[q][3] the query's constant of the approximate distance = a.s * accumulator + constant.
+template <int JQ, int MODE, bool I8 = false>
 __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
+  typedef V7Op<I8> OP;
+  typedef typename OP::frag frag_t;
+  typedef typename OP::accv acc_t;
+  typedef typename OP::scalar thr_t;
   constexpr int QT = 128 * JQ;   // queries per tile
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int ASLOT = 32768;  // 256 rows x 128 B
@@ -380,9 +425,9 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
     asm volatile("global_load_lds_dwordx4 %0, %1" : : "v"(g_off0), "s"(sb) : "memory");
   };
 
-  f32x16 acc[8][JQ];
-  half8 fb[2][4][JQ];
-  half8 fa[2][8];
+  acc_t acc[8][JQ];
+  frag_t fb[2][4][JQ];
+  frag_t fa[2][8];
   int64_t qj[JQ];
   // Tq = T/s: a row passes iff acc >= Tq (s < 0); cj: approx-mode constant of the query.  Per-lane constants of the
   // query tile: parked in LDS and read back at each epilogue - as registers they would be live across the K loop, get
@@ -391,8 +436,8 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
 #pragma unroll
   for (int j = 0; j < JQ; ++j) {
     qj[j] = (int64_t)qslot * QT + wave * (32 * JQ) + j * 32 + l31;
-    tq_lds[j * 64 + lane] = a.T[qj[j]] * a.inv_s;
-    tq_lds[(2 + j) * 64 + lane] = MODE != FM_IDS ? (a.metric == 0 ? a.qstat[qj[j] * 4] : (a.metric == 1 ? 1.f : 0.f)) : 0.f;
+    tq_lds[j * 64 + lane] = I8 ? a.T[qj[j]] : a.T[qj[j]] * a.inv_s;   // (I8: int32 bits, moved as they are)
+    tq_lds[(2 + j) * 64 + lane] = MODE != FM_IDS ? (I8 ? a.qstat[qj[j] * 4 + 3] : (a.metric == 0 ? a.qstat[qj[j] * 4] : (a.metric == 1 ? 1.f : 0.f))) : 0.f;
   }
   // Everything derived from the lane id that the K loop keeps in registers is RE-DERIVED at the top of every tile from
   // v_mbcnt (a dozen VALU instructions): values that live across the tile loop get spilled around the epilogue's
@@ -515,9 +560,9 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
         asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         if (JQ == 2 && first && kk == 0) {   // D != C: the second block's accumulator is born from the first block's initial value
-          acc[i][JQ - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][i], fb[rb][kk][JQ - 1], acc[i][0], 0, 0, 0);
+          acc[i][JQ - 1] = OP::mfma(fa[cur][i], fb[rb][kk][JQ - 1], acc[i][0]);
         } else {
-          acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][i], fb[rb][kk][0], acc[i][0], 0, 0, 0);
+          acc[i][0] = OP::mfma(fa[cur][i], fb[rb][kk][0], acc[i][0]);
         }
         __builtin_amdgcn_sched_barrier(0);
         {
@@ -559,8 +604,8 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);
         if (JQ == 2) {
-          if (first && kk == 0) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][i], fb[rb][kk][0], acc[i][0], 0, 0, 0);
-          else acc[i][JQ - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][i], fb[rb][kk][JQ - 1], acc[i][JQ - 1], 0, 0, 0);
+          if (first && kk == 0) acc[i][0] = OP::mfma(fa[cur][i], fb[rb][kk][0], acc[i][0]);
+          else acc[i][JQ - 1] = OP::mfma(fa[cur][i], fb[rb][kk][JQ - 1], acc[i][JQ - 1]);
         }
         __builtin_amdgcn_sched_barrier(0);
         // (all loads of the loop stay in straight-line code: around a branch hipcc gives an asm load's destination a fresh
@@ -611,13 +656,13 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
 #pragma unroll
       for (int j = 0; j < JQ; ++j) {
         const int64_t qjt = (int64_t)tile_qt(qi_c) * QT + wave * (32 * JQ) + j * 32 + ((lane16 >> 4) & 31);
-        tq_lds[j * 64 + (lane16 >> 4)] = a.T[qjt] * a.inv_s;
+        tq_lds[j * 64 + (lane16 >> 4)] = I8 ? a.T[qjt] : a.T[qjt] * a.inv_s;
         float cm;   // (materialised here from a scalar: as an ordinary value hipcc keeps it in a VGPR across the tile loop and spills it)
         {
           const int sv = a.metric == 1 ? 0x3f800000 : 0;   // 1.0f : 0.0f
           asm volatile("v_mov_b32 %0, %1" : "=v"(cm) : "s"(sv));
         }
-        tq_lds[(2 + j) * 64 + (lane16 >> 4)] = MODE != FM_IDS ? (a.metric == 0 ? a.qstat[qjt * 4] : cm) : 0.f;
+        tq_lds[(2 + j) * 64 + (lane16 >> 4)] = MODE != FM_IDS ? (I8 ? a.qstat[qjt * 4 + 3] : (a.metric == 0 ? a.qstat[qjt * 4] : cm)) : 0.f;
       }
     }
     if (t + 1 < ntile) issue_base(ri_n, (int)((t + 1) & 1));
@@ -630,11 +675,19 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
         const int rbase = i * 32 + kh4;
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
-          const float4 bv = *reinterpret_cast<const float4*>(&bl0[rbase + 8 * gq]);
-          acc[i][0][4 * gq + 0] = bv.x;
-          acc[i][0][4 * gq + 1] = bv.y;
-          acc[i][0][4 * gq + 2] = bv.z;
-          acc[i][0][4 * gq + 3] = bv.w;
+          if (I8) {
+            const int4 bv = *reinterpret_cast<const int4*>(&bl0[rbase + 8 * gq]);
+            acc[i][0][4 * gq + 0] = bv.x;
+            acc[i][0][4 * gq + 1] = bv.y;
+            acc[i][0][4 * gq + 2] = bv.z;
+            acc[i][0][4 * gq + 3] = bv.w;
+          } else {
+            const float4 bv = *reinterpret_cast<const float4*>(&bl0[rbase + 8 * gq]);
+            acc[i][0][4 * gq + 0] = bv.x;
+            acc[i][0][4 * gq + 1] = bv.y;
+            acc[i][0][4 * gq + 2] = bv.z;
+            acc[i][0][4 * gq + 3] = bv.w;
+          }
         }
         __builtin_amdgcn_sched_barrier(0);   // one row block at a time: hoisting all 64 reads costs spills
       }
@@ -663,10 +716,11 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
     u32 lne;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lne));
     const int l31e = (int)(lne & 31), kh4e = (int)(lne >> 5) * 4;
-    float Tq[JQ], cj[JQ];
+    thr_t Tq[JQ];
+    float cj[JQ];
 #pragma unroll
     for (int j = 0; j < JQ; ++j) {
-      Tq[j] = tq_lds[j * 64 + lne];
+      Tq[j] = __builtin_bit_cast(thr_t, tq_lds[j * 64 + lne]);
       cj[j] = MODE == FM_DENSE ? tq_lds[(2 + j) * 64 + lne] : 0.f;   // (FM_KEYS reads it where a row passes: one live register less)
     }
 #pragma unroll
@@ -681,7 +735,7 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int64_t row = row0 + rbase + (r & 3) + 8 * (r >> 2);
-              float dapx = acc[i][j][r] * a.s + cj[j];
+              float dapx = (float)acc[i][j][r] * a.s + cj[j];
               const bool nan = dapx != dapx;
               if (a.metric == 0) dapx = fmaxf(dapx, 0.f);
               if (row < a.row_hi)
@@ -692,7 +746,7 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
           continue;
         }
         // the block's running max: 8 x v_max3_f32 (fmaxf chains cost 10: hipcc canonicalises the first two operands)
-        const float mx = max16f(acc[i][j]);
+        const thr_t mx = OP::max16(acc[i][j]);
         if (__any(mx >= Tq[j])) {
           // (rare) everything the hit path needs is derived behind this opaque copy of the lane id, or hipcc hoists the
           // address arithmetic of all 16 blocks into the common path
@@ -706,7 +760,7 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
               if (row < a.row_hi && qq < a.nq) {
                 float dapx = 0.f;
                 if (MODE == FM_KEYS) {
-                  dapx = acc[i][j][r] * a.s + tq_lds[(2 + j) * 64 + lne];
+                  dapx = (float)acc[i][j][r] * a.s + tq_lds[(2 + j) * 64 + lne];
                   if (a.metric == 0) dapx = fmaxf(dapx, 0.f);
                 }
                 const u32 e = atomicAdd(wcnt, 1u);   // LDS: no VMEM counter involved

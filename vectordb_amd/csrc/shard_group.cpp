@@ -227,6 +227,7 @@ class ShardGroup : public IndexBase {
       t.main_kernel_launches += s.main_kernel_launches;
       t.main_kernel_rows += s.main_kernel_rows;
       t.main_kernel_queries = std::max(t.main_kernel_queries, s.main_kernel_queries);
+      t.main_kernel_bits = std::max(t.main_kernel_bits, s.main_kernel_bits);
     }
     *out = t;
     return EPS_OK;

@@ -347,6 +347,7 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
     }
 #undef EPS_TRV_LAUNCH
     ix.stats_.main_kernel_launches += 1;
+    ix.stats_.main_kernel_bits = 32;
     if (q0 + cnt >= nq) (void)hipEventRecord(ix.evk1_, s);   // (with several slices the pair spans all traversal launches and the post kernels between them)
     pa.tail = tail ? tail + q0 * tail_k : nullptr;
     pa.run_keys = run_keys + q0 * k;

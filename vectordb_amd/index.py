@@ -17,7 +17,7 @@ import numpy as np
 
 from . import _lib as lib
 from ._lib import (EpsillaError, SearchParams, BuildParams, SearchStats, MODE_REFERENCE, MODE_FLAT, MODE_GRAPH,
-                   FLAT_AUTO, FLAT_STREAM, FLAT_MFMA, METRIC_EUCLIDEAN, METRIC_COSINE, METRIC_DOT_PRODUCT, OPS)
+                   FLAT_AUTO, FLAT_STREAM, FLAT_MFMA, FLAT_MFMA_I8, METRIC_EUCLIDEAN, METRIC_COSINE, METRIC_DOT_PRODUCT, OPS)
 
 METRICS = {"EUCLIDEAN": 0, "COSINE": 1, "DOT_PRODUCT": 2, "L2": 0, "IP": 2, 0: 0, 1: 1, 2: 2}
 BruteforceThreshold = 512  # vec_search_executor.hpp:28
