@@ -91,7 +91,7 @@ def test_i8_engine_on_other_distributions(amd, kind):
     st = ix.stats()
     b = ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
     same(a, b, kind)
-    if kind in ("gauss", "signed_ip", "tiny"):
+    if kind in ("gauss", "tiny"):
         assert st["main_kernel_bits"] == 8 and st["overflow_queries"] == 0, st
     auto = ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_AUTO)
     same(auto, b, kind + " (auto)")
