@@ -313,8 +313,10 @@ Status VecSearchExecutor::Search(const VectorPtr query_data, vectordb::engine::T
   if (eps_index_set_int_filter(dev.h, nullptr, 0, 0, EPS_OP_NONE, 0) != EPS_OK) return fail("filter reset");
   if (!program.empty()) {
     // the attribute rows are handed over as they are: TableSegmentMVP::attribute_table_, primitive_offset_ bytes per row
-    if (eps_index_set_filter_program(dev.h, program.data(), (int32_t)program.size(), table_segment->attribute_table_,
-                                     table_segment->primitive_offset_, total_vector) != EPS_OK)
+    // (append-only: an update of the reference's table is delete + insert, table_segment_mvp.cpp:476-587; the device mirror is per
+    // table segment, so a dropped-and-recreated table never meets a cached copy)
+    if (eps_index_set_filter_program_ex(dev.h, program.data(), (int32_t)program.size(), table_segment->attribute_table_,
+                                        table_segment->primitive_offset_, total_vector, EPS_FILTER_ROWS_APPEND_ONLY) != EPS_OK)
       return fail("filter program upload");
   } else if (eps_index_set_filter_program(dev.h, nullptr, 0, nullptr, 0, 0) != EPS_OK) {
     return fail("filter reset");
@@ -352,8 +354,8 @@ Status VecSearchExecutor::Search(const VectorPtr query_data, vectordb::engine::T
     // graph -> min(n_indexed, limit, L_local) (:872)
     size_t want = limit;
     if (!prefilter_enabled_) want = std::min<size_t>(want, (size_t)std::max<int64_t>(L_local_, 1));
-    if (flat && want > 1024)
-      throw std::runtime_error("gfx950 executor: more than 1024 results per query from a brute-force search (PreFilter / tables below 512 indexed rows) are not supported");
+    want = std::min<size_t>(want, (size_t)std::max<int64_t>(total_vector, 1));   // (never more results than rows)
+    if (want > ((size_t)1 << 20)) throw std::runtime_error("gfx950 executor: more than 1048576 results per query are not supported");
     const int32_t k = (int32_t)want;
     std::vector<int64_t> ids((size_t)k);
     std::vector<float> dist((size_t)k);
@@ -428,8 +430,7 @@ Status VecSearchExecutor::Search(const VectorPtr query_data, vectordb::engine::T
     }
     if (cap >= 1024) break;
   }
-  if (want > 1024)
-    throw std::runtime_error("gfx950 executor: more than 1024 results per query from a brute-force search are not supported");
+  if (want > ((size_t)1 << 20)) throw std::runtime_error("gfx950 executor: more than 1048576 results per query are not supported");
   // selective host-only filter: visibility of every row, evaluated on the host - the reference's own cost for every
   // brute-force query (:746-755); @distance, if the filter reads it, comes from the host distance function as there
   bool uses_distance = false;
@@ -488,8 +489,8 @@ void RunBatch(DeviceField& dev, int64_t dim, std::vector<Pending*>& batch) {
   if (err.empty() && eps_index_set_int_filter(dev.h, nullptr, 0, 0, EPS_OP_NONE, 0) != EPS_OK) fail("filter reset");
   if (err.empty()) {
     const int32_t rc = h.program.empty() ? eps_index_set_filter_program(dev.h, nullptr, 0, nullptr, 0, 0)
-                                         : eps_index_set_filter_program(dev.h, h.program.data(), (int32_t)h.program.size(), h.segment->attribute_table_,
-                                                                        h.segment->primitive_offset_, total_vector);
+                                         : eps_index_set_filter_program_ex(dev.h, h.program.data(), (int32_t)h.program.size(), h.segment->attribute_table_,
+                                                                           h.segment->primitive_offset_, total_vector, EPS_FILTER_ROWS_APPEND_ONLY);
     if (rc != EPS_OK) fail("filter program upload");
   }
   if (err.empty() && eps_index_set_deleted(dev.h, deleted.data(), (int64_t)deleted.size()) != EPS_OK) fail("deleted upload");
@@ -535,8 +536,8 @@ Status VecSearchExecutor::SearchBatched(const float* query, vectordb::engine::Ta
     // same result-count rules as the unbatched path above
     size_t want = limit;
     if (!prefilter_enabled_) want = std::min<size_t>(want, (size_t)std::max<int64_t>(L_local_, 1));
-    if ((prefilter_enabled_ || brute_force_search_) && want > 1024)
-      throw std::runtime_error("gfx950 executor: more than 1024 results per query from a brute-force search (PreFilter / tables below 512 indexed rows) are not supported");
+    want = std::min<size_t>(want, (size_t)std::max<int64_t>(table_segment->record_number_, 1));
+    if (want > ((size_t)1 << 20)) throw std::runtime_error("gfx950 executor: more than 1048576 results per query are not supported");
     me.k = (int32_t)want;
   }
   me.graph_owner = ann_index_.get();

@@ -217,10 +217,16 @@ int32_t eps_index_set_int_filter(eps_index* h, const void* column, int64_t strid
 /* compiled filter program (see eps_filter_op): `rows` = packed attribute rows (host or device), row i at rows + i*stride_bytes,
  * n_rows of them.  Replaces eps_index_set_int_filter's filter; nops = 0 clears.  A row is visible iff it is not deleted
  * and the program leaves a non-zero value.  Programs are limited to 64 instructions and a stack depth of 16.  Host rows
- * are treated as append-only (as TableSegmentMVP::attribute_table_ is): a later call with the same `rows` pointer and
- * stride uploads only the rows beyond those already handed over. */
+ * are copied to the device, all of them, on every call. */
 int32_t eps_index_set_filter_program(eps_index* h, const eps_filter_op* ops, int32_t nops, const void* rows, int64_t stride_bytes,
                                      int64_t n_rows);
+/* The same with flags.  EPS_FILTER_ROWS_APPEND_ONLY: the caller promises that the host rows it handed over before FROM THIS
+ * POINTER (same stride, same table attached) have not changed since - TableSegmentMVP::attribute_table_ is such a table: an
+ * update is delete + insert (db/table_segment_mvp.cpp:476-587) - so only the rows beyond those already on the device are
+ * uploaded.  Re-attaching rows (eps_index_attach_rows) forgets the cached copy. */
+#define EPS_FILTER_ROWS_APPEND_ONLY 1
+int32_t eps_index_set_filter_program_ex(eps_index* h, const eps_filter_op* ops, int32_t nops, const void* rows, int64_t stride_bytes,
+                                        int64_t n_rows, int32_t flags);
 
 /* graph over rows [0,n): built on the device, or supplied / exported as the reference's CSR */
 int32_t eps_index_build(eps_index* h, int64_t n, const eps_build_params* p);

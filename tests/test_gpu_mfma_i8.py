@@ -170,10 +170,11 @@ def test_i8_engine_adversarial_order_and_selective_filter(amd):
 
 
 def test_i8_mirror_is_extended_by_appended_rows(amd):
-    """Appended rows are quantised on the grid the table already has (values beyond it are clamped; their residual grows, the
-    bound stays valid) - the mirror is not rebuilt, and the answer over old + new rows equals the scan's."""
+    """Appended rows are quantised on the grid the table already has - the mirror is extended, not rebuilt - and the answer over
+    old + new rows equals the scan's.  Rows beyond the grid are clamped: their residual enters the (per-index) bound, which may
+    then be too loose for the 8-bit pass to pay (the fp16 pass takes over); the answer does not change."""
     n0, n1, d, nq = 80_000, 30_000, 256, 128
-    X0, X1, Q = data(n0, d, 1), data(n1, d, 2) * 1.2 - 0.1, data(nq, d, 3)
+    X0, X1, Q = data(n0, d, 1), data(n1, d, 2) * 0.98 + 0.01, data(nq, d, 3)
     ix = amd.GpuIndex(d, 0)
     ix.attach_rows(X0)
     ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
@@ -183,6 +184,10 @@ def test_i8_mirror_is_extended_by_appended_rows(amd):
     b = ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
     same(a, b, "after append")
     assert (a[0] >= n0).any()                              # some of the new rows are among the answers
+    X2 = data(5_000, d, 4) * 1.5 - 0.25                    # far outside [0, 1): clamped on the grid
+    ix.append_rows(X2)
+    a = ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
+    same(a, ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM), "after an out-of-grid append")
     ix.close()
 
 

@@ -57,6 +57,35 @@ def test_flat_batch_sizes_and_large_k(amd, oracle, nq):
     ix.close()
 
 
+@pytest.mark.parametrize("k", [1025, 3000])
+def test_flat_more_than_1024_results_per_query(amd, oracle, k):
+    """BruteForceSearch has no result cap (it sorts all n candidates, vec_search_executor.cpp:756-767; DBServer passes the
+    caller's `limit` through).  Beyond 1024 results the stream scan pages: page p = the best keys ordered after page p-1's
+    last.  Every engine request ends there; with deleted rows and a filter; k > n returns the n visible rows."""
+    n, d = 5000, 24
+    X, Q = data(n, d, 61), data(3, d, 62)
+    bits = bitset(n, range(0, n, 7))
+    idc = np.arange(n, dtype=np.int64)
+    ix = amd.GpuIndex(d, 0)
+    ix.attach_rows(X)
+    for eng in (amd.FLAT_AUTO, amd.FLAT_STREAM, amd.FLAT_MFMA, amd.FLAT_MFMA_I8):
+        ids, dist, cnt = ix.search(Q, k, mode=amd.MODE_FLAT, flat_engine=eng)
+        for qi in range(len(Q)):
+            rid, rd = oracle.topk_flat(0, X, Q[qi], k)
+            assert int(cnt[qi]) == k
+            assert_topk_match(ids[qi], dist[qi], rid, rd, what="k%d q%d" % (k, qi))
+    ix.set_deleted(bits)
+    ix.set_int_filter(idc, "<", 4000)
+    flt, keep = make_filter(deleted=bits, attr=idc, stride=8, width=8, op="<", value=4000)
+    ids, dist, cnt = ix.search(Q, 4000, mode=amd.MODE_FLAT)
+    for qi in range(len(Q)):
+        rid, rd = oracle.topk_flat(0, X, Q[qi], 4000, flt=flt)
+        assert int(cnt[qi]) == len(rid) < 4000
+        assert_topk_match(ids[qi][:len(rid)], dist[qi][:len(rid)], rid, rd, what="filtered q%d" % qi)
+        assert (ids[qi][len(rid):] == -1).all()
+    ix.close()
+
+
 def test_flat_deleted_and_filter(amd, oracle):
     n, d = 3000, 48
     X, Q = data(n, d, 3), data(6, d, 4)

@@ -33,7 +33,7 @@ def _close_evals(ev_gpu, ev_or, what=""):
 
 
 @pytest.mark.parametrize("T,L,I", [(2, 500, 15), (4, 500, 15), (4, 100, 15), (4, 500, 1), (4, 500, 3), (8, 300, 15), (3, 64, 2),
-                                   (16, 500, 15), (1, 500, 1), (1, 100, 4)])
+                                   (16, 500, 15), (1, 500, 1), (1, 100, 4), (17, 500, 15), (24, 300, 4), (32, 500, 15)])
 def test_lockstep_workers_match_oracle(amd, oracle, T, L, I):
     """IntraQueryThreads = T workers with local queues, PickTopMToWorkers, GlobalSyncInterval = I and
     MergeAllQueuesToMaster: the device result equals the oracle's SearchImpl under the lockstep interleaving - the whole
@@ -55,6 +55,45 @@ def test_lockstep_workers_match_oracle(amd, oracle, T, L, I):
         assert_topk_match(ids[qi], dist[qi], oid[:k], od[:k], what="T%d L%d I%d q%d" % (T, L, I, qi))
     _close_evals(ev_gpu, ev_or, "T%d L%d I%d" % (T, L, I))
     ix.close()
+
+
+def test_reference_parameter_ranges_run_or_are_refused(amd, oracle):
+    """The reference accepts IntraQueryThreads up to 128 and SearchQueueSize up to 10^7 (config/config.hpp:28-44).  The device
+    runs what it can (T x longest adjacency list <= 2048 edge slots per step: T <= 32 at the build's out-degree cap) and REFUSES
+    the rest with EPS_DB_UNSUPPORTED_ERROR - it never runs another configuration than the one asked for (r2 clamped T to 16)."""
+    z, off, nbr, nav = _golden_graph()
+    X, Q = data(2000, 32, 42), data(4, 32, 49)
+    ix = amd.GpuIndex(32, 0)
+    ix.attach_rows(X)
+    ix.set_graph(off, nbr, nav)
+    maxdeg = int(np.max(np.diff(off)))
+    dp = (maxdeg + 7) // 8 * 8
+    t_ok = min(128, 2048 // dp)
+    ids, dist, cnt = ix.search(Q, 10, mode=amd.MODE_GRAPH, intra_threads=t_ok, master_queue=500, local_queue=500)
+    init = oracle.prepare_init_ids(off, nbr, nav, 500)
+    for qi, q in enumerate(Q):
+        oid, od, _ = oracle.search_impl(0, X, off, nbr, init, q, T=t_ok, L=500, lockstep=True)
+        assert_topk_match(ids[qi], dist[qi], oid[:10], od[:10], what="T%d q%d" % (t_ok, qi))
+    for bad in ({"intra_threads": 129}, {"intra_threads": 2048 // dp + 1} if 2048 // dp < 128 else {"intra_threads": 200}):
+        with pytest.raises(amd.EpsillaError) as e:
+            ix.search(Q, 10, mode=amd.MODE_GRAPH, master_queue=500, local_queue=500, **bad)
+        assert e.value.code == 50002, (bad, e.value)
+        assert "IntraQueryThreads" in str(e.value)
+    ix.close()
+    # queue sizes beyond 2^20 (only reachable on tables that large): refused by name, not clamped
+    n = (1 << 20) + 4096
+    Xb = np.zeros((n, 4), np.float32)
+    Xb[:, 0] = np.arange(n, dtype=np.float32)
+    offb = np.arange(n + 1, dtype=np.int64)
+    nbrb = ((np.arange(n, dtype=np.int64) + 1) % n)
+    ixb = amd.GpuIndex(4, 0)
+    ixb.attach_rows(Xb)
+    ixb.set_graph(offb, nbrb, 0)
+    for kw, name in (({"master_queue": n, "local_queue": 500}, "SearchQueueSize"), ({"master_queue": 500, "local_queue": n}, "LocalQueueSize")):
+        with pytest.raises(amd.EpsillaError) as e:
+            ixb.search(Xb[:1], 10, mode=amd.MODE_GRAPH, intra_threads=2, **kw)
+        assert e.value.code == 50002 and name in str(e.value), e.value
+    ixb.close()
 
 
 def test_local_queue_smaller_than_master(amd, oracle):

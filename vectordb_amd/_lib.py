@@ -17,13 +17,14 @@ EPS_NOT_IMPLEMENTED_ERROR = 50009
 METRIC_EUCLIDEAN, METRIC_COSINE, METRIC_DOT_PRODUCT = 0, 1, 2
 MODE_REFERENCE, MODE_FLAT, MODE_GRAPH = 0, 1, 2
 FLAT_AUTO, FLAT_STREAM, FLAT_MFMA, FLAT_MFMA_I8 = 0, 1, 2, 3
+FILTER_ROWS_APPEND_ONLY = 1
 OPS = {None: 0, "": 0, "<": 1, "<=": 2, "==": 3, "=": 3, ">=": 4, ">": 5, "!=": 6, "<>": 6}
 
 EXPORTS = [
     "eps_default_search_params", "eps_default_build_params", "eps_index_create", "eps_index_create_sharded", "eps_index_destroy",
     "eps_index_last_error", "eps_index_set_stream", "eps_index_synchronize", "eps_index_attach_rows",
     "eps_index_append_rows", "eps_index_row_count", "eps_index_load_table", "eps_index_set_id_map", "eps_index_set_deleted",
-    "eps_index_set_int_filter", "eps_index_set_filter_program", "eps_index_search_walk", "eps_index_select_edges", "eps_index_inter_insert", "eps_index_build", "eps_index_set_graph", "eps_index_graph_info",
+    "eps_index_set_int_filter", "eps_index_set_filter_program", "eps_index_set_filter_program_ex", "eps_index_search_walk", "eps_index_select_edges", "eps_index_inter_insert", "eps_index_build", "eps_index_set_graph", "eps_index_graph_info",
     "eps_index_get_graph", "eps_index_save_graph", "eps_index_load_graph", "eps_index_search",
     "eps_index_last_stats", "eps_index_kernel_times", "eps_normalize_rows", "eps_merge_topk", "eps_merge_topk_packed",
 ]
@@ -105,6 +106,7 @@ def load():
     L.eps_index_set_deleted.argtypes = [vp, vp, i64]
     L.eps_index_set_int_filter.argtypes = [vp, vp, i64, i32, i32, i64]
     L.eps_index_set_filter_program.argtypes = [vp, C.POINTER(FilterOp), i32, vp, i64, i64]
+    L.eps_index_set_filter_program_ex.argtypes = [vp, C.POINTER(FilterOp), i32, vp, i64, i64, i32]
     L.eps_index_search_walk.argtypes = [vp, vp, i64, i32, i32, C.POINTER(SearchParams), vp, vp, vp]
     L.eps_index_select_edges.argtypes = [vp, vp, i64, vp, i32, i32, i32, vp, vp]
     L.eps_index_inter_insert.argtypes = [vp, vp, vp, i64, i32, vp, vp]

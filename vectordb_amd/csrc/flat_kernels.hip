@@ -55,12 +55,13 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(FlatScanArgs a) {
   const int64_t end = begin + chunk < a.row_end ? begin + chunk : a.row_end;
 
   WaveTopK<KPL> list[NQ];
-  u64 thr[NQ];
+  u64 thr[NQ], lo[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     list[q].init();
     const int64_t qq = (q0 + q < a.nq) ? q0 + q : a.nq - 1;
     thr[q] = a.thr_in ? a.thr_in[qq] : KEY_EMPTY;
+    lo[q] = a.lo_in ? a.lo_in[qq * a.lo_stride] : 0;   // result pages beyond the first: only keys ordered after the previous page's last
   }
 
   for (int64_t r0 = begin; r0 < end; r0 += RPW * U) {
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(FlatScanArgs a) {
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         const u64 key = make_key(finish_dist(a.metric, acc[u][q]), (u32)row[u]);
-        offer<NQ, KPL>(list, thr, q, key, valid, a.f, a.k, false);
+        offer<NQ, KPL>(list, thr, q, key, valid && (!a.lo_in || key > lo[q]), a.f, a.k, false);
       }
     }
   }

@@ -141,6 +141,8 @@ int32_t Index::attach_rows_strided(const float* rows, int64_t n, int64_t pitch) 
   }
   n_rows_ = n;
   ++rows_version_;
+  prog_rows_host_ = nullptr;   // a new table: attribute rows cached from the previous one are not its rows, whatever their address
+  prog_rows_uploaded_ = 0;
   // state that was sized for the previous table does not carry over: a graph over more rows than are attached now, a
   // deleted bitset or an attribute column of the old length
   if (n_indexed_ > n) {
@@ -227,8 +229,10 @@ int32_t Index::load_table(const char* path, const eps_table_layout* lay, int64_t
   (void)first_id;
   if (n64 >= ((uint64_t)1 << 31) || bitset_size < 0 || !need((size_t)bitset_size)) return corrupt();
   const int64_t n = (int64_t)n64;
+  if (bitset_size < (n + 7) / 8) return corrupt();   // the reference writes the whole ConcurrentBitset (capacity bits >= record count)
   const uint8_t* bits = reinterpret_cast<const uint8_t*>(base + pos);
   pos += (size_t)bitset_size;
+  if ((uint64_t)lay->primitive_offset > fsize || (n > 0 && (uint64_t)lay->primitive_offset > (uint64_t)fsize / (uint64_t)n)) return corrupt();   // (n * offset cannot wrap)
   const size_t attr_bytes = (size_t)n * (size_t)lay->primitive_offset;
   if (!need(attr_bytes)) return corrupt();
   const char* attrs = base + pos;
@@ -253,10 +257,8 @@ int32_t Index::load_table(const char* path, const eps_table_layout* lay, int64_t
   if (!need(8)) return corrupt();            // trailing WAL id
   int32_t rc = attach_rows(field_rows, n);   // the mapped pages go to HBM directly; no host copy of the table is made
   if (rc != EPS_OK) return rc;
-  if (bitset_size >= (n + 7) / 8 && n > 0) {
-    rc = set_deleted(bits, bitset_size);
-    if (rc != EPS_OK) return rc;
-  }
+  rc = n > 0 ? set_deleted(bits, bitset_size) : set_deleted(nullptr, 0);   // (never a bitset left over from a previous table)
+  if (rc != EPS_OK) return rc;
   if (attr_bytes > 0) {   // keep the attribute rows on the device for a later filter program
     HIP_TRY(hipStreamSynchronize(stream_));
     if (!prog_rows_buf_.reserve(attr_bytes)) return fail(EPS_INFRA_UNEXPECTED_ERROR, "load_table: out of device memory (attribute rows)");
@@ -344,7 +346,14 @@ int32_t Index::set_int_filter(const void* column, int64_t stride, int32_t width,
   return EPS_OK;
 }
 
-int32_t Index::set_filter_program(const eps_filter_op* ops, int32_t nops, const void* rows, int64_t stride, int64_t n_rows) {
+int32_t Index::set_filter_program(const eps_filter_op* ops, int32_t nops, const void* rows, int64_t stride, int64_t n_rows, int32_t flags) {
+  return set_filter_program_pitched(ops, nops, rows, stride, stride, n_rows, flags);
+}
+
+// rows: row i at rows + i * src_pitch, row_bytes (<= src_pitch) of it are the attribute row.  A hash-sharded table hands every
+// shard the same memory with src_pitch = shards * row_bytes: only the shard's own rows are uploaded, packed at row_bytes.
+int32_t Index::set_filter_program_pitched(const eps_filter_op* ops, int32_t nops, const void* rows, int64_t src_pitch, int64_t row_bytes, int64_t n_rows,
+                                          int32_t flags) {
   HIP_TRY(hipSetDevice(device_));
   if (nops <= 0 || !ops) {
     prog_len_ = 0;
@@ -354,11 +363,13 @@ int32_t Index::set_filter_program(const eps_filter_op* ops, int32_t nops, const 
   }
   if (nops > 64) return fail(EPS_DB_UNSUPPORTED_ERROR, "set_filter_program: more than 64 instructions");
   const bool use_loaded = !rows && loaded_attr_rows_ > 0 && loaded_attr_rows_ >= n_rows_;   // the rows eps_index_load_table kept
+  int64_t stride = row_bytes;   // of the device copy
   if (use_loaded) {
     stride = loaded_attr_stride_;
     n_rows = loaded_attr_rows_;
   }
-  if ((!rows && !use_loaded) || stride <= 0 || n_rows < n_rows_) return fail(EPS_USER_ERROR, "set_filter_program: attribute rows missing or shorter than the table");
+  if ((!rows && !use_loaded) || stride <= 0 || n_rows < n_rows_ || (!use_loaded && src_pitch < row_bytes))
+    return fail(EPS_USER_ERROR, "set_filter_program: attribute rows missing or shorter than the table");
   // validate: known opcodes, attribute loads inside a row, stack discipline
   int sp = 0, maxsp = 0;
   bool uses_dist = false;
@@ -388,15 +399,20 @@ int32_t Index::set_filter_program(const eps_filter_op* ops, int32_t nops, const 
     d_prog_rows_ = prog_rows_buf_.as<uint8_t>();
   } else if (is_device_ptr(rows)) {
     d_prog_rows_ = static_cast<const uint8_t*>(rows);
+    stride = src_pitch;   // used in place
     prog_rows_host_ = nullptr;
     loaded_attr_rows_ = 0;
   } else {
     loaded_attr_rows_ = 0;
-    // Host attribute rows are append-only in the reference (an update is delete + insert, table_segment_mvp.cpp:476-587), so
-    // rows handed over earlier from the same table are kept and only the new tail crosses PCIe.
+    // Default: the whole table is uploaded (the caller may have edited it in place, or another table may live at the same address).
+    // EPS_FILTER_ROWS_APPEND_ONLY is the caller's promise that rows handed over earlier FROM THIS POINTER are unchanged - true for
+    // the reference's attribute table, where an update is delete + insert (table_segment_mvp.cpp:476-587) - then only the new
+    // tail crosses PCIe.
     const size_t bytes = (size_t)n_rows * (size_t)stride;
-    const bool same = prog_rows_host_ == rows && prog_rows_stride_ == stride && prog_rows_uploaded_ <= n_rows && prog_rows_buf_.p;
-    size_t have = same ? (size_t)prog_rows_uploaded_ * (size_t)stride : 0;
+    const bool same = (flags & EPS_FILTER_ROWS_APPEND_ONLY) && prog_rows_host_ == rows && prog_rows_stride_ == stride && prog_rows_pitch_ == src_pitch &&
+                      prog_rows_uploaded_ <= n_rows && prog_rows_buf_.p;
+    const int64_t have_rows = same ? prog_rows_uploaded_ : 0;
+    const size_t have = (size_t)have_rows * (size_t)stride;
     if (bytes > prog_rows_buf_.cap) {
       DevBuf bigger;
       if (!bigger.reserve(bytes + bytes / 2 + 16)) return fail(EPS_INFRA_UNEXPECTED_ERROR, "set_filter_program: out of device memory");
@@ -408,11 +424,16 @@ int32_t Index::set_filter_program(const eps_filter_op* ops, int32_t nops, const 
       bigger.p = nullptr;
       bigger.cap = 0;
     }
-    if (bytes > have)
-      HIP_TRY(hipMemcpyAsync(static_cast<char*>(prog_rows_buf_.p) + have, static_cast<const char*>(rows) + have, bytes - have, hipMemcpyHostToDevice, stream_));
+    if (n_rows > have_rows) {
+      const char* src = static_cast<const char*>(rows) + (size_t)have_rows * (size_t)src_pitch;
+      char* dst = static_cast<char*>(prog_rows_buf_.p) + have;
+      if (src_pitch == stride) HIP_TRY(hipMemcpyAsync(dst, src, bytes - have, hipMemcpyHostToDevice, stream_));
+      else HIP_TRY(hipMemcpy2DAsync(dst, (size_t)stride, src, (size_t)src_pitch, (size_t)stride, (size_t)(n_rows - have_rows), hipMemcpyHostToDevice, stream_));
+    }
     d_prog_rows_ = prog_rows_buf_.as<uint8_t>();
     prog_rows_host_ = rows;
     prog_rows_stride_ = stride;
+    prog_rows_pitch_ = src_pitch;
     prog_rows_uploaded_ = n_rows;
   }
   HIP_TRY(hipStreamSynchronize(stream_));
@@ -543,6 +564,25 @@ int32_t Index::build(int64_t n, const eps_build_params* p) {
 // ------------------------------------------------------------------------------------------------ search
 int32_t Index::flat_stream(const float* dq, int64_t nq, int k, int64_t row_begin, int64_t row_end, u64* run_keys,
                            bool merge_run, int metric, bool filtered) {
+  if (k <= 1024) return flat_stream_page(dq, nq, k, row_begin, row_end, run_keys, merge_run, metric, filtered, nullptr, 0);
+  // More than 1024 results per query (the reference's BruteForceSearch has no cap: it sorts all n candidates,
+  // vec_search_executor.cpp:756-767): pages of 1024 - page p is the scan's 1024 best keys ordered AFTER the last key of page
+  // p-1 ((dist, id) keys are unique per row, so the pages are disjoint and their concatenation is the sorted answer).
+  if (merge_run) return fail(EPS_DB_UNSUPPORTED_ERROR, "search: merging into an existing result list of more than 1024 entries is not supported");
+  if (!page_buf_.reserve((size_t)nq * 1024 * sizeof(u64))) return fail(EPS_INFRA_UNEXPECTED_ERROR, "search: out of device memory (result page)");
+  for (int done = 0; done < k; done += 1024) {
+    const int kc = std::min(1024, k - done);
+    const int32_t rc = flat_stream_page(dq, nq, kc, row_begin, row_end, page_buf_.as<u64>(), false, metric, filtered,
+                                        done ? run_keys + (done - 1) : nullptr, k);
+    if (rc != EPS_OK) return rc;
+    HIP_TRY(hipMemcpy2DAsync(run_keys + done, (size_t)k * sizeof(u64), page_buf_.p, (size_t)kc * sizeof(u64), (size_t)kc * sizeof(u64), (size_t)nq,
+                             hipMemcpyDeviceToDevice, stream_));
+  }
+  return EPS_OK;
+}
+
+int32_t Index::flat_stream_page(const float* dq, int64_t nq, int k, int64_t row_begin, int64_t row_end, u64* run_keys,
+                                bool merge_run, int metric, bool filtered, const u64* lo, int64_t lo_stride) {
   if (row_end <= row_begin) {
     if (!merge_run) launch_fill_u64(run_keys, nq * k, KEY_EMPTY, stream_);
     return EPS_OK;
@@ -563,6 +603,8 @@ int32_t Index::flat_stream(const float* dq, int64_t nq, int k, int64_t row_begin
   a.partial = partial_buf_.as<u64>();
   a.W = W;
   a.thr_in = nullptr;
+  a.lo_in = lo;
+  a.lo_stride = lo_stride;
   HIP_TRY(hipEventRecord(evk0_, stream_));
   launch_flat_scan(a, stream_);
   HIP_TRY(hipEventRecord(evk1_, stream_));
@@ -632,8 +674,6 @@ int32_t Index::search(const float* queries, int64_t nq, int32_t k, const eps_sea
     }
   }
   if (mode == EPS_MODE_GRAPH && n_indexed_ <= 0) return fail(EPS_USER_ERROR, "search: graph mode requested but no graph is set");
-  if (mode == EPS_MODE_FLAT && k > 1024)
-    return fail(EPS_DB_UNSUPPORTED_ERROR, "search: more than 1024 results per query from a flat scan are not supported (the per-wavefront top-k lists hold 1024 entries)");
 
   if (!run_buf_.reserve((size_t)nq * k * sizeof(u64))) return fail(EPS_INFRA_UNEXPECTED_ERROR, "search: out of device memory (results)");
   u64* run_keys = run_buf_.as<u64>();
@@ -651,6 +691,7 @@ int32_t Index::search(const float* queries, int64_t nq, int32_t k, const eps_sea
     // a filter on @distance needs exact distances wherever it is evaluated; the MFMA engine selects its seeds on
     // approximate keys, so such searches stay on the exact stream engine
     if (prog_len_ > 0 && prog_uses_dist_ && !prefilter_call_) engine = EPS_FLAT_STREAM;
+    if (keff > 1024) engine = EPS_FLAT_STREAM;   // result pages (see flat_stream)
     int32_t rc;
     if (keff == k) {
       rc = engine == EPS_FLAT_MFMA ? flat_mfma_search(*this, dq, nq, k, run_keys, false, bits)
@@ -839,7 +880,11 @@ int32_t eps_index_set_int_filter(eps_index* h, const void* col, int64_t stride, 
   GUARD(h, IX(h)->set_int_filter(col, stride, width, op, c));
 }
 int32_t eps_index_set_filter_program(eps_index* h, const eps_filter_op* ops, int32_t nops, const void* rows, int64_t stride, int64_t n_rows) {
-  GUARD(h, IX(h)->set_filter_program(ops, nops, rows, stride, n_rows));
+  GUARD(h, IX(h)->set_filter_program(ops, nops, rows, stride, n_rows, 0));
+}
+int32_t eps_index_set_filter_program_ex(eps_index* h, const eps_filter_op* ops, int32_t nops, const void* rows, int64_t stride, int64_t n_rows,
+                                        int32_t flags) {
+  GUARD(h, IX(h)->set_filter_program(ops, nops, rows, stride, n_rows, flags));
 }
 int32_t eps_index_search_walk(eps_index* h, const float* q, int64_t nq, int32_t limit, int32_t cap, const eps_search_params* p, int64_t* ids,
                               float* dist, int32_t* counts) {

@@ -39,7 +39,7 @@ class IndexBase {
   virtual int32_t set_id_map(int64_t base, int64_t stride) = 0;
   virtual int32_t set_deleted(const uint8_t* bits, int64_t nbytes) = 0;
   virtual int32_t set_int_filter(const void* column, int64_t stride, int32_t width, int32_t op, int64_t constant) = 0;
-  virtual int32_t set_filter_program(const eps_filter_op* ops, int32_t nops, const void* rows, int64_t stride, int64_t n_rows) = 0;
+  virtual int32_t set_filter_program(const eps_filter_op* ops, int32_t nops, const void* rows, int64_t stride, int64_t n_rows, int32_t flags = 0) = 0;
   virtual int32_t build(int64_t n, const eps_build_params* p) = 0;
   virtual int32_t set_graph(int64_t n, const int64_t* off, const int64_t* nbr, int64_t nav) = 0;
   virtual int32_t graph_info(int64_t* n, int64_t* edges, int64_t* nav) const = 0;
@@ -75,7 +75,9 @@ class Index : public IndexBase {
   int32_t set_id_map(int64_t base, int64_t stride) override;
   int32_t set_deleted(const uint8_t* bits, int64_t nbytes) override;
   int32_t set_int_filter(const void* column, int64_t stride, int32_t width, int32_t op, int64_t constant) override;
-  int32_t set_filter_program(const eps_filter_op* ops, int32_t nops, const void* rows, int64_t stride, int64_t n_rows) override;
+  int32_t set_filter_program(const eps_filter_op* ops, int32_t nops, const void* rows, int64_t stride, int64_t n_rows, int32_t flags = 0) override;
+  int32_t set_filter_program_pitched(const eps_filter_op* ops, int32_t nops, const void* rows, int64_t src_pitch, int64_t row_bytes, int64_t n_rows,
+                                     int32_t flags);
   int32_t build(int64_t n, const eps_build_params* p) override;
   int32_t set_graph(int64_t n, const int64_t* off, const int64_t* nbr, int64_t nav) override;
   int32_t graph_info(int64_t* n, int64_t* edges, int64_t* nav) const override;
@@ -122,7 +124,7 @@ class Index : public IndexBase {
   DevBuf prog_buf_, prog_rows_buf_;   // compiled filter program + (when handed over from the host) the attribute rows
   const uint8_t* d_prog_rows_ = nullptr;
   const void* prog_rows_host_ = nullptr;   // host table the cached device copy mirrors (append-only)
-  int64_t prog_rows_stride_ = 0, prog_rows_uploaded_ = 0;
+  int64_t prog_rows_stride_ = 0, prog_rows_pitch_ = 0, prog_rows_uploaded_ = 0;
   int64_t loaded_attr_rows_ = 0, loaded_attr_stride_ = 0;   // attribute rows kept by load_table
   int64_t prog_stride_ = 0, prog_rows_n_ = 0;
   int32_t prog_len_ = 0;
@@ -139,7 +141,7 @@ class Index : public IndexBase {
   HalfMirror* mirror_ = nullptr;
 
   // scratch
-  DevBuf q_buf_, partial_buf_, run_buf_, ids_buf_, dist_buf_, cnt_buf_, tmp_buf_;
+  DevBuf q_buf_, partial_buf_, run_buf_, ids_buf_, dist_buf_, cnt_buf_, tmp_buf_, page_buf_;
   hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
   // main-kernel event pairs of the last KRING search calls (read back after a run without a sync inside it);
   // evk0_/evk1_ alias the pair of the call in progress
@@ -157,6 +159,8 @@ class Index : public IndexBase {
  private:
   int32_t flat_stream(const float* dq, int64_t nq, int k, int64_t row_begin, int64_t row_end, u64* run_keys,
                       bool merge_run, int metric = -1, bool filtered = true);
+  int32_t flat_stream_page(const float* dq, int64_t nq, int k, int64_t row_begin, int64_t row_end, u64* run_keys, bool merge_run, int metric,
+                           bool filtered, const u64* lo, int64_t lo_stride);
   friend int32_t flat_mfma_search(Index&, const float*, int64_t, int, u64*, bool, int);
   friend int32_t flat_mfma_search_slice(Index&, const float*, int64_t, int, u64*, bool, int, int);
   friend int32_t graph_build(Index&, int64_t, const eps_build_params&);

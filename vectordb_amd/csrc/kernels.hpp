@@ -21,6 +21,8 @@ struct FlatScanArgs {
   u64* partial;                 // [nq][W][k] per-wave sorted lists
   int W;                        // wavefronts per query = gridDim.x * 4
   const u64* thr_in;            // optional [nq] initial thresholds (only keys < thr can enter), or null
+  const u64* lo_in;             // optional: only keys > lo_in[q * lo_stride] can enter (paging through results beyond 1024 per query), or null
+  int64_t lo_stride;
 };
 // returns W (partial lists per query). `partial` must hold nq * flat_scan_waves(...) * k keys.
 int flat_scan_waves(int64_t nrows, int64_t nq, int dim);

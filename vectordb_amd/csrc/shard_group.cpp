@@ -9,8 +9,11 @@
 // All eps_index_* entry points work on the handle eps_index_create_sharded returns.  Host pointers only (a sharded table
 // is ingested from the DBMS's host column; each shard reads its rows with one strided copy, nothing is re-packed).
 #include <algorithm>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -24,6 +27,12 @@ class ShardGroup : public IndexBase {
  public:
   ShardGroup(int64_t dim, int metric) : dim_(dim), metric_(metric) {}
   ~ShardGroup() override {
+    {
+      std::lock_guard<std::mutex> lk(pool_mu_);
+      pool_stop_ = true;
+    }
+    pool_job_.notify_all();
+    for (auto& t : pool_) t.join();
     const int dev0 = shard_.empty() ? 0 : shard_[0]->device_;
     free_on(dev0, gathered_);
     free_on(dev0, m_ids_);
@@ -50,26 +59,51 @@ class ShardGroup : public IndexBase {
         (void)hipDeviceEnablePeerAccess(devices[0], 0);
         (void)hipGetLastError();
       }
+    // one worker thread per shard for the lifetime of the group (r2 spawned and joined G threads per call, search included)
+    for (int s = 0; s < shards; ++s) pool_.emplace_back([this, s]() { worker(s); });
     return EPS_OK;
   }
 
   int G() const { return (int)shard_.size(); }
   int64_t rows_of(int s, int64_t n) const { return n > s ? (n - s + G() - 1) / G() : 0; }
 
-  template <class F>
-  int32_t each(F&& f) {   // f(s, Index&) on every shard, concurrently; first error wins
-    std::vector<int32_t> rc((size_t)G(), EPS_OK);
-    std::vector<std::thread> th;
-    for (int s = 0; s < G(); ++s) th.emplace_back([&, s]() {
+  void worker(int s) {
+    (void)hipSetDevice(shard_[s]->device_);
+    uint64_t seen = 0;
+    std::unique_lock<std::mutex> lk(pool_mu_);
+    for (;;) {
+      pool_job_.wait(lk, [&] { return pool_stop_ || pool_gen_ != seen; });
+      if (pool_stop_) return;
+      seen = pool_gen_;
+      lk.unlock();
+      int32_t rc;
       try {
-        rc[s] = f(s, *shard_[s]);
+        rc = pool_fn_(s, *shard_[s]);
       } catch (const std::exception& e) {
-        rc[s] = shard_[s]->fail(EPS_DB_UNEXPECTED_ERROR, e.what());
+        rc = shard_[s]->fail(EPS_DB_UNEXPECTED_ERROR, e.what());
+      } catch (...) {
+        rc = shard_[s]->fail(EPS_DB_UNEXPECTED_ERROR, "unexpected exception");
       }
-    });
-    for (auto& t : th) t.join();
+      lk.lock();
+      pool_rc_[s] = rc;
+      if (--pool_pending_ == 0) pool_done_.notify_all();
+    }
+  }
+
+  template <class F>
+  int32_t each(F&& f) {   // f(s, Index&) on every shard, concurrently, on the group's worker threads; first error wins
+    {
+      std::unique_lock<std::mutex> lk(pool_mu_);
+      pool_fn_ = std::function<int32_t(int, Index&)>(std::forward<F>(f));
+      pool_rc_.assign((size_t)G(), EPS_OK);
+      pool_pending_ = G();
+      ++pool_gen_;
+      pool_job_.notify_all();
+      pool_done_.wait(lk, [&] { return pool_pending_ == 0; });
+      pool_fn_ = nullptr;
+    }
     for (int s = 0; s < G(); ++s)
-      if (rc[s] != EPS_OK) return fail(rc[s], "shard " + std::to_string(s) + ": " + shard_[s]->last_error());
+      if (pool_rc_[s] != EPS_OK) return fail(pool_rc_[s], "shard " + std::to_string(s) + ": " + shard_[s]->last_error());
     return EPS_OK;
   }
 
@@ -119,11 +153,12 @@ class ShardGroup : public IndexBase {
       return ix.set_int_filter(static_cast<const char*>(column) + (int64_t)s * stride, stride * G(), width, op, constant);
     });
   }
-  int32_t set_filter_program(const eps_filter_op* ops, int32_t nops, const void* rows, int64_t stride, int64_t n_rows) override {
+  int32_t set_filter_program(const eps_filter_op* ops, int32_t nops, const void* rows, int64_t stride, int64_t n_rows, int32_t flags) override {
     if (nops <= 0 || !ops) return each([](int, Index& ix) { return ix.set_filter_program(nullptr, 0, nullptr, 0, 0); });
     if (!rows || is_device_ptr(rows)) return fail(EPS_DB_UNSUPPORTED_ERROR, "sharded index: attribute rows come from host memory");
-    return each([&](int s, Index& ix) {
-      return ix.set_filter_program(ops, nops, static_cast<const char*>(rows) + (int64_t)s * stride, stride * G(), rows_of(s, n_rows));
+    if (stride <= 0 || n_rows < n_rows_) return fail(EPS_USER_ERROR, "set_filter_program: attribute rows missing or shorter than the table");
+    return each([&](int s, Index& ix) {   // the shard's rows are every G-th row: ONLY those are uploaded (packed at the original stride)
+      return ix.set_filter_program_pitched(ops, nops, static_cast<const char*>(rows) + (int64_t)s * stride, stride * G(), stride, rows_of(s, n_rows), flags);
     });
   }
   int32_t build(int64_t n, const eps_build_params* p) override {   // every shard builds the graph of its own rows
@@ -146,7 +181,9 @@ class ShardGroup : public IndexBase {
     if (nav) *nav = -1;
     return EPS_OK;
   }
-  int32_t get_graph(int64_t*, int64_t*) const override { return EPS_DB_UNSUPPORTED_ERROR; }
+  int32_t get_graph(int64_t*, int64_t*) const override {
+    return const_cast<ShardGroup*>(this)->fail(EPS_DB_UNSUPPORTED_ERROR, "sharded index: there is one graph per shard; save them with eps_index_save_graph (<path>.shard<s>)");
+  }
   int32_t save_graph(const char* path) override {   // <path>.shard<s>, each in the reference's ann_graph file format
     if (!path) return fail(EPS_USER_ERROR, "save_graph: null path");
     return each([&](int s, Index& ix) { return ix.save_graph((std::string(path) + ".shard" + std::to_string(s)).c_str()); });
@@ -232,7 +269,22 @@ class ShardGroup : public IndexBase {
     *out = t;
     return EPS_OK;
   }
-  int kernel_times(double* ms_out, int cap) override { return shard_[0]->kernel_times(ms_out, cap); }
+  int kernel_times(double* ms_out, int cap) override {   // per call the slowest shard, as last_stats reports
+    if (!ms_out || cap <= 0) return 0;
+    int n = -1;
+    std::vector<double> t((size_t)cap);
+    for (auto& ix : shard_) {
+      const int c = ix->kernel_times(t.data(), cap);
+      if (n < 0) {
+        n = c;
+        std::copy(t.begin(), t.begin() + c, ms_out);
+      } else {
+        n = std::min(n, c);   // (aligned at the most recent call)
+        for (int i = 0; i < n; ++i) ms_out[i] = std::max(ms_out[i], t[(size_t)i]);
+      }
+    }
+    return n < 0 ? 0 : n;
+  }
 
  private:
   static void free_on(int dev, void*& p) {
@@ -250,6 +302,15 @@ class ShardGroup : public IndexBase {
   void* m_ids_ = nullptr;
   void* m_dist_ = nullptr;
   size_t cap_ = 0, stride_ = 0;
+  // worker pool
+  std::vector<std::thread> pool_;
+  std::mutex pool_mu_;
+  std::condition_variable pool_job_, pool_done_;
+  std::function<int32_t(int, Index&)> pool_fn_;
+  std::vector<int32_t> pool_rc_;
+  uint64_t pool_gen_ = 0;
+  int pool_pending_ = 0;
+  bool pool_stop_ = false;
 };
 
 }  // namespace

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "index.hpp"
@@ -113,6 +114,7 @@ struct PostArgs {
   int tail_k;
   int k;              // output width
   int K;              // searchLimit = min(n_indexed, limit, L_local): slots that take part in the tail merge
+  int Klds;           // slots staged in LDS: K when there is a tail to merge, else 0 (the walk then reads the queue from HBM)
   int Kout;           // results wanted per query (= K for Search(); the whole walk for eps_index_search_walk)
   int cand_num_tail;  // min(L_master, n_total)
   int cand_num;       // min(L_master, n_indexed)
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(64) void post_kernel(PostArgs a) {
   const int L = a.L;
   const int lane = threadIdx.x;
   const u64* qu = a.queue + q * L;
-  for (int i = lane; i < a.K; i += 64) m[i] = plain_key(qu[i]);
+  for (int i = lane; i < a.Klds; i += 64) m[i] = plain_key(qu[i]);
   if (lane == 0) s_cand = a.cand_num;
   __syncthreads();
   if (a.tail && lane == 0) {
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(64) void post_kernel(PostArgs a) {
   for (int base = 0; base < cand_num && res < a.Kout; base += 64) {
     const int i = base + lane;
     u64 v = KEY_EMPTY;
-    if (i < cand_num) v = i < a.K ? m[i] : plain_key(qu[i]);
+    if (i < cand_num) v = i < a.Klds ? m[i] : plain_key(qu[i]);
     const bool ok = v != KEY_EMPTY && row_visible(a.f, key_id(v), key_dist(v));
     const u64 mask = __ballot(ok);
     const int rank = res + __popcll(mask & ((1ull << lane) - 1ull));
@@ -208,12 +210,14 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
   const int64_t n = ix.n_indexed_;
   int64_t L = p.master_queue;
   if (L > n) L = n;  // the reference would spin forever in PrepareInitIds when L > n (see prepare_init_ids)
+  // The reference accepts SearchQueueSize up to 10^7 and IntraQueryThreads up to 128 (config/config.hpp:28-44).  What the device
+  // does not run it refuses - it never runs a different configuration than the one asked for.
   if (L > ((int64_t)1 << 20)) return ix.fail(EPS_DB_UNSUPPORTED_ERROR, "search: SearchQueueSize > 1048576 is not supported (use the flat engines)");
   int64_t Lq = p.local_queue;
   if (Lq > n) Lq = n;
-  if (Lq > ((int64_t)1 << 20)) Lq = (int64_t)1 << 20;
-  int T = p.intra_threads;
-  if (T > TRV2_MAXT) T = TRV2_MAXT;   // more workers than a workgroup can usefully keep in flight
+  if (Lq > ((int64_t)1 << 20)) return ix.fail(EPS_DB_UNSUPPORTED_ERROR, "search: LocalQueueSize > 1048576 is not supported (use the flat engines)");
+  const int T = p.intra_threads;
+  if (T > TRV2_MAXT) return ix.fail(EPS_DB_UNSUPPORTED_ERROR, "search: IntraQueryThreads > 128 is not supported (the reference's own limit, config/config.hpp:29)");
   const int I = (int)std::min<int64_t>(p.sync_interval, 1 << 20);
   int Lp2 = 1;
   while (Lp2 < L) Lp2 <<= 1;
@@ -229,7 +233,9 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
     g.init_L = L;
   }
   const int dp = (int)(((g.fixed_deg > 0 ? (int64_t)g.fixed_deg : std::max<int64_t>(g.max_degree, 1)) + 7) / 8 * 8);   // edge slots per worker and step
-  if ((int64_t)T * dp > 2048) return ix.fail(EPS_DB_UNSUPPORTED_ERROR, "search: IntraQueryThreads x maximum out-degree > 2048 is not supported");
+  if ((int64_t)T * dp > 2048)   // the T adjacency lists of one lockstep step share the workgroup's LDS
+    return ix.fail(EPS_DB_UNSUPPORTED_ERROR, "search: IntraQueryThreads x maximum out-degree (rounded up to 8) > 2048 is not supported: " + std::to_string(T) + " x " +
+                                                 std::to_string(dp) + " (at the build's out-degree cap of 64: IntraQueryThreads <= 32)");
   const int64_t qtot = (int64_t)(T - 1) * Lq + Lp2;
   const bool vec4 = (ix.dim_ % 4 == 0) && ((reinterpret_cast<uintptr_t>(ix.d_rows_) & 15) == 0);
   // queues in LDS while a workgroup's working set leaves room for at least two workgroups per CU (the row gathers of
@@ -305,7 +311,7 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
   const int64_t n_total = ix.n_rows_;
   const u64* tail = nullptr;
   const int limit = walk_limit > 0 ? walk_limit : k;   // the reference's `limit`
-  const int tail_k = std::min(limit, 1024);            // only min(|tail|, limit) tail entries are ever merged (:890-899)
+  const int tail_k = std::min(limit, 8192);            // only min(|tail|, limit) tail entries are ever merged (:890-899)
   if (n_total > n) {
     if (!g.tail.reserve((size_t)nq * tail_k * 8)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "search: out of device memory");
     int32_t rc = ix.flat_stream(dq, nq, tail_k, n, n_total, g.tail.as<u64>(), false);
@@ -321,8 +327,9 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
   if (limit < K) K = limit;
   if (p.local_queue < K) K = p.local_queue;
   if (L < K) K = L;
-  if (tail && K > 1024) return ix.fail(EPS_DB_UNSUPPORTED_ERROR, "search: limit > 1024 with an un-indexed tail is not supported");
+  if (tail && K > 8192) return ix.fail(EPS_DB_UNSUPPORTED_ERROR, "search: limit > 8192 with an un-indexed tail is not supported (rebuild the graph over the new rows)");
   pa.K = (int)K;
+  pa.Klds = tail ? (int)K : 0;   // <= 64 KB of LDS; without a tail nothing is staged, whatever K
   pa.Kout = walk_limit > 0 ? k : (int)K;
   pa.cand_num_tail = (int)std::min<int64_t>(L, n_total);
   pa.cand_num = (int)std::min<int64_t>(L, n);
@@ -351,7 +358,7 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
     if (q0 + cnt >= nq) (void)hipEventRecord(ix.evk1_, s);   // (with several slices the pair spans all traversal launches and the post kernels between them)
     pa.tail = tail ? tail + q0 * tail_k : nullptr;
     pa.run_keys = run_keys + q0 * k;
-    hipLaunchKernelGGL(post_kernel, dim3((unsigned)cnt), dim3(64), (size_t)K * 8, s, pa);
+    hipLaunchKernelGGL(post_kernel, dim3((unsigned)cnt), dim3(64), (size_t)pa.Klds * 8, s, pa);
   }
   er = hipGetLastError();
   if (er != hipSuccess) return ix.hip_fail(er, "traversal launch");

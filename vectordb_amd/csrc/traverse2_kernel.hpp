@@ -58,8 +58,10 @@ struct Trv2Args {
 #define EPS_TRV_U 4   // rows in flight per lane group in the distance phases
 #endif
 constexpr int TRV2_SB = 4096;       // keys of the LDS staging block of the QGLOBAL bitonic sort
-constexpr int TRV2_MAXT = 16;
-constexpr int TRV2_SH = 192;        // ints of scalar scratch
+constexpr int TRV2_MAXT = 128;      // the reference's limit for IntraQueryThreads (config/config.hpp:29)
+// ints of scalar scratch: 16 scalars, eight [TS] per-worker arrays, [16] per-wave counts, [TS + 16] edge offsets; TS = T rounded up to 16
+__host__ __device__ inline int trv2_tstride(int T) { return T <= 16 ? 16 : (T + 15) & ~15; }
+__host__ __device__ inline int trv2_sh_ints(int T) { return 48 + 9 * trv2_tstride(T); }
 constexpr u32 TRV2_NONE = 0xFFFFFFFFu;
 
 __device__ __forceinline__ u64 q2key(float d, u32 id) { return ((u64)f2ord(d + 0.0f) << 32) | ((u64)id << 1); }
@@ -116,19 +118,21 @@ __global__ __launch_bounds__(NW * 64) void traverse2_kernel(Trv2Args a) {
   u32* hid = reinterpret_cast<u32*>(npos + ecap);                           // [H] node id, TRV2_NONE = empty
   int* hmin = reinterpret_cast<int*>(hid + H);                              // [H] lowest edge slot that met the node this step
   int* auxl = hmin + H;                                                     // !QGLOBAL: [2*Lq] MergeAll scratch (T > 1)
-  int* sh = auxl + ((QGLOBAL || T == 1) ? 0 : 2 * Lq);                      // [TRV2_SH]
+  int* sh = auxl + ((QGLOBAL || T == 1) ? 0 : 2 * Lq);                      // [trv2_sh_ints(T)]
   // sh[0] scratch (first found / pmin), sh[1] unchecked count, sh[2] undo-log fill, sh[3] any worker selected,
   // sh[4] running prefix, sh[5] non-duplicate count, sh[6] r of MergeAll, sh[7] log overflow
-  int* s_kuc = sh + 16;     // [T] first possibly-unchecked position per queue
-  int* s_size = sh + 32;    // [T] queue sizes
-  int* s_its = sh + 48;     // [T] expansions done this round
-  int* s_sel = sh + 64;     // [T] node selected this step, or -1
-  int* s_deg = sh + 80;     // [T] its degree
-  int* s_wcnt = sh + 96;    // [T] ids to evaluate
-  int* s_nnew = sh + 112;   // [T] keys that passed the bound
-  int* s_wave = sh + 128;   // [NW] per-wave counts
-  int* s_selpos = sh + 144; // [T] queue position of the selected candidate
-  int* s_eoff = sh + 160;   // [T+1] first edge slot of every worker in this step
+  const int TS = trv2_tstride(T);
+  const int SH = trv2_sh_ints(T);
+  int* s_kuc = sh + 16;            // [T] first possibly-unchecked position per queue
+  int* s_size = s_kuc + TS;        // [T] queue sizes
+  int* s_its = s_size + TS;        // [T] expansions done this round
+  int* s_sel = s_its + TS;         // [T] node selected this step, or -1
+  int* s_deg = s_sel + TS;         // [T] its degree
+  int* s_wcnt = s_deg + TS;        // [T] ids to evaluate
+  int* s_nnew = s_wcnt + TS;       // [T] keys that passed the bound
+  int* s_wave = s_nnew + TS;       // [NW <= 16] per-wave counts
+  int* s_selpos = s_wave + 16;     // [T] queue position of the selected candidate
+  int* s_eoff = s_selpos + TS;     // [T+1] first edge slot of every worker in this step
 
   const int tid = threadIdx.x;
   const int lane = lane_id();
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(NW * 64) void traverse2_kernel(Trv2Args a) {
   for (int64_t q = slot; q < a.nq; q += gridDim.x) {
     // ------------------------------------------------------------------ InitializeSetLPara (:446-485)
     for (int i = tid; i < qstride; i += NT) sq[i] = i < dim ? a.queries[q * dim + i] : 0.f;
-    for (int i = tid; i < TRV2_SH; i += NT) sh[i] = 0;
+    for (int i = tid; i < SH; i += NT) sh[i] = 0;
     for (int i = tid; i < H; i += NT) {
       hid[i] = TRV2_NONE;
       hmin[i] = 0x7FFFFFFF;
@@ -504,7 +508,8 @@ __global__ __launch_bounds__(NW * 64) void traverse2_kernel(Trv2Args a) {
         // f. AddIntoQueue for every worker: merge its sorted survivors into its queue in place.  The workers are handled side
         //    by side, TPW threads each, in the same barrier schedule (the chunk loop runs as long as the longest needs).
         {
-          const int Tp = T <= 1 ? 1 : (T <= 2 ? 2 : (T <= 4 ? 4 : (T <= 8 ? 8 : 16)));
+          int Tp = 1;
+          while (Tp < T) Tp <<= 1;                 // (T <= 128 <= NT)
           const int TPW = NT / Tp;                 // threads per worker
           const int CW = TPW * R;                  // queue entries per worker and chunk
           const int w = tid / TPW;                 // this thread's worker (may be >= T: idle group)
@@ -680,7 +685,7 @@ inline size_t traverse2_lds_bytes(int dim, int T, int Lq, int64_t qtot, int dp, 
   const int qstride = (dim + 3) & ~3;
   const size_t ecap = (size_t)T * dp;
   return (size_t)qstride * 4 + (qglobal ? (size_t)TRV2_SB : (size_t)qtot) * 8 + ecap * (8 + 8 + 4 + 4 + 4 + 4) + (size_t)traverse2_hash_slots(T, dp) * 8 +
-         ((qglobal || T == 1) ? 0 : (size_t)2 * Lq * 4) + TRV2_SH * 4;
+         ((qglobal || T == 1) ? 0 : (size_t)2 * Lq * 4) + (size_t)trv2_sh_ints(T) * 4;
 }
 
 }  // namespace eps

@@ -129,10 +129,13 @@ class GpuIndex:
         base = C.c_void_p(_ptr(column).value + offset)
         self._check(self.L.eps_index_set_int_filter(self.h, base, stride, width, OPS[op], int(value)))
 
-    def set_filter_program(self, program, rows=None, stride=None):
+    def set_filter_program(self, program, rows=None, stride=None, append_only=False):
         """program: postfix list of ("const", x) | ("dist",) | ("i8"|"i16"|"i32"|"i64"|"f32"|"f64"|"bool", byte_offset) |
         (operator,) with operators + - * / % < <= = <> >= > and or not =b <>b (see eps_filter_op); rows: the packed
-        attribute rows (numpy structured/2-D uint8 array or device tensor), row i at i*stride bytes.  None / [] clears."""
+        attribute rows (numpy structured/2-D uint8 array or device tensor), row i at i*stride bytes.  None / [] clears.
+        Host rows are uploaded in full on every call (edit the array in place and call again to refresh);
+        append_only=True promises that rows handed over earlier from the same array are unchanged, so only the new tail is
+        uploaded (EPS_FILTER_ROWS_APPEND_ONLY)."""
         if not program:
             self._check(self.L.eps_index_set_filter_program(self.h, None, 0, None, 0, 0))
             return
@@ -151,7 +154,8 @@ class GpuIndex:
             stride = stride or rows.strides[0]
         n_rows = rows.shape[0]
         self._keep["prog_rows"] = rows
-        self._check(self.L.eps_index_set_filter_program(self.h, ops, len(program), _ptr(rows), stride, n_rows))
+        self._check(self.L.eps_index_set_filter_program_ex(self.h, ops, len(program), _ptr(rows), stride, n_rows,
+                                                           lib.FILTER_ROWS_APPEND_ONLY if append_only else 0))
 
     def search_walk(self, queries, limit, cap, **kw):
         """eps_index_search_walk: the <= cap candidates the reference's post-filter loop would walk (host queries)"""
