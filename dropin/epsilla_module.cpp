@@ -10,16 +10,19 @@
 // Additive entry points (the reference module has no way to trigger an index build and takes one vector per call):
 //   rebuild() -> int                                   DBServer::Rebuild (db_server.hpp:112) as leader; the graph is built
 //                                                      on the device by ANNGraphSegment::BuildFromVectorTable
+//   load_db_scaled(db_name, db_path, vector_scale, wal_enabled=True) -> int
+//                                                      load_db with the table capacity the REST API calls vectorScale
 //   query_batch(table_name, query_field, query_vectors, response_fields, limit, filter, with_distance)
-//       -> (int, list[list[dict]])                     the same as query() for a list of vectors: the calls are issued
-//                                                      concurrently (GIL released) through the unchanged
-//                                                      DBServer::Search, and the executor's micro-batcher
-//                                                      (dropin/vec_search_executor.cpp) coalesces them into device batches
+//       -> (int, list[list[dict]])                     query() for N vectors (a 2-D float32 / float64 buffer such as a NumPy
+//                                                      array, or a list of lists): ONE eps_index_search with nq = N through
+//                                                      VecSearchExecutor::SearchBatch, one projection pass; element q of the
+//                                                      result equals query(..., query_vectors[q], ...)[1]
 #define PyInit_epsilla PyInit_epsilla_reference_binding
 #include "bindings/python/interface.cpp"  // the reference's binding, from where it lies under $(REF)
 #undef PyInit_epsilla
 
 #include <atomic>
+#include <cstring>
 #include <thread>
 
 static PyObject* eps_rebuild(PyObject* self, PyObject* args, PyObject* kwargs) {
@@ -43,97 +46,311 @@ static PyObject* eps_rebuild(PyObject* self, PyObject* args, PyObject* kwargs) {
   return PyLong_FromLong(code);
 }
 
-static PyObject* eps_query_batch(PyObject* self, PyObject* args, PyObject* kwargs) {
+// load_db with the table capacity as an argument.  The REST entry takes it from the request ("vectorScale",
+// server/web_server/web_controller.hpp:120-140); the binding hard-codes 150000 (interface.cpp:55-61), and the segment loader
+// refuses files with more records than that (table_segment_mvp.cpp:161-166).
+static PyObject* eps_load_db_scaled(PyObject* self, PyObject* args, PyObject* kwargs) {
   (void)self;
-  static const char* keywords[] = {"table_name", "query_field", "query_vectors", "response_fields", "limit", "filter", "with_distance", "threads", NULL};
-  const char *tableNamePtr, *queryFieldPtr, *queryFilterPtr;
-  int limit, withDistance, threads = 64;
-  PyObject *queryVectors, *responseFields;
-  if (!PyArg_ParseTupleAndKeywords(args, kwargs, "ssOOisp|i", (char**)keywords, &tableNamePtr, &queryFieldPtr, &queryVectors, &responseFields,
-                                   &limit, &queryFilterPtr, &withDistance, &threads))
-    return NULL;
-  if (!PyList_Check(queryVectors) || !PyList_Check(responseFields)) {
-    PyErr_SetString(PyExc_Exception, "query_vectors and response_fields must be lists");
+  static const char* keywords[] = {"db_name", "db_path", "vector_scale", "wal_enabled", NULL};
+  const char *namePtr, *pathPtr;
+  long long scale = 150000;
+  int wal = 1;
+  if (!PyArg_ParseTupleAndKeywords(args, kwargs, "ssL|p", (char**)keywords, &namePtr, &pathPtr, &scale, &wal)) return NULL;
+  const std::string name = namePtr, path = pathPtr;
+  if (name.empty() || path.empty() || scale <= 0) {
+    PyErr_SetString(PyExc_Exception, "load_db_scaled: empty db name / path, or vector_scale <= 0");
     return NULL;
   }
-  const Py_ssize_t nq = PyList_Size(queryVectors);
-  std::vector<std::vector<float>> vecs((size_t)nq);
-  for (Py_ssize_t q = 0; q < nq; ++q) {
-    PyObject* v = PyList_GetItem(queryVectors, q);
-    if (!PyList_Check(v)) {
-      PyErr_SetString(PyExc_Exception, "query_vectors must be a list of lists of float");
+  int code = 0;
+  std::string err;
+  Py_BEGIN_ALLOW_THREADS
+  try {
+    std::unordered_map<std::string, std::string> headers;
+    code = db->LoadDB(name, path, (int64_t)scale, wal != 0, headers).code();
+  } catch (const std::exception& e) {
+    err = e.what();
+  }
+  Py_END_ALLOW_THREADS
+  if (!err.empty()) {
+    PyErr_SetString(PyExc_Exception, err.c_str());
+    return NULL;
+  }
+  return PyLong_FromLong(code);
+}
+
+// ---- query_batch: ONE device batch for all the vectors -------------------------------------------------------------------
+// What DBServer::Search (db/db_server.cpp:458-510) and TableMVP::Search (db/table_mvp.cpp:300-399) do per vector is done once
+// for the batch - table / field lookup and validation, filter parsing, query normalisation for COSINE, one executor from the
+// field's pool - then VecSearchExecutor::SearchBatch (one eps_index_search with nq = N) and one projection pass.
+namespace {
+
+struct FieldPlan {   // how to turn one response field of one row into a Python object without a JSON round trip
+  std::string name;
+  vectordb::engine::meta::FieldType type;
+  size_t offset = 0;   // byte offset inside the attribute row / index of the variable-length column / of the vector table
+  int64_t dim = 0;
+  PyObject* key = nullptr;
+};
+
+// the projection of TableMVP::Project (db/table_mvp.cpp:462-583) for primitive, string and dense-vector fields, built directly as
+// Python objects; fields it does not cover (JSON, GEO_POINT, sparse vectors) make the caller use Project + json.loads instead
+bool PlanFields(vectordb::engine::TableMVP& table, std::vector<std::string>& fields, std::vector<FieldPlan>& plan) {
+  using vectordb::engine::meta::FieldType;
+  if (fields.empty())
+    for (auto& f : table.table_schema_.fields_)
+      if (!f.is_index_field_) fields.push_back(f.name_);
+  auto& seg = *table.table_segment_;
+  for (auto& name : fields) {
+    FieldPlan p;
+    p.name = name;
+    p.type = table.field_name_field_type_map_[name];
+    p.offset = seg.field_name_mem_offset_map_[name];
+    switch (p.type) {
+      case FieldType::INT1: case FieldType::INT2: case FieldType::INT4: case FieldType::INT8: case FieldType::FLOAT:
+      case FieldType::DOUBLE: case FieldType::BOOL: case FieldType::STRING:
+        break;
+      case FieldType::VECTOR_FLOAT: case FieldType::VECTOR_DOUBLE:
+        p.dim = seg.vector_dims_[p.offset];
+        break;
+      default:
+        return false;
+    }
+    plan.push_back(p);
+  }
+  return true;
+}
+
+PyObject* RowToDict(vectordb::engine::TableSegmentMVP& seg, const std::vector<FieldPlan>& plan, int64_t id, bool with_distance, double distance,
+                    PyObject* dist_key) {
+  using vectordb::engine::meta::FieldType;
+  PyObject* d = PyDict_New();
+  if (!d) return NULL;
+  for (auto& p : plan) {
+    const char* at = seg.attribute_table_ + p.offset + id * seg.primitive_offset_;
+    PyObject* v = NULL;
+    switch (p.type) {
+      case FieldType::INT1: { int8_t x; std::memcpy(&x, at, 1); v = PyLong_FromLongLong(x); break; }
+      case FieldType::INT2: { int16_t x; std::memcpy(&x, at, 2); v = PyLong_FromLongLong(x); break; }
+      case FieldType::INT4: { int32_t x; std::memcpy(&x, at, 4); v = PyLong_FromLongLong(x); break; }
+      case FieldType::INT8: { int64_t x; std::memcpy(&x, at, 8); v = PyLong_FromLongLong(x); break; }
+      case FieldType::FLOAT: { float x; std::memcpy(&x, at, 4); v = PyFloat_FromDouble((double)x); break; }
+      case FieldType::DOUBLE: { double x; std::memcpy(&x, at, 8); v = PyFloat_FromDouble(x); break; }
+      case FieldType::BOOL: { bool x; std::memcpy(&x, at, 1); v = PyBool_FromLong(x ? 1 : 0); break; }
+      case FieldType::STRING: {
+        const std::string& str = std::get<std::string>(seg.var_len_attr_table_[p.offset][id]);
+        v = PyUnicode_FromStringAndSize(str.data(), (Py_ssize_t)str.size());
+        break;
+      }
+      default: {   // dense vector
+        v = PyList_New((Py_ssize_t)p.dim);
+        if (v)
+          for (int64_t k = 0; k < p.dim; ++k) PyList_SET_ITEM(v, (Py_ssize_t)k, PyFloat_FromDouble((double)seg.vector_tables_[p.offset][id * p.dim + k]));
+      }
+    }
+    if (!v || PyDict_SetItem(d, p.key, v) < 0) {
+      Py_XDECREF(v);
+      Py_DECREF(d);
       return NULL;
     }
-    const Py_ssize_t d = PyList_Size(v);
-    vecs[q].resize((size_t)d);
-    for (Py_ssize_t i = 0; i < d; ++i) vecs[q][i] = (float)PyFloat_AsDouble(PyList_GetItem(v, i));
+    Py_DECREF(v);
   }
-  if (PyErr_Occurred()) return NULL;
+  if (with_distance) {
+    PyObject* v = PyFloat_FromDouble(distance);
+    if (!v || PyDict_SetItem(d, dist_key, v) < 0) {
+      Py_XDECREF(v);
+      Py_DECREF(d);
+      return NULL;
+    }
+    Py_DECREF(v);
+  }
+  return d;
+}
+
+}  // namespace
+
+static PyObject* eps_query_batch(PyObject* self, PyObject* args, PyObject* kwargs) {
+  (void)self;
+  static const char* keywords[] = {"table_name", "query_field", "query_vectors", "response_fields", "limit", "filter", "with_distance", NULL};
+  const char *tableNamePtr, *queryFieldPtr, *queryFilterPtr;
+  int limit, withDistance;
+  PyObject *queryVectors, *responseFields;
+  if (!PyArg_ParseTupleAndKeywords(args, kwargs, "ssOOisp", (char**)keywords, &tableNamePtr, &queryFieldPtr, &queryVectors, &responseFields,
+                                   &limit, &queryFilterPtr, &withDistance))
+    return NULL;
+  if (!PyList_Check(responseFields)) {
+    PyErr_SetString(PyExc_Exception, "response_fields must be a list");
+    return NULL;
+  }
+  // ---- the query matrix: any C-contiguous 2-D buffer of float32 / float64 (NumPy array, torch CPU tensor, memoryview), or a
+  // list of lists of float
+  std::vector<float> qbuf;
+  const float* qptr = nullptr;
+  Py_ssize_t nq = 0, dim = 0;
+  Py_buffer view;
+  bool have_view = false;
+  if (PyObject_CheckBuffer(queryVectors) && PyObject_GetBuffer(queryVectors, &view, PyBUF_C_CONTIGUOUS | PyBUF_FORMAT) == 0) {
+    have_view = true;
+    const bool f32 = view.format && (std::strcmp(view.format, "f") == 0 || std::strcmp(view.format, "<f") == 0 || std::strcmp(view.format, "=f") == 0);
+    const bool f64 = view.format && (std::strcmp(view.format, "d") == 0 || std::strcmp(view.format, "<d") == 0 || std::strcmp(view.format, "=d") == 0);
+    if (view.ndim != 2 || !(f32 || f64)) {
+      PyBuffer_Release(&view);
+      PyErr_SetString(PyExc_Exception, "query_vectors: a 2-D C-contiguous float32 / float64 buffer, or a list of lists of float");
+      return NULL;
+    }
+    nq = view.shape[0];
+    dim = view.shape[1];
+    if (f32) {
+      qptr = static_cast<const float*>(view.buf);
+    } else {
+      qbuf.resize((size_t)nq * dim);
+      const double* src = static_cast<const double*>(view.buf);
+      for (size_t i = 0; i < qbuf.size(); ++i) qbuf[i] = (float)src[i];
+      qptr = qbuf.data();
+    }
+  } else {
+    PyErr_Clear();
+    if (!PyList_Check(queryVectors)) {
+      PyErr_SetString(PyExc_Exception, "query_vectors: a 2-D C-contiguous float32 / float64 buffer, or a list of lists of float");
+      return NULL;
+    }
+    nq = PyList_Size(queryVectors);
+    for (Py_ssize_t q = 0; q < nq; ++q) {
+      PyObject* v = PyList_GetItem(queryVectors, q);
+      if (!PyList_Check(v) || (q > 0 && PyList_Size(v) != dim)) {
+        PyErr_SetString(PyExc_Exception, "query_vectors must be a list of lists of float of one length");
+        return NULL;
+      }
+      if (q == 0) {
+        dim = PyList_Size(v);
+        qbuf.resize((size_t)nq * dim);
+      }
+      for (Py_ssize_t i = 0; i < dim; ++i) qbuf[(size_t)q * dim + i] = (float)PyFloat_AsDouble(PyList_GetItem(v, i));
+    }
+    if (PyErr_Occurred()) return NULL;
+    qptr = qbuf.data();
+  }
+  struct ViewGuard {
+    Py_buffer* v;
+    ~ViewGuard() { if (v) PyBuffer_Release(v); }
+  } guard{have_view ? &view : nullptr};
+
   std::vector<std::string> fields;
   for (Py_ssize_t i = 0; i < PyList_Size(responseFields); ++i) {
     PyObject* s = PyObject_Str(PyList_GetItem(responseFields, i));
+    if (!s) return NULL;
     fields.push_back(PyUnicode_AsUTF8(s));
-    Py_XDECREF(s);
+    Py_DECREF(s);
   }
-  const std::string tableName = tableNamePtr, queryField = queryFieldPtr, queryFilter = queryFilterPtr;
-  std::vector<std::string> results((size_t)nq);
-  std::vector<int> codes((size_t)nq, 0);
-  std::vector<std::string> errors((size_t)nq);
+  const std::string tableName = tableNamePtr, queryFilter = queryFilterPtr;
+  std::string fieldName = queryFieldPtr;
+
+  // ---- lookups and validation, as DBServer::Search / TableMVP::Search
+  std::string err;
+  std::shared_ptr<vectordb::engine::TableMVP> table;
+  std::vector<vectordb::query::expr::ExprNodePtr> filter_nodes;
+  std::vector<int64_t> ids;
+  std::vector<float> dist;
+  std::vector<int32_t> counts;
+  int32_t width = 0;
+  std::vector<float> normalized;
   Py_BEGIN_ALLOW_THREADS
-  std::atomic<Py_ssize_t> next{0};
-  auto worker = [&]() {
-    for (;;) {
-      const Py_ssize_t q = next.fetch_add(1);
-      if (q >= nq) break;
-      try {
-        auto result = vectordb::Json();
-        auto facetsConfig = vectordb::Json();
-        facetsConfig.LoadFromString("[]");
-        auto facets = vectordb::Json();
-        std::vector<std::string> f = fields;
-        std::string fieldName = queryField;
-        auto status = db->Search(db_name, tableName, fieldName, f, (int64_t)vecs[q].size(), vecs[q].data(), limit, result, queryFilter,
-                                 withDistance != 0, facetsConfig, facets);
-        codes[q] = status.code();
-        if (status.ok()) results[q] = result.DumpToString(); else errors[q] = status.message();
-      } catch (const std::exception& e) {
-        codes[q] = -1;
-        errors[q] = e.what();
-      }
+  try {
+    using vectordb::engine::meta::FieldType;
+    auto database = db->GetDB(db_name);
+    if (!database) throw std::runtime_error("DB not found: " + db_name);
+    table = database->GetTable(tableName);
+    if (!table) throw std::runtime_error("Table not found: " + tableName);
+    if (fieldName.empty()) {
+      for (auto& f : table->table_schema_.fields_)
+        if (f.field_type_ == FieldType::VECTOR_FLOAT || f.field_type_ == FieldType::VECTOR_DOUBLE || f.field_type_ == FieldType::SPARSE_VECTOR_FLOAT ||
+            f.field_type_ == FieldType::SPARSE_VECTOR_DOUBLE) {
+          if (!fieldName.empty()) throw std::runtime_error("Must specify queryField if there are more than 1 vector fields.");
+          fieldName = f.name_;
+        }
     }
-  };
-  const int nt = (int)std::max<Py_ssize_t>(1, std::min<Py_ssize_t>(nq, threads));
-  std::vector<std::thread> pool;
-  for (int t = 0; t < nt; ++t) pool.emplace_back(worker);
-  for (auto& t : pool) t.join();
-  Py_END_ALLOW_THREADS
-  for (Py_ssize_t q = 0; q < nq; ++q)
-    if (codes[q] != 0) {
-      PyErr_SetString(PyExc_Exception, errors[q].c_str());
-      return NULL;
+    auto st = vectordb::query::expr::Expr::ParseNodeFromStr(queryFilter, filter_nodes, table->field_name_field_type_map_);
+    if (!st.ok()) throw std::runtime_error(st.message());
+    if (table->field_name_field_type_map_.find(fieldName) == table->field_name_field_type_map_.end()) throw std::runtime_error("Field name not found: " + fieldName);
+    for (auto& f : fields)
+      if (table->field_name_field_type_map_.find(f) == table->field_name_field_type_map_.end()) throw std::runtime_error("Field name not found: " + f);
+    const auto ftype = table->field_name_field_type_map_[fieldName];
+    if (ftype != FieldType::VECTOR_FLOAT && ftype != FieldType::VECTOR_DOUBLE) throw std::runtime_error("query_batch: the query field must be a dense vector field");
+    if (table->field_name_metric_type_map_[fieldName] == vectordb::engine::meta::MetricType::COSINE) {   // (table_mvp.cpp:333-343)
+      normalized.assign(qptr, qptr + (size_t)nq * dim);
+      for (Py_ssize_t q = 0; q < nq; ++q) vectordb::engine::Normalize((vectordb::engine::DenseVectorPtr)(normalized.data() + (size_t)q * dim), dim);
+      qptr = normalized.data();
     }
-  PyObject* json_module = PyImport_ImportModule("json");
-  if (!json_module) return NULL;
-  PyObject* loads = PyObject_GetAttrString(json_module, "loads");
-  Py_DECREF(json_module);
-  if (!loads) return NULL;
-  PyObject* out = PyList_New(nq);
-  for (Py_ssize_t q = 0; q < nq; ++q) {
-    PyObject* r = PyObject_CallFunction(loads, "s", results[q].c_str());
-    if (!r) {
-      Py_DECREF(loads);
-      Py_DECREF(out);
-      return NULL;
-    }
-    PyList_SetItem(out, q, r);
+    const int64_t field_offset = table->table_segment_->vec_field_name_executor_pool_idx_map_[fieldName];
+    std::unique_lock<std::mutex> lock(table->executor_pool_mutex_);
+    auto pool = table->executor_pool_.at(field_offset);
+    auto executor = vectordb::engine::execution::RAIIVecSearchExecutor(pool, pool->acquire());
+    lock.unlock();
+    if (nq > 0 && dim != executor.exec_->dimension_) throw std::runtime_error("Query dimension doesn't match the vector field dimension.");
+    if (nq > 0) executor.exec_->SearchBatch(qptr, nq, table->table_segment_.get(), (size_t)std::max(limit, 0), filter_nodes, ids, dist, counts, width);
+  } catch (const std::exception& e) {
+    err = e.what();
+    if (err.empty()) err = "query_batch failed";
   }
-  Py_DECREF(loads);
+  Py_END_ALLOW_THREADS
+  if (!err.empty()) {
+    PyErr_SetString(PyExc_Exception, err.c_str());
+    return NULL;
+  }
+
+  // ---- projection, once for the whole batch
+  PyObject* out = PyList_New(nq);
+  if (!out) return NULL;
+  std::vector<FieldPlan> plan;
+  const bool direct = PlanFields(*table, fields, plan);
+  PyObject* dist_key = PyUnicode_FromString("@distance");
+  PyObject* loads = NULL;
+  if (direct) {
+    for (auto& p : plan) p.key = PyUnicode_FromString(p.name.c_str());
+  } else {
+    PyObject* json_module = PyImport_ImportModule("json");
+    loads = json_module ? PyObject_GetAttrString(json_module, "loads") : NULL;
+    Py_XDECREF(json_module);
+  }
+  bool ok = dist_key && (direct || loads);
+  for (Py_ssize_t q = 0; ok && q < nq; ++q) {
+    const int64_t cnt = std::min<int64_t>(counts[(size_t)q], limit);
+    PyObject* rows = NULL;
+    if (direct) {
+      rows = PyList_New((Py_ssize_t)cnt);
+      for (int64_t i = 0; rows && i < cnt; ++i) {
+        PyObject* d = RowToDict(*table->table_segment_, plan, ids[(size_t)q * width + i], withDistance != 0, (double)dist[(size_t)q * width + i], dist_key);
+        if (!d) {
+          Py_CLEAR(rows);
+          break;
+        }
+        PyList_SET_ITEM(rows, (Py_ssize_t)i, d);
+      }
+    } else {   // the reference's own projection + its JSON round trip (interface.cpp:333-360)
+      std::vector<int64_t> qi(ids.begin() + (size_t)q * width, ids.begin() + (size_t)q * width + cnt);
+      std::vector<double> qd(dist.begin() + (size_t)q * width, dist.begin() + (size_t)q * width + cnt);
+      vectordb::Json result;
+      std::vector<std::string> f = fields;
+      auto st = table->Project(f, cnt, qi, result, withDistance != 0, qd);
+      if (!st.ok()) PyErr_SetString(PyExc_Exception, st.message().c_str());
+      else rows = PyObject_CallFunction(loads, "s", result.DumpToString().c_str());
+    }
+    if (!rows) ok = false; else PyList_SET_ITEM(out, q, rows);
+  }
+  for (auto& p : plan) Py_XDECREF(p.key);
+  Py_XDECREF(dist_key);
+  Py_XDECREF(loads);
+  if (!ok) {
+    Py_DECREF(out);
+    if (!PyErr_Occurred()) PyErr_SetString(PyExc_Exception, "query_batch: projection failed");
+    return NULL;
+  }
   return Py_BuildValue("(iN)", 0, out);
 }
 
 static PyMethodDef EpsillaGfx950Methods[] = {
     {"rebuild", (PyCFunction)(void (*)(void))eps_rebuild, METH_VARARGS | METH_KEYWORDS, "build the ANN graphs now (additive: DBServer::Rebuild as leader)"},
-    {"query_batch", (PyCFunction)(void (*)(void))eps_query_batch, METH_VARARGS | METH_KEYWORDS, "query() for a list of vectors (additive)"},
+    {"query_batch", (PyCFunction)(void (*)(void))eps_query_batch, METH_VARARGS | METH_KEYWORDS, "query() for N vectors in one device batch (additive)"},
+    {"load_db_scaled", (PyCFunction)(void (*)(void))eps_load_db_scaled, METH_VARARGS | METH_KEYWORDS, "load_db with the table capacity (the REST API's vectorScale) as an argument (additive)"},
     {NULL, NULL, 0, NULL}};
 
 PyMODINIT_FUNC PyInit_epsilla(void) {

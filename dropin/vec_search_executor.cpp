@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <limits>
 #include <map>
 #include <mutex>
 #include <stdexcept>
@@ -470,9 +471,10 @@ bool SameKey(const Pending& a, const Pending& b) {
          (a.program.empty() || std::memcmp(a.program.data(), b.program.data(), a.program.size() * sizeof(eps_filter_op)) == 0);
 }
 
-void RunBatch(DeviceField& dev, int64_t dim, std::vector<Pending*>& batch) {
+// One device batch: bring the mirror up to date for the batch's key (rows, graph, filter program, deleted bitset), then ONE
+// eps_index_search over nq contiguous queries.  Returns the error text ("" = ok).
+std::string RunSearch(DeviceField& dev, int64_t dim, const Pending& h, const float* q, int64_t nq, int64_t* ids, float* dist, int32_t* cnt) {
   std::lock_guard<std::mutex> lk(dev.mu);
-  Pending& h = *batch[0];
   std::string err;
   auto fail = [&](const char* what) { err = std::string("gfx950 executor: ") + what + ": " + eps_index_last_error(dev.h); };
   const int64_t total_vector = h.segment->record_number_;
@@ -494,13 +496,6 @@ void RunBatch(DeviceField& dev, int64_t dim, std::vector<Pending*>& batch) {
     if (rc != EPS_OK) fail("filter program upload");
   }
   if (err.empty() && eps_index_set_deleted(dev.h, deleted.data(), (int64_t)deleted.size()) != EPS_OK) fail("deleted upload");
-  const int64_t nq = (int64_t)batch.size();
-  const int32_t k = h.k;
-  std::vector<float> q((size_t)nq * dim);
-  std::vector<int64_t> ids((size_t)nq * k);
-  std::vector<float> dist((size_t)nq * k);
-  std::vector<int32_t> cnt((size_t)nq);
-  for (int64_t i = 0; i < nq; ++i) std::memcpy(&q[(size_t)i * dim], batch[i]->query, sizeof(float) * dim);
   if (err.empty()) {
     eps_search_params p;
     eps_default_search_params(&p);
@@ -511,8 +506,21 @@ void RunBatch(DeviceField& dev, int64_t dim, std::vector<Pending*>& batch) {
     p.master_queue = h.L;
     p.local_queue = h.Lq;
     p.sync_interval = h.I;
-    if (eps_index_search(dev.h, q.data(), nq, k, &p, ids.data(), dist.data(), cnt.data()) != EPS_OK) fail("search");
+    if (eps_index_search(dev.h, q, nq, h.k, &p, ids, dist, cnt) != EPS_OK) fail("search");
   }
+  return err;
+}
+
+void RunBatch(DeviceField& dev, int64_t dim, std::vector<Pending*>& batch) {
+  Pending& h = *batch[0];
+  const int64_t nq = (int64_t)batch.size();
+  const int32_t k = h.k;
+  std::vector<float> q((size_t)nq * dim);
+  std::vector<int64_t> ids((size_t)nq * k);
+  std::vector<float> dist((size_t)nq * k);
+  std::vector<int32_t> cnt((size_t)nq);
+  for (int64_t i = 0; i < nq; ++i) std::memcpy(&q[(size_t)i * dim], batch[i]->query, sizeof(float) * dim);
+  const std::string err = RunSearch(dev, dim, h, q.data(), nq, ids.data(), dist.data(), cnt.data());
   for (int64_t i = 0; i < nq; ++i) {
     Pending& r = *batch[i];
     r.error = err;
@@ -525,31 +533,80 @@ void RunBatch(DeviceField& dev, int64_t dim, std::vector<Pending*>& batch) {
 }
 }  // namespace
 
+// the part of a request every member of a device batch must agree on (result count rules: see Search)
+void VecSearchExecutor::FillKey(Pending& me, vectordb::engine::TableSegmentMVP* table_segment, size_t limit, const std::vector<eps_filter_op>* program) {
+  if (program) me.program = *program;
+  me.segment = table_segment;
+  size_t want = limit;
+  if (!prefilter_enabled_) want = std::min<size_t>(want, (size_t)std::max<int64_t>(L_local_, 1));
+  want = std::min<size_t>(want, (size_t)std::max<int64_t>(table_segment->record_number_, 1));
+  if (want > ((size_t)1 << 20)) throw std::runtime_error("gfx950 executor: more than 1048576 results per query are not supported");
+  me.k = (int32_t)want;
+}
+
+// Additive batched entry (the reference is one vector per call: bindings/python/interface.cpp:260-331,
+// db_server.cpp:458-510, executor_pool.hpp:10-31): nq queries, row-major, answered by ONE eps_index_search when the filter is
+// empty or compiles to a device program - the same mirror synchronisation, the same mode selection and the same result caps
+// as nq calls of Search().  Filters with host-only leaves run query by query through Search().  ids / dist: [nq][width]
+// (-1 / +inf beyond counts[q]).
+Status VecSearchExecutor::SearchBatch(const float* queries, int64_t nq, vectordb::engine::TableSegmentMVP* table_segment, const size_t limit,
+                                      std::vector<ExprNodePtr>& filter_nodes, std::vector<int64_t>& ids, std::vector<float>& dist,
+                                      std::vector<int32_t>& counts, int32_t& width) {
+  width = 0;
+  ids.clear();
+  dist.clear();
+  counts.assign((size_t)std::max<int64_t>(nq, 0), 0);
+  if (!std::holds_alternative<DenseVectorColumnDataContainer>(vector_column_))
+    throw std::runtime_error("gfx950 executor: sparse-vector fields are not served by the device executor");
+  if (!dev_) throw std::runtime_error("no usable gfx950 device (libepsilla_gfx950 has no CPU fallback)");
+  if (nq <= 0 || limit == 0) return Status::OK();
+  const int root0 = static_cast<int>(filter_nodes.size()) - 1;
+  const bool unfiltered = root0 < 0 || (filter_nodes[root0]->node_type == NodeType::BoolConst && filter_nodes[root0]->bool_value);
+  std::vector<eps_filter_op> program;
+  bool on_device = unfiltered;
+  if (!unfiltered) {
+    Compiler c{filter_nodes, table_segment};
+    c.Logical((size_t)root0, true);
+    if (!c.host_only && c.out.size() <= 64) {
+      program.swap(c.out);
+      on_device = true;
+    }
+  }
+  if (on_device) {
+    Pending key;
+    FillKey(key, table_segment, limit, unfiltered ? nullptr : &program);
+    width = key.k;
+    ids.resize((size_t)nq * width);
+    dist.resize((size_t)nq * width);
+    const std::string err = RunSearch(*dev_, dimension_, key, queries, nq, ids.data(), dist.data(), counts.data());
+    if (!err.empty()) throw std::runtime_error(err);
+    return Status::OK();
+  }
+  // host-evaluated predicate: the reference's own walk per query
+  size_t w = std::min<size_t>(limit, (size_t)std::max<int64_t>((int64_t)table_segment->record_number_, 1));
+  if (!prefilter_enabled_) w = std::min<size_t>(w, (size_t)std::max<int64_t>(L_local_, 1));
+  width = (int32_t)w;
+  ids.assign((size_t)nq * width, -1);
+  dist.assign((size_t)nq * width, std::numeric_limits<float>::infinity());
+  for (int64_t q = 0; q < nq; ++q) {
+    int64_t rs = 0;
+    Search(const_cast<float*>(queries + q * dimension_), table_segment, limit, filter_nodes, rs);
+    rs = std::min<int64_t>(rs, width);
+    counts[(size_t)q] = (int32_t)rs;
+    for (int64_t i = 0; i < rs; ++i) {
+      ids[(size_t)q * width + i] = search_result_[i];
+      dist[(size_t)q * width + i] = (float)distance_[i];
+    }
+  }
+  return Status::OK();
+}
+
 Status VecSearchExecutor::SearchBatched(const float* query, vectordb::engine::TableSegmentMVP* table_segment, size_t limit,
                                         int64_t& result_size, const std::vector<eps_filter_op>* program) {
   DeviceField& dev = *dev_;
   Pending me;
-  if (program) me.program = *program;
   me.query = query;
-  me.segment = table_segment;
-  {
-    // same result-count rules as the unbatched path above
-    size_t want = limit;
-    if (!prefilter_enabled_) want = std::min<size_t>(want, (size_t)std::max<int64_t>(L_local_, 1));
-    want = std::min<size_t>(want, (size_t)std::max<int64_t>(table_segment->record_number_, 1));
-    if (want > ((size_t)1 << 20)) throw std::runtime_error("gfx950 executor: more than 1048576 results per query are not supported");
-    me.k = (int32_t)want;
-  }
-  me.graph_owner = ann_index_.get();
-  me.graph_n = total_indexed_vector_;
-  me.start_point = start_search_point_;
-  me.off = offset_table_;
-  me.nbr = neighbor_list_;
-  me.T = num_threads_;
-  me.L = L_master_;
-  me.Lq = L_local_;
-  me.I = subsearch_iterations_;
-  me.prefilter = prefilter_enabled_;
+  FillKey(me, table_segment, limit, program);
   std::unique_lock<std::mutex> lk(dev.qmu);
   dev.queue.push_back(&me);
   while (!me.done) {
@@ -560,7 +617,7 @@ Status VecSearchExecutor::SearchBatched(const float* query, vectordb::engine::Ta
     dev.busy = true;  // become the leader: serve the head of the queue and everything compatible with it
     std::vector<Pending*> batch;
     Pending* head = dev.queue.front();
-    for (auto it = dev.queue.begin(); it != dev.queue.end() && batch.size() < 256;) {
+    for (auto it = dev.queue.begin(); it != dev.queue.end() && batch.size() < 2048;) {   // (2048 = one filter slice of the matrix engine)
       if (SameKey(**it, *head)) {
         batch.push_back(*it);
         it = dev.queue.erase(it);

@@ -43,6 +43,7 @@ namespace execution {
 constexpr const int BruteforceThreshold = 512;  // reference :28
 
 struct DeviceField;  // shared per-field GPU mirror (dropin/vec_search_executor.cpp)
+struct Pending;      // one request of the micro-batcher (same file)
 
 class VecSearchExecutor {
  public:
@@ -78,7 +79,15 @@ class VecSearchExecutor {
                            const size_t skip, const size_t limit, vectordb::Json& primary_keys,
                            std::vector<vectordb::query::expr::ExprNodePtr>& filter_nodes, int64_t& result_size);
 
+  // Additive (the reference takes one vector per call): nq row-major queries answered by ONE device batch when
+  // the filter is empty or compiles to a device program, with the mode selection and result caps of nq Search() calls.
+  // ids / dist: [nq][width] (-1 / +inf beyond counts[q]).  Throws like Search().
+  Status SearchBatch(const float* queries, int64_t nq, vectordb::engine::TableSegmentMVP* table_segment, const size_t limit,
+                     std::vector<vectordb::query::expr::ExprNodePtr>& filter_nodes, std::vector<int64_t>& ids, std::vector<float>& dist,
+                     std::vector<int32_t>& counts, int32_t& width);
+
  private:
+  void FillKey(Pending& key, vectordb::engine::TableSegmentMVP* table_segment, size_t limit, const std::vector<eps_filter_op>* program);
   // unfiltered queries and queries with a device-compiled filter: coalesced with the concurrent calls of the pool's other
   // executors that carry the same filter program into one device batch
   Status SearchBatched(const float* query, vectordb::engine::TableSegmentMVP* table_segment, size_t limit, int64_t& result_size,

@@ -5,7 +5,10 @@ module directory first on sys.path:
     python scripts/epsilla_module_driver.py MODULE_DIR DB_PATH cities|batch|c1 [rows] [dim] [queries]
   cities  the fixture of engine/test/bindings/python/test.py (5 cities, 3 metrics, filter, duplicate PK, delete)
   batch   rows x dim random table: query() one by one, then (drop-in only) rebuild() and query_batch()
-  c1      BASELINE configs[0]: rows x dim inserted through insert() in 1000-row JSON batches, `queries` query() calls"""
+  c1      BASELINE configs[0]: rows x dim inserted through insert() in 1000-row JSON batches, `queries` query() calls
+  bulk    rows x dim written as the reference's own table files (vectordb_amd/segment_file.py) and loaded by the reference's
+          loader (drop-in: load_db_scaled), then query() for the first 16 queries and query_batch() for all of them as ONE NumPy
+          matrix, unfiltered and with "ID < rows/2"; args: rows dim queries [metric] [batches]"""
 import json
 import sys
 import time
@@ -29,6 +32,70 @@ def create_table(name, fields):
     ctypes.pythonapi.Py_IncRef(ctypes.py_object(fields))
     return epsilla.create_table(table_name=name, table_fields=fields)
 
+
+if what == "bulk":
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from vectordb_amd.segment_file import write_database
+    metric = sys.argv[7] if len(sys.argv) > 7 else "EUCLIDEAN"
+    batches = int(sys.argv[8]) if len(sys.argv) > 8 else 3
+    rng = np.random.default_rng(42)
+    t0 = time.perf_counter()
+    X = np.empty((rows, dim), np.float32)
+    for s in range(0, rows, 1 << 18):
+        X[s:s + (1 << 18)] = rng.random((min(1 << 18, rows - s), dim), dtype=np.float32)
+    if metric == "COSINE":
+        for s in range(0, rows, 1 << 18):
+            X[s:s + (1 << 18)] /= np.linalg.norm(X[s:s + (1 << 18)], axis=1, keepdims=True)
+    Q = np.random.default_rng(43).random((nq, dim), dtype=np.float32)
+    out["generate_s"] = time.perf_counter() - t0
+    fields = [{"name": "ID", "dataType": "INT", "primaryKey": True},
+              {"name": "V", "dataType": "VECTOR_FLOAT", "dimensions": dim, "metricType": metric}]
+    t0 = time.perf_counter()
+    write_database(db_path, "T", fields, {"ID": np.arange(rows, dtype=np.int32), "V": X})
+    out["write_files_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    if hasattr(epsilla, "load_db_scaled"):
+        assert epsilla.load_db_scaled(db_name="db", db_path=db_path, vector_scale=rows + 1024, wal_enabled=False) == 0
+    else:
+        assert rows <= 150000, "the reference binding loads at most 150000 rows per table"
+        assert epsilla.load_db(db_name="db", db_path=db_path) == 0
+    epsilla.use_db(db_name="db")
+    out["load_db_s"] = time.perf_counter() - t0
+    kw = dict(table_name="T", query_field="V", response_fields=["ID"], limit=10, with_distance=True)
+    out["single"] = {}
+    for flt in ("", "ID < %d" % (rows // 2)):
+        t0 = time.perf_counter()
+        res = []
+        for q in Q[:16]:
+            code, resp = epsilla.query(query_vector=q.tolist(), filter=flt, **kw)
+            res.append([[r["ID"] for r in resp], [r["@distance"] for r in resp]])
+        out["single"][flt] = {"results": res, "first16_s": time.perf_counter() - t0}
+    if hasattr(epsilla, "query_batch"):
+        out["batch"] = {}
+        for flt in ("", "ID < %d" % (rows // 2)):
+            code, resp = epsilla.query_batch(query_vectors=Q, filter=flt, **kw)          # (warm: mirrors, filter program)
+            t0 = time.perf_counter()
+            for _ in range(batches):
+                code, resp = epsilla.query_batch(query_vectors=Q, filter=flt, **kw)
+            sec = (time.perf_counter() - t0) / batches
+            assert code == 0 and len(resp) == nq
+            out["batch"][flt] = {"qps": nq / sec, "ms_per_batch": 1e3 * sec, "queries": nq, "batches": batches,
+                                 "results": [[[r["ID"] for r in rr], [r["@distance"] for r in rr]] for rr in resp[:64]]}
+        code, resp2 = epsilla.query_batch(query_vectors=[q.tolist() for q in Q[:8]], filter="", **kw)   # list-of-lists form
+        out["batch"]["lists"] = [[[r["ID"] for r in rr], [r["@distance"] for r in rr]] for rr in resp2]
+        code, resp3 = epsilla.query_batch(query_vectors=Q[:4].astype(np.float64), filter="", table_name="T", query_field="V", response_fields=[],
+                                          limit=3, with_distance=False)                               # all fields, float64 queries
+        out["batch"]["all_fields_keys"] = sorted(resp3[0][0].keys())
+        out["batch"]["all_fields_ids"] = [[r["ID"] for r in rr] for rr in resp3]
+        # exact ground truth of the first queries straight from the rows (numpy, float64)
+    gt = []
+    for q in Q[:4]:
+        d = ((X.astype(np.float64) - q) ** 2).sum(1) if metric == "EUCLIDEAN" and rows <= 2_000_000 else None
+        gt.append(None if d is None else np.argsort(d, kind="stable")[:10].tolist())
+    out["numpy_top10"] = gt
+    print("EPSILLA_JSON " + json.dumps(out))
+    sys.exit(0)
 
 assert epsilla.load_db(db_name="db", db_path=db_path) == 0
 epsilla.use_db(db_name="db")

@@ -95,6 +95,37 @@ def test_gfx950_module_rebuild_and_query_batch():
             assert np.allclose(flat[i][1], ref["flat"]["results"][i][1], rtol=1e-4)
 
 
+@pytest.mark.gpu
+def test_gfx950_module_query_batch_is_one_device_batch_and_equals_single_queries(tmp_path):
+    """query_batch() takes the N vectors as ONE matrix (NumPy float32; also float64 and lists of lists), issues
+    ONE eps_index_search(nq = N) through VecSearchExecutor::SearchBatch and projects once.  Element q equals query(vector q) - ids
+    position by position, distances to 1e-6 - unfiltered and with an attribute filter (compiled to the device program); the table
+    is brought in through the reference's own file loader from files written in its format (100 000 rows: within the reference
+    binding's own 150 000-row capacity, so its module loads the same files side by side)."""
+    if not _have(GPU_DIR):
+        pytest.skip("dropin/_build/epsilla.so not built (make -C dropin)")
+    rows, dim, nq = 100_000, 64, 300
+    out = _run(GPU_DIR, "bulk", rows, dim, nq)
+    for flt in ("", "ID < %d" % (rows // 2)):
+        single, batch = out["single"][flt]["results"], out["batch"][flt]["results"]
+        for i in range(16):
+            assert single[i][0] == batch[i][0], (flt, i, single[i], batch[i])
+            assert np.allclose(single[i][1], batch[i][1], rtol=1e-6, atol=0)
+            if flt:
+                assert max(batch[i][0]) < rows // 2
+    for i in range(4):
+        assert out["batch"][""]["results"][i][0] == out["numpy_top10"][i], i
+    assert out["batch"]["lists"] == out["batch"][""]["results"][:8]
+    assert out["batch"]["all_fields_keys"] == ["ID", "V"]
+    assert out["batch"]["all_fields_ids"] == [r[0][:3] for r in out["batch"][""]["results"][:4]]
+    if _have(REF_DIR):   # the reference's own module over the same files
+        ref = _run(REF_DIR, "bulk", rows, dim, 16)
+        for flt in ("", "ID < %d" % (rows // 2)):
+            for i in range(16):
+                assert ref["single"][flt]["results"][i][0] == out["single"][flt]["results"][i][0], (flt, i)
+                assert np.allclose(ref["single"][flt]["results"][i][1], out["single"][flt]["results"][i][1], rtol=1e-4)
+
+
 def test_gfx950_module_loads_on_cpu_and_refuses_to_search_without_a_gpu():
     """CPU: the drop-in module imports (the reference binding's 8 methods + rebuild + query_batch), ingests through the unchanged
     DBServer, and a query fails loudly when no gfx950 device is usable - there is no CPU fallback behind the binding either."""
@@ -105,7 +136,7 @@ def test_gfx950_module_loads_on_cpu_and_refuses_to_search_without_a_gpu():
 import sys, ctypes
 sys.path.insert(0, %r)
 import epsilla
-names = ["load_db", "unload_db", "use_db", "create_table", "insert", "query", "drop_table", "delete", "rebuild", "query_batch"]
+names = ["load_db", "unload_db", "use_db", "create_table", "insert", "query", "drop_table", "delete", "rebuild", "query_batch", "load_db_scaled"]
 assert all(hasattr(epsilla, n) for n in names), [n for n in names if not hasattr(epsilla, n)]
 assert epsilla.backend == "gfx950"
 assert epsilla.load_db(db_name="db", db_path=sys.argv[1]) == 0
