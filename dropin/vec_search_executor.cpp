@@ -542,6 +542,16 @@ void VecSearchExecutor::FillKey(Pending& me, vectordb::engine::TableSegmentMVP* 
   want = std::min<size_t>(want, (size_t)std::max<int64_t>(table_segment->record_number_, 1));
   if (want > ((size_t)1 << 20)) throw std::runtime_error("gfx950 executor: more than 1048576 results per query are not supported");
   me.k = (int32_t)want;
+  me.graph_owner = ann_index_.get();
+  me.graph_n = total_indexed_vector_;
+  me.start_point = start_search_point_;
+  me.off = offset_table_;
+  me.nbr = neighbor_list_;
+  me.T = num_threads_;
+  me.L = L_master_;
+  me.Lq = L_local_;
+  me.I = subsearch_iterations_;
+  me.prefilter = prefilter_enabled_;
 }
 
 // Additive batched entry (the reference is one vector per call: bindings/python/interface.cpp:260-331,
