@@ -332,6 +332,9 @@ class Ref:
         dptr = C.POINTER(C.c_double)
         L.ref_bruteforce_many.restype = C.c_double
         L.ref_bruteforce_many.argtypes = [C.c_void_p, i64, i64, C.c_int, C.c_int, fptr, i64, i64, iptr, fptr, dptr]
+        if hasattr(L, "ref_prefilter_many"):
+            L.ref_prefilter_many.restype = C.c_double
+            L.ref_prefilter_many.argtypes = [C.c_void_p, i64, i64, C.c_int, C.c_int, C.c_void_p, C.c_char_p, fptr, i64, i64, iptr, fptr, iptr, dptr]
         L.ref_pool_search.restype = C.c_double
         L.ref_pool_search.argtypes = [vp, C.c_void_p, i64, C.c_int, C.c_int, C.c_int, i64, i64, fptr, i64, i64, iptr, fptr, dptr]
         L.ref_dist_calls_reset.restype = C.c_uint64
@@ -464,6 +467,22 @@ class Ref:
         self.L.ref_bruteforce_many(rows_ptr, n, d, metric, threads, _f(Q), nq, k, _i(ids), _f(ds),
                                    sec.ctypes.data_as(C.POINTER(C.c_double)))
         return ids, ds, sec
+
+    def prefilter_many(self, rows_ptr, n, d, id_column, flt, Q, k, metric=0, threads=1):
+        """the reference's PreFilterBruteForceSearch (:770-831) per query under the filter text `flt` over one INT4 attribute
+        "ID" (id_column: int32[n], C-contiguous, kept alive by the caller); returns ids, dists, visible-row counts, seconds"""
+        Q = np.ascontiguousarray(Q, np.float32)
+        nq = Q.shape[0]
+        ids = np.empty((nq, k), np.int64)
+        ds = np.empty((nq, k), np.float32)
+        cnt = np.empty(nq, np.int64)
+        sec = np.empty(nq, np.float64)
+        assert id_column.dtype == np.int32 and id_column.flags.c_contiguous and id_column.shape[0] == n
+        r = self.L.ref_prefilter_many(rows_ptr, n, d, metric, threads, id_column.ctypes.data_as(C.c_void_p), flt.encode(), _f(Q), nq, k, _i(ids), _f(ds),
+                                      _i(cnt), sec.ctypes.data_as(C.POINTER(C.c_double)))
+        if r < 0:
+            raise ValueError("the reference could not parse the filter %r" % flt)
+        return ids, ds, cnt, sec
 
     def pool_search(self, g, rows_ptr, d, Q, K, E, T, L, I=15, metric=0):
         """E executors x T OpenMP workers (the reference's ExecutorPool concurrency); returns ids, dists, latencies, wall s"""

@@ -33,6 +33,7 @@
 #include "db/index/distances.hpp"
 #include "db/index/knn/knn.hpp"
 #include "db/index/nsg/nsg.hpp"
+#include "query/expr/expr.hpp"
 #include "query/expr/expr_evaluator.hpp"
 #include "utils/concurrent_bitset.hpp"
 
@@ -318,6 +319,44 @@ double ref_bruteforce_many(float* rows, int64_t n, int64_t d, int metric, int th
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     total += sec;
     if (per_query_s) per_query_s[q] = sec;
+    for (int64_t i = 0; i < k; ++i) {
+      const bool ok = i < (int64_t)ex.brute_force_queue_.size();
+      ids[q * k + i] = ok ? ex.brute_force_queue_[i].id_ : -1;
+      dists[q * k + i] = ok ? ex.brute_force_queue_[i].distance_ : 0.f;
+    }
+  }
+  return total;
+}
+
+// The reference's own PreFilterBruteForceSearch (vec_search_executor.cpp:770-831) with a real filter expression: `filter` is
+// parsed by the reference's Expr::ParseNodeFromStr over a table with ONE INT4 attribute "ID" whose packed attribute rows are
+// `id_column` (4 bytes per row), and evaluated per row by the reference's ExprEvaluator::LogicalEvaluate - BASELINE configs[3]
+// ("COSINE + ID<N metadata filter") on the reference side.  Returns the total seconds; result counts in counts[q].
+double ref_prefilter_many(float* rows, int64_t n, int64_t d, int metric, int threads, int32_t* id_column, const char* filter, float* queries,
+                          int64_t nq, int64_t k, int64_t* ids, float* dists, int64_t* counts, double* per_query_s) {
+  auto g = std::make_shared<ANNGraphSegment>(true);
+  size_t dim = (size_t)d;
+  vectordb::DistFunc df = vectordb::GetDistFunc(meta::FieldType::VECTOR_FLOAT, ToMetric(metric));
+  VecSearchExecutor ex(d, 0, g, nullptr, nullptr, rows, df, &dim, threads, 500, 500, 15, true);
+  vectordb::ConcurrentBitset deleted(n);
+  std::vector<vectordb::query::expr::ExprNodePtr> nodes;
+  std::unordered_map<std::string, meta::FieldType> field_map{{"ID", meta::FieldType::INT4}};
+  auto st = vectordb::query::expr::Expr::ParseNodeFromStr(filter, nodes, field_map);
+  if (!st.ok()) return -1.0;
+  std::unordered_map<std::string, size_t> offs{{"ID", 0}};
+  int64_t prim = 4, nvar = 0;
+  std::vector<vectordb::engine::VariableLenAttrColumnContainer> var;
+  vectordb::query::expr::ExprEvaluator ev(nodes, offs, prim, nvar, reinterpret_cast<char*>(id_column), var);
+  const int root = (int)nodes.size() - 1;
+  double total = 0;
+  for (int64_t q = 0; q < nq; ++q) {
+    omp_set_num_threads(threads);
+    auto t0 = std::chrono::steady_clock::now();
+    ex.PreFilterBruteForceSearch(queries + q * d, 0, n, deleted, ev, nullptr, root);
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    total += sec;
+    if (per_query_s) per_query_s[q] = sec;
+    if (counts) counts[q] = (int64_t)ex.brute_force_queue_.size();
     for (int64_t i = 0; i < k; ++i) {
       const bool ok = i < (int64_t)ex.brute_force_queue_.size();
       ids[q * k + i] = ok ? ex.brute_force_queue_[i].id_ : -1;

@@ -1,0 +1,115 @@
+"""Parity at BASELINE.json's full sizes (configs[2] and configs[3]: 10M x 768, k = 10, batch 1024, one MI355X) against the
+COMPILED REFERENCE (oracle/_ref = the reference's own sources): position-wise ids, distances to 1e-4 - not set recall.
+
+  configs[2]  L2: eps_index_search (EPS_FLAT_AUTO -> int8 matrix filter + fp32 re-rank) vs the reference's BruteForceSearch
+              (engine/db/execution/vec_search_executor.cpp:717-768) on 8 of the 1024 queries, the fp32 stream engine on 64, and
+              size-independent properties on all 1024 (sorted by (dist, id), unique ids, k results);
+  configs[3]  COSINE on rows normalised as at insert (db/table_segment_mvp.cpp:574-587) + `ID < N` at 10 / 50 / 90 % selectivity
+              (Config::PreFilter semantics) vs the reference's PreFilterBruteForceSearch (:770-831) driven by the reference's own
+              filter parser and ExprEvaluator, 2-3 queries per selectivity.
+
+The 10M-row table is generated on the device (seeded), copied once to page-aligned host memory for the reference (30.7 GB).
+Needs ~31 GB of host memory and ~45 GB of HBM; takes about a minute, most of it the reference's scans."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import assert_topk_match
+
+pytestmark = pytest.mark.gpu
+N, D, B, K = 10_000_000, 768, 1024, 10
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import vectordb_amd
+    from vectordb_amd.build import build
+    build()
+    return vectordb_amd
+
+
+@pytest.fixture(scope="module")
+def table(ref):
+    import torch
+    if torch.cuda.mem_get_info(0)[0] < 60 << 30:
+        pytest.skip("needs ~45 GB of free HBM")
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(42)
+    X = torch.empty((N, D), dtype=torch.float32, device=dev)
+    for s in range(0, N, 1 << 19):
+        e = min(N, s + (1 << 19))
+        X[s:e] = torch.rand((e - s, D), generator=g, device=dev)
+    Q = torch.rand((B, D), generator=torch.Generator(device=dev).manual_seed(43), device=dev)
+    threads = int(ref.L.ref_omp_max_threads())
+    arr, ptr = ref.alloc_rows(N, D, threads)
+    state = {"X": X, "Q": Q, "arr": arr, "ptr": ptr, "threads": threads, "torch": torch, "dev": dev}
+    yield state
+    ref.free_rows(ptr)
+
+
+def _to_host(t):
+    X, arr = t["X"], t["arr"]
+    for s in range(0, N, 1 << 19):
+        e = min(N, s + (1 << 19))
+        arr[s:e] = X[s:e].cpu().numpy()
+
+
+def _search(amd, t, ix, n_queries, **kw):
+    torch = t["torch"]
+    ids = torch.empty((n_queries, K), dtype=torch.int64, device=t["dev"])
+    dd = torch.empty((n_queries, K), dtype=torch.float32, device=t["dev"])
+    cnt = torch.empty((n_queries,), dtype=torch.int32, device=t["dev"])
+    ix.search(t["Q"][:n_queries], K, out=(ids, dd, cnt), **kw)
+    ix.synchronize()
+    return ids.cpu().numpy(), dd.cpu().numpy(), cnt.cpu().numpy(), ix.stats()
+
+
+def test_configs2_10M_x_768_L2_batch_1024_matches_the_reference_bruteforce(amd, ref, table):
+    t = table
+    _to_host(t)
+    ix = amd.GpuIndex(D, "EUCLIDEAN", device=0).use_torch_stream()
+    ix.attach_rows(t["X"])
+    ids, dd, cnt, st = _search(amd, t, ix, B, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_AUTO)
+    assert st["main_kernel_bits"] == 8 and st["overflow_queries"] == 0 and st["rerank_rows"] > 0, st   # the headline path itself
+    # the reference, same rows, same queries
+    nref = 8
+    rid, rd, sec = ref.bruteforce_many(t["ptr"], N, D, t["Q"][:nref].cpu().numpy(), K, metric=0, threads=t["threads"])
+    for q in range(nref):
+        assert_topk_match(ids[q], dd[q], rid[q], rd[q], what="configs[2] q%d" % q)
+    # the fp32 stream engine (the library's other exact path), bit for bit on 64 queries
+    sid, sd, scnt, _ = _search(amd, t, ix, 64, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
+    assert np.array_equal(ids[:64], sid) and np.array_equal(dd[:64], sd)
+    # size-independent properties on the whole batch
+    assert (cnt == K).all() and (ids >= 0).all() and (ids < N).all()
+    assert (np.diff(dd, axis=1) >= 0).all()
+    assert all(len(set(r.tolist())) == K for r in ids)
+    tie = np.diff(dd, axis=1) == 0
+    assert (np.diff(ids, axis=1)[tie] > 0).all()          # equal distances are ordered by id (Candidate::operator<)
+    ix.close()
+
+
+def test_configs3_10M_x_768_cosine_with_id_filter_matches_the_reference_prefilter(amd, ref, table):
+    t = table
+    torch = t["torch"]
+    amd.normalize_rows(t["X"], only_if_nonzero=True, device=0, stream=torch.cuda.current_stream().cuda_stream)   # as at insert
+    amd.normalize_rows(t["Q"], only_if_nonzero=False, device=0, stream=torch.cuda.current_stream().cuda_stream)  # as TableMVP::Search
+    torch.cuda.synchronize()
+    _to_host(t)
+    idc = torch.arange(N, dtype=torch.int32, device=t["dev"])
+    idc_host = np.arange(N, dtype=np.int32)
+    ix = amd.GpuIndex(D, "COSINE", device=0).use_torch_stream()
+    ix.attach_rows(t["X"])
+    for sel in (0.5, 0.1, 0.9):
+        qh = t["Q"][:3 if sel == 0.5 else 2].cpu().numpy()   # (the reference evaluates its expression tree on all 10M rows per query: ~5 s each)
+        bound = int(N * sel)
+        ix.set_int_filter(idc, "<", bound)
+        ids, dd, cnt, st = _search(amd, t, ix, B, mode=amd.MODE_REFERENCE, prefilter=1)
+        assert st["main_kernel_bits"] == 8, st
+        assert (cnt == K).all() and (ids < bound).all() and (ids >= 0).all()
+        assert (np.diff(dd, axis=1) >= 0).all()
+        rid, rd, rcnt, sec = ref.prefilter_many(t["ptr"], N, D, idc_host, "ID < %d" % bound, qh, K, metric=1, threads=t["threads"])
+        assert (rcnt == bound).all()
+        for q in range(len(qh)):
+            assert_topk_match(ids[q], dd[q], rid[q], rd[q], what="configs[3] %d%% q%d" % (int(sel * 100), q))
+    ix.close()
