@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--graph-rows", type=int, default=1_000_000, help="rows of the secondary traversal measurement (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline legs (0 = skip)")
     ap.add_argument("--scale", default="rows", choices=["queries", "rows"])
+    ap.add_argument("--configs", default="c2,c4", help="further BASELINE configs measured into the line's `configs` object at N = 1: c2 (1M x 768, batch 1, latency), "
+                                                     "c4 (COSINE + ID < N filter on the --rows table, batch --batch); 'none' skips them")
     return ap.parse_args()
 
 
@@ -113,21 +115,40 @@ def recall_of(got, want):
     return float(np.mean([len(set(got[i].tolist()) & set(want[i].tolist())) / float(want.shape[1]) for i in range(len(want))]))
 
 
-def cpu_baseline(args, torch, X, Q, gt_ids, graph, budget_s):
-    """The reference's own CPU paths (oracle/_ref = the reference's sources compiled verbatim) timed on this box's host
-    cores on the SAME rows, bounded by sampling queries, not rows:
-      leg "bruteforce": VecSearchExecutor::BruteForceSearch (:717-768) over all rows, OpenMP over all cores - exact, so it
-                        is the reference's answer at recall >= 0.999 whenever its traversal needs a queue so long that it
-                        evaluates most of the table (uniform data: profiles/r2_graph_*.jsonl);
-      leg "graph":      SearchImpl under the reference's concurrency model, E executors x T OpenMP workers = cores, at
-                        the reference's default SearchQueueSize, on the device-built graph of the first rows (if any).
-    Reported baseline only - never part of the product path."""
-    from oracle import pyoracle
-    cores = os.cpu_count() or 1
-    n, d = X.shape
-    k = args.k
-    if not pyoracle.ref_available():
-        orc = pyoracle.Oracle()                       # plain-C restatement, scalar: a far weaker baseline, labelled "port"
+class CpuBaseline:
+    """The reference's own CPU paths (oracle/_ref = the reference's sources compiled verbatim) timed on this box's host cores on
+    the SAME rows, bounded by sampling queries, not rows.  Reported baselines only - never part of the product
+    path; everything under oracle/ that bench.py touches is touched in this class."""
+
+    def __init__(self, torch, X):
+        from oracle import pyoracle
+        self.py = pyoracle
+        self.torch = torch
+        self.n, self.d = X.shape
+        self.cores = os.cpu_count() or 1
+        self.ref = pyoracle.Ref() if pyoracle.ref_available() else None
+        self.ptr = None
+        if self.ref is not None:
+            self.threads = int(self.ref.L.ref_omp_max_threads())
+            self.arr, self.ptr = self.ref.alloc_rows(self.n, self.d, self.threads)   # page-aligned, first-touched by the scan's own OpenMP schedule
+            self.copy_s = self.load(X)
+
+    def load(self, X):
+        t0 = time.time()
+        step = 1 << 19
+        for s in range(0, self.n, step):
+            e = min(self.n, s + step)
+            self.arr[s:e] = X[s:e].cpu().numpy()
+        return time.time() - t0
+
+    def close(self):
+        if self.ptr is not None:
+            self.ref.free_rows(self.ptr)
+            self.ptr = None
+
+    def port(self, X, Q, budget_s):
+        """oracle/_ref absent: the plain-C restatement, scalar - a far weaker baseline, labelled "port" """
+        orc = self.py.Oracle()
         rows = X[:200_000].cpu().numpy()
         q = Q[0].cpu().numpy()
         t0 = time.time()
@@ -136,77 +157,207 @@ def cpu_baseline(args, torch, X, Q, gt_ids, graph, budget_s):
             orc.dist_batch(0, rows, q)
             done += 1
         sec = time.time() - t0
-        return {"value": done * rows.shape[0] / sec / n, "unit": "queries/s", "cores": 1, "kind": "port",
-                "sample": "%d scalar scans of a %d-row sample, scaled to %d rows (oracle/_ref absent)" % (done, rows.shape[0], n)}
-    ref = pyoracle.Ref()
-    threads = int(ref.L.ref_omp_max_threads())
-    t0 = time.time()
-    arr, ptr = ref.alloc_rows(n, d, threads)            # page-aligned, first-touched by the scan's own OpenMP schedule
-    step = 1 << 19
-    for s in range(0, n, step):
-        e = min(n, s + step)
-        arr[s:e] = X[s:e].cpu().numpy()
-    copy_s = time.time() - t0
-    legs = []
-    Qh = Q.cpu().numpy()
-    # ---- leg: reference brute force over all rows
-    nb = 2
-    ids, ds, sec = ref.bruteforce_many(ptr, n, d, Qh[:nb], k, threads=threads)
-    per = float(np.mean(sec[1:])) if nb > 1 else float(sec[0])
-    more = int(max(0, min(len(Qh) - nb, (budget_s * 0.6 - float(np.sum(sec))) / max(per, 1e-3))))
-    if more > 0:
-        ids2, ds2, sec2 = ref.bruteforce_many(ptr, n, d, Qh[nb:nb + more], k, threads=threads)
-        ids, sec = np.concatenate([ids, ids2]), np.concatenate([sec, sec2])
-    nbq = len(sec)
-    bf_qps = (nbq - 1) / float(np.sum(sec[1:])) if nbq > 1 else 1.0 / float(sec[0])   # first query pays the scratch allocation
-    legs.append({"leg": "bruteforce", "what": "reference VecSearchExecutor::BruteForceSearch over %d x %d rows, %d OpenMP threads" % (n, d, threads),
-                 "qps": bf_qps, "queries": nbq, "p50_ms": 1e3 * float(np.median(sec)), "p99_ms": 1e3 * float(np.max(sec)),
-                 "recall_at_10": recall_of(ids, gt_ids[:nbq]), "evals_per_query": n,
-                 "effective_GBps": bf_qps * n * d * 4 / 1e9})
-    # ---- leg: the distance phase of that brute force on its own (GetDistFunc under `omp parallel for`, :729-735) + an O(n)
-    # top-k selection instead of the reference's serial compaction and std::sort of all n candidates: what the host's memory
-    # system delivers to the reference's distance kernel
-    try:
-        t0 = time.time()
-        nscan = 0
-        sel_ids = []
-        while nscan < min(4, len(Qh)) and (nscan == 0 or time.time() - t0 < budget_s * 0.1):
-            dist = ref.dist_batch(0, arr, Qh[nscan])
-            idx = np.argpartition(dist, k)[:k]
-            sel_ids.append(idx[np.lexsort((idx, dist[idx]))])
-            nscan += 1
-        sec_scan = (time.time() - t0) / nscan
-        legs.append({"leg": "distance_scan_only", "what": "reference fvec_L2sqr via GetDistFunc over %d x %d rows under omp parallel for (%d threads) + numpy argpartition top-%d; "
-                                                         "not a path the reference has (its BruteForceSearch adds a serial compaction and a std::sort of all candidates)" % (n, d, threads, k),
-                     "qps": 1.0 / sec_scan, "queries": nscan, "recall_at_10": recall_of(np.stack(sel_ids), gt_ids[:nscan]), "effective_GBps": n * d * 4 / sec_scan / 1e9})
-    except Exception as e:   # a report only
-        legs.append({"leg": "distance_scan_only", "what": "failed: %r" % (e,), "qps": 0.0, "queries": 0, "recall_at_10": 0.0})
-    # ---- leg: reference graph search, E executors x T workers
-    if graph is not None:
+        return {"value": done * rows.shape[0] / sec / self.n, "unit": "queries/s", "cores": 1, "kind": "port",
+                "sample": "%d scalar scans of a %d-row sample, scaled to %d rows (oracle/_ref absent)" % (done, rows.shape[0], self.n)}
+
+    def bruteforce(self, Qh, k, gt_ids, budget_s, rows=None, metric=0):
+        """leg "bruteforce": VecSearchExecutor::BruteForceSearch (:717-768) over the first `rows` rows, OpenMP over all cores -
+        exact, so it is the reference's answer at recall >= 0.999 whenever its traversal needs a queue so long that it evaluates
+        most of the table (uniform data: profiles/r2_graph_*.jsonl)"""
+        ref, n, d, threads = self.ref, rows or self.n, self.d, self.threads
+        nb = 2
+        ids, ds, sec = ref.bruteforce_many(self.ptr, n, d, Qh[:nb], k, metric=metric, threads=threads)
+        per = float(np.mean(sec[1:])) if nb > 1 else float(sec[0])
+        more = int(max(0, min(len(Qh) - nb, (budget_s - float(np.sum(sec))) / max(per, 1e-3))))
+        if more > 0:
+            ids2, ds2, sec2 = ref.bruteforce_many(self.ptr, n, d, Qh[nb:nb + more], k, metric=metric, threads=threads)
+            ids, sec = np.concatenate([ids, ids2]), np.concatenate([sec, sec2])
+        nbq = len(sec)
+        qps = (nbq - 1) / float(np.sum(sec[1:])) if nbq > 1 else 1.0 / float(sec[0])   # first query pays the scratch allocation
+        return {"leg": "bruteforce", "what": "reference VecSearchExecutor::BruteForceSearch over %d x %d rows, %d OpenMP threads" % (n, d, threads),
+                "qps": qps, "queries": nbq, "p50_ms": 1e3 * float(np.median(sec[1:] if nbq > 1 else sec)), "p99_ms": 1e3 * float(np.max(sec[1:] if nbq > 1 else sec)),
+                "recall_at_10": recall_of(ids, gt_ids[:nbq]) if gt_ids is not None else None, "evals_per_query": n, "effective_GBps": qps * n * d * 4 / 1e9}
+
+    def distance_scan(self, Qh, k, gt_ids, budget_s):
+        """the distance phase of that brute force on its own (GetDistFunc under `omp parallel for`, :729-735) + an O(n) top-k
+        selection instead of the reference's serial compaction and std::sort of all n candidates: what the host's memory system
+        delivers to the reference's distance kernel"""
+        try:
+            t0 = time.time()
+            nscan = 0
+            sel_ids = []
+            while nscan < min(4, len(Qh)) and (nscan == 0 or time.time() - t0 < budget_s):
+                dist = self.ref.dist_batch(0, self.arr, Qh[nscan])
+                idx = np.argpartition(dist, k)[:k]
+                sel_ids.append(idx[np.lexsort((idx, dist[idx]))])
+                nscan += 1
+            sec_scan = (time.time() - t0) / nscan
+            return {"leg": "distance_scan_only",
+                    "what": "reference fvec_L2sqr via GetDistFunc over %d x %d rows under omp parallel for (%d threads) + numpy argpartition top-%d; "
+                            "not a path the reference has (its BruteForceSearch adds a serial compaction and a std::sort of all candidates)" % (self.n, self.d, self.threads, k),
+                    "qps": 1.0 / sec_scan, "queries": nscan, "recall_at_10": recall_of(np.stack(sel_ids), gt_ids[:nscan]), "effective_GBps": self.n * self.d * 4 / sec_scan / 1e9}
+        except Exception as e:   # a report only
+            return {"leg": "distance_scan_only", "what": "failed: %r" % (e,), "qps": 0.0, "queries": 0, "recall_at_10": 0.0}
+
+    def graph(self, graph, Qh, k, Lcpu, budget_s, E=None, T=4):
+        """leg "graph": SearchImpl under the reference's concurrency model, E executors x T OpenMP workers (E x T = cores by default;
+        E = 1: single-query latency), at SearchQueueSize Lcpu, on the device-built graph of the first rows"""
+        ref = self.ref
         off, nbr, nav, gn, ggt = graph
         g = ref.graph_from_arrays(off, nbr, nav)
-        T = 4
-        Lcpu = args.L if args.mode == "graph" else 500
-        E = max(1, threads // T)
-        nqg = min(len(Qh), 4 * E)
-        ids_g, ds_g, lat, wall = ref.pool_search(g, ptr, d, Qh[:nqg], k, E=E, T=T, L=Lcpu)
-        reps = int(max(0, min(16, (budget_s * 0.3) / max(wall, 1e-3) - 1)))
-        if reps > 0:
+        E = E or max(1, self.threads // T)
+        nqg = min(len(Qh), 4 * E if E > 1 else 32)
+        ids_g, ds_g, lat, wall = ref.pool_search(g, self.ptr, self.d, Qh[:nqg], k, E=E, T=T, L=Lcpu)
+        reps = int(max(0, min(16, budget_s / max(wall, 1e-3) - 1)))
+        if reps > 0 and E > 1:
             nqg2 = min(len(Qh), nqg * (reps + 1))
-            ids_g, ds_g, lat, wall = ref.pool_search(g, ptr, d, Qh[:nqg2], k, E=E, T=T, L=Lcpu)
+            ids_g, ds_g, lat, wall = ref.pool_search(g, self.ptr, self.d, Qh[:nqg2], k, E=E, T=T, L=Lcpu)
             nqg = nqg2
-        legs.append({"leg": "graph", "what": "reference SearchImpl on the device-built graph of the first %d rows, %d executors x %d OpenMP workers, SearchQueueSize %d" % (gn, E, T, Lcpu),
-                     "qps": nqg / wall, "queries": nqg, "p50_ms": 1e3 * float(np.median(lat)), "p99_ms": 1e3 * float(np.percentile(lat, 99)),
-                     "recall_at_10": recall_of(ids_g, ggt[:nqg]), "rows": gn})
         ref.L.ref_graph_free(g)
-    ref.free_rows(ptr)
+        return {"leg": "graph", "what": "reference SearchImpl on the device-built graph of the first %d rows, %d executor(s) x %d OpenMP workers, SearchQueueSize %d" % (gn, E, T, Lcpu),
+                "qps": nqg / wall, "queries": nqg, "p50_ms": 1e3 * float(np.median(lat)), "p99_ms": 1e3 * float(np.percentile(lat, 99)),
+                "recall_at_10": recall_of(ids_g, ggt[:nqg]), "rows": gn}
+
+    def prefilter(self, idc_host, flt, Qh, k, metric, gt_ids=None):
+        """the reference's PreFilterBruteForceSearch (:770-831) with its own filter parser / ExprEvaluator (BASELINE configs[3])"""
+        ids, ds, cnt, sec = self.ref.prefilter_many(self.ptr, self.n, self.d, idc_host, flt, Qh, k, metric=metric, threads=self.threads)
+        return {"leg": "prefilter_bruteforce", "what": "reference PreFilterBruteForceSearch, filter %r, %d x %d rows, %d OpenMP threads" % (flt, self.n, self.d, self.threads),
+                "qps": len(sec) / float(np.sum(sec)), "queries": len(sec), "p50_ms": 1e3 * float(np.median(sec)), "p99_ms": 1e3 * float(np.max(sec)),
+                "visible_rows": int(cnt[0]), "recall_at_10": recall_of(ids, gt_ids[:len(sec)]) if gt_ids is not None else None}
+
+
+def cpu_baseline(cpu, args, X, Q, gt_ids, graph, budget_s):
+    """the `cpu_baseline` object of the headline line (BASELINE configs[2]): legs bruteforce / distance_scan_only / graph"""
+    n, d, k = cpu.n, cpu.d, args.k
+    if cpu.ref is None:
+        return cpu.port(X, Q, budget_s)
+    Qh = Q.cpu().numpy()
+    legs = [cpu.bruteforce(Qh, k, gt_ids, budget_s * 0.6), cpu.distance_scan(Qh, k, gt_ids, budget_s * 0.1)]
+    if graph is not None:
+        legs.append(cpu.graph(graph, Qh, k, args.L if args.mode == "graph" else 500, budget_s * 0.3))
     # the baseline of record is the best path the REFERENCE itself offers at recall >= 0.999 on the full table
     ok = [l for l in legs if l["leg"] in ("bruteforce", "graph") and l["recall_at_10"] >= 0.999 and l.get("rows", n) == n]
     best = max(ok, key=lambda l: l["qps"]) if ok else legs[0]
-    return {"value": best["qps"], "unit": "queries/s", "cores": threads, "kind": "reference", "best_leg": best["leg"],
+    return {"value": best["qps"], "unit": "queries/s", "cores": cpu.threads, "kind": "reference", "best_leg": best["leg"],
             "sample": "%s: %d queries on the full %d x %d table (rows copied from the GPU in %.1f s, parallel first touch); host has %d logical cores"
-                      % (best["what"], best["queries"], n, d, copy_s, cores),
+                      % (best["what"], best["queries"], n, d, cpu.copy_s, cpu.cores),
             "legs": legs}
+
+
+def config_c2(amd, torch, args, X, qlast, dev, stream, local_rank, cpu, graph_index, graph_for_cpu):
+    """BASELINE configs[1]: 1M x 768 L2, k = 10, batch = 1 - single-query latency on one MI355X, inputs resident in HBM; every call
+    is timed from issue to torch.cuda.synchronize().  Exact engines (fp32 stream scan, int8 matrix filter) and the traversal at the
+    reference's defaults; beside them the reference's BruteForceSearch and SearchImpl (one executor, T = 4) on this box's cores."""
+    n1, d, k = args.graph_rows, args.dim, args.k
+    out = {"workload": "%d x %d L2, k=%d, batch=1: one query per call, sequential" % (n1, d, k)}
+    ix = amd.GpuIndex(d, args.metric, device=local_rank)
+    ix.set_stream(stream)
+    ix.attach_rows(X[:n1])
+    o = (torch.empty((1, k), dtype=torch.int64, device=dev), torch.empty((1, k), dtype=torch.float32, device=dev), torch.empty((1,), dtype=torch.int32, device=dev))
+    nq1 = min(200, qlast.shape[0])
+
+    def latency(index, **kw):
+        for i in range(3):
+            index.search(qlast[i:i + 1], k, out=o, **kw)
+        torch.cuda.synchronize()
+        lat, res = [], []
+        for i in range(nq1):
+            t0 = time.perf_counter()
+            index.search(qlast[i:i + 1], k, out=o, **kw)
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t0)
+            res.append(o[0][0].cpu().numpy().copy())
+        km = index.kernel_times(64)
+        return {"p50_ms": 1e3 * float(np.median(lat)), "p99_ms": 1e3 * float(np.percentile(lat, 99)), "qps": nq1 / float(np.sum(lat)), "queries": nq1,
+                "main_kernel_ms": float(np.median(km)) if km else None}, np.stack(res)
+    gpu = {}
+    gpu["stream"], gt1 = latency(ix, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
+    if gpu["stream"]["main_kernel_ms"]:
+        ach = n1 * d * 4 / (gpu["stream"]["main_kernel_ms"] * 1e-3) / 1e9
+        gpu["stream"]["roofline"] = {"bound": "hbm", "kernel": "flat_scan_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                     "note": "a %.1f GB table: partly served by L2 / Infinity Cache on repeated scans" % (n1 * d * 4 / 1e9)}
+    gpu["stream"]["recall_at_10"] = 1.0
+    ix.search(qlast[:64], k, out=(torch.empty((64, k), dtype=torch.int64, device=dev), torch.empty((64, k), dtype=torch.float32, device=dev),
+                                  torch.empty((64,), dtype=torch.int32, device=dev)), mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)   # builds the 8-bit mirror
+    gpu["mfma_i8"], r8 = latency(ix, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
+    gpu["mfma_i8"]["recall_at_10"] = recall_of(r8, gt1)
+    gpu["auto"], ra = latency(ix, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_AUTO)
+    gpu["auto"]["recall_at_10"] = recall_of(ra, gt1)
+    if graph_index is not None:
+        gpu["graph_T4_L500"], rg = latency(graph_index, mode=amd.MODE_GRAPH, intra_threads=4, master_queue=500, local_queue=500)
+        gpu["graph_T4_L500"]["recall_at_10"] = recall_of(rg, gt1)
+    ix.close()
+    exact = [v for v in gpu.values() if v["recall_at_10"] >= 0.999]
+    out["gpu"] = gpu
+    out["value"] = {"p50_ms": min(v["p50_ms"] for v in exact), "what": "best exact engine, end to end per call (host issue + device + sync), inputs in HBM"}
+    if cpu is not None and cpu.ref is not None:
+        try:
+            Qh = qlast[:64].cpu().numpy()
+            legs = [cpu.bruteforce(Qh, k, gt1, 4.0, rows=n1)]
+            if graph_for_cpu is not None:
+                gg = (graph_for_cpu[0], graph_for_cpu[1], graph_for_cpu[2], graph_for_cpu[3], gt1)
+                legs.append(cpu.graph(gg, Qh, k, 500, 3.0, E=1, T=4))
+            out["cpu_reference"] = {"cores": cpu.threads, "legs": legs}
+        except Exception as e:
+            out["cpu_reference"] = {"failed": repr(e)}
+    return out
+
+
+def config_c4(amd, torch, args, X, qlast, dev, stream, local_rank, cpu):
+    """BASELINE configs[3]: 10M x 768 COSINE + `ID < N` metadata filter, k = 10, batch 1024.  Rows normalised as at insert
+    (table_segment_mvp.cpp:574-587), queries as TableMVP::Search does (table_mvp.cpp:333-343); the filter is evaluated inside the
+    exact scan (Config::PreFilter semantics: the reference's post-filter over the top-L walk starves, SURVEY 8d).  Beside it the
+    reference's PreFilterBruteForceSearch with its own expression evaluator."""
+    n, d, k, b = X.shape[0], args.dim, args.k, qlast.shape[0]
+    out = {"workload": "%dM x %d COSINE + ID < N, k=%d, batch=%d, filter evaluated inside the exact scan" % (n // 1_000_000, d, k, b)}
+    Xn = torch.empty_like(X)
+    for s in range(0, n, 1 << 19):
+        e = min(n, s + (1 << 19))
+        Xn[s:e] = X[s:e]
+    amd.normalize_rows(Xn, only_if_nonzero=True, device=local_rank, stream=stream)
+    Qn = qlast.clone()
+    amd.normalize_rows(Qn, only_if_nonzero=False, device=local_rank, stream=stream)
+    torch.cuda.synchronize()
+    idc = torch.arange(n, dtype=torch.int32, device=dev)
+    ix = amd.GpuIndex(d, "COSINE", device=local_rank)
+    ix.set_stream(stream)
+    ix.attach_rows(Xn)
+    o = (torch.empty((b, k), dtype=torch.int64, device=dev), torch.empty((b, k), dtype=torch.float32, device=dev), torch.empty((b,), dtype=torch.int32, device=dev))
+    g64 = (torch.empty((64, k), dtype=torch.int64, device=dev), torch.empty((64, k), dtype=torch.float32, device=dev), torch.empty((64,), dtype=torch.int32, device=dev))
+    out["gpu"] = {}
+    gts = {}
+    for sel in (0.5, 0.1, 0.9):
+        bound = int(n * sel)
+        ix.set_int_filter(idc, "<", bound)
+        kw = dict(mode=amd.MODE_REFERENCE, prefilter=1)
+        ix.search(Qn, k, out=o, **kw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            ix.search(Qn, k, out=o, **kw)
+        torch.cuda.synchronize()
+        sec = (time.perf_counter() - t0) / 3
+        st = ix.stats()
+        got = o[0].cpu().numpy().copy()
+        ix.search(Qn[:64], k, out=g64, flat_engine=amd.FLAT_STREAM, **kw)
+        torch.cuda.synchronize()
+        gts[sel] = g64[0].cpu().numpy().copy()
+        out["gpu"]["ID < %d (%d %%)" % (bound, int(sel * 100))] = {
+            "qps": b / sec, "ms_per_step": 1e3 * sec, "recall_at_10": recall_of(got[:64], gts[sel]), "recall_check": "64 queries vs the fp32 stream engine with the same filter",
+            "all_results_pass_the_filter": bool((got < bound).all()), "operand_bits": int(st.get("main_kernel_bits", 0)), "rerank_rows_per_query": st["rerank_rows"] / float(b),
+            "main_kernel_ms": float(np.median(ix.kernel_times(3)))}
+    ix.close()
+    if cpu is not None and cpu.ref is not None:
+        try:
+            copy_s = cpu.load(Xn)
+            idc_host = np.arange(n, dtype=np.int32)
+            Qh = Qn[:2].cpu().numpy()
+            legs = [cpu.prefilter(idc_host, "ID < %d" % int(n * 0.5), Qh, k, 1, gts[0.5]), cpu.prefilter(idc_host, "ID < %d" % int(n * 0.1), Qh[:1], k, 1, gts[0.1])]
+            out["cpu_reference"] = {"cores": cpu.threads, "legs": legs, "normalised_rows_copied_in_s": copy_s}
+        except Exception as e:
+            out["cpu_reference"] = {"failed": repr(e)}
+    del Xn
+    return out
 
 
 def main():
@@ -366,6 +517,7 @@ def main():
     # ---- secondary: the traversal kernel at the reference's defaults on a device-built graph of the first rows
     secondary = None
     graph_for_cpu = None
+    ix2 = None
     if args.mode == "flat" and world == 1 and args.graph_rows and args.graph_rows <= n:
         gn = args.graph_rows
         ix2 = amd.GpuIndex(d, args.metric, device=local_rank)
@@ -401,7 +553,6 @@ def main():
         if args.cpu_seconds > 0:
             off, nbr, nav = ix2.get_graph()
             graph_for_cpu = (off, nbr, nav, gn, ggt)
-        ix2.close()
 
     if args.mode == "graph" and world == 1 and args.cpu_seconds > 0:
         off, nbr, nav = ix.get_graph()
@@ -447,7 +598,9 @@ def main():
             "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 (exact fp32 distances; the batched scan runs an fp16-MFMA lower-bound filter with fp32 accumulation, survivors re-ranked in fp32)"
+            "dtype": ("f32 (exact fp32 distances; the batched scan runs %s as a lower-bound filter, survivors re-ranked in fp32)"
+                      % ("an int8 MFMA pass (int32 accumulation) over an 8-bit mirror of the rows" if int(st.get("main_kernel_bits", 0)) == 8 else
+                         "an fp16 MFMA pass (fp32 accumulation) over a half mirror of the rows" if int(st.get("main_kernel_bits", 0)) == 16 else "no matrix pass"))
                      if args.mode == "flat" else "f32",
             "data": "synthetic" if args.data == "uniform" else ("synthetic (clustered: 1000 Gaussian clusters, sigma 0.1 - SURVEY 8d secondary set)" if args.data == "clustered"
                                                                 else "synthetic (manifold: 16-dimensional uniform latent embedded in %d dimensions + 1%% noise - tertiary set, not the BASELINE recipe)" % d),
@@ -469,14 +622,34 @@ def main():
             res["graph_build_s"] = build_s
         if secondary:
             res["secondary_traversal"] = secondary
+        cpu = None
         if args.cpu_seconds > 0 and world == 1:
             try:
-                res["cpu_baseline"] = cpu_baseline(args, torch, X, qlast, gt, graph_for_cpu, args.cpu_seconds)
+                cpu = CpuBaseline(torch, X)
+                res["cpu_baseline"] = cpu_baseline(cpu, args, X, qlast, gt, graph_for_cpu, args.cpu_seconds)
                 res["gpu_over_cpu"] = qps / res["cpu_baseline"]["value"] if res["cpu_baseline"].get("value") else None
             except Exception as e:  # the baseline is a report, never a dependency of the product path
                 res["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": os.cpu_count(), "kind": "reference",
                                        "sample": "failed: %r" % (e,)}
+        # ---- the other single-GPU configurations of BASELINE.json, each with the reference's CPU path beside it
+        want = [] if (args.configs == "none" or world > 1 or args.mode != "flat" or args.data != "uniform") else args.configs.split(",")
+        if want:
+            res["configs"] = {}
+            if "c2" in want and args.graph_rows and args.graph_rows <= n:
+                try:
+                    res["configs"]["c2_1Mx768_b1_latency"] = config_c2(amd, torch, args, X, qlast, dev, stream, local_rank, cpu, ix2, graph_for_cpu)
+                except Exception as e:
+                    res["configs"]["c2_1Mx768_b1_latency"] = {"failed": repr(e)}
+            if "c4" in want and args.metric == "EUCLIDEAN":
+                try:
+                    res["configs"]["c4_cosine_id_filter_b1024"] = config_c4(amd, torch, args, X, qlast, dev, stream, local_rank, cpu)
+                except Exception as e:
+                    res["configs"]["c4_cosine_id_filter_b1024"] = {"failed": repr(e)}
+        if cpu is not None:
+            cpu.close()
         print(json.dumps(res))
+    if ix2 is not None:
+        ix2.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -620,17 +620,26 @@ static int32_t ensure_mirror8(Index& ix) {
 }
 
 bool flat_mfma_profitable(const Index& ix, int64_t nq, int k) {
-  // FLAT_AUTO: both engines return the same bits, so this is purely a cost decision (scripts/bench_midbatch.py:
-  // 10M x 768: stream 5.1 / 11.3 / 43.7 ms vs filter 3.5 / 3.6 / 3.8 ms at 1 / 8 / 32 queries - the filter reads the
-  // half-size fp16 mirror once per <= 2048 queries, the stream scan reads the fp32 rows once per 4 queries;
-  // 200k x 128: break-even near 32 queries).
+  // FLAT_AUTO: both engines return the same bits, so this is purely a cost decision.  The stream scan reads the fp32 rows once
+  // per 4 queries; the filter reads its mirror once per <= 2048 queries - the 8-bit mirror is a quarter of the rows' bytes, the
+  // fp16 mirror half - and pays ~20 small launches and one host sync per call (bench.py configs c2, 1M x 768, one query: stream
+  // 0.72 ms, 8-bit filter 0.48 ms end to end; scripts/bench_midbatch.py, 10M x 768: stream 5.1 / 11.3 / 43.7 ms vs fp16 filter
+  // 3.5 / 3.6 / 3.8 ms at 1 / 8 / 32 queries).
   if (ix.n_rows_ < 65536 || k > 128) return false;
-  const bool have_mirror = ix.mirror_ && ix.mirror_->version == ix.rows_version_;
-  if (have_mirror && !ix.mirror_->fp16_range_ok) return false;
-  if (nq < 8 && !have_mirror) return false;   // do not spend 50 % more HBM on a mirror for single-query traffic alone
-  const double rows = (double)ix.n_rows_, d = (double)ix.dim_, dp = (double)((ix.dim_ + 127) / 128 * 128);
-  const double stream_s = std::ceil((double)nq / 4.0) * rows * d * 4.0 / 6.0e12 + 0.05e-3;
-  const double filter_s = 0.25e-3 + std::max(rows * dp * 2.0 / 5.0e12, 2.0 * 256.0 * std::ceil((double)nq / 256.0) * rows * dp / 1.2e15);
+  const HalfMirror* m = ix.mirror_;
+  const bool have16 = m && m->version == ix.rows_version_;
+  const bool known8 = m && m->version8 == ix.rows_version_;
+  const bool have8 = known8 && m->i8_ok;
+  const bool can16 = !have16 || m->fp16_range_ok;
+  if (known8 && !have8 && !can16) return false;                 // neither mirror can serve this table
+  if (nq < 8 && !have8 && !have16) return false;                // do not spend HBM on a mirror for single-query traffic alone
+  const bool use8 = have8 || !known8;                            // (an 8-bit mirror would be built first)
+  const double rows = (double)ix.n_rows_, d = (double)ix.dim_;
+  const double op_bytes = use8 ? std::max(512.0, std::ceil(d / 256.0) * 256.0) : std::ceil(d / 128.0) * 256.0;   // operand bytes per row
+  const double rate = use8 ? 2.0e15 : 1.2e15;                    // matrix rate the filter kernel reaches
+  const double dp = use8 ? op_bytes : op_bytes / 2.0;
+  const double stream_s = std::ceil((double)nq / 4.0) * rows * d * 4.0 / 6.0e12 + 0.2e-3;
+  const double filter_s = 0.35e-3 + std::max(rows * op_bytes / 5.0e12, 2.0 * 128.0 * std::ceil((double)nq / 128.0) * rows * dp / rate);
   return filter_s < stream_s;
 }
 
