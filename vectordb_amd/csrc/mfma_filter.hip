@@ -699,12 +699,22 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   std::vector<int64_t> bounds;
   if (seeded) {
     bounds.push_back(approx ? S0 : 0);   // approx mode keeps the head's approximate keys themselves: no second visit
-    const double r = std::max(4.0, std::cbrt((double)n / (double)S0));
+    // Stage count.  A stage whose rows outnumber the rows before it by a factor f passes ~ k * c * f candidates per query, c = how
+    // many times more rows lie within the bound's margin of the threshold than below it (fp16: ~1; int8: ~4-5 on U[0,1) rows at
+    // d = 768); S stages with equal ratios (n / S0)^(1/S) cost S * k * c * (n / S0)^(1/S) candidates and S times the per-stage
+    // overhead (launch tails + one re-rank launch, ~0.1 ms at 10M rows).  A candidate costs its wavefront ~900 cycles in the
+    // filter's epilogue and 3 KB of gather in the re-rank, so the looser 8-bit bound wants more, smaller steps (measured at
+    // 10M x 768, batch 1024: EPS_MFMA_STAGES sweep in profiles/r3_stage_sweep.txt).
+    const char* st_env = getenv("EPS_MFMA_STAGES");
+    const int nstages = st_env ? std::min(8, std::max(1, atoi(st_env))) : (i8 ? 6 : 3);
+    const double r = std::max(i8 ? 3.0 : 4.0, std::pow((double)n / (double)S0, 1.0 / (double)nstages));
     // stage boundaries on multiples of the rows one "round" of the persistent grid covers (256 workgroups x 256 rows /
     // query tiles), so the small stages do not end on a mostly idle round
     const int64_t qt = std::max<int64_t>(1, b_pad / 256);
     const int64_t unit = 256 * std::max<int64_t>(1, 256 / std::gcd<int64_t>(256, qt));
-    for (double f : {r, r * r}) {
+    double f = 1.0;
+    for (int st = 1; st < nstages; ++st) {
+      f *= r;
       int64_t bnd = (int64_t)((double)S0 * f) / ROWPAD * ROWPAD;
       if (bnd >= 2 * unit) bnd = bnd / unit * unit;
       if (bnd < n && bnd > bounds.back()) bounds.push_back(bnd);
@@ -753,6 +763,14 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   fa.sync_shift = getenv("EPS_MFMA_SYNC_SHIFT") ? std::min(8, std::max(0, atoi(getenv("EPS_MFMA_SYNC_SHIFT")))) : 2;
   fa.dense = 0;
   fa.ablate = 0;
+  fa.prof = nullptr;
+#ifdef EPS_V7_PROF
+  static DevBuf prof_buf;   // (lab builds only)
+  if (prof_buf.reserve(64)) {
+    (void)hipMemsetAsync(prof_buf.p, 0, 64, s);
+    fa.prof = prof_buf.as<unsigned long long>();
+  }
+#endif
 
   RerankArgs ra;
   ra.rows = ix.d_rows_;
@@ -913,6 +931,14 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   if (er == hipSuccess) er = hipMemcpyAsync(&h.total, total, 8, hipMemcpyDeviceToHost, s);
   if (er == hipSuccess) er = hipStreamSynchronize(s);
   if (er != hipSuccess) return ix.hip_fail(er, "MFMA filter");
+#ifdef EPS_V7_PROF
+  if (fa.prof) {
+    unsigned long long pr[4] = {0, 0, 0, 0};
+    (void)hipMemcpy(pr, fa.prof, 32, hipMemcpyDeviceToHost);
+    if (pr[3]) fprintf(stderr, "[eps v7 prof] wave-tiles %llu: head %.0f  K loop %.0f  epilogue %.0f cycles per tile (all stages of this call)\n", pr[3],
+                       (double)pr[0] / pr[3], (double)pr[1] / pr[3], (double)pr[2] / pr[3]);
+  }
+#endif
   ix.stats_.rerank_rows += (int64_t)h.total;
   ix.stats_.dist_evals += nq * (n - bounds[0]) + (seeded ? nq * S0 : 0);   // (exact mode visits the head twice)
   ix.stats_.main_kernel_launches = 1;

@@ -43,6 +43,7 @@ struct FilterArgs {
   int metric;
   u32* cnt;
   int cap;
+  unsigned long long* prof;   // lab builds (-DEPS_V7_PROF) only: [4] shader-clock sums over all wavefronts: tile head, K loop, epilogue, tiles
   int ablate;           // profiling only (EPS_MFMA_ABLATE): v1: bit0 skip staging loads, bit1 skip MFMAs, bit2 skip LDS
                         // fragment reads; v3: bit3 skip the query-operand DMA, bit4 skip the row-operand DMA
 };
@@ -631,7 +632,13 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
     asm volatile("" ::: "memory");
   };
 
+#ifdef EPS_V7_PROF
+  unsigned long long pf_head = 0, pf_k = 0, pf_epi = 0;
+#endif
   for (int64_t t = 0; t < ntile; ++t) {
+#ifdef EPS_V7_PROF
+    const unsigned long long pf_t0 = __builtin_readcyclecounter();
+#endif
     const int64_t row0 = (a.tile0 + tile_rt(ri_c)) * 256;
     const int64_t qbase = (int64_t)tile_qt(qi_c) * QT + wave * (32 * JQ);   // scalar
     lane_values();
@@ -692,12 +699,18 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
         __builtin_amdgcn_sched_barrier(0);   // one row block at a time: hoisting all 64 reads costs spills
       }
     }
+#ifdef EPS_V7_PROF
+    const unsigned long long pf_t1 = __builtin_readcyclecounter();
+#endif
     step(std::integral_constant<int, 0>{}, std::true_type{});
     step(std::integral_constant<int, 1>{}, std::false_type{});
     for (int kt = 2; kt < KT; kt += 2) {
       step(std::integral_constant<int, 0>{}, std::false_type{});
       step(std::integral_constant<int, 1>{}, std::false_type{});
     }
+#ifdef EPS_V7_PROF
+    const unsigned long long pf_t2 = __builtin_readcyclecounter();
+#endif
     if (rendezvous && wave == 0 && t + 1 < ntile && ((t + 1) & sync_mask) == 0 && lane16 == 0) __hip_atomic_fetch_add(gs_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     A_t = A_n;
     B_t = B_n;
@@ -779,7 +792,21 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
     if (MODE != FM_DENSE) {
       if (*reinterpret_cast<volatile u32*>(wcnt) >= (u32)(V7_CAPW / 2)) flush();
     }
+#ifdef EPS_V7_PROF
+    const unsigned long long pf_t3 = __builtin_readcyclecounter();
+    pf_head += pf_t1 - pf_t0;
+    pf_k += pf_t2 - pf_t1;
+    pf_epi += pf_t3 - pf_t2;
+#endif
   }
+#ifdef EPS_V7_PROF
+  if (a.prof && (threadIdx.x & 63) == 0) {
+    atomicAdd(&a.prof[0], pf_head);
+    atomicAdd(&a.prof[1], pf_k);
+    atomicAdd(&a.prof[2], pf_epi);
+    atomicAdd(&a.prof[3], (unsigned long long)ntile);
+  }
+#endif
   if (MODE != FM_DENSE) flush();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
