@@ -245,6 +245,16 @@ int32_t eps_index_select_edges(eps_index* h, const int64_t* nodes, int64_t m, co
  * does not depend on the order in which the device produces them.  out_ids [n][out_degree] (-1 padded), out_deg [n]; host arrays. */
 int32_t eps_index_inter_insert(eps_index* h, const int64_t* ids, const int32_t* deg, int64_t n, int32_t out_degree, int64_t* out_ids,
                                int32_t* out_deg);
+/* The first stage on its own: the K-nearest-neighbour graph of rows [0,n) that the build links (the reference's KNNGraph /
+ * NN-Descent stage, db/index/knn/knn.hpp:90-135; K = p->knng).  out_ids [n][min(K, n-1)] host, closest first, -1 padded, the node
+ * itself excluded.  Exact below 65 536 rows; above, the 128 closest by approximate key re-ranked in exact fp32. */
+int32_t eps_index_knn_graph(eps_index* h, int64_t n, const eps_build_params* p, int64_t* out_ids);
+/* The Link stage on its own (NsgIndex::Link without InterInsert, db/index/nsg/nsg.cpp:488-516: per node GetNeighbors :158-268 on the
+ * kNN graph from the navigation node's first search_length neighbours, then SyncPrune :540-580 = pool + the node's own kNN row,
+ * sorted, SelectEdge over the first candidate_pool_size).  knn: [n][min(p->knng, n-1)] host (NULL: the device's own kNN stage);
+ * navigation_point < 0: the closest row to the centroid (reported in *nav_out).  out_ids [n][out_degree] (-1 padded), out_deg [n]. */
+int32_t eps_index_link(eps_index* h, int64_t n, const int64_t* knn, int64_t navigation_point, const eps_build_params* p, int64_t* out_ids,
+                       int32_t* out_deg, int64_t* nav_out);
 int32_t eps_index_set_graph(eps_index* h, int64_t n, const int64_t* offsets, const int64_t* neighbors,
                             int64_t navigation_point);
 int32_t eps_index_graph_info(const eps_index* h, int64_t* n, int64_t* edges, int64_t* navigation_point);

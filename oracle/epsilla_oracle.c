@@ -866,6 +866,70 @@ void eo_inter_insert(const float* rows, int64_t n, int64_t d, const int64_t* ids
   free_lists(s.nsg, n);
 }
 
+/* The per-node half of NsgIndex::Link (nsg.cpp:488-516): GetNeighbors on the kNN graph + SyncPrune (:540-580) for every node, in
+ * node order.  Shared by eo_nsg_build (whose whole result is pinned bit-exactly to the reference) and eo_nsg_link. */
+static void link_stage(nsg_t* s, uint8_t* flags, eo_nb* resset, float* cut, eo_nb* result) {
+  const int64_t n = s->n, d = s->d, out_degree = s->out_degree;
+  const float* rows = s->rows;
+  nbvec full = {0, 0, 0};
+  for (int64_t v = 0; v < n; ++v) {
+    full.n = 0;
+    memset(flags, 0, (size_t)n);
+    get_neighbors(s, rows + v * d, resset, s->knng, flags, &full, 1, 1);
+    /* SyncPrune (nsg.cpp:540-580) */
+    for (int64_t i = 0; i < s->knng[v].n; ++i) {
+      int64_t id = s->knng[v].v[i];
+      if (flags[id]) continue;
+      eo_nb nb = {id, eo_fvec_l2sqr(rows + v * d, rows + id * d, d), 1};
+      nbvec_push(&full, nb);
+    }
+    nb_sort(full.v, full.n);
+    int64_t cursor = 0, rn = 0;
+    if (full.v[cursor].id == v) cursor++;
+    result[rn++] = full.v[cursor];
+    select_edge(s, &cursor, full.v, full.n, result, &rn, 1);
+    float* dp = cut + v * out_degree;
+    for (int64_t i = 0; i < rn; ++i) {
+      ivec_push(&s->nsg[v], result[i].id);
+      dp[i] = result[i].dist;
+    }
+    if (rn < out_degree) dp[rn] = -1;
+  }
+  free(full.v);
+}
+
+/* The Link stage alone on a given kNN graph and navigation node: what every node's edge list is BEFORE InterInsert.
+ * out_ids [n][out_degree] (-1 padded), out_deg [n].  (With K >= search_length - the defaults, 100 >= 45 - GetNeighbors never
+ * draws random start nodes, nsg.cpp:187, so the stage has no hidden state besides its inputs.) */
+void eo_nsg_link(const float* rows, int64_t n, int64_t d, const int64_t* knn, int64_t K, int64_t search_length, int64_t out_degree,
+                 int64_t cand_pool, int64_t nav, unsigned seed0, int64_t* out_ids, int64_t* out_deg) {
+  nsg_t s;
+  s.rows = rows; s.n = n; s.d = d;
+  s.search_length = search_length; s.out_degree = out_degree; s.cand_pool = cand_pool;
+  s.seed = seed0;
+  s.nav = nav;
+  s.knng = (ivec*)calloc((size_t)n, sizeof(ivec));
+  s.nsg = (ivec*)calloc((size_t)n, sizeof(ivec));
+  for (int64_t i = 0; i < n; ++i)
+    for (int64_t j = 0; j < K; ++j)
+      if (knn[i * K + j] >= 0) ivec_push(&s.knng[i], knn[i * K + j]);
+  uint8_t* flags = (uint8_t*)calloc((size_t)n, 1);
+  eo_nb* resset = (eo_nb*)malloc(sizeof(eo_nb) * (size_t)(search_length + 2));
+  float* cut = (float*)malloc(sizeof(float) * (size_t)(n * out_degree));
+  eo_nb* result = (eo_nb*)malloc(sizeof(eo_nb) * (size_t)(out_degree + 1));
+  link_stage(&s, flags, resset, cut, result);
+  for (int64_t v = 0; v < n; ++v) {
+    out_deg[v] = s.nsg[v].n;
+    for (int64_t j = 0; j < out_degree; ++j) out_ids[v * out_degree + j] = j < s.nsg[v].n ? s.nsg[v].v[j] : -1;
+  }
+  free(result);
+  free(cut);
+  free(resset);
+  free(flags);
+  free_lists(s.knng, n);
+  free_lists(s.nsg, n);
+}
+
 /* NsgIndex::Build (nsg.cpp:45-99).  knn: n*K ids, -1 padded.  Result is kept in a static and fetched
  * with eo_nsg_fetch().  Returns the total number of edges.  seed0 = 100 is the reference's initial
  * value of the global rand_r state (nsg.cpp:19). */
@@ -899,32 +963,8 @@ int64_t eo_nsg_build(const float* rows, int64_t n, int64_t d, const int64_t* knn
   /* Link (nsg.cpp:488-538) */
   float* cut = (float*)malloc(sizeof(float) * (size_t)(n * out_degree));
   {
-    nbvec full = {0, 0, 0};
     eo_nb* result = (eo_nb*)malloc(sizeof(eo_nb) * (size_t)(out_degree + 1));
-    for (int64_t v = 0; v < n; ++v) {
-      full.n = 0;
-      memset(flags, 0, (size_t)n);
-      get_neighbors(&s, rows + v * d, resset, s.knng, flags, &full, 1, 1);
-      /* SyncPrune (nsg.cpp:540-580) */
-      for (int64_t i = 0; i < s.knng[v].n; ++i) {
-        int64_t id = s.knng[v].v[i];
-        if (flags[id]) continue;
-        eo_nb nb = {id, eo_fvec_l2sqr(rows + v * d, rows + id * d, d), 1};
-        nbvec_push(&full, nb);
-      }
-      nb_sort(full.v, full.n);
-      int64_t cursor = 0, rn = 0;
-      if (full.v[cursor].id == v) cursor++;
-      result[rn++] = full.v[cursor];
-      select_edge(&s, &cursor, full.v, full.n, result, &rn, 1);
-      float* dp = cut + v * out_degree;
-      for (int64_t i = 0; i < rn; ++i) {
-        ivec_push(&s.nsg[v], result[i].id);
-        dp[i] = result[i].dist;
-      }
-      if (rn < out_degree) dp[rn] = -1;
-    }
-    free(full.v);
+    link_stage(&s, flags, resset, cut, result);
     inter_insert_all(&s, cut, result);
     free(result);
   }

@@ -104,6 +104,8 @@ class Oracle:
         L.eo_merge_fixed.restype = i64
         L.eo_merge_fixed.argtypes = [C.POINTER(EoCand), i64, C.POINTER(EoCand), i64]
         L.eo_knn_exact.argtypes = [C.c_int, fptr, i64, i64, i64, iptr]
+        L.eo_nsg_link.restype = None
+        L.eo_nsg_link.argtypes = [fptr, i64, i64, iptr, i64, i64, i64, i64, i64, C.c_uint, iptr, iptr]
         L.eo_nsg_build.restype = i64
         L.eo_nsg_build.argtypes = [fptr, i64, i64, iptr, i64, i64, i64, i64, C.c_uint]
         L.eo_select_edge.restype = i64
@@ -220,6 +222,17 @@ class Oracle:
         nbr = np.empty(max(e, 1), np.int64)
         nav = self.L.eo_nsg_fetch(_i(off), _i(nbr))
         return off, nbr[:e], nav
+
+    def nsg_link(self, rows, knn, nav, search_length=45, out_degree=50, cand_pool=300, seed=100):
+        """the Link stage alone (GetNeighbors + SyncPrune per node, before InterInsert) on the kNN graph `knn` [n][K] (-1 padded)
+        from navigation node `nav`; returns (ids [n][out_degree] -1 padded, deg [n])"""
+        rows = np.ascontiguousarray(rows, np.float32)
+        knn = np.ascontiguousarray(knn, np.int64)
+        n, d = rows.shape
+        ids = np.empty((n, out_degree), np.int64)
+        deg = np.empty(n, np.int64)
+        self.L.eo_nsg_link(_f(rows), n, d, _i(knn), knn.shape[1], search_length, out_degree, cand_pool, int(nav), seed, _i(ids), _i(deg))
+        return ids, deg
 
     def select_edge(self, rows, node, cands, depth=300, out_degree=50):
         rows = np.ascontiguousarray(rows, np.float32)

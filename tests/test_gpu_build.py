@@ -249,3 +249,112 @@ def test_build_visited_hash_is_exact(amd, monkeypatch):
     (o1, n1, v1), (o2, n2, v2) = graphs
     assert v1 == v2 and np.array_equal(o1, o2) and np.array_equal(n1, n2)
 
+
+
+# ----------------------------------------------------------------------------------------------- stage-level parity (a16 / a17)
+def _list_agreement(a, da, b, db):
+    """per-node edge lists a [n][R] (-1 padded, da valid) vs b: fraction identical as ordered lists, mean Jaccard of the sets"""
+    same, jac = 0, 0.0
+    for v in range(len(a)):
+        x, y = a[v, :da[v]].tolist(), b[v, :db[v]].tolist()
+        same += x == y
+        sx, sy = set(x), set(y)
+        jac += len(sx & sy) / float(max(1, len(sx | sy)))
+    return same / float(len(a)), jac / float(len(a))
+
+
+def test_device_knn_lists_against_the_oracles_exact_knn(amd, oracle):
+    """a16, the kNN-graph stage on its own (eps_index_knn_graph).  Below 65 536 rows the stage is an exact scan: the lists equal
+    the oracle's exact kNN (up to fp32 near-ties).  Above, the 128 closest rows by the 8-bit approximate key are re-ranked in
+    exact fp32: list recall >= 0.999 against exact kNN (the reference's NN-Descent is approximate too and reaches less,
+    test_knn_exact_contains_nndescent)."""
+    n, d, K = 3000, 16, 100
+    X = data(n, d, 77)
+    ix = amd.GpuIndex(d, 0)
+    ix.attach_rows(X)
+    got = ix.knn_graph()
+    want = oracle.knn_exact(0, X, K)
+    assert got.shape == want.shape == (n, K)
+    ident = np.mean([(got[v] == want[v]).all() for v in range(n)])
+    rec = recall_at_k(got, want)
+    assert rec >= 0.9999 and ident >= 0.98, (rec, ident)     # differences only where two neighbours are an fp32 near-tie
+    assert not (got == np.arange(n)[:, None]).any() and (got >= 0).all()
+    ix.close()
+    n, d = 70_000, 96
+    X = data(n, d, 78)
+    ix = amd.GpuIndex(d, 0)
+    ix.attach_rows(X)
+    got = ix.knn_graph()
+    ix.close()
+    sample = np.random.default_rng(1).choice(n, 300, replace=False)
+    X64 = X.astype(np.float64)
+    want = []
+    for v in sample:
+        dd = ((X64 - X64[v]) ** 2).sum(1)
+        dd[v] = np.inf
+        want.append(np.argsort(dd, kind="stable")[:K])
+    want = np.stack(want)
+    rec = recall_at_k(got[sample], want)
+    first = np.mean(got[sample, 0] == want[:, 0])
+    assert rec >= 0.999 and first >= 0.995, (rec, first)
+    assert (got >= 0).all() and not (got == np.arange(n)[:, None]).any()
+
+
+@pytest.mark.parametrize("n,d", [(3000, 16), (12000, 32)])
+def test_device_link_stage_against_the_oracle_on_an_identical_knn_graph(amd, oracle, n, d):
+    """a17, the Link stage on its own (eps_index_link): every node's GetNeighbors search over the kNN graph from the navigation
+    node's neighbours (nsg.cpp:158-268) + SyncPrune (:540-580: pool + own kNN row, sort, SelectEdge over the first 300), on the
+    SAME kNN graph and the SAME navigation node as the oracle's Link stage (code shared with the oracle's whole build, which is
+    bit-exact with the reference's NsgIndex::Build).  With K >= search_length the stage draws no random numbers (nsg.cpp:187 is
+    never reached), so the two sides are functions of identical inputs; they may differ only through fp32 summation order
+    (near-ties in the pool order, or at the `dist >= worst` / MRNG comparisons)."""
+    X = data(n, d, 80 + d)
+    knn = oracle.knn_exact(0, X, 100)
+    ooff, onbr, onav = oracle.nsg_build(X, knn)
+    want, wdeg = oracle.nsg_link(X, knn, onav)
+    ix = amd.GpuIndex(d, 0)
+    ix.attach_rows(X)
+    got, gdeg, nav = ix.link(knn, onav)
+    assert nav == onav
+    same, jac = _list_agreement(got, gdeg, want, wdeg.astype(np.int64))
+    print("Link stage %d x %d: %.4f of the nodes have the identical ordered edge list, mean Jaccard %.5f" % (n, d, same, jac))
+    assert same >= 0.999 and jac >= 0.9995, (same, jac)    # (measured: 1.0000 / 1.00000 at both sizes)
+    assert (gdeg >= 1).all() and (gdeg <= 50).all()
+    # ... and through InterInsert: device Link + device InterInsert vs oracle Link + oracle InterInsert on their own outputs
+    g2, gd2 = ix.inter_insert(got, gdeg, 50)
+    w2, wd2 = oracle.inter_insert(X, want, wdeg, 50)
+    same2, jac2 = _list_agreement(g2, gd2, np.asarray(w2), np.asarray(wd2).astype(np.int64))
+    print("Link + InterInsert %d x %d: mean Jaccard %.5f (list ORDER differs by design: the device re-sorts a node's edges, the reference appends)" % (n, d, jac2))
+    assert jac2 >= 0.98, (same2, jac2)    # (edge SETS; where a list overflows the two InterInserts differ by design, DESIGN.md 3.4)
+    ix.close()
+
+
+def test_where_the_device_build_differs_from_the_reference_by_design(amd, oracle):
+    """The stages above are like-for-like; the whole graphs are not identical, for three stated reasons, each checked here:
+      1. navigation node: the reference walks the kNN graph greedily from a RANDOM start towards the centroid
+         (InitNavigationPoint, nsg.cpp:101-155: rand_r) and takes the best node it meets; the device takes the exact argmin.  The
+         device's node is never farther from the centroid than the reference's.
+      2. InterInsert where a list overflows: the reference prunes after every single offer in node order (and keeps a stale
+         tail, nsg.cpp:632-639), the device prunes once over all offers (test_device_inter_insert_...: identical when nothing
+         overflows).
+      3. connectivity repair: the reference attaches unreached nodes in DFS order without a degree cap (+rand_r when its search
+         meets no reached node, nsg.cpp:759-768); the device keeps every out-degree <= 64.  Both graphs are connected."""
+    n, d = 4000, 16
+    X = data(n, d, 91)
+    knn = oracle.knn_exact(0, X, 100)
+    ooff, onbr, onav = oracle.nsg_build(X, knn)
+    ix = amd.GpuIndex(d, 0)
+    ix.attach_rows(X)
+    ix.build()
+    off, nbr, nav = ix.get_graph()
+    cen = X.astype(np.float64).mean(0)
+    dist_c = ((X - cen) ** 2).sum(1)
+    assert dist_c[nav] <= dist_c[onav] + 1e-9 and nav == int(np.argmin(dist_c))
+    check_graph(off, nbr, nav, n)
+    check_graph(ooff, onbr, onav, n)
+    assert np.diff(off).max() <= 64
+    # same edges for the overwhelming part all the same: the design differences touch few nodes
+    jac = np.mean([len(set(nbr[off[v]:off[v + 1]]) & set(onbr[ooff[v]:ooff[v + 1]])) / float(len(set(nbr[off[v]:off[v + 1]]) | set(onbr[ooff[v]:ooff[v + 1]])))
+                   for v in range(n)])
+    assert jac >= 0.9, jac
+    ix.close()

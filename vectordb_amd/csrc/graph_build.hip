@@ -49,6 +49,26 @@ __global__ void knn_extract_kernel(const u64* run_keys, int k1, int64_t q0, int6
   for (; o < K; ++o) dst[o] = TRV_NONE;
 }
 
+// the approximate top-kA of a kNN pass as candidate lists for the exact re-rank (run_keys is reset to EMPTY for it)
+__global__ void knn_keys_to_cand_kernel(const u64* approx_keys, int kA, int64_t nq, u32* cand, u32* cnt) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  u32 c = 0;
+  for (int e = 0; e < kA; ++e) {
+    const u64 key = approx_keys[q * kA + e];
+    if (key != KEY_EMPTY) cand[q * (int64_t)kA + c++] = key_id(key);
+  }
+  cnt[q] = c;
+}
+__global__ void knn_export_kernel(const u32* knn, int64_t count, int64_t* out) {   // u32 lists (TRV_NONE padded) -> int64 (-1 padded)
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) out[i] = knn[i] == TRV_NONE ? -1 : (int64_t)knn[i];
+}
+__global__ void knn_import_kernel(const int64_t* in, int64_t count, int64_t n, u32* knn) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) knn[i] = (in[i] < 0 || in[i] >= n) ? TRV_NONE : (u32)in[i];
+}
+
 // ------------------------------------------------------------------------------------------------ centroid
 __global__ __launch_bounds__(256) void centroid_kernel(const float* rows, int64_t n, int dim, int64_t rows_per_block,
                                                        float* acc) {
@@ -405,10 +425,11 @@ static int32_t inter_insert_device(Index& ix, const u32* nsg_ids, const float* n
   return EPS_OK;
 }
 
-int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp) {
+int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp, const BuildStage* hook) {
   hipStream_t s = ix.stream_;
   const int dim = (int)ix.dim_;
   if (n <= 1) {
+    if (hook && hook->stop_after) return ix.fail(EPS_USER_ERROR, "build stage: need at least two rows");
     std::vector<int64_t> off((size_t)n + 1, 0), nbr;
     return ix.set_graph(n, off.data(), nbr.data(), 0);
   }
@@ -440,27 +461,71 @@ int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp) {
   };
   (void)hipEventRecord(e0, s);
 
-  // ---- 1. kNN graph
-  DevBuf knn, run;
+  // ---- 1. kNN graph (KNNGraph / NN-Descent in the reference, knn.hpp:90-135, nndescent.hpp:96-192: approximate there).
+  // Below 65 536 rows: exact stream scan.  Above: every block of B rows goes through the matrix filter in its approximate-key
+  // mode (8-bit operands, r3), which selects the kA = 128 closest rows by approximate key, and those 128 are re-ranked in exact
+  // fp32 - the lists are the exact K nearest unless a true neighbour's approximate rank falls beyond 128 (the approximate key's
+  // error is a small fraction of the gap between the K-th and the 128-th neighbour; tests/test_gpu_build.py measures the recall).
+  DevBuf knn, run, runA, candA, cntA;
   const int k1 = K + 1;
   static const int64_t B = getenv("EPS_BUILD_BLOCK") ? std::max(256, atoi(getenv("EPS_BUILD_BLOCK"))) : 2048;   // queries per kNN pass
-  if (!knn.reserve((size_t)n * K * 4) || !run.reserve((size_t)B * k1 * 8)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "build: out of device memory (kNN graph)");
   const bool use_mfma = n >= 65536;
-  ix.scan_limit_ = n;  // the graph covers rows [0,n) only
-  for (int64_t q0 = 0; q0 < n; q0 += B) {
-    const int64_t nq = std::min(B, n - q0);
-    const float* dq = ix.d_rows_ + q0 * dim;
-    int32_t rc = use_mfma ? flat_mfma_search(ix, dq, nq, k1, run.as<u64>(), true)
-                          : ix.flat_stream(dq, nq, k1, 0, n, run.as<u64>(), false, -1, false);
-    if (rc != EPS_OK) {
-      ix.scan_limit_ = -1;
-      return rc;
+  const int kA = (int)std::min<int64_t>(n, std::max(k1, 128));
+  if (!knn.reserve((size_t)n * K * 4) || !run.reserve((size_t)B * k1 * 8)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "build: out of device memory (kNN graph)");
+  if (hook && hook->knn_in) {   // stage entry: the caller's kNN graph instead
+    DevBuf tmp;
+    if (!tmp.reserve((size_t)n * K * 8)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "build: out of device memory (kNN graph)");
+    HIPCHK(hipMemcpyAsync(tmp.p, hook->knn_in, (size_t)n * K * 8, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(knn_import_kernel, dim3((unsigned)(((int64_t)n * K + 255) / 256)), dim3(256), 0, s, tmp.as<int64_t>(), (int64_t)n * K, n, knn.as<u32>());
+    HIPCHK(hipStreamSynchronize(s));
+  } else {
+    if (use_mfma && (!runA.reserve((size_t)B * kA * 8) || !candA.reserve((size_t)B * kA * 4) || !cntA.reserve((size_t)B * 4)))
+      return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "build: out of device memory (kNN graph)");
+    ix.scan_limit_ = n;  // the graph covers rows [0,n) only
+    for (int64_t q0 = 0; q0 < n; q0 += B) {
+      const int64_t nq = std::min(B, n - q0);
+      const float* dq = ix.d_rows_ + q0 * dim;
+      int32_t rc;
+      if (use_mfma) {
+        rc = flat_mfma_search(ix, dq, nq, kA, runA.as<u64>(), true);
+        if (rc == EPS_OK) {
+          hipLaunchKernelGGL(knn_keys_to_cand_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, runA.as<u64>(), kA, nq, candA.as<u32>(), cntA.as<u32>());
+          launch_fill_u64(run.as<u64>(), nq * k1, KEY_EMPTY, s);
+          RerankArgs ra;
+          ra.rows = ix.d_rows_;
+          ra.dim = dim;
+          ra.metric = ix.metric_;
+          ra.queries = dq;
+          ra.nq = nq;
+          ra.k = k1;
+          ra.f = no_filter();
+          ra.cand = candA.as<u32>();
+          ra.cand_count = cntA.as<u32>();
+          ra.cap = kA;
+          ra.run_keys = run.as<u64>();
+          launch_rerank(ra, s);
+        }
+      } else {
+        rc = ix.flat_stream(dq, nq, k1, 0, n, run.as<u64>(), false, -1, false);
+      }
+      if (rc != EPS_OK) {
+        ix.scan_limit_ = -1;
+        return rc;
+      }
+      hipLaunchKernelGGL(knn_extract_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, run.as<u64>(), k1, q0, nq, K,
+                         knn.as<u32>());
     }
-    hipLaunchKernelGGL(knn_extract_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, run.as<u64>(), k1, q0, nq, K,
-                       knn.as<u32>());
+    ix.scan_limit_ = -1;
   }
-  ix.scan_limit_ = -1;
   lap("kNN graph");
+  if (hook && hook->stop_after == 1) {
+    DevBuf tmp;
+    if (!tmp.reserve((size_t)n * K * 8)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "build: out of device memory (kNN graph)");
+    hipLaunchKernelGGL(knn_export_kernel, dim3((unsigned)(((int64_t)n * K + 255) / 256)), dim3(256), 0, s, knn.as<u32>(), (int64_t)n * K, tmp.as<int64_t>());
+    HIPCHK(hipMemcpyAsync(hook->out_ids, tmp.p, (size_t)n * K * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return EPS_OK;
+  }
 
   // ---- 2. navigation node: closest row to the centroid (always L2)
   DevBuf cen;
@@ -476,7 +541,7 @@ int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp) {
   u64 navkey = 0;
   HIPCHK(hipMemcpyAsync(&navkey, run.p, 8, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
-  const int64_t nav = (int64_t)key_id(navkey);
+  const int64_t nav = (hook && hook->nav_in >= 0 && hook->nav_in < n) ? hook->nav_in : (int64_t)key_id(navkey);
   lap("navigation node");
 
   // seeds of every Link search: the first Ls kNN entries of nav (GetNeighbors, nsg.cpp:174-195), then nav+1, ...
@@ -606,6 +671,18 @@ int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp) {
   }
   HIPCHK(hipGetLastError());
   lap("Link (search + SelectEdge)");
+  if (hook && hook->stop_after == 2) {   // what Link leaves: per node <= R edges, before InterInsert
+    std::vector<u32> li((size_t)n * R), ld((size_t)n);
+    HIPCHK(hipMemcpyAsync(li.data(), nsg_ids.p, (size_t)n * R * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(ld.data(), nsg_deg.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (int64_t v = 0; v < n; ++v) {
+      hook->out_deg[v] = (int32_t)ld[v];
+      for (int j = 0; j < R; ++j) hook->out_ids[v * R + j] = j < (int)ld[v] ? (int64_t)li[(size_t)v * R + j] : -1;
+    }
+    if (hook->nav_out) *hook->nav_out = nav;
+    return EPS_OK;
+  }
   if (debug) {
     unsigned long long hcnt[3] = {0, 0, 0};
     HIPCHK(hipMemcpyAsync(hcnt, counters.p, 24, hipMemcpyDeviceToHost, s));

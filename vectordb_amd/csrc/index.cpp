@@ -915,6 +915,45 @@ int32_t eps_index_inter_insert(eps_index* h, const int64_t* ids, const int32_t* 
     return map_exception(ix);
   }
 }
+int32_t eps_index_knn_graph(eps_index* h, int64_t n, const eps_build_params* p, int64_t* out_ids) {
+  if (!h || !out_ids) return EPS_USER_ERROR;
+  Index* ix = dynamic_cast<Index*>(IX(h));
+  if (!ix) return IX(h)->fail(EPS_DB_UNSUPPORTED_ERROR, "knn_graph: single-device indices only");
+  try {
+    eps_build_params bp;
+    if (p) bp = *p; else eps_default_build_params(&bp);
+    if (n < 2 || n > ix->row_count()) return ix->fail(EPS_USER_ERROR, "knn_graph: n must be in [2, rows]");
+    if (hipSetDevice(ix->device_) != hipSuccess) return ix->fail(EPS_INFRA_UNEXPECTED_ERROR, "hipSetDevice");
+    eps::BuildStage st;
+    st.stop_after = 1;
+    st.out_ids = out_ids;
+    return eps::graph_build(*ix, n, bp, &st);
+  } catch (...) {
+    return map_exception(ix);
+  }
+}
+int32_t eps_index_link(eps_index* h, int64_t n, const int64_t* knn, int64_t navigation_point, const eps_build_params* p, int64_t* out_ids,
+                       int32_t* out_deg, int64_t* nav_out) {
+  if (!h || !out_ids || !out_deg) return EPS_USER_ERROR;
+  Index* ix = dynamic_cast<Index*>(IX(h));
+  if (!ix) return IX(h)->fail(EPS_DB_UNSUPPORTED_ERROR, "link: single-device indices only");
+  try {
+    eps_build_params bp;
+    if (p) bp = *p; else eps_default_build_params(&bp);
+    if (n < 2 || n > ix->row_count()) return ix->fail(EPS_USER_ERROR, "link: n must be in [2, rows]");
+    if (hipSetDevice(ix->device_) != hipSuccess) return ix->fail(EPS_INFRA_UNEXPECTED_ERROR, "hipSetDevice");
+    eps::BuildStage st;
+    st.knn_in = knn;
+    st.nav_in = navigation_point;
+    st.stop_after = 2;
+    st.out_ids = out_ids;
+    st.out_deg = out_deg;
+    st.nav_out = nav_out;
+    return eps::graph_build(*ix, n, bp, &st);
+  } catch (...) {
+    return map_exception(ix);
+  }
+}
 int32_t eps_index_load_table(eps_index* h, const char* path, const eps_table_layout* layout, int64_t* n_out) {
   if (!h) return EPS_USER_ERROR;
   Index* ix = dynamic_cast<Index*>(IX(h));

@@ -25,6 +25,7 @@ struct DevBuf {  // growable device allocation
   T* as() const { return static_cast<T*>(p); }
 };
 
+struct BuildStage;   // stage-level entry of the graph build (below)
 struct HalfMirror;   // fp16 mirror + per-row bounds for the MFMA filter engine (mfma_filter.hip)
 struct GraphDev;     // device CSR + traversal scratch (traverse.hip)
 
@@ -163,7 +164,7 @@ class Index : public IndexBase {
                            bool filtered, const u64* lo, int64_t lo_stride);
   friend int32_t flat_mfma_search(Index&, const float*, int64_t, int, u64*, bool, int);
   friend int32_t flat_mfma_search_slice(Index&, const float*, int64_t, int, u64*, bool, int, int);
-  friend int32_t graph_build(Index&, int64_t, const eps_build_params&);
+  friend int32_t graph_build(Index&, int64_t, const eps_build_params&, const BuildStage*);
   friend int32_t select_edges(Index&, const int64_t*, int64_t, const int64_t*, int32_t, int32_t, int32_t, int64_t*, int32_t*);
   friend int32_t inter_insert(Index&, const int64_t*, const int32_t*, int64_t, int32_t, int64_t*, int32_t*);
   friend int32_t graph_search(Index&, const float*, int64_t, int, const eps_search_params&, u64*, int64_t*, int);
@@ -182,7 +183,16 @@ void graph_free(GraphDev* g);
 // writes result keys [nq][k] and counts
 int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_search_params& p, u64* run_keys,
                      int64_t* evals, int walk_limit = 0);
-int32_t graph_build(Index& ix, int64_t n, const eps_build_params& p);
+// stage-level entry of the build (eps_index_knn_graph / eps_index_link): run a prefix of the stages, on caller-supplied inputs
+struct BuildStage {
+  const int64_t* knn_in = nullptr;   // [n][K] kNN graph to link (-1 padded) instead of computing one
+  int64_t nav_in = -1;               // navigation node to use (-1: the closest row to the centroid)
+  int stop_after = 0;                // 1: after the kNN graph (out_ids [n][K]); 2: after Link (out_ids [n][R], out_deg [n]); 0: whole build
+  int64_t* out_ids = nullptr;
+  int32_t* out_deg = nullptr;
+  int64_t* nav_out = nullptr;
+};
+int32_t graph_build(Index& ix, int64_t n, const eps_build_params& p, const BuildStage* stage = nullptr);
 int32_t select_edges(Index& ix, const int64_t* nodes, int64_t m, const int64_t* cands, int32_t cpn, int32_t depth, int32_t R, int64_t* out_ids,
                      int32_t* out_deg);
 int32_t inter_insert(Index& ix, const int64_t* ids, const int32_t* deg, int64_t n, int32_t R, int64_t* out_ids, int32_t* out_deg);

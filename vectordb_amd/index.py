@@ -213,6 +213,34 @@ class GpuIndex:
             setattr(bp, k_, v)
         self._check(self.L.eps_index_build(self.h, self.row_count if n is None else n, C.byref(bp)))
 
+    def knn_graph(self, n=None, **kw):
+        """the kNN-graph stage of the build alone (eps_index_knn_graph): ids [n][min(knng, n-1)], closest first, -1 padded"""
+        bp = BuildParams()
+        self.L.eps_default_build_params(C.byref(bp))
+        for k_, v in kw.items():
+            setattr(bp, k_, v)
+        n = self.row_count if n is None else n
+        out = np.empty((n, min(int(bp.knng), n - 1)), np.int64)
+        self._check(self.L.eps_index_knn_graph(self.h, n, C.byref(bp), _ptr(out)))
+        return out
+
+    def link(self, knn=None, nav=-1, n=None, **kw):
+        """the Link stage alone (eps_index_link) on the kNN graph `knn` [n][K] (None: the device's own) from navigation node `nav`
+        (-1: the closest row to the centroid); returns (ids [n][out_degree] -1 padded, deg [n], nav)"""
+        bp = BuildParams()
+        self.L.eps_default_build_params(C.byref(bp))
+        for k_, v in kw.items():
+            setattr(bp, k_, v)
+        n = self.row_count if n is None else n
+        if knn is not None:
+            knn = np.ascontiguousarray(knn, np.int64)
+            assert knn.shape == (n, min(int(bp.knng), n - 1)), knn.shape
+        out = np.empty((n, int(bp.out_degree)), np.int64)
+        deg = np.empty(n, np.int32)
+        nav_out = C.c_int64(-1)
+        self._check(self.L.eps_index_link(self.h, n, _ptr(knn), int(nav), C.byref(bp), _ptr(out), _ptr(deg), C.byref(nav_out)))
+        return out, deg, int(nav_out.value)
+
     def select_edges(self, nodes, cands, depth=300, out_degree=50):
         """SyncPrune's sort + SelectEdge for given candidate lists (eps_index_select_edges); returns (ids [m][R] -1 padded, deg [m])"""
         nodes = np.ascontiguousarray(nodes, np.int64)
