@@ -506,6 +506,10 @@ std::string RunSearch(DeviceField& dev, int64_t dim, const Pending& h, const flo
     p.master_queue = h.L;
     p.local_queue = h.Lq;
     p.sync_interval = h.I;
+    // EPS_DROPIN_FILTER_IN_TRAVERSAL=1 (opt-in, NOT the reference's semantics): graph searches with a device-compiled filter judge every
+    // row they evaluate instead of the final top-L walk, so selective filters still return `limit` rows
+    static const bool filter_in_traversal = getenv("EPS_DROPIN_FILTER_IN_TRAVERSAL") && atoi(getenv("EPS_DROPIN_FILTER_IN_TRAVERSAL")) != 0;
+    p.filter_in_traversal = filter_in_traversal ? 1 : 0;
     if (eps_index_search(dev.h, q, nq, h.k, &p, ids, dist, cnt) != EPS_OK) fail("search");
   }
   return err;

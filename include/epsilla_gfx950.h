@@ -132,6 +132,11 @@ typedef struct eps_search_params {
   int64_t master_queue;    /* Config::MasterQueueSize (L)                                      */
   int64_t local_queue;     /* Config::LocalQueueSize (result cap, :872)                        */
   int64_t sync_interval;   /* Config::GlobalSyncInterval (expansions per worker per round)     */
+  int32_t filter_in_traversal; /* 0 (default): the reference's semantics - deleted rows and the filter are judged on the
+                              final top-L walk only (vec_search_executor.cpp:905-927), so a selective filter returns fewer than
+                              `limit` rows.  1 (NOT the reference's answer): graph searches judge every row
+                              they EVALUATE and return the closest visible ones; invisible rows still steer the walk.          */
+  int32_t reserved;
 } eps_search_params;
 
 /* Build knobs; defaults = NSGConfig(45,50,300,100) (db/ann_graph_segment.cpp:29). */

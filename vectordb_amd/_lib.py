@@ -33,7 +33,7 @@ EXPORTS = [
 class SearchParams(C.Structure):
     _fields_ = [("mode", C.c_int32), ("flat_engine", C.c_int32), ("prefilter", C.c_int32),
                 ("intra_threads", C.c_int32), ("master_queue", C.c_int64), ("local_queue", C.c_int64),
-                ("sync_interval", C.c_int64)]
+                ("sync_interval", C.c_int64), ("filter_in_traversal", C.c_int32), ("reserved", C.c_int32)]
 
 
 class BuildParams(C.Structure):

@@ -788,6 +788,8 @@ void eps_default_search_params(eps_search_params* p) {
   p->master_queue = 500;    // Config::MasterQueueSize{500}      (:19)
   p->local_queue = 500;     // Config::LocalQueueSize{500}       (:20)
   p->sync_interval = 15;    // Config::GlobalSyncInterval{15}    (:21)
+  p->filter_in_traversal = 0;
+  p->reserved = 0;
 }
 
 void eps_default_build_params(eps_build_params* p) {

@@ -37,6 +37,7 @@ struct GraphDev {
   DevBuf queue;      // u64 [nq][L]
   DevBuf counters;   // unsigned long long [2]
   DevBuf tail;       // u64 [nq][k] brute-force tail lists
+  DevBuf elog, elog_cnt;   // filtered traversal: u64 [slice][ecap] evaluated (dist, id) keys, u32 [slice] counts
 };
 
 void graph_free(GraphDev* g) { delete g; }
@@ -265,7 +266,7 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
   if (qglobal) slots = std::min<int64_t>(slots, std::max<int64_t>(1, ((int64_t)8 << 30) / (qtot * 8)));
   const int vcap = (int)std::min<int64_t>((int64_t)1 << 20, std::max<int64_t>(1024, words / 4));
   // results of the traversal are consumed per slice of queries so that the [slice][L] queue copy stays below 2 GiB
-  const int64_t slice = std::max<int64_t>(1, std::min<int64_t>(nq, ((int64_t)2 << 30) / (L * 8)));
+  const int64_t slice = std::max<int64_t>(1, std::min<int64_t>(nq, ((int64_t)2 << 30) / (std::max<int64_t>(L, p.filter_in_traversal ? std::min<int64_t>(n, std::max<int64_t>(16384, 64 * L)) : 0) * 8)));
   if (!g.visited.reserve((size_t)slots * words * 4) || !g.vlog.reserve((size_t)slots * vcap * 4) ||
       !g.queue.reserve((size_t)slice * L * 8) || !g.counters.reserve(256) ||
       (qglobal && (!g.qglobal.reserve((size_t)slots * qtot * 8) || !g.auxglobal.reserve((size_t)slots * 2 * Lq * 4))))
@@ -306,6 +307,17 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
   a.vcap = vcap;
   a.counters = g.counters.as<unsigned long long>();
   a.prof = prof ? g.counters.as<unsigned long long>() + 8 : nullptr;
+  // Filtered traversal (eps_search_params::filter_in_traversal): the reference judges deleted rows and the filter on
+  // the final top-L walk only (:905-927), so a filter that lets 1 % of the rows through leaves ~L/100 results.  Here every row
+  // the search EVALUATES (an order of magnitude more than L) is logged with its distance and the k closest VISIBLE ones are the
+  // answer; invisible rows keep their place in the queues, i.e. the walk itself is the reference's.
+  const FilterSpec fspec = ix.filter_spec();
+  const bool filtered = p.filter_in_traversal != 0 && walk_limit == 0 && (fspec.deleted || fspec.column || fspec.prog);
+  if (filtered && k > 1024) return ix.fail(EPS_DB_UNSUPPORTED_ERROR, "search: filter_in_traversal returns at most 1024 rows per query");
+  const int64_t ecap = filtered ? std::min<int64_t>(n, std::max<int64_t>(16384, 64 * L)) : 0;
+  a.elog = nullptr;
+  a.elog_cnt = nullptr;
+  a.elog_cap = (int)ecap;
 
   // brute-force tail over the rows the graph does not cover yet (:885-900)
   const int64_t n_total = ix.n_rows_;
@@ -341,6 +353,11 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
     a.queries = dq + q0 * ix.dim_;
     a.nq = cnt;
     a.out_queue = g.queue.as<u64>();
+    if (filtered) {
+      if (!g.elog.reserve((size_t)slice * ecap * 8) || !g.elog_cnt.reserve((size_t)slice * 4)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "search: out of device memory (evaluation log)");
+      a.elog = g.elog.as<u64>();
+      a.elog_cnt = g.elog_cnt.as<u32>();
+    }
     const int sl = (int)std::min<int64_t>(slots, cnt);
 #define EPS_TRV_LAUNCH(V4, NW_)                                        \
   do {                                                                 \
@@ -358,7 +375,13 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
     if (q0 + cnt >= nq) (void)hipEventRecord(ix.evk1_, s);   // (with several slices the pair spans all traversal launches and the post kernels between them)
     pa.tail = tail ? tail + q0 * tail_k : nullptr;
     pa.run_keys = run_keys + q0 * k;
-    hipLaunchKernelGGL(post_kernel, dim3((unsigned)cnt), dim3(64), (size_t)pa.Klds * 8, s, pa);
+    if (filtered) {
+      // the k closest visible evaluated rows (+ the visible rows of the un-indexed tail, already filtered by its flat scan)
+      launch_merge_lists(a.elog, (int)ecap, k, cnt, run_keys + q0 * k, false, s, a.elog_cnt, &fspec);
+      if (tail) launch_merge_lists(tail + q0 * tail_k, tail_k, k, cnt, run_keys + q0 * k, true, s);
+    } else {
+      hipLaunchKernelGGL(post_kernel, dim3((unsigned)cnt), dim3(64), (size_t)pa.Klds * 8, s, pa);
+    }
   }
   er = hipGetLastError();
   if (er != hipSuccess) return ix.hip_fail(er, "traversal launch");

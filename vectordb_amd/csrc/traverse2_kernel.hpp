@@ -52,6 +52,11 @@ struct Trv2Args {
   u64* out_queue;       // [nq][L] final master queues
   unsigned long long* counters;  // [0] distance evaluations, [1] expansions, [2] steps, [3] rounds
   unsigned long long* prof;      // optional [16]: shader-clock ticks per phase summed over the workgroups (EPS_TRV_PROF)
+  // filtered traversal (eps_search_params::filter_in_traversal): every distance the search evaluates is also logged as a plain
+  // (dist, id) key, so that the caller can pick the k best VISIBLE rows among ALL evaluated nodes instead of among the final queue
+  u64* elog;                     // [nq][elog_cap] or null
+  u32* elog_cnt;                 // [nq] evaluations of the query (may exceed elog_cap: only the first elog_cap are stored)
+  int elog_cap;
 };
 
 #ifndef EPS_TRV_U
@@ -120,7 +125,7 @@ __global__ __launch_bounds__(NW * 64) void traverse2_kernel(Trv2Args a) {
   int* auxl = hmin + H;                                                     // !QGLOBAL: [2*Lq] MergeAll scratch (T > 1)
   int* sh = auxl + ((QGLOBAL || T == 1) ? 0 : 2 * Lq);                      // [trv2_sh_ints(T)]
   // sh[0] scratch (first found / pmin), sh[1] unchecked count, sh[2] undo-log fill, sh[3] any worker selected,
-  // sh[4] running prefix, sh[5] non-duplicate count, sh[6] r of MergeAll, sh[7] log overflow
+  // sh[4] running prefix, sh[5] non-duplicate count, sh[6] r of MergeAll, sh[7] log overflow, sh[8] evaluations logged (elog)
   const int TS = trv2_tstride(T);
   const int SH = trv2_sh_ints(T);
   int* s_kuc = sh + 16;            // [T] first possibly-unchecked position per queue
@@ -190,7 +195,14 @@ __global__ __launch_bounds__(NW * 64) void traverse2_kernel(Trv2Args a) {
       row_dists<U, 1, VEC4>(rp, sq, qstride, dim, a.metric, G, acc);
 #pragma unroll
       for (int u = 0; u < U; ++u)
-        if (ok[u] && t == 0) master[c0 + u * RPW + g] = q2key(finish_dist(a.metric, acc[u][0]), id[u]);
+        if (ok[u] && t == 0) {
+          const float dseed = finish_dist(a.metric, acc[u][0]);
+          master[c0 + u * RPW + g] = q2key(dseed, id[u]);
+          if (a.elog) {
+            const int lp = atomicAdd(&sh[8], 1);
+            if (lp < a.elog_cap) a.elog[q * (int64_t)a.elog_cap + lp] = make_key(dseed, id[u]);
+          }
+        }
     }
     evals += L;
     __syncthreads();
@@ -465,6 +477,10 @@ __global__ __launch_bounds__(NW * 64) void traverse2_kernel(Trv2Args a) {
             if (ok[u] && t == 0) {
               const float d = finish_dist(a.metric, acc[u][0]);
               newk[slotk[u]] = (d > bound) ? KEY_EMPTY : q2key(d, id[u]);
+              if (a.elog) {   // (also the candidates the bound drops: a visible row beyond the queue's worst may still be an answer)
+                const int lp = atomicAdd(&sh[8], 1);
+                if (lp < a.elog_cap) a.elog[q * (int64_t)a.elog_cap + lp] = make_key(d, id[u]);
+              }
             }
           }
         }
@@ -652,6 +668,7 @@ __global__ __launch_bounds__(NW * 64) void traverse2_kernel(Trv2Args a) {
     // ------------------------------------------------------------------ results + visited reset
     if (a.out_queue)
       for (int i = tid; i < L; i += NT) a.out_queue[q * L + i] = master[i];
+    if (a.elog_cnt && tid == 0) a.elog_cnt[q] = (u32)sh[8];
     const int nlog = sh[2];
     if (sh[7] || nlog > a.vcap) {
       for (int64_t i = tid; i < a.words; i += NT) vis[i] = 0;
