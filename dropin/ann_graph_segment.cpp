@@ -8,6 +8,7 @@
 #include <fstream>
 #include <stdexcept>
 
+#include "dist_func.hpp"
 #include "epsilla_gfx950.h"
 #include "utils/common_util.hpp"
 
@@ -52,6 +53,9 @@ ANNGraphSegment::ANNGraphSegment(const std::string& db_catalog_path, int64_t tab
     neighbor_list_ = new int64_t[edges > 0 ? edges : 1];
     file.read(reinterpret_cast<char*>(neighbor_list_), sizeof(int64_t) * edges);
     file.read(reinterpret_cast<char*>(&navigation_point_), sizeof(navigation_point_));
+    // n nodes without a single edge is the placeholder a hash-sharded mirror leaves (its shards keep the real graphs, see
+    // BuildFromVectorTable): nothing here can be walked, so the segment counts as "not built" and its executors scan exactly
+    if (n >= 2 && edges == 0) record_number_ = 0;
   } else {
     auto mkdir_status = server::CommonUtil::CreateDirectory(db_catalog_path + "/" + std::to_string(table_id));
     if (!mkdir_status.ok()) throw mkdir_status.message();
@@ -87,26 +91,13 @@ void ANNGraphSegment::BuildFromVectorTable(VectorColumnData vector_column, int64
   if (!std::holds_alternative<DenseVectorColumnDataContainer>(vector_column))
     throw std::runtime_error("sparse-vector graphs are not built on the device (host DBMS path, SURVEY 2 row 14)");
   logger_.Debug("gfx950 graph build start");
-  eps_index* h = nullptr;
-  int32_t rc = eps_index_create(dim, ToEpsMetric(metricType), 0, &h);
-  if (rc != EPS_OK) throw std::runtime_error("eps_index_create failed: no usable gfx950 device");
-  auto fail = [&](const char* what) {
-    std::string msg = std::string(what) + ": " + eps_index_last_error(h);
-    eps_index_destroy(h);
-    throw std::runtime_error(msg);
-  };
-  if (eps_index_attach_rows(h, std::get<DenseVectorColumnDataContainer>(vector_column), n) != EPS_OK) fail("attach_rows");
-  if (eps_index_build(h, n, nullptr) != EPS_OK) fail("build");  // defaults = NSGConfig(45,50,300,100)
-  int64_t gn = 0, edges = 0, nav = 0;
-  eps_index_graph_info(h, &gn, &edges, &nav);
-  int64_t* off = new int64_t[gn + 1];
-  int64_t* nbr = new int64_t[edges > 0 ? edges : 1];
-  if (eps_index_get_graph(h, off, nbr) != EPS_OK) {
-    delete[] off;
-    delete[] nbr;
-    fail("get_graph");
-  }
-  eps_index_destroy(h);
+  // The graph is built on the field's device mirror - the HBM copy of the column its executors search (r2 created a second index on
+  // device 0, uploaded the whole table again and freed it).  With EPS_DEVICES the mirror is hash-sharded and every shard builds
+  // and keeps the graph of its own rows on its own device.
+  int64_t *off = nullptr, *nbr = nullptr, nav = 0;
+  const std::string err = epsdrop::BuildGraphOnMirror(std::get<DenseVectorColumnDataContainer>(vector_column), n, dim, ToEpsMetric(metricType), this, &off, &nbr,
+                                                      &nav, &device_mirror_);
+  if (!err.empty()) throw std::runtime_error("gfx950 graph build: " + err);
   delete[] offset_table_;
   delete[] neighbor_list_;
   offset_table_ = off;

@@ -55,6 +55,9 @@ struct Pending {
   std::string error;
 };
 
+struct DeviceField;
+std::shared_ptr<DeviceField> AcquireFieldForBuild(const float* column, int64_t dim, int metric);
+
 struct DeviceField {
   std::mutex mu;
   // micro-batcher: concurrent Search() calls of the pool's executors are coalesced into one
@@ -70,7 +73,9 @@ struct DeviceField {
   int64_t attached = 0;            // rows already in HBM
   const void* graph_owner = nullptr;  // ANNGraphSegment whose CSR is on the device
   int64_t graph_n = -1;
-  bool sharded = false;            // several GPUs: searches are exact flat scans per shard (a graph over the whole table cannot be split)
+  bool sharded = false;            // several GPUs (EPS_DEVICES): every shard searches its rows, the per-shard top-k lists are merged
+  const void* shard_graph_owner = nullptr;   // sharded: the ANNGraphSegment whose per-shard graphs the shards hold (BuildGraphOnMirror)
+  int64_t shard_graph_n = -1;
   std::vector<uint8_t> mask;       // scratch: deleted | !filter, for filters evaluated on the host
   ~DeviceField() {
     if (h) eps_index_destroy(h);
@@ -113,6 +118,10 @@ std::shared_ptr<DeviceField> AcquireField(const float* column, int64_t dim, int 
   g_fields[key] = sp;
   return sp;
 }
+
+}  // namespace
+std::shared_ptr<DeviceField> AcquireFieldForBuild(const float* column, int64_t dim, int metric) { return AcquireField(column, dim, metric); }
+namespace {
 
 // ---- filter compiler: ExprNode tree -> eps_filter_op postfix program -------------------------------------------------
 struct Compiler {
@@ -501,6 +510,9 @@ std::string RunSearch(DeviceField& dev, int64_t dim, const Pending& h, const flo
     eps_default_search_params(&p);
     static const bool prefer_exact = getenv("EPS_DROPIN_PREFER_EXACT") && atoi(getenv("EPS_DROPIN_PREFER_EXACT")) != 0;
     p.mode = prefer_exact && !h.prefilter ? EPS_MODE_FLAT : EPS_MODE_REFERENCE;
+    // a sharded mirror searches graphs only if its shards hold the graphs of THIS request's segment (built by BuildGraphOnMirror);
+    // otherwise exact per-shard scans
+    if (dev.sharded && !(dev.shard_graph_owner == h.graph_owner && dev.shard_graph_n == h.graph_n && h.graph_n > 0)) p.mode = EPS_MODE_FLAT;
     p.prefilter = h.prefilter ? 1 : 0;
     p.intra_threads = h.T;
     p.master_queue = h.L;
@@ -716,3 +728,41 @@ Status VecSearchExecutor::SearchByAttribute(meta::TableSchema& table_schema, vec
 }  // namespace execution
 }  // namespace engine
 }  // namespace vectordb
+
+std::string epsdrop::BuildGraphOnMirror(const float* column, int64_t n, int64_t dim, int metric, const void* owner, int64_t** off, int64_t** nbr,
+                                        int64_t* nav, std::shared_ptr<void>* keep) {
+  using vectordb::engine::execution::DeviceField;
+  std::shared_ptr<DeviceField> devp = vectordb::engine::execution::AcquireFieldForBuild(column, dim, metric);
+  if (!devp) return "no usable gfx950 device (libepsilla_gfx950 has no CPU fallback)";
+  DeviceField& dev = *devp;
+  std::lock_guard<std::mutex> lk(dev.mu);
+  auto fail = [&](const char* what) { return std::string(what) + ": " + eps_index_last_error(dev.h); };
+  if (n > dev.attached) {   // only the rows the mirror does not hold yet cross PCIe
+    const int32_t rc = dev.attached == 0 ? eps_index_attach_rows(dev.h, column, n) : eps_index_append_rows(dev.h, column + dev.attached * dim, n - dev.attached);
+    if (rc != EPS_OK) return fail("row upload");
+    dev.attached = n;
+  }
+  if (eps_index_build(dev.h, n, nullptr) != EPS_OK) return fail("build");   // defaults = NSGConfig(45,50,300,100)
+  if (dev.sharded) {
+    *off = new int64_t[n + 1]();
+    *nbr = new int64_t[1]();
+    *nav = 0;
+    dev.shard_graph_owner = owner;
+    dev.shard_graph_n = n;
+  } else {
+    int64_t gn = 0, edges = 0;
+    eps_index_graph_info(dev.h, &gn, &edges, nav);
+    *off = new int64_t[gn + 1];
+    *nbr = new int64_t[edges > 0 ? edges : 1];
+    if (eps_index_get_graph(dev.h, *off, *nbr) != EPS_OK) {
+      delete[] *off;
+      delete[] *nbr;
+      *off = *nbr = nullptr;
+      return fail("get_graph");
+    }
+    dev.graph_owner = owner;   // the device index already holds this graph: the segment's executors need not upload it again
+    dev.graph_n = n;
+  }
+  *keep = devp;
+  return "";
+}

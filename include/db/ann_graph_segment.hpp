@@ -7,6 +7,7 @@
 #pragma once
 
 #include <atomic>
+#include <memory>
 #include <string>
 #include <unordered_map>
 #include <variant>
@@ -46,6 +47,7 @@ class ANNGraphSegment {
   int64_t* offset_table_;    // new[]-owned CSR offsets, record_number_ + 1 entries
   int64_t* neighbor_list_;   // new[]-owned CSR neighbours
   int64_t navigation_point_;
+  std::shared_ptr<void> device_mirror_;   // (additive) keeps the field's device mirror - which holds this graph - alive with the graph
 };
 
 }  // namespace engine

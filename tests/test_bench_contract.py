@@ -51,3 +51,20 @@ def test_bench_two_ranks_on_one_gpu_merge_equals_unsharded_scan():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak"
     assert "rows_total=300000" in d["config"]["workload"]
     assert d["recall_at_10"] == 1.0 and d["recall_check"]["ground_truth_vs_torch_fp32_scan"] == 1.0
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_on_one_gpu():
+    """BASELINE configs[4]'s shape (8 shards, one packed all-gather, k-way merge) with the driver's launch line, on the one GPU of
+    this box: eight gloo ranks, each with its own shard of the rows (row i = local * 8 + rank).  Exercises what the 8-GPU run
+    exercises - rank-local shards, the id map, the gather layout for 8 contributions, the merge - except RCCL itself."""
+    env = dict(os.environ, EPS_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                        "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+                        "--rows", "80000", "--batch", "64", "--cpu-seconds", "0"], capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and "rows_total=640000" in d["config"]["workload"]
+    assert d["recall_at_10"] == 1.0 and d["recall_check"]["ground_truth_vs_torch_fp32_scan"] == 1.0

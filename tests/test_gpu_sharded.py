@@ -138,3 +138,39 @@ def test_dropin_dbserver_over_a_sharded_executor(tmp_path):
             assert np.allclose([x["@distance"] for x in d], [x["@distance"] for x in r], rtol=1e-4)
     finally:
         os.environ.pop("EPS_DEVICES", None)
+
+
+def test_dropin_rebuild_builds_per_shard_graphs_on_the_mirror(tmp_path):
+    """EPS_DEVICES=0,0 + Rebuild(): ANNGraphSegment::BuildFromVectorTable builds on the field's device mirror - every shard the
+    graph of its own rows, on its own device - and the executors then walk the per-shard graphs (SearchQueueSize 500 over 1250-row
+    shards evaluates nearly everything: recall >= 0.99 against the reference DBServer's exact answers); rows inserted after the
+    rebuild are found through the shards' brute-force tails."""
+    from oracle.pyoracle import DROPIN_SO, Ref, dropin_available, ref_available
+    if not (dropin_available() and ref_available()):
+        pytest.skip("needs dropin/_build and oracle/_ref")
+    os.environ["EPS_DEVICES"] = "0,0"
+    try:
+        ref, drop = Ref(), Ref(DROPIN_SO)
+        schema = {"name": "T", "fields": [{"name": "ID", "dataType": "INT", "primaryKey": True},
+                                           {"name": "V", "dataType": "VECTOR_FLOAT", "dimensions": 16, "metricType": "EUCLIDEAN"}]}
+        n = 2500
+        X = data(n + 40, 16, 21)
+        recs = [{"ID": int(i), "V": [float(x) for x in X[i]]} for i in range(n + 40)]
+        Q = data(24, 16, 22)
+        outs = []
+        for lib, name in ((ref, "ref"), (drop, "drop")):
+            db = lib.db(str(tmp_path / name))
+            assert db.create_table(schema) == 0 and db.insert("T", recs[:n]) == 0
+            if lib is drop:
+                assert db.rebuild() == 0
+            assert db.insert("T", recs[n:]) == 0
+            outs.append([db.search("T", "V", q, 10, fields=("ID",)) for q in Q])
+            db.close()
+        hits = 0
+        for (rc, r), (rc2, d) in zip(*outs):
+            assert rc == rc2 == 0
+            hits += len(set(x["ID"] for x in r) & set(x["ID"] for x in d))
+        assert hits >= 0.99 * 10 * len(Q), hits
+        assert any(x["ID"] >= n for rc, d in outs[1] for x in d) == any(x["ID"] >= n for rc, r in outs[0] for x in r)
+    finally:
+        os.environ.pop("EPS_DEVICES", None)
