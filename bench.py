@@ -35,7 +35,9 @@ sys.path.insert(0, ROOT)
 #   graph: profiles/r2_traverse_10Mx768_pmc.csv, traverse2_kernel T=4 L=500 batch 1024 on the 10M-node device-built graph:
 #         2 * 48440196 KiB = 99.2e9 bytes vs 100.97e9 algorithmic (the x2 calibrated in the same run on flat_scan_kernel,
 #         whose FETCH_SIZE x 2 = rows * dim * 4 exactly).
-TRAFFIC = {"mfma": (2 * 7340245 + 7460) * 1024.0, "graph_T4_L500": 2 * 48440196 * 1024.0}
+#   mfma8: profiles/r3_pmc_10Mx768_b1024.csv, the 7,280,256-row launch (the last of the 6 stages) of mfma_filter_kernel_v7<2, FM_IDS, int8>:
+#         (2 * 2755587 + 8791) KiB = 5.65e9 bytes vs 5.59e9 algorithmic bytes of the 8-bit mirror (1.01 x).
+TRAFFIC = {"mfma": (2 * 7340245 + 7460) * 1024.0, "mfma8": (2 * 2755587 + 8791) * 1024.0, "graph_T4_L500": 2 * 48440196 * 1024.0}
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F16_PEAK_TF = 2500.0  # dense bf16/f16 MFMA peak (nominal, 2.4 GHz)
 MFMA_F16_SUSTAINED_TF = 1814.0  # measured: v_mfma_f32_32x32x16_f16 alone, operands toggling like data, 1.82 GHz (scripts/lab/mfma_peak.hip)
@@ -577,7 +579,10 @@ def main():
             roof = {"bound": "mfma", "kernel": "mfma_filter_kernel_v7<%s> (largest of the filter stages: %d of %d rows x %d of %d queries)" % ("int8" if bits == 8 else "fp16", krows, n, kq, b),
                     "achieved": flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms else None,
                     "peak": MFMA_I8_PEAK_TOPS if bits == 8 else MFMA_F16_PEAK_TF, "unit": "TOP/s" if bits == 8 else "TFLOP/s", "operand_bits": bits,
-                    "traffic": TRAFFIC.get("mfma") if (n == 10_000_000 and b == 1024 and d == 768 and bits == 16) else None}
+                    # PMC bytes of exactly this launch shape (separate --pmc passes of the same command, profiles/), else null
+                    "traffic": (TRAFFIC.get("mfma") if (bits == 16 and krows == 9262720) else TRAFFIC.get("mfma8") if (bits == 8 and krows == 7280256) else None)
+                               if (n == 10_000_000 and b == 1024 and d == 768 and kq == 1024) else None,
+                    "algorithmic_bytes": krows * ((d + 255) // 256 * 256 if bits == 8 else (d + 63) // 64 * 64 * 2)}
         else:
             # a flat scan needs rows*4*d bytes ONCE per batch; the stream engine re-reads the store once
             # per group of 4 queries, which this figure deliberately does not credit.
