@@ -706,8 +706,9 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
     // filter's epilogue and 3 KB of gather in the re-rank, so the looser 8-bit bound wants more, smaller steps (measured at
     // 10M x 768, batch 1024: EPS_MFMA_STAGES sweep in profiles/r3_stage_sweep.txt).
     const char* st_env = getenv("EPS_MFMA_STAGES");
-    // (few queries: the per-stage overhead outweighs the candidates a stage saves - bench.py configs c2, one query on 1M x 768)
-    int nstages = i8 ? (nq >= 256 ? 6 : (nq >= 32 ? 4 : 2)) : 3;
+    // (also for few queries: one query on 1M x 768 - bench.py configs c2 - takes 0.48 ms end to end with 6 stages and 0.56 ms with 2:
+    // the re-rank is one workgroup per query, so a stage's candidate list, not the launch count, sets the latency)
+    int nstages = i8 ? 6 : 3;
     if (i8)   // ... but never so few that a stage's expected k * c * ratio candidates come near the list capacity
       while (nstages < 8 && (double)k * 5.0 * std::pow((double)n / (double)S0, 1.0 / (double)nstages) > 0.5 * (double)cap) ++nstages;
     if (st_env) nstages = std::min(8, std::max(1, atoi(st_env)));
