@@ -98,6 +98,29 @@ def test_i8_engine_on_other_distributions(amd, kind):
     ix.close()
 
 
+def test_auto_stops_paying_for_an_8_bit_pass_that_never_filters(amd):
+    """One huge outlier stretches the grid 100 x: every batch's 8-bit lists overflow and the fp16 pass answers.  After three such
+    batches in a row EPS_FLAT_AUTO goes to the fp16 pass directly (no overflow any more); an explicit EPS_FLAT_MFMA_I8 request
+    still runs the 8-bit pass; every answer is the stream scan's."""
+    rng = np.random.default_rng(6)
+    n, d, nq = 90_000, 256, 96
+    X = rng.random((n, d), dtype=np.float32)
+    X[4321, 3] = 100.0
+    Q = rng.random((nq, d), dtype=np.float32)
+    ix = amd.GpuIndex(d, 0)
+    ix.attach_rows(X)
+    ref = ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
+    seen = []
+    for it in range(5):
+        same(ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_AUTO), ref, "auto %d" % it)
+        st = ix.stats()
+        seen.append((st["overflow_queries"] > 0, st["main_kernel_bits"]))
+    assert all(o for o, b in seen[:3]) and seen[3] == (False, 16) and seen[4] == (False, 16), seen
+    same(ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8), ref, "explicit int8")
+    assert ix.stats()["overflow_queries"] > 0
+    ix.close()
+
+
 def test_i8_engine_declines_tables_it_cannot_serve(amd):
     """All values equal (no grid), or a non-finite value: the request for the 8-bit pass is served by the fp16 / stream engine,
     same answer."""

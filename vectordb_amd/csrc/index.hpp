@@ -163,7 +163,7 @@ class Index : public IndexBase {
   int32_t flat_stream_page(const float* dq, int64_t nq, int k, int64_t row_begin, int64_t row_end, u64* run_keys, bool merge_run, int metric,
                            bool filtered, const u64* lo, int64_t lo_stride);
   friend int32_t flat_mfma_search(Index&, const float*, int64_t, int, u64*, bool, int);
-  friend int32_t flat_mfma_search_slice(Index&, const float*, int64_t, int, u64*, bool, int, int);
+  friend int32_t flat_mfma_search_slice(Index&, const float*, int64_t, int, u64*, bool, int, int, bool);
   friend int32_t graph_build(Index&, int64_t, const eps_build_params&, const BuildStage*);
   friend int32_t select_edges(Index&, const int64_t*, int64_t, const int64_t*, int32_t, int32_t, int32_t, int64_t*, int32_t*);
   friend int32_t inter_insert(Index&, const int64_t*, const int32_t*, int64_t, int32_t, int64_t*, int32_t*);
@@ -175,7 +175,8 @@ class Index : public IndexBase {
 // bits: operand width of the filter pass - 8 (int8 mirror; falls back to 16 where the table does not fit an 8-bit grid or the
 // candidate lists overflow), 16 (fp16 mirror), 0 = the library's choice
 int32_t flat_mfma_search(Index& ix, const float* dq, int64_t nq, int k, u64* run_keys, bool approx = false, int bits = 0);
-int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u64* run_keys, bool approx, int cap_scale = 1, int bits = 16);  // <= 2048 queries
+int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u64* run_keys, bool approx, int cap_scale = 1, int bits = 16,
+                               bool auto_bits = false);  // <= 2048 queries
 bool flat_mfma_profitable(const Index& ix, int64_t nq, int k);  // AUTO heuristic
 void half_mirror_free(HalfMirror* m);
 int32_t graph_upload(Index& ix);

@@ -83,6 +83,7 @@ struct HalfMirror {
   int64_t version8 = -1, n8 = 0, n_pad8 = 0;
   int d_pad8 = 0;
   bool i8_ok = false;
+  int i8_overflows = 0;         // consecutive batches whose 8-bit pass overflowed its candidate lists (the fp16 pass then answered)
   int64_t extended_rows8 = 0;
   int64_t version = -1;
   int64_t n = 0, n_pad = 0;
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(256) void query_prep8_kernel(const float* q, int64_
 
 // the 8-bit form of threshold_kernel: T[j] = int32 threshold in accumulator units (a row passes iff dot + acc0 >= T[j])
 __global__ void threshold8_kernel(const u64* run_keys, int k, int64_t nq, int64_t b_pad, const float* qstat, const float* scal8, int metric,
-                                  float u, int* T, u32* cnt, u32* gsync, float slack) {
+                                  float u, int* T, u32* cnt, u32* gsync, float slack, int approx) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= b_pad) return;
   if (j < nq) cnt[j] = 0;
@@ -426,7 +427,9 @@ __global__ void threshold8_kernel(const u64* run_keys, int k, int64_t nq, int64_
   const float margin = s * (nq_ * e1max + eq * nxhmax);
   // fp32 evaluation of the re-ranked keys, of R and of C (each a d-term sum of the magnitude below), and of the two divisions by u
   const float scale = (metric == 0 ? (fabsf(thr) + qn2 + xnmax) : (fabsf(thr) + 1.f + nq_ * nxhmax)) + fabsf(Cq) + rmax;
-  const float t = (thr - c) + margin + slack * scale + 4.f * u;
+  // approx mode (the build's kNN stage) ranks on the approximate keys themselves: a row is wanted iff its APPROXIMATE key beats the
+  // k-th best approximate key so far - no margin (with it ~4.7 x the rows pass, and every one costs an append)
+  const float t = approx ? (thr - c) + slack * scale + 4.f * u : (thr - c) + margin + slack * scale + 4.f * u;
   float v = floorf((Cq - t) / u) - 2.f;
   v = fminf(fmaxf(v, -1073741824.f), 1073741824.f);
   T[j] = v >= 1073741824.f ? 0x7FFFFFFF : (int)v;
@@ -436,7 +439,7 @@ __global__ void threshold8_kernel(const u64* run_keys, int k, int64_t nq, int64_
 // Also resets what the stage's filter launch accumulates into (candidate counts, group arrival counters), so a stage is
 // threshold -> filter -> counts -> re-rank without separate memsets.
 __global__ void threshold_kernel(const u64* run_keys, int k, int64_t nq, int64_t b_pad, const float* qstat,
-                                 const float* scal, int metric, float* T, u32* cnt, u32* gsync, float slack) {
+                                 const float* scal, int metric, float* T, u32* cnt, u32* gsync, float slack, int approx) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= b_pad) return;
   if (j < nq) cnt[j] = 0;
@@ -458,7 +461,7 @@ __global__ void threshold_kernel(const u64* run_keys, int k, int64_t nq, int64_t
   const float c = metric == 0 ? qn2 : (metric == 1 ? 1.f : 0.f);
   const float margin = s * (nq_ * e1max + eq * nxhmax);
   const float scale = metric == 0 ? (fabsf(thr) + qn2 + xnmax) : (fabsf(thr) + 1.f + nq_ * nxhmax);
-  float t = (thr - c) + margin + slack * scale;
+  float t = (thr - c) + (approx ? 0.f : margin) + slack * scale;   // (approx mode ranks on the approximate keys: no margin)
   T[j] = fminf(t, FMAX);
 }
 
@@ -612,6 +615,7 @@ static int32_t ensure_mirror8(Index& ix) {
     m.x8.release();
     m.acc0.release();
   }
+  if (!extend) m.i8_overflows = 0;
   m.n8 = n;
   m.n_pad8 = n_pad;
   m.d_pad8 = d_pad8;
@@ -643,14 +647,17 @@ bool flat_mfma_profitable(const Index& ix, int64_t nq, int k) {
   return filter_s < stream_s;
 }
 
-int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u64* run_keys, bool approx, int cap_scale, int bits) {
+int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u64* run_keys, bool approx, int cap_scale, int bits, bool auto_bits) {
   // operand width of the filter pass: 8 = int8 mirror (when the table fits its grid), 16 = fp16 mirror
   bool i8 = bits == 8;
   int32_t rc = EPS_OK;
   if (i8) {
     rc = ensure_mirror8(ix);
     if (rc != EPS_OK) return rc;
-    if (!ix.mirror_->i8_ok) i8 = false;
+    // a table whose 8-bit bound is too loose to filter (an outlier stretches the grid, rows far outside it) overflows on every
+    // batch: after three in a row the library's own choice stops paying for the 8-bit pass first (an explicit EPS_FLAT_MFMA_I8
+    // request still gets it; re-attaching rows re-arms it)
+    if (!ix.mirror_->i8_ok || (auto_bits && ix.mirror_->i8_overflows >= 3)) i8 = false;
   }
   if (!i8) {
     rc = ensure_mirror(ix);
@@ -890,10 +897,10 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
     const int64_t lo = bounds[st], hi = bounds[st + 1];
     if (i8)
       hipLaunchKernelGGL(threshold8_kernel, dim3((unsigned)((b_pad + 255) / 256)), dim3(256), 0, s, run_keys, k, nq, b_pad, m.qstat.as<float>(),
-                         m.scal8.as<float>(), ix.metric_, u8, m.T.as<int>(), cnt, m.gsync.as<u32>(), rerank_slack);
+                         m.scal8.as<float>(), ix.metric_, u8, m.T.as<int>(), cnt, m.gsync.as<u32>(), rerank_slack, approx ? 1 : 0);
     else
       hipLaunchKernelGGL(threshold_kernel, dim3((unsigned)((b_pad + 255) / 256)), dim3(256), 0, s, run_keys, k, nq, b_pad,
-                         m.qstat.as<float>(), m.scal.as<float>(), ix.metric_, m.T.as<float>(), cnt, m.gsync.as<u32>(), rerank_slack);
+                         m.qstat.as<float>(), m.scal.as<float>(), ix.metric_, m.T.as<float>(), cnt, m.gsync.as<u32>(), rerank_slack, approx ? 1 : 0);
     fa.tile0 = lo / bm;
     fa.ntiles = (hi + bm - 1) / bm - fa.tile0;
     fa.row_hi = hi;
@@ -953,11 +960,15 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
       // (selective filters inflate the lists by 1 / pass fraction, adversarial row orders by more): first retry with 16 x
       // the candidate slots - re-ranking tens of thousands of rows per query is still ~50 x cheaper than the stream scan
       // of a large batch - then the exact stream engine
-      if (i8) return flat_mfma_search_slice(ix, dq, nq, k, run_keys, approx, 1, 16);   // the looser 8-bit bound let too much through: fp16 pass
-      if (cap_scale == 1 && (size_t)nq * cap * 16 * 8 <= ((size_t)4 << 30)) return flat_mfma_search_slice(ix, dq, nq, k, run_keys, approx, 16, 16);
+      if (i8) {   // the looser 8-bit bound let too much through: fp16 pass
+        m.i8_overflows += 1;
+        return flat_mfma_search_slice(ix, dq, nq, k, run_keys, approx, 1, 16, false);
+      }
+      if (cap_scale == 1 && (size_t)nq * cap * 16 * 8 <= ((size_t)4 << 30)) return flat_mfma_search_slice(ix, dq, nq, k, run_keys, approx, 16, 16, false);
       return ix.flat_stream(dq, nq, k, 0, n, run_keys, false);
     }
   }
+  if (i8) m.i8_overflows = 0;
   return EPS_OK;
 }
 
@@ -965,14 +976,15 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
 // each XCD's 4 MB L2 while the row operand streams past; at 4096 / 8192 queries per pass the query fragments thrash L2
 // and the filter drops to 0.37 / 0.27 of the MFMA peak (0.46 in slices; bench.py --rows 1250000 --batch 8192).
 int32_t flat_mfma_search(Index& ix, const float* dq, int64_t nq, int k, u64* run_keys, bool approx, int bits) {
-  if (bits != 8 && bits != 16) {   // the library's choice: 8-bit first pass unless switched off (EPS_MFMA_BITS=16, A/B) - tables it cannot serve fall back by themselves
+  const bool auto_bits = bits != 8 && bits != 16;
+  if (auto_bits) {   // the library's choice: 8-bit first pass unless switched off (EPS_MFMA_BITS=16, A/B) - tables it cannot serve fall back by themselves
     const char* e = getenv("EPS_MFMA_BITS");
     bits = (e && atoi(e) == 16) ? 16 : 8;
   }
   const int64_t slice = getenv("EPS_MFMA_MAX_BATCH") ? std::max(256, atoi(getenv("EPS_MFMA_MAX_BATCH"))) : 2048;
-  if (nq <= slice) return flat_mfma_search_slice(ix, dq, nq, k, run_keys, approx, 1, bits);
+  if (nq <= slice) return flat_mfma_search_slice(ix, dq, nq, k, run_keys, approx, 1, bits, auto_bits);
   for (int64_t q0 = 0; q0 < nq; q0 += slice) {   // the counters in ix.stats_ accumulate over the slices
-    const int32_t rc = flat_mfma_search_slice(ix, dq + q0 * ix.dim_, std::min(slice, nq - q0), k, run_keys + q0 * k, approx, 1, bits);
+    const int32_t rc = flat_mfma_search_slice(ix, dq + q0 * ix.dim_, std::min(slice, nq - q0), k, run_keys + q0 * k, approx, 1, bits, auto_bits);
     if (rc != EPS_OK) return rc;
   }
   return EPS_OK;
