@@ -152,6 +152,37 @@ __device__ __forceinline__ bool row_visible(const FilterSpec& f, u32 id, float d
   return true;
 }
 
+// ---- pass thresholds of the MFMA filter stages (mfma_filter.hip explains the bounds).  kth_dist: the k-th best exact (or, in approx
+// mode, approximate) distance so far; qs: the query's |q|^2, |q|, |q - qh|, (8-bit: C + const) ; sc: the mirror's maxima.
+// fp16 operands: T in key space (float)
+__device__ __forceinline__ float stage_threshold16(float thr, const float* qs, const float* sc, int metric, float slack, int approx) {
+  const float qn2 = qs[0], nq_ = qs[1], eq = qs[2];
+  const float e1max = sc[0], nxhmax = sc[1], xnmax = sc[2];
+  const float s = metric == 0 ? 2.f : 1.f;
+  const float c = metric == 0 ? qn2 : (metric == 1 ? 1.f : 0.f);
+  const float margin = s * (nq_ * e1max + eq * nxhmax);
+  const float scale = metric == 0 ? (fabsf(thr) + qn2 + xnmax) : (fabsf(thr) + 1.f + nq_ * nxhmax);
+  const float t = (thr - c) + (approx ? 0.f : margin) + slack * scale;   // (approx mode ranks on the approximate keys: no margin)
+  return fminf(t, 3.0e38f);
+}
+// int8 operands: T in accumulator units (int32): a row passes iff dot + acc0 >= T
+__device__ __forceinline__ int stage_threshold8(float thr, const float* qs, const float* sc, int metric, float u, float slack, int approx) {
+  const float qn2 = qs[0], nq_ = qs[1], eq = qs[2];
+  const float e1max = sc[0], nxhmax = sc[1], xnmax = sc[2], rmax = sc[4];
+  const float s = metric == 0 ? 2.f : 1.f;
+  const float c = metric == 0 ? qn2 : (metric == 1 ? 1.f : 0.f);
+  const float Cq = qs[3] - c;
+  const float margin = s * (nq_ * e1max + eq * nxhmax);
+  // fp32 evaluation of the re-ranked keys, of R and of C (each a d-term sum of the magnitude below), and of the two divisions by u
+  const float scale = (metric == 0 ? (fabsf(thr) + qn2 + xnmax) : (fabsf(thr) + 1.f + nq_ * nxhmax)) + fabsf(Cq) + rmax;
+  // approx mode (the build's kNN stage) ranks on the approximate keys themselves: a row is wanted iff its APPROXIMATE key beats the
+  // k-th best approximate key so far - no margin (with it ~4.7 x the rows pass, and every one costs an append)
+  const float t = approx ? (thr - c) + slack * scale + 4.f * u : (thr - c) + margin + slack * scale + 4.f * u;
+  float v = floorf((Cq - t) / u) - 2.f;
+  v = fminf(fmaxf(v, -1073741824.f), 1073741824.f);
+  return v >= 1073741824.f ? 0x7FFFFFFF : (int)v;
+}
+
 // Seed sample of the MFMA engine: sample entry i is table row i for the first `head` entries (the head of the table), then
 // rows spread evenly over the rest: head + ((i - head) * stride >> 32), stride = (rest rows / rest entries) in 32.32.
 __host__ __device__ __forceinline__ u32 seed_row(u32 i, u32 head, u64 stride) {

@@ -199,14 +199,19 @@ void launch_merge_lists(const u64* partial, int lists, int k, int64_t nq, u64* r
 
 // ------------------------------------------------------------------------------------------------
 // exact re-rank of candidate rows gathered by id (fp32, direct form) into the running top-k.
-template <int KPL, bool VEC4>
-__global__ __launch_bounds__(256) void rerank_kernel(RerankArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // [qstride] query, then 4 lists
+// NW wavefronts per query: 4 for batches (one workgroup per query fills the chip), 16 for a handful of queries (latency: a stage's
+// ~150 candidate rows are 3 gather rounds instead of 10).
+template <int KPL, bool VEC4, int NW>
+__global__ __launch_bounds__(NW * 64) void rerank_kernel(RerankArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [qstride] query, then NW lists
+  constexpr int NT = NW * 64;
   const int dim = a.dim;
   const int qstride = (dim + 3) & ~3;
   u64* sh = reinterpret_cast<u64*>(smem + qstride);  // qstride*4 bytes is a multiple of 16
   const int64_t q = blockIdx.x;
-  for (int i = threadIdx.x; i < qstride; i += 256) smem[i] = i < dim ? a.queries[q * dim + i] : 0.f;
+  for (int i = threadIdx.x; i < qstride; i += NT) smem[i] = i < dim ? a.queries[q * dim + i] : 0.f;
+  if (a.fuse && a.gsync && q == 0)
+    for (int i = threadIdx.x; i < 256; i += NT) a.gsync[i] = 0;
   __syncthreads();
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
@@ -215,7 +220,8 @@ __global__ __launch_bounds__(256) void rerank_kernel(RerankArgs a) {
   const int g = lane / G;
   const int t = lane & (G - 1);
   constexpr int U = 4;
-  u32 cnt = a.cand_count[q];
+  const u32 cnt_raw = a.cand_count[q];
+  u32 cnt = cnt_raw;
   if (cnt > (u32)a.cap) cnt = (u32)a.cap;
   const u32* cand = a.cand + q * (int64_t)a.cap;
 
@@ -225,7 +231,7 @@ __global__ __launch_bounds__(256) void rerank_kernel(RerankArgs a) {
   thr[0] = a.run_keys[q * a.k + (a.k - 1)];
   if (wave == 0) L[0].load(a.run_keys + q * a.k, a.k);
 
-  for (u32 c0 = wave * RPW * U; c0 < cnt; c0 += 4 * RPW * U) {
+  for (u32 c0 = wave * RPW * U; c0 < cnt; c0 += NW * RPW * U) {
     const float* rp[U];
     u32 id[U];
     bool ok[U];
@@ -245,10 +251,10 @@ __global__ __launch_bounds__(256) void rerank_kernel(RerankArgs a) {
     }
   }
   L[0].store(sh + wave * (KPL * 64), a.k);
-  __syncthreads();
+  __syncthreads();   // (every wavefront has read the query's candidate count by now)
   if (wave == 0) {
     FilterSpec nof = {nullptr, nullptr, 0, 0, 0, 0};
-    for (int w = 1; w < 4; ++w) {
+    for (int w = 1; w < NW; ++w) {
       for (int e0 = 0; e0 < a.k; e0 += 64) {
         const int e = e0 + lane;
         const u64 key = e < a.k ? sh[w * (KPL * 64) + e] : KEY_EMPTY;
@@ -256,6 +262,24 @@ __global__ __launch_bounds__(256) void rerank_kernel(RerankArgs a) {
       }
     }
     L[0].store(a.run_keys + q * a.k, a.k);
+    if (a.fuse) {
+      const u64 kth = L[0].entry(a.k - 1);   // (wave-uniform)
+      if (lane == 0) {
+        if (a.fuse & 1) {
+          if (cnt_raw > (u32)a.cap) atomicAdd(a.overflow, 1u);
+          atomicAdd(a.total, (unsigned long long)cnt);
+        }
+        a.cand_count[q] = 0;
+        if (a.T_next) {
+          const float* qs = a.qstat + q * 4;
+          if (a.bits == 8) {
+            static_cast<int*>(a.T_next)[q] = kth == KEY_EMPTY ? -(1 << 30) : stage_threshold8(key_dist(kth), qs, a.scal, a.metric, a.u, a.slack, 0);
+          } else {
+            static_cast<float*>(a.T_next)[q] = kth == KEY_EMPTY ? 3.0e38f : stage_threshold16(key_dist(kth), qs, a.scal, a.metric, a.slack, 0);
+          }
+        }
+      }
+    }
   }
 }
 
@@ -263,14 +287,18 @@ void launch_rerank(const RerankArgs& a, hipStream_t s) {
   if (a.nq <= 0) return;
   const bool vec4 = (a.dim % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.rows) & 15) == 0);
   const int kpl = pick_kpl(a.k);
-  const size_t shm = (size_t)((a.dim + 3) & ~3) * sizeof(float) + (size_t)4 * kpl * 64 * sizeof(u64);
-#define EPS_CASE(KPL_)                                                                                   \
-  if (kpl == KPL_) {                                                                                     \
-    if (vec4)                                                                                            \
-      hipLaunchKernelGGL((rerank_kernel<KPL_, true>), dim3((unsigned)a.nq), dim3(256), shm, s, a);      \
-    else                                                                                                 \
-      hipLaunchKernelGGL((rerank_kernel<KPL_, false>), dim3((unsigned)a.nq), dim3(256), shm, s, a);     \
-    return;                                                                                              \
+  const int nw = (a.nq <= 64 && kpl <= 4) ? 16 : 4;
+  const size_t shm = (size_t)((a.dim + 3) & ~3) * sizeof(float) + (size_t)nw * kpl * 64 * sizeof(u64);
+#define EPS_CASE(KPL_)                                                                                               \
+  if (kpl == KPL_) {                                                                                                 \
+    if (nw == 16) {                                                                                                  \
+      if (vec4) hipLaunchKernelGGL((rerank_kernel<KPL_, true, 16>), dim3((unsigned)a.nq), dim3(1024), shm, s, a);    \
+      else hipLaunchKernelGGL((rerank_kernel<KPL_, false, 16>), dim3((unsigned)a.nq), dim3(1024), shm, s, a);        \
+    } else {                                                                                                         \
+      if (vec4) hipLaunchKernelGGL((rerank_kernel<KPL_, true, 4>), dim3((unsigned)a.nq), dim3(256), shm, s, a);      \
+      else hipLaunchKernelGGL((rerank_kernel<KPL_, false, 4>), dim3((unsigned)a.nq), dim3(256), shm, s, a);          \
+    }                                                                                                                \
+    return;                                                                                                          \
   }
   EPS_CASE(1) EPS_CASE(2) EPS_CASE(4) EPS_CASE(8) EPS_CASE(16)
 #undef EPS_CASE

@@ -503,6 +503,7 @@ int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp, const Buil
           ra.cand_count = cntA.as<u32>();
           ra.cap = kA;
           ra.run_keys = run.as<u64>();
+          ra.fuse = 0;
           launch_rerank(ra, s);
         }
       } else {

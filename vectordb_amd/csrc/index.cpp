@@ -679,6 +679,26 @@ int32_t Index::search(const float* queries, int64_t nq, int32_t k, const eps_sea
   u64* run_keys = run_buf_.as<u64>();
   HIP_TRY(hipEventRecord(ev0_, stream_));
 
+  // results out (decided before the engines run: the matrix engine launches the result conversion itself, in front of its final
+  // host sync, so that the device does not idle through that round trip)
+  int64_t* d_ids = ids;
+  float* d_dist = dist;
+  int32_t* d_cnt = counts;
+  if (!out_dev) {
+    if (!ids_buf_.reserve((size_t)nq * k * sizeof(int64_t)) || !dist_buf_.reserve((size_t)nq * k * sizeof(float)) ||
+        !cnt_buf_.reserve((size_t)nq * sizeof(int32_t)))
+      return fail(EPS_INFRA_UNEXPECTED_ERROR, "search: out of device memory (outputs)");
+    d_ids = ids_buf_.as<int64_t>();
+    d_dist = dist_buf_.as<float>();
+    d_cnt = cnt_buf_.as<int32_t>();
+  }
+  result_finalized_ = false;
+  auto finalize = [&]() {
+    launch_finalize(run_keys, nq, k, id_base_, id_stride_, d_ids, d_dist, d_cnt, stream_);
+    (void)hipEventRecord(ev1_, stream_);
+    result_finalized_ = true;
+  };
+
   int keff = k;
   if (mode == EPS_MODE_FLAT) {
     if (cap_local && p.local_queue < keff) keff = (int)p.local_queue;
@@ -694,8 +714,15 @@ int32_t Index::search(const float* queries, int64_t nq, int32_t k, const eps_sea
     if (keff > 1024) engine = EPS_FLAT_STREAM;   // result pages (see flat_stream)
     int32_t rc;
     if (keff == k) {
-      rc = engine == EPS_FLAT_MFMA ? flat_mfma_search(*this, dq, nq, k, run_keys, false, bits)
-                                   : flat_stream(dq, nq, k, 0, n_rows_, run_keys, false);
+      if (engine == EPS_FLAT_MFMA) {
+        pre_sync_ = finalize;   // (called by the engine in front of its final sync; again after a fall-back pass)
+        pre_sync_nq_ = nq;
+        rc = flat_mfma_search(*this, dq, nq, k, run_keys, false, bits);
+        pre_sync_ = nullptr;
+        pre_sync_nq_ = -1;
+      } else {
+        rc = flat_stream(dq, nq, k, 0, n_rows_, run_keys, false);
+      }
     } else {
       // narrower result (L_local cap): compute into a k_eff-wide list, then widen
       if (!tmp_buf_.reserve((size_t)nq * keff * sizeof(u64))) return fail(EPS_INFRA_UNEXPECTED_ERROR, "search: out of device memory");
@@ -714,20 +741,7 @@ int32_t Index::search(const float* queries, int64_t nq, int32_t k, const eps_sea
   }
   (void)limit;
 
-  // results out
-  int64_t* d_ids = ids;
-  float* d_dist = dist;
-  int32_t* d_cnt = counts;
-  if (!out_dev) {
-    if (!ids_buf_.reserve((size_t)nq * k * sizeof(int64_t)) || !dist_buf_.reserve((size_t)nq * k * sizeof(float)) ||
-        !cnt_buf_.reserve((size_t)nq * sizeof(int32_t)))
-      return fail(EPS_INFRA_UNEXPECTED_ERROR, "search: out of device memory (outputs)");
-    d_ids = ids_buf_.as<int64_t>();
-    d_dist = dist_buf_.as<float>();
-    d_cnt = cnt_buf_.as<int32_t>();
-  }
-  launch_finalize(run_keys, nq, k, id_base_, id_stride_, d_ids, d_dist, d_cnt, stream_);
-  HIP_TRY(hipEventRecord(ev1_, stream_));
+  if (!result_finalized_) finalize();
   if (!out_dev) {
     HIP_TRY(hipMemcpyAsync(ids, d_ids, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipMemcpyAsync(dist, d_dist, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, stream_));

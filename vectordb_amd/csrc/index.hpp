@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -156,6 +157,11 @@ class Index : public IndexBase {
   int64_t fcol_rows_ = 0;       // rows the attribute column behind d_fcol_ covers
 
   eps_search_stats stats_{};
+  // set by search() around a matrix-engine call: what the engine launches right before its final host sync (the result conversion),
+  // so that the device works through the round trip; only called when the batch is one slice
+  std::function<void()> pre_sync_;
+  bool result_finalized_ = false;   // the conversion has run on the CURRENT contents of the result keys (an engine that rewrites them clears it)
+  int64_t pre_sync_nq_ = -1;   // queries of the call that set it (a batch run in slices converts after the last slice instead)
 
  private:
   int32_t flat_stream(const float* dq, int64_t nq, int k, int64_t row_begin, int64_t row_end, u64* run_keys,

@@ -43,9 +43,22 @@ struct RerankArgs {
   int k;
   FilterSpec f;
   const u32* cand;          // [nq][cap] local row ids
-  const u32* cand_count;    // [nq] (may exceed cap: only min(count,cap) are present)
+  u32* cand_count;          // [nq] (may exceed cap: only min(count,cap) are present); zeroed per query when fuse is set
   int cap;
   u64* run_keys;            // [nq][k] in/out
+  // Stage bookkeeping of the MFMA engine folded into the re-rank (r3; it was two tiny launches per stage): after query q's re-rank
+  // the block (i) adds the stage's candidate count to the overflow / total counters, (ii) computes the NEXT stage's pass threshold
+  // from the query's new k-th best exact key, (iii) zeroes the query's candidate count and (block 0) the group arrival counters
+  // for the next filter launch.  fuse = 0: none of it.
+  int fuse;
+  u32* overflow;            // [1]
+  unsigned long long* total;   // [1]
+  void* T_next;             // float [b_pad] (fp16 operands) / int [b_pad] (int8 operands), or null after the last stage
+  const float* qstat;       // [b_pad][4]
+  const float* scal;        // the mirror's maxima
+  int bits;                 // 8 | 16
+  float u, slack;
+  u32* gsync;               // [256] or null
 };
 void launch_rerank(const RerankArgs& a, hipStream_t s);
 

@@ -402,67 +402,39 @@ __global__ __launch_bounds__(256) void query_prep8_kernel(const float* q, int64_
   }
 }
 
-// the 8-bit form of threshold_kernel: T[j] = int32 threshold in accumulator units (a row passes iff dot + acc0 >= T[j])
+// T[j]: pass threshold of query j for the next filter launch, from the current k-th best key (formulas: device_common.hpp,
+// stage_threshold8 / stage_threshold16).  Also resets what the launch accumulates into (candidate counts, group arrival counters).
+// In exact mode a stage's re-rank computes the next stage's thresholds itself (RerankArgs::fuse); these kernels serve the
+// approx mode (kNN build), the unseeded staging, and the padding entries.
 __global__ void threshold8_kernel(const u64* run_keys, int k, int64_t nq, int64_t b_pad, const float* qstat, const float* scal8, int metric,
-                                  float u, int* T, u32* cnt, u32* gsync, float slack, int approx) {
+                                  float u, int* T, u32* cnt, u32* gsync, float slack, int approx, int pad_only) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= b_pad) return;
-  if (j < nq) cnt[j] = 0;
-  if (gsync && j < 256) gsync[j] = 0;
+  if (!pad_only && gsync && j < 256) gsync[j] = 0;   // (all 256 counters, whatever nq: b_pad >= 256)
   if (j >= nq) {
-    T[j] = 0x7FFFFFFF;
+    T[j] = 0x7FFFFFFF;   // padding queries never pass
     return;
   }
+  if (pad_only) return;
+  cnt[j] = 0;
   const u64 kth = run_keys[j * k + (k - 1)];
-  if (kth == KEY_EMPTY) {
-    T[j] = -(1 << 30);   // fewer than k visible rows so far: everything passes (bounded by the candidate cap)
-    return;
-  }
-  const float thr = key_dist(kth);
-  const float qn2 = qstat[j * 4 + 0], nq_ = qstat[j * 4 + 1], eq = qstat[j * 4 + 2];
-  const float e1max = scal8[0], nxhmax = scal8[1], xnmax = scal8[2], rmax = scal8[4];
-  const float s = metric == 0 ? 2.f : 1.f;
-  const float c = metric == 0 ? qn2 : (metric == 1 ? 1.f : 0.f);
-  const float Cq = qstat[j * 4 + 3] - c;
-  const float margin = s * (nq_ * e1max + eq * nxhmax);
-  // fp32 evaluation of the re-ranked keys, of R and of C (each a d-term sum of the magnitude below), and of the two divisions by u
-  const float scale = (metric == 0 ? (fabsf(thr) + qn2 + xnmax) : (fabsf(thr) + 1.f + nq_ * nxhmax)) + fabsf(Cq) + rmax;
-  // approx mode (the build's kNN stage) ranks on the approximate keys themselves: a row is wanted iff its APPROXIMATE key beats the
-  // k-th best approximate key so far - no margin (with it ~4.7 x the rows pass, and every one costs an append)
-  const float t = approx ? (thr - c) + slack * scale + 4.f * u : (thr - c) + margin + slack * scale + 4.f * u;
-  float v = floorf((Cq - t) / u) - 2.f;
-  v = fminf(fmaxf(v, -1073741824.f), 1073741824.f);
-  T[j] = v >= 1073741824.f ? 0x7FFFFFFF : (int)v;
+  // fewer than k visible rows so far: everything passes (bounded by the candidate cap)
+  T[j] = kth == KEY_EMPTY ? -(1 << 30) : stage_threshold8(key_dist(kth), qstat + j * 4, scal8, metric, u, slack, approx);
 }
 
-// T[j]: pass threshold in approx-key space for query j, from the current k-th best exact distance.
-// Also resets what the stage's filter launch accumulates into (candidate counts, group arrival counters), so a stage is
-// threshold -> filter -> counts -> re-rank without separate memsets.
 __global__ void threshold_kernel(const u64* run_keys, int k, int64_t nq, int64_t b_pad, const float* qstat,
-                                 const float* scal, int metric, float* T, u32* cnt, u32* gsync, float slack, int approx) {
+                                 const float* scal, int metric, float* T, u32* cnt, u32* gsync, float slack, int approx, int pad_only) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= b_pad) return;
-  if (j < nq) cnt[j] = 0;
-  if (gsync && j < 256) gsync[j] = 0;
+  if (!pad_only && gsync && j < 256) gsync[j] = 0;
   if (j >= nq) {
     T[j] = -__builtin_inff();
     return;
   }
+  if (pad_only) return;
+  cnt[j] = 0;
   const u64 kth = run_keys[j * k + (k - 1)];
-  const float FMAX = 3.0e38f;
-  if (kth == KEY_EMPTY) {
-    T[j] = FMAX;  // fewer than k visible rows so far: everything passes (bounded by the candidate cap)
-    return;
-  }
-  const float thr = key_dist(kth);
-  const float qn2 = qstat[j * 4 + 0], nq_ = qstat[j * 4 + 1], eq = qstat[j * 4 + 2];
-  const float e1max = scal[0], nxhmax = scal[1], xnmax = scal[2];
-  const float s = metric == 0 ? 2.f : 1.f;
-  const float c = metric == 0 ? qn2 : (metric == 1 ? 1.f : 0.f);
-  const float margin = s * (nq_ * e1max + eq * nxhmax);
-  const float scale = metric == 0 ? (fabsf(thr) + qn2 + xnmax) : (fabsf(thr) + 1.f + nq_ * nxhmax);
-  float t = (thr - c) + (approx ? 0.f : margin) + slack * scale;   // (approx mode ranks on the approximate keys: no margin)
-  T[j] = fminf(t, FMAX);
+  T[j] = kth == KEY_EMPTY ? 3.0e38f : stage_threshold16(key_dist(kth), qstat + j * 4, scal, metric, slack, approx);
 }
 
 
@@ -796,6 +768,17 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   ra.cand_count = cnt;
   ra.cap = cap;
   ra.run_keys = run_keys;
+  // stage bookkeeping folded into the re-rank (exact mode): counts of the stage it follows + thresholds of the stage that follows it
+  ra.fuse = approx ? 0 : 1;
+  ra.overflow = overflow;
+  ra.total = total;
+  ra.T_next = nullptr;
+  ra.qstat = m.qstat.as<float>();
+  ra.scal = i8 ? m.scal8.as<float>() : m.scal.as<float>();
+  ra.bits = i8 ? 8 : 16;
+  ra.u = u8;
+  ra.slack = 0.f;   // (set below, with the stages)
+  ra.gsync = m.gsync.as<u32>();
 
   const int bm = BM3;   // every kernel generation works on 256-row tiles
   const size_t shm = version >= 7 ? V7_LDS_BYTES : 2 * 65536 + 2 * 256 * sizeof(float);
@@ -843,6 +826,12 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
       else hipLaunchKernelGGL(mfma_filter_kernel_v3, dim3((unsigned)num_cus), dim3(512), shm, s, f3);
     }
   };
+  // fp32 rounding of the keys the threshold compares: |x|^2, |q|^2 and the re-ranked distance are each a 64-lane sum of
+  // d_pad/64 sequential fmas per lane plus a 6-level shuffle tree, i.e. <= (d_pad/64 + 6) * 2^-24 relative to their
+  // magnitude each; doubled for safety.  (A fixed 8e-6 was only enough up to d ~ 1000.)
+  const float rerank_slack = std::max(8e-6f, 2.f * (3.f * ((float)((ix.dim_ + 63) / 64 * 64) / 64.f + 6.f) + 2.f) * 5.9604645e-8f);
+  ra.slack = rerank_slack;
+  const bool fused = !approx;   // exact mode: every re-rank also does its stage's counts and the next stage's thresholds
   if (seeded) {
     launch_fill_u64(reinterpret_cast<u64*>(m.T.p), b_pad / 2, 0x7F8000007F800000ull, s);   // T = +inf: every head row is a candidate
     const bool dense = version >= 7;   // v7 writes the head's keys densely (slot = row); older kernels append with atomics
@@ -885,22 +874,28 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
     launch_merge_lists(f0.cand_keys, cap, k, nq, run_keys, false, s, cnt, approx ? nullptr : &fs, seed_stride, seed_head);   // k best approximate keys of the visible seeds
     if (!approx) {
       hipLaunchKernelGGL(seed_to_cand_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, run_keys, k, nq, fa.cand, cap, cnt, seed_stride, seed_head);
+      ra.fuse = 2;                                                              // (thresholds of the first stage; the seeds are not a stage's candidates)
+      ra.T_next = m.T.p;
       launch_rerank(ra, s);                                                    // -> their exact keys
     }
   }
-  // fp32 rounding of the keys the threshold compares: |x|^2, |q|^2 and the re-ranked distance are each a 64-lane sum of
-  // d_pad/64 sequential fmas per lane plus a 6-level shuffle tree, i.e. <= (d_pad/64 + 6) * 2^-24 relative to their
-  // magnitude each; doubled for safety.  (A fixed 8e-6 was only enough up to d ~ 1000.)
-  const float rerank_slack = std::max(8e-6f, 2.f * (3.f * ((float)((ix.dim_ + 63) / 64 * 64) / 64.f + 6.f) + 2.f) * 5.9604645e-8f);
   bool first = true;
   for (size_t st = 0; st + 1 < bounds.size(); ++st) {
     const int64_t lo = bounds[st], hi = bounds[st + 1];
-    if (i8)
-      hipLaunchKernelGGL(threshold8_kernel, dim3((unsigned)((b_pad + 255) / 256)), dim3(256), 0, s, run_keys, k, nq, b_pad, m.qstat.as<float>(),
-                         m.scal8.as<float>(), ix.metric_, u8, m.T.as<int>(), cnt, m.gsync.as<u32>(), rerank_slack, approx ? 1 : 0);
-    else
-      hipLaunchKernelGGL(threshold_kernel, dim3((unsigned)((b_pad + 255) / 256)), dim3(256), 0, s, run_keys, k, nq, b_pad,
-                         m.qstat.as<float>(), m.scal.as<float>(), ix.metric_, m.T.as<float>(), cnt, m.gsync.as<u32>(), rerank_slack, approx ? 1 : 0);
+    {
+      // thresholds of this stage: from the previous re-rank (fused), except for the padding entries (once), the approx mode and
+      // the unseeded staging (whose stage 0 was a stream scan)
+      const bool have_T = fused && (st > 0 || seeded);
+      const int pad_only = have_T ? 1 : 0;
+      if (!have_T || st == 0) {
+        if (i8)
+          hipLaunchKernelGGL(threshold8_kernel, dim3((unsigned)((b_pad + 255) / 256)), dim3(256), 0, s, run_keys, k, nq, b_pad, m.qstat.as<float>(),
+                             m.scal8.as<float>(), ix.metric_, u8, m.T.as<int>(), cnt, m.gsync.as<u32>(), rerank_slack, approx ? 1 : 0, pad_only);
+        else
+          hipLaunchKernelGGL(threshold_kernel, dim3((unsigned)((b_pad + 255) / 256)), dim3(256), 0, s, run_keys, k, nq, b_pad,
+                             m.qstat.as<float>(), m.scal.as<float>(), ix.metric_, m.T.as<float>(), cnt, m.gsync.as<u32>(), rerank_slack, approx ? 1 : 0, pad_only);
+      }
+    }
     fa.tile0 = lo / bm;
     fa.ntiles = (hi + bm - 1) / bm - fa.tile0;
     fa.row_hi = hi;
@@ -913,7 +908,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
     }
     launch_filter(fa);
     if (biggest) (void)hipEventRecord(ix.evk1_, s);
-    hipLaunchKernelGGL(stage_counts_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, cnt, nq, cap, overflow, total);
+    if (!fused) hipLaunchKernelGGL(stage_counts_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, cnt, nq, cap, overflow, total);
     if (getenv("EPS_DEBUG")) {
       std::vector<u32> hc((size_t)nq);
       std::vector<float> hT((size_t)nq);
@@ -926,10 +921,13 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
       for (int64_t j = 0; j < nq; ++j) { mn = std::min(mn, hc[j]); mx = std::max(mx, hc[j]); sum += hc[j]; tmin = std::min(tmin, hT[j]); tmax = std::max(tmax, hT[j]); empt += hk[j * k + k - 1] == KEY_EMPTY; big += hc[j] > (u32)cap; }
       fprintf(stderr, "[eps] stage %zu rows [%lld,%lld) tiles %lld: cnt min %u mean %.1f max %u (>cap: %lld), T min %g max %g, empty kth %lld, scal %g %g %g\n", st, (long long)lo, (long long)hi, (long long)fa.ntiles, mn, sum / nq, mx, (long long)big, tmin, tmax, (long long)empt, m.h_scal[0], m.h_scal[1], m.h_scal[2]);
     }
-    if (approx)
-      launch_merge_lists(fa.cand_keys, cap, k, nq, run_keys, true, s, cnt);  // select on the fp16 keys
-    else
+    if (approx) {
+      launch_merge_lists(fa.cand_keys, cap, k, nq, run_keys, true, s, cnt);  // select on the approximate keys
+    } else {
+      ra.fuse = 3;                                                            // this stage's counts + the next stage's thresholds
+      ra.T_next = (st + 2 < bounds.size()) ? m.T.p : nullptr;
       launch_rerank(ra, s);
+    }
     first = false;
   }
   (void)first;
@@ -939,6 +937,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
     u32 overflow, pad;
     unsigned long long total;
   } h = {0, 0, 0};
+  if (ix.pre_sync_ && !approx && nq == ix.pre_sync_nq_) ix.pre_sync_();   // (speculative: a fall-back pass below converts again)
   er = hipMemcpyAsync(&h.overflow, overflow, 4, hipMemcpyDeviceToHost, s);
   if (er == hipSuccess) er = hipMemcpyAsync(&h.total, total, 8, hipMemcpyDeviceToHost, s);
   if (er == hipSuccess) er = hipStreamSynchronize(s);
@@ -955,6 +954,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   ix.stats_.dist_evals += nq * (n - bounds[0]) + (seeded ? nq * S0 : 0);   // (exact mode visits the head twice)
   ix.stats_.main_kernel_launches = 1;
   if (h.overflow) {
+    ix.result_finalized_ = false;   // (whatever was converted before the sync is stale: a pass below rewrites the result keys)
     ix.stats_.overflow_queries += h.overflow;
     if (!approx && !fa.ablate) {
       // (selective filters inflate the lists by 1 / pass fraction, adversarial row orders by more): first retry with 16 x
