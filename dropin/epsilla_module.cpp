@@ -313,7 +313,7 @@ static PyObject* eps_query_batch(PyObject* self, PyObject* args, PyObject* kwarg
   }
   bool ok = dist_key && (direct || loads);
   for (Py_ssize_t q = 0; ok && q < nq; ++q) {
-    const int64_t cnt = std::min<int64_t>(counts[(size_t)q], limit);
+    const int64_t cnt = std::max<int64_t>(0, std::min<int64_t>(q < (Py_ssize_t)counts.size() ? counts[(size_t)q] : 0, limit));
     PyObject* rows = NULL;
     if (direct) {
       rows = PyList_New((Py_ssize_t)cnt);

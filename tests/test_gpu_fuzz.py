@@ -49,7 +49,8 @@ def test_auto_engine_equals_stream_engine(amd, c):
     a = ix.search(Q, c["k"], mode=amd.MODE_FLAT, flat_engine=amd.FLAT_AUTO)
     b = ix.search(Q, c["k"], mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
     m = ix.search(Q, c["k"], mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA)
-    for got in (a, m):
+    m8 = ix.search(Q, c["k"], mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
+    for got in (a, m, m8):
         assert np.array_equal(got[0], b[0]), "%d result ids differ" % (got[0] != b[0]).sum()
         assert np.array_equal(got[1], b[1]) and np.array_equal(got[2], b[2])
     ids = b[0][b[0] >= 0]

@@ -976,6 +976,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
 // each XCD's 4 MB L2 while the row operand streams past; at 4096 / 8192 queries per pass the query fragments thrash L2
 // and the filter drops to 0.37 / 0.27 of the MFMA peak (0.46 in slices; bench.py --rows 1250000 --batch 8192).
 int32_t flat_mfma_search(Index& ix, const float* dq, int64_t nq, int k, u64* run_keys, bool approx, int bits) {
+  if (ix.n_rows_ <= 0) return ix.flat_stream(dq, nq, k, 0, 0, run_keys, false);   // (nothing to mirror)
   const bool auto_bits = bits != 8 && bits != 16;
   if (auto_bits) {   // the library's choice: 8-bit first pass unless switched off (EPS_MFMA_BITS=16, A/B) - tables it cannot serve fall back by themselves
     const char* e = getenv("EPS_MFMA_BITS");
