@@ -32,12 +32,13 @@ sys.path.insert(0, ROOT)
 # MI355X_MICROARCH.md prescribes: gfx950 FETCH_SIZE counts 128-B requests at 64 B -> x2; FETCH_SIZE/WRITE_SIZE in KiB):
 #   mfma: profiles/r2_pmc_10Mx768_b1024.csv, mean of the four 9,262,720-row launches of mfma_filter_kernel_v7<2, FM_IDS>:
 #         (2 * 7340245 + 7460) KiB = 15.04e9 bytes vs 14.23e9 algorithmic bytes of the fp16 mirror (1.06 x; r1: 14.43e9).
-#   graph: profiles/r2_traverse_10Mx768_pmc.csv, traverse2_kernel T=4 L=500 batch 1024 on the 10M-node device-built graph:
-#         2 * 48440196 KiB = 99.2e9 bytes vs 100.97e9 algorithmic (the x2 calibrated in the same run on flat_scan_kernel,
-#         whose FETCH_SIZE x 2 = rows * dim * 4 exactly).
+#   graph: profiles/r3_traverse_10Mx768_pmc.csv, traverse2_kernel T=4 L=500 batch 1024 on the 10M-node device-built graph, 8-bit
+#         prefilter on: (2 * 22850910 + 2205166) KiB = 49.1e9 bytes vs 44.6e9 algorithmic (1.10 x; the x2 calibrated in the same
+#         run on flat_scan_kernel, whose FETCH_SIZE x 2 = rows * dim * 4 exactly; the writes are the visited-set atomics).
+#         r2, every evaluation on its fp32 row (profiles/r2_traverse_10Mx768_pmc.csv): 2 * 48440196 KiB = 99.2e9 vs 100.97e9.
 #   mfma8: profiles/r3_pmc_10Mx768_b1024.csv, the 7,280,256-row launch (the last of the 6 stages) of mfma_filter_kernel_v7<2, FM_IDS, int8>:
 #         (2 * 2755587 + 8791) KiB = 5.65e9 bytes vs 5.59e9 algorithmic bytes of the 8-bit mirror (1.01 x).
-TRAFFIC = {"mfma": (2 * 7340245 + 7460) * 1024.0, "mfma8": (2 * 2755587 + 8791) * 1024.0, "graph_T4_L500": 2 * 48440196 * 1024.0}
+TRAFFIC = {"mfma": (2 * 7340245 + 7460) * 1024.0, "mfma8": (2 * 2755587 + 8791) * 1024.0, "graph_T4_L500": (2 * 22850910 + 2205166) * 1024.0}
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F16_PEAK_TF = 2500.0  # dense bf16/f16 MFMA peak (nominal, 2.4 GHz)
 MFMA_F16_SUSTAINED_TF = 1814.0  # measured: v_mfma_f32_32x32x16_f16 alone, operands toggling like data, 1.82 GHz (scripts/lab/mfma_peak.hip)
@@ -545,13 +546,13 @@ def main():
         gel = (time.perf_counter() - t1) / 3
         gms = float(np.mean(ix2.kernel_times(3)))
         gst = ix2.stats()
-        alg = gst["dist_evals"] * (4.0 * d + 4) + gst["expansions"] * (8 + 4.0 * ge_ / gn_)
+        alg = amd.traversal_gather_bytes(gst, d, ge_ / float(gn_), 500 * b)
         secondary = {"what": "traverse2_kernel (SearchImpl, IntraQueryThreads=4, SearchQueueSize=500) on the device-built NSG of the first %d rows, batch %d" % (gn, b),
                      "build_s": gbuild, "avg_degree": ge_ / float(gn_), "qps": b / gel, "recall_at_10": recall_of(o2[0].cpu().numpy(), ggt),
                      "evals_per_query": gst["dist_evals"] / float(b), "expansions_per_query": gst["expansions"] / float(b),
                      "roofline": {"bound": "hbm", "achieved": alg / (gms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": alg / (gms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms_per_launch": gms,
-                                  "note": "algorithmic gather bytes E*(4d+4) + X*(8+4*deg); a %d-row table (%.1f GB) is partly served by L2/Infinity Cache - the HBM-only figure is the 10M-row run under profiles/" % (gn, gn * d * 4 / 1e9)}}
+                                  "note": "algorithmic gather bytes (vectordb_amd.traversal_gather_bytes); a %d-row table (%.1f GB) is partly served by L2/Infinity Cache - the HBM-only figure is the 10M-row run under profiles/" % (gn, gn * d * 4 / 1e9)}}
         if args.cpu_seconds > 0:
             off, nbr, nav = ix2.get_graph()
             graph_for_cpu = (off, nbr, nav, gn, ggt)
@@ -568,10 +569,12 @@ def main():
         used_mfma = st.get("rerank_rows", 0) > 0
         if args.mode == "graph":
             n_, e_, nav_ = ix.graph_info()
-            alg_bytes = st["dist_evals"] * (4.0 * d + 4) + st["expansions"] * (8 + 4.0 * e_ / n_)
-            roof = {"bound": "hbm", "kernel": "traverse2_kernel (gather: E*(4d+4) + X*(8+4*deg) bytes, E evaluations and X expansions counted by the kernel)",
+            alg_bytes = amd.traversal_gather_bytes(st, d, e_ / float(n_), min(args.L, n) * b)
+            roof = {"bound": "hbm", "kernel": "traverse2_kernel (gather: X*(8+4*deg) adjacency bytes + per evaluation the 8-bit mirror row (d+4 bytes), the fp32 row (4d) only for "
+                                              "seeds and for neighbours the 8-bit bound cannot rule out; E, X and the fp32 reads counted by the kernel)",
+                    "fp32_rows_per_query": st["rerank_rows"] / float(b),
                     "achieved": alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "traffic": TRAFFIC.get("graph_T4_L500") if (n == 10_000_000 and b == 1024 and d == 768 and args.T == 4 and args.L == 500 and args.data == "uniform") else None}
+                    "traffic": TRAFFIC.get("graph_T4_L500") if (n == 10_000_000 and b == 1024 and d == 768 and args.T == 4 and args.L == 500 and args.data == "uniform" and st["rerank_rows"] > 0) else None}
         elif used_mfma:
             # algorithmic flops of the timed launch: 2 * batch * rows * d, on the fp16 dense MFMA roof
             flops = 2.0 * kq * krows * d   # queries x rows of the timed launch (batches > 2048 run in slices)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Graph-traversal measurements: device build, then a sweep of SearchQueueSize / IntraQueryThreads with
 recall@10 against the exact scan, queries/s, distance evaluations and the algorithmic gather rate
-E*(4d) + X*(8 + 4*deg) + E*4 bytes over the kernel time.
+(vectordb_amd.traversal_gather_bytes) over the kernel time.
 
     python scripts/bench_graph.py --rows 1000000 --dim 768 --data uniform|clustered [--batch 1024] [--L 500,2000]
                                   [--T 1,4] [--save-graph PATH | --load-graph PATH]        -> JSON lines
@@ -115,11 +115,11 @@ def main():
             torch.cuda.synchronize()
             el = (time.perf_counter() - t1) / args.reps
             st = ix.stats()
-            byt = st["dist_evals"] * (4.0 * d + 4) + st["expansions"] * (8 + 4 * deg)
+            byt = amd.traversal_gather_bytes(st, d, deg, min(L, n) * b)
             km = float(np.median(kms))
             print(json.dumps({"config": "%s %d x %d graph traversal batch=%d T=%d L=%d" % (args.data, n, d, b, T, L),
                               "qps": b / el, "recall_at_10": recall(ob[0].cpu().numpy(), gti), "evals_per_query": st["dist_evals"] / float(b),
-                              "expansions_per_query": st["expansions"] / float(b), "kernel_ms": km,
+                              "expansions_per_query": st["expansions"] / float(b), "fp32_rows_per_query": st["rerank_rows"] / float(b), "kernel_ms": km,
                               "achieved_GBps": byt / (km * 1e-3) / 1e9, "frac_of_8TBps": byt / (km * 1e-3) / 8e12,
                               "vs_flat_qps": (b / el) / (b / flat_s)}), flush=True)
 

@@ -37,6 +37,6 @@ for T in (4, 1):
         ix.search(Q, 10, out=out, mode=amd.MODE_GRAPH, intra_threads=T, master_queue=500, local_queue=500)
         torch.cuda.synchronize()
         st = ix.stats()
-        alg = st["dist_evals"] * (4.0 * d + 4) + st["expansions"] * (8 + 4.0 * e_ / n_)
+        alg = amd.traversal_gather_bytes(st, d, e_ / float(n_), 500 * b)
         print(json.dumps({"launch": "traverse2_kernel T=%d L=500 batch=%d #%d" % (T, b, it), "dist_evals": st["dist_evals"], "expansions": st["expansions"],
                           "algorithmic_bytes": alg, "kernel_ms": st["main_kernel_ms"], "algorithmic_GBps": alg / (st["main_kernel_ms"] * 1e-3) / 1e9}))

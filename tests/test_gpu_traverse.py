@@ -34,10 +34,13 @@ def _close_evals(ev_gpu, ev_or, what=""):
 
 @pytest.mark.parametrize("T,L,I", [(2, 500, 15), (4, 500, 15), (4, 100, 15), (4, 500, 1), (4, 500, 3), (8, 300, 15), (3, 64, 2),
                                    (16, 500, 15), (1, 500, 1), (1, 100, 4), (17, 500, 15), (24, 300, 4), (32, 500, 15)])
-def test_lockstep_workers_match_oracle(amd, oracle, T, L, I):
-    """IntraQueryThreads = T workers with local queues, PickTopMToWorkers, GlobalSyncInterval = I and
+@pytest.mark.parametrize("prefilter", ["0", "1"])
+def test_lockstep_workers_match_oracle(amd, oracle, monkeypatch, T, L, I, prefilter):
+    """(prefilter: the 8-bit lower-bound test ahead of the fp32 rows, forced off / on - the same bits either way.)
+    IntraQueryThreads = T workers with local queues, PickTopMToWorkers, GlobalSyncInterval = I and
     MergeAllQueuesToMaster: the device result equals the oracle's SearchImpl under the lockstep interleaving - the whole
     master queue (ids, distances) and the number of distance evaluations."""
+    monkeypatch.setenv("EPS_TRV_PREFILTER", prefilter)
     z, off, nbr, nav = _golden_graph()
     X, Q = data(2000, 32, 42), data(24, 32, 47)
     ix = amd.GpuIndex(32, 0)
@@ -46,6 +49,8 @@ def test_lockstep_workers_match_oracle(amd, oracle, T, L, I):
     k = min(L, 500)
     ids, dist, cnt = ix.search(Q, k, mode=amd.MODE_GRAPH, intra_threads=T, master_queue=L, local_queue=L, sync_interval=I)
     ev_gpu = ix.stats()["dist_evals"]
+    if prefilter == "1":
+        assert 0 < ix.stats()["rerank_rows"] < ev_gpu
     init = oracle.prepare_init_ids(off, nbr, nav, L)
     ev_or = 0
     for qi, q in enumerate(Q):
@@ -54,6 +59,33 @@ def test_lockstep_workers_match_oracle(amd, oracle, T, L, I):
         assert int(cnt[qi]) == k
         assert_topk_match(ids[qi], dist[qi], oid[:k], od[:k], what="T%d L%d I%d q%d" % (T, L, I, qi))
     _close_evals(ev_gpu, ev_or, "T%d L%d I%d" % (T, L, I))
+    ix.close()
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("n,d,T,L", [(20000, 128, 1, 500), (20000, 100, 4, 200), (6000, 768, 4, 500), (6000, 1030, 2, 300), (20000, 19, 1, 64)])
+def test_prefilter_is_invisible(amd, monkeypatch, n, d, T, L, metric):
+    """Step d0 (traverse2_kernel.hpp): a neighbour is dropped on its 8-bit mirror row only when that row PROVES dist > bound, so
+    the walk - queue contents, distances, evaluation and expansion counts - is the same bit for bit with the prefilter off and
+    on; on, most neighbours never have their fp32 row read.  Also after rows were appended beyond the grid (clamped codes)."""
+    X, Q = data(n, d, 3 + d), data(32, d, 4 + d)
+    if metric == 2:
+        X = X - 0.5   # (signed inner products)
+    X[n - 50:] *= 3.0   # rows the build sees; the grid covers them
+    ix = amd.GpuIndex(d, metric)
+    ix.attach_rows(X)
+    ix.build(n)
+    k = min(L, 100)
+    res = {}
+    for pf in ("0", "1"):
+        monkeypatch.setenv("EPS_TRV_PREFILTER", pf)
+        ids, dist, cnt = ix.search(Q, k, mode=amd.MODE_GRAPH, intra_threads=T, master_queue=L, local_queue=L)
+        st = ix.stats()
+        res[pf] = (ids.copy(), dist.copy(), cnt.copy(), st["dist_evals"], st["expansions"], st["rerank_rows"])
+    a, b = res["0"], res["1"]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)) and np.array_equal(a[2], b[2])
+    assert a[3] == b[3] and a[4] == b[4]
+    assert b[5] < b[3] - 32 * L, (b[5], b[3])   # (how many rows the bound settles depends on how much of the table the queue covers)
     ix.close()
 
 

@@ -36,3 +36,29 @@ def test_filter_kernels_do_not_spill(tmp_path):
     for k, u in usage.items():
         if "mfma_filter_kernel_v3" in k:
             assert u["ScratchSize [bytes/lane]"] == 0, (k, u)
+
+
+@pytest.mark.skipif(not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")), reason="needs hipcc")
+def test_traversal_kernel_keeps_four_waves_per_simd(tmp_path):
+    """graph_search plans its launch (workgroups per CU) for 4 wavefronts per SIMD, i.e. <= 128 VGPRs; the kernel is compiled for
+    exactly that and the few registers that do not fit are spilled outside the gather loops - a handful of dwords, pinned here."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-I" + os.path.join(ROOT, "include"),
+                        "-c", os.path.join(ROOT, "vectordb_amd", "csrc", "traverse.hip"), "-o", str(tmp_path / "tr.o"),
+                        "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    usage = {}
+    name = None
+    for line in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            usage[name] = {}
+        m = re.search(r"(VGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]): (\d+)", line)
+        if m and name:
+            usage[name][m.group(1)] = int(m.group(2))
+    trv = {k: v for k, v in usage.items() if "traverse2_kernel" in k}
+    assert len(trv) == 12, list(usage)   # {float4, scalar} row loads x {4, 8, 16} wavefronts x queues in {LDS, HBM}
+    for k, u in trv.items():
+        assert u["VGPRs"] <= 128 and u["Occupancy [waves/SIMD]"] >= 4, (k, u)
+        assert u["ScratchSize [bytes/lane]"] <= 64, (k, u)

@@ -165,6 +165,13 @@ __device__ __forceinline__ float stage_threshold16(float thr, const float* qs, c
   const float t = (thr - c) + (approx ? 0.f : margin) + slack * scale;   // (approx mode ranks on the approximate keys: no margin)
   return fminf(t, 3.0e38f);
 }
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+// value on the table's 8-bit grid (xh = z + step * xi)
+__device__ __forceinline__ int quant8(float x, float z, float inv_step) {
+  float t = rintf((x - z) * inv_step);
+  t = fminf(fmaxf(t, -127.f), 127.f);   // (rows appended after the grid was fixed may lie outside it: clamped, the residual grows, the bound stays valid)
+  return (int)t;
+}
 // int8 operands: T in accumulator units (int32): a row passes iff dot + acc0 >= T
 __device__ __forceinline__ int stage_threshold8(float thr, const float* qs, const float* sc, int metric, float u, float slack, int approx) {
   const float qn2 = qs[0], nq_ = qs[1], eq = qs[2];

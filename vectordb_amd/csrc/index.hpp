@@ -27,6 +27,13 @@ struct DevBuf {  // growable device allocation
 };
 
 struct BuildStage;   // stage-level entry of the graph build (below)
+struct Quant8View {   // the table's 8-bit mirror as other kernels see it (mfma_filter.hip)
+  const signed char* x8 = nullptr;
+  const int* acc0 = nullptr;
+  const float* scal8 = nullptr;
+  int d_pad8 = 0;
+  float z = 0.f, step = 1.f, u = 1.f;
+};
 struct HalfMirror;   // fp16 mirror + per-row bounds for the MFMA filter engine (mfma_filter.hip)
 struct GraphDev;     // device CSR + traversal scratch (traverse.hip)
 
@@ -168,6 +175,8 @@ class Index : public IndexBase {
                       bool merge_run, int metric = -1, bool filtered = true);
   int32_t flat_stream_page(const float* dq, int64_t nq, int k, int64_t row_begin, int64_t row_end, u64* run_keys, bool merge_run, int metric,
                            bool filtered, const u64* lo, int64_t lo_stride);
+  friend int32_t quant8_view(Index&, Quant8View*);
+  friend void quant8_queries(Index&, const Quant8View&, const float*, int64_t, signed char*, float*);
   friend int32_t flat_mfma_search(Index&, const float*, int64_t, int, u64*, bool, int);
   friend int32_t flat_mfma_search_slice(Index&, const float*, int64_t, int, u64*, bool, int, int, bool);
   friend int32_t graph_build(Index&, int64_t, const eps_build_params&, const BuildStage*);
@@ -184,6 +193,8 @@ int32_t flat_mfma_search(Index& ix, const float* dq, int64_t nq, int k, u64* run
 int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u64* run_keys, bool approx, int cap_scale = 1, int bits = 16,
                                bool auto_bits = false);  // <= 2048 queries
 bool flat_mfma_profitable(const Index& ix, int64_t nq, int k);  // AUTO heuristic
+int32_t quant8_view(Index& ix, Quant8View* v);
+void quant8_queries(Index& ix, const Quant8View& v, const float* dq, int64_t nq, signed char* q8, float* qstat);
 void half_mirror_free(HalfMirror* m);
 int32_t graph_upload(Index& ix);
 void graph_free(GraphDev* g);

@@ -275,12 +275,6 @@ __global__ __launch_bounds__(256) void minmax_kernel(const float* rows, int64_t 
   if (__any(bad) && lane_id() == 0) atomicMax(&scal8[3], __float_as_uint(1.f));   // inf / NaN somewhere: the grid would be meaningless
 }
 
-__device__ __forceinline__ int quant8(float x, float z, float inv_step) {
-  float t = rintf((x - z) * inv_step);
-  t = fminf(fmaxf(t, -127.f), 127.f);   // (rows appended after the grid was fixed may lie outside it: clamped, the residual grows, the bound stays valid)
-  return (int)t;
-}
-
 // rows [row0, n_pad) are (re)written, as in half_mirror_kernel.  metric 0: R = |x|^2 - 2 z sx SX - d z^2 = sum (x_k - z)^2 + 2 z (x_k - xh_k)
 // (summed in this form: no cancellation for tables far from the origin); otherwise R = -z sx SX.  u = |s| sx^2.
 __global__ __launch_bounds__(256) void quant_mirror_kernel(const float* rows, int64_t row0, int64_t n, int64_t n_pad, int dim, int d_pad8, float z, float step,
@@ -593,6 +587,30 @@ static int32_t ensure_mirror8(Index& ix) {
   m.d_pad8 = d_pad8;
   m.version8 = ix.rows_version_;
   return EPS_OK;
+}
+
+// The 8-bit mirror for kernels outside this file (the traversal's lower-bound prefilter): built or extended on demand;
+// v->x8 stays null when the table cannot be put on one grid (non-finite values, constants beyond int32).
+int32_t quant8_view(Index& ix, Quant8View* v) {
+  *v = Quant8View();
+  const int32_t rc = ensure_mirror8(ix);
+  if (rc != EPS_OK) return rc;
+  const HalfMirror& m = *ix.mirror_;
+  if (!m.i8_ok) return EPS_OK;
+  v->x8 = m.x8.as<signed char>();
+  v->acc0 = m.acc0.as<int>();
+  v->scal8 = m.scal8.as<float>();
+  v->d_pad8 = m.d_pad8;
+  v->z = m.z8;
+  v->step = m.step8;
+  v->u = (ix.metric_ == 0 ? 2.f : 1.f) * m.step8 * m.step8;
+  return EPS_OK;
+}
+
+// nq queries on the mirror's grid: q8 [nq][d_pad8], qstat [nq][4] (device buffers of the caller)
+void quant8_queries(Index& ix, const Quant8View& v, const float* dq, int64_t nq, signed char* q8, float* qstat) {
+  hipLaunchKernelGGL(query_prep8_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, ix.stream_, dq, nq, nq, (int)ix.dim_, v.d_pad8, v.z, v.step,
+                     1.f / v.step, ix.metric_, q8, qstat);
 }
 
 bool flat_mfma_profitable(const Index& ix, int64_t nq, int k) {

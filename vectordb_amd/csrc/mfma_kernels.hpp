@@ -12,7 +12,6 @@ namespace eps {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 64;                        // K-step of every kernel generation

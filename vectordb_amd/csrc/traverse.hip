@@ -37,6 +37,7 @@ struct GraphDev {
   DevBuf queue;      // u64 [nq][L]
   DevBuf counters;   // unsigned long long [2]
   DevBuf tail;       // u64 [nq][k] brute-force tail lists
+  DevBuf q8, qstat8;       // prefilter: the batch on the mirror's grid, signed char [nq][d_pad8], float [nq][4]
   DevBuf elog, elog_cnt;   // filtered traversal: u64 [slice][ecap] evaluated (dist, id) keys, u32 [slice] counts
 };
 
@@ -243,11 +244,28 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
   // the other one cover this one's queue maintenance); larger SearchQueueSize: queues in HBM
   // Between 80 and 150 KB the queues still fit the CU's LDS once: one workgroup of 16 wavefronts per CU then beats queues in
   // HBM with 4 x 4 wavefronts (T = 4, L = 2000 at 10M x 768, batch 1024: 80 ms vs 108 ms); beyond that: queues in HBM.
-  const size_t lds_need = traverse2_lds_bytes((int)ix.dim_, T, (int)Lq, qtot, dp, false);
+  // Filtered traversal (eps_search_params::filter_in_traversal, SURVEY 8f rank 4): the reference judges deleted rows and the filter on
+  // the final top-L walk only (:905-927), so a filter that lets 1 % of the rows through leaves ~L/100 results.  Here every row
+  // the search EVALUATES (an order of magnitude more than L) is logged with its distance and the k closest VISIBLE ones are the
+  // answer; invisible rows keep their place in the queues, i.e. the walk itself is the reference's.
+  const FilterSpec fspec = ix.filter_spec();
+  const bool filtered = p.filter_in_traversal != 0 && walk_limit == 0 && (fspec.deleted || fspec.column || fspec.prog);
+  // 8-bit lower-bound prefilter of the distance phase (traverse2_kernel.hpp, step d0): pays when a mirror row is much shorter than
+  // the fp32 row and the table is beyond the caches; the filtered traversal logs EVERY evaluated distance, so it cannot skip any.
+  // EPS_TRV_PREFILTER=0/1 overrides (A/B, small-table tests).
+  bool prefilter = !filtered && ix.dim_ >= 128 && n >= 65536;
+  if (const char* e = getenv("EPS_TRV_PREFILTER")) prefilter = !filtered && atoi(e) != 0;
+  Quant8View q8v;
+  if (prefilter) {
+    const int32_t rc = quant8_view(ix, &q8v);
+    if (rc != EPS_OK) return rc;
+    prefilter = q8v.x8 != nullptr;
+  }
+  const size_t lds_need = traverse2_lds_bytes((int)ix.dim_, T, (int)Lq, qtot, dp, false, prefilter);
   const size_t lds_limit = getenv("EPS_TRV_LDS_KB") ? (size_t)std::max(16, atoi(getenv("EPS_TRV_LDS_KB"))) * 1024 : (size_t)150 * 1024;   // (A/B knob)
   const bool qglobal = lds_need > lds_limit;
   const bool one_per_cu = !qglobal && lds_need > (size_t)80 * 1024;
-  const size_t shm = traverse2_lds_bytes((int)ix.dim_, T, (int)Lq, qtot, dp, qglobal);
+  const size_t shm = traverse2_lds_bytes((int)ix.dim_, T, (int)Lq, qtot, dp, qglobal, prefilter);
   // few queries: 16 wavefronts per query (latency); many queries: fewer per query (throughput, more queries per CU)
   const char* waves_s = getenv("EPS_TRV_WAVES");
   int nw = waves_s ? atoi(waves_s) : ((nq <= 256 || one_per_cu) ? 16 : 4);
@@ -307,17 +325,27 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
   a.vcap = vcap;
   a.counters = g.counters.as<unsigned long long>();
   a.prof = prof ? g.counters.as<unsigned long long>() + 8 : nullptr;
-  // Filtered traversal (eps_search_params::filter_in_traversal, SURVEY 8f rank 4): the reference judges deleted rows and the filter on
-  // the final top-L walk only (:905-927), so a filter that lets 1 % of the rows through leaves ~L/100 results.  Here every row
-  // the search EVALUATES (an order of magnitude more than L) is logged with its distance and the k closest VISIBLE ones are the
-  // answer; invisible rows keep their place in the queues, i.e. the walk itself is the reference's.
-  const FilterSpec fspec = ix.filter_spec();
-  const bool filtered = p.filter_in_traversal != 0 && walk_limit == 0 && (fspec.deleted || fspec.column || fspec.prog);
   if (filtered && k > 1024) return ix.fail(EPS_DB_UNSUPPORTED_ERROR, "search: filter_in_traversal returns at most 1024 rows per query");
   const int64_t ecap = filtered ? std::min<int64_t>(n, std::max<int64_t>(16384, 64 * L)) : 0;
   a.elog = nullptr;
   a.elog_cnt = nullptr;
   a.elog_cap = (int)ecap;
+  a.x8 = prefilter ? q8v.x8 : nullptr;
+  a.acc0 = q8v.acc0;
+  a.scal8 = q8v.scal8;
+  a.d_pad8 = q8v.d_pad8;
+  a.u8 = q8v.u;
+  a.q8 = nullptr;
+  a.qstat8 = nullptr;
+  if (prefilter) {
+    if (!g.q8.reserve((size_t)nq * q8v.d_pad8) || !g.qstat8.reserve((size_t)nq * 16)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "search: out of device memory");
+    quant8_queries(ix, q8v, dq, nq, g.q8.as<signed char>(), g.qstat8.as<float>());
+  }
+  {   // fp32 rounding of the distances step d compares with the bound: G lanes x (d / G) sequential fmas + a log2(G)-level tree
+    const int G = group_lanes(ix.dim_, vec4);
+    const float terms = (float)((ix.dim_ + G - 1) / G) + 6.f;
+    a.slack8 = std::max(8e-6f, 2.f * (3.f * terms + 2.f) * 5.9604645e-8f);
+  }
 
   // brute-force tail over the rows the graph does not cover yet (:885-900)
   const int64_t n_total = ix.n_rows_;
@@ -351,6 +379,8 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
   for (int64_t q0 = 0; q0 < nq; q0 += slice) {
     const int64_t cnt = std::min(slice, nq - q0);
     a.queries = dq + q0 * ix.dim_;
+    a.q8 = prefilter ? g.q8.as<signed char>() + q0 * q8v.d_pad8 : nullptr;
+    a.qstat8 = prefilter ? g.qstat8.as<float>() + q0 * 4 : nullptr;
     a.nq = cnt;
     a.out_queue = g.queue.as<u64>();
     if (filtered) {
@@ -401,6 +431,8 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
   }
   ix.stats_.dist_evals += (int64_t)h[0];
   ix.stats_.expansions += (int64_t)h[1];
+  if (prefilter) ix.stats_.rerank_rows += (int64_t)h[4];   // fp32 rows step d still read (seeds not counted)
+  if (prof && prefilter) fprintf(stderr, "[eps trv]   8-bit prefilter: %.1f of %.1f neighbour evaluations per query read the fp32 row\n", (double)h[4] / nq, (double)(h[0] - (unsigned long long)(L * nq)) / nq);
   if (evals_out) *evals_out = (int64_t)h[0];
   return EPS_OK;
 }

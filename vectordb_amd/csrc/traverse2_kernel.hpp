@@ -50,23 +50,43 @@ struct Trv2Args {
   u32* vlog;            // [slots][vcap] undo log
   int vcap;
   u64* out_queue;       // [nq][L] final master queues
-  unsigned long long* counters;  // [0] distance evaluations, [1] expansions, [2] steps, [3] rounds
+  unsigned long long* counters;  // [0] distance evaluations, [1] expansions, [2] steps, [3] rounds, [4] fp32 rows read in step d
   unsigned long long* prof;      // optional [16]: shader-clock ticks per phase summed over the workgroups (EPS_TRV_PROF)
   // filtered traversal (eps_search_params::filter_in_traversal): every distance the search evaluates is also logged as a plain
   // (dist, id) key, so that the caller can pick the k best VISIBLE rows among ALL evaluated nodes instead of among the final queue
   u64* elog;                     // [nq][elog_cap] or null
   u32* elog_cnt;                 // [nq] evaluations of the query (may exceed elog_cap: only the first elog_cap are stored)
   int elog_cap;
+  // exact lower-bound prefilter of step d on the table's 8-bit mirror (mfma_filter.hip: one grid per table, integer dot product,
+  // the row constant folded into acc0): a neighbour whose 768-byte mirror row PROVES `dist > bound` is dropped without its fp32
+  // row ever being read; every other neighbour goes through the unchanged fp32 evaluation.  Results are bit-identical with or
+  // without it (the proof is the flat engine's: device_common.hpp stage_threshold8).  x8 == null: off.
+  const signed char* x8;         // [n_pad][d_pad8]
+  const int* acc0;               // [n_pad]
+  const float* scal8;            // the mirror's table-wide bounds (residual, |xh|, |x|^2, -, |R|)
+  const signed char* q8;         // [nq][d_pad8] the queries on the same grid
+  const float* qstat8;           // [nq][4] |q|^2, |q|, |q - qh|, C + c
+  int d_pad8;
+  float u8, slack8;
 };
 
 #ifndef EPS_TRV_U
 #define EPS_TRV_U 4   // rows in flight per lane group in the distance phases
 #endif
+#ifndef EPS_TRV_U8
+#define EPS_TRV_U8 2   // prefilter: mirror rows in flight per lane group ...
+#endif
+#ifndef EPS_TRV_NL8
+#define EPS_TRV_NL8 3  // ... and 16-byte pieces of each per lane
+#endif
 constexpr int TRV2_SB = 4096;       // keys of the LDS staging block of the QGLOBAL bitonic sort
 constexpr int TRV2_MAXT = 128;      // the reference's limit for IntraQueryThreads (config/config.hpp:29)
-// ints of scalar scratch: 16 scalars, eight [TS] per-worker arrays, [16] per-wave counts, [TS + 16] edge offsets; TS = T rounded up to 16
+// ints of scalar scratch: 16 scalars, nine [TS] per-worker arrays, [16] per-wave counts, [TS + 16] edge offsets; TS = T rounded up to 16
 __host__ __device__ inline int trv2_tstride(int T) { return T <= 16 ? 16 : (T + 15) & ~15; }
-__host__ __device__ inline int trv2_sh_ints(int T) { return 48 + 9 * trv2_tstride(T); }
+__host__ __device__ inline int trv2_sh_ints(int T) { return 48 + 10 * trv2_tstride(T); }
+// bytes of the prefilter's LDS block: the query's four statistics, the query on the 8-bit grid, alignment spare
+__host__ __device__ inline int trv2_q8len(int dim) { return (dim + 15) & ~15; }
+__host__ __device__ inline int trv2_pf_bytes(int dim) { return 16 + 16 + trv2_q8len(dim); }
 constexpr u32 TRV2_NONE = 0xFFFFFFFFu;
 
 __device__ __forceinline__ u64 q2key(float d, u32 id) { return ((u64)f2ord(d + 0.0f) << 32) | ((u64)id << 1); }
@@ -102,7 +122,7 @@ __device__ __forceinline__ void bitonic_passes(u64* buf, int n, int64_t gbase, i
 }
 
 template <bool VEC4, int NW, bool QGLOBAL>
-__global__ __launch_bounds__(NW * 64) void traverse2_kernel(Trv2Args a) {
+__global__ __launch_bounds__(NW * 64, 4) void traverse2_kernel(Trv2Args a) {   // (4 wavefronts per SIMD: <= 128 VGPRs, the occupancy the host side plans with)
   constexpr int NT = NW * 64;
   constexpr int R = 4;           // queue elements per thread and merge chunk
   constexpr int C = NT * R;
@@ -125,7 +145,8 @@ __global__ __launch_bounds__(NW * 64) void traverse2_kernel(Trv2Args a) {
   int* auxl = hmin + H;                                                     // !QGLOBAL: [2*Lq] MergeAll scratch (T > 1)
   int* sh = auxl + ((QGLOBAL || T == 1) ? 0 : 2 * Lq);                      // [trv2_sh_ints(T)]
   // sh[0] scratch (first found / pmin), sh[1] unchecked count, sh[2] undo-log fill, sh[3] any worker selected,
-  // sh[4] running prefix, sh[5] non-duplicate count, sh[6] r of MergeAll, sh[7] log overflow, sh[8] evaluations logged (elog)
+  // sh[4] running prefix, sh[5] non-duplicate count, sh[6] r of MergeAll, sh[7] log overflow, sh[8] evaluations logged (elog),
+  // sh[9] prefilter threshold of this step
   const int TS = trv2_tstride(T);
   const int SH = trv2_sh_ints(T);
   int* s_kuc = sh + 16;            // [T] first possibly-unchecked position per queue
@@ -137,7 +158,18 @@ __global__ __launch_bounds__(NW * 64) void traverse2_kernel(Trv2Args a) {
   int* s_nnew = s_wcnt + TS;       // [T] keys that passed the bound
   int* s_wave = s_nnew + TS;       // [NW <= 16] per-wave counts
   int* s_selpos = s_wave + 16;     // [T] queue position of the selected candidate
-  int* s_eoff = s_selpos + TS;     // [T+1] first edge slot of every worker in this step
+  int* s_pcnt = s_selpos + TS;     // [T] ids that passed the 8-bit prefilter
+  int* s_eoff = s_pcnt + TS;       // [T+1] first edge slot of every worker in this step
+  // prefilter block (only present in the launch's LDS size when a.x8): statistics of the query on the table's grid, then the query
+  const bool pf = a.x8 != nullptr;
+  const size_t pf_off = ((size_t)(reinterpret_cast<unsigned char*>(sh + SH) - smem_raw) + 15) & ~(size_t)15;
+  float* qst = reinterpret_cast<float*>(smem_raw + pf_off);                // [4] |q|^2, |q|, |q - qh|, C + c
+  signed char* sq8 = reinterpret_cast<signed char*>(qst + 4);               // [q8len]
+  const int q8len = trv2_q8len(dim);
+  constexpr int U8 = EPS_TRV_U8, NL8 = EPS_TRV_NL8;
+  int G8 = 4;
+  while (G8 < 64 && G8 * 16 * NL8 < q8len) G8 <<= 1;                        // lanes per mirror row (NL8 pieces of 16 bytes each)
+  const int RPW8 = 64 / G8;
 
   const int tid = threadIdx.x;
   const int lane = lane_id();
@@ -153,22 +185,26 @@ __global__ __launch_bounds__(NW * 64) void traverse2_kernel(Trv2Args a) {
   u64* qbase = QGLOBAL ? a.qglobal + slot * a.qtot : qlds;
   int* aux = QGLOBAL ? a.auxglobal + slot * (int64_t)(2 * Lq) : auxl;
   u64* master = qbase + (int64_t)(T - 1) * Lq;
-  unsigned long long evals = 0, expansions = 0, steps = 0, rounds = 0;
-  // phase clocks (wave-uniform scalar reads; summed by thread 0): 0 seeds+sort, 1 scatter, 2 select, 3 gather+visited,
-  // 4 dedupe, 5 distances, 6 rank sort, 7 queue insert, 8 merge-all, 9 results+reset
-  unsigned long long pt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long evals = 0, expansions = 0, steps = 0, rounds = 0, fetched = 0;
+  // phase clocks (wave-uniform scalar reads; thread 0 adds every lap to the launch's totals - only with EPS_TRV_PROF, no
+  // registers held otherwise): 0 seeds+sort, 1 scatter, 2 select, 3 gather+visited, 4 dedupe, 5 distances, 6 rank sort,
+  // 7 queue insert, 8 merge-all, 9 results+reset
   const bool prof = a.prof != nullptr;
   long long tprev = prof ? clock64() : 0;
 #define TRV2_LAP(i)                 \
   if (prof) {                       \
     const long long tn = clock64(); \
-    pt[i] += (unsigned long long)(tn - tprev); \
+    if (tid == 0) atomicAdd(&a.prof[i], (unsigned long long)(tn - tprev)); \
     tprev = tn;                     \
   }
 
   for (int64_t q = slot; q < a.nq; q += gridDim.x) {
     // ------------------------------------------------------------------ InitializeSetLPara (:446-485)
     for (int i = tid; i < qstride; i += NT) sq[i] = i < dim ? a.queries[q * dim + i] : 0.f;
+    if (pf) {   // the query on the table's grid and its statistics (query_prep8_kernel, launched ahead of this kernel)
+      for (int i = tid; i < (q8len >> 2); i += NT) reinterpret_cast<u32*>(sq8)[i] = reinterpret_cast<const u32*>(a.q8 + q * a.d_pad8)[i];
+      if (tid < 4) qst[tid] = a.qstat8[q * 4 + tid];
+    }
     for (int i = tid; i < SH; i += NT) sh[i] = 0;
     for (int i = tid; i < H; i += NT) {
       hid[i] = TRV2_NONE;
@@ -446,6 +482,83 @@ __global__ __launch_bounds__(NW * 64) void traverse2_kernel(Trv2Args a) {
         int nwork = 0;
         for (int w = 0; w < T; ++w) nwork += s_wcnt[w];
         evals += nwork;
+        const u32* wk = work;
+        if (pf) {
+          // d0. 8-bit lower bound first: dot(xi, qi) + acc0[x] >= Tq(bound) is NECESSARY for dist <= bound (the integer dot product is
+          //     exact, the row constant and the quantisation residuals are on the safe side of the threshold), so only the rows that
+          //     pass are worth their 4 d bytes.  Survivors are compacted per worker; everything downstream sees the smaller lists.
+          if (tid == 0) sh[9] = stage_threshold8(bound, qst, a.scal8, a.metric, a.u8, a.slack8, 0);
+          if (tid < T) s_pcnt[tid] = 0;
+          __syncthreads();
+          const int Tq = sh[9];
+          u32* surv = reinterpret_cast<u32*>(npos);   // (insert positions are not live before step f)
+          const int g8 = lane / G8, t8 = lane & (G8 - 1);
+          // G8 lanes per row, every lane NL8 16-byte pieces of it 16*G8 bytes apart (one instruction covers 16*G8 contiguous bytes
+          // of each of its 64/G8 rows); U8 rows per lane group: U8*NL8 loads in flight per lane, 64/G8*U8 rows per wavefront and pass
+          for (int c0 = wave * RPW8 * U8; c0 < nwork; c0 += NW * RPW8 * U8) {
+            const signed char* rp8[U8];
+            int wslot[U8], dot[U8], a0[U8];   // wslot: (worker << 16) | slot of the id in `work`, -1 = past the end
+#pragma unroll
+            for (int u = 0; u < U8; ++u) {
+              int ci = c0 + u * RPW8 + g8;
+              const bool ok = ci < nwork;
+              if (!ok) ci = nwork - 1;
+              int w = 0, base = 0;
+              for (; w < T - 1; ++w) {
+                const int c = s_wcnt[w];
+                if (ci < base + c) break;
+                base += c;
+              }
+              const int sl = s_eoff[w] + (ci - base);
+              wslot[u] = ok ? ((w << 16) | sl) : -1;
+              const u32 id = work[sl];
+              rp8[u] = a.x8 + (int64_t)id * a.d_pad8;
+              a0[u] = t8 == 0 ? a.acc0[id] : 0;    // (in flight with the row pieces)
+              dot[u] = 0;
+            }
+#pragma unroll 1
+            for (int c = t8 * 16; c < q8len; c += G8 * 16 * NL8) {
+              i32x4 xv[U8][NL8];
+#pragma unroll
+              for (int j = 0; j < NL8; ++j) {
+                const int cj = c + j * G8 * 16;
+                const bool in = cj < q8len;
+#pragma unroll
+                for (int u = 0; u < U8; ++u) xv[u][j] = in ? *reinterpret_cast<const i32x4*>(rp8[u] + cj) : i32x4{0, 0, 0, 0};
+              }
+#pragma unroll
+              for (int j = 0; j < NL8; ++j) {
+                const int cj = c + j * G8 * 16;
+                const i32x4 qv = cj < q8len ? *reinterpret_cast<const i32x4*>(sq8 + cj) : i32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int u = 0; u < U8; ++u) {
+                  dot[u] = __builtin_amdgcn_sdot4(xv[u][j][0], qv[0], dot[u], false);
+                  dot[u] = __builtin_amdgcn_sdot4(xv[u][j][1], qv[1], dot[u], false);
+                  dot[u] = __builtin_amdgcn_sdot4(xv[u][j][2], qv[2], dot[u], false);
+                  dot[u] = __builtin_amdgcn_sdot4(xv[u][j][3], qv[3], dot[u], false);
+                }
+              }
+            }
+            for (int o = G8 >> 1; o > 0; o >>= 1) {
+#pragma unroll
+              for (int u = 0; u < U8; ++u) dot[u] += __shfl_xor(dot[u], o);
+            }
+#pragma unroll
+            for (int u = 0; u < U8; ++u)
+              if (wslot[u] >= 0 && t8 == 0 && dot[u] + a0[u] >= Tq) {
+                const int sl = wslot[u] & 0xFFFF, w = wslot[u] >> 16;
+                const int pp = atomicAdd(&s_pcnt[w], 1);
+                surv[s_eoff[w] + pp] = work[sl];
+              }
+          }
+          __syncthreads();
+          if (tid < T) s_wcnt[tid] = s_pcnt[tid];
+          __syncthreads();
+          wk = surv;
+          nwork = 0;
+          for (int w = 0; w < T; ++w) nwork += s_wcnt[w];
+        }
+        fetched += nwork;
         if (tid < T) {   // pad every segment's keys to a multiple of 8 with EMPTY (sorts last, never counted)
           const int c = s_wcnt[tid];
           for (int p = c; p < ((c + 7) & ~7); ++p) newk[s_eoff[tid] + p] = KEY_EMPTY;
@@ -467,7 +580,7 @@ __global__ __launch_bounds__(NW * 64) void traverse2_kernel(Trv2Args a) {
               base += c;
             }
             slotk[u] = s_eoff[w] + (ci - base);
-            id[u] = work[slotk[u]];
+            id[u] = wk[slotk[u]];
             rp[u] = a.rows + (int64_t)id[u] * dim;
           }
           float acc[U][1];
@@ -686,8 +799,7 @@ __global__ __launch_bounds__(NW * 64) void traverse2_kernel(Trv2Args a) {
     atomicAdd(&a.counters[1], expansions);
     atomicAdd(&a.counters[2], steps);
     atomicAdd(&a.counters[3], rounds);
-    if (prof)
-      for (int i = 0; i < 10; ++i) atomicAdd(&a.prof[i], pt[i]);
+    atomicAdd(&a.counters[4], fetched);
   }
 }
 
@@ -698,11 +810,11 @@ inline int traverse2_hash_slots(int T, int dp) {
   while (h < 2 * T * dp) h <<= 1;
   return h;
 }
-inline size_t traverse2_lds_bytes(int dim, int T, int Lq, int64_t qtot, int dp, bool qglobal) {
+inline size_t traverse2_lds_bytes(int dim, int T, int Lq, int64_t qtot, int dp, bool qglobal, bool prefilter = false) {
   const int qstride = (dim + 3) & ~3;
   const size_t ecap = (size_t)T * dp;
   return (size_t)qstride * 4 + (qglobal ? (size_t)TRV2_SB : (size_t)qtot) * 8 + ecap * (8 + 8 + 4 + 4 + 4 + 4) + (size_t)traverse2_hash_slots(T, dp) * 8 +
-         ((qglobal || T == 1) ? 0 : (size_t)2 * Lq * 4) + (size_t)trv2_sh_ints(T) * 4;
+         ((qglobal || T == 1) ? 0 : (size_t)2 * Lq * 4) + (size_t)trv2_sh_ints(T) * 4 + (prefilter ? (size_t)trv2_pf_bytes(dim) : 0);
 }
 
 }  // namespace eps

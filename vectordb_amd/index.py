@@ -305,6 +305,19 @@ class GpuIndex:
         return {f: getattr(s, f) for f, _ in SearchStats._fields_}
 
 
+def traversal_gather_bytes(stats, dim, avg_degree, seed_evals=0):
+    """Algorithmic bytes the traversal kernel gathers for the search `stats` describes: adjacency lists X*(8 + 4*deg); rows
+    E*(4d + 4) when every evaluation reads its fp32 row; with the 8-bit prefilter (stats["rerank_rows"] > 0: fp32 rows read in
+    step d) the seed evaluations and the survivors read 4d bytes, every neighbour evaluation its mirror row (d rounded up to 16
+    bytes) + the 4-byte row constant.  seed_evals: SearchQueueSize x queries (seeds are always evaluated in fp32)."""
+    e, x, f = float(stats["dist_evals"]), float(stats["expansions"]), float(stats["rerank_rows"])
+    adj = x * (8 + 4.0 * avg_degree)
+    if f <= 0:
+        return e * (4.0 * dim + 4) + adj
+    q8 = (dim + 15) // 16 * 16
+    return (seed_evals + f) * 4.0 * dim + (e - seed_evals) * (q8 + 4.0) + e * 4 + adj
+
+
 def merge_topk_packed(gathered, shard_stride_bytes, dist_offset_bytes, shards, nq, k, out_dist, out_ids, device=0, stream=None):
     """gathered: one device buffer = the all-gather of every rank's packed [ids int64[nq][k] | dist float[nq][k]]."""
     L = lib.load()
