@@ -251,6 +251,23 @@ def test_build_visited_hash_is_exact(amd, monkeypatch):
 
 
 
+def test_build_prefilter_is_invisible(amd, monkeypatch):
+    """Link / connectivity searches test a neighbour's 8-bit mirror row before reading its fp32 row (traverse_kernel.hpp step 3a);
+    the test only ever drops what `dist > bound` would drop, so the graph is the same with it off and on."""
+    graphs = []
+    for n, d in ((80_000, 256), (30_000, 130)):
+        X = data(n, d, 31)
+        for pf in ("0", "1"):
+            monkeypatch.setenv("EPS_BUILD_PREFILTER", pf)
+            ix = amd.GpuIndex(d, 0)
+            ix.attach_rows(X)
+            ix.build()
+            graphs.append(ix.get_graph())
+            ix.close()
+        (o1, n1, v1), (o2, n2, v2) = graphs[-2:]
+        assert v1 == v2 and np.array_equal(o1, o2) and np.array_equal(n1, n2)
+
+
 # ----------------------------------------------------------------------------------------------- stage-level parity (a16 / a17)
 def _list_agreement(a, da, b, db):
     """per-node edge lists a [n][R] (-1 padded, da valid) vs b: fraction identical as ordered lists, mean Jaccard of the sets"""
@@ -300,14 +317,17 @@ def test_device_knn_lists_against_the_oracles_exact_knn(amd, oracle):
     assert (got >= 0).all() and not (got == np.arange(n)[:, None]).any()
 
 
+@pytest.mark.parametrize("prefilter", ["0", "1"])
 @pytest.mark.parametrize("n,d", [(3000, 16), (12000, 32)])
-def test_device_link_stage_against_the_oracle_on_an_identical_knn_graph(amd, oracle, n, d):
-    """a17, the Link stage on its own (eps_index_link): every node's GetNeighbors search over the kNN graph from the navigation
+def test_device_link_stage_against_the_oracle_on_an_identical_knn_graph(amd, oracle, monkeypatch, n, d, prefilter):
+    """(prefilter: the searches' 8-bit lower-bound test ahead of the fp32 rows, forced off / on.)
+    a17, the Link stage on its own (eps_index_link): every node's GetNeighbors search over the kNN graph from the navigation
     node's neighbours (nsg.cpp:158-268) + SyncPrune (:540-580: pool + own kNN row, sort, SelectEdge over the first 300), on the
     SAME kNN graph and the SAME navigation node as the oracle's Link stage (code shared with the oracle's whole build, which is
     bit-exact with the reference's NsgIndex::Build).  With K >= search_length the stage draws no random numbers (nsg.cpp:187 is
     never reached), so the two sides are functions of identical inputs; they may differ only through fp32 summation order
     (near-ties in the pool order, or at the `dist >= worst` / MRNG comparisons)."""
+    monkeypatch.setenv("EPS_BUILD_PREFILTER", prefilter)
     X = data(n, d, 80 + d)
     knn = oracle.knn_exact(0, X, 100)
     ooff, onbr, onav = oracle.nsg_build(X, knn)

@@ -598,8 +598,19 @@ int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp, const Buil
   if (bp.candidate_pool_size <= 0 || Lp2 > 2048) Lp2 = 2048;   // (unlimited depth: the 2048 closest)
   if (Lp2 < Ls) return ix.fail(EPS_DB_UNSUPPORTED_ERROR, "build: search_length > 2048 is not supported");
   const int Lcap = Lp2;
-  const size_t trv_shm = traverse_lds_bytes(dim, Lp2, true);
-  const size_t trv_shm_bm = traverse_lds_bytes(dim, Lp2, false);
+  // 8-bit lower-bound prefilter of the searches' distance step (traverse_kernel.hpp, step 3a): the mirror is the one the kNN stage
+  // just scanned; EPS_BUILD_PREFILTER=0 turns it off (A/B - the graph is the same either way)
+  Quant8View q8v;
+  bool prefilter = dim >= 128 && !(getenv("EPS_BUILD_PREFILTER") && atoi(getenv("EPS_BUILD_PREFILTER")) == 0);
+  if (const char* e = getenv("EPS_BUILD_PREFILTER")) prefilter = atoi(e) != 0;
+  DevBuf q8b, qstat8b;
+  if (prefilter) {
+    const int32_t rc = quant8_view(ix, &q8v);
+    if (rc != EPS_OK) return rc;
+    prefilter = q8v.x8 != nullptr;
+  }
+  const size_t trv_shm = traverse_lds_bytes(dim, Lp2, true, prefilter);
+  const size_t trv_shm_bm = traverse_lds_bytes(dim, Lp2, false, prefilter);
   const size_t prn_shm = prune_lds_bytes(dim, R);
   TraverseArgs ta;
   ta.rows = ix.d_rows_;
@@ -620,10 +631,27 @@ int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp, const Buil
   ta.hslots = ghash_vis ? GHASH_SLOTS : 0;
   ta.out_queue = nullptr;
   ta.counters = counters.as<unsigned long long>();
-  ta.counters_n = 3;
+  ta.counters_n = 4;
   ta.log = logb.as<u64>();
   ta.log_cnt = logc.as<u32>();
   ta.log_cap = Lcap;
+  ta.x8 = nullptr;
+  ta.acc0 = q8v.acc0;
+  ta.scal8 = q8v.scal8;
+  ta.q8 = nullptr;
+  ta.qstat8 = nullptr;
+  ta.d_pad8 = q8v.d_pad8;
+  ta.u8 = q8v.u;
+  {
+    const int G = group_lanes(dim, vec4);
+    ta.slack8 = std::max(8e-6f, 2.f * (3.f * ((float)((dim + G - 1) / G) + 6.f) + 2.f) * 5.9604645e-8f);
+  }
+  if (prefilter) {
+    if (!q8b.reserve((size_t)NB * q8v.d_pad8) || !qstat8b.reserve((size_t)NB * 16)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "build: out of device memory");
+    ta.x8 = q8v.x8;
+    ta.q8 = q8b.as<signed char>();
+    ta.qstat8 = qstat8b.as<float>();
+  }
   PruneArgs pa;
   std::memset(&pa, 0, sizeof(pa));
   pa.rows = ix.d_rows_;
@@ -663,6 +691,7 @@ int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp, const Buil
   for (int64_t v0 = 0; v0 < n; v0 += NB) {
     const int64_t nb = std::min(NB, n - v0);
     ta.queries = ix.d_rows_ + v0 * dim;
+    if (prefilter) quant8_queries(ix, q8v, ta.queries, nb, q8b.as<signed char>(), qstat8b.as<float>());
     HIPCHK(launch_link_search(nb));
     pa.v0 = v0;
     if (vec4)
@@ -685,11 +714,12 @@ int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp, const Buil
     return EPS_OK;
   }
   if (debug) {
-    unsigned long long hcnt[3] = {0, 0, 0};
-    HIPCHK(hipMemcpyAsync(hcnt, counters.p, 24, hipMemcpyDeviceToHost, s));
+    unsigned long long hcnt[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(hcnt, counters.p, 32, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     fprintf(stderr, "[eps build] Link: %.0f evaluations, %.1f expansions per search; queue of %d kept as the pool; visited set: %s, %llu searches filled it\n",
             (double)hcnt[0] / (double)n, (double)hcnt[1] / (double)n, Lcap, bitmap_vis ? "bitmap" : (ghash_vis ? "hash of 32768 in HBM" : "hash of 8192 in LDS"), hcnt[2]);
+    if (prefilter) fprintf(stderr, "[eps build] Link: 8-bit prefilter on, %.0f neighbour evaluations per search read the fp32 row\n", (double)hcnt[3] / (double)n);
   }
 
   // ---- 4. InterInsert
@@ -767,6 +797,7 @@ int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp, const Buil
       const int64_t nb = std::min(OB, m - o0);
       hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)nb), dim3(256), 0, s, ix.d_rows_, d_orph.as<u32>() + o0, nb, dim, d_q.as<float>());
       ta.queries = d_q.as<float>();
+      if (prefilter) quant8_queries(ix, q8v, ta.queries, nb, q8b.as<signed char>(), qstat8b.as<float>());
       HIPCHK(launch_link_search(nb));
       // the TRACE_K closest evaluated nodes of every search, ascending
       launch_merge_lists(logb.as<u64>(), Lcap, TRACE_K, nb, d_top.as<u64>(), false, s, logc.as<u32>());

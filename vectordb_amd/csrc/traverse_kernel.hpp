@@ -31,6 +31,14 @@ struct TraverseArgs {
   u64* log;          // LOG mode: [nq][log_cap] plain (dist,id) keys: the final queue = the L closest evaluated nodes, ascending
   u32* log_cnt;      // [nq]
   int log_cap;       // >= L
+  // exact 8-bit lower-bound prefilter of step 3 (same test as traverse2_kernel's step d0); x8 == null: off
+  const signed char* x8;   // [n_pad][d_pad8] the table's 8-bit mirror
+  const int* acc0;         // [n_pad]
+  const float* scal8;
+  const signed char* q8;   // [gridDim.x][d_pad8] this launch's queries on the mirror's grid
+  const float* qstat8;     // [gridDim.x][4]
+  int d_pad8;
+  float u8, slack8;
 };
 
 constexpr int TRV_HASH = 8192;   // LDS visited hash slots (HASHVIS mode), power of two
@@ -86,7 +94,8 @@ __global__ __launch_bounds__(NW * 64) void traverse_kernel(TraverseArgs a) {
   const int hbits = (HASHVIS && a.ghash) ? 31 - __clz(a.hslots) : 13;
   const int hlimit = (HASHVIS && a.ghash) ? (a.hslots / 4) * 3 : (TRV_HASH * 3) / 4;
   // sh[0]=work count, sh[1]=selected count, sh[2]=k (first possibly-unchecked position), sh[3]=valid new count,
-  // sh[4]=r_min, sh[5]=position of the first selected candidate, sh[6]=hash fill, sh[7]=log fill, sh[8..8+M) selected node ids, sh[24..24+M+1) edge prefix, sh[48..48+NW) per-wave counts
+  // sh[4]=r_min, sh[5]=position of the first selected candidate, sh[6]=hash fill, sh[7]=log fill, sh[8..8+M) selected node ids, sh[24..24+M+1) edge prefix, sh[41]=prefilter
+  // threshold, sh[42]=prefilter survivors of this chunk, sh[43]=fp32 rows read in step 3, sh[48..48+NW) per-wave counts
   const int tid = threadIdx.x;
   const int lane = lane_id();
   const int wave = tid >> 6;
@@ -97,6 +106,16 @@ __global__ __launch_bounds__(NW * 64) void traverse_kernel(TraverseArgs a) {
   const int g = lane / G;
   const int t = lane & (G - 1);
   constexpr int U = 4;
+  // prefilter block at the end of the launch's LDS (traverse_lds_bytes(..., prefilter = true))
+  const bool pf = a.x8 != nullptr;
+  const size_t pf_off = ((size_t)qstride * 4 + (size_t)a.Lp2 * 8 + TRV_CHUNK * 8 * 2 + TRV_CHUNK * 4 + 64 * 4 + ((HASHVIS && !a.ghash) ? TRV_HASH * 4 : 0) + 15) & ~(size_t)15;
+  float* qst = reinterpret_cast<float*>(smem_raw + pf_off);      // [4]
+  signed char* sq8 = reinterpret_cast<signed char*>(qst + 4);     // [q8len]
+  const int q8len = (dim + 15) & ~15;
+  constexpr int U8 = 2, NL8 = 3;
+  int G8 = 4;
+  while (G8 < 64 && G8 * 16 * NL8 < q8len) G8 <<= 1;
+  const int RPW8 = 64 / G8;
   u32* vis = HASHVIS ? nullptr : a.visited + q * a.words;
   unsigned long long evals = 0, expansions = 0;
   u64* qlog = LOG ? a.log + q * (int64_t)a.log_cap : nullptr;
@@ -106,9 +125,14 @@ __global__ __launch_bounds__(NW * 64) void traverse_kernel(TraverseArgs a) {
     if (tid == 0) sh[6] = 0;
   }
   if (LOG && tid == 0) sh[7] = 0;
+  if (tid == 0) sh[43] = 0;   // (read again by thread 0 only)
   if (HASHVIS || LOG) __syncthreads();
 
   for (int i = tid; i < qstride; i += NT) sq[i] = i < dim ? a.queries[q * dim + i] : 0.f;
+  if (pf) {
+    for (int i = tid; i < (q8len >> 2); i += NT) reinterpret_cast<u32*>(sq8)[i] = reinterpret_cast<const u32*>(a.q8 + q * a.d_pad8)[i];
+    if (tid < 4) qst[tid] = a.qstat8[q * 4 + tid];
+  }
   for (int i = tid; i < a.Lp2; i += NT) queue[i] = KEY_EMPTY;
   // InitializeSetLPara (:446-485): mark seeds visited, L seed distances, sort
   const int NS = a.nseeds > 0 ? a.nseeds : L;     // seeds (<= L)
@@ -225,12 +249,73 @@ __global__ __launch_bounds__(NW * 64) void traverse_kernel(TraverseArgs a) {
         if (fresh) work[wbase + __popcll(m & ((1ull << lane) - 1ull))] = nb;
       }
       __syncthreads();
-      const int nwork = sh[0];
+      int nwork = sh[0];
       if (nwork == 0) continue;
       evals += nwork;
 
       // 3. distances; drop candidates beyond the current worst-of-queue (dist > bound, :427)
       const float bound = key_dist(queue[L - 1]);
+      const u32* wk = work;
+      if (pf) {
+        // 3a. the 8-bit mirror row first: dot(xi, qi) + acc0[x] >= Tq(bound) is necessary for dist <= bound (device_common.hpp,
+        //     stage_threshold8), so only the rows that pass are read in fp32.  While the queue is not full everything passes.
+        if (tid == 0) {
+          sh[41] = queue[L - 1] == KEY_EMPTY ? (int)0x80000000 : stage_threshold8(bound, qst, a.scal8, a.metric, a.u8, a.slack8, 0);
+          sh[42] = 0;
+        }
+        __syncthreads();
+        const int Tq = sh[41];
+        u32* surv = reinterpret_cast<u32*>(sorted);   // (free until step 4)
+        const int g8 = lane / G8, t8 = lane & (G8 - 1);
+        for (int c0 = wave * RPW8 * U8; c0 < nwork; c0 += NW * RPW8 * U8) {
+          const signed char* rp8[U8];
+          int slot[U8], dot[U8], a0[U8];
+#pragma unroll
+          for (int u = 0; u < U8; ++u) {
+            const int ci = c0 + u * RPW8 + g8;
+            slot[u] = ci < nwork ? ci : -1;
+            const u32 id = work[ci < nwork ? ci : nwork - 1];
+            rp8[u] = a.x8 + (int64_t)id * a.d_pad8;
+            a0[u] = t8 == 0 ? a.acc0[id] : 0;
+            dot[u] = 0;
+          }
+#pragma unroll 1
+          for (int c = t8 * 16; c < q8len; c += G8 * 16 * NL8) {
+            i32x4 xv[U8][NL8];
+#pragma unroll
+            for (int j = 0; j < NL8; ++j) {
+              const int cj = c + j * G8 * 16;
+              const bool in = cj < q8len;
+#pragma unroll
+              for (int u = 0; u < U8; ++u) xv[u][j] = in ? *reinterpret_cast<const i32x4*>(rp8[u] + cj) : i32x4{0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int j = 0; j < NL8; ++j) {
+              const int cj = c + j * G8 * 16;
+              const i32x4 qv = cj < q8len ? *reinterpret_cast<const i32x4*>(sq8 + cj) : i32x4{0, 0, 0, 0};
+#pragma unroll
+              for (int u = 0; u < U8; ++u) {
+                dot[u] = __builtin_amdgcn_sdot4(xv[u][j][0], qv[0], dot[u], false);
+                dot[u] = __builtin_amdgcn_sdot4(xv[u][j][1], qv[1], dot[u], false);
+                dot[u] = __builtin_amdgcn_sdot4(xv[u][j][2], qv[2], dot[u], false);
+                dot[u] = __builtin_amdgcn_sdot4(xv[u][j][3], qv[3], dot[u], false);
+              }
+            }
+          }
+          for (int o = G8 >> 1; o > 0; o >>= 1) {
+#pragma unroll
+            for (int u = 0; u < U8; ++u) dot[u] += __shfl_xor(dot[u], o);
+          }
+#pragma unroll
+          for (int u = 0; u < U8; ++u)
+            if (slot[u] >= 0 && t8 == 0 && dot[u] + a0[u] >= Tq) surv[atomicAdd(&sh[42], 1)] = work[slot[u]];
+        }
+        __syncthreads();
+        nwork = sh[42];
+        wk = surv;
+        if (nwork == 0) continue;
+        if (tid == 0) sh[43] += nwork;
+      }
       for (int c0 = wave * RPW * U; c0 < nwork; c0 += NW * RPW * U) {
         const float* rp[U];
         u32 id[U];
@@ -239,7 +324,7 @@ __global__ __launch_bounds__(NW * 64) void traverse_kernel(TraverseArgs a) {
         for (int u = 0; u < U; ++u) {
           const int ci = c0 + u * RPW + g;
           ok[u] = ci < nwork;
-          id[u] = work[ok[u] ? ci : nwork - 1];
+          id[u] = wk[ok[u] ? ci : nwork - 1];
           rp[u] = a.rows + (int64_t)id[u] * dim;
         }
         float acc[U][1];
@@ -335,14 +420,16 @@ __global__ __launch_bounds__(NW * 64) void traverse_kernel(TraverseArgs a) {
   if (tid == 0) {
     atomicAdd(&a.counters[0], evals);
     atomicAdd(&a.counters[1], expansions);
+    if (pf && a.counters_n > 3) atomicAdd(&a.counters[3], (unsigned long long)sh[43]);   // fp32 rows step 3 still read
     if (HASHVIS && a.counters_n > 2 && sh[6] + TRV_CHUNK > hlimit) atomicAdd(&a.counters[2], 1ull);   // searches that filled the visited hash
   }
 }
 
 
-inline size_t traverse_lds_bytes(int dim, int Lp2, bool hashvis) {
+inline size_t traverse_lds_bytes(int dim, int Lp2, bool hashvis, bool prefilter = false) {
   const int qstride = (dim + 3) & ~3;
-  return (size_t)qstride * 4 + (size_t)Lp2 * 8 + TRV_CHUNK * 8 * 2 + TRV_CHUNK * 4 + 64 * 4 + (hashvis ? TRV_HASH * 4 : 0);
+  return (size_t)qstride * 4 + (size_t)Lp2 * 8 + TRV_CHUNK * 8 * 2 + TRV_CHUNK * 4 + 64 * 4 + (hashvis ? TRV_HASH * 4 : 0) +
+         (prefilter ? (size_t)(16 + 16 + ((dim + 15) & ~15)) : 0);
 }
 
 }  // namespace eps
