@@ -89,6 +89,35 @@ def test_prefilter_is_invisible(amd, monkeypatch, n, d, T, L, metric):
     ix.close()
 
 
+def test_prefilter_with_rows_outside_the_mirrors_grid(amd, oracle, monkeypatch):
+    """The 8-bit grid is fixed when the mirror is first built; rows appended later are quantised on it and CLAMPED where they lie
+    outside.  Their residual then enters the bound (it gets looser, never wrong): a graph over old + new rows is walked the same
+    with the prefilter on, and equals the oracle's walk; so are queries far outside the grid."""
+    n0, n1, d, L = 70_000, 10_000, 128, 300
+    X0, X1 = data(n0, d, 71), data(n1, d, 72) * 1.6 - 0.3
+    X = np.concatenate([X0, X1])
+    Q = np.concatenate([data(12, d, 73), data(4, d, 74) * 2.5 - 0.7])
+    ix = amd.GpuIndex(d, 0)
+    ix.attach_rows(X0)
+    ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)   # the mirror (and its grid) exist from here on
+    ix.append_rows(X1)
+    ix.build(n0 + n1)
+    off, nbr, nav = ix.get_graph()
+    res = {}
+    for pf in ("0", "1"):
+        monkeypatch.setenv("EPS_TRV_PREFILTER", pf)
+        ids, dist, cnt = ix.search(Q, 50, mode=amd.MODE_GRAPH, intra_threads=2, master_queue=L, local_queue=L)
+        st = ix.stats()
+        res[pf] = (ids.copy(), dist.copy(), st["dist_evals"], st["rerank_rows"])
+    assert np.array_equal(res["0"][0], res["1"][0]) and np.array_equal(res["0"][1].view(np.uint32), res["1"][1].view(np.uint32))
+    assert res["0"][2] == res["1"][2] and 0 < res["1"][3] < res["1"][2]
+    init = oracle.prepare_init_ids(off, nbr, nav, L)
+    for qi in (0, 5, 13, 15):
+        oid, od, _ = oracle.search_impl(0, X, off, nbr, init, Q[qi], T=2, L=L, lockstep=True)
+        assert_topk_match(res["1"][0][qi], res["1"][1][qi], oid[:50], od[:50], what="q%d" % qi)
+    ix.close()
+
+
 def test_reference_parameter_ranges_run_or_are_refused(amd, oracle):
     """The reference accepts IntraQueryThreads up to 128 and SearchQueueSize up to 10^7 (config/config.hpp:28-44).  The device
     runs what it can (T x longest adjacency list <= 2048 edge slots per step: T <= 32 at the build's out-degree cap) and REFUSES
