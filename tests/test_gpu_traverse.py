@@ -68,7 +68,7 @@ def test_prefilter_is_invisible(amd, monkeypatch, n, d, T, L, metric):
     """Step d0 (traverse2_kernel.hpp): a neighbour is dropped on its 8-bit mirror row only when that row PROVES dist > bound, so
     the walk - queue contents, distances, evaluation and expansion counts - is the same bit for bit with the prefilter off and
     on; on, most neighbours never have their fp32 row read.  Also after rows were appended beyond the grid (clamped codes)."""
-    X, Q = data(n, d, 3 + d), data(32, d, 4 + d)
+    X, Q = data(n, d, 3 + d), data(300 if d == 100 else 32, d, 4 + d)   # (> 256 queries: the 4-wavefront form of the kernel)
     if metric == 2:
         X = X - 0.5   # (signed inner products)
     X[n - 50:] *= 3.0   # rows the build sees; the grid covers them
@@ -195,10 +195,12 @@ def test_visited_bitmaps_are_clean_between_searches(amd, oracle):
     ix.close()
 
 
-@pytest.mark.parametrize("T,L", [(1, 3000), (1, 6000), (4, 2500), (4, 6000), (1, 12000), (2, 12000)])
-def test_large_search_queue(amd, oracle, T, L):
+@pytest.mark.parametrize("T,L,prefilter", [(1, 3000, "0"), (1, 6000, "0"), (4, 2500, "0"), (4, 6000, "0"), (1, 12000, "0"), (2, 12000, "0"),
+                                           (4, 2500, "1"), (4, 6000, "1"), (1, 12000, "1")])
+def test_large_search_queue(amd, oracle, monkeypatch, T, L, prefilter):
     """SearchQueueSize beyond the LDS-resident queue (config.hpp:37-44 allows up to 1e7): queues in HBM, bitonic sort
     staged through LDS, chunked in-place merges.  Whole master queue vs the oracle (first 1000 entries returned)."""
+    monkeypatch.setenv("EPS_TRV_PREFILTER", prefilter)
     n, d = 12000, 24
     X, Q = data(n, d, 5), data(6, d, 6)
     ix = amd.GpuIndex(d, 0)
