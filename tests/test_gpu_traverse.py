@@ -118,6 +118,39 @@ def test_prefilter_with_rows_outside_the_mirrors_grid(amd, oracle, monkeypatch):
     ix.close()
 
 
+def test_prefilter_switches_itself_off_where_it_does_not_pay(amd, monkeypatch):
+    """On rows of low intrinsic dimension the neighbours' distances are small against the table's value range, the 8-bit bound
+    cannot tell them apart and nearly every neighbour passes it: after two such searches the index stops using it (the answers
+    never depended on it); on uniform rows it stays on."""
+    monkeypatch.delenv("EPS_TRV_PREFILTER", raising=False)
+    rng = np.random.default_rng(5)
+    n, d = 70_000, 128
+    A = (0.25 * rng.standard_normal((8, d))).astype(np.float32)
+    X = (rng.random((n, 8), dtype=np.float32) @ A + 0.01 * rng.standard_normal((n, d)).astype(np.float32)).astype(np.float32)
+    Q = (rng.random((64, 8), dtype=np.float32) @ A).astype(np.float32)
+    ix = amd.GpuIndex(d, 0)
+    ix.attach_rows(X)
+    ix.build(n)
+    seen, first = [], None
+    for it in range(4):
+        ids, dist, cnt = ix.search(Q, 10, mode=amd.MODE_GRAPH, intra_threads=4, master_queue=200, local_queue=200)
+        st = ix.stats()
+        seen.append(st["rerank_rows"] / float(st["dist_evals"]))
+        first = (ids.copy(), dist.copy()) if first is None else first
+        assert np.array_equal(ids, first[0]) and np.array_equal(dist.view(np.uint32), first[1].view(np.uint32))
+    assert seen[0] > 0.55 and seen[1] > 0.55 and seen[2] == 0.0 and seen[3] == 0.0, seen
+    ix.close()
+    U = data(n, d, 77)
+    ix = amd.GpuIndex(d, 0)
+    ix.attach_rows(U)
+    ix.build(n)
+    for it in range(3):
+        ix.search(U[:64], 10, mode=amd.MODE_GRAPH, intra_threads=4, master_queue=200, local_queue=200)
+        st = ix.stats()
+        assert 0 < st["rerank_rows"] < 0.6 * st["dist_evals"], (it, st)
+    ix.close()
+
+
 def test_reference_parameter_ranges_run_or_are_refused(amd, oracle):
     """The reference accepts IntraQueryThreads up to 128 and SearchQueueSize up to 10^7 (config/config.hpp:28-44).  The device
     runs what it can (T x longest adjacency list <= 2048 edge slots per step: T <= 32 at the build's out-degree cap) and REFUSES

@@ -693,6 +693,19 @@ int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp, const Buil
     ta.queries = ix.d_rows_ + v0 * dim;
     if (prefilter) quant8_queries(ix, q8v, ta.queries, nb, q8b.as<signed char>(), qstat8b.as<float>());
     HIPCHK(launch_link_search(nb));
+    if (v0 == 0 && prefilter && !getenv("EPS_BUILD_PREFILTER") && n > NB) {
+      // judged on the first batch: where more than 60 % of the neighbour evaluations still read the fp32 row (distances small
+      // against the table's value range: clustered / low intrinsic dimension) the 8-bit test is pure overhead - off for the rest
+      unsigned long long hc[4] = {0, 0, 0, 0};
+      HIPCHK(hipMemcpyAsync(hc, counters.p, 32, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
+      const double nbr_evals = (double)hc[0] - (double)nb * Ls;
+      if (nbr_evals > 0 && (double)hc[3] > 0.6 * nbr_evals) {
+        prefilter = false;
+        ta.x8 = nullptr;
+        if (debug) fprintf(stderr, "[eps build] Link: 8-bit prefilter switched off after the first batch (%.0f %% of the neighbour evaluations passed it)\n", 100.0 * (double)hc[3] / nbr_evals);
+      }
+    }
     pa.v0 = v0;
     if (vec4)
       hipLaunchKernelGGL((prune_kernel<true>), dim3((unsigned)nb), dim3(256), prn_shm, s, pa);

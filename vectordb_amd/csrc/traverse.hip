@@ -38,6 +38,12 @@ struct GraphDev {
   DevBuf counters;   // unsigned long long [2]
   DevBuf tail;       // u64 [nq][k] brute-force tail lists
   DevBuf q8, qstat8;       // prefilter: the batch on the mirror's grid, signed char [nq][d_pad8], float [nq][4]
+  // the prefilter pays only where the 8-bit bound settles most neighbours (uniform-like value distributions: 82 % at 10M x 768);
+  // where distances are small against the table's value range (clustered / low intrinsic dimension) most rows pass it and it is
+  // pure overhead.  Judged on what the kernel counts: two consecutive searches in which more than 60 % of the neighbour evaluations
+  // still read the fp32 row switch it off for this graph (until the graph is replaced).
+  int pf_strikes = 0;
+  bool pf_off = false;
   DevBuf elog, elog_cnt;   // filtered traversal: u64 [slice][ecap] evaluated (dist, id) keys, u32 [slice] counts
 };
 
@@ -47,6 +53,8 @@ int32_t graph_upload(Index& ix) {
   if (!ix.graph_) ix.graph_ = new GraphDev();
   GraphDev& g = *ix.graph_;
   g.init_L = -1;
+  g.pf_strikes = 0;
+  g.pf_off = false;
   const int64_t n = ix.n_indexed_;
   if (n <= 0) return EPS_OK;
   const int64_t e = ix.h_off_[n];
@@ -253,8 +261,9 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
   // 8-bit lower-bound prefilter of the distance phase (traverse2_kernel.hpp, step d0): pays when a mirror row is much shorter than
   // the fp32 row and the table is beyond the caches; the filtered traversal logs EVERY evaluated distance, so it cannot skip any.
   // EPS_TRV_PREFILTER=0/1 overrides (A/B, small-table tests).
-  bool prefilter = !filtered && ix.dim_ >= 128 && n >= 65536;
-  if (const char* e = getenv("EPS_TRV_PREFILTER")) prefilter = !filtered && atoi(e) != 0;
+  bool prefilter = !filtered && ix.dim_ >= 128 && n >= 65536 && !g.pf_off;
+  const char* pf_env = getenv("EPS_TRV_PREFILTER");
+  if (pf_env) prefilter = !filtered && atoi(pf_env) != 0;
   Quant8View q8v;
   if (prefilter) {
     const int32_t rc = quant8_view(ix, &q8v);
@@ -432,6 +441,13 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
   ix.stats_.dist_evals += (int64_t)h[0];
   ix.stats_.expansions += (int64_t)h[1];
   if (prefilter) ix.stats_.rerank_rows += (int64_t)h[4];   // fp32 rows step d still read (seeds not counted)
+  if (prefilter && !pf_env) {
+    const unsigned long long nbr_evals = h[0] > (unsigned long long)(L * nq) ? h[0] - (unsigned long long)(L * nq) : 0;
+    if (nbr_evals >= 4096) {   // (enough evaluations to judge)
+      g.pf_strikes = (double)h[4] > 0.6 * (double)nbr_evals ? g.pf_strikes + 1 : 0;
+      if (g.pf_strikes >= 2) g.pf_off = true;
+    }
+  }
   if (prof && prefilter) fprintf(stderr, "[eps trv]   8-bit prefilter: %.1f of %.1f neighbour evaluations per query read the fp32 row\n", (double)h[4] / nq, (double)(h[0] - (unsigned long long)(L * nq)) / nq);
   if (evals_out) *evals_out = (int64_t)h[0];
   return EPS_OK;
