@@ -207,11 +207,11 @@ __global__ __launch_bounds__(64) void post_kernel(PostArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ host
-template <bool VEC4, int NW, bool QG>
+template <bool VEC4, int NW, bool QG, bool PF>
 static void launch_trv2(const Trv2Args& a, int slots, size_t shm, hipStream_t s) {
   // (idempotent and cheap; per call so that no process-wide state is needed)
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(traverse2_kernel<VEC4, NW, QG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-  hipLaunchKernelGGL((traverse2_kernel<VEC4, NW, QG>), dim3((unsigned)slots), dim3(NW * 64), shm, s, a);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(traverse2_kernel<VEC4, NW, QG, PF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+  hipLaunchKernelGGL((traverse2_kernel<VEC4, NW, QG, PF>), dim3((unsigned)slots), dim3(NW * 64), shm, s, a);
 }
 
 int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_search_params& p, u64* run_keys,
@@ -400,8 +400,13 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
     const int sl = (int)std::min<int64_t>(slots, cnt);
 #define EPS_TRV_LAUNCH(V4, NW_)                                        \
   do {                                                                 \
-    if (qglobal) launch_trv2<V4, NW_, true>(a, sl, shm, s);            \
-    else launch_trv2<V4, NW_, false>(a, sl, shm, s);                   \
+    if (qglobal) {                                                     \
+      if (prefilter) launch_trv2<V4, NW_, true, true>(a, sl, shm, s);  \
+      else launch_trv2<V4, NW_, true, false>(a, sl, shm, s);           \
+    } else {                                                           \
+      if (prefilter) launch_trv2<V4, NW_, false, true>(a, sl, shm, s); \
+      else launch_trv2<V4, NW_, false, false>(a, sl, shm, s);          \
+    }                                                                  \
   } while (0)
     if (vec4) {
       if (nw == 16) EPS_TRV_LAUNCH(true, 16); else if (nw == 8) EPS_TRV_LAUNCH(true, 8); else EPS_TRV_LAUNCH(true, 4);

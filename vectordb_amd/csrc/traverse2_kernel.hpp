@@ -121,8 +121,10 @@ __device__ __forceinline__ void bitonic_passes(u64* buf, int n, int64_t gbase, i
   }
 }
 
-template <bool VEC4, int NW, bool QGLOBAL>
-__global__ __launch_bounds__(NW * 64, 4) void traverse2_kernel(Trv2Args a) {   // (4 wavefronts per SIMD: <= 128 VGPRs, the occupancy the host side plans with)
+// PF: with the 8-bit prefilter (step d0).  Compiled for 4 wavefronts per SIMD (<= 128 VGPRs, the occupancy the host side plans
+// with; a handful of dwords spill outside the loops); the form without it needs no such cap (109-117 VGPRs, nothing spilled).
+template <bool VEC4, int NW, bool QGLOBAL, bool PF>
+__global__ __launch_bounds__(NW * 64, PF ? 4 : 1) void traverse2_kernel(Trv2Args a) {
   constexpr int NT = NW * 64;
   constexpr int R = 4;           // queue elements per thread and merge chunk
   constexpr int C = NT * R;
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(NW * 64, 4) void traverse2_kernel(Trv2Args a) {   /
   int* s_pcnt = s_selpos + TS;     // [T] ids that passed the 8-bit prefilter
   int* s_eoff = s_pcnt + TS;       // [T+1] first edge slot of every worker in this step
   // prefilter block (only present in the launch's LDS size when a.x8): statistics of the query on the table's grid, then the query
-  const bool pf = a.x8 != nullptr;
+  constexpr bool pf = PF;   // (a.x8 != null)
   const size_t pf_off = ((size_t)(reinterpret_cast<unsigned char*>(sh + SH) - smem_raw) + 15) & ~(size_t)15;
   float* qst = reinterpret_cast<float*>(smem_raw + pf_off);                // [4] |q|^2, |q|, |q - qh|, C + c
   signed char* sq8 = reinterpret_cast<signed char*>(qst + 4);               // [q8len]
