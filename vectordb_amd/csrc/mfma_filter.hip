@@ -703,9 +703,12 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
     // filter's epilogue and 3 KB of gather in the re-rank, so the looser 8-bit bound wants more, smaller steps (measured at
     // 10M x 768, batch 1024: EPS_MFMA_STAGES sweep in profiles/r3_stage_sweep.txt).
     const char* st_env = getenv("EPS_MFMA_STAGES");
-    // (also for few queries: one query on 1M x 768 - bench.py configs c2 - takes 0.48 ms end to end with 6 stages and 0.56 ms with 2:
-    // the re-rank is one workgroup per query, so a stage's candidate list, not the launch count, sets the latency)
-    int nstages = i8 ? 6 : 3;
+    // Few queries (<= 64): 4 stages.  A call is then a chain of short dependent launches (profiles/r3_single_query_timeline.txt: one
+    // query on 1M x 768 = 400 us of back-to-back kernels, 185 us of them the filter stages streaming the mirror once, 110 us seven
+    // one-workgroup re-ranks), and two re-ranks less beat the longer lists: scripts/lab/stages_by_batch.py, 1M x 768, p50 ms at
+    // 1 / 16 / 64 queries: 0.392 / 0.440 / 0.504 (3 stages), 0.400 / 0.438 / 0.494 (4), 0.431 / 0.466 / 0.515 (6); from 128 queries
+    // on 6 stages win (0.648 vs 0.707 with 3), at 10M rows as well.
+    int nstages = i8 ? (nq <= 64 ? 4 : 6) : 3;
     if (i8)   // ... but never so few that a stage's expected k * c * ratio candidates come near the list capacity
       while (nstages < 8 && (double)k * 5.0 * std::pow((double)n / (double)S0, 1.0 / (double)nstages) > 0.5 * (double)cap) ++nstages;
     if (st_env) nstages = std::min(8, std::max(1, atoi(st_env)));
