@@ -110,3 +110,22 @@ int main(void) {
     assert [C.sizeof(_lib.FilterOp), _lib.FilterOp.arg.offset, _lib.FilterOp.ival.offset, _lib.FilterOp.dval.offset] == c["fop"]
     assert C.sizeof(_lib.TableLayout) == c["layout"]
 
+
+
+def test_traversal_gather_bytes_accounting():
+    """bench.py / scripts/bench_graph.py price the traversal kernel with this: without the 8-bit prefilter every evaluation reads
+    its fp32 row; with it (rerank_rows = fp32 rows read in step d) seeds and survivors read 4d bytes, every neighbour evaluation
+    the mirror row (d rounded up to 16) + its 4-byte constant.  The two forms agree when every neighbour passes the prefilter,
+    up to the mirror bytes themselves."""
+    import vectordb_amd as amd
+    d, deg, seeds = 768, 50.0, 500 * 1024
+    off = {"dist_evals": 32_000 * 1024, "expansions": 590 * 1024, "rerank_rows": 0}
+    assert amd.traversal_gather_bytes(off, d, deg, seeds) == off["dist_evals"] * (4.0 * d + 4) + off["expansions"] * (8 + 4 * deg)
+    on = dict(off, rerank_rows=5_700 * 1024)
+    want = (seeds + on["rerank_rows"]) * 4.0 * d + (on["dist_evals"] - seeds) * (768 + 4.0) + on["dist_evals"] * 4 + on["expansions"] * (8 + 4 * deg)
+    assert amd.traversal_gather_bytes(on, d, deg, seeds) == want
+    assert 0.40 < want / amd.traversal_gather_bytes(off, d, deg, seeds) < 0.50      # (the 10M x 768 measurement: 44.6 of 101 GB)
+    allpass = dict(off, rerank_rows=off["dist_evals"] - seeds)
+    extra = (off["dist_evals"] - seeds) * (768 + 4.0)
+    assert amd.traversal_gather_bytes(allpass, d, deg, seeds) == amd.traversal_gather_bytes(off, d, deg, seeds) + extra
+    assert amd.traversal_gather_bytes(dict(off, rerank_rows=1), 100, deg, 0) > 0     # d not a multiple of 16: mirror row rounded up to 112
