@@ -60,11 +60,13 @@ def test_auto_engine_equals_stream_engine(amd, c):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", list(range(24)))
-def test_fuzz_traversal_matches_oracle_lockstep(amd, oracle, seed):
-    """Seeded fuzz of the traversal kernel over worker counts, queue sizes (LocalQueueSize != SearchQueueSize included), sync
+def test_fuzz_traversal_matches_oracle_lockstep(amd, oracle, monkeypatch, seed):
+    """(Odd seeds run with the 8-bit prefilter forced on, even seeds with it off.)
+    Seeded fuzz of the traversal kernel over worker counts, queue sizes (LocalQueueSize != SearchQueueSize included), sync
     intervals, metrics, batch sizes (4- and 16-wavefront variants) and adjacency shapes (fixed stride; CSR with lists beyond 64
     entries, duplicates and empty lists) against the oracle's SearchImpl under the lockstep schedule: whole returned prefix of the
     master queue and the evaluation count."""
+    monkeypatch.setenv("EPS_TRV_PREFILTER", str(seed & 1))
     rng = np.random.default_rng(1000 + seed)
     n = int(rng.integers(600, 1500))
     d = int(rng.choice([8, 24, 33, 64]))
