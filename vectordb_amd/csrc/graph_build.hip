@@ -601,7 +601,7 @@ int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp, const Buil
   // 8-bit lower-bound prefilter of the searches' distance step (traverse_kernel.hpp, step 3a): the mirror is the one the kNN stage
   // just scanned; EPS_BUILD_PREFILTER=0 turns it off (A/B - the graph is the same either way)
   Quant8View q8v;
-  bool prefilter = dim >= 128 && !(getenv("EPS_BUILD_PREFILTER") && atoi(getenv("EPS_BUILD_PREFILTER")) == 0);
+  bool prefilter = dim >= 128;
   if (const char* e = getenv("EPS_BUILD_PREFILTER")) prefilter = atoi(e) != 0;
   DevBuf q8b, qstat8b;
   if (prefilter) {
