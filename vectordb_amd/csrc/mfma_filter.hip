@@ -432,6 +432,16 @@ __global__ void threshold_kernel(const u64* run_keys, int k, int64_t nq, int64_t
 }
 
 
+// Start of a seeded call in one launch (three memset nodes cost a single-query call ~50 us): thresholds = +inf, every query's list
+// length = the seed count (the dense seed pass writes slot = row), overflow flag and candidate total = 0, group counters = 0.
+__global__ void seed_prologue_kernel(u64* T2, int64_t n2, u64 v, u32* cnt, int64_t nq, u32 cntv, u32* gsync) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n2) T2[i] = v;
+  if (i < nq) cnt[i] = cntv;
+  if (i < 8) cnt[nq + i] = 0;
+  if (gsync && i < 256) gsync[i] = 0;
+}
+
 // seed sample: the first S/2 rows of the table plus S/2 rows spread evenly over the rest, copied next to each other (a
 // positional filter - "only the newest rows" or "only the oldest" - leaves at least half of the seeds' share visible)
 __global__ __launch_bounds__(256) void seed_sample_kernel(const _Float16* xh, const u32* base_s, const u32* base, unsigned long long stride,
@@ -743,7 +753,8 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   u32* overflow = cnt + nq;                                                    // [1]
   unsigned long long* total = reinterpret_cast<unsigned long long*>(cnt + nq + 2);  // 8-byte aligned? ensured below
   if ((reinterpret_cast<uintptr_t>(total) & 7) != 0) total = reinterpret_cast<unsigned long long*>(cnt + nq + 3);
-  hipError_t er = hipMemsetAsync(cnt + nq, 0, 32, s);
+  const bool prologue = seeded && version >= 7;   // one launch resets everything a seeded call starts from (below)
+  hipError_t er = prologue ? hipSuccess : hipMemsetAsync(cnt + nq, 0, 32, s);
   if (er != hipSuccess) return ix.hip_fail(er, "memset");
 
   FilterArgs fa;
@@ -827,7 +838,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
       f3.tiles_q = (int)(b_pad / BN3);
       if (version >= 7) {
         f3.group_sync = gsync_env ? m.gsync.as<u32>() : nullptr;
-        if (f3.group_sync && f3.dense) (void)hipMemsetAsync(f3.group_sync, 0, 1024, s);   // (stages: reset by threshold_kernel)
+        if (f3.group_sync && f3.dense && !prologue) (void)hipMemsetAsync(f3.group_sync, 0, 1024, s);   // (stages: reset by threshold_kernel / the re-rank)
         const int mode = f3.dense ? FM_DENSE : (f3.cand_keys ? FM_KEYS : FM_IDS);
         const dim3 grid((unsigned)num_cus), block(256);
 #define EPS_V7_LAUNCH(JQ_, I8_)                                                                                             \
@@ -854,10 +865,16 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   ra.slack = rerank_slack;
   const bool fused = !approx;   // exact mode: every re-rank also does its stage's counts and the next stage's thresholds
   if (seeded) {
-    launch_fill_u64(reinterpret_cast<u64*>(m.T.p), b_pad / 2, 0x7F8000007F800000ull, s);   // T = +inf: every head row is a candidate
     const bool dense = version >= 7;   // v7 writes the head's keys densely (slot = row); older kernels append with atomics
-    er = dense ? hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(cnt), (int)S0, (size_t)nq, s) : hipMemsetAsync(cnt, 0, (size_t)nq * 4, s);
-    if (er != hipSuccess) return ix.hip_fail(er, "memset");
+    if (prologue) {
+      const int64_t cells = std::max<int64_t>(std::max<int64_t>(b_pad / 2, nq), 256);
+      hipLaunchKernelGGL(seed_prologue_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, s, reinterpret_cast<u64*>(m.T.p), b_pad / 2, 0x7F8000007F800000ull,
+                         cnt, nq, (u32)S0, gsync_env ? m.gsync.as<u32>() : nullptr);
+    } else {
+      launch_fill_u64(reinterpret_cast<u64*>(m.T.p), b_pad / 2, 0x7F8000007F800000ull, s);   // T = +inf: every head row is a candidate
+      er = dense ? hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(cnt), (int)S0, (size_t)nq, s) : hipMemsetAsync(cnt, 0, (size_t)nq * 4, s);
+      if (er != hipSuccess) return ix.hip_fail(er, "memset");
+    }
     unsigned long long seed_stride = 0;   // != 0: the seed pass ran over the sample, ids are sample indices
     u32 seed_head = 0;
     FilterArgs f0 = fa;
