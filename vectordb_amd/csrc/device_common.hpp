@@ -273,7 +273,15 @@ __host__ __device__ inline int group_lanes(int64_t dim, bool vec4) {
 // Accumulate U rows x NQ queries.  rowp[u] points at the row for this lane's group (already clamped to
 // a valid row); qs = LDS copy of the NQ queries, each dim floats (16-B aligned when VEC4).
 // Returns raw accumulators reduced over the G lanes of the group (valid in every lane of the group).
-template <int U, int NQ, bool VEC4>
+// NL = 16-byte pieces of every row a lane has in flight at once (VEC4 only).  The loop over a row's pieces has a run-time trip
+// count, so hipcc issues the U loads of one piece, waits for them, multiplies, and only then issues the next piece: at d = 768
+// (three pieces per lane) a GATHER of U rows costs three dependent memory round trips.  NL = 3 issues all of them first; the
+// fmas run in the same order either way, so the sums are bit-identical.  It costs 32 more VGPRs at U = 4 and every kernel that
+// gathers rows is at its occupancy edge, so it is a lab knob, not the default (profiles/r3_row_pieces_in_flight_ab.txt): traversal
+// with the 8-bit prefilter (-DEPS_TRV_NL=3) 1M x 768: T = 1 8.85 -> 8.03 ms, T = 4 7.26 -> 6.92 ms, but 10M x 768 T = 4 10.2 ->
+// 10.4 ms (T = 1 11.3 -> 10.6); without the prefilter 13.0 -> 16.6 ms (4 -> 3 wavefronts per SIMD); the build's searches
+// (Link 2.74 -> 2.88 s); the re-rank: no change.
+template <int U, int NQ, bool VEC4, int NL = 1>
 __device__ __forceinline__ void row_dists(const float* const (&rowp)[U], const float* qs, int64_t qstride, int dim,
                                           int metric, int G, float (&acc)[U][NQ]) {
   const int t = lane_id() & (G - 1);
@@ -281,6 +289,44 @@ __device__ __forceinline__ void row_dists(const float* const (&rowp)[U], const f
   for (int u = 0; u < U; ++u)
 #pragma unroll
     for (int q = 0; q < NQ; ++q) acc[u][q] = 0.f;
+  if (VEC4 && NL > 1) {
+    for (int c = t * 4; c < dim; c += G * 4 * NL) {
+      float4 x[NL][U];
+#pragma unroll
+      for (int j = 0; j < NL; ++j) {
+        const int cj = c + j * G * 4;
+        if (cj < dim) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) x[j][u] = *reinterpret_cast<const float4*>(rowp[u] + cj);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NL; ++j) {
+        const int cj = c + j * G * 4;
+        if (cj < dim) {
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) {
+            const float4 qv = *reinterpret_cast<const float4*>(qs + q * qstride + cj);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              if (metric == 0) {
+                const float a = x[j][u].x - qv.x, b = x[j][u].y - qv.y, c2 = x[j][u].z - qv.z, d2 = x[j][u].w - qv.w;
+                acc[u][q] = fmaf(a, a, acc[u][q]);
+                acc[u][q] = fmaf(b, b, acc[u][q]);
+                acc[u][q] = fmaf(c2, c2, acc[u][q]);
+                acc[u][q] = fmaf(d2, d2, acc[u][q]);
+              } else {
+                acc[u][q] = fmaf(x[j][u].x, qv.x, acc[u][q]);
+                acc[u][q] = fmaf(x[j][u].y, qv.y, acc[u][q]);
+                acc[u][q] = fmaf(x[j][u].z, qv.z, acc[u][q]);
+                acc[u][q] = fmaf(x[j][u].w, qv.w, acc[u][q]);
+              }
+            }
+          }
+        }
+      }
+    }
+  } else
   if (VEC4) {
     for (int c = t * 4; c < dim; c += G * 4) {
       float4 x[U];

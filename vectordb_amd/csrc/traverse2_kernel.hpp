@@ -73,6 +73,9 @@ struct Trv2Args {
 #ifndef EPS_TRV_U
 #define EPS_TRV_U 4   // rows in flight per lane group in the distance phases
 #endif
+#ifndef EPS_TRV_NL
+#define EPS_TRV_NL 1   // 16-byte pieces of an fp32 row a lane has in flight in the prefilter form of the kernel (row_dists, device_common.hpp; 3 measured: mixed)
+#endif
 #ifndef EPS_TRV_U8
 #define EPS_TRV_U8 2   // prefilter: mirror rows in flight per lane group ...
 #endif
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(NW * 64, PF ? 4 : 1) void traverse2_kernel(Trv2Args
         rp[u] = a.rows + (int64_t)id[u] * dim;
       }
       float acc[U][1];
-      row_dists<U, 1, VEC4>(rp, sq, qstride, dim, a.metric, G, acc);
+      row_dists<U, 1, VEC4, (PF ? EPS_TRV_NL : 1)>(rp, sq, qstride, dim, a.metric, G, acc);
 #pragma unroll
       for (int u = 0; u < U; ++u)
         if (ok[u] && t == 0) {
@@ -586,7 +589,7 @@ __global__ __launch_bounds__(NW * 64, PF ? 4 : 1) void traverse2_kernel(Trv2Args
             rp[u] = a.rows + (int64_t)id[u] * dim;
           }
           float acc[U][1];
-          row_dists<U, 1, VEC4>(rp, sq, qstride, dim, a.metric, G, acc);
+          row_dists<U, 1, VEC4, (PF ? EPS_TRV_NL : 1)>(rp, sq, qstride, dim, a.metric, G, acc);
 #pragma unroll
           for (int u = 0; u < U; ++u) {
             if (ok[u] && t == 0) {
