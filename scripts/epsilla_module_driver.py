@@ -88,6 +88,23 @@ if what == "bulk":
                                           limit=3, with_distance=False)                               # all fields, float64 queries
         out["batch"]["all_fields_keys"] = sorted(resp3[0][0].keys())
         out["batch"]["all_fields_ids"] = [[r["ID"] for r in rr] for rr in resp3]
+        if os.environ.get("EPS_MODULE_REBUILD") and hasattr(epsilla, "rebuild"):
+            # the reference's semantics from here on: Rebuild() builds the NSG (on the field's device mirror), searches walk it
+            exact64 = out["batch"][""]["results"]
+            t0 = time.perf_counter()
+            out["rebuild_code"] = epsilla.rebuild()
+            out["rebuild_s"] = time.perf_counter() - t0
+            code, resp = epsilla.query_batch(query_vectors=Q, filter="", **kw)
+            t0 = time.perf_counter()
+            for _ in range(batches):
+                code, resp = epsilla.query_batch(query_vectors=Q, filter="", **kw)
+            sec = (time.perf_counter() - t0) / batches
+            assert code == 0 and len(resp) == nq
+            hit = sum(len(set(r["ID"] for r in resp[i]) & set(exact64[i][0])) for i in range(len(exact64)))
+            code1, resp1 = epsilla.query(query_vector=Q[0].tolist(), filter="", **kw)
+            out["graph"] = {"qps": nq / sec, "ms_per_batch": 1e3 * sec, "queries": nq, "batches": batches,
+                            "recall_at_10_vs_exact_first_64": hit / float(10 * len(exact64)),
+                            "query()_equals_query_batch()[0]": [r["ID"] for r in resp1] == [r["ID"] for r in resp[0]]}
         # exact ground truth of the first queries straight from the rows (numpy, float64)
     gt = []
     for q in Q[:4]:
