@@ -271,13 +271,18 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
     prefilter = q8v.x8 != nullptr;
   }
   const size_t lds_need = traverse2_lds_bytes((int)ix.dim_, T, (int)Lq, qtot, dp, false, prefilter);
-  const size_t lds_limit = getenv("EPS_TRV_LDS_KB") ? (size_t)std::max(16, atoi(getenv("EPS_TRV_LDS_KB"))) * 1024 : (size_t)150 * 1024;   // (A/B knob)
+  // r3 (scripts/lab/trv_large_l2.sh, bench_random_graph.py): for BATCHES that band is better served with the queues in HBM and 8
+  // wavefronts per query, two queries per CU (T = 4, L = 2000, batch 1024: 1M x 768 46.6 -> 39.4 ms, 10M-row proxy 56.8 -> 49.3 ms;
+  // 4 wavefronts 64.6, 16 wavefronts 66.1), and 8 wavefronts also beat the 4 that queues in HBM used to get (L = 4000: 126.6 ->
+  // 93.6 ms, L = 8000: 350.8 -> 246.7 ms).  A handful of queries (<= 256, latency) keeps the one-workgroup-per-CU form.
+  const size_t lds_limit = getenv("EPS_TRV_LDS_KB") ? (size_t)std::max(16, atoi(getenv("EPS_TRV_LDS_KB"))) * 1024
+                                                     : (nq <= 256 ? (size_t)150 * 1024 : (size_t)80 * 1024);   // (A/B knob)
   const bool qglobal = lds_need > lds_limit;
   const bool one_per_cu = !qglobal && lds_need > (size_t)80 * 1024;
   const size_t shm = traverse2_lds_bytes((int)ix.dim_, T, (int)Lq, qtot, dp, qglobal, prefilter);
   // few queries: 16 wavefronts per query (latency); many queries: fewer per query (throughput, more queries per CU)
   const char* waves_s = getenv("EPS_TRV_WAVES");
-  int nw = waves_s ? atoi(waves_s) : ((nq <= 256 || one_per_cu) ? 16 : 4);
+  int nw = waves_s ? atoi(waves_s) : ((nq <= 256 || one_per_cu) ? 16 : (qglobal ? 8 : 4));
   if (const char* wide_s = getenv("EPS_TRV_WIDE")) nw = atoi(wide_s) != 0 ? 16 : 4;   // (older switch)
   if (nw != 4 && nw != 8 && nw != 16) nw = 4;
   hipDeviceProp_t prop;
