@@ -12,7 +12,7 @@ import numpy as np
 
 
 def run(which, n, d, nq, threads):
-    from oracle.pyoracle import DROPIN_SO, Ref, ref_available
+    from oracle.pyoracle import DROPIN_SO, Ref
     lib = Ref(DROPIN_SO) if which == "dropin" else Ref()
     lib.L.ref_config(4, 500, 1, 0, 16)
     db = lib.db(os.path.join(tempfile.mkdtemp(), "db"), scale=n + 1000, wal=False)

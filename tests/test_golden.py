@@ -4,7 +4,6 @@ scripts/gen_golden.py) and vs. the known-answer cases of the reference's own gte
 import os
 
 import numpy as np
-import pytest
 
 from oracle.pyoracle import make_filter
 

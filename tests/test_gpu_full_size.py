@@ -10,7 +10,6 @@ COMPILED REFERENCE (oracle/_ref = the reference's own sources): position-wise id
 
 The 10M-row table is generated on the device (seeded), copied once to page-aligned host memory for the reference (30.7 GB).
 Needs ~31 GB of host memory and ~45 GB of HBM; takes about a minute, most of it the reference's scans."""
-import os
 
 import numpy as np
 import pytest
