@@ -162,6 +162,7 @@ typedef struct eps_search_stats {
   int64_t main_kernel_rows; /* rows covered by the launch timed in main_kernel_ms              */
   int64_t main_kernel_queries; /* queries covered by that launch (large batches run in slices)  */
   int64_t main_kernel_bits; /* operand width of that launch: 32 (fp32 stream / traversal), 16 or 8 (matrix engine) */
+  int64_t i8_declined;      /* 1: this call probed the 8-bit pass on this table, found its bound too loose for the data and ran the fp16 pass (r4) */
 } eps_search_stats;
 
 void eps_default_search_params(eps_search_params* p);

@@ -58,7 +58,7 @@ class SearchStats(C.Structure):
     _fields_ = [("dist_evals", C.c_int64), ("expansions", C.c_int64), ("rerank_rows", C.c_int64),
                 ("overflow_queries", C.c_int64), ("kernel_ms", C.c_double), ("main_kernel_ms", C.c_double),
                 ("main_kernel_launches", C.c_int64), ("main_kernel_rows", C.c_int64),
-                ("main_kernel_queries", C.c_int64), ("main_kernel_bits", C.c_int64)]
+                ("main_kernel_queries", C.c_int64), ("main_kernel_bits", C.c_int64), ("i8_declined", C.c_int64)]
 
 
 class EpsillaError(RuntimeError):

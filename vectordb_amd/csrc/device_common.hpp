@@ -172,19 +172,21 @@ __device__ __forceinline__ int quant8(float x, float z, float inv_step) {
   t = fminf(fmaxf(t, -127.f), 127.f);   // (rows appended after the grid was fixed may lie outside it: clamped, the residual grows, the bound stays valid)
   return (int)t;
 }
-// int8 operands: T in accumulator units (int32): a row passes iff dot + acc0 >= T
+// int8 operands: T in accumulator units (int32): a row passes iff dot + acc0 >= T.  thr: a distance; qs: |q|^2, |q - mu|, |q' - qh'|, C[q]
+// (query_prep8_kernel); sc: max |x' - xh'|, max |xh'|, max |x|^2, -, max |R|, |mu| (quant_mirror_kernel).  Restated in numpy, with the
+// implication it must guarantee, in tests/test_bound_math.py.
 __device__ __forceinline__ int stage_threshold8(float thr, const float* qs, const float* sc, int metric, float u, float slack, int approx) {
-  const float qn2 = qs[0], nq_ = qs[1], eq = qs[2];
-  const float e1max = sc[0], nxhmax = sc[1], xnmax = sc[2], rmax = sc[4];
+  const float qn2 = qs[0], nqc = qs[1], eq = qs[2], Cq = qs[3];
+  const float e1max = sc[0], nxhmax = sc[1], xnmax = sc[2], rmax = sc[4], mun = sc[5];
   const float s = metric == 0 ? 2.f : 1.f;
-  const float c = metric == 0 ? qn2 : (metric == 1 ? 1.f : 0.f);
-  const float Cq = qs[3] - c;
-  const float margin = s * (nq_ * e1max + eq * nxhmax);
-  // fp32 evaluation of the re-ranked keys, of R and of C (each a d-term sum of the magnitude below), and of the two divisions by u
-  const float scale = (metric == 0 ? (fabsf(thr) + qn2 + xnmax) : (fabsf(thr) + 1.f + nq_ * nxhmax)) + fabsf(Cq) + rmax;
+  const float margin = s * (nqc * e1max + eq * nxhmax);   // Cauchy-Schwarz on the two stored residuals, in the centred frame
+  // fp32 evaluation of the re-ranked distance, of R and of C (each a d-term sum whose terms' magnitudes sum to at most the scale
+  // below), of x - mu, and of the two divisions by u
+  const float scale = metric == 0 ? fabsf(thr) + 2.f * fabsf(Cq) + 2.f * rmax
+                                  : fabsf(thr) + 1.f + sqrtf(qn2) * (sqrtf(xnmax) + mun) + mun * (nxhmax + e1max) + fabsf(Cq) + rmax;
   // approx mode (the build's kNN stage) ranks on the approximate keys themselves: a row is wanted iff its APPROXIMATE key beats the
-  // k-th best approximate key so far - no margin (with it ~4.7 x the rows pass, and every one costs an append)
-  const float t = approx ? (thr - c) + slack * scale + 4.f * u : (thr - c) + margin + slack * scale + 4.f * u;
+  // k-th best approximate key so far - no margin (with it several times the rows pass, and every one costs an append)
+  const float t = approx ? thr + slack * scale + 4.f * u : thr + margin + slack * scale + 4.f * u;
   float v = floorf((Cq - t) / u) - 2.f;
   v = fminf(fmaxf(v, -1073741824.f), 1073741824.f);
   return v >= 1073741824.f ? 0x7FFFFFFF : (int)v;

@@ -644,7 +644,7 @@ int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp, const Buil
   ta.u8 = q8v.u;
   {
     const int G = group_lanes(dim, vec4);
-    ta.slack8 = std::max(8e-6f, 2.f * (3.f * ((float)((dim + G - 1) / G) + 6.f) + 2.f) * 5.9604645e-8f);
+    ta.slack8 = std::max(8e-6f, 2.f * (3.f * ((float)((dim + G - 1) / G) + 6.f) + 6.f) * 5.9604645e-8f);
   }
   if (prefilter) {
     if (!q8b.reserve((size_t)NB * q8v.d_pad8) || !qstat8b.reserve((size_t)NB * 16)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "build: out of device memory");

@@ -31,8 +31,9 @@ struct Quant8View {   // the table's 8-bit mirror as other kernels see it (mfma_
   const signed char* x8 = nullptr;
   const int* acc0 = nullptr;
   const float* scal8 = nullptr;
+  const float* mu = nullptr;   // [d_pad8] the grid's centre (one value per column)
   int d_pad8 = 0;
-  float z = 0.f, step = 1.f, u = 1.f;
+  float step = 1.f, u = 1.f;
 };
 struct HalfMirror;   // fp16 mirror + per-row bounds for the MFMA filter engine (mfma_filter.hip)
 struct GraphDev;     // device CSR + traversal scratch (traverse.hip)

@@ -79,7 +79,9 @@ struct HalfMirror {
   DevBuf scal8;    // float [8]: max |x - xh|, max |xh|, max |x|^2, bad flag, max |R|, -, min (ordered u32), max (ordered u32)
   DevBuf q8;       // int8 [b_pad][d_pad8]
   float h_scal8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  float z8 = 0.f, step8 = 0.f;  // the grid
+  DevBuf mu8;      // float [d_pad8]: the grid's centre, one value per column (zeros beyond dim)
+  float step8 = 0.f;            // the grid: xh' = step8 * xi around mu8
+  bool i8_trusted = false;      // the library's own choice has seen a batch through the 8-bit pass on this mirror (no probe needed)
   int64_t version8 = -1, n8 = 0, n_pad8 = 0;
   int d_pad8 = 0;
   bool i8_ok = false;
@@ -237,47 +239,96 @@ __global__ __launch_bounds__(256) void query_prep_kernel(const float* q, int64_t
 }
 
 // ------------------------------------------------------------------------------------------------ 8-bit mirror
-// value range of the table (ordered-u32 images, so atomicMin / atomicMax work on them): scal8[6] = min, scal8[7] = max
-__global__ __launch_bounds__(256) void minmax_kernel(const float* rows, int64_t count, u32* scal8) {
+// r4: the grid is CENTRED.  Rows and queries are quantised as x' = x - mu on a symmetric grid, xh' = step * xi, with one mu per
+// COLUMN (column means of a strided sample of the table + the mid-range of what is left, so that the grid is symmetric).  Distances
+// do not care: |x - q|^2 = |x' - q'|^2, q.x = q'.x' + mu.x' + q.mu - the cross terms are a per-row and a per-query constant, exact in
+// fp32, folded into R[x] and C[q] - and the Cauchy-Schwarz margin now scales with |q - mu| and |x - mu| instead of |q| and |x|:
+// half the margin on U[0,1) rows (every candidate the filter passes for nothing costs a 3 KB gather in the re-rank, an fp32 row in
+// the traversal), a third on tables whose columns have their own means, and tables far from the origin lose nothing.  ANY mu keeps
+// the bound valid (tests/test_bound_math.py::test_any_centre_keeps_the_bound_valid): it only has to be the same vector for the rows
+// and the queries, so it is fixed when the mirror is first built and kept when rows are appended.
+constexpr int CENTRE_SEG = 32;   // segments of the sample, summed in a fixed order: mu is bit-reproducible (the build's approximate
+                                 // kNN keys depend on it, and two builds of one table must give the same graph)
+// partial column sums of sample rows r = (seg * per_seg + i) * stride, i < per_seg:  part[seg][col]
+__global__ __launch_bounds__(256) void colsum_kernel(const float* rows, int64_t n, int dim, int64_t stride, int64_t per_seg, float* part) {
+  __shared__ float red[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int sub = threadIdx.x >> 6;
+  const int64_t seg = blockIdx.y;
+  float s = 0.f;
+  if (col < dim) {
+    for (int64_t i = sub; i < per_seg; i += 4) {
+      const int64_t r = (seg * per_seg + i) * stride;
+      if (r < n) s += rows[r * dim + col];
+    }
+  }
+  red[sub][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (sub == 0 && col < dim) part[seg * dim + col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+// mean[col] = sum of the segments (fixed order) / sampled rows; columns beyond dim: 0
+__global__ void colmean_kernel(const float* part, int dim, int d_pad8, float inv_count, float* mu) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= d_pad8) return;
+  float s = 0.f;
+  if (col < dim)
+    for (int g = 0; g < CENTRE_SEG; ++g) s += part[g * dim + col];
+  mu[col] = col < dim ? s * inv_count : 0.f;
+}
+// value range of x - mean over the whole table (ordered-u32 images, so atomicMin / atomicMax work on them): scal8[6] = min,
+// scal8[7] = max; one wavefront per row, grid-stride
+__global__ __launch_bounds__(256) void minmax_kernel(const float* rows, int64_t n, int dim, const float* mean, u32* scal8) {
   float lo = __builtin_inff(), hi = -__builtin_inff();
   bool bad = false;
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  if ((reinterpret_cast<uintptr_t>(rows) & 15) == 0) {
-    const int64_t c4 = count / 4;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < c4; i += stride) {
-      const float4 v = reinterpret_cast<const float4*>(rows)[i];
-      lo = fminf(fminf(lo, v.x), fminf(fminf(v.y, v.z), v.w));
-      hi = fmaxf(fmaxf(hi, v.x), fmaxf(fmaxf(v.y, v.z), v.w));
-      bad |= !(fabsf(v.x) < 3.0e38f) || !(fabsf(v.y) < 3.0e38f) || !(fabsf(v.z) < 3.0e38f) || !(fabsf(v.w) < 3.0e38f);
-    }
-    for (int64_t i = c4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) {
-      lo = fminf(lo, rows[i]);
-      hi = fmaxf(hi, rows[i]);
-      bad |= !(fabsf(rows[i]) < 3.0e38f);
-    }
-  } else {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) {
-      lo = fminf(lo, rows[i]);
-      hi = fmaxf(hi, rows[i]);
-      bad |= !(fabsf(rows[i]) < 3.0e38f);
+  const int lane = lane_id();
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const bool vec = (dim & 3) == 0 && ((reinterpret_cast<uintptr_t>(rows) & 15) == 0);
+  for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += nwaves) {
+    const float* src = rows + r * dim;
+    if (vec) {
+      for (int c = lane * 4; c < dim; c += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(src + c);
+        const float4 m = *reinterpret_cast<const float4*>(mean + c);
+        const float a = v.x - m.x, b = v.y - m.y, c2 = v.z - m.z, d2 = v.w - m.w;
+        lo = fminf(fminf(lo, a), fminf(fminf(b, c2), d2));
+        hi = fmaxf(fmaxf(hi, a), fmaxf(fmaxf(b, c2), d2));
+        bad |= !(fabsf(v.x) < 3.0e38f) || !(fabsf(v.y) < 3.0e38f) || !(fabsf(v.z) < 3.0e38f) || !(fabsf(v.w) < 3.0e38f);
+      }
+    } else {
+      for (int c = lane; c < dim; c += 64) {
+        const float a = src[c] - mean[c];
+        lo = fminf(lo, a);
+        hi = fmaxf(hi, a);
+        bad |= !(fabsf(src[c]) < 3.0e38f);
+      }
     }
   }
   for (int o = 32; o > 0; o >>= 1) {
     lo = fminf(lo, __shfl_xor(lo, o));
     hi = fmaxf(hi, __shfl_xor(hi, o));
   }
-  if (lane_id() == 0) {
+  if (lane == 0) {
     if (lo <= hi) {
       atomicMin(&scal8[6], f2ord(lo + 0.0f));
       atomicMax(&scal8[7], f2ord(hi + 0.0f));
     }
   }
-  if (__any(bad) && lane_id() == 0) atomicMax(&scal8[3], __float_as_uint(1.f));   // inf / NaN somewhere: the grid would be meaningless
+  if (__any(bad) && lane == 0) atomicMax(&scal8[3], __float_as_uint(1.f));   // inf / NaN somewhere: the grid would be meaningless
+}
+// mu = mean + z0 (z0: mid-range of x - mean, so that the grid is symmetric around 0); scal8[5] = |mu| (enters the fp32 slack of IP / COSINE)
+__global__ __launch_bounds__(64) void mu_finish_kernel(float* mu, int dim, float z0, float* scal8) {
+  float s2 = 0.f;
+  for (int c = lane_id(); c < dim; c += 64) {
+    const float v = mu[c] + z0;
+    mu[c] = v;
+    s2 = fmaf(v, v, s2);
+  }
+  for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
+  if (lane_id() == 0) scal8[5] = sqrtf(s2) * 1.00001f;
 }
 
-// rows [row0, n_pad) are (re)written, as in half_mirror_kernel.  metric 0: R = |x|^2 - 2 z sx SX - d z^2 = sum (x_k - z)^2 + 2 z (x_k - xh_k)
-// (summed in this form: no cancellation for tables far from the origin); otherwise R = -z sx SX.  u = |s| sx^2.
-__global__ __launch_bounds__(256) void quant_mirror_kernel(const float* rows, int64_t row0, int64_t n, int64_t n_pad, int dim, int d_pad8, float z, float step,
+// rows [row0, n_pad) are (re)written, as in half_mirror_kernel.  x' = x - mu;  metric 0: R = |x'|^2; otherwise R = -mu.x'.  u = |s| step^2.
+__global__ __launch_bounds__(256) void quant_mirror_kernel(const float* rows, int64_t row0, int64_t n, int64_t n_pad, int dim, int d_pad8, const float* mu, float step,
                                                            float inv_step, float inv_u, int metric, signed char* x8, int* acc0, float* scal8) {
   const int lane = lane_id();
   const int64_t nwaves = (int64_t)gridDim.x * 4;
@@ -291,8 +342,7 @@ __global__ __launch_bounds__(256) void quant_mirror_kernel(const float* rows, in
       continue;
     }
     const float* src = rows + r * dim;
-    float s2 = 0.f, e2 = 0.f, h2 = 0.f, rr = 0.f;
-    int sx_sum = 0;
+    float s2 = 0.f, e2 = 0.f, h2 = 0.f, c2 = 0.f, mx = 0.f;
     for (int c = lane * 4; c < d_pad8; c += 256) {   // d_pad8 is a multiple of 256
       float xs[4] = {0.f, 0.f, 0.f, 0.f};
       if (vec) {
@@ -304,20 +354,22 @@ __global__ __launch_bounds__(256) void quant_mirror_kernel(const float* rows, in
 #pragma unroll
         for (int e = 0; e < 4; ++e) xs[e] = c + e < dim ? src[c + e] : 0.f;
       }
+      const float4 mv = *reinterpret_cast<const float4*>(mu + c);   // (mu has d_pad8 entries, zeros beyond dim)
+      const float ms[4] = {mv.x, mv.y, mv.z, mv.w};
       u32 packed = 0;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         if (c + e < dim) {
-          const int xi = quant8(xs[e], z, inv_step);
-          const float dx = xs[e] - z;
-          const float res = fmaf(-step, (float)xi, dx);     // x - xh
-          const float xh = fmaf(step, (float)xi, z);
+          const float dx = xs[e] - ms[e];                   // x'
+          const int xi = quant8(dx, 0.f, inv_step);
+          const float res = fmaf(-step, (float)xi, dx);     // x' - xh'
+          const float xh = step * (float)xi;
           packed |= (u32)(xi & 255) << (8 * e);
-          sx_sum += xi;
           s2 = fmaf(xs[e], xs[e], s2);
           e2 = fmaf(res, res, e2);
           h2 = fmaf(xh, xh, h2);
-          rr += fmaf(dx, dx, 2.f * z * res);
+          c2 = fmaf(dx, dx, c2);
+          mx = fmaf(ms[e], dx, mx);
         }
       }
       *reinterpret_cast<u32*>(dst + c) = packed;
@@ -326,14 +378,14 @@ __global__ __launch_bounds__(256) void quant_mirror_kernel(const float* rows, in
       s2 += __shfl_xor(s2, o);
       e2 += __shfl_xor(e2, o);
       h2 += __shfl_xor(h2, o);
-      rr += __shfl_xor(rr, o);
-      sx_sum += __shfl_xor(sx_sum, o);
+      c2 += __shfl_xor(c2, o);
+      mx += __shfl_xor(mx, o);
     }
-    const float R = metric == 0 ? rr : -z * step * (float)sx_sum;
+    const float R = metric == 0 ? c2 : -mx;
     const float a0 = ceilf(-R * inv_u) + 1.f;
     if (!(fabsf(a0) < 536870912.f)) m_bad = 1.f;   // |acc0| must stay below 2^29 (the dot product adds < 2^27)
     if (lane == 0) acc0[r] = (int)fminf(fmaxf(a0, -536870912.f), 536870912.f);
-    m_e1 = fmaxf(m_e1, sqrtf(e2) * 1.00001f);
+    m_e1 = fmaxf(m_e1, sqrtf(e2) * 1.00001f + 1.2e-7f * sqrtf(c2));   // (+ the rounding of x - mu itself)
     m_nxh = fmaxf(m_nxh, sqrtf(h2) * 1.00001f);
     m_xn = fmaxf(m_xn, s2);
     m_r = fmaxf(m_r, fabsf(R));
@@ -348,9 +400,9 @@ __global__ __launch_bounds__(256) void quant_mirror_kernel(const float* rows, in
   }
 }
 
-// queries on the table's grid.  qstat[r] = |q|^2, |q|, |q - qh|, C[q] + const(q) (the constant that turns u-scaled accumulators
-// into approximate distances: dist ~ a.s * acc + qstat[3])
-__global__ __launch_bounds__(256) void query_prep8_kernel(const float* q, int64_t nq, int64_t b_pad, int dim, int d_pad8, float z, float step, float inv_step,
+// queries on the table's grid.  qstat[r] = |q|^2, |q'|, |q' - qh'|, C[q] (the constant that turns u-scaled accumulators into
+// approximate distances: dist ~ a.s * acc + qstat[3]);  q' = q - mu;  C = |q'|^2 (L2), 1 - q.mu (COSINE), -q.mu (DOT)
+__global__ __launch_bounds__(256) void query_prep8_kernel(const float* q, int64_t nq, int64_t b_pad, int dim, int d_pad8, const float* mu, float step, float inv_step,
                                                           int metric, signed char* q8, float* qstat) {
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= b_pad) return;
@@ -362,20 +414,22 @@ __global__ __launch_bounds__(256) void query_prep8_kernel(const float* q, int64_
     return;
   }
   const float* src = q + r * dim;
-  float s2 = 0.f, e2 = 0.f;
-  int sq_sum = 0;
+  float s2 = 0.f, e2 = 0.f, c2 = 0.f, qm = 0.f;
   for (int c = lane * 4; c < d_pad8; c += 256) {
     u32 packed = 0;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       if (c + e < dim) {
         const float x = src[c + e];
-        const int qi = quant8(x, z, inv_step);
-        const float res = fmaf(-step, (float)qi, x - z);
+        const float m = mu[c + e];
+        const float dx = x - m;
+        const int qi = quant8(dx, 0.f, inv_step);
+        const float res = fmaf(-step, (float)qi, dx);
         packed |= (u32)(qi & 255) << (8 * e);
-        sq_sum += qi;
         s2 = fmaf(x, x, s2);
+        c2 = fmaf(dx, dx, c2);
         e2 = fmaf(res, res, e2);
+        qm = fmaf(x, m, qm);
       }
     }
     *reinterpret_cast<u32*>(dst + c) = packed;
@@ -383,16 +437,14 @@ __global__ __launch_bounds__(256) void query_prep8_kernel(const float* q, int64_
   for (int o = 32; o > 0; o >>= 1) {
     s2 += __shfl_xor(s2, o);
     e2 += __shfl_xor(e2, o);
-    sq_sum += __shfl_xor(sq_sum, o);
+    c2 += __shfl_xor(c2, o);
+    qm += __shfl_xor(qm, o);
   }
   if (lane == 0) {
-    const float sabs = metric == 0 ? 2.f : 1.f;
-    const float C = -(float)dim * z * z - sabs * z * step * (float)sq_sum;
-    const float c = metric == 0 ? s2 : (metric == 1 ? 1.f : 0.f);
     qstat[r * 4 + 0] = s2;
-    qstat[r * 4 + 1] = sqrtf(s2) * 1.000001f;
-    qstat[r * 4 + 2] = sqrtf(e2) * 1.00001f;
-    qstat[r * 4 + 3] = C + c;
+    qstat[r * 4 + 1] = sqrtf(c2) * 1.000001f;
+    qstat[r * 4 + 2] = sqrtf(e2) * 1.00001f + 1.2e-7f * sqrtf(c2);
+    qstat[r * 4 + 3] = metric == 0 ? c2 : (metric == 1 ? 1.f - qm : -qm);
   }
 }
 
@@ -544,7 +596,7 @@ static float host_ord2f(u32 o) {
   return f;
 }
 
-// the 8-bit mirror: grid from the table's value range on the first build, kept when rows are appended
+// the 8-bit mirror: centre and grid from the table's values on the first build, kept when rows are appended
 static int32_t ensure_mirror8(Index& ix) {
   if (!ix.mirror_) ix.mirror_ = new HalfMirror();
   HalfMirror& m = *ix.mirror_;
@@ -553,34 +605,46 @@ static int32_t ensure_mirror8(Index& ix) {
   const bool extend = m.version8 == ix.rows_version_ && m.n8 > 0 && m.n8 < n && m.i8_ok;
   const int64_t n_pad = (n + ROWPAD - 1) / ROWPAD * ROWPAD;
   const int d_pad8 = std::max(512, (int)((ix.dim_ + 255) / 256 * 256));   // K-steps of 128 bytes, in pairs, at least four
+  const int dim = (int)ix.dim_;
   hipStream_t s = ix.stream_;
   const size_t keep_rows = extend ? (size_t)m.n8 : 0;
-  if (!grow_keep(m.x8, (size_t)n_pad * d_pad8, keep_rows * d_pad8, s) || !grow_keep(m.acc0, (size_t)n_pad * 4, keep_rows * 4, s) || !m.scal8.reserve(64))
+  if (!grow_keep(m.x8, (size_t)n_pad * d_pad8, keep_rows * d_pad8, s) || !grow_keep(m.acc0, (size_t)n_pad * 4, keep_rows * 4, s) || !m.scal8.reserve(64) ||
+      !m.mu8.reserve((size_t)d_pad8 * 4))
     return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory for the 8-bit mirror");
   hipError_t er = hipSuccess;
   if (!extend) {
     er = hipMemsetAsync(m.scal8.p, 0, 32, s);
     if (er == hipSuccess) er = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(m.scal8.as<u32>() + 6), (int)0xFFFFFFFFu, 1, s);
     if (er != hipSuccess) return ix.hip_fail(er, "memset");
-    const int64_t count = n * ix.dim_;
-    hipLaunchKernelGGL(minmax_kernel, dim3((unsigned)std::min<int64_t>((count + 1023) / 1024, 4096)), dim3(256), 0, s, ix.d_rows_, count, m.scal8.as<u32>());
+    // centre: column means of up to 65 536 rows spread evenly over the table (any centre is valid, see above), summed in a fixed order
+    const int64_t sample = std::min<int64_t>(n, 65536);
+    const int64_t stride = std::max<int64_t>(1, n / sample);
+    const int64_t per_seg = (sample + CENTRE_SEG - 1) / CENTRE_SEG;
+    const int64_t sampled = std::min<int64_t>((n + stride - 1) / stride, per_seg * CENTRE_SEG);
+    DevBuf part;
+    if (!part.reserve((size_t)CENTRE_SEG * dim * 4)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory for the 8-bit mirror");
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((dim + 63) / 64), CENTRE_SEG), dim3(256), 0, s, ix.d_rows_, n, dim, stride, per_seg, part.as<float>());
+    hipLaunchKernelGGL(colmean_kernel, dim3((unsigned)((d_pad8 + 255) / 256)), dim3(256), 0, s, part.as<float>(), dim, d_pad8, 1.f / (float)sampled, m.mu8.as<float>());
+    hipLaunchKernelGGL(minmax_kernel, dim3((unsigned)std::min<int64_t>((n + 3) / 4, 8192)), dim3(256), 0, s, ix.d_rows_, n, dim, m.mu8.as<float>(), m.scal8.as<u32>());
     er = hipMemcpyAsync(m.h_scal8, m.scal8.p, 32, hipMemcpyDeviceToHost, s);
-    if (er == hipSuccess) er = hipStreamSynchronize(s);
+    if (er == hipSuccess) er = hipStreamSynchronize(s);   // (also keeps `part` alive until its readers are done)
     if (er != hipSuccess) return ix.hip_fail(er, "8-bit mirror: value range");
     u32 omin, omax;
     std::memcpy(&omin, &m.h_scal8[6], 4);
     std::memcpy(&omax, &m.h_scal8[7], 4);
     const float lo = host_ord2f(omin), hi = host_ord2f(omax);
     m.i8_ok = m.h_scal8[3] == 0.f && omin <= omax && hi > lo && std::isfinite(lo) && std::isfinite(hi) && std::isfinite(hi - lo);
-    m.z8 = m.i8_ok ? 0.5f * lo + 0.5f * hi : 0.f;
-    m.step8 = m.i8_ok ? (hi - lo) / 254.f : 1.f;
+    const float z0 = m.i8_ok ? 0.5f * lo + 0.5f * hi : 0.f;
+    const float half = m.i8_ok ? std::max(hi - z0, z0 - lo) : 127.f;
+    m.step8 = half / 127.f;
     if (m.i8_ok && !(m.step8 > 0.f && std::isfinite(1.f / (m.step8 * m.step8)))) m.i8_ok = false;
+    if (m.i8_ok) hipLaunchKernelGGL(mu_finish_kernel, dim3(1), dim3(64), 0, s, m.mu8.as<float>(), dim, z0, m.scal8.as<float>());
   }
   if (m.i8_ok) {
     const float u = (ix.metric_ == 0 ? 2.f : 1.f) * m.step8 * m.step8;
     const int64_t row0 = extend ? m.n8 : 0;
     hipLaunchKernelGGL(quant_mirror_kernel, dim3((unsigned)std::min<int64_t>((n_pad - row0 + 3) / 4, 8192)), dim3(256), 0, s, ix.d_rows_, row0, n, n_pad,
-                       (int)ix.dim_, d_pad8, m.z8, m.step8, 1.f / m.step8, 1.f / u, ix.metric_, m.x8.as<signed char>(), m.acc0.as<int>(), m.scal8.as<float>());
+                       dim, d_pad8, m.mu8.as<float>(), m.step8, 1.f / m.step8, 1.f / u, ix.metric_, m.x8.as<signed char>(), m.acc0.as<int>(), m.scal8.as<float>());
     er = hipMemcpyAsync(m.h_scal8, m.scal8.p, 32, hipMemcpyDeviceToHost, s);
     if (er == hipSuccess) er = hipStreamSynchronize(s);
     if (er != hipSuccess) return ix.hip_fail(er, "8-bit mirror build");
@@ -591,7 +655,10 @@ static int32_t ensure_mirror8(Index& ix) {
     m.x8.release();
     m.acc0.release();
   }
-  if (!extend) m.i8_overflows = 0;
+  if (!extend) {
+    m.i8_overflows = 0;
+    m.i8_trusted = false;
+  }
   m.n8 = n;
   m.n_pad8 = n_pad;
   m.d_pad8 = d_pad8;
@@ -610,8 +677,8 @@ int32_t quant8_view(Index& ix, Quant8View* v) {
   v->x8 = m.x8.as<signed char>();
   v->acc0 = m.acc0.as<int>();
   v->scal8 = m.scal8.as<float>();
+  v->mu = m.mu8.as<float>();
   v->d_pad8 = m.d_pad8;
-  v->z = m.z8;
   v->step = m.step8;
   v->u = (ix.metric_ == 0 ? 2.f : 1.f) * m.step8 * m.step8;
   return EPS_OK;
@@ -619,7 +686,7 @@ int32_t quant8_view(Index& ix, Quant8View* v) {
 
 // nq queries on the mirror's grid: q8 [nq][d_pad8], qstat [nq][4] (device buffers of the caller)
 void quant8_queries(Index& ix, const Quant8View& v, const float* dq, int64_t nq, signed char* q8, float* qstat) {
-  hipLaunchKernelGGL(query_prep8_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, ix.stream_, dq, nq, nq, (int)ix.dim_, v.d_pad8, v.z, v.step,
+  hipLaunchKernelGGL(query_prep8_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, ix.stream_, dq, nq, nq, (int)ix.dim_, v.d_pad8, v.mu, v.step,
                      1.f / v.step, ix.metric_, q8, qstat);
 }
 
@@ -678,7 +745,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
       !m.cnt.reserve((size_t)(nq + 4) * 4 + 16) || !(i8 ? m.q8.reserve((size_t)b_pad * m.d_pad8) : m.qh.reserve((size_t)b_pad * m.d_pad * 2)))
     return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory (scratch)");
   if (i8)
-    hipLaunchKernelGGL(query_prep8_kernel, dim3((unsigned)((b_pad + 3) / 4)), dim3(256), 0, s, dq, nq, b_pad, (int)ix.dim_, m.d_pad8, m.z8, m.step8,
+    hipLaunchKernelGGL(query_prep8_kernel, dim3((unsigned)((b_pad + 3) / 4)), dim3(256), 0, s, dq, nq, b_pad, (int)ix.dim_, m.d_pad8, m.mu8.as<float>(), m.step8,
                        1.f / m.step8, ix.metric_, m.q8.as<signed char>(), m.qstat.as<float>());
   else
     hipLaunchKernelGGL(query_prep_kernel, dim3((unsigned)((b_pad + 3) / 4)), dim3(256), 0, s, dq, nq, b_pad, (int)ix.dim_,
@@ -861,7 +928,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   // fp32 rounding of the keys the threshold compares: |x|^2, |q|^2 and the re-ranked distance are each a 64-lane sum of
   // d_pad/64 sequential fmas per lane plus a 6-level shuffle tree, i.e. <= (d_pad/64 + 6) * 2^-24 relative to their
   // magnitude each; doubled for safety.  (A fixed 8e-6 was only enough up to d ~ 1000.)
-  const float rerank_slack = std::max(8e-6f, 2.f * (3.f * ((float)((ix.dim_ + 63) / 64 * 64) / 64.f + 6.f) + 2.f) * 5.9604645e-8f);
+  const float rerank_slack = std::max(8e-6f, 2.f * (3.f * ((float)((ix.dim_ + 63) / 64 * 64) / 64.f + 6.f) + 6.f) * 5.9604645e-8f);
   ra.slack = rerank_slack;
   const bool fused = !approx;   // exact mode: every re-rank also does its stage's counts and the next stage's thresholds
   if (seeded) {
@@ -918,6 +985,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
     }
   }
   bool first = true;
+  const bool probe = i8 && auto_bits && !approx && seeded && !m.i8_trusted && bounds.size() > 3 && !(getenv("EPS_MFMA_PROBE") && atoi(getenv("EPS_MFMA_PROBE")) == 0);
   for (size_t st = 0; st + 1 < bounds.size(); ++st) {
     const int64_t lo = bounds[st], hi = bounds[st + 1];
     {
@@ -965,6 +1033,24 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
       ra.fuse = 3;                                                            // this stage's counts + the next stage's thresholds
       ra.T_next = (st + 2 < bounds.size()) ? m.T.p : nullptr;
       launch_rerank(ra, s);
+      if (probe && st == 0) {
+        // The library's own choice of the 8-bit pass is PROBED once per mirror: every stage passes ~ k * c * ratio candidates per query
+        // (c = how many times more rows lie within the bound's margin of the threshold than below it), so the first, smallest stage
+        // predicts the others.  Where c is large - rows whose neighbours are close against the value range: low intrinsic dimension,
+        // tight clusters - the lists of the big stages would overflow and the batch would pay the 8-bit attempt AND the fp16 pass
+        // (r3: 10M x 768 manifold set 73 k -> 39 k q/s); here it pays one small stage and one sync, once.
+        struct { u32 overflow, pad; unsigned long long total; } hp = {0, 0, 0};
+        er = hipMemcpyAsync(&hp.overflow, overflow, 4, hipMemcpyDeviceToHost, s);
+        if (er == hipSuccess) er = hipMemcpyAsync(&hp.total, total, 8, hipMemcpyDeviceToHost, s);
+        if (er == hipSuccess) er = hipStreamSynchronize(s);
+        if (er != hipSuccess) return ix.hip_fail(er, "MFMA filter (probe)");
+        if (hp.overflow || hp.total > (unsigned long long)nq * (unsigned long long)cap / 6) {
+          m.i8_overflows = 3;   // declined for this mirror (re-attaching rows re-arms it; EPS_FLAT_MFMA_I8 still forces it)
+          ix.stats_.i8_declined += 1;
+          return flat_mfma_search_slice(ix, dq, nq, k, run_keys, approx, 1, 16, false);
+        }
+        m.i8_trusted = true;
+      }
     }
     first = false;
   }
@@ -1000,6 +1086,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
       // of a large batch - then the exact stream engine
       if (i8) {   // the looser 8-bit bound let too much through: fp16 pass
         m.i8_overflows += 1;
+        m.i8_trusted = false;
         return flat_mfma_search_slice(ix, dq, nq, k, run_keys, approx, 1, 16, false);
       }
       if (cap_scale == 1 && (size_t)nq * cap * 16 * 8 <= ((size_t)4 << 30)) return flat_mfma_search_slice(ix, dq, nq, k, run_keys, approx, 16, 16, false);

@@ -101,6 +101,35 @@ template <> struct V7Op<true> {
   static __device__ __forceinline__ scalar max16(const accv& v) { return max16i(v); }
 };
 
+// VGPR-form accumulators (r4).  An MFMA's C / D operands may live in arch VGPRs as well as in the accumulator file (one ACC_CD bit
+// for both), and its A / B operands may live in AGPRs.  v7 kept all 256 accumulators in AGPRs and the 128 fragment registers in
+// VGPRs - so the epilogue paid 256 v_accvgpr_read_b32 per tile (VALU cannot read AGPRs), half of its ~4.5 k cycles.  With
+// EPS_V7_VI = n the first n of the 8 row blocks (32 n accumulators... x JQ) are kept in arch VGPRs and the operand fragments move to
+// the accumulator file (the LDS / global loads that fill them are hand-issued asm already and can target AGPRs directly): the
+// epilogue's max / compare chains read those blocks in place.  The MFMAs become inline asm, which hipcc neither schedules nor pads:
+// every hazard is handled where it arises (see the kernel).
+#ifndef EPS_V7_VI
+#define EPS_V7_VI 0
+#endif
+#if EPS_V7_VI > 0
+#define EPS_FRAG_C "=a"
+template <bool I8> struct V7Asm;
+template <> struct V7Asm<true> {
+  template <class A, class F> static __device__ __forceinline__ void v(A& acc, const F& a, const F& b) { asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(acc) : "a"(a), "a"(b)); }
+  template <class A, class F> static __device__ __forceinline__ void a_(A& acc, const F& a, const F& b) { asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+a"(acc) : "a"(a), "a"(b)); }
+  template <class A, class F> static __device__ __forceinline__ void v2(A& d, const F& a, const F& b, const A& c) { asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %3" : "=&v"(d) : "a"(a), "a"(b), "v"(c)); }
+  template <class A, class F> static __device__ __forceinline__ void a2(A& d, const F& a, const F& b, const A& c) { asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %3" : "=&a"(d) : "a"(a), "a"(b), "a"(c)); }
+};
+template <> struct V7Asm<false> {
+  template <class A, class F> static __device__ __forceinline__ void v(A& acc, const F& a, const F& b) { asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(a), "a"(b)); }
+  template <class A, class F> static __device__ __forceinline__ void a_(A& acc, const F& a, const F& b) { asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "a"(a), "a"(b)); }
+  template <class A, class F> static __device__ __forceinline__ void v2(A& d, const F& a, const F& b, const A& c) { asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(d) : "a"(a), "a"(b), "v"(c)); }
+  template <class A, class F> static __device__ __forceinline__ void a2(A& d, const F& a, const F& b, const A& c) { asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&a"(d) : "a"(a), "a"(b), "a"(c)); }
+};
+#else
+#define EPS_FRAG_C "=v"
+#endif
+
 __device__ __forceinline__ int swz(int row, int chunk) { return (row << 3) + (chunk ^ ((row >> 1) & 7)); }  // 16-B granule index
 
 // ------------------------------------------------------------------------------------------------ v3 kernel
@@ -322,9 +351,9 @@ __global__ __launch_bounds__(512, 2) void mfma_filter_kernel_v3(FilterArgs a) {
 
 // hand-issued LDS fragment reads and global fragment loads (waited for by count; hipcc's own waitcnt insertion would
 // drain the queues at every use)
-#define EPS_DS_READ_B128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define EPS_DS_READ_B128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : EPS_FRAG_C(dst) : "v"(addr), "n"(off))
 #define EPS_GLOAD_B128(dst, voff, sbase, off) \
-  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(off))
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : EPS_FRAG_C(dst) : "v"(voff), "s"(sbase), "n"(off))
 
 // ------------------------------------------------------------------------------------------------ v7 kernel
 // (v5, the 8-wavefront predecessor of this kernel, lives in scripts/lab/lab_v5.hpp.)  Its operand transport - query
@@ -559,11 +588,21 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
         const _Float16* vsrc = nullptr;
         asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+#if EPS_V7_VI > 0
+        if (JQ == 2 && first && kk == 0) {   // D != C: the second block's accumulator is born from the first block's initial value
+          if (i < EPS_V7_VI) V7Asm<I8>::v2(acc[i][JQ - 1], fa[cur][i], fb[rb][kk][JQ - 1], acc[i][0]);
+          else V7Asm<I8>::a2(acc[i][JQ - 1], fa[cur][i], fb[rb][kk][JQ - 1], acc[i][0]);
+        } else {
+          if (i < EPS_V7_VI) V7Asm<I8>::v(acc[i][0], fa[cur][i], fb[rb][kk][0]);
+          else V7Asm<I8>::a_(acc[i][0], fa[cur][i], fb[rb][kk][0]);
+        }
+#else
         if (JQ == 2 && first && kk == 0) {   // D != C: the second block's accumulator is born from the first block's initial value
           acc[i][JQ - 1] = OP::mfma(fa[cur][i], fb[rb][kk][JQ - 1], acc[i][0]);
         } else {
           acc[i][0] = OP::mfma(fa[cur][i], fb[rb][kk][0], acc[i][0]);
         }
+#endif
         __builtin_amdgcn_sched_barrier(0);
         {
           switch (i) {
@@ -603,10 +642,22 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
           }
         }
         __builtin_amdgcn_sched_barrier(0);
+#if EPS_V7_VI > 0
+        if (JQ == 2) {
+          if (first && kk == 0) {
+            if (i < EPS_V7_VI) V7Asm<I8>::v(acc[i][0], fa[cur][i], fb[rb][kk][0]);
+            else V7Asm<I8>::a_(acc[i][0], fa[cur][i], fb[rb][kk][0]);
+          } else {
+            if (i < EPS_V7_VI) V7Asm<I8>::v(acc[i][JQ - 1], fa[cur][i], fb[rb][kk][JQ - 1]);
+            else V7Asm<I8>::a_(acc[i][JQ - 1], fa[cur][i], fb[rb][kk][JQ - 1]);
+          }
+        }
+#else
         if (JQ == 2) {
           if (first && kk == 0) acc[i][0] = OP::mfma(fa[cur][i], fb[rb][kk][0], acc[i][0]);
           else acc[i][JQ - 1] = OP::mfma(fa[cur][i], fb[rb][kk][JQ - 1], acc[i][JQ - 1]);
         }
+#endif
         __builtin_amdgcn_sched_barrier(0);
         // (all loads of the loop stay in straight-line code: around a branch hipcc gives an asm load's destination a fresh
         // register and copies it - possibly before the data has landed; r2 tried to stagger the wavefronts' DMA issue that way)
@@ -707,6 +758,11 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
       step(std::integral_constant<int, 0>{}, std::false_type{});
       step(std::integral_constant<int, 1>{}, std::false_type{});
     }
+#if EPS_V7_VI > 0
+    // the asm MFMAs' results are read by VALU code below (max / compare on the VGPR blocks, v_accvgpr_read on the others): hipcc pads
+    // nothing after an asm statement, an 8-pass MFMA's D needs 11 wait states before a VALU reader, a 16-pass one 19
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+#endif
 #ifdef EPS_V7_PROF
     const unsigned long long pf_t2 = __builtin_readcyclecounter();
 #endif

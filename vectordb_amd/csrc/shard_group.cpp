@@ -265,6 +265,7 @@ class ShardGroup : public IndexBase {
       t.main_kernel_rows += s.main_kernel_rows;
       t.main_kernel_queries = std::max(t.main_kernel_queries, s.main_kernel_queries);
       t.main_kernel_bits = std::max(t.main_kernel_bits, s.main_kernel_bits);
+      t.i8_declined += s.i8_declined;
     }
     *out = t;
     return EPS_OK;

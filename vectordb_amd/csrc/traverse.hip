@@ -358,7 +358,7 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
   {   // fp32 rounding of the distances step d compares with the bound: G lanes x (d / G) sequential fmas + a log2(G)-level tree
     const int G = group_lanes(ix.dim_, vec4);
     const float terms = (float)((ix.dim_ + G - 1) / G) + 6.f;
-    a.slack8 = std::max(8e-6f, 2.f * (3.f * terms + 2.f) * 5.9604645e-8f);
+    a.slack8 = std::max(8e-6f, 2.f * (3.f * terms + 6.f) * 5.9604645e-8f);
   }
 
   // brute-force tail over the rows the graph does not cover yet (:885-900)
