@@ -2,7 +2,9 @@
 """Headline benchmark: QPS at recall@10 >= 0.999 on 10M x 768 L2, k=10, batch=1024 (BASELINE.json configs[2]),
 synthetic i.i.d. U[0,1) fp32 rows generated on the device, inputs resident in HBM when the timed region starts.
 
-    python bench.py [--gpus N --steps K --warmup W]       (N > 1 is launched by torch.distributed.run)
+    python bench.py [--gpus N --steps K --warmup W]       (N > 1: under torch.distributed.run one rank per GPU, as the driver launches it;
+                                                            started plain, bench.py launches the N ranks itself; --inproc: one process,
+                                                            eps_index_create_sharded over N devices)
 
 One "step" = one batch of queries through the hot path (eps_index_search: flat scan or graph traversal -> top-k).
 With N > 1 the corpus is hash-sharded by row index (row i lives on rank i mod N), every rank answers the same query
@@ -28,17 +30,28 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# HBM bytes per launch of the dominant kernel from the PMC counters under profiles/ (separate --pmc passes, corrected as
-# MI355X_MICROARCH.md prescribes: gfx950 FETCH_SIZE counts 128-B requests at 64 B -> x2; FETCH_SIZE/WRITE_SIZE in KiB):
-#   mfma: profiles/r2_pmc_10Mx768_b1024.csv, mean of the four 9,262,720-row launches of mfma_filter_kernel_v7<2, FM_IDS>:
-#         (2 * 7340245 + 7460) KiB = 15.04e9 bytes vs 14.23e9 algorithmic bytes of the fp16 mirror (1.06 x; r1: 14.43e9).
-#   graph: profiles/r3_traverse_10Mx768_pmc.csv, traverse2_kernel T=4 L=500 batch 1024 on the 10M-node device-built graph, 8-bit
-#         prefilter on: (2 * 22850910 + 2205166) KiB = 49.1e9 bytes vs 44.6e9 algorithmic (1.10 x; the x2 calibrated in the same
-#         run on flat_scan_kernel, whose FETCH_SIZE x 2 = rows * dim * 4 exactly; the writes are the visited-set atomics).
-#         r2, every evaluation on its fp32 row (profiles/r2_traverse_10Mx768_pmc.csv): 2 * 48440196 KiB = 99.2e9 vs 100.97e9.
-#   mfma8: profiles/r3_pmc_10Mx768_b1024.csv, the 7,280,256-row launch (the last of the 6 stages) of mfma_filter_kernel_v7<2, FM_IDS, int8>:
-#         (2 * 2755587 + 8791) KiB = 5.65e9 bytes vs 5.59e9 algorithmic bytes of the 8-bit mirror (1.01 x).
-TRAFFIC = {"mfma": (2 * 7340245 + 7460) * 1024.0, "mfma8": (2 * 2755587 + 8791) * 1024.0, "graph_T4_L500": (2 * 22850910 + 2205166) * 1024.0}
+# HBM traffic of the dominant kernel is a PMC measurement (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, corrected as
+# MI355X_MICROARCH.md prescribes: gfx950 FETCH_SIZE counts 128-B requests at 64 B -> x2; KiB units) and cannot be taken inside this
+# run: `roofline.traffic` is null here and `roofline.traffic_reference` names the committed profile of the same launch shape (file,
+# sha256 of the file as it lies in this tree, the bytes it shows, and which round's kernel it was taken on).
+TRAFFIC_REF = {
+    "mfma8": {"file": "profiles/r3_pmc_10Mx768_b1024.csv", "bytes_per_launch": (2 * 2755587 + 8791) * 1024.0, "algorithmic_bytes": 7280256 * 768.0,
+              "launch": "mfma_filter_kernel_v7<2, FM_IDS, int8>, 7,280,256 rows x 1024 queries (last of 6 stages)", "taken_on": "r3 kernel (same operand stream)"},
+    "mfma": {"file": "profiles/r2_pmc_10Mx768_b1024.csv", "bytes_per_launch": (2 * 7340245 + 7460) * 1024.0, "algorithmic_bytes": 9262720 * 1536.0,
+             "launch": "mfma_filter_kernel_v7<2, FM_IDS> (fp16), 9,262,720 rows x 1024 queries", "taken_on": "r2 kernel"},
+    "graph_T4_L500": {"file": "profiles/r3_traverse_10Mx768_pmc.csv", "bytes_per_launch": (2 * 22850910 + 2205166) * 1024.0, "algorithmic_bytes": 44.6e9,
+                      "launch": "traverse2_kernel T=4 L=500 batch 1024, 10M-node device-built graph, 8-bit prefilter on", "taken_on": "r3 kernel"},
+}
+
+
+def traffic_ref(key):
+    import hashlib
+    r = dict(TRAFFIC_REF[key])
+    path = os.path.join(ROOT, r["file"])
+    r["sha256"] = hashlib.sha256(open(path, "rb").read()).hexdigest() if os.path.exists(path) else None
+    return r
+
+
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F16_PEAK_TF = 2500.0  # dense bf16/f16 MFMA peak (nominal, 2.4 GHz)
 MFMA_F16_SUSTAINED_TF = 1814.0  # measured: v_mfma_f32_32x32x16_f16 alone, operands toggling like data, 1.82 GHz (scripts/lab/mfma_peak.hip)
@@ -70,8 +83,11 @@ def parse():
     ap.add_argument("--graph-rows", type=int, default=1_000_000, help="rows of the secondary traversal measurement (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline legs (0 = skip)")
     ap.add_argument("--scale", default="rows", choices=["queries", "rows"])
-    ap.add_argument("--configs", default="c2,c4", help="further BASELINE configs measured into the line's `configs` object at N = 1: c2 (1M x 768, batch 1, latency), "
-                                                     "c4 (COSINE + ID < N filter on the --rows table, batch --batch); 'none' skips them")
+    ap.add_argument("--inproc", action="store_true", help="N > 1 in ONE process: eps_index_create_sharded over devices 0..N-1 (the form the single-process "
+                                                          "reference DBMS uses), per-shard lists merged on the caller's device; no torch.distributed")
+    ap.add_argument("--configs", default="c2,c4,secondary", help="further BASELINE configs measured into the line's `configs` object at N = 1: c2 (1M x 768, batch 1, latency), "
+                                                     "c4 (COSINE + ID < N filter on the --rows table, batch --batch), secondary (SURVEY 8d clustered set + the manifold set at --graph-rows: "
+                                                     "flat and graph legs); 'none' skips them")
     return ap.parse_args()
 
 
@@ -139,8 +155,9 @@ class CpuBaseline:
     def load(self, X):
         t0 = time.time()
         step = 1 << 19
-        for s in range(0, self.n, step):
-            e = min(self.n, s + step)
+        rows = min(self.n, X.shape[0])   # (a smaller table overwrites the head of the buffer: the legs that follow scan only those rows)
+        for s in range(0, rows, step):
+            e = min(rows, s + step)
             self.arr[s:e] = X[s:e].cpu().numpy()
         return time.time() - t0
 
@@ -363,14 +380,180 @@ def config_c4(amd, torch, args, X, qlast, dev, stream, local_rank, cpu):
     return out
 
 
+def config_secondary(amd, torch, args, dev, stream, local_rank, cpu, kind):
+    """The sets the BASELINE recipe is NOT ("additionally report one clustered synthetic set clearly labelled as secondary"):
+    `clustered` = 1000 Gaussian clusters (centres U[0,1)^d, sigma 0.1), `manifold` = a 16-dimensional uniform latent embedded linearly in d
+    dimensions + 1 % noise (what learned embeddings look like; tertiary).  --graph-rows rows, batch --batch: the exact flat scan (which
+    operand width the library chose, whether it probed the 8-bit pass and declined it) and the traversal on a device-built NSG at the
+    reference's T = 4 for two queue sizes, beside the reference's own SearchImpl on the same graph.  Shows where each path wins."""
+    n1, d, k, b = args.graph_rows, args.dim, args.k, args.batch
+    gc = torch.Generator(device=dev).manual_seed(41)
+    centres = torch.rand((1000, d), generator=gc, device=dev) if kind == "clustered" else 0.25 * torch.randn((16, d), generator=gc, device=dev)
+    X1 = gen_rows(torch, n1, d, 142, dev, kind, centres)
+    Q1 = gen_rows(torch, b, d, 143, dev, kind, centres)
+    out = {"workload": "%d x %d L2, k=%d, batch=%d, synthetic %s set (NOT the BASELINE recipe)" % (n1, d, k, b, kind)}
+    ix = amd.GpuIndex(d, "EUCLIDEAN", device=local_rank)
+    ix.set_stream(stream)
+    ix.attach_rows(X1)
+    o = (torch.empty((b, k), dtype=torch.int64, device=dev), torch.empty((b, k), dtype=torch.float32, device=dev), torch.empty((b,), dtype=torch.int32, device=dev))
+    nrec = min(256, b)
+    g = (torch.empty((nrec, k), dtype=torch.int64, device=dev), torch.empty((nrec, k), dtype=torch.float32, device=dev), torch.empty((nrec,), dtype=torch.int32, device=dev))
+    ix.search(Q1[:nrec], k, out=g, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
+    ix.synchronize()
+    gt = g[0].cpu().numpy().copy()
+
+    def timed(index, reps=3, **kw):
+        index.search(Q1, k, out=o, **kw)
+        index.synchronize()
+        first = index.stats()
+        index.search(Q1, k, out=o, **kw)
+        index.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            index.search(Q1, k, out=o, **kw)
+        index.synchronize()
+        return (time.perf_counter() - t0) / reps, index.stats(), first
+    sec, st, first = timed(ix, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_AUTO)
+    flat_ids = o[0].cpu().numpy().copy()
+    out["flat"] = {"qps": b / sec, "ms_per_step": 1e3 * sec, "recall_at_10": recall_of(flat_ids[:nrec], gt), "recall_check": "%d queries vs the fp32 stream engine" % nrec,
+                   "operand_bits": int(st.get("main_kernel_bits", 0)), "rerank_rows_per_query": st["rerank_rows"] / float(b), "overflow_queries": int(st["overflow_queries"]),
+                   "first_call_probed_and_declined_the_8bit_pass": bool(first.get("i8_declined", 0))}
+    t0 = time.perf_counter()
+    ix.build(n1)
+    ix.synchronize()
+    out["graph_build_s"] = time.perf_counter() - t0
+    gn_, ge_, _ = ix.graph_info()
+    out["graph"] = {}
+    for L in (100, 500):
+        sec, st, _ = timed(ix, mode=amd.MODE_GRAPH, intra_threads=4, master_queue=L, local_queue=L)
+        out["graph"]["T4_L%d" % L] = {"qps": b / sec, "ms_per_step": 1e3 * sec, "recall_at_10": recall_of(o[0].cpu().numpy(), flat_ids),
+                                      "evals_per_query": st["dist_evals"] / float(b), "fp32_rows_per_query": st["rerank_rows"] / float(b)}
+    out["graph"]["avg_degree"] = ge_ / float(gn_)
+    if cpu is not None and cpu.ref is not None:
+        try:
+            cpu.load(X1)
+            Qh = Q1.cpu().numpy()
+            off, nbr, nav = ix.get_graph()
+            legs = [cpu.bruteforce(Qh[:8], k, flat_ids, 2.0, rows=n1)]
+            for L in (100, 500):
+                legs.append(cpu.graph((off, nbr, nav, n1, flat_ids), Qh, k, L, 2.0))
+            out["cpu_reference"] = {"cores": cpu.threads, "legs": legs}
+        except Exception as e:
+            out["cpu_reference"] = {"failed": repr(e)}
+    ix.close()
+    del X1
+    return out
+
+
+def main_inproc(args):
+    """--inproc: the OTHER multi-GPU form of SURVEY 8e - one process, eps_index_create_sharded over devices 0..N-1 (what the
+    single-process reference DBMS would hold): every shard's rows generated on its own device and handed over in place
+    (eps_index_attach_shard_rows), queries and results on device 0, per-shard lists pushed peer to peer and merged there.  Same
+    workload and JSON contract as the one-process-per-GPU form; no torch.distributed, no RCCL."""
+    import torch
+    import vectordb_amd as amd
+    from vectordb_amd.build import build
+    build()
+    G = args.gpus
+    ndev = torch.cuda.device_count()
+    backend_note = ""
+    if ndev < G:
+        if os.environ.get("EPS_BENCH_BACKEND", "nccl") == "nccl":
+            raise SystemExit("bench.py --inproc --gpus %d: only %d device(s) visible" % (G, ndev))
+        backend_note = " (EPS_BENCH_BACKEND != nccl: %d shards on %d device(s) - plumbing check, not a measurement)" % (G, ndev)
+    devices = [s % max(1, ndev) for s in range(G)]
+    n, d, b, k = args.rows, args.dim, args.batch, args.k
+    if args.scale == "queries":
+        n, b = args.rows // G, args.batch * G
+    grp = amd.GpuIndex(d, args.metric, devices=devices)
+    parts = []
+    for s in range(G):
+        dev = torch.device("cuda", devices[s])
+        torch.cuda.set_device(dev)
+        parts.append(gen_rows(torch, n, d, 42 + s, dev, "uniform"))
+        torch.cuda.synchronize(dev)
+        grp.attach_shard_rows(s, parts[-1])
+    dev0 = torch.device("cuda", devices[0])
+    torch.cuda.set_device(dev0)
+    gq = torch.Generator(device=dev0).manual_seed(43)
+    queries = [torch.rand((b, d), generator=gq, device=dev0, dtype=torch.float32) for _ in range(args.steps + args.warmup)]
+    ids = torch.empty((b, k), dtype=torch.int64, device=dev0)
+    dd = torch.empty((b, k), dtype=torch.float32, device=dev0)
+    cnt = torch.empty((b,), dtype=torch.int32, device=dev0)
+    torch.cuda.synchronize()
+    engine = {"auto": amd.FLAT_AUTO, "stream": amd.FLAT_STREAM, "mfma": amd.FLAT_MFMA, "mfma8": amd.FLAT_MFMA_I8}[args.engine]
+    skw = dict(mode=amd.MODE_FLAT, flat_engine=engine)
+    for w in range(args.warmup):
+        grp.search(queries[w], k, out=(ids, dd, cnt), **skw)
+    grp.synchronize()
+    t0 = time.perf_counter()
+    for s_ in range(args.steps):
+        grp.search(queries[args.warmup + s_], k, out=(ids, dd, cnt), **skw)
+    grp.synchronize()
+    elapsed = time.perf_counter() - t0
+    st = grp.stats()
+    main_ms = grp.kernel_times(64)[-args.steps:]
+    got = ids.cpu().numpy().copy()
+    nrec = min(args.recall_queries, b)
+    g = (torch.empty((nrec, k), dtype=torch.int64, device=dev0), torch.empty((nrec, k), dtype=torch.float32, device=dev0), torch.empty((nrec,), dtype=torch.int32, device=dev0))
+    torch.cuda.synchronize()
+    grp.search(queries[-1][:nrec], k, out=g, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
+    grp.synchronize()
+    recall = recall_of(got[:nrec], g[0].cpu().numpy())
+    qps = b * args.steps / elapsed
+    kernel_ms = float(np.mean(main_ms)) if main_ms else 0.0
+    bits = int(st.get("main_kernel_bits", 0))
+    # st sums the shards' counters: rows of the timed launch over ALL shards, time = the slowest shard
+    flops = 2.0 * float(st.get("main_kernel_queries", b) or b) * float(st["main_kernel_rows"]) * d
+    peak = (MFMA_I8_PEAK_TOPS if bits == 8 else MFMA_F16_PEAK_TF) * G
+    roof = {"bound": "mfma", "kernel": "mfma_filter_kernel_v7<%s>, largest stage, summed over the %d shards (time = the slowest shard)" % ("int8" if bits == 8 else "fp16", G),
+            "achieved": flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms else None, "peak": peak, "unit": "TOP/s" if bits == 8 else "TFLOP/s", "traffic": None,
+            "kernel_ms_per_launch": kernel_ms}
+    roof["frac"] = roof["achieved"] / peak if roof["achieved"] else None
+    print(json.dumps({
+        "metric": "QPS @ recall@10>=0.999, 10Mx768 L2", "value": qps, "unit": "queries/s", "n_gpus": G, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 (exact fp32 distances; %d-bit matrix pass as a lower-bound filter, survivors re-ranked in fp32)" % bits, "data": "synthetic",
+        "recall_at_10": recall, "recall_check": {"queries": nrec, "ground_truth": "exact fp32 stream scan through the same shard group"},
+        "config": {"workload": "%dM x %d L2 exact flat scan, k=%d, batch=%d per step, %d rows per GPU, %d GPU(s), rows_total=%d, ONE process: eps_index_create_sharded%s"
+                               % ((n * G) // 1_000_000, d, k, b, n, G, n * G, backend_note),
+                   "mode": "flat", "engine": args.engine, "parallelism": "in-process shard group x%d: row-hash shards, peer-to-peer push of packed top-k, merge on device 0" % G},
+        "roofline": roof, "stats": {"rerank_rows_per_query": st["rerank_rows"] / float(b), "overflow_queries": st["overflow_queries"]},
+        "work_rate": {"value": qps * n * G, "unit": "query*rows/s"}}))
+    grp.close()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher around it: re-exec under torch.distributed.run, one rank per GPU (the same
+    line the driver uses), and pass its exit code on.  Never silently measures fewer GPUs than asked for."""
+    import socket
+    import subprocess
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and not args.inproc and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+    if args.inproc:
+        return main_inproc(args)
     import torch
     import torch.distributed as dist
     import vectordb_amd as amd
     from vectordb_amd.build import build
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d (or let bench.py launch the ranks itself: "
+                         "unset WORLD_SIZE)" % (args.gpus, world, args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # EPS_BENCH_BACKEND=gloo lets the N > 1 path be exercised with several ranks on ONE GPU (exchange staged through the
@@ -574,7 +757,8 @@ def main():
                                               "seeds and for neighbours the 8-bit bound cannot rule out; E, X and the fp32 reads counted by the kernel)",
                     "fp32_rows_per_query": st["rerank_rows"] / float(b),
                     "achieved": alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "traffic": TRAFFIC.get("graph_T4_L500") if (n == 10_000_000 and b == 1024 and d == 768 and args.T == 4 and args.L == 500 and args.data == "uniform" and st["rerank_rows"] > 0) else None}
+                    "traffic": None,
+                    "traffic_reference": traffic_ref("graph_T4_L500") if (n == 10_000_000 and b == 1024 and d == 768 and args.T == 4 and args.L == 500 and args.data == "uniform" and st["rerank_rows"] > 0) else None}
         elif used_mfma:
             # algorithmic flops of the timed launch: 2 * batch * rows * d, on the fp16 dense MFMA roof
             flops = 2.0 * kq * krows * d   # queries x rows of the timed launch (batches > 2048 run in slices)
@@ -582,10 +766,17 @@ def main():
             roof = {"bound": "mfma", "kernel": "mfma_filter_kernel_v7<%s> (largest of the filter stages: %d of %d rows x %d of %d queries)" % ("int8" if bits == 8 else "fp16", krows, n, kq, b),
                     "achieved": flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms else None,
                     "peak": MFMA_I8_PEAK_TOPS if bits == 8 else MFMA_F16_PEAK_TF, "unit": "TOP/s" if bits == 8 else "TFLOP/s", "operand_bits": bits,
-                    # PMC bytes of exactly this launch shape (separate --pmc passes of the same command, profiles/), else null
-                    "traffic": (TRAFFIC.get("mfma") if (bits == 16 and krows == 9262720) else TRAFFIC.get("mfma8") if (bits == 8 and krows == 7280256) else None)
-                               if (n == 10_000_000 and b == 1024 and d == 768 and kq == 1024) else None,
+                    # PMC bytes are not measurable inside this run: null, and the committed profile of exactly this launch shape beside it
+                    "traffic": None,
+                    "traffic_reference": (traffic_ref("mfma") if (bits == 16 and krows == 9262720) else traffic_ref("mfma8") if (bits == 8 and krows == 7280256) else None)
+                                         if (n == 10_000_000 and b == 1024 and d == 768 and kq == 1024) else None,
                     "algorithmic_bytes": krows * ((d + 255) // 256 * 256 if bits == 8 else (d + 63) // 64 * 64 * 2)}
+            # the same kernel runs once per filter stage: all stage launches of the LAST timed step (hipEvent pairs around each)
+            if st.get("filter_ms_all", 0) > 0 and st.get("filter_rows_all", 0) > 0:
+                fl_all = 2.0 * kq * float(st["filter_rows_all"]) * d
+                roof["all_stage_launches"] = {"kernel_ms": st["filter_ms_all"], "rows": int(st["filter_rows_all"]),
+                                              "achieved": fl_all / (st["filter_ms_all"] * 1e-3) / 1e12, "frac": fl_all / (st["filter_ms_all"] * 1e-3) / 1e12 / roof["peak"],
+                                              "what": "every mfma_filter_kernel_v7 stage launch of the last timed step (seed pass excluded), same peak"}
         else:
             # a flat scan needs rows*4*d bytes ONCE per batch; the stream engine re-reads the store once
             # per group of 4 queries, which this figure deliberately does not credit.
@@ -593,6 +784,9 @@ def main():
             roof = {"bound": "hbm", "kernel": "flat_scan_kernel", "achieved": alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms else None,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
         roof["frac"] = (roof["achieved"] / roof["peak"]) if roof["achieved"] else None
+        if used_mfma and args.mode == "flat":
+            # whole step against the same roof: the step's algorithmic work (2 * batch * rows * d) over ms_per_step - re-ranks, seeds, launches included
+            roof["whole_step_frac"] = 2.0 * b * n * d / (elapsed / args.steps) / 1e12 / roof["peak"]
         if used_mfma and args.mode == "flat" and roof["achieved"]:
             sus = MFMA_I8_SUSTAINED_TOPS if roof.get("operand_bits") == 8 else MFMA_F16_SUSTAINED_TF
             roof["sustained_peak_measured"] = sus
@@ -653,6 +847,12 @@ def main():
                     res["configs"]["c4_cosine_id_filter_b1024"] = config_c4(amd, torch, args, X, qlast, dev, stream, local_rank, cpu)
                 except Exception as e:
                     res["configs"]["c4_cosine_id_filter_b1024"] = {"failed": repr(e)}
+            if "secondary" in want and args.graph_rows and args.graph_rows <= n:
+                for kind in ("clustered", "manifold"):   # (last: the CPU legs overwrite the head of the host copy of the table)
+                    try:
+                        res["configs"]["secondary_%s_%dx%d" % (kind, args.graph_rows, d)] = config_secondary(amd, torch, args, dev, stream, local_rank, cpu, kind)
+                    except Exception as e:
+                        res["configs"]["secondary_%s_%dx%d" % (kind, args.graph_rows, d)] = {"failed": repr(e)}
         if cpu is not None:
             cpu.close()
         print(json.dumps(res))

@@ -162,6 +162,8 @@ typedef struct eps_search_stats {
   int64_t main_kernel_rows; /* rows covered by the launch timed in main_kernel_ms              */
   int64_t main_kernel_queries; /* queries covered by that launch (large batches run in slices)  */
   int64_t main_kernel_bits; /* operand width of that launch: 32 (fp32 stream / traversal), 16 or 8 (matrix engine) */
+  double filter_ms_all;     /* device time of ALL filter-stage launches of the call (the dominant kernel runs once per stage; r4) */
+  int64_t filter_rows_all;  /* rows those launches covered, summed (x main_kernel_queries = the call's matrix work)              */
   int64_t i8_declined;      /* 1: this call probed the 8-bit pass on this table, found its bound too loose for the data and ran the fp16 pass (r4) */
 } eps_search_stats;
 
@@ -171,10 +173,14 @@ void eps_default_build_params(eps_build_params* p);
 int32_t eps_index_create(int64_t dim, int32_t metric, int32_t device, eps_index** out);
 /* Hash-sharded index over `shards` GPUs of THIS process: row i of the table lives on shard i mod shards (device
  * devices[i mod shards]) as local row i / shards; every shard answers the whole batch on its rows, the per-shard top-k lists
- * are pushed to devices[0] peer to peer (xGMI) and merged there.  The handle works with every eps_index_* entry point below;
- * rows, queries, bitsets, filter columns and results are HOST buffers (each shard reads its rows with one strided copy);
- * eps_index_build builds one graph per shard, eps_index_save/load_graph use <path>.shard<s> files; eps_index_set_graph (one
- * graph over the whole table), device pointers, eps_index_set_stream and eps_index_search_walk are not available.
+ * are pushed peer to peer (xGMI) to the device that holds the caller's result buffers (devices[0] for host results) and merged
+ * there.  The handle works with every eps_index_* entry point below.  Rows: a HOST table (eps_index_attach_rows: each shard reads
+ * its rows with one strided copy) or, shard by shard, rows that already live on the shard's device (eps_index_attach_shard_rows).
+ * Queries and results: host buffers, or (r4) device buffers on any device of the group - a shard on another device gets the
+ * queries with one peer copy, the merge writes straight into the caller's ids / dist / counts (which must live together), and as
+ * with a plain index the caller synchronises (eps_index_synchronize).  Bitsets, filter columns and attribute rows are host
+ * buffers.  eps_index_build builds one graph per shard, eps_index_save/load_graph use <path>.shard<s> files; eps_index_set_graph
+ * (one graph over the whole table), eps_index_set_stream and eps_index_search_walk are not available.
  * devices may repeat an ordinal (several shards on one GPU). */
 int32_t eps_index_create_sharded(int64_t dim, int32_t metric, const int32_t* devices, int32_t shards, eps_index** out);
 int32_t eps_index_destroy(eps_index* h);
@@ -192,6 +198,11 @@ int32_t eps_index_synchronize(eps_index* h);
 int32_t eps_index_attach_rows(eps_index* h, const float* rows, int64_t n);
 /* rows beyond the current count (the un-indexed tail, :885-900); only for host-attached (owned) stores */
 int32_t eps_index_append_rows(eps_index* h, const float* rows, int64_t n_new);
+/* rows of ONE shard of a hash-sharded index: local row l is global row l * shards + shard; host memory (copied) or memory of the
+ * shard's own device (borrowed).  Once every shard holds its rows the table has sum(n_local) rows; the counts must be the hash
+ * split of that sum (shard s holds ceil((n - s) / shards) rows) or searches and builds fail with EPS_USER_ERROR.  On a plain index
+ * shard 0 is the index itself.  (r4; replaces what TableSegmentMVP::vector_tables_ is for one GPU, table_segment_mvp.hpp:85) */
+int32_t eps_index_attach_shard_rows(eps_index* h, int32_t shard, const float* rows, int64_t n_local);
 int64_t eps_index_row_count(const eps_index* h);
 
 /* On-disk table segment of the reference (`<db>/<table_id>/data_mvp.bin`, TableSegmentMVP::SaveTableSegment,

@@ -68,3 +68,43 @@ def test_bench_eight_ranks_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 8 and d["scaling"] == "weak" and "rows_total=640000" in d["config"]["workload"]
     assert d["recall_at_10"] == 1.0 and d["recall_check"]["ground_truth_vs_torch_fp32_scan"] == 1.0
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    """`--gpus N` is what the line reports as n_gpus: under a launcher that started a different number of ranks bench.py stops
+    instead of measuring fewer GPUs than asked for (r3's flag was parsed and never read).  CPU-only: fails before any device call."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                       timeout=600, cwd=ROOT, env=env)
+    assert r.returncode != 0 and "--gpus 2 but WORLD_SIZE=1" in (r.stderr + r.stdout), (r.returncode, r.stderr[-500:])
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks_when_started_plain():
+    """`python bench.py --gpus 2` with no launcher around it (the form the driver used for N = 1): bench.py re-executes itself under
+    torch.distributed.run with two ranks; gloo here, both on this box's one GPU."""
+    env = {k_: v for k_, v in os.environ.items() if k_ not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(EPS_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rows", "120000", "--batch", "64",
+                        "--cpu-seconds", "0"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and "rows_total=240000" in d["config"]["workload"] and d["recall_at_10"] == 1.0
+
+
+@pytest.mark.gpu
+def test_bench_inproc_shard_group():
+    """--inproc: the one-process form of SURVEY 8e (eps_index_create_sharded, rows attached per shard on the shard's device, queries
+    and results in device memory, merge on device 0) under the same JSON contract; two shards on this box's one GPU."""
+    env = dict(os.environ, EPS_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--inproc", "--steps", "2", "--warmup", "1", "--rows", "120000",
+                        "--batch", "64"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and "rows_total=240000" in d["config"]["workload"] and d["recall_at_10"] == 1.0
+    for key in ("metric", "value", "unit", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key

@@ -317,6 +317,35 @@ def test_device_knn_lists_against_the_oracles_exact_knn(amd, oracle):
     assert (got >= 0).all() and not (got == np.arange(n)[:, None]).any()
 
 
+def test_device_knn_lists_at_d_768(amd):
+    """a16 at the headline's dimension: the approximate path of the kNN stage - 8-bit keys select 128 rows per
+    block of 2048 queries WITHOUT the bound's margin, fp32 re-rank to 100 - on 200 000 x 768 uniform rows, where the 8-bit key noise
+    relative to the neighbour spacing is what it is at 10M x 768 (the spacing shrinks with n, so this size is the easier end:
+    profiles/ hold the 10M build's own recall).  300 sampled rows against exact fp64 kNN (torch, on the device): list recall >= 0.999,
+    the first neighbour right in >= 99.5 %."""
+    import torch
+    n, d, K = 200_000, 768, 100
+    g = torch.Generator(device="cuda").manual_seed(79)
+    Xd = torch.rand((n, d), generator=g, device="cuda", dtype=torch.float32)
+    torch.cuda.synchronize()
+    ix = amd.GpuIndex(d, 0)
+    ix.attach_rows(Xd)
+    got = ix.knn_graph()
+    ix.close()
+    assert got.shape == (n, K) and (got >= 0).all() and not (got[::97] == np.arange(n)[::97, None]).any()
+    sample = np.random.default_rng(2).choice(n, 300, replace=False)
+    X64 = Xd.double()
+    want = []
+    for v in sample:
+        dd = ((X64 - X64[int(v)]) ** 2).sum(1)
+        dd[int(v)] = float("inf")
+        want.append(torch.argsort(dd, stable=True)[:K].cpu().numpy())
+    want = np.stack(want)
+    rec = recall_at_k(got[sample], want)
+    first = np.mean(got[sample, 0] == want[:, 0])
+    assert rec >= 0.999 and first >= 0.995, (rec, first)
+
+
 @pytest.mark.parametrize("prefilter", ["0", "1"])
 @pytest.mark.parametrize("n,d", [(3000, 16), (12000, 32)])
 def test_device_link_stage_against_the_oracle_on_an_identical_knn_graph(amd, oracle, monkeypatch, n, d, prefilter):

@@ -2,6 +2,8 @@
 integer thresholds, exact fp32 re-rank).  The contract is the fp16 engine's: the SAME exact answer as the fp32 stream scan
 (`BruteForceSearch`, reference engine/db/execution/vec_search_executor.cpp:717-768), bit for bit, for any data - the filter's
 bound is computed from the residuals of the stored bytes, so coarse operands may only cost re-ranked rows, never results."""
+import os
+
 import numpy as np
 import pytest
 
@@ -99,9 +101,11 @@ def test_i8_engine_on_other_distributions(amd, kind):
 
 
 def test_auto_stops_paying_for_an_8_bit_pass_that_never_filters(amd):
-    """One huge outlier stretches the grid 100 x: every batch's 8-bit lists overflow and the fp16 pass answers.  After three such
-    batches in a row EPS_FLAT_AUTO goes to the fp16 pass directly (no overflow any more); an explicit EPS_FLAT_MFMA_I8 request
-    still runs the 8-bit pass; every answer is the stream scan's."""
+    """One huge outlier stretches the grid 100 x: the 8-bit bound cannot filter this table.  r4: the library's own choice PROBES the
+    8-bit pass on the first batch it sends through a mirror - the candidate count of the first, smallest stage predicts the others -
+    finds it too loose and answers with the fp16 pass at once (r3 paid three whole overflowing 8-bit attempts first); later batches
+    go to the fp16 pass directly; an explicit EPS_FLAT_MFMA_I8 request still runs the 8-bit pass (and overflows into the fp16 pass);
+    every answer is the stream scan's.  EPS_MFMA_PROBE=0 restores the r3 behaviour (three overflows, then fp16)."""
     rng = np.random.default_rng(6)
     n, d, nq = 90_000, 256, 96
     X = rng.random((n, d), dtype=np.float32)
@@ -111,13 +115,44 @@ def test_auto_stops_paying_for_an_8_bit_pass_that_never_filters(amd):
     ix.attach_rows(X)
     ref = ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
     seen = []
-    for it in range(5):
+    for it in range(4):
         same(ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_AUTO), ref, "auto %d" % it)
         st = ix.stats()
-        seen.append((st["overflow_queries"] > 0, st["main_kernel_bits"]))
-    assert all(o for o, b in seen[:3]) and seen[3] == (False, 16) and seen[4] == (False, 16), seen
+        seen.append((st["overflow_queries"] > 0, st["main_kernel_bits"], st["i8_declined"]))
+    assert seen[0] == (False, 16, 1) and all(s == (False, 16, 0) for s in seen[1:]), seen
     same(ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8), ref, "explicit int8")
     assert ix.stats()["overflow_queries"] > 0
+    ix.close()
+    os.environ["EPS_MFMA_PROBE"] = "0"
+    try:
+        ix = amd.GpuIndex(d, 0)
+        ix.attach_rows(X)
+        seen = []
+        for it in range(5):
+            same(ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_AUTO), ref, "auto, no probe %d" % it)
+            st = ix.stats()
+            seen.append((st["overflow_queries"] > 0, st["main_kernel_bits"]))
+        assert all(o for o, b in seen[:3]) and seen[3] == (False, 16) and seen[4] == (False, 16), seen
+        ix.close()
+    finally:
+        del os.environ["EPS_MFMA_PROBE"]
+
+
+def test_auto_keeps_the_8_bit_pass_where_it_filters_and_probes_only_once(amd):
+    """... and on a table the centred grid serves (a 16-dimensional manifold in 256 dimensions - r3's grid overflowed on such rows at
+    scale) the probe passes: every AUTO batch runs the 8-bit pass, none is declined, all equal the stream scan."""
+    rng = np.random.default_rng(16)
+    n, d, nq = 120_000, 256, 200
+    A = (0.25 * rng.standard_normal((16, d))).astype(np.float32)
+    X = (rng.random((n, 16), dtype=np.float32) @ A + 0.01 * rng.standard_normal((n, d)).astype(np.float32)).astype(np.float32)
+    Q = (rng.random((nq, 16), dtype=np.float32) @ A + 0.01 * rng.standard_normal((nq, d)).astype(np.float32)).astype(np.float32)
+    ix = amd.GpuIndex(d, 0)
+    ix.attach_rows(X)
+    ref = ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
+    for it in range(3):
+        same(ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_AUTO), ref, "auto %d" % it)
+        st = ix.stats()
+        assert (st["main_kernel_bits"], st["i8_declined"], st["overflow_queries"]) == (8, 0, 0), (it, st)
     ix.close()
 
 

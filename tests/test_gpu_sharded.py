@@ -72,6 +72,52 @@ def test_sharded_large_batch_mfma_engine_and_program_filter(amd):
     grp.close()
 
 
+def test_sharded_device_buffers_and_rows_attached_per_shard(amd):
+    """r4: rows handed over shard by shard where they already live on the shard's device (eps_index_attach_shard_rows: local row l =
+    global row l * G + shard), queries and results in device memory (a torch tensor on a device of the group): the per-shard lists are
+    merged on the device that holds the caller's result buffers, no host hop, counts included.  Same ids / distances / counts as the
+    host-buffer form of the same group and as one plain index; a group whose shards do not hold a hash split of the table refuses."""
+    import torch
+    n, d, G = 30_001, 40, 3
+    X, Q = data(n, d, 31), data(33, d, 32)
+    one = amd.GpuIndex(d, 0)
+    one.attach_rows(X)
+    host = amd.GpuIndex(d, 0, devices=[0] * G)
+    host.attach_rows(X)
+    grp = amd.GpuIndex(d, 0, devices=[0] * G)
+    parts = [torch.from_numpy(np.ascontiguousarray(X[s::G])).cuda() for s in range(G)]
+    grp.attach_shard_rows(0, parts[0])
+    with pytest.raises(amd.EpsillaError):          # shards 1, 2 still empty: not a hash split of 10 001 rows
+        grp.search(Q, 10, mode=amd.MODE_FLAT)
+    grp.attach_shard_rows(1, parts[1])
+    grp.attach_shard_rows(2, np.ascontiguousarray(X[2::G]))   # host rows of one shard work too
+    assert grp.row_count == n
+    dele = bitset(n, range(0, n, 5))
+    Qd = torch.from_numpy(Q).cuda()
+    k = 10
+    for setup in ("plain", "deleted"):
+        for ix in (one, host, grp):
+            ix.set_deleted(dele if setup == "deleted" else None)
+        a = one.search(Q, k, mode=amd.MODE_FLAT)
+        b = host.search(Q, k, mode=amd.MODE_FLAT)
+        o = (torch.full((len(Q), k), -7, dtype=torch.int64, device="cuda"), torch.zeros((len(Q), k), dtype=torch.float32, device="cuda"),
+             torch.zeros((len(Q),), dtype=torch.int32, device="cuda"))
+        torch.cuda.synchronize()   # (the shards run on their own streams: the fills above must have landed)
+        grp.search(Qd, k, out=o, mode=amd.MODE_FLAT)
+        grp.synchronize()
+        c = (o[0].cpu().numpy(), o[1].cpu().numpy(), o[2].cpu().numpy())
+        for got, what in ((b, "host buffers"), (c, "device buffers")):
+            assert np.array_equal(a[0], got[0]) and np.array_equal(a[1], got[1]) and np.array_equal(a[2], got[2]), (setup, what)
+    # fewer visible rows than k: -1 / +inf padding and counts from the device merge
+    few = bitset(n, [i for i in range(n) if i not in (5, 6, 7)])
+    grp.set_deleted(few)
+    grp.search(Qd[:4], k, out=(o[0][:4], o[1][:4], o[2][:4]), mode=amd.MODE_FLAT)
+    grp.synchronize()
+    assert o[2][:4].cpu().tolist() == [3] * 4 and sorted(o[0][0, :3].cpu().tolist()) == [5, 6, 7] and (o[0][0, 3:] == -1).all()
+    for ix in (one, host, grp):
+        ix.close()
+
+
 def test_sharded_build_graph_search_and_graph_files(amd, tmp_path):
     """one graph per shard (built on the shard's rows), traversal per shard, merged: unique global ids, the same answer after
     a save / load round trip through per-shard files in the reference's ann_graph format"""

@@ -32,7 +32,9 @@ def test_filter_kernels_do_not_spill(tmp_path):
     assert len(v7) == 12, list(usage)   # {128, 256}-query tiles x {ids, keys, dense} epilogues x {fp16, int8} operands
     for k, u in v7.items():
         assert u["ScratchSize [bytes/lane]"] == 0, (k, u)
-        assert u["AGPRs"] in (128, 256), (k, u)      # the accumulators live in AGPRs
+        # r4 (EPS_V7_VI = 7): 7 of the 8 row blocks' accumulators live in arch VGPRs (the epilogue reads them in place), the operand
+        # fragments and the last row block in the accumulator file; one wavefront per SIMD either way
+        assert 64 <= u["AGPRs"] <= 200 and u["VGPRs"] <= 256 and u["Occupancy [waves/SIMD]"] >= 1, (k, u)
     for k, u in usage.items():
         if "mfma_filter_kernel_v3" in k:
             assert u["ScratchSize [bytes/lane]"] == 0, (k, u)

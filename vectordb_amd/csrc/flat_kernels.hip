@@ -360,10 +360,11 @@ void launch_normalize(float* rows, int64_t n, int dim, bool only_if_nonzero, hip
 // k-way merge of per-shard sorted lists by (dist, id) — what every rank does after the all-gather.
 // shard s's lists start `stride_bytes` after shard s-1's (0 = densely packed [shards][nq][k] arrays)
 __global__ void merge_shards_kernel(const float* dist, const int64_t* ids, int shards, int64_t nq, int k,
-                                    float* out_dist, int64_t* out_ids, int64_t stride_bytes) {
+                                    float* out_dist, int64_t* out_ids, int64_t stride_bytes, int32_t* out_counts) {
   const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= nq) return;
   int head[16];
+  int found = 0;
   for (int s = 0; s < shards; ++s) head[s] = 0;
   for (int e = 0; e < k; ++e) {
     int best = -1;
@@ -386,14 +387,16 @@ __global__ void merge_shards_kernel(const float* dist, const int64_t* ids, int s
       out_dist[q * k + e] = bd;
       out_ids[q * k + e] = bi;
       head[best]++;
+      ++found;
     }
   }
+  if (out_counts) out_counts[q] = found;
 }
 void launch_merge_shards(const float* dist, const int64_t* ids, int shards, int64_t nq, int k, float* out_dist,
-                         int64_t* out_ids, hipStream_t s, int64_t stride_bytes) {
+                         int64_t* out_ids, hipStream_t s, int64_t stride_bytes, int32_t* out_counts) {
   if (nq <= 0) return;
   hipLaunchKernelGGL(merge_shards_kernel, dim3((unsigned)((nq + 127) / 128)), dim3(128), 0, s, dist, ids, shards, nq, k,
-                     out_dist, out_ids, stride_bytes);
+                     out_dist, out_ids, stride_bytes, out_counts);
 }
 
 }  // namespace eps

@@ -60,6 +60,9 @@ Index::~Index() {
   for (auto& pr : kring_)
     for (auto& e : pr)
       if (e) (void)hipEventDestroy(e);
+  for (auto& pr : stage_ev_)
+    for (auto& e : pr)
+      if (e) (void)hipEventDestroy(e);
   if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -95,6 +98,8 @@ int32_t Index::init() {
     for (auto& e : pr) HIP_TRY(hipEventCreate(&e));
   evk0_ = kring_[0][0];
   evk1_ = kring_[0][1];
+  for (auto& pr : stage_ev_)
+    for (auto& e : pr) HIP_TRY(hipEventCreate(&e));
   return EPS_OK;
 }
 
@@ -632,6 +637,7 @@ int32_t Index::search(const float* queries, int64_t nq, int32_t k, const eps_sea
     return fail(EPS_USER_ERROR, "search: queue sizes, sync interval and thread count must be positive");
   HIP_TRY(hipSetDevice(device_));
   std::memset(&stats_, 0, sizeof(stats_));
+  stage_n_ = 0;
   if (d_deleted_ && deleted_bytes_ < (n_rows_ + 7) / 8)
     return fail(EPS_USER_ERROR, "search: the deleted bitset is shorter than the table (rows were appended): call set_deleted again");
   if (f_op_ && d_fcol_ && fcol_rows_ < n_rows_)
@@ -760,6 +766,10 @@ int32_t Index::last_stats(eps_search_stats* out) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, ev0_, ev1_) == hipSuccess) s.kernel_ms = ms;
     if (s.main_kernel_launches > 0 && hipEventElapsedTime(&ms, evk0_, evk1_) == hipSuccess) s.main_kernel_ms = ms;
+    double all = 0.0;
+    for (int i = 0; i < stage_n_; ++i)
+      if (hipEventElapsedTime(&ms, stage_ev_[i][0], stage_ev_[i][1]) == hipSuccess) all += ms;
+    s.filter_ms_all = all;
   }
   (void)hipGetLastError();
   *out = s;
@@ -889,6 +899,7 @@ int32_t eps_index_set_stream(eps_index* h, void* s) { GUARD(h, IX(h)->set_stream
 int32_t eps_index_synchronize(eps_index* h) { GUARD(h, IX(h)->synchronize()); }
 int32_t eps_index_attach_rows(eps_index* h, const float* rows, int64_t n) { GUARD(h, IX(h)->attach_rows(rows, n)); }
 int32_t eps_index_append_rows(eps_index* h, const float* rows, int64_t n) { GUARD(h, IX(h)->append_rows(rows, n)); }
+int32_t eps_index_attach_shard_rows(eps_index* h, int32_t shard, const float* rows, int64_t n_local) { GUARD(h, IX(h)->attach_shard_rows(shard, rows, n_local)); }
 int64_t eps_index_row_count(const eps_index* h) { return h ? CIX(h)->row_count() : -1; }
 int32_t eps_index_set_id_map(eps_index* h, int64_t b, int64_t s) { GUARD(h, IX(h)->set_id_map(b, s)); }
 int32_t eps_index_set_deleted(eps_index* h, const uint8_t* bits, int64_t nbytes) { GUARD(h, IX(h)->set_deleted(bits, nbytes)); }

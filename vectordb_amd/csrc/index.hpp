@@ -46,6 +46,8 @@ class IndexBase {
   virtual int32_t synchronize() = 0;
   virtual int32_t attach_rows(const float* rows, int64_t n) = 0;
   virtual int32_t append_rows(const float* rows, int64_t n_new) = 0;
+  // rows of one shard of a hash-sharded index (local row l = global row l * shards + shard); a plain index is its own shard 0
+  virtual int32_t attach_shard_rows(int32_t shard, const float* rows, int64_t n_local) = 0;
   virtual int32_t set_id_map(int64_t base, int64_t stride) = 0;
   virtual int32_t set_deleted(const uint8_t* bits, int64_t nbytes) = 0;
   virtual int32_t set_int_filter(const void* column, int64_t stride, int32_t width, int32_t op, int64_t constant) = 0;
@@ -78,6 +80,10 @@ class Index : public IndexBase {
   int32_t set_stream(void* s) override;
   int32_t synchronize() override;
   int32_t attach_rows(const float* rows, int64_t n) override;
+  int32_t attach_shard_rows(int32_t shard, const float* rows, int64_t n_local) override {
+    if (shard != 0) return fail(EPS_USER_ERROR, "attach_shard_rows: not a sharded index (only shard 0 exists)");
+    return attach_rows(rows, n_local);
+  }
   // rows of a strided host table: row i at rows + i*pitch_floats (hash-sharded tables: pitch = shards*dim)
   int32_t attach_rows_strided(const float* rows, int64_t n, int64_t pitch_floats);
   int32_t append_rows_strided(const float* rows, int64_t n_new, int64_t pitch_floats);
@@ -160,6 +166,11 @@ class Index : public IndexBase {
   bool kring_valid_[KRING] = {};
   int64_t kring_seq_ = 0;
   hipEvent_t evk0_ = nullptr, evk1_ = nullptr;
+  // event pairs around EVERY filter-stage launch of the call in progress (eps_search_stats::filter_ms_all: the dominant kernel runs
+  // once per stage, the ring above times the largest launch only)
+  static constexpr int STAGE_EV = 32;
+  hipEvent_t stage_ev_[STAGE_EV][2] = {};
+  int stage_n_ = 0;
   int kernel_times(double* ms_out, int cap) override;
   int64_t deleted_bytes_ = 0;   // length of the bitset behind d_deleted_
   int64_t fcol_rows_ = 0;       // rows the attribute column behind d_fcol_ covers

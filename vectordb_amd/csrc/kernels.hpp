@@ -68,7 +68,7 @@ void launch_finalize(const u64* run_keys, int64_t nq, int k, int64_t id_base, in
 
 void launch_normalize(float* rows, int64_t n, int dim, bool only_if_nonzero, hipStream_t s);
 void launch_merge_shards(const float* dist, const int64_t* ids, int shards, int64_t nq, int k, float* out_dist,
-                         int64_t* out_ids, hipStream_t s, int64_t stride_bytes = 0);
+                         int64_t* out_ids, hipStream_t s, int64_t stride_bytes = 0, int32_t* out_counts = nullptr);
 void launch_fill_u64(u64* p, int64_t n, u64 v, hipStream_t s);
 
 }  // namespace eps

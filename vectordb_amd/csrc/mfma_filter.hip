@@ -1012,7 +1012,13 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
       ix.stats_.main_kernel_queries = nq;
       ix.stats_.main_kernel_bits = i8 ? 8 : 16;
     }
+    const int sev = (!approx && ix.stage_n_ < Index::STAGE_EV) ? ix.stage_n_++ : -1;   // (the build's kNN stage runs thousands of calls: untimed)
+    if (sev >= 0) (void)hipEventRecord(ix.stage_ev_[sev][0], s);
     launch_filter(fa);
+    if (sev >= 0) {
+      (void)hipEventRecord(ix.stage_ev_[sev][1], s);
+      ix.stats_.filter_rows_all += hi - lo;
+    }
     if (biggest) (void)hipEventRecord(ix.evk1_, s);
     if (!fused) hipLaunchKernelGGL(stage_counts_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, cnt, nq, cap, overflow, total);
     if (getenv("EPS_DEBUG")) {

@@ -109,7 +109,7 @@ template <> struct V7Op<true> {
 // epilogue's max / compare chains read those blocks in place.  The MFMAs become inline asm, which hipcc neither schedules nor pads:
 // every hazard is handled where it arises (see the kernel).
 #ifndef EPS_V7_VI
-#define EPS_V7_VI 0
+#define EPS_V7_VI 7
 #endif
 #if EPS_V7_VI > 0
 #define EPS_FRAG_C "=a"
@@ -814,7 +814,14 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
           continue;
         }
         // the block's running max: 8 x v_max3_f32 (fmaxf chains cost 10: hipcc canonicalises the first two operands)
+#if defined(EPS_V7_ABL) && (EPS_V7_ABL & 1)
+        continue;   // lab ablation: no epilogue work at all (results are wrong; what the whole epilogue costs)
+#endif
         const thr_t mx = OP::max16(acc[i][j]);
+#if defined(EPS_V7_ABL) && (EPS_V7_ABL & 2)
+        asm volatile("" ::"v"(mx));   // lab ablation: maxima computed, never compared (what compare + branch + hit path cost)
+        continue;
+#endif
         if (__any(mx >= Tq[j])) {
           // (rare) everything the hit path needs is derived behind this opaque copy of the lane id, or hipcc hoists the
           // address arithmetic of all 16 blocks into the common path
@@ -844,9 +851,11 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
         }
       }
     }
+#if !(defined(EPS_V7_ABL) && (EPS_V7_ABL & 4))   // (lab ablation: no flush check)
     if (MODE != FM_DENSE) {
       if (*reinterpret_cast<volatile u32*>(wcnt) >= (u32)(V7_CAPW / 2)) flush();
     }
+#endif
 #ifdef EPS_V7_PROF
     const unsigned long long pf_t3 = __builtin_readcyclecounter();
     pf_head += pf_t1 - pf_t0;

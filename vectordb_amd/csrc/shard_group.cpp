@@ -6,8 +6,11 @@
 // xGMI with hipMemcpyPeerAsync (peer-to-peer, no host hop) and merged there by the same k-way merge kernel the
 // one-process-per-GPU form runs after its RCCL all-gather (bench.py).  There is no other exchange step.
 //
-// All eps_index_* entry points work on the handle eps_index_create_sharded returns.  Host pointers only (a sharded table
-// is ingested from the DBMS's host column; each shard reads its rows with one strided copy, nothing is re-packed).
+// All eps_index_* entry points work on the handle eps_index_create_sharded returns.  A sharded table is ingested from the DBMS's
+// host column (each shard reads its rows with one strided copy, nothing is re-packed) or shard by shard from rows that already
+// live on the shard's device (eps_index_attach_shard_rows, r4).  Queries and results are host buffers, or (r4) device buffers on
+// any device of the group: a shard on another device gets the queries with one peer copy, and the per-shard lists are gathered
+// and merged on the device that holds the caller's result buffers - no host hop, no host sync.
 #include <algorithm>
 #include <condition_variable>
 #include <cstring>
@@ -23,6 +26,17 @@ namespace eps {
 
 namespace {
 
+// device ordinal of a device / managed pointer, -1 for host memory
+int device_of(const void* p) {
+  if (!p) return -1;
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  return (a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged) ? a.device : -1;
+}
+
 class ShardGroup : public IndexBase {
  public:
   ShardGroup(int64_t dim, int metric) : dim_(dim), metric_(metric) {}
@@ -33,7 +47,7 @@ class ShardGroup : public IndexBase {
     }
     pool_job_.notify_all();
     for (auto& t : pool_) t.join();
-    const int dev0 = shard_.empty() ? 0 : shard_[0]->device_;
+    const int dev0 = merge_dev_ >= 0 ? merge_dev_ : (shard_.empty() ? 0 : shard_[0]->device_);
     free_on(dev0, gathered_);
     free_on(dev0, m_ids_);
     free_on(dev0, m_dist_);
@@ -50,15 +64,16 @@ class ShardGroup : public IndexBase {
       ix->set_id_map(s, shards);
       shard_.push_back(std::move(ix));
     }
-    // peer access between shard 0's device (where the merge runs) and the others; failure is not fatal (copies are staged)
-    for (int s = 1; s < shards; ++s)
-      if (devices[s] != devices[0]) {
-        (void)hipSetDevice(devices[0]);
-        (void)hipDeviceEnablePeerAccess(devices[s], 0);
-        (void)hipSetDevice(devices[s]);
-        (void)hipDeviceEnablePeerAccess(devices[0], 0);
-        (void)hipGetLastError();
-      }
+    // peer access between every pair of the group's devices (the merge runs where the caller's result buffers live); failure is
+    // not fatal (hipMemcpyPeerAsync then stages through the host)
+    for (int a = 0; a < shards; ++a)
+      for (int b = 0; b < shards; ++b)
+        if (devices[a] != devices[b]) {
+          (void)hipSetDevice(devices[a]);
+          (void)hipDeviceEnablePeerAccess(devices[b], 0);
+          (void)hipGetLastError();
+        }
+    shard_rows_.assign((size_t)shards, 0);
     // one worker thread per shard for the lifetime of the group (r2 spawned and joined G threads per call, search included)
     for (int s = 0; s < shards; ++s) pool_.emplace_back([this, s]() { worker(s); });
     return EPS_OK;
@@ -115,8 +130,31 @@ class ShardGroup : public IndexBase {
     if (n < 0 || (n > 0 && !rows)) return fail(EPS_USER_ERROR, "attach_rows: bad arguments");
     if (is_device_ptr(rows)) return fail(EPS_DB_UNSUPPORTED_ERROR, "sharded index: rows are ingested from host memory");
     const int32_t rc = each([&](int s, Index& ix) { return ix.attach_rows_strided(rows + (int64_t)s * dim_, rows_of(s, n), (int64_t)G() * dim_); });
-    if (rc == EPS_OK) n_rows_ = n;
+    if (rc == EPS_OK) {
+      n_rows_ = n;
+      for (int s = 0; s < G(); ++s) shard_rows_[(size_t)s] = rows_of(s, n);
+    }
     return rc;
+  }
+  // rows of ONE shard (local row l = global row l * G + shard), host memory or memory of the shard's own device (used in place)
+  int32_t attach_shard_rows(int32_t shard, const float* rows, int64_t n_local) override {
+    if (shard < 0 || shard >= G() || n_local < 0 || (n_local > 0 && !rows)) return fail(EPS_USER_ERROR, "attach_shard_rows: bad arguments");
+    const int dv = device_of(rows);
+    if (dv >= 0 && dv != shard_[(size_t)shard]->device_)
+      return fail(EPS_USER_ERROR, "attach_shard_rows: the rows live on device " + std::to_string(dv) + ", shard " + std::to_string(shard) + " on device " +
+                                      std::to_string(shard_[(size_t)shard]->device_));
+    if (hipSetDevice(shard_[(size_t)shard]->device_) != hipSuccess) return fail(EPS_INFRA_UNEXPECTED_ERROR, "hipSetDevice");
+    const int32_t rc = shard_[(size_t)shard]->attach_rows(rows, n_local);
+    if (rc != EPS_OK) return fail(rc, "shard " + std::to_string(shard) + ": " + shard_[(size_t)shard]->last_error());
+    shard_rows_[(size_t)shard] = n_local;
+    n_rows_ = 0;
+    for (int64_t v : shard_rows_) n_rows_ += v;
+    return EPS_OK;
+  }
+  bool split_ok() const {   // the shards hold a hash split of n_rows_ rows (attach_shard_rows fills them one at a time)
+    for (int s = 0; s < G(); ++s)
+      if (shard_rows_[(size_t)s] != rows_of(s, n_rows_)) return false;
+    return true;
   }
   int32_t append_rows(const float* rows, int64_t n_new) override {
     if (n_new < 0 || (n_new > 0 && !rows)) return fail(EPS_USER_ERROR, "append_rows: bad arguments");
@@ -128,7 +166,10 @@ class ShardGroup : public IndexBase {
       const int64_t cnt = n_new > first ? (n_new - first + G() - 1) / G() : 0;
       return cnt ? ix.append_rows_strided(rows + first * dim_, cnt, (int64_t)G() * dim_) : EPS_OK;
     });
-    if (rc == EPS_OK) n_rows_ += n_new;
+    if (rc == EPS_OK) {
+      n_rows_ += n_new;
+      for (int s = 0; s < G(); ++s) shard_rows_[(size_t)s] = rows_of(s, n_rows_);
+    }
     return rc;
   }
   int32_t set_id_map(int64_t, int64_t) override { return fail(EPS_DB_UNSUPPORTED_ERROR, "sharded index: the id map is the sharding itself"); }
@@ -163,6 +204,7 @@ class ShardGroup : public IndexBase {
   }
   int32_t build(int64_t n, const eps_build_params* p) override {   // every shard builds the graph of its own rows
     if (n < 0 || n > n_rows_) return fail(EPS_USER_ERROR, "build: n exceeds the attached rows");
+    if (!split_ok()) return fail(EPS_USER_ERROR, "build: the shards' row counts are not a hash split of the table (attach_shard_rows on every shard first)");
     return each([&](int s, Index& ix) { return ix.build(rows_of(s, n), p); });
   }
   int32_t set_graph(int64_t, const int64_t*, const int64_t*, int64_t) override {
@@ -198,43 +240,73 @@ class ShardGroup : public IndexBase {
     if (nq < 0 || k <= 0) return fail(EPS_USER_ERROR, "search: nq must be >= 0 and k > 0");
     if (nq == 0) return EPS_OK;
     if (!queries || !ids || !dist) return fail(EPS_USER_ERROR, "search: null buffer");
-    if (is_device_ptr(queries) || is_device_ptr(ids)) return fail(EPS_DB_UNSUPPORTED_ERROR, "sharded index: queries and results live in host memory");
     if (walk_limit) return fail(EPS_DB_UNSUPPORTED_ERROR, "sharded index: candidate walks are per index");
-    const int dev0 = shard_[0]->device_;
+    if (!split_ok()) return fail(EPS_USER_ERROR, "search: the shards' row counts are not a hash split of the table (attach_shard_rows on every shard first)");
+    // where the buffers live: host, or a device of the group (r4).  The merge runs on the device that holds the result buffers
+    // (shard 0's for host results); ids / dist / counts must live together.
+    const int q_dev = device_of(queries), r_dev = device_of(ids);
+    if (device_of(dist) != r_dev || (counts && device_of(counts) != r_dev)) return fail(EPS_USER_ERROR, "search: ids, dist and counts must live in the same memory");
+    int ms = 0;   // the shard whose device (and stream) merges
+    if (r_dev >= 0) {
+      ms = -1;
+      for (int s = 0; s < G(); ++s)
+        if (shard_[(size_t)s]->device_ == r_dev) { ms = s; break; }
+      if (ms < 0) return fail(EPS_DB_UNSUPPORTED_ERROR, "sharded index: device result buffers must live on one of the group's devices");
+    }
+    const int mdev = shard_[(size_t)ms]->device_;
     const size_t nk = (size_t)nq * k;
-    // per-shard results stay on the shard's device; they are pushed to shard 0's device and merged there
-    if (hipSetDevice(dev0) != hipSuccess) return fail(EPS_INFRA_UNEXPECTED_ERROR, "hipSetDevice");
-    if (nk > cap_) {
-      free_on(dev0, m_ids_);
-      free_on(dev0, m_dist_);
-      free_on(dev0, gathered_);
+    // per-shard results stay on the shard's device; they are pushed to the merging device and merged there
+    if (nk > cap_ || mdev != merge_dev_) {
+      const int old = merge_dev_ >= 0 ? merge_dev_ : mdev;
+      free_on(old, m_ids_);
+      free_on(old, m_dist_);
+      free_on(old, gathered_);
+      cap_ = 0;
+      if (hipSetDevice(mdev) != hipSuccess) return fail(EPS_INFRA_UNEXPECTED_ERROR, "hipSetDevice");
       // one gathered buffer: [G][ids int64[nk] | dist f32[nk]] (the layout eps_merge_topk_packed takes)
       stride_ = (nk * 12 + 7) / 8 * 8;
       if (hipMalloc(&gathered_, stride_ * G()) != hipSuccess || hipMalloc(&m_ids_, nk * 8) != hipSuccess || hipMalloc(&m_dist_, nk * 4) != hipSuccess)
         return fail(EPS_INFRA_UNEXPECTED_ERROR, "search: out of device memory (shard merge)");
       cap_ = nk;
+      merge_dev_ = mdev;
     }
+    stride_ = (nk * 12 + 7) / 8 * 8;   // (the gathered layout of THIS call; the buffer holds at least cap_ entries per shard)
     local_ids_.resize((size_t)G());
     local_dist_.resize((size_t)G());
     local_cnt_.resize((size_t)G());
+    local_q_.resize((size_t)G());
+    const size_t qbytes = (size_t)nq * dim_ * sizeof(float);
     int32_t rc = each([&](int s, Index& ix) -> int32_t {
       if (hipSetDevice(ix.device_) != hipSuccess) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "hipSetDevice");
       if (!local_ids_[s].reserve(nk * 8) || !local_dist_[s].reserve(nk * 4) || !local_cnt_[s].reserve((size_t)nq * 4))
         return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "search: out of device memory");
-      int32_t r = ix.search(queries, nq, k, pp, local_ids_[s].as<int64_t>(), local_dist_[s].as<float>(), local_cnt_[s].as<int32_t>());
+      const float* q = queries;
+      if (q_dev >= 0 && q_dev != ix.device_) {   // device queries on another GPU: one peer copy (3 MB at batch 1024 x 768)
+        if (!local_q_[s].reserve(qbytes)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "search: out of device memory");
+        const hipError_t eq = hipMemcpyPeerAsync(local_q_[s].p, ix.device_, queries, q_dev, qbytes, ix.stream_);
+        if (eq != hipSuccess) return ix.hip_fail(eq, "peer copy of the queries");
+        q = local_q_[s].as<float>();
+      }
+      int32_t r = ix.search(q, nq, k, pp, local_ids_[s].as<int64_t>(), local_dist_[s].as<float>(), local_cnt_[s].as<int32_t>());
       if (r != EPS_OK) return r;
-      // the one exchange step: this shard's [nq][k] lists -> shard 0's device, peer to peer over xGMI
+      // the one exchange step: this shard's [nq][k] lists -> the merging device, peer to peer over xGMI
       char* dst = static_cast<char*>(gathered_) + (size_t)s * stride_;
-      hipError_t e = hipMemcpyPeerAsync(dst, dev0, local_ids_[s].p, ix.device_, nk * 8, ix.stream_);
-      if (e == hipSuccess) e = hipMemcpyPeerAsync(dst + nk * 8, dev0, local_dist_[s].p, ix.device_, nk * 4, ix.stream_);
+      hipError_t e = hipMemcpyPeerAsync(dst, mdev, local_ids_[s].p, ix.device_, nk * 8, ix.stream_);
+      if (e == hipSuccess) e = hipMemcpyPeerAsync(dst + nk * 8, mdev, local_dist_[s].p, ix.device_, nk * 4, ix.stream_);
       if (e == hipSuccess) e = hipStreamSynchronize(ix.stream_);
       return e == hipSuccess ? EPS_OK : ix.hip_fail(e, "peer copy of the shard's top-k");
     });
     if (rc != EPS_OK) return rc;
-    if (hipSetDevice(dev0) != hipSuccess) return fail(EPS_INFRA_UNEXPECTED_ERROR, "hipSetDevice");
-    hipStream_t s0 = shard_[0]->stream_;
-    launch_merge_shards(reinterpret_cast<const float*>(static_cast<char*>(gathered_) + nk * 8), static_cast<const int64_t*>(gathered_), G(), nq, k,
-                        static_cast<float*>(m_dist_), static_cast<int64_t*>(m_ids_), s0, (int64_t)stride_);
+    if (hipSetDevice(mdev) != hipSuccess) return fail(EPS_INFRA_UNEXPECTED_ERROR, "hipSetDevice");
+    hipStream_t s0 = shard_[(size_t)ms]->stream_;
+    const float* gd = reinterpret_cast<const float*>(static_cast<char*>(gathered_) + nk * 8);
+    if (r_dev >= 0) {   // device results: merged straight into the caller's buffers; the caller synchronises (eps_index_synchronize)
+      launch_merge_shards(gd, static_cast<const int64_t*>(gathered_), G(), nq, k, dist, ids, s0, (int64_t)stride_, counts);
+      const hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return fail(EPS_INFRA_UNEXPECTED_ERROR, std::string("shard merge: ") + hipGetErrorString(e));
+      return EPS_OK;
+    }
+    launch_merge_shards(gd, static_cast<const int64_t*>(gathered_), G(), nq, k, static_cast<float*>(m_dist_), static_cast<int64_t*>(m_ids_), s0, (int64_t)stride_);
     hipError_t e = hipMemcpyAsync(ids, m_ids_, nk * 8, hipMemcpyDeviceToHost, s0);
     if (e == hipSuccess) e = hipMemcpyAsync(dist, m_dist_, nk * 4, hipMemcpyDeviceToHost, s0);
     if (e == hipSuccess) e = hipStreamSynchronize(s0);
@@ -266,6 +338,8 @@ class ShardGroup : public IndexBase {
       t.main_kernel_queries = std::max(t.main_kernel_queries, s.main_kernel_queries);
       t.main_kernel_bits = std::max(t.main_kernel_bits, s.main_kernel_bits);
       t.i8_declined += s.i8_declined;
+      t.filter_ms_all = std::max(t.filter_ms_all, s.filter_ms_all);
+      t.filter_rows_all += s.filter_rows_all;
     }
     *out = t;
     return EPS_OK;
@@ -298,7 +372,9 @@ class ShardGroup : public IndexBase {
   int metric_;
   int64_t n_rows_ = 0;
   std::vector<std::unique_ptr<Index>> shard_;
-  std::vector<DevBuf> local_ids_, local_dist_, local_cnt_;
+  std::vector<int64_t> shard_rows_;   // rows every shard holds (attach_rows: the hash split; attach_shard_rows: as handed over)
+  std::vector<DevBuf> local_ids_, local_dist_, local_cnt_, local_q_;
+  int merge_dev_ = -1;                // device gathered_ / m_ids_ / m_dist_ live on
   void* gathered_ = nullptr;
   void* m_ids_ = nullptr;
   void* m_dist_ = nullptr;

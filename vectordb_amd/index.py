@@ -42,8 +42,8 @@ def GetDistFunc(field_type="VECTOR_FLOAT", metric_type="EUCLIDEAN"):
 
 class GpuIndex:
     def __init__(self, dim, metric="EUCLIDEAN", device=0, devices=None):
-        """devices = [d0, d1, ...]: a hash-sharded index over those GPUs of this process (eps_index_create_sharded; host buffers
-        only); otherwise one index on `device`."""
+        """devices = [d0, d1, ...]: a hash-sharded index over those GPUs of this process (eps_index_create_sharded; host buffers,
+        or device rows per shard / device queries and results on a device of the group); otherwise one index on `device`."""
         self.L = lib.load()
         self.dim = int(dim)
         self.metric = METRICS[metric]
@@ -81,6 +81,15 @@ class GpuIndex:
         assert rows.shape[1] == self.dim
         self._keep["rows"] = rows
         self._check(self.L.eps_index_attach_rows(self.h, _ptr(rows), rows.shape[0]))
+
+    def attach_shard_rows(self, shard, rows):
+        """rows of ONE shard of a sharded index (local row l = global row l * shards + shard): numpy, or a tensor on the shard's own
+        device (borrowed).  eps_index_attach_shard_rows."""
+        if not _is_dev(rows):
+            rows = np.ascontiguousarray(rows, np.float32)
+        assert rows.shape[1] == self.dim
+        self._keep["rows%d" % shard] = rows
+        self._check(self.L.eps_index_attach_shard_rows(self.h, int(shard), _ptr(rows), rows.shape[0]))
 
     def append_rows(self, rows):
         if not _is_dev(rows):
