@@ -347,6 +347,13 @@ Status VecSearchExecutor::Search(const VectorPtr query_data, vectordb::engine::T
   p.sync_interval = subsearch_iterations_;
   const bool flat = prefilter_enabled_ || brute_force_search_ || dev.sharded || prefer_exact;
   if (prefer_exact && !prefilter_enabled_ && !brute_force_search_) p.mode = EPS_MODE_FLAT;
+  if (dev.sharded) {
+    // A sharded mirror walks graphs only if its shards hold the graphs of THIS executor's segment (BuildGraphOnMirror) - and never for
+    // a host-evaluated filter: the brute-force branch below hands the shards a full visibility mask and expects an EXACT scan, a
+    // per-shard walk would judge the mask on its top-L only and return too few rows (RunSearch has the same rule)
+    const bool shard_graph = dev.shard_graph_owner == ann_index_.get() && dev.shard_graph_n == total_indexed_vector_ && total_indexed_vector_ > 0;
+    if (host_filter || !shard_graph) p.mode = EPS_MODE_FLAT;
+  }
   auto publish = [&](const int64_t* ids, const float* dist, int64_t count) {
     if ((size_t)count > search_result_.size()) {
       search_result_.resize(count);

@@ -606,7 +606,7 @@ int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp, const Buil
   DevBuf q8b, qstat8b;
   if (prefilter) {
     const int32_t rc = quant8_view(ix, &q8v);
-    if (rc != EPS_OK) return rc;
+    if (rc != EPS_OK) q8v = Quant8View();   // (optional: without the mirror the searches read the fp32 rows, the graph is the same)
     prefilter = q8v.x8 != nullptr;
   }
   const size_t trv_shm = traverse_lds_bytes(dim, Lp2, true, prefilter);

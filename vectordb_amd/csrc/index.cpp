@@ -148,6 +148,7 @@ int32_t Index::attach_rows_strided(const float* rows, int64_t n, int64_t pitch) 
   ++rows_version_;
   prog_rows_host_ = nullptr;   // a new table: attribute rows cached from the previous one are not its rows, whatever their address
   prog_rows_uploaded_ = 0;
+  loaded_attr_rows_ = 0;       // ... nor are the rows a previous eps_index_load_table kept (load_table sets them again after attaching)
   // state that was sized for the previous table does not carry over: a graph over more rows than are attached now, a
   // deleted bitset or an attribute column of the old length
   if (n_indexed_ > n) {
@@ -721,11 +722,18 @@ int32_t Index::search(const float* queries, int64_t nq, int32_t k, const eps_sea
     int32_t rc;
     if (keff == k) {
       if (engine == EPS_FLAT_MFMA) {
-        pre_sync_ = finalize;   // (called by the engine in front of its final sync; again after a fall-back pass)
+        // (called by the engine in front of its final sync; again after a fall-back pass.  The callable captures locals of this
+        // frame: the guard clears it on every way out, an exception from the engine included)
+        struct PreSyncGuard {
+          Index& ix;
+          ~PreSyncGuard() {
+            ix.pre_sync_ = nullptr;
+            ix.pre_sync_nq_ = -1;
+          }
+        } guard{*this};
+        pre_sync_ = finalize;
         pre_sync_nq_ = nq;
         rc = flat_mfma_search(*this, dq, nq, k, run_keys, false, bits);
-        pre_sync_ = nullptr;
-        pre_sync_nq_ = -1;
       } else {
         rc = flat_stream(dq, nq, k, 0, n_rows_, run_keys, false);
       }

@@ -195,6 +195,7 @@ class Index : public IndexBase {
   friend int32_t select_edges(Index&, const int64_t*, int64_t, const int64_t*, int32_t, int32_t, int32_t, int64_t*, int32_t*);
   friend int32_t inter_insert(Index&, const int64_t*, const int32_t*, int64_t, int32_t, int64_t*, int32_t*);
   friend int32_t graph_search(Index&, const float*, int64_t, int, const eps_search_params&, u64*, int64_t*, int);
+  friend int32_t graph_search_impl(Index&, const float*, int64_t, int, const eps_search_params&, u64*, int64_t*, int, int64_t);
 };
 
 // engines implemented in their own translation units
@@ -213,6 +214,8 @@ void graph_free(GraphDev* g);
 // writes result keys [nq][k] and counts
 int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_search_params& p, u64* run_keys,
                      int64_t* evals, int walk_limit = 0);
+int32_t graph_search_impl(Index& ix, const float* dq, int64_t nq, int k, const eps_search_params& p, u64* run_keys, int64_t* evals, int walk_limit,
+                          int64_t ecap_min);   // (ecap_min: slots of the filtered traversal's evaluation log, grown on overflow)
 // stage-level entry of the build (eps_index_knn_graph / eps_index_link): run a prefix of the stages, on caller-supplied inputs
 struct BuildStage {
   const int64_t* knn_in = nullptr;   // [n][K] kNN graph to link (-1 padded) instead of computing one

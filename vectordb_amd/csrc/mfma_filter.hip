@@ -609,8 +609,15 @@ static int32_t ensure_mirror8(Index& ix) {
   hipStream_t s = ix.stream_;
   const size_t keep_rows = extend ? (size_t)m.n8 : 0;
   if (!grow_keep(m.x8, (size_t)n_pad * d_pad8, keep_rows * d_pad8, s) || !grow_keep(m.acc0, (size_t)n_pad * 4, keep_rows * 4, s) || !m.scal8.reserve(64) ||
-      !m.mu8.reserve((size_t)d_pad8 * 4))
+      !m.mu8.reserve((size_t)d_pad8 * 4)) {
+    (void)hipGetLastError();
+    if (!extend) {   // (nothing half-built stays behind: the callers for whom the mirror is optional carry on without it)
+      m.x8.release();
+      m.acc0.release();
+      m.version8 = -1;
+    }
     return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory for the 8-bit mirror");
+  }
   hipError_t er = hipSuccess;
   if (!extend) {
     er = hipMemsetAsync(m.scal8.p, 0, 32, s);

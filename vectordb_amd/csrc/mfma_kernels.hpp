@@ -111,6 +111,9 @@ template <> struct V7Op<true> {
 #ifndef EPS_V7_VI
 #define EPS_V7_VI 7
 #endif
+#ifndef EPS_V7_TILE
+#define EPS_V7_TILE (EPS_V7_VI > 0)   // tile-level epilogue test (see the kernel): only with VGPR-form accumulators
+#endif
 #if EPS_V7_VI > 0
 #define EPS_FRAG_C "=a"
 template <bool I8> struct V7Asm;
@@ -786,11 +789,79 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
     const int l31e = (int)(lne & 31), kh4e = (int)(lne >> 5) * 4;
     thr_t Tq[JQ];
     float cj[JQ];
+#if EPS_V7_TILE
+    // the tile's thresholds: the LDS reads are issued here and waited for after the max chains below (hipcc sinks an ordinary load to its
+    // first use and waits for it there, ~100 exposed cycles per tile)
+    u32 tqraw[2] = {0u, 0u};
+    if (I8 && MODE != FM_DENSE) {
+      const u32 tq_addr = (u32)(uintptr_t)(__attribute__((address_space(3))) float*)tq_lds + lne * 4u;
+      asm volatile("ds_read_b32 %0, %1" : "=v"(tqraw[0]) : "v"(tq_addr));
+      if (JQ == 2) asm volatile("ds_read_b32 %0, %1 offset:256" : "=v"(tqraw[1]) : "v"(tq_addr));
+    }
+#endif
 #pragma unroll
     for (int j = 0; j < JQ; ++j) {
+#if EPS_V7_TILE
+      if (!(I8 && MODE != FM_DENSE))
+#endif
       Tq[j] = __builtin_bit_cast(thr_t, tq_lds[j * 64 + lne]);
       cj[j] = MODE == FM_DENSE ? tq_lds[(2 + j) * 64 + lne] : 0.f;   // (FM_KEYS reads it where a row passes: one live register less)
     }
+    // Tile-level test (r4, 8-bit kernel).  The per-block form below costs a wavefront ~1800 cycles per tile although a block passes
+    // once in ~100 (lab ablations, profiles/r4_epilogue_ablation.txt: the 16 maxima themselves 2 % of the kernel, the 16 compare +
+    // TAKEN-branch pairs around the hit code and the hit code 9 %): with one wavefront per SIMD nothing hides a taken branch's
+    // refetch.  With the accumulators in arch VGPRs a second look at them is free, so: the maximum of ALL 128 values a lane holds for
+    // each of its query columns (four interleaved v_max3 chains, no branch), ONE compare per column, ONE branch per tile that is NOT
+    // taken on the common path; only a tile in which something passed (one in six at the last stage of a 10M-row scan) runs the
+    // per-block code, and only it can have filled the pending list, so the flush check moves there too.
+    bool tile_hit = true;
+#if EPS_V7_TILE
+    if (I8 && MODE != FM_DENSE) {
+      bool h = false;
+#pragma unroll
+      for (int j = 0; j < JQ; ++j) {
+        int p0 = (int)acc[0][j][0], p1 = (int)acc[0][j][1], p2 = (int)acc[0][j][2], p3 = (int)acc[0][j][3];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+          for (int r = (i == 0 ? 4 : 0); r < 16; r += 4) {
+            if (i < EPS_V7_VI) {
+              const int a0 = (int)acc[i][j][r], a1 = (int)acc[i][j][r + 1], a2 = (int)acc[i][j][r + 2], a3 = (int)acc[i][j][r + 3];
+              p0 = p0 > a0 ? p0 : a0;
+              p1 = p1 > a1 ? p1 : a1;
+              p2 = p2 > a2 ? p2 : a2;
+              p3 = p3 > a3 ? p3 : a3;
+            } else {
+              // a block that lives in the accumulator file: read through two scratch registers, four values at a time (as plain C++
+              // hipcc copies the whole block out, and back in again when it runs out of arch VGPRs)
+              int t0, t1;
+              asm("v_accvgpr_read_b32 %2, %4\n\tv_accvgpr_read_b32 %3, %5\n\tv_max_i32 %0, %0, %2\n\tv_max_i32 %1, %1, %3\n\t"
+                  "v_accvgpr_read_b32 %2, %6\n\tv_accvgpr_read_b32 %3, %7\n\tv_max_i32 %0, %0, %2\n\tv_max_i32 %1, %1, %3"
+                  : "+v"(p0), "+v"(p1), "=&v"(t0), "=&v"(t1)
+                  : "a"((int)acc[i][j][r]), "a"((int)acc[i][j][r + 1]), "a"((int)acc[i][j][r + 2]), "a"((int)acc[i][j][r + 3]));
+            }
+          }
+        }
+        const int m01 = p0 > p1 ? p0 : p1, m23 = p2 > p3 ? p2 : p3;
+        if (j == 0) {   // (after the first column's chains: the thresholds have long landed)
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tqraw[0]), "+v"(tqraw[1]));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        Tq[j] = (thr_t)(int)tqraw[j];
+        h |= (m01 > m23 ? m01 : m23) >= (int)Tq[j];
+      }
+      tile_hit = __any(h);
+    }
+#endif
+    if (__builtin_expect(tile_hit, 0)) {
+#if EPS_V7_TILE && EPS_V7_VI > 0 && EPS_V7_VI < 8
+    if (I8 && MODE != FM_DENSE) {   // (the blocks in the accumulator file become "new" values here, or hipcc copies them out on the common path)
+#pragma unroll
+      for (int i = EPS_V7_VI; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < JQ; ++j) asm volatile("" : "+a"(acc[i][j]));
+    }
+#endif
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int rbase = i * 32 + kh4e;
@@ -856,6 +927,7 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
       if (*reinterpret_cast<volatile u32*>(wcnt) >= (u32)(V7_CAPW / 2)) flush();
     }
 #endif
+    }   // tile_hit
 #ifdef EPS_V7_PROF
     const unsigned long long pf_t3 = __builtin_readcyclecounter();
     pf_head += pf_t1 - pf_t0;

@@ -214,8 +214,14 @@ static void launch_trv2(const Trv2Args& a, int slots, size_t shm, hipStream_t s)
   hipLaunchKernelGGL((traverse2_kernel<VEC4, NW, QG, PF>), dim3((unsigned)slots), dim3(NW * 64), shm, s, a);
 }
 
-int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_search_params& p, u64* run_keys,
-                     int64_t* evals_out, int walk_limit) {
+// result keys beyond the first K of every query -> empty (the reference's result-count cap)
+__global__ void cap_keys_kernel(u64* run_keys, int64_t nq, int k, int K) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nq * k && (int)(i % k) >= K) run_keys[i] = KEY_EMPTY;
+}
+
+int32_t graph_search_impl(Index& ix, const float* dq, int64_t nq, int k, const eps_search_params& p, u64* run_keys,
+                                 int64_t* evals_out, int walk_limit, int64_t ecap_min) {
   GraphDev& g = *ix.graph_;
   const int64_t n = ix.n_indexed_;
   int64_t L = p.master_queue;
@@ -266,8 +272,13 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
   if (pf_env) prefilter = !filtered && atoi(pf_env) != 0;
   Quant8View q8v;
   if (prefilter) {
+    // the prefilter is an optimisation: if its mirror (n x d bytes, a quarter of the table) cannot be had - HBM-tight tables - the
+    // walk runs on the fp32 rows as it did before the prefilter existed, and stops asking for this graph
     const int32_t rc = quant8_view(ix, &q8v);
-    if (rc != EPS_OK) return rc;
+    if (rc != EPS_OK) {
+      q8v = Quant8View();
+      g.pf_off = true;
+    }
     prefilter = q8v.x8 != nullptr;
   }
   const size_t lds_need = traverse2_lds_bytes((int)ix.dim_, T, (int)Lq, qtot, dp, false, prefilter);
@@ -298,7 +309,10 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
   if (qglobal) slots = std::min<int64_t>(slots, std::max<int64_t>(1, ((int64_t)8 << 30) / (qtot * 8)));
   const int vcap = (int)std::min<int64_t>((int64_t)1 << 20, std::max<int64_t>(1024, words / 4));
   // results of the traversal are consumed per slice of queries so that the [slice][L] queue copy stays below 2 GiB
-  const int64_t slice = std::max<int64_t>(1, std::min<int64_t>(nq, ((int64_t)2 << 30) / (std::max<int64_t>(L, p.filter_in_traversal ? std::min<int64_t>(n, std::max<int64_t>(16384, 64 * L)) : 0) * 8)));
+  // filtered traversal: slots of a query's evaluation log - every distance the walk evaluates is logged; a walk that evaluates more
+  // (large T x I, high degree) reports it and the search is repeated with a log that holds them all (ecap_min, below)
+  const int64_t ecap_plan = std::min<int64_t>(n, std::max<int64_t>(std::max<int64_t>(16384, 64 * L), ecap_min));
+  const int64_t slice = std::max<int64_t>(1, std::min<int64_t>(nq, ((int64_t)2 << 30) / (std::max<int64_t>(L, p.filter_in_traversal ? ecap_plan : 0) * 8)));
   if (!g.visited.reserve((size_t)slots * words * 4) || !g.vlog.reserve((size_t)slots * vcap * 4) ||
       !g.queue.reserve((size_t)slice * L * 8) || !g.counters.reserve(256) ||
       (qglobal && (!g.qglobal.reserve((size_t)slots * qtot * 8) || !g.auxglobal.reserve((size_t)slots * 2 * Lq * 4))))
@@ -340,7 +354,7 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
   a.counters = g.counters.as<unsigned long long>();
   a.prof = prof ? g.counters.as<unsigned long long>() + 8 : nullptr;
   if (filtered && k > 1024) return ix.fail(EPS_DB_UNSUPPORTED_ERROR, "search: filter_in_traversal returns at most 1024 rows per query");
-  const int64_t ecap = filtered ? std::min<int64_t>(n, std::max<int64_t>(16384, 64 * L)) : 0;
+  const int64_t ecap = filtered ? ecap_plan : 0;
   a.elog = nullptr;
   a.elog_cnt = nullptr;
   a.elog_cap = (int)ecap;
@@ -428,6 +442,9 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
       // the k closest visible evaluated rows (+ the visible rows of the un-indexed tail, already filtered by its flat scan)
       launch_merge_lists(a.elog, (int)ecap, k, cnt, run_keys + q0 * k, false, s, a.elog_cnt, &fspec);
       if (tail) launch_merge_lists(tail + q0 * tail_k, tail_k, k, cnt, run_keys + q0 * k, true, s);
+      // the same result-count cap as the unfiltered path: min(n_indexed, limit, LocalQueueSize) (:872)
+      const int64_t Kf = std::min<int64_t>(std::min<int64_t>(n, limit), p.local_queue);
+      if (Kf < k) hipLaunchKernelGGL(cap_keys_kernel, dim3((unsigned)((cnt * k + 255) / 256)), dim3(256), 0, s, run_keys + q0 * k, cnt, k, (int)Kf);
     } else {
       hipLaunchKernelGGL(post_kernel, dim3((unsigned)cnt), dim3(64), (size_t)pa.Klds * 8, s, pa);
     }
@@ -440,6 +457,12 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
   if (er == hipSuccess) er = hipStreamSynchronize(s);
   if (er != hipSuccess) return ix.hip_fail(er, "traversal");
   g.vis_dirty = false;
+  if (filtered && h[5] > 0) {
+    // some query evaluated more rows than its log holds; the evaluations that were dropped are the LATE ones - the closest.  Repeat
+    // with a log sized for the longest walk seen (bounded by n: a walk evaluates a row at most once)
+    const int64_t need = std::min<int64_t>(n, (int64_t)h[6] + (int64_t)h[6] / 4 + 1024);
+    if (need > ecap) return graph_search_impl(ix, dq, nq, k, p, run_keys, evals_out, walk_limit, need);
+  }
   if (prof) {
     static const char* names[10] = {"seeds+sort", "scatter", "select", "gather+visited", "dedupe", "distances", "rank sort", "queue insert", "merge-all", "results+reset"};
     unsigned long long tot = 0;
@@ -461,6 +484,10 @@ int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_se
   if (prof && prefilter) fprintf(stderr, "[eps trv]   8-bit prefilter: %.1f of %.1f neighbour evaluations per query read the fp32 row\n", (double)h[4] / nq, (double)(h[0] - (unsigned long long)(L * nq)) / nq);
   if (evals_out) *evals_out = (int64_t)h[0];
   return EPS_OK;
+}
+
+int32_t graph_search(Index& ix, const float* dq, int64_t nq, int k, const eps_search_params& p, u64* run_keys, int64_t* evals_out, int walk_limit) {
+  return graph_search_impl(ix, dq, nq, k, p, run_keys, evals_out, walk_limit, 0);
 }
 
 }  // namespace eps

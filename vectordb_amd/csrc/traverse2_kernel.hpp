@@ -786,7 +786,13 @@ __global__ __launch_bounds__(NW * 64, PF ? 4 : 1) void traverse2_kernel(Trv2Args
     // ------------------------------------------------------------------ results + visited reset
     if (a.out_queue)
       for (int i = tid; i < L; i += NT) a.out_queue[q * L + i] = master[i];
-    if (a.elog_cnt && tid == 0) a.elog_cnt[q] = (u32)sh[8];
+    if (a.elog_cnt && tid == 0) {
+      a.elog_cnt[q] = (u32)sh[8];
+      if ((int)sh[8] > a.elog_cap) {   // the log was too short for this walk: the host repeats the search with a longer one
+        atomicAdd(&a.counters[5], 1ull);
+        atomicMax(&a.counters[6], (unsigned long long)sh[8]);
+      }
+    }
     const int nlog = sh[2];
     if (sh[7] || nlog > a.vcap) {
       for (int64_t i = tid; i < a.words; i += NT) vis[i] = 0;
