@@ -18,6 +18,7 @@
 //                                                      VecSearchExecutor::SearchBatch, one projection pass; element q of the
 //                                                      result equals query(..., query_vectors[q], ...)[1]
 #define PyInit_epsilla PyInit_epsilla_reference_binding
+#include "epsdrop/search_batch.hpp"
 #include "bindings/python/interface.cpp"  // the reference's binding, from where it lies under $(REF)
 #undef PyInit_epsilla
 
@@ -244,49 +245,19 @@ static PyObject* eps_query_batch(PyObject* self, PyObject* args, PyObject* kwarg
   const std::string tableName = tableNamePtr, queryFilter = queryFilterPtr;
   std::string fieldName = queryFieldPtr;
 
-  // ---- lookups and validation, as DBServer::Search / TableMVP::Search
+  // ---- lookups, validation, COSINE normalisation, executor and ONE device batch: the C++-level entry any host can call
+  // (epsdrop::SearchBatch, include/epsdrop/search_batch.hpp)
   std::string err;
-  std::shared_ptr<vectordb::engine::TableMVP> table;
-  std::vector<vectordb::query::expr::ExprNodePtr> filter_nodes;
-  std::vector<int64_t> ids;
-  std::vector<float> dist;
-  std::vector<int32_t> counts;
-  int32_t width = 0;
-  std::vector<float> normalized;
+  epsdrop::BatchHits hits;
   Py_BEGIN_ALLOW_THREADS
   try {
-    using vectordb::engine::meta::FieldType;
-    auto database = db->GetDB(db_name);
-    if (!database) throw std::runtime_error("DB not found: " + db_name);
-    table = database->GetTable(tableName);
-    if (!table) throw std::runtime_error("Table not found: " + tableName);
-    if (fieldName.empty()) {
-      for (auto& f : table->table_schema_.fields_)
-        if (f.field_type_ == FieldType::VECTOR_FLOAT || f.field_type_ == FieldType::VECTOR_DOUBLE || f.field_type_ == FieldType::SPARSE_VECTOR_FLOAT ||
-            f.field_type_ == FieldType::SPARSE_VECTOR_DOUBLE) {
-          if (!fieldName.empty()) throw std::runtime_error("Must specify queryField if there are more than 1 vector fields.");
-          fieldName = f.name_;
-        }
+    for (auto& f : fields) {   // (TableMVP::Search checks the response fields before it searches, table_mvp.cpp:310-314)
+      auto database = db->GetDB(db_name);
+      auto t = database ? database->GetTable(tableName) : nullptr;
+      if (t && t->field_name_field_type_map_.find(f) == t->field_name_field_type_map_.end()) throw std::runtime_error("Field name not found: " + f);
     }
-    auto st = vectordb::query::expr::Expr::ParseNodeFromStr(queryFilter, filter_nodes, table->field_name_field_type_map_);
-    if (!st.ok()) throw std::runtime_error(st.message());
-    if (table->field_name_field_type_map_.find(fieldName) == table->field_name_field_type_map_.end()) throw std::runtime_error("Field name not found: " + fieldName);
-    for (auto& f : fields)
-      if (table->field_name_field_type_map_.find(f) == table->field_name_field_type_map_.end()) throw std::runtime_error("Field name not found: " + f);
-    const auto ftype = table->field_name_field_type_map_[fieldName];
-    if (ftype != FieldType::VECTOR_FLOAT && ftype != FieldType::VECTOR_DOUBLE) throw std::runtime_error("query_batch: the query field must be a dense vector field");
-    if (table->field_name_metric_type_map_[fieldName] == vectordb::engine::meta::MetricType::COSINE) {   // (table_mvp.cpp:333-343)
-      normalized.assign(qptr, qptr + (size_t)nq * dim);
-      for (Py_ssize_t q = 0; q < nq; ++q) vectordb::engine::Normalize((vectordb::engine::DenseVectorPtr)(normalized.data() + (size_t)q * dim), dim);
-      qptr = normalized.data();
-    }
-    const int64_t field_offset = table->table_segment_->vec_field_name_executor_pool_idx_map_[fieldName];
-    std::unique_lock<std::mutex> lock(table->executor_pool_mutex_);
-    auto pool = table->executor_pool_.at(field_offset);
-    auto executor = vectordb::engine::execution::RAIIVecSearchExecutor(pool, pool->acquire());
-    lock.unlock();
-    if (nq > 0 && dim != executor.exec_->dimension_) throw std::runtime_error("Query dimension doesn't match the vector field dimension.");
-    if (nq > 0) executor.exec_->SearchBatch(qptr, nq, table->table_segment_.get(), (size_t)std::max(limit, 0), filter_nodes, ids, dist, counts, width);
+    const vectordb::Status st = epsdrop::SearchBatch(*db, db_name, tableName, fieldName, qptr, (int64_t)nq, (int64_t)dim, (int64_t)limit, queryFilter, &hits);
+    if (!st.ok()) throw std::runtime_error(st.message().empty() ? std::string("query_batch failed") : st.message());
   } catch (const std::exception& e) {
     err = e.what();
     if (err.empty()) err = "query_batch failed";
@@ -296,6 +267,11 @@ static PyObject* eps_query_batch(PyObject* self, PyObject* args, PyObject* kwarg
     PyErr_SetString(PyExc_Exception, err.c_str());
     return NULL;
   }
+  std::shared_ptr<vectordb::engine::TableMVP> table = hits.table;
+  std::vector<int64_t>& ids = hits.ids;
+  std::vector<float>& dist = hits.dist;
+  std::vector<int32_t>& counts = hits.counts;
+  const int32_t width = hits.width;
 
   // ---- projection, once for the whole batch
   PyObject* out = PyList_New(nq);

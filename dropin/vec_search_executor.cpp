@@ -77,10 +77,44 @@ struct DeviceField {
   const void* shard_graph_owner = nullptr;   // sharded: the ANNGraphSegment whose per-shard graphs the shards hold (BuildGraphOnMirror)
   int64_t shard_graph_n = -1;
   std::vector<uint8_t> mask;       // scratch: deleted | !filter, for filters evaluated on the host
+  std::vector<int32_t> devices;    // the device list the mirror was created on (a rebuild's side copy lives on the same devices)
+  // A rebuild works on a SIDE index (a device copy of rows [0, n), eps_index_clone_rows) while this one keeps serving; the finished
+  // index waits here until the first search of the NEW segment's executors adopts it (BuildGraphOnMirror / Adopt below).
+  eps_index* pending_h = nullptr;
+  const void* pending_owner = nullptr;
+  int64_t pending_n = -1;
+  const void* retired_owner = nullptr;   // the segment whose graph the adopted index replaced: its last executors run on the new graph
   ~DeviceField() {
     if (h) eps_index_destroy(h);
+    if (pending_h) eps_index_destroy(pending_h);
   }
 };
+
+// dev.mu held.  A search of the segment `owner` arrives: if the rebuild that produced that segment left its index waiting, it becomes
+// the serving index now - the rows appended since the build's snapshot are added from the host column (only they cross PCIe), the
+// old index is released.  Returns an error text or "".
+static std::string AdoptPendingBuild(DeviceField& dev, const void* owner, int64_t dim) {
+  if (!dev.pending_h || dev.pending_owner != owner) return "";
+  if (dev.attached > dev.pending_n) {
+    if (eps_index_append_rows(dev.pending_h, dev.column + dev.pending_n * dim, dev.attached - dev.pending_n) != EPS_OK)
+      return std::string("gfx950 executor: row upload (adopting the rebuilt index): ") + eps_index_last_error(dev.pending_h);
+  }
+  eps_index* old = dev.h;
+  dev.h = dev.pending_h;
+  dev.pending_h = nullptr;
+  dev.retired_owner = dev.sharded ? dev.shard_graph_owner : dev.graph_owner;
+  if (dev.sharded) {
+    dev.shard_graph_owner = owner;
+    dev.shard_graph_n = dev.pending_n;
+  } else {
+    dev.graph_owner = owner;
+    dev.graph_n = dev.pending_n;
+  }
+  dev.pending_owner = nullptr;
+  dev.pending_n = -1;
+  eps_index_destroy(old);
+  return "";
+}
 
 namespace {
 std::mutex g_mu;
@@ -109,10 +143,12 @@ std::shared_ptr<DeviceField> AcquireField(const float* column, int64_t dim, int 
       p = *end == ',' ? end + 1 : end;
     }
   }
+  if (devices.empty()) devices.push_back(0);
+  sp->devices = devices;
   if (devices.size() > 1) {
     if (eps_index_create_sharded(dim, metric, devices.data(), (int32_t)devices.size(), &sp->h) != EPS_OK) return nullptr;
     sp->sharded = true;
-  } else if (eps_index_create(dim, metric, devices.empty() ? 0 : devices[0], &sp->h) != EPS_OK) {
+  } else if (eps_index_create(dim, metric, devices[0], &sp->h) != EPS_OK) {
     return nullptr;  // no gfx950 device: Search() reports it
   }
   g_fields[key] = sp;
@@ -303,7 +339,13 @@ Status VecSearchExecutor::Search(const VectorPtr query_data, vectordb::engine::T
     if (rc != EPS_OK) return fail("row upload");
     dev.attached = total_vector;
   }
-  if (!dev.sharded && (dev.graph_owner != ann_index_.get() || dev.graph_n != total_indexed_vector_)) {
+  {
+    const std::string aerr = AdoptPendingBuild(dev, ann_index_.get(), dimension_);
+    if (!aerr.empty()) throw std::runtime_error(aerr);
+  }
+  // (an executor of the segment a rebuild just replaced finishes on the new graph: uploading its old CSR again would only be undone by
+  // the next search of the new segment)
+  if (!dev.sharded && ann_index_.get() != dev.retired_owner && (dev.graph_owner != ann_index_.get() || dev.graph_n != total_indexed_vector_)) {
     if (eps_index_set_graph(dev.h, total_indexed_vector_, offset_table_, neighbor_list_, start_search_point_) != EPS_OK)
       return fail("graph upload");
     dev.graph_owner = ann_index_.get();
@@ -499,7 +541,8 @@ std::string RunSearch(DeviceField& dev, int64_t dim, const Pending& h, const flo
                                          : eps_index_append_rows(dev.h, dev.column + dev.attached * dim, total_vector - dev.attached);
     if (rc != EPS_OK) fail("row upload"); else dev.attached = total_vector;
   }
-  if (err.empty() && !dev.sharded && (dev.graph_owner != h.graph_owner || dev.graph_n != h.graph_n)) {
+  if (err.empty()) err = AdoptPendingBuild(dev, h.graph_owner, dim);
+  if (err.empty() && !dev.sharded && h.graph_owner != dev.retired_owner && (dev.graph_owner != h.graph_owner || dev.graph_n != h.graph_n)) {
     if (eps_index_set_graph(dev.h, h.graph_n, h.off, h.nbr, h.start_point) != EPS_OK) fail("graph upload");
     else { dev.graph_owner = h.graph_owner; dev.graph_n = h.graph_n; }
   }
@@ -742,33 +785,86 @@ std::string epsdrop::BuildGraphOnMirror(const float* column, int64_t n, int64_t 
   std::shared_ptr<DeviceField> devp = vectordb::engine::execution::AcquireFieldForBuild(column, dim, metric);
   if (!devp) return "no usable gfx950 device (libepsilla_gfx950 has no CPU fallback)";
   DeviceField& dev = *devp;
-  std::lock_guard<std::mutex> lk(dev.mu);
-  auto fail = [&](const char* what) { return std::string(what) + ": " + eps_index_last_error(dev.h); };
-  if (n > dev.attached) {   // only the rows the mirror does not hold yet cross PCIe
-    const int32_t rc = dev.attached == 0 ? eps_index_attach_rows(dev.h, column, n) : eps_index_append_rows(dev.h, column + dev.attached * dim, n - dev.attached);
-    if (rc != EPS_OK) return fail("row upload");
-    dev.attached = n;
+  // The build must not hold the field's serving lock (at 10M rows eps_index_build is minutes, and every Search / RunSearch
+  // of the field takes dev.mu): under the lock only the rows the mirror does not hold yet are uploaded and rows [0, n) are copied
+  // device to device into a SIDE index (eps_index_clone_rows: 30 GB in ~10 ms); the build then runs on that copy while the old index
+  // and the old graph keep serving - what the reference's Rebuild does with its snapshot of rows [0, n) (table_mvp.cpp:133-195).
+  // The finished index is adopted by the first search of the new segment's executors (AdoptPendingBuild).  If the copy does not fit
+  // (tables beyond half of the HBM) the build runs in place under the lock, as in r3.
+  eps_index* side = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(dev.mu);
+    auto fail = [&](const char* what) { return std::string(what) + ": " + eps_index_last_error(dev.h); };
+    if (n > dev.attached) {   // only the rows the mirror does not hold yet cross PCIe
+      const int32_t rc = dev.attached == 0 ? eps_index_attach_rows(dev.h, column, n) : eps_index_append_rows(dev.h, column + dev.attached * dim, n - dev.attached);
+      if (rc != EPS_OK) return fail("row upload");
+      dev.attached = n;
+    }
+    static const bool in_place = getenv("EPS_DROPIN_BUILD_IN_PLACE") && atoi(getenv("EPS_DROPIN_BUILD_IN_PLACE")) != 0;
+    if (!in_place) {
+      const int32_t rc = dev.sharded ? eps_index_create_sharded(dim, metric, dev.devices.data(), (int32_t)dev.devices.size(), &side)
+                                     : eps_index_create(dim, metric, dev.devices[0], &side);
+      if (rc != EPS_OK) side = nullptr;
+      if (side && eps_index_clone_rows(side, dev.h, n) != EPS_OK) {   // (no room for a second copy of the rows)
+        eps_index_destroy(side);
+        side = nullptr;
+      }
+    }
+    if (!side) {   // in place, holding the lock (r3 behaviour)
+      if (eps_index_build(dev.h, n, nullptr) != EPS_OK) return fail("build");   // defaults = NSGConfig(45,50,300,100)
+      if (dev.sharded) {
+        *off = new int64_t[n + 1]();
+        *nbr = new int64_t[1]();
+        *nav = 0;
+        dev.shard_graph_owner = owner;
+        dev.shard_graph_n = n;
+      } else {
+        int64_t gn = 0, edges = 0;
+        eps_index_graph_info(dev.h, &gn, &edges, nav);
+        *off = new int64_t[gn + 1];
+        *nbr = new int64_t[edges > 0 ? edges : 1];
+        if (eps_index_get_graph(dev.h, *off, *nbr) != EPS_OK) {
+          delete[] *off;
+          delete[] *nbr;
+          *off = *nbr = nullptr;
+          return fail("get_graph");
+        }
+        dev.graph_owner = owner;   // the device index already holds this graph: the segment's executors need not upload it again
+        dev.graph_n = n;
+      }
+      *keep = devp;
+      return "";
+    }
   }
-  if (eps_index_build(dev.h, n, nullptr) != EPS_OK) return fail("build");   // defaults = NSGConfig(45,50,300,100)
+  // ---- the build itself: on the side index, nobody waits for it
+  auto sfail = [&](const char* what) {
+    const std::string e = std::string(what) + ": " + eps_index_last_error(side);
+    eps_index_destroy(side);
+    return e;
+  };
+  if (eps_index_build(side, n, nullptr) != EPS_OK) return sfail("build");
   if (dev.sharded) {
     *off = new int64_t[n + 1]();
     *nbr = new int64_t[1]();
     *nav = 0;
-    dev.shard_graph_owner = owner;
-    dev.shard_graph_n = n;
   } else {
     int64_t gn = 0, edges = 0;
-    eps_index_graph_info(dev.h, &gn, &edges, nav);
+    eps_index_graph_info(side, &gn, &edges, nav);
     *off = new int64_t[gn + 1];
     *nbr = new int64_t[edges > 0 ? edges : 1];
-    if (eps_index_get_graph(dev.h, *off, *nbr) != EPS_OK) {
+    if (eps_index_get_graph(side, *off, *nbr) != EPS_OK) {
       delete[] *off;
       delete[] *nbr;
       *off = *nbr = nullptr;
-      return fail("get_graph");
+      return sfail("get_graph");
     }
-    dev.graph_owner = owner;   // the device index already holds this graph: the segment's executors need not upload it again
-    dev.graph_n = n;
+  }
+  {
+    std::lock_guard<std::mutex> lk(dev.mu);
+    if (dev.pending_h) eps_index_destroy(dev.pending_h);   // (a build whose segment was never searched)
+    dev.pending_h = side;
+    dev.pending_owner = owner;
+    dev.pending_n = n;
   }
   *keep = devp;
   return "";

@@ -203,6 +203,11 @@ int32_t eps_index_append_rows(eps_index* h, const float* rows, int64_t n_new);
  * split of that sum (shard s holds ceil((n - s) / shards) rows) or searches and builds fail with EPS_USER_ERROR.  On a plain index
  * shard 0 is the index itself.  (r4; replaces what TableSegmentMVP::vector_tables_ is for one GPU, table_segment_mvp.hpp:85) */
 int32_t eps_index_attach_shard_rows(eps_index* h, int32_t shard, const float* rows, int64_t n_local);
+/* dst gets its OWN device copy of the first n rows of src - an index of the same kind on the same device(s): plain / plain, or two
+ * shard groups over the same device list - with one device-to-device copy per shard; replaces dst's rows like eps_index_attach_rows.
+ * What TableMVP::Rebuild's snapshot is for the reference (table_mvp.cpp:133-156: the build works on rows [0, n) while inserts and
+ * searches go on): the drop-in builds the new graph on such a copy and swaps it in, so a rebuild never blocks queries (r4). */
+int32_t eps_index_clone_rows(eps_index* dst, eps_index* src, int64_t n);
 int64_t eps_index_row_count(const eps_index* h);
 
 /* On-disk table segment of the reference (`<db>/<table_id>/data_mvp.bin`, TableSegmentMVP::SaveTableSegment,

@@ -363,6 +363,8 @@ class Ref:
         L.ref_db_swap_executors.argtypes = [vp]
         L.ref_db_search.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, fptr, i64, i64, C.c_char_p,
                                     C.c_int, C.c_char_p, i64]
+        if hasattr(L, "ref_db_search_batch"):   # (drop-in build only)
+            L.ref_db_search_batch.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, fptr, i64, i64, i64, C.c_char_p, C.c_int, C.c_char_p, i64]
         L.ref_db_search_mt.restype = C.c_double
         L.ref_db_search_mt.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, fptr, i64, i64, i64, C.c_int, iptr]
         L.ref_db_search_mt_filter.restype = C.c_double
@@ -535,6 +537,15 @@ class Ref:
             buf = C.create_string_buffer(cap)
             rc = self.r.L.ref_db_search(self.h, self.name, table.encode(), field.encode(), ",".join(fields).encode(),
                                         _f(q), len(q), limit, flt.encode(), int(with_distance), buf, cap)
+            txt = buf.value.decode()
+            return rc, (json.loads(txt) if rc == 0 else txt)
+
+        def search_batch(self, table, field, Q, limit, fields=("ID",), flt="", with_distance=True, cap=1 << 26):
+            """epsdrop::SearchBatch through the drop-in library (C++ level): Q.shape[0] vectors, one device batch"""
+            Q = np.ascontiguousarray(Q, np.float32)
+            buf = C.create_string_buffer(cap)
+            rc = self.r.L.ref_db_search_batch(self.h, self.name, table.encode(), field.encode(), ",".join(fields).encode(), _f(Q), Q.shape[0], Q.shape[1],
+                                              limit, flt.encode(), int(with_distance), buf, cap)
             txt = buf.value.decode()
             return rc, (json.loads(txt) if rc == 0 else txt)
 

@@ -408,6 +408,7 @@ double ref_pool_search(void* graph, float* rows, int64_t d, int metric, int E, i
 
 #endif  // !EPS_DROPIN
 #ifdef EPS_DROPIN
+#include "epsdrop/search_batch.hpp"
 extern "C" {
 #endif
 
@@ -492,6 +493,36 @@ int ref_db_search(void* h, const char* db, const char* table, const char* field,
   }
   return st.code();
 }
+
+#ifdef EPS_DROPIN
+// The drop-in's C++-level batched entry (include/epsdrop/search_batch.hpp): nq vectors, ONE device batch; result = JSON array of nq
+// arrays of records.  Only in the drop-in build (the reference has no batched entry to compare with: the test compares it with nq
+// ref_db_search calls on both builds).
+int ref_db_search_batch(void* h, const char* db, const char* table, const char* field, const char* fields_csv, float* q, int64_t nq,
+                        int64_t d, int64_t limit, const char* filter, int with_distance, char* out, int64_t cap) {
+  std::vector<std::string> fields;
+  std::string cur;
+  for (const char* p = fields_csv; *p; ++p) {
+    if (*p == ',') {
+      if (!cur.empty()) fields.push_back(cur);
+      cur.clear();
+    } else {
+      cur.push_back(*p);
+    }
+  }
+  if (!cur.empty()) fields.push_back(cur);
+  vectordb::Json result;
+  vectordb::Status st = epsdrop::SearchBatch(*static_cast<vectordb::engine::DBServer*>(h), db, table, field, fields, q, nq, d, limit, result, filter,
+                                             with_distance != 0);
+  const std::string s = st.ok() ? result.DumpToString() : st.message();
+  if (cap > 0) {
+    size_t n = std::min<size_t>(s.size(), (size_t)cap - 1);
+    memcpy(out, s.data(), n);
+    out[n] = 0;
+  }
+  return st.code();
+}
+#endif
 
 // DBServer::Project (the "get" path: VecSearchExecutor::SearchByAttribute underneath, no vector arithmetic).
 int ref_db_get(void* h, const char* db, const char* table, const char* fields_csv, const char* pk_json, const char* filter,

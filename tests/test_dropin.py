@@ -200,6 +200,63 @@ def test_dropin_matches_reference_dbserver_on_random_data(dropin, tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not ref_available(), reason="needs oracle/_ref")
+def test_cpp_level_batch_entry_equals_single_searches_and_the_reference(dropin, tmp_path):
+    """epsdrop::SearchBatch (include/epsdrop/search_batch.hpp, C++ in libepsilla_dropin.so - what a REST handler of a batched endpoint
+    would call; db_server.cpp:458-510 answers one vector per call): N vectors -> ONE device batch -> a JSON array of N result arrays.
+    Element q equals DBServer::Search of vector q through the same drop-in, and the REFERENCE DBServer's own answer: three metrics
+    (COSINE: queries normalised per vector as table_mvp.cpp:333-343), a device-compiled filter, a host-only (string) filter, deletes,
+    before and after a rebuild; errors carry the reference's Status codes."""
+    ref = Ref()
+    n, d = 1500, 12
+    schema = {"name": "T", "fields": [{"name": "ID", "dataType": "INT", "primaryKey": True}, {"name": "Tag", "dataType": "STRING"},
+                                       {"name": "E", "dataType": "VECTOR_FLOAT", "dimensions": d, "metricType": "EUCLIDEAN"},
+                                       {"name": "C", "dataType": "VECTOR_FLOAT", "dimensions": d, "metricType": "COSINE"},
+                                       {"name": "P", "dataType": "VECTOR_FLOAT", "dimensions": d, "metricType": "DOT_PRODUCT"}]}
+    X = data(n, d, 41)
+    recs = [{"ID": int(i), "Tag": "t%d" % (i % 5), "E": [float(x) for x in X[i]], "C": [float(x) for x in X[i]], "P": [float(x) for x in X[i]]} for i in range(n)]
+    Q = data(9, d, 42) * 2.0
+    dbs = []
+    for lib, name in ((ref, "ref"), (dropin, "drop")):
+        lib.L.ref_config(1, 500, 1, 0, 2)
+        db = lib.db(str(tmp_path / name))
+        assert db.create_table(schema) == 0 and db.insert("T", recs) == 0 and db.delete("T", [3, 4, 700]) == 0
+        dbs.append(db)
+    rdb, ddb = dbs
+
+    def check(tag):
+        for field in ("E", "C", "P"):
+            for flt, limit in (("", 10), ("ID >= 300 AND ID < 1200", 7), ("Tag = 't2'", 5)):
+                rc, batch = ddb.search_batch("T", field, Q, limit, fields=("ID", "Tag"), flt=flt)
+                assert rc == 0 and len(batch) == len(Q), (tag, field, flt, batch)
+                for qi, q in enumerate(Q):
+                    rc1, one = ddb.search("T", field, q, limit, fields=("ID", "Tag"), flt=flt)
+                    rc2, want = rdb.search("T", field, q, limit, fields=("ID", "Tag"), flt=flt)
+                    assert rc1 == 0 and rc2 == 0
+                    assert [r["ID"] for r in batch[qi]] == [r["ID"] for r in one] == [r["ID"] for r in want], (tag, field, flt, qi)
+                    assert [r["Tag"] for r in batch[qi]] == [r["Tag"] for r in want]
+                    assert np.allclose([r["@distance"] for r in batch[qi]], [r["@distance"] for r in want], rtol=1e-4, atol=1e-6)
+    check("flat")
+    for db in dbs:
+        assert db.rebuild() == 0
+    check("graph")       # (1500 rows, SearchQueueSize 500: both graphs are exact here)
+    # the only vector field is resolved when the name is empty - not here (three fields): the reference's error, its code
+    rc, msg = ddb.search_batch("T", "", Q, 5)
+    assert rc != 0 and "queryField" in msg
+    rc, msg = ddb.search_batch("T", "E", Q, 5, flt="NoSuchField > 3")
+    rc2, msg2 = rdb.search("T", "E", Q[0], 5, flt="NoSuchField > 3")
+    assert rc == rc2 != 0
+    rc, msg = ddb.search_batch("Nope", "E", Q, 5)
+    assert rc != 0 and "Table not found" in msg
+    rc, msg = ddb.search_batch("T", "E", Q[:, :5], 5)
+    assert rc != 0 and "dimension" in msg
+    for db in dbs:
+        db.close()
+    ref.L.ref_config(4, 500, 1, 0, 16)
+    dropin.L.ref_config(4, 500, 1, 0, 16)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not ref_available(), reason="needs oracle/_ref")
 def test_concurrent_clients_are_micro_batched_and_match_reference(dropin, tmp_path):
     """16 client threads issuing single-vector DBServer::Search calls (what concurrent REST requests do): the drop-in
     coalesces them into device batches; every answer must equal the reference DBServer's answer to the same query,

@@ -126,12 +126,22 @@ int32_t Index::synchronize() {
 int32_t Index::attach_rows(const float* rows, int64_t n) { return attach_rows_strided(rows, n, dim_); }
 int32_t Index::append_rows(const float* rows, int64_t n_new) { return append_rows_strided(rows, n_new, dim_); }
 
-int32_t Index::attach_rows_strided(const float* rows, int64_t n, int64_t pitch) {
+int32_t Index::clone_rows(IndexBase& src_base, int64_t n) {
+  Index* src = dynamic_cast<Index*>(&src_base);
+  if (!src || src == this) return fail(EPS_USER_ERROR, "clone_rows: the source must be another plain index");
+  if (src->dim_ != dim_ || src->device_ != device_) return fail(EPS_USER_ERROR, "clone_rows: source and destination differ in dimension or device");
+  if (n < 0 || n > src->n_rows_) return fail(EPS_USER_ERROR, "clone_rows: n exceeds the source's rows");
+  HIP_TRY(hipSetDevice(device_));
+  HIP_TRY(hipStreamSynchronize(src->stream_));   // (the source's rows are complete)
+  return attach_rows_strided(src->d_rows_, n, dim_, true);
+}
+
+int32_t Index::attach_rows_strided(const float* rows, int64_t n, int64_t pitch, bool copy_device_rows) {
   if (n < 0 || (n > 0 && !rows) || pitch < dim_) return fail(EPS_USER_ERROR, "attach_rows: bad arguments");
   if (n >= (int64_t)1 << 31) return fail(EPS_DB_UNSUPPORTED_ERROR, "attach_rows: more than 2^31-1 rows per index (shard first)");
   HIP_TRY(hipSetDevice(device_));
   HIP_TRY(hipStreamSynchronize(stream_));
-  if (is_device_ptr(rows) && pitch == dim_) {
+  if (is_device_ptr(rows) && pitch == dim_ && !copy_device_rows) {
     rows_buf_.release();
     d_rows_ = rows;
     rows_owned_ = false;
@@ -908,6 +918,10 @@ int32_t eps_index_synchronize(eps_index* h) { GUARD(h, IX(h)->synchronize()); }
 int32_t eps_index_attach_rows(eps_index* h, const float* rows, int64_t n) { GUARD(h, IX(h)->attach_rows(rows, n)); }
 int32_t eps_index_append_rows(eps_index* h, const float* rows, int64_t n) { GUARD(h, IX(h)->append_rows(rows, n)); }
 int32_t eps_index_attach_shard_rows(eps_index* h, int32_t shard, const float* rows, int64_t n_local) { GUARD(h, IX(h)->attach_shard_rows(shard, rows, n_local)); }
+int32_t eps_index_clone_rows(eps_index* dst, eps_index* src, int64_t n) {
+  if (!src) return EPS_USER_ERROR;
+  GUARD(dst, IX(dst)->clone_rows(*IX(src), n));
+}
 int64_t eps_index_row_count(const eps_index* h) { return h ? CIX(h)->row_count() : -1; }
 int32_t eps_index_set_id_map(eps_index* h, int64_t b, int64_t s) { GUARD(h, IX(h)->set_id_map(b, s)); }
 int32_t eps_index_set_deleted(eps_index* h, const uint8_t* bits, int64_t nbytes) { GUARD(h, IX(h)->set_deleted(bits, nbytes)); }

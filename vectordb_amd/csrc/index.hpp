@@ -48,6 +48,9 @@ class IndexBase {
   virtual int32_t append_rows(const float* rows, int64_t n_new) = 0;
   // rows of one shard of a hash-sharded index (local row l = global row l * shards + shard); a plain index is its own shard 0
   virtual int32_t attach_shard_rows(int32_t shard, const float* rows, int64_t n_local) = 0;
+  // an OWNED device copy of the first n rows of `src` (an index of the same kind on the same device(s)): what a build on the side
+  // works on while `src` keeps serving and growing
+  virtual int32_t clone_rows(IndexBase& src, int64_t n) = 0;
   virtual int32_t set_id_map(int64_t base, int64_t stride) = 0;
   virtual int32_t set_deleted(const uint8_t* bits, int64_t nbytes) = 0;
   virtual int32_t set_int_filter(const void* column, int64_t stride, int32_t width, int32_t op, int64_t constant) = 0;
@@ -84,8 +87,10 @@ class Index : public IndexBase {
     if (shard != 0) return fail(EPS_USER_ERROR, "attach_shard_rows: not a sharded index (only shard 0 exists)");
     return attach_rows(rows, n_local);
   }
+  int32_t clone_rows(IndexBase& src, int64_t n) override;
+  const float* device_rows() const { return d_rows_; }
   // rows of a strided host table: row i at rows + i*pitch_floats (hash-sharded tables: pitch = shards*dim)
-  int32_t attach_rows_strided(const float* rows, int64_t n, int64_t pitch_floats);
+  int32_t attach_rows_strided(const float* rows, int64_t n, int64_t pitch_floats, bool copy_device_rows = false);
   int32_t append_rows_strided(const float* rows, int64_t n_new, int64_t pitch_floats);
   int32_t append_rows(const float* rows, int64_t n_new) override;
   int32_t set_id_map(int64_t base, int64_t stride) override;

@@ -112,7 +112,7 @@ template <> struct V7Op<true> {
 #define EPS_V7_VI 7
 #endif
 #ifndef EPS_V7_TILE
-#define EPS_V7_TILE (EPS_V7_VI > 0)   // tile-level epilogue test (see the kernel): only with VGPR-form accumulators
+#define EPS_V7_TILE 0   // tile-level epilogue test (see the kernel; measured 1.5 % slower than the per-block form, profiles/r4_epilogue_ablation.txt): lab switch, needs EPS_V7_VI > 0
 #endif
 #if EPS_V7_VI > 0
 #define EPS_FRAG_C "=a"
@@ -893,7 +893,15 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
         asm volatile("" ::"v"(mx));   // lab ablation: maxima computed, never compared (what compare + branch + hit path cost)
         continue;
 #endif
+#if defined(EPS_V7_ABL) && (EPS_V7_ABL & 8)
+        if (__any(mx >= Tq[j])) asm volatile("s_nop 0");   // lab ablation: compare + branch, empty hit path (what the 16 branch pairs cost)
+        continue;
+#endif
+#if defined(EPS_V7_ABL) && (EPS_V7_ABL & 16)
+        if (__any(mx >= Tq[j]) && a.ablate) {   // lab ablation: the hit code is all there (code size, branches) and never runs (a.ablate == 0)
+#else
         if (__any(mx >= Tq[j])) {
+#endif
           // (rare) everything the hit path needs is derived behind this opaque copy of the lane id, or hipcc hoists the
           // address arithmetic of all 16 blocks into the common path
           int l31h = l31e, rbh = rbase;

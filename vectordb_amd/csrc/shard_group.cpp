@@ -151,6 +151,19 @@ class ShardGroup : public IndexBase {
     for (int64_t v : shard_rows_) n_rows_ += v;
     return EPS_OK;
   }
+  int32_t clone_rows(IndexBase& src_base, int64_t n) override {
+    ShardGroup* src = dynamic_cast<ShardGroup*>(&src_base);
+    if (!src || src == this || src->G() != G() || src->dim_ != dim_) return fail(EPS_USER_ERROR, "clone_rows: the source must be another shard group of the same shape");
+    for (int s = 0; s < G(); ++s)
+      if (src->shard_[(size_t)s]->device_ != shard_[(size_t)s]->device_) return fail(EPS_USER_ERROR, "clone_rows: the groups' shards live on different devices");
+    if (n < 0 || n > src->n_rows_ || !src->split_ok()) return fail(EPS_USER_ERROR, "clone_rows: n exceeds the source's rows");
+    const int32_t rc = each([&](int s, Index& ix) { return ix.clone_rows(*src->shard_[(size_t)s], rows_of(s, n)); });
+    if (rc == EPS_OK) {
+      n_rows_ = n;
+      for (int s = 0; s < G(); ++s) shard_rows_[(size_t)s] = rows_of(s, n);
+    }
+    return rc;
+  }
   bool split_ok() const {   // the shards hold a hash split of n_rows_ rows (attach_shard_rows fills them one at a time)
     for (int s = 0; s < G(); ++s)
       if (shard_rows_[(size_t)s] != rows_of(s, n_rows_)) return false;
