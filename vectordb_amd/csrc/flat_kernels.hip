@@ -142,7 +142,8 @@ void launch_flat_scan(const FlatScanArgs& a, hipStream_t s) {
 // One block per query.
 template <int KPL>
 __global__ __launch_bounds__(256) void merge_lists_kernel(const u64* partial, int lists, int k, u64* run_keys,
-                                                          int merge_run, const u32* counts, FilterSpec vis, u64 id_stride, u32 id_head) {
+                                                          int merge_run, const u32* counts, FilterSpec vis, u64 id_stride, u32 id_head,
+                                                          u32* seed_cand, int seed_cap, u32* seed_cnt) {
   __shared__ u64 sh[4][KPL * 64];
   const int64_t q = blockIdx.x;
   const int lane = lane_id();
@@ -179,18 +180,34 @@ __global__ __launch_bounds__(256) void merge_lists_kernel(const u64* partial, in
         offer<1, KPL>(L, thr, 0, key, key != KEY_EMPTY, nof, k, false);
       }
     }
-    L[0].store(run_keys + q * k, k);
+    if (seed_cand) {   // the k best seeds' rows -> the query's candidate list; run_keys stays empty (the re-rank fills it with exact keys)
+      int c = 0;
+#pragma unroll
+      for (int r = 0; r < KPL; ++r) {
+        const int e = r * 64 + lane;
+        const u64 key = L[0].key[r];
+        const bool ok = e < k && key != KEY_EMPTY;
+        const unsigned long long m = __ballot(ok);
+        if (ok) seed_cand[q * (int64_t)seed_cap + c + __popcll(m & ((1ull << lane) - 1ull))] = id_stride ? seed_row(key_id(key), id_head, id_stride) : key_id(key);
+        c += __popcll(m);
+        if (e < k) run_keys[q * k + e] = KEY_EMPTY;
+      }
+      if (lane == 0) seed_cnt[q] = (u32)c;
+    } else {
+      L[0].store(run_keys + q * k, k);
+    }
   }
 }
 
 void launch_merge_lists(const u64* partial, int lists, int k, int64_t nq, u64* run_keys, bool merge_run, hipStream_t s,
-                        const u32* counts, const FilterSpec* visible, u64 id_stride, u32 id_head) {
+                        const u32* counts, const FilterSpec* visible, u64 id_stride, u32 id_head, u32* seed_cand, int seed_cap, u32* seed_cnt) {
   const FilterSpec vis = visible ? *visible : no_filter();
   if (nq <= 0) return;
   const int kpl = pick_kpl(k);
 #define EPS_CASE(KPL_) \
   if (kpl == KPL_) {   \
-    hipLaunchKernelGGL((merge_lists_kernel<KPL_>), dim3((unsigned)nq), dim3(256), 0, s, partial, lists, k, run_keys, merge_run ? 1 : 0, counts, vis, id_stride, id_head); \
+    hipLaunchKernelGGL((merge_lists_kernel<KPL_>), dim3((unsigned)nq), dim3(256), 0, s, partial, lists, k, run_keys, merge_run ? 1 : 0, counts, vis, id_stride, id_head, \
+                       seed_cand, seed_cap, seed_cnt);                                                                                                  \
     return;            \
   }
   EPS_CASE(1) EPS_CASE(2) EPS_CASE(4) EPS_CASE(8) EPS_CASE(16)
@@ -262,6 +279,21 @@ __global__ __launch_bounds__(NW * 64) void rerank_kernel(RerankArgs a) {
       }
     }
     L[0].store(a.run_keys + q * a.k, a.k);
+    if (a.fin_ids) {   // the call's last re-rank: the caller-visible result of this query (finalize_kernel's arithmetic)
+      int c = 0;
+#pragma unroll
+      for (int r = 0; r < KPL; ++r) {
+        const int e = r * 64 + lane;
+        const u64 key = L[0].key[r];
+        const bool valid = e < a.k && key != KEY_EMPTY;
+        if (e < a.k) {
+          a.fin_ids[q * a.k + e] = valid ? (int64_t)key_id(key) * a.fin_stride + a.fin_base : -1;
+          a.fin_dist[q * a.k + e] = valid ? key_dist(key) : __builtin_inff();
+        }
+        c += __popcll(__ballot(valid));
+      }
+      if (a.fin_counts && lane == 0) a.fin_counts[q] = c;
+    }
     if (a.fuse) {
       const u64 kth = L[0].entry(a.k - 1);   // (wave-uniform)
       if (lane == 0) {

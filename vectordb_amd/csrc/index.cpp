@@ -739,10 +739,16 @@ int32_t Index::search(const float* queries, int64_t nq, int32_t k, const eps_sea
           ~PreSyncGuard() {
             ix.pre_sync_ = nullptr;
             ix.pre_sync_nq_ = -1;
+            ix.fin_ids_ = nullptr;
+            ix.fin_dist_ = nullptr;
+            ix.fin_cnt_ = nullptr;
           }
         } guard{*this};
         pre_sync_ = finalize;
         pre_sync_nq_ = nq;
+        fin_ids_ = d_ids;
+        fin_dist_ = d_dist;
+        fin_cnt_ = d_cnt;
         rc = flat_mfma_search(*this, dq, nq, k, run_keys, false, bits);
       } else {
         rc = flat_stream(dq, nq, k, 0, n_rows_, run_keys, false);

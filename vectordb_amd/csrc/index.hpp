@@ -186,6 +186,10 @@ class Index : public IndexBase {
   std::function<void()> pre_sync_;
   bool result_finalized_ = false;   // the conversion has run on the CURRENT contents of the result keys (an engine that rewrites them clears it)
   int64_t pre_sync_nq_ = -1;   // queries of the call that set it (a batch run in slices converts after the last slice instead)
+  // ... and where that conversion writes: the matrix engine's last re-rank does it itself (RerankArgs::fin_*) instead of a launch
+  int64_t* fin_ids_ = nullptr;
+  float* fin_dist_ = nullptr;
+  int32_t* fin_cnt_ = nullptr;
 
  private:
   int32_t flat_stream(const float* dq, int64_t nq, int k, int64_t row_begin, int64_t row_end, u64* run_keys,

@@ -30,8 +30,11 @@ void launch_flat_scan(const FlatScanArgs& a, hipStream_t s);
 
 // merge the `slots` keys of each query (plus, if merge_run, the existing run_keys[q][k]) into run_keys[q][k].
 // counts (optional): per-query number of valid keys at the front of its slots (candidate lists).
+// seed_cand != null (the MFMA engine's seed stage, r4): instead of the k best keys, their ROWS go to seed_cand[q][0 .. count) (sample
+// indices mapped by seed_row), seed_cnt[q] = count and run_keys[q] is left EMPTY - what seed_to_cand_kernel did in a launch of its own
 void launch_merge_lists(const u64* keys, int slots, int k, int64_t nq, u64* run_keys, bool merge_run, hipStream_t s,
-                        const u32* counts = nullptr, const FilterSpec* visible = nullptr, u64 id_stride = 0, u32 id_head = 0);
+                        const u32* counts = nullptr, const FilterSpec* visible = nullptr, u64 id_stride = 0, u32 id_head = 0,
+                        u32* seed_cand = nullptr, int seed_cap = 0, u32* seed_cnt = nullptr);
 
 // exact fp32 re-rank of gathered candidate rows into run_keys (sorted, unique)
 struct RerankArgs {
@@ -59,6 +62,12 @@ struct RerankArgs {
   int bits;                 // 8 | 16
   float u, slack;
   u32* gsync;               // [256] or null
+  // the call's LAST re-rank also converts the result keys (ids = local * stride + base, distances, counts): finalize_kernel's work
+  // without its launch (r4: a single-query call is a chain of short dependent launches); fin_ids == null: not this launch
+  int64_t* fin_ids = nullptr;
+  float* fin_dist = nullptr;
+  int32_t* fin_counts = nullptr;
+  int64_t fin_base = 0, fin_stride = 1;
 };
 void launch_rerank(const RerankArgs& a, hipStream_t s);
 

@@ -71,6 +71,7 @@ struct HalfMirror {
   DevBuf T;        // float [b_pad]
   DevBuf cand;     // u32 [b][cap]
   DevBuf cnt;      // u32 [b] + overflow counter at [b]
+  DevBuf seedc;    // u32 [b][k]: rows of the k best seeds of every query (the seed stage's candidate lists)
   // 8-bit mirror (first-pass operand of the filter, see above)
   DevBuf x8;       // int8 [n_pad8][d_pad8]
   DevBuf acc0;     // int32 [n_pad8]: accumulator start of every row = ceil(-R/u) + 1 (-2^30 on padding rows)
@@ -402,14 +403,39 @@ __global__ __launch_bounds__(256) void quant_mirror_kernel(const float* rows, in
 
 // queries on the table's grid.  qstat[r] = |q|^2, |q'|, |q' - qh'|, C[q] (the constant that turns u-scaled accumulators into
 // approximate distances: dist ~ a.s * acc + qstat[3]);  q' = q - mu;  C = |q'|^2 (L2), 1 - q.mu (COSINE), -q.mu (DOT)
+// (r4) what the flat engine used to do in two more launches of its own, for calls that are a chain of short dependent launches (one
+// query: every launch is ~5 us of latency): the fragment-major copy of the query operand the v7 kernel reads (pack_qf_kernel) and the
+// start state of a seeded call (seed_prologue_kernel).  All-null: plain query_prep8 (the traversal's prefilter).
+struct Prep8Extra {
+  signed char* qf = nullptr;   // fragment-major copy: [b_pad/32][d_pad8/32][64 lanes][16 bytes]
+  u64* T2 = nullptr;           // prologue: thresholds (pairs), n2 entries, value Tv
+  int64_t n2 = 0;
+  u64 Tv = 0;
+  u32* cnt = nullptr;          // prologue: cnt[0 .. nq) = cntv, cnt[nq .. nq + 8) = 0
+  u32 cntv = 0;
+  u32* gsync = nullptr;        // prologue: 256 group counters = 0
+};
 __global__ __launch_bounds__(256) void query_prep8_kernel(const float* q, int64_t nq, int64_t b_pad, int dim, int d_pad8, const float* mu, float step, float inv_step,
-                                                          int metric, signed char* q8, float* qstat) {
+                                                          int metric, signed char* q8, float* qstat, Prep8Extra x) {
+  if (blockIdx.x == 0) {   // the seeded call's start state (nothing in this launch reads it)
+    for (int64_t i = threadIdx.x; x.T2 && i < x.n2; i += 256) x.T2[i] = x.Tv;
+    for (int64_t i = threadIdx.x; x.cnt && i < nq + 8; i += 256) x.cnt[i] = i < nq ? x.cntv : 0u;
+    if (x.gsync) x.gsync[threadIdx.x] = 0;
+  }
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= b_pad) return;
   const int lane = lane_id();
   signed char* dst = q8 + r * d_pad8;
+  // where byte column c of row r lives in the fragment-major copy
+  const int64_t fbase = x.qf ? ((r >> 5) * (int64_t)(d_pad8 >> 5)) * 1024 + (r & 31) * 16 : 0;
+  auto fput = [&](int c, u32 v) {
+    if (x.qf) *reinterpret_cast<u32*>(x.qf + fbase + (int64_t)(c >> 5) * 1024 + ((c >> 4) & 1) * 512 + (c & 15)) = v;
+  };
   if (r >= nq) {
-    for (int c = lane * 4; c < d_pad8; c += 256) *reinterpret_cast<u32*>(dst + c) = 0u;
+    for (int c = lane * 4; c < d_pad8; c += 256) {
+      *reinterpret_cast<u32*>(dst + c) = 0u;
+      fput(c, 0u);
+    }
     if (lane == 0) qstat[r * 4 + 0] = qstat[r * 4 + 1] = qstat[r * 4 + 2] = qstat[r * 4 + 3] = 0.f;
     return;
   }
@@ -420,19 +446,20 @@ __global__ __launch_bounds__(256) void query_prep8_kernel(const float* q, int64_
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       if (c + e < dim) {
-        const float x = src[c + e];
+        const float xv = src[c + e];
         const float m = mu[c + e];
-        const float dx = x - m;
+        const float dx = xv - m;
         const int qi = quant8(dx, 0.f, inv_step);
         const float res = fmaf(-step, (float)qi, dx);
         packed |= (u32)(qi & 255) << (8 * e);
-        s2 = fmaf(x, x, s2);
+        s2 = fmaf(xv, xv, s2);
         c2 = fmaf(dx, dx, c2);
         e2 = fmaf(res, res, e2);
-        qm = fmaf(x, m, qm);
+        qm = fmaf(xv, m, qm);
       }
     }
     *reinterpret_cast<u32*>(dst + c) = packed;
+    fput(c, packed);
   }
   for (int o = 32; o > 0; o >>= 1) {
     s2 += __shfl_xor(s2, o);
@@ -694,7 +721,7 @@ int32_t quant8_view(Index& ix, Quant8View* v) {
 // nq queries on the mirror's grid: q8 [nq][d_pad8], qstat [nq][4] (device buffers of the caller)
 void quant8_queries(Index& ix, const Quant8View& v, const float* dq, int64_t nq, signed char* q8, float* qstat) {
   hipLaunchKernelGGL(query_prep8_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, ix.stream_, dq, nq, nq, (int)ix.dim_, v.d_pad8, v.mu, v.step,
-                     1.f / v.step, ix.metric_, q8, qstat);
+                     1.f / v.step, ix.metric_, q8, qstat, Prep8Extra());
 }
 
 bool flat_mfma_profitable(const Index& ix, int64_t nq, int k) {
@@ -749,23 +776,43 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   const int d_pad_h = i8 ? m.d_pad8 / 2 : m.d_pad;      // row pitch of the operand in 2-byte units (what the kernels count in)
   const float u8 = (ix.metric_ == 0 ? 2.f : 1.f) * m.step8 * m.step8;   // key units per accumulator unit of the 8-bit pass
   if (!m.qstat.reserve((size_t)b_pad * 16) || !m.T.reserve((size_t)b_pad * 4) || !m.cand.reserve((size_t)nq * cap * 8) ||
-      !m.cnt.reserve((size_t)(nq + 4) * 4 + 16) || !(i8 ? m.q8.reserve((size_t)b_pad * m.d_pad8) : m.qh.reserve((size_t)b_pad * m.d_pad * 2)))
+      !m.cnt.reserve((size_t)(nq + 4) * 4 + 16) || !m.seedc.reserve((size_t)nq * k * 4) || !(i8 ? m.q8.reserve((size_t)b_pad * m.d_pad8) : m.qh.reserve((size_t)b_pad * m.d_pad * 2)))
     return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory (scratch)");
-  if (i8)
-    hipLaunchKernelGGL(query_prep8_kernel, dim3((unsigned)((b_pad + 3) / 4)), dim3(256), 0, s, dq, nq, b_pad, (int)ix.dim_, m.d_pad8, m.mu8.as<float>(), m.step8,
-                       1.f / m.step8, ix.metric_, m.q8.as<signed char>(), m.qstat.as<float>());
-  else
-    hipLaunchKernelGGL(query_prep_kernel, dim3((unsigned)((b_pad + 3) / 4)), dim3(256), 0, s, dq, nq, b_pad, (int)ix.dim_,
-                       m.d_pad, m.qh.as<_Float16>(), m.qstat.as<float>(), m.drop);
-  const _Float16* q_op = i8 ? reinterpret_cast<const _Float16*>(m.q8.p) : m.qh.as<_Float16>();   // the query operand, row-major
   // kernel choice: v5 / v7 want K-steps in pairs (d_pad % 128 == 0, >= 256); other shapes stay on v3
   const char* ver_s = getenv("EPS_MFMA_KERNEL");   // 3 | 7 (A/B); v7 needs K-steps in pairs, other shapes stay on v3
   const int version_env = (ver_s && atoi(ver_s) == 3 && !i8) ? 3 : 7;
   const int version = (version_env == 7 && (d_pad_h % 128 != 0 || d_pad_h < 256)) ? 3 : version_env;   // (the 8-bit mirror is padded for v7)
-  if (version >= 7) {
-    if (!m.qf.reserve((size_t)b_pad * d_pad_h * 2)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory (scratch)");
-    hipLaunchKernelGGL(pack_qf_kernel, dim3((unsigned)((b_pad / 32) * (d_pad_h / 16))), dim3(64), 0, s, q_op, m.qf.as<_Float16>(), b_pad, d_pad_h);
+  if (version >= 7 && !m.qf.reserve((size_t)b_pad * d_pad_h * 2)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory (scratch)");
+  if (!m.gsync.reserve(1024)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory (scratch)");
+  // (what the staging below decides, needed here already: the 8-bit query preparation also lays down a seeded call's start state)
+  const int64_t S0 = std::max<int64_t>(4096, (int64_t)(32 * k + ROWPAD - 1) / ROWPAD * ROWPAD);
+  const bool seed_env = !(getenv("EPS_MFMA_SEED") && atoi(getenv("EPS_MFMA_SEED")) == 0);
+  const bool seeded = seed_env && n > 4 * S0;   // with a filter the seeds are the k best VISIBLE head rows
+  const bool prologue = seeded && version >= 7;   // one launch resets everything a seeded call starts from
+  const bool gsync_env = !(getenv("EPS_MFMA_GROUPSYNC") && atoi(getenv("EPS_MFMA_GROUPSYNC")) == 0);
+  const bool prep_does_it_all = i8 && version >= 7;   // fragment-major copy + prologue inside query_prep8_kernel: two launches less per call
+  if (i8) {
+    Prep8Extra px;
+    if (prep_does_it_all) {
+      px.qf = m.qf.as<signed char>();
+      if (prologue) {   // thresholds = 0x7F800000 pairs (+inf as fp32; as the 8-bit pass's int32 thresholds: never passes - the padding entries keep it)
+        px.T2 = reinterpret_cast<u64*>(m.T.p);
+        px.n2 = b_pad / 2;
+        px.Tv = 0x7F8000007F800000ull;
+        px.cnt = m.cnt.as<u32>();
+        px.cntv = (u32)S0;
+        px.gsync = gsync_env ? m.gsync.as<u32>() : nullptr;
+      }
+    }
+    hipLaunchKernelGGL(query_prep8_kernel, dim3((unsigned)((b_pad + 3) / 4)), dim3(256), 0, s, dq, nq, b_pad, (int)ix.dim_, m.d_pad8, m.mu8.as<float>(), m.step8,
+                       1.f / m.step8, ix.metric_, m.q8.as<signed char>(), m.qstat.as<float>(), px);
+  } else {
+    hipLaunchKernelGGL(query_prep_kernel, dim3((unsigned)((b_pad + 3) / 4)), dim3(256), 0, s, dq, nq, b_pad, (int)ix.dim_,
+                       m.d_pad, m.qh.as<_Float16>(), m.qstat.as<float>(), m.drop);
   }
+  const _Float16* q_op = i8 ? reinterpret_cast<const _Float16*>(m.q8.p) : m.qh.as<_Float16>();   // the query operand, row-major
+  if (version >= 7 && !prep_does_it_all)
+    hipLaunchKernelGGL(pack_qf_kernel, dim3((unsigned)((b_pad / 32) * (d_pad_h / 16))), dim3(64), 0, s, q_op, m.qf.as<_Float16>(), b_pad, d_pad_h);
 
   // Staging.  Every MFMA stage needs a valid upper bound T of the final k-th best exact key; it tightens stage by stage.
   //  * seeded (exact mode, no deleted bitset / attribute filter): the head [0, S0) goes through the SAME MFMA kernel in
@@ -773,10 +820,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   //    the first T (any k exact keys bound the k-th best).  The stages then start at row 0; the exact re-rank dedups rows
   //    it meets twice.  Stage sizes grow by the cube root of n / S0, which minimises the re-ranked rows ~ k * sum(ratios).
   //  * otherwise: the head is scanned exactly (with the filter) by the stream kernel, stages 32 x and 256 x S0.
-  int64_t S0 = std::max<int64_t>(4096, (int64_t)(32 * k + ROWPAD - 1) / ROWPAD * ROWPAD);
   const FilterSpec fs = ix.filter_spec();
-  const bool seed_env = !(getenv("EPS_MFMA_SEED") && atoi(getenv("EPS_MFMA_SEED")) == 0);
-  const bool seeded = seed_env && n > 4 * S0;   // with a filter the seeds are the k best VISIBLE head rows
   std::vector<int64_t> bounds;
   if (seeded) {
     bounds.push_back(approx ? S0 : 0);   // approx mode keeps the head's approximate keys themselves: no second visit
@@ -792,7 +836,9 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
     // one-workgroup re-ranks), and two re-ranks less beat the longer lists: scripts/lab/stages_by_batch.py, 1M x 768, p50 ms at
     // 1 / 16 / 64 queries: 0.392 / 0.440 / 0.504 (3 stages), 0.400 / 0.438 / 0.494 (4), 0.431 / 0.466 / 0.515 (6); from 128 queries
     // on 6 stages win (0.648 vs 0.707 with 3), at 10M rows as well.
-    int nstages = i8 ? (nq <= 64 ? 4 : 6) : 3;
+    // r4, a handful of queries (<= 4): 3 stages - with the centred grid a stage passes half the candidates it used to, and every stage
+    // less is one filter launch tail and one one-workgroup re-rank off a chain of dependent launches (scripts/lab/single_query_stages.sh)
+    int nstages = i8 ? (nq <= 4 ? 3 : (nq <= 64 ? 4 : 6)) : 3;
     if (i8)   // ... but never so few that a stage's expected k * c * ratio candidates come near the list capacity
       while (nstages < 8 && (double)k * 5.0 * std::pow((double)n / (double)S0, 1.0 / (double)nstages) > 0.5 * (double)cap) ++nstages;
     if (st_env) nstages = std::min(8, std::max(1, atoi(st_env)));
@@ -824,10 +870,11 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   ix.stats_.main_kernel_launches = 0;
 
   u32* cnt = m.cnt.as<u32>();
+  u32* seed_cand_buf = m.seedc.as<u32>();
+  u32* seed_cnt_buf = cnt;   // (merge_lists reads a query's seed count before it writes the candidate count there; the re-rank zeroes it)
   u32* overflow = cnt + nq;                                                    // [1]
   unsigned long long* total = reinterpret_cast<unsigned long long*>(cnt + nq + 2);  // 8-byte aligned? ensured below
   if ((reinterpret_cast<uintptr_t>(total) & 7) != 0) total = reinterpret_cast<unsigned long long*>(cnt + nq + 3);
-  const bool prologue = seeded && version >= 7;   // one launch resets everything a seeded call starts from (below)
   hipError_t er = prologue ? hipSuccess : hipMemsetAsync(cnt + nq, 0, 32, s);
   if (er != hipSuccess) return ix.hip_fail(er, "memset");
 
@@ -904,8 +951,6 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   }
   const int num_cus = m.num_cus;
   const bool narrow_env = !(getenv("EPS_MFMA_NARROW") && atoi(getenv("EPS_MFMA_NARROW")) == 0);
-  const bool gsync_env = !(getenv("EPS_MFMA_GROUPSYNC") && atoi(getenv("EPS_MFMA_GROUPSYNC")) == 0);
-  if (!m.gsync.reserve(1024)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory (scratch)");
   auto launch_filter = [&](const FilterArgs& f) {
     {
       FilterArgs f3 = f;
@@ -940,7 +985,9 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   const bool fused = !approx;   // exact mode: every re-rank also does its stage's counts and the next stage's thresholds
   if (seeded) {
     const bool dense = version >= 7;   // v7 writes the head's keys densely (slot = row); older kernels append with atomics
-    if (prologue) {
+    if (prologue && prep_does_it_all) {
+      // (query_prep8_kernel laid the start state down)
+    } else if (prologue) {
       const int64_t cells = std::max<int64_t>(std::max<int64_t>(b_pad / 2, nq), 256);
       hipLaunchKernelGGL(seed_prologue_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, s, reinterpret_cast<u64*>(m.T.p), b_pad / 2, 0x7F8000007F800000ull,
                          cnt, nq, (u32)S0, gsync_env ? m.gsync.as<u32>() : nullptr);
@@ -983,15 +1030,24 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
     f0.ntiles = (S0 + bm - 1) / bm;
     f0.row_hi = S0;
     launch_filter(f0);
-    launch_merge_lists(f0.cand_keys, cap, k, nq, run_keys, false, s, cnt, approx ? nullptr : &fs, seed_stride, seed_head);   // k best approximate keys of the visible seeds
+    // k best approximate keys of the visible seeds; exact mode: straight to the candidate lists of the re-rank that follows (the
+    // dense seed keys live in the upper half of the candidate buffer's u64 view, the lists in its u32 view: disjoint for cap >= 2 k)
+    if (approx) launch_merge_lists(f0.cand_keys, cap, k, nq, run_keys, false, s, cnt, nullptr, seed_stride, seed_head);
+    else launch_merge_lists(f0.cand_keys, cap, k, nq, run_keys, false, s, cnt, &fs, seed_stride, seed_head, seed_cand_buf, k, seed_cnt_buf);
     if (!approx) {
-      hipLaunchKernelGGL(seed_to_cand_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, run_keys, k, nq, fa.cand, cap, cnt, seed_stride, seed_head);
+      ra.cand = seed_cand_buf;
+      ra.cap = k;
+      ra.cand_count = seed_cnt_buf;
       ra.fuse = 2;                                                              // (thresholds of the first stage; the seeds are not a stage's candidates)
       ra.T_next = m.T.p;
       launch_rerank(ra, s);                                                    // -> their exact keys
+      ra.cand = fa.cand;
+      ra.cap = cap;
+      ra.cand_count = cnt;
     }
   }
   bool first = true;
+  bool fin_done = false;
   const bool probe = i8 && auto_bits && !approx && seeded && !m.i8_trusted && bounds.size() > 3 && !(getenv("EPS_MFMA_PROBE") && atoi(getenv("EPS_MFMA_PROBE")) == 0);
   for (size_t st = 0; st + 1 < bounds.size(); ++st) {
     const int64_t lo = bounds[st], hi = bounds[st + 1];
@@ -1000,7 +1056,9 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
       // the unseeded staging (whose stage 0 was a stream scan)
       const bool have_T = fused && (st > 0 || seeded);
       const int pad_only = have_T ? 1 : 0;
-      if (!have_T || st == 0) {
+      // (8-bit, seeded: the prologue left 0x7F800000 in the padding entries - as an int32 threshold "never passes" - and the dense
+      // seed pass does not read thresholds, so the pad-only launch is not needed)
+      if ((!have_T || st == 0) && !(have_T && i8 && prologue)) {
         if (i8)
           hipLaunchKernelGGL(threshold8_kernel, dim3((unsigned)((b_pad + 255) / 256)), dim3(256), 0, s, run_keys, k, nq, b_pad, m.qstat.as<float>(),
                              m.scal8.as<float>(), ix.metric_, u8, m.T.as<int>(), cnt, m.gsync.as<u32>(), rerank_slack, approx ? 1 : 0, pad_only);
@@ -1045,7 +1103,20 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
     } else {
       ra.fuse = 3;                                                            // this stage's counts + the next stage's thresholds
       ra.T_next = (st + 2 < bounds.size()) ? m.T.p : nullptr;
+      const bool fin_here = biggest && ix.pre_sync_ && nq == ix.pre_sync_nq_ && ix.fin_ids_ != nullptr;
+      if (fin_here) {   // the last re-rank writes the caller-visible result itself (rewritten by a fall-back pass if the lists overflowed)
+        ra.fin_ids = ix.fin_ids_;
+        ra.fin_dist = ix.fin_dist_;
+        ra.fin_counts = ix.fin_cnt_;
+        ra.fin_base = ix.id_base_;
+        ra.fin_stride = ix.id_stride_;
+      }
       launch_rerank(ra, s);
+      if (fin_here) {
+        (void)hipEventRecord(ix.ev1_, s);
+        ix.result_finalized_ = true;
+        fin_done = true;
+      }
       if (probe && st == 0) {
         // The library's own choice of the 8-bit pass is PROBED once per mirror: every stage passes ~ k * c * ratio candidates per query
         // (c = how many times more rows lie within the bound's margin of the threshold than below it), so the first, smallest stage
@@ -1074,7 +1145,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
     u32 overflow, pad;
     unsigned long long total;
   } h = {0, 0, 0};
-  if (ix.pre_sync_ && !approx && nq == ix.pre_sync_nq_) ix.pre_sync_();   // (speculative: a fall-back pass below converts again)
+  if (!fin_done && ix.pre_sync_ && !approx && nq == ix.pre_sync_nq_) ix.pre_sync_();   // (speculative: a fall-back pass below converts again)
   er = hipMemcpyAsync(&h.overflow, overflow, 4, hipMemcpyDeviceToHost, s);
   if (er == hipSuccess) er = hipMemcpyAsync(&h.total, total, 8, hipMemcpyDeviceToHost, s);
   if (er == hipSuccess) er = hipStreamSynchronize(s);
