@@ -1,7 +1,7 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r3s
+O=$R/gpurun_out/r4sq
 mkdir -p $O
 (timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o sq -- python $R/scripts/prof_single_query.py 1000000 768 > $O/run.log 2>&1)
 cd $R

@@ -1077,7 +1077,9 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
       ix.stats_.main_kernel_queries = nq;
       ix.stats_.main_kernel_bits = i8 ? 8 : 16;
     }
-    const int sev = (!approx && ix.stage_n_ < Index::STAGE_EV) ? ix.stage_n_++ : -1;   // (the build's kNN stage runs thousands of calls: untimed)
+    // (timed for throughput-sized batches only: an event record between two dependent launches costs a single-query chain ~4 us per
+    // launch boundary; the build's kNN stage runs thousands of calls: untimed)
+    const int sev = (!approx && nq >= 256 && ix.stage_n_ < Index::STAGE_EV) ? ix.stage_n_++ : -1;
     if (sev >= 0) (void)hipEventRecord(ix.stage_ev_[sev][0], s);
     launch_filter(fa);
     if (sev >= 0) {
