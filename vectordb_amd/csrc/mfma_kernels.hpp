@@ -111,6 +111,9 @@ template <> struct V7Op<true> {
 #ifndef EPS_V7_VI
 #define EPS_V7_VI 7
 #endif
+#ifndef EPS_V7_HITMASK
+#define EPS_V7_HITMASK 1   // FM_IDS hit blocks: per-lane bit mask of the passing values instead of 16 exec-masked branches (see the kernel)
+#endif
 #ifndef EPS_V7_TILE
 #define EPS_V7_TILE 0   // tile-level epilogue test (see the kernel; measured 1.5 % slower than the per-block form, profiles/r4_epilogue_ablation.txt): lab switch, needs EPS_V7_VI > 0
 #endif
@@ -907,6 +910,41 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
           int l31h = l31e, rbh = rbase;
           asm volatile("" : "+v"(l31h), "+v"(rbh));
           const int64_t qq = qbase + j * 32 + l31h;
+#if EPS_V7_HITMASK
+          // r4: the hit block without 16 exec-masked branches (lab ablation, profiles/r4_epilogue_ablation.txt: the hit code running costs
+          // the launch 3 %, its being there - 35 KB of unrolled per-value branches - another 2 %).  Row-id lists need no accumulator
+          // VALUE, only WHICH of a lane's 16 values passed: a 16-bit mask per lane (branch-free compares), then only the lanes with a
+          // bit set walk their bits - almost always one lane, one bit.  (Approximate-key lists pick the value by a 16-way select.)
+          {
+            u32 hm = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hm |= acc[i][j][r] >= Tq[j] ? (1u << r) : 0u;
+            if (qq >= a.nq) hm = 0;
+            while (hm) {
+              const int r = __builtin_ctz(hm);
+              hm &= hm - 1;
+              const int64_t row64 = row0 + rbh + (r & 3) + 8 * (r >> 2);
+              if (row64 >= a.row_hi) continue;       // (rows beyond the stage's last row: the tile that crosses it)
+              const u32 row = (u32)row64;
+              float dapx = 0.f;
+              if (MODE == FM_KEYS) {   // the value itself: picked out of the lane's 16 by a select chain (rare path)
+                thr_t v = acc[i][j][0];
+#pragma unroll
+                for (int rr = 1; rr < 16; ++rr) v = r == rr ? acc[i][j][rr] : v;
+                dapx = (float)v * a.s + tq_lds[(2 + j) * 64 + lne];
+                if (a.metric == 0) dapx = fmaxf(dapx, 0.f);
+              }
+              const u32 e = atomicAdd(wcnt, 1u);   // LDS: no VMEM counter involved
+              if (e < (u32)V7_CAPW) {
+                wbuf[e] = ((u64)qq << 32) | row;
+                if (MODE == FM_KEYS) wkey[e] = dapx;
+              } else {
+                append(qq, row, dapx);
+              }
+            }
+            continue;
+          }
+#endif
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             if (acc[i][j][r] >= Tq[j]) {
