@@ -35,12 +35,14 @@ sys.path.insert(0, ROOT)
 # run: `roofline.traffic` is null here and `roofline.traffic_reference` names the committed profile of the same launch shape (file,
 # sha256 of the file as it lies in this tree, the bytes it shows, and which round's kernel it was taken on).
 TRAFFIC_REF = {
-    "mfma8": {"file": "profiles/r3_pmc_10Mx768_b1024.csv", "bytes_per_launch": (2 * 2755587 + 8791) * 1024.0, "algorithmic_bytes": 7280256 * 768.0,
-              "launch": "mfma_filter_kernel_v7<2, FM_IDS, int8>, 7,280,256 rows x 1024 queries (last of 6 stages)", "taken_on": "r3 kernel (same operand stream)"},
+    "mfma8": {"file": "profiles/r4_pmc_10Mx768_b1024.csv", "bytes_per_launch": (2 * 2753469 + 3857) * 1024.0, "algorithmic_bytes": 7280256 * 768.0,
+              "launch": "mfma_filter_kernel_v7<2, FM_IDS, int8>, 7,280,256 rows x 1024 queries (last of 6 stages), occurrence 5 of the PMC passes",
+              "taken_on": "r4 kernel (scripts/run_flat_profile_r4.sh)"},
     "mfma": {"file": "profiles/r2_pmc_10Mx768_b1024.csv", "bytes_per_launch": (2 * 7340245 + 7460) * 1024.0, "algorithmic_bytes": 9262720 * 1536.0,
              "launch": "mfma_filter_kernel_v7<2, FM_IDS> (fp16), 9,262,720 rows x 1024 queries", "taken_on": "r2 kernel"},
-    "graph_T4_L500": {"file": "profiles/r3_traverse_10Mx768_pmc.csv", "bytes_per_launch": (2 * 22850910 + 2205166) * 1024.0, "algorithmic_bytes": 44.6e9,
-                      "launch": "traverse2_kernel T=4 L=500 batch 1024, 10M-node device-built graph, 8-bit prefilter on", "taken_on": "r3 kernel"},
+    "graph_T4_L500": {"file": "profiles/r4_traverse_10Mx768_pmc.csv", "bytes_per_launch": (2 * 21158743 + 2204587) * 1024.0, "algorithmic_bytes": 41.1e9,
+                      "launch": "traverse2_kernel T=4 L=500 batch 1024, 10M-node device-built graph, 8-bit prefilter on the centred grid (occurrences 0, 1)",
+                      "taken_on": "r4 kernel (scripts/run_10m_graph_r4.sh)"},
 }
 
 
@@ -53,6 +55,8 @@ def traffic_ref(key):
 
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_GATHER_CEILING_GBS = 6050.0   # measured here: random whole-row gathers (768 B and 3 KB rows, 30 GB table, 2-8 rows in flight per lane group,
+                                  # 4-8 wavefronts per SIMD) with nothing else in the kernel: 5.99-6.10 TB/s (scripts/lab/gather_peak.hip, profiles/r4_gather_peak.txt)
 MFMA_F16_PEAK_TF = 2500.0  # dense bf16/f16 MFMA peak (nominal, 2.4 GHz)
 MFMA_F16_SUSTAINED_TF = 1814.0  # measured: v_mfma_f32_32x32x16_f16 alone, operands toggling like data, 1.82 GHz (scripts/lab/mfma_peak.hip)
 MFMA_I8_PEAK_TOPS = 5000.0      # dense 8-bit MFMA peak: twice the fp16 rate (MI355X_MICROARCH.md lists the FP8 dense peak ~5 P and I8 at ~2x bf16)
@@ -784,6 +788,9 @@ def main():
             roof = {"bound": "hbm", "kernel": "flat_scan_kernel", "achieved": alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms else None,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
         roof["frac"] = (roof["achieved"] / roof["peak"]) if roof["achieved"] else None
+        if args.mode == "graph" and roof["achieved"]:
+            roof["gather_ceiling_measured"] = HBM_GATHER_CEILING_GBS
+            roof["frac_of_gather_ceiling"] = roof["achieved"] / HBM_GATHER_CEILING_GBS
         if used_mfma and args.mode == "flat":
             # whole step against the same roof: the step's algorithmic work (2 * batch * rows * d) over ms_per_step - re-ranks, seeds, launches included
             roof["whole_step_frac"] = 2.0 * b * n * d / (elapsed / args.steps) / 1e12 / roof["peak"]
