@@ -19,17 +19,44 @@ F = np.float32
 EPS24 = F(5.9604645e-8)
 
 
+ACC_FORCE = 0x38000000   # start value of a row that must pass whatever the threshold (thresholds are clamped to <= TQ_MAX, |dot| < 2^27)
+TQ_MAX = 0x30000000
+TAIL = 1e-7   # share of the SAMPLE's values the grid may leave outside on either side (ensure_mirror8: centre_hist_kernel)
+
+
 def col_centre(X, sample=None):
-    """what ensure_mirror8 does on the first build: column means (fp32) of a strided sample, then the mid-range of x - mean"""
+    """what ensure_mirror8 does on the first build: column means (fp32) of a strided sample; then the grid's range from a 4096-bin
+    histogram of x - mean over the sample, clipped so that at most max(2, TAIL * values) sample values lie outside on either side (one
+    outlier value must not stretch the grid for ten million rows: a clamped row pays with ITS residual, below); centre = mean + mid-range
+    of the clipped interval.  Returns (mu, half-range)."""
     S = X if sample is None else X[sample]
     mean = (S.astype(F).sum(0, dtype=F) / F(len(S))).astype(F)
     c = (X - mean).astype(F)
-    z0 = F(0.5) * F(c.min()) + F(0.5) * F(c.max())
-    return (mean + z0).astype(F)
+    lo, hi = F(c.min()), F(c.max())
+    cs = (S - mean).astype(F)
+    binw = (hi - lo) / F(4096.0)
+    if not binw > 0:
+        return mean, F(0.0)
+    b = np.clip(((cs - lo) * (F(1.0) / binw)).astype(np.int64), 0, 4095)
+    hist = np.bincount(b.ravel(), minlength=4096)
+    tol = max(2, int(TAIL * cs.size))
+    cum = np.cumsum(hist)
+    blo = int(np.searchsorted(cum, tol, side="right"))              # first bin whose cumulative count exceeds tol
+    cumr = np.cumsum(hist[::-1])
+    bhi = 4095 - int(np.searchsorted(cumr, tol, side="right"))
+    clo = lo + F(blo) * binw
+    chi = lo + F(bhi + 1) * binw
+    if not chi > clo:
+        clo, chi = lo, hi
+    z0 = F(0.5) * clo + F(0.5) * chi
+    return (mean + z0).astype(F), F(max(chi - z0, z0 - clo))
 
 
 def mirror(X, metric, mu=None, step=None):
-    mu = col_centre(X) if mu is None else mu
+    if mu is None:
+        mu, half = col_centre(X)
+        if step is None:
+            step = half / F(127.0)
     xc = (X - mu).astype(F)                                   # x' = fl(x - mu)
     if step is None:
         step = F(max(abs(F(xc.min())), abs(F(xc.max())))) / F(127.0)
@@ -44,11 +71,33 @@ def mirror(X, metric, mu=None, step=None):
         R = x2c
     else:
         R = -(mu * xc).sum(1, dtype=F)
-    acc0 = (np.ceil(-R / u) + 1).astype(np.int64)
-    e1 = (np.sqrt((res * res).sum(1, dtype=F)) * F(1.00001) + F(1.2e-7) * np.sqrt(x2c)).astype(F)   # + the rounding of x - mu
-    scal = dict(e1max=F(e1.max()), nxhmax=F((np.sqrt((xh * xh).sum(1, dtype=F)) * F(1.00001)).max()),
-                xnmax=F((X * X).sum(1, dtype=F).max()), rmax=F(np.abs(R).max()), mun=F(np.sqrt((mu * mu).sum(dtype=F)) * F(1.00001)))
-    return dict(mu=mu, step=step, inv=inv, xi=xi, acc0=acc0, u=u, s=s, scal=scal)
+    a0 = np.ceil(-R / u) + 1
+    # per ROW (r4): the two norms the Cauchy-Schwarz margin multiplies the query's with
+    erow = (np.sqrt((res * res).sum(1, dtype=F)) * F(1.00001) + F(1.2e-7) * np.sqrt(x2c)).astype(F)   # + the rounding of x - mu
+    hrow = (np.sqrt((xh * xh).sum(1, dtype=F)) * F(1.00001)).astype(F)
+    # a row whose constant leaves the accumulator's range (an outlier far outside the clipped grid) is FORCED: its test is not evaluated,
+    # it always passes (fold) - in approximate-key mode it never does (acc0 = -2^30, as on padding rows); it does not enter the maxima
+    forced = ~(np.abs(a0) < 536870912.0)
+    acc0 = np.where(forced, -(1 << 30), a0).astype(np.int64)
+    erow = np.where(forced, F(np.inf), erow).astype(F)
+    ok = ~forced
+    xn = (X * X).sum(1, dtype=F)
+    mx = lambda v: F(v[ok].max()) if ok.any() else F(0.0)
+    scal = dict(e1max=mx(erow), nxhmax=mx(hrow), xnmax=mx(xn), rmax=mx(np.abs(R)), mun=F(np.sqrt((mu * mu).sum(dtype=F)) * F(1.00001)))
+    scal["xcmax"] = F(scal["nxhmax"] + scal["e1max"])        # >= max |x - mu| of the rows that are tested
+    return dict(mu=mu, step=step, inv=inv, xi=xi, acc0=acc0, u=u, s=s, scal=scal, erow=erow, hrow=hrow, forced=forced)
+
+
+def fold(m, qss):
+    """fold8_kernel: the margin of every ROW for a whole batch of queries, added to the row's accumulator start value - its own two
+    norms times the batch's LARGEST query norms (>= every query's own margin for that row) - so that the thresholds carry none"""
+    qn = F(max(q["nq"] for q in qss))
+    eq = F(max(q["eq"] for q in qss))
+    with np.errstate(invalid="ignore", over="ignore"):
+        marg = (m["s"] * (qn * m["erow"] + eq * m["hrow"])).astype(F)
+        add = np.ceil(marg / m["u"]) + 1
+    force = m["forced"] | ~(add < 536870912.0)
+    return np.where(force, ACC_FORCE, m["acc0"] + np.where(force, 0, add).astype(np.int64))
 
 
 def query(q, m, metric):
@@ -62,17 +111,16 @@ def query(q, m, metric):
     return qi, dict(qn2=s2, nq=F(np.sqrt(s2c) * F(1.000001)), eq=F(np.sqrt((res * res).sum(dtype=F)) * F(1.00001) + F(1.2e-7) * np.sqrt(s2c)), Cq=F(Cq))
 
 
-def threshold(thr, qs, m, metric, slack):
+def threshold(thr, qs, m, metric, slack, folded=False):
     sc = m["scal"]
-    margin = m["s"] * (qs["nq"] * sc["e1max"] + qs["eq"] * sc["nxhmax"])
-    xcmax = sc["nxhmax"] + sc["e1max"]                        # >= max |x - mu|
+    margin = F(0.0) if folded else m["s"] * (qs["nq"] * sc["e1max"] + qs["eq"] * sc["nxhmax"])
     if metric == 0:
         scale = abs(thr) + F(2.0) * abs(qs["Cq"]) + F(2.0) * sc["rmax"]
     else:
         qn = F(np.sqrt(qs["qn2"]))
-        scale = abs(thr) + F(1.0) + qn * (F(np.sqrt(sc["xnmax"])) + sc["mun"]) + sc["mun"] * xcmax + abs(qs["Cq"]) + sc["rmax"]
+        scale = abs(thr) + F(1.0) + qn * (F(np.sqrt(sc["xnmax"])) + sc["mun"]) + sc["mun"] * sc["xcmax"] + abs(qs["Cq"]) + sc["rmax"]
     t = thr + margin + F(slack) * scale + F(4.0) * m["u"]
-    return int(np.clip(np.floor((qs["Cq"] - t) / m["u"]) - 2, -(1 << 30), 1 << 30))
+    return int(np.clip(np.floor((qs["Cq"] - t) / m["u"]) - 2, -(1 << 30), TQ_MAX))
 
 
 def dist(q, X, metric):
@@ -93,46 +141,61 @@ CASES = {
     "tiny range": lambda r, n, d: (0.5 + 1e-4 * r.random((n, d))).astype(F),
     "heavy tail": lambda r, n, d: (r.standard_normal((n, d)) * np.exp(r.standard_normal((n, 1)))).astype(F),
     "columns with their own means": lambda r, n, d: (r.standard_normal((1, d)) * 5.0 + 0.3 * r.standard_normal((n, d))).astype(F),
+    "a few outlier values": lambda r, n, d: _with_outliers(r, r.random((n, d), dtype=F)),
 }
+
+
+def _with_outliers(r, X):
+    for _ in range(5):
+        X[r.integers(len(X)), r.integers(X.shape[1])] = F(r.choice([-1.0, 1.0]) * r.uniform(20.0, 200.0))
+    return X
 
 
 @pytest.mark.parametrize("metric", [0, 1, 2])
 @pytest.mark.parametrize("case", sorted(CASES))
 def test_rows_within_the_threshold_always_pass_the_8bit_test(case, metric):
+    """both forms of the test: thresholds that carry the table-wide margin (the build's and any caller's that does not fold), and r4's
+    per-row margins folded into the accumulators' start values for the batch (fold) with margin-free thresholds"""
     rng = np.random.default_rng(abs(hash((case, metric))) % (1 << 31))
     n, d = 4000, 96
     X = CASES[case](rng, n, d)
     if metric == 1:
         X /= np.linalg.norm(X, axis=1, keepdims=True)
-    m = mirror(X, metric, mu=col_centre(X, sample=slice(0, None, 7)))
+    mu, half = col_centre(X, sample=slice(0, None, 7))
+    m = mirror(X, metric, mu=mu, step=half / F(127.0))
     # rows appended after the grid was fixed, some far outside it: quantised with clamped codes, their residual enters the bound
-    span = F(X.max() - X.min())
+    span = F(np.percentile(X, 99.9) - np.percentile(X, 0.1))
     Xa = np.concatenate([X[:200] + F(0.2) * span * np.sign(rng.standard_normal((200, d))).astype(F), X[200:400]])   # up to 20 % of the range outside
     if metric == 1:
         Xa /= np.linalg.norm(Xa, axis=1, keepdims=True)
     m2 = mirror(np.concatenate([X, Xa]), metric, mu=m["mu"], step=m["step"])
     slack = slack_of(d)
     worst = 1 << 40
-    if not (np.abs(m["acc0"]) < (1 << 29)).all():     # the device declines a table whose row constants leave int32 (the fp16 pass serves it)
+    if m["forced"].mean() > 0.01:     # the device declines a table most of whose row constants leave int32 (the fp16 pass serves it)
         assert metric != 0 and case in ("far from the origin", "tiny range")   # (mu large against the step: |R| / u = |mu . x'| / step^2)
         pytest.skip("row constants beyond int32: no 8-bit mirror for this table")
     for mm, rows in ((m, X), (m2, np.concatenate([X, Xa]))):
-        if not (np.abs(mm["acc0"]) < (1 << 29)).all():
-            continue
+        qs_all, per_q = [], []
         for qk in range(12):
             q = rows[rng.integers(len(rows))] + F(0.05) * rng.standard_normal(d).astype(F) if qk % 3 else CASES[case](rng, 1, d)[0] * F(3.0) - F(1.0)
             if metric == 1:
                 q = q / np.linalg.norm(q)
             q = q.astype(F)
             qi, qs = query(q, mm, metric)
+            qs_all.append(qs)
+            per_q.append((q, qi, qs))
+        acc0f = fold(mm, qs_all)            # ONE fold for the batch of 12 queries
+        for q, qi, qs in per_q:
             dd = dist(q, rows, metric)
-            lhs = mm["xi"].astype(np.int64) @ qi.astype(np.int64) + mm["acc0"]
+            dot = mm["xi"].astype(np.int64) @ qi.astype(np.int64)
             for frac in (0.001, 0.02, 0.3):
                 thr = F(np.partition(dd, int(frac * len(dd)))[int(frac * len(dd))])
-                Tq = threshold(thr, qs, mm, metric, slack)
                 inside = dd <= thr
-                assert (lhs[inside] >= Tq).all(), (case, metric, qk, frac, int((lhs[inside] < Tq).sum()))
-                worst = min(worst, int((lhs[inside] - Tq).min()))
+                Tq = threshold(thr, qs, mm, metric, slack)   # (forced rows are only ever tested in the folded form)
+                assert ((dot + mm["acc0"])[inside & ~mm["forced"]] >= Tq).all(), (case, metric, frac, "table-wide margin")
+                Tf = threshold(thr, qs, mm, metric, slack, folded=True)
+                assert ((dot + acc0f)[inside] >= Tf).all(), (case, metric, frac, "folded per-row margins")
+                worst = min(worst, int(((dot + acc0f)[inside] - Tf).min()))
     assert worst >= 0
 
 
@@ -144,7 +207,7 @@ def test_any_centre_keeps_the_bound_valid():
     for metric in (0, 1, 2):
         for mu in (np.zeros(d, F), rng.standard_normal(d).astype(F), np.full(d, 0.5, F)):
             m = mirror(X, metric, mu=mu)
-            if not (np.abs(m["acc0"]) < (1 << 29)).all():
+            if m["forced"].any():
                 continue
             for _ in range(6):
                 q = rng.random(d, dtype=F)
@@ -173,3 +236,39 @@ def test_the_bound_is_not_vacuous_on_uniform_rows():
     # the margin itself: 2 (|q'| e1 + |eq| |xh'|) ~ 1.0 key units where the uncentred grid had ~2.0
     margin = m["s"] * (qs["nq"] * m["scal"]["e1max"] + qs["eq"] * m["scal"]["nxhmax"])
     assert margin < 1.2, margin
+
+
+def test_one_outlier_value_costs_its_row_not_the_table():
+    """r4: the clipped grid + per-row margins.  One value of 100 in a U[0,1) table stretched r3's / early r4's grid 100 x and the
+    table-wide margin with it (the 8-bit pass could not filter: the fp16 pass served the table).  Now the grid is set by the bulk of
+    the values, the outlier's row is clamped, carries its own large residual and simply always passes; every other row is filtered as
+    if the outlier were not there."""
+    rng = np.random.default_rng(4)
+    n, d = 3000, 768
+    X = rng.random((n, d), dtype=F)
+    clean = mirror(X, 0)
+    X[1234, 5] = F(100.0)
+    m = mirror(X, 0)
+    assert m["step"] < F(1.05) * clean["step"]                       # the grid did not stretch
+    assert not m["forced"].any() and m["erow"][1234] > 50 and np.delete(m["erow"], 1234).max() < 2 * clean["erow"].max()
+    q = rng.random(d, dtype=F)
+    qi, qs = query(q, m, 0)
+    dd = dist(q, X, 0)
+    thr = F(np.partition(dd, n // 20)[n // 20])
+    lhs = m["xi"].astype(np.int64) @ qi.astype(np.int64) + fold(m, [qs])
+    Tf = threshold(thr, qs, m, 0, slack_of(d), folded=True)
+    passed = (lhs >= Tf).mean()
+    assert (lhs[dd <= thr] >= Tf).all() and passed < 0.16, passed   # (the outlier row itself is provably far: it does not pass)
+    # ... where the table-wide margin is useless on the same mirror
+    Tq = threshold(thr, qs, m, 0, slack_of(d))
+    X2 = rng.random((n, d), dtype=F)
+    X2[1234, 5] = F(1000.0)         # so far out that its row constant leaves the accumulator's range: the row is FORCED (always passes)
+    m3 = mirror(X2, 0)
+    assert m3["forced"][1234] and m3["forced"].sum() == 1
+    qi3, qs3 = query(q, m3, 0)
+    dd3 = dist(q, X2, 0)
+    thr3 = F(np.partition(dd3, n // 20)[n // 20])
+    dot3 = m3["xi"].astype(np.int64) @ qi3.astype(np.int64)
+    folded = (dot3 + fold(m3, [qs3]) >= threshold(thr3, qs3, m3, 0, slack_of(d), folded=True))
+    tablewide = (dot3 + m3["acc0"] >= threshold(thr3, qs3, m3, 0, slack_of(d)))
+    assert folded[dd3 <= thr3].all() and folded[1234] and folded.mean() < 0.16 and tablewide[(dd3 <= thr3) & ~m3["forced"]].all()

@@ -101,16 +101,17 @@ def test_i8_engine_on_other_distributions(amd, kind):
 
 
 def test_auto_stops_paying_for_an_8_bit_pass_that_never_filters(amd):
-    """One huge outlier stretches the grid 100 x: the 8-bit bound cannot filter this table.  r4: the library's own choice PROBES the
+    """A table the 8-bit bound cannot filter (heavy-tailed values in every row).  r4: the library's own choice PROBES the
     8-bit pass on the first batch it sends through a mirror - the candidate count of the first, smallest stage predicts the others -
     finds it too loose and answers with the fp16 pass at once (r3 paid three whole overflowing 8-bit attempts first); later batches
     go to the fp16 pass directly; an explicit EPS_FLAT_MFMA_I8 request still runs the 8-bit pass (and overflows into the fp16 pass);
     every answer is the stream scan's.  EPS_MFMA_PROBE=0 restores the r3 behaviour (three overflows, then fp16)."""
     rng = np.random.default_rng(6)
     n, d, nq = 90_000, 256, 96
-    X = rng.random((n, d), dtype=np.float32)
-    X[4321, 3] = 100.0
-    Q = rng.random((nq, d), dtype=np.float32)
+    # (r4's clipped grid + per-row margins serve a table with a FEW outliers - next test; what defeats ONE grid is a heavy tail in every
+    # row: Cauchy values - whatever the grid, most rows are clamped somewhere and carry residuals as large as the distances)
+    X = np.clip(rng.standard_cauchy((n, d)), -1e5, 1e5).astype(np.float32)
+    Q = np.clip(rng.standard_cauchy((nq, d)), -1e5, 1e5).astype(np.float32)
     ix = amd.GpuIndex(d, 0)
     ix.attach_rows(X)
     ref = ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
@@ -136,6 +137,46 @@ def test_auto_stops_paying_for_an_8_bit_pass_that_never_filters(amd):
         ix.close()
     finally:
         del os.environ["EPS_MFMA_PROBE"]
+
+
+def test_a_few_outlier_values_cost_their_rows_not_the_table(amd):
+    """r4: the grid is clipped to the bulk of the values and every row carries its own residual norms, folded per batch into its
+    accumulator start value.  One value of 100 in a U[0,1) table (r3 / early r4: grid stretched 100 x, 8-bit pass useless, fp16 pass
+    served the table) now only clamps its own row; a value so far out that the row's constant leaves the accumulator's range makes the
+    row FORCED (always a candidate, re-ranked exactly).  The 8-bit pass serves the table, nothing is declined or overflows, and the
+    outlier rows are still found exactly when they ARE the answer (queries = those rows; a query that is itself far outside the grid)."""
+    rng = np.random.default_rng(26)
+    n, d, nq = 100_000, 256, 80
+    X = rng.random((n, d), dtype=np.float32)
+    X[4321, 3] = 100.0            # clamped, large residual, still tested
+    X[777, 200] = -40.0
+    X[60_000, 17] = 30_000.0      # forced: |R| / u beyond 2^29
+    Q = rng.random((nq, d), dtype=np.float32)
+    ix = amd.GpuIndex(d, 0)
+    ix.attach_rows(X)
+    ref = ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
+    for it in range(3):
+        same(ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_AUTO), ref, "auto %d" % it)
+        st = ix.stats()
+        assert (st["main_kernel_bits"], st["i8_declined"], st["overflow_queries"]) == (8, 0, 0), (it, st)
+        assert st["rerank_rows"] < 400 * nq, st        # ... and it FILTERS (the forced row adds one candidate per query and stage)
+    # queries that ARE the outlier rows (far outside the grid themselves: their batch's margins are as large as their residuals, the
+    # lists overflow and the fp16 / stream engines answer - exactly): the rows are found
+    Qo = np.stack([X[4321], X[777], X[60_000], X[60_000] + np.float32(0.01)] + [Q[i] for i in range(8)])
+    refo = ix.search(Qo, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
+    assert refo[0][0, 0] == 4321 and refo[0][1, 0] == 777 and refo[0][2, 0] == 60_000 and refo[0][3, 0] == 60_000
+    same(ix.search(Qo, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8), refo, "outlier queries")
+    same(ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_AUTO), ref, "regular batch again")
+    assert ix.stats()["main_kernel_bits"] == 8
+    # rows appended after the grid was fixed, one of them far outside: same machinery
+    Xa = rng.random((500, d), dtype=np.float32)
+    Xa[7, 9] = 55.0
+    ix.append_rows(Xa)
+    ref = ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
+    same(ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8), ref, "appended outlier")
+    st = ix.stats()
+    assert st["main_kernel_bits"] == 8 and st["overflow_queries"] == 0, st
+    ix.close()
 
 
 def test_auto_keeps_the_8_bit_pass_where_it_filters_and_probes_only_once(amd):

@@ -118,11 +118,39 @@ def test_prefilter_with_rows_outside_the_mirrors_grid(amd, oracle, monkeypatch):
     ix.close()
 
 
+def test_prefilter_with_outlier_rows(amd, oracle, monkeypatch):
+    """r4: outlier values (one clamped, one so far out that its row is forced) in a table the traversal prefilters: the walk is the
+    same bit for bit with the prefilter off and on, equals the oracle's, and the prefilter still filters (per-row margins: the outliers
+    cost their own rows, not everybody's bound)."""
+    n, d, L = 70_000, 128, 300
+    X = data(n, d, 91)
+    X[123, 5] = 80.0
+    X[45_678, 100] = -25_000.0
+    Q = data(16, d, 92)
+    ix = amd.GpuIndex(d, 0)
+    ix.attach_rows(X)
+    ix.build(n)
+    off, nbr, nav = ix.get_graph()
+    res = {}
+    for pf in ("0", "1"):
+        monkeypatch.setenv("EPS_TRV_PREFILTER", pf)
+        ids, dist, cnt = ix.search(Q, 20, mode=amd.MODE_GRAPH, intra_threads=2, master_queue=L, local_queue=L)
+        st = ix.stats()
+        res[pf] = (ids.copy(), dist.copy(), st["dist_evals"], st["rerank_rows"])
+    assert np.array_equal(res["0"][0], res["1"][0]) and np.array_equal(res["0"][1].view(np.uint32), res["1"][1].view(np.uint32))
+    assert res["0"][2] == res["1"][2] and 0 < res["1"][3] < 0.6 * res["1"][2]
+    init = oracle.prepare_init_ids(off, nbr, nav, L)
+    for qi in (0, 1, 7):
+        oid, od, _ = oracle.search_impl(0, X, off, nbr, init, Q[qi], T=2, L=L, lockstep=True)
+        assert_topk_match(res["1"][0][qi], res["1"][1][qi], oid[:20], od[:20], what="q%d" % qi)
+    ix.close()
+
+
 def test_prefilter_switches_itself_off_where_it_does_not_pay(amd, monkeypatch):
     """Where the 8-bit bound cannot tell the neighbours apart nearly every neighbour passes it and the extra pass only costs: after two
     such searches the index stops using it (the answers never depended on it); where it filters it stays on.  r3's grid lost rows of
     low intrinsic dimension that way (77 % passed on the 10M manifold set); the centred grid of r4 filters them (41 % here) and stays
-    on - what still defeats it is a table whose value range is stretched by an outlier (one grid for all rows)."""
+    on - what still defeats it is a table with a heavy tail in every row (one grid for all rows)."""
     monkeypatch.delenv("EPS_TRV_PREFILTER", raising=False)
     rng = np.random.default_rng(5)
     n, d = 70_000, 128
@@ -137,7 +165,10 @@ def test_prefilter_switches_itself_off_where_it_does_not_pay(amd, monkeypatch):
         st = ix.stats()
         assert 0 < st["rerank_rows"] < 0.55 * st["dist_evals"], (it, st)
     ix.close()
-    X[4321, 3] = 60.0       # one value far outside everything else: the grid's step grows 30 x, the bound with it
+    # (a few outlier values no longer defeat it either: clipped grid + per-row margins, test_prefilter_with_outlier_rows below; a heavy
+    # tail in EVERY row does: most rows are clamped somewhere, their residuals are as large as the distances)
+    X = np.clip(rng.standard_cauchy((n, d)), -1e4, 1e4).astype(np.float32)
+    Q = np.clip(rng.standard_cauchy((64, d)), -1e4, 1e4).astype(np.float32)
     ix = amd.GpuIndex(d, 0)
     ix.attach_rows(X)
     ix.build(n)

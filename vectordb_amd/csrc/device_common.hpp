@@ -177,19 +177,20 @@ __device__ __forceinline__ int quant8(float x, float z, float inv_step) {
 // implication it must guarantee, in tests/test_bound_math.py.
 __device__ __forceinline__ int stage_threshold8(float thr, const float* qs, const float* sc, int metric, float u, float slack, int approx) {
   const float qn2 = qs[0], nqc = qs[1], eq = qs[2], Cq = qs[3];
-  const float e1max = sc[0], nxhmax = sc[1], xnmax = sc[2], rmax = sc[4], mun = sc[5];
+  const float e1max = sc[0], nxhmax = sc[1], xnmax = sc[2], rmax = sc[4], mun = sc[5], xcmax = sc[6];   // (folded launches: sc[0] = sc[1] = 0, the margin is in the rows' start values)
   const float s = metric == 0 ? 2.f : 1.f;
   const float margin = s * (nqc * e1max + eq * nxhmax);   // Cauchy-Schwarz on the two stored residuals, in the centred frame
   // fp32 evaluation of the re-ranked distance, of R and of C (each a d-term sum whose terms' magnitudes sum to at most the scale
   // below), of x - mu, and of the two divisions by u
   const float scale = metric == 0 ? fabsf(thr) + 2.f * fabsf(Cq) + 2.f * rmax
-                                  : fabsf(thr) + 1.f + sqrtf(qn2) * (sqrtf(xnmax) + mun) + mun * (nxhmax + e1max) + fabsf(Cq) + rmax;
+                                  : fabsf(thr) + 1.f + sqrtf(qn2) * (sqrtf(xnmax) + mun) + mun * xcmax + fabsf(Cq) + rmax;
   // approx mode (the build's kNN stage) ranks on the approximate keys themselves: a row is wanted iff its APPROXIMATE key beats the
   // k-th best approximate key so far - no margin (with it several times the rows pass, and every one costs an append)
   const float t = approx ? thr + slack * scale + 4.f * u : thr + margin + slack * scale + 4.f * u;
   float v = floorf((Cq - t) / u) - 2.f;
-  v = fminf(fmaxf(v, -1073741824.f), 1073741824.f);
-  return v >= 1073741824.f ? 0x7FFFFFFF : (int)v;
+  // (never above TQ_MAX8: a forced row - start value ACC_FORCE = 0x38000000, |dot| < 2^27 - passes every threshold a query can have)
+  v = fminf(fmaxf(v, -1073741824.f), 805306368.f);
+  return (int)v;
 }
 
 // Seed sample of the MFMA engine: sample entry i is table row i for the first `head` entries (the head of the table), then

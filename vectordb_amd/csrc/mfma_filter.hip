@@ -77,13 +77,21 @@ struct HalfMirror {
   DevBuf acc0;     // int32 [n_pad8]: accumulator start of every row = ceil(-R/u) + 1 (-2^30 on padding rows)
   DevBuf sx8, sacc0;            // seed sample of the 8-bit mirror
   int64_t sample8_version = -1, sample8_n = 0, sample8_rows = 0;
-  DevBuf scal8;    // float [8]: max |x - xh|, max |xh|, max |x|^2, bad flag, max |R|, -, min (ordered u32), max (ordered u32)
+  DevBuf scal8;    // float [8]: max |x' - xh'|, max |xh'|, max |x|^2, bad flag, max |R|, |mu|, max |x'| (during the build: min / max of x - mean as ordered u32 in [6], [7])
+  // r4, per-row margins: the two norms of every row the Cauchy-Schwarz margin multiplies the query's with (erow = +inf: a row whose
+  // constant leaves the accumulator's range - it is not tested, it always passes), the batch's folded start values, the maxima with
+  // the two margin entries zeroed (what thresholds of folded launches read), the batch's largest query norms, the range histogram
+  DevBuf erow, hrow;   // float [n_pad8]
+  DevBuf acc0b;        // int32 [n_pad8]: acc0 + the row's margin for the CURRENT batch (fold8_kernel)
+  DevBuf scal8f;       // float [8]
+  DevBuf qmax;         // u32 [2]: float bits of the batch's max |q'| and max |q' - qh'| (query_prep8_kernel, atomicMax)
+  DevBuf hist;         // u32 [4096 + 8]: histogram of x - mean over the sample; [4096]: forced rows
   DevBuf q8;       // int8 [b_pad][d_pad8]
   float h_scal8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   DevBuf mu8;      // float [d_pad8]: the grid's centre, one value per column (zeros beyond dim)
   float step8 = 0.f;            // the grid: xh' = step8 * xi around mu8
   bool i8_trusted = false;      // the library's own choice has seen a batch through the 8-bit pass on this mirror (no probe needed)
-  int64_t version8 = -1, n8 = 0, n_pad8 = 0;
+  int64_t version8 = -1, n8 = 0, n_pad8 = 0, forced_rows8 = 0;
   int d_pad8 = 0;
   bool i8_ok = false;
   int i8_overflows = 0;         // consecutive batches whose 8-bit pass overflowed its candidate lists (the fp16 pass then answered)
@@ -328,9 +336,57 @@ __global__ __launch_bounds__(64) void mu_finish_kernel(float* mu, int dim, float
   if (lane_id() == 0) scal8[5] = sqrtf(s2) * 1.00001f;
 }
 
+// r4: the grid's range is set by the BULK of the values: 4096-bin histogram of x - mean over the sample rows (integer atomics: the
+// result does not depend on the order), the host cuts both tails at max(2, 1e-7 x values) sample values.  One outlier value used to
+// stretch the grid - and with it every row's margin - by its distance; now its row is clamped and pays with ITS OWN residual.
+__global__ __launch_bounds__(256) void centre_hist_kernel(const float* rows, int64_t n, int dim, int64_t stride, int64_t sampled, const float* mean, float lo,
+                                                          float inv_binw, u32* hist) {
+  __shared__ u32 h[4096];
+  for (int i = threadIdx.x; i < 4096; i += 256) h[i] = 0;
+  __syncthreads();
+  for (int64_t j = blockIdx.x; j < sampled; j += gridDim.x) {
+    const int64_t r = j * stride;
+    if (r >= n) break;
+    const float* src = rows + r * dim;
+    for (int c = threadIdx.x; c < dim; c += 256) {
+      int b = (int)((src[c] - mean[c] - lo) * inv_binw);
+      b = b < 0 ? 0 : (b > 4095 ? 4095 : b);
+      atomicAdd(&h[b], 1u);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 4096; i += 256)
+    if (h[i]) atomicAdd(&hist[i], h[i]);
+}
+constexpr int ACC_FORCE = 0x38000000;   // start value of a row that must pass whatever the threshold (thresholds <= TQ_MAX8, |dot| < 2^27)
+// the batch's margins folded into the rows' start values: acc0b[x] = acc0[x] + ceil(|s| (Qn E[x] + Eq H[x]) / u) + 1, Qn / Eq = the batch's
+// largest |q'| / |q' - qh'| (>= every query's own margin for row x); forced rows and rows whose margin leaves the range: ACC_FORCE
+__global__ __launch_bounds__(256) void fold8_kernel(const int* acc0, const float* erow, const float* hrow, int64_t n, int64_t n_pad, const u32* qmax, float s_abs,
+                                                    float inv_u, int* acc0b) {
+  const float qn = __uint_as_float(qmax[0]), eq = __uint_as_float(qmax[1]);
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n_pad; r += (int64_t)gridDim.x * 256) {
+    int v = acc0[r];
+    if (r < n) {
+      const float add = ceilf(s_abs * (qn * erow[r] + eq * hrow[r]) * inv_u) + 1.f;
+      v = add < 536870912.f ? v + (int)add : ACC_FORCE;   // (erow = +inf, or a NaN: forced)
+    }
+    acc0b[r] = v;
+  }
+}
+// after (re)quantising: scal8[6] = max |x'| bound (for the thresholds' fp32 slack); scal8f = scal8 with the two margin entries zeroed
+__global__ void scal_finish_kernel(float* scal8, float* scal8f) {
+  if (threadIdx.x == 0) {
+    scal8[6] = scal8[0] + scal8[1];
+    scal8[7] = 0.f;
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) scal8f[threadIdx.x] = threadIdx.x < 2 ? 0.f : scal8[threadIdx.x];
+}
+
 // rows [row0, n_pad) are (re)written, as in half_mirror_kernel.  x' = x - mu;  metric 0: R = |x'|^2; otherwise R = -mu.x'.  u = |s| step^2.
 __global__ __launch_bounds__(256) void quant_mirror_kernel(const float* rows, int64_t row0, int64_t n, int64_t n_pad, int dim, int d_pad8, const float* mu, float step,
-                                                           float inv_step, float inv_u, int metric, signed char* x8, int* acc0, float* scal8) {
+                                                           float inv_step, float inv_u, int metric, signed char* x8, int* acc0, float* scal8, float* erow,
+                                                           float* hrow, u32* forced_count) {
   const int lane = lane_id();
   const int64_t nwaves = (int64_t)gridDim.x * 4;
   float m_e1 = 0.f, m_nxh = 0.f, m_xn = 0.f, m_bad = 0.f, m_r = 0.f;
@@ -339,7 +395,11 @@ __global__ __launch_bounds__(256) void quant_mirror_kernel(const float* rows, in
     signed char* dst = x8 + r * d_pad8;
     if (r >= n) {
       for (int c = lane * 4; c < d_pad8; c += 256) *reinterpret_cast<u32*>(dst + c) = 0u;
-      if (lane == 0) acc0[r] = -(1 << 30);
+      if (lane == 0) {
+        acc0[r] = -(1 << 30);
+        erow[r] = 0.f;
+        hrow[r] = 0.f;
+      }
       continue;
     }
     const float* src = rows + r * dim;
@@ -384,13 +444,24 @@ __global__ __launch_bounds__(256) void quant_mirror_kernel(const float* rows, in
     }
     const float R = metric == 0 ? c2 : -mx;
     const float a0 = ceilf(-R * inv_u) + 1.f;
-    if (!(fabsf(a0) < 536870912.f)) m_bad = 1.f;   // |acc0| must stay below 2^29 (the dot product adds < 2^27)
-    if (lane == 0) acc0[r] = (int)fminf(fmaxf(a0, -536870912.f), 536870912.f);
-    m_e1 = fmaxf(m_e1, sqrtf(e2) * 1.00001f + 1.2e-7f * sqrtf(c2));   // (+ the rounding of x - mu itself)
-    m_nxh = fmaxf(m_nxh, sqrtf(h2) * 1.00001f);
+    const float e1 = sqrtf(e2) * 1.00001f + 1.2e-7f * sqrtf(c2);   // (+ the rounding of x - mu itself)
+    const float nxh = sqrtf(h2) * 1.00001f;
+    if (s2 != s2 || !(s2 < 3.0e38f)) m_bad = 1.f;
+    // |acc0| must stay below 2^29 (the dot product adds < 2^27).  A row beyond that - an outlier far outside the clipped grid - is FORCED:
+    // never selected on approximate keys (acc0 = -2^30, as on padding rows), always passed by the exact filter (erow = +inf -> fold8_kernel
+    // gives it ACC_FORCE); it does not enter the table's maxima (they only serve rows that are tested)
+    const bool forced = !(fabsf(a0) < 536870912.f);
+    if (lane == 0) {
+      acc0[r] = forced ? -(1 << 30) : (int)a0;
+      erow[r] = forced ? __builtin_inff() : e1;
+      hrow[r] = nxh;
+      if (forced) atomicAdd(forced_count, 1u);
+    }
+    if (forced) continue;
+    m_e1 = fmaxf(m_e1, e1);
+    m_nxh = fmaxf(m_nxh, nxh);
     m_xn = fmaxf(m_xn, s2);
     m_r = fmaxf(m_r, fabsf(R));
-    if (s2 != s2 || !(s2 < 3.0e38f)) m_bad = 1.f;
   }
   if (lane == 0) {
     atomic_max_pos(&scal8[0], m_e1);
@@ -414,6 +485,7 @@ struct Prep8Extra {
   u32* cnt = nullptr;          // prologue: cnt[0 .. nq) = cntv, cnt[nq .. nq + 8) = 0
   u32 cntv = 0;
   u32* gsync = nullptr;        // prologue: 256 group counters = 0
+  u32* qmax = nullptr;         // [2] (zeroed by the caller): atomicMax of the float bits of |q'| and |q' - qh'| over the batch (fold8_kernel reads them)
 };
 __global__ __launch_bounds__(256) void query_prep8_kernel(const float* q, int64_t nq, int64_t b_pad, int dim, int d_pad8, const float* mu, float step, float inv_step,
                                                           int metric, signed char* q8, float* qstat, Prep8Extra x) {
@@ -468,10 +540,15 @@ __global__ __launch_bounds__(256) void query_prep8_kernel(const float* q, int64_
     qm += __shfl_xor(qm, o);
   }
   if (lane == 0) {
+    const float nqc = sqrtf(c2) * 1.000001f, eqc = sqrtf(e2) * 1.00001f + 1.2e-7f * sqrtf(c2);
     qstat[r * 4 + 0] = s2;
-    qstat[r * 4 + 1] = sqrtf(c2) * 1.000001f;
-    qstat[r * 4 + 2] = sqrtf(e2) * 1.00001f + 1.2e-7f * sqrtf(c2);
+    qstat[r * 4 + 1] = nqc;
+    qstat[r * 4 + 2] = eqc;
     qstat[r * 4 + 3] = metric == 0 ? c2 : (metric == 1 ? 1.f - qm : -qm);
+    if (x.qmax) {   // (non-negative floats order like their bit patterns; a NaN's pattern is above every number: its batch forces every row)
+      atomicMax(&x.qmax[0], __float_as_uint(nqc));
+      atomicMax(&x.qmax[1], __float_as_uint(eqc));
+    }
   }
 }
 
@@ -636,11 +713,15 @@ static int32_t ensure_mirror8(Index& ix) {
   hipStream_t s = ix.stream_;
   const size_t keep_rows = extend ? (size_t)m.n8 : 0;
   if (!grow_keep(m.x8, (size_t)n_pad * d_pad8, keep_rows * d_pad8, s) || !grow_keep(m.acc0, (size_t)n_pad * 4, keep_rows * 4, s) || !m.scal8.reserve(64) ||
-      !m.mu8.reserve((size_t)d_pad8 * 4)) {
+      !m.mu8.reserve((size_t)d_pad8 * 4) || !grow_keep(m.erow, (size_t)n_pad * 4, keep_rows * 4, s) || !grow_keep(m.hrow, (size_t)n_pad * 4, keep_rows * 4, s) ||
+      !m.acc0b.reserve((size_t)n_pad * 4) || !m.scal8f.reserve(64) || !m.qmax.reserve(16) || !m.hist.reserve((4096 + 8) * 4)) {
     (void)hipGetLastError();
     if (!extend) {   // (nothing half-built stays behind: the callers for whom the mirror is optional carry on without it)
       m.x8.release();
       m.acc0.release();
+      m.erow.release();
+      m.hrow.release();
+      m.acc0b.release();
       m.version8 = -1;
     }
     return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory for the 8-bit mirror");
@@ -668,8 +749,39 @@ static int32_t ensure_mirror8(Index& ix) {
     std::memcpy(&omax, &m.h_scal8[7], 4);
     const float lo = host_ord2f(omin), hi = host_ord2f(omax);
     m.i8_ok = m.h_scal8[3] == 0.f && omin <= omax && hi > lo && std::isfinite(lo) && std::isfinite(hi) && std::isfinite(hi - lo);
-    const float z0 = m.i8_ok ? 0.5f * lo + 0.5f * hi : 0.f;
-    const float half = m.i8_ok ? std::max(hi - z0, z0 - lo) : 127.f;
+    float clo = lo, chi = hi;
+    if (m.i8_ok) {   // clip both tails of the SAMPLE's x - mean at max(2, 1e-7 x values) values (centre_hist_kernel)
+      const float binw = (hi - lo) / 4096.f;
+      std::vector<u32> hh(4096);
+      er = hipMemsetAsync(m.hist.p, 0, (4096 + 8) * 4, s);
+      if (er != hipSuccess) return ix.hip_fail(er, "memset");
+      if (binw > 0.f && std::isfinite(1.f / binw)) {
+        hipLaunchKernelGGL(centre_hist_kernel, dim3((unsigned)std::min<int64_t>(sampled, 4096)), dim3(256), 0, s, ix.d_rows_, n, dim, stride, sampled, m.mu8.as<float>(),
+                           lo, 1.f / binw, m.hist.as<u32>());
+        er = hipMemcpyAsync(hh.data(), m.hist.p, 4096 * 4, hipMemcpyDeviceToHost, s);
+        if (er == hipSuccess) er = hipStreamSynchronize(s);
+        if (er != hipSuccess) return ix.hip_fail(er, "8-bit mirror: value histogram");
+        const unsigned long long tol = std::max<unsigned long long>(2ull, (unsigned long long)(1e-7 * (double)sampled * (double)dim));
+        unsigned long long cum = 0;
+        int blo = 0, bhi = 4095;
+        for (blo = 0; blo < 4096; ++blo) {
+          cum += hh[(size_t)blo];
+          if (cum > tol) break;
+        }
+        cum = 0;
+        for (bhi = 4095; bhi >= 0; --bhi) {
+          cum += hh[(size_t)bhi];
+          if (cum > tol) break;
+        }
+        const float a = lo + (float)blo * binw, b = lo + (float)(bhi + 1) * binw;
+        if (blo < 4096 && bhi >= 0 && b > a) {
+          clo = a;
+          chi = b;
+        }
+      }
+    }
+    const float z0 = m.i8_ok ? 0.5f * clo + 0.5f * chi : 0.f;
+    const float half = m.i8_ok ? std::max(chi - z0, z0 - clo) : 127.f;
     m.step8 = half / 127.f;
     if (m.i8_ok && !(m.step8 > 0.f && std::isfinite(1.f / (m.step8 * m.step8)))) m.i8_ok = false;
     if (m.i8_ok) hipLaunchKernelGGL(mu_finish_kernel, dim3(1), dim3(64), 0, s, m.mu8.as<float>(), dim, z0, m.scal8.as<float>());
@@ -678,16 +790,26 @@ static int32_t ensure_mirror8(Index& ix) {
     const float u = (ix.metric_ == 0 ? 2.f : 1.f) * m.step8 * m.step8;
     const int64_t row0 = extend ? m.n8 : 0;
     hipLaunchKernelGGL(quant_mirror_kernel, dim3((unsigned)std::min<int64_t>((n_pad - row0 + 3) / 4, 8192)), dim3(256), 0, s, ix.d_rows_, row0, n, n_pad,
-                       dim, d_pad8, m.mu8.as<float>(), m.step8, 1.f / m.step8, 1.f / u, ix.metric_, m.x8.as<signed char>(), m.acc0.as<int>(), m.scal8.as<float>());
+                       dim, d_pad8, m.mu8.as<float>(), m.step8, 1.f / m.step8, 1.f / u, ix.metric_, m.x8.as<signed char>(), m.acc0.as<int>(), m.scal8.as<float>(),
+                       m.erow.as<float>(), m.hrow.as<float>(), m.hist.as<u32>() + 4096);
+    hipLaunchKernelGGL(scal_finish_kernel, dim3(1), dim3(64), 0, s, m.scal8.as<float>(), m.scal8f.as<float>());
+    u32 forced = 0;
     er = hipMemcpyAsync(m.h_scal8, m.scal8.p, 32, hipMemcpyDeviceToHost, s);
+    if (er == hipSuccess) er = hipMemcpyAsync(&forced, m.hist.as<u32>() + 4096, 4, hipMemcpyDeviceToHost, s);
     if (er == hipSuccess) er = hipStreamSynchronize(s);
     if (er != hipSuccess) return ix.hip_fail(er, "8-bit mirror build");
-    if (m.h_scal8[3] != 0.f) m.i8_ok = false;   // a row constant beyond int32 (or a non-finite value): the fp16 engine serves this table
+    m.forced_rows8 = (int64_t)forced;   // (accumulated over extensions: the counter is only zeroed with the histogram)
+    // a non-finite value, or a table most of whose row constants leave the accumulator's range (IP / COSINE far from the origin: |mu . x'| / step^2):
+    // the fp16 engine serves this table
+    if (m.h_scal8[3] != 0.f || (double)forced > 0.01 * (double)n) m.i8_ok = false;
     m.extended_rows8 += extend ? n - row0 : 0;
   }
   if (!m.i8_ok) {   // nothing of it is used: give the memory back
     m.x8.release();
     m.acc0.release();
+    m.erow.release();
+    m.hrow.release();
+    m.acc0b.release();
   }
   if (!extend) {
     m.i8_overflows = 0;
@@ -709,8 +831,10 @@ int32_t quant8_view(Index& ix, Quant8View* v) {
   const HalfMirror& m = *ix.mirror_;
   if (!m.i8_ok) return EPS_OK;
   v->x8 = m.x8.as<signed char>();
-  v->acc0 = m.acc0.as<int>();
-  v->scal8 = m.scal8.as<float>();
+  // (what the traversal kernels read: the start values with the CURRENT batch's per-row margins folded in - quant8_queries below folds
+  // them after every query preparation - and the maxima whose two margin entries are zero: their thresholds carry no margin)
+  v->acc0 = m.acc0b.as<int>();
+  v->scal8 = m.scal8f.as<float>();
   v->mu = m.mu8.as<float>();
   v->d_pad8 = m.d_pad8;
   v->step = m.step8;
@@ -720,8 +844,14 @@ int32_t quant8_view(Index& ix, Quant8View* v) {
 
 // nq queries on the mirror's grid: q8 [nq][d_pad8], qstat [nq][4] (device buffers of the caller)
 void quant8_queries(Index& ix, const Quant8View& v, const float* dq, int64_t nq, signed char* q8, float* qstat) {
+  HalfMirror& m = *ix.mirror_;
+  Prep8Extra px;
+  px.qmax = m.qmax.as<u32>();
+  (void)hipMemsetAsync(m.qmax.p, 0, 8, ix.stream_);
   hipLaunchKernelGGL(query_prep8_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, ix.stream_, dq, nq, nq, (int)ix.dim_, v.d_pad8, v.mu, v.step,
-                     1.f / v.step, ix.metric_, q8, qstat, Prep8Extra());
+                     1.f / v.step, ix.metric_, q8, qstat, px);
+  hipLaunchKernelGGL(fold8_kernel, dim3((unsigned)std::min<int64_t>((m.n_pad8 + 255) / 256, 8192)), dim3(256), 0, ix.stream_, m.acc0.as<int>(), m.erow.as<float>(),
+                     m.hrow.as<float>(), m.n8, m.n_pad8, m.qmax.as<u32>(), ix.metric_ == 0 ? 2.f : 1.f, 1.f / v.u, m.acc0b.as<int>());
 }
 
 bool flat_mfma_profitable(const Index& ix, int64_t nq, int k) {
@@ -791,8 +921,15 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   const bool prologue = seeded && version >= 7;   // one launch resets everything a seeded call starts from
   const bool gsync_env = !(getenv("EPS_MFMA_GROUPSYNC") && atoi(getenv("EPS_MFMA_GROUPSYNC")) == 0);
   const bool prep_does_it_all = i8 && version >= 7;   // fragment-major copy + prologue inside query_prep8_kernel: two launches less per call
+  hipError_t er_ = hipSuccess;
+  const bool fold = i8 && !approx;   // exact mode: per-row margins folded into the start values, thresholds without margin
   if (i8) {
     Prep8Extra px;
+    if (fold) {
+      px.qmax = m.qmax.as<u32>();
+      er_ = hipMemsetAsync(m.qmax.p, 0, 8, s);
+      if (er_ != hipSuccess) return ix.hip_fail(er_, "memset");
+    }
     if (prep_does_it_all) {
       px.qf = m.qf.as<signed char>();
       if (prologue) {   // thresholds = 0x7F800000 pairs (+inf as fp32; as the 8-bit pass's int32 thresholds: never passes - the padding entries keep it)
@@ -806,6 +943,9 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
     }
     hipLaunchKernelGGL(query_prep8_kernel, dim3((unsigned)((b_pad + 3) / 4)), dim3(256), 0, s, dq, nq, b_pad, (int)ix.dim_, m.d_pad8, m.mu8.as<float>(), m.step8,
                        1.f / m.step8, ix.metric_, m.q8.as<signed char>(), m.qstat.as<float>(), px);
+    if (fold)
+      hipLaunchKernelGGL(fold8_kernel, dim3((unsigned)std::min<int64_t>((m.n_pad8 + 255) / 256, 8192)), dim3(256), 0, s, m.acc0.as<int>(), m.erow.as<float>(),
+                         m.hrow.as<float>(), m.n8, m.n_pad8, m.qmax.as<u32>(), ix.metric_ == 0 ? 2.f : 1.f, 1.f / u8, m.acc0b.as<int>());
   } else {
     hipLaunchKernelGGL(query_prep_kernel, dim3((unsigned)((b_pad + 3) / 4)), dim3(256), 0, s, dq, nq, b_pad, (int)ix.dim_,
                        m.d_pad, m.qh.as<_Float16>(), m.qstat.as<float>(), m.drop);
@@ -882,8 +1022,9 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   fa.xh = i8 ? reinterpret_cast<const _Float16*>(m.x8.p) : m.xh.as<_Float16>();
   fa.qh = q_op;
   fa.qf = m.qf.as<_Float16>();
-  fa.base = i8 ? m.acc0.as<float>() : (ix.metric_ == 0 ? m.xn.as<float>() : m.zeros.as<float>());   // (8-bit: int32 words, only ever moved)
-  fa.base_s = i8 ? m.acc0.as<float>() : (ix.metric_ == 0 ? m.xn_s.as<float>() : m.zeros_s.as<float>());
+  // (8-bit: int32 words, only ever moved; exact mode: the batch's folded start values)
+  fa.base = i8 ? (fold ? m.acc0b.as<float>() : m.acc0.as<float>()) : (ix.metric_ == 0 ? m.xn.as<float>() : m.zeros.as<float>());
+  fa.base_s = i8 ? (fold ? m.acc0b.as<float>() : m.acc0.as<float>()) : (ix.metric_ == 0 ? m.xn_s.as<float>() : m.zeros_s.as<float>());
   fa.T = m.T.as<float>();
   fa.d_pad = d_pad_h;
   fa.tiles_q = (int)(b_pad / BN3);
@@ -927,7 +1068,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   ra.total = total;
   ra.T_next = nullptr;
   ra.qstat = m.qstat.as<float>();
-  ra.scal = i8 ? m.scal8.as<float>() : m.scal.as<float>();
+  ra.scal = i8 ? (fold ? m.scal8f.as<float>() : m.scal8.as<float>()) : m.scal.as<float>();
   ra.bits = i8 ? 8 : 16;
   ra.u = u8;
   ra.slack = 0.f;   // (set below, with the stages)
@@ -1014,7 +1155,10 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
       if (smp_version != ix.rows_version_ || smp_n != n || smp_rows != S0) {   // (also after an append: n changed)
         if (!smp_x.reserve((size_t)S0 * d_pad_h * 2) || !smp_base.reserve((size_t)S0 * 4) || !smp_base_u.reserve((size_t)S0 * 4))
           return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory (seed sample)");
-        hipLaunchKernelGGL(seed_sample_kernel, dim3((unsigned)S0), dim3(256), 0, s, fa.xh, reinterpret_cast<const u32*>(fa.base_s), reinterpret_cast<const u32*>(fa.base),
+        // (8-bit: the sample keeps the UNFOLDED start values - the dense seed pass ranks approximate keys and tests nothing - so it stays
+        // valid from batch to batch)
+        hipLaunchKernelGGL(seed_sample_kernel, dim3((unsigned)S0), dim3(256), 0, s, fa.xh, i8 ? m.acc0.as<u32>() : reinterpret_cast<const u32*>(fa.base_s),
+                           i8 ? m.acc0.as<u32>() : reinterpret_cast<const u32*>(fa.base),
                            sample_stride, sample_head, d_pad_h, smp_x.as<_Float16>(), smp_base.as<u32>(), smp_base_u.as<u32>());
         smp_version = ix.rows_version_;
         smp_n = n;
@@ -1061,7 +1205,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
       if ((!have_T || st == 0) && !(have_T && i8 && prologue)) {
         if (i8)
           hipLaunchKernelGGL(threshold8_kernel, dim3((unsigned)((b_pad + 255) / 256)), dim3(256), 0, s, run_keys, k, nq, b_pad, m.qstat.as<float>(),
-                             m.scal8.as<float>(), ix.metric_, u8, m.T.as<int>(), cnt, m.gsync.as<u32>(), rerank_slack, approx ? 1 : 0, pad_only);
+                             fold ? m.scal8f.as<float>() : m.scal8.as<float>(), ix.metric_, u8, m.T.as<int>(), cnt, m.gsync.as<u32>(), rerank_slack, approx ? 1 : 0, pad_only);
         else
           hipLaunchKernelGGL(threshold_kernel, dim3((unsigned)((b_pad + 255) / 256)), dim3(256), 0, s, run_keys, k, nq, b_pad,
                              m.qstat.as<float>(), m.scal.as<float>(), ix.metric_, m.T.as<float>(), cnt, m.gsync.as<u32>(), rerank_slack, approx ? 1 : 0, pad_only);
