@@ -164,6 +164,7 @@ typedef struct eps_search_stats {
   int64_t main_kernel_bits; /* operand width of that launch: 32 (fp32 stream / traversal), 16 or 8 (matrix engine) */
   double filter_ms_all;     /* device time of ALL filter-stage launches of the call (the dominant kernel runs once per stage; r4) */
   int64_t filter_rows_all;  /* rows those launches covered, summed (x main_kernel_queries = the call's matrix work)              */
+  int64_t i8_folded;        /* 1: the 8-bit pass of this call ran with per-row margins folded into the rows' start values (a table whose rows differ: clamped / forced outlier rows; r4) */
   int64_t i8_declined;      /* 1: this call probed the 8-bit pass on this table, found its bound too loose for the data and ran the fp16 pass (r4) */
 } eps_search_stats;
 

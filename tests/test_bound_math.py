@@ -33,21 +33,35 @@ def col_centre(X, sample=None):
     mean = (S.astype(F).sum(0, dtype=F) / F(len(S))).astype(F)
     c = (X - mean).astype(F)
     lo, hi = F(c.min()), F(c.max())
-    cs = (S - mean).astype(F)
-    binw = (hi - lo) / F(4096.0)
-    if not binw > 0:
-        return mean, F(0.0)
-    b = np.clip(((cs - lo) * (F(1.0) / binw)).astype(np.int64), 0, 4095)
-    hist = np.bincount(b.ravel(), minlength=4096)
-    tol = max(2, int(TAIL * cs.size))
-    cum = np.cumsum(hist)
-    blo = int(np.searchsorted(cum, tol, side="right"))              # first bin whose cumulative count exceeds tol
-    cumr = np.cumsum(hist[::-1])
-    bhi = 4095 - int(np.searchsorted(cumr, tol, side="right"))
-    clo = lo + F(blo) * binw
-    chi = lo + F(bhi + 1) * binw
-    if not chi > clo:
-        clo, chi = lo, hi
+    tol = max(2, int(TAIL * S.size))
+
+    def clip_range(mean, clo, chi):
+        cs = (S - mean).astype(F)
+        for _ in range(3):      # (an outlier thousands of grid widths away leaves the bulk in ONE bin: the histogram is taken again inside the cut)
+            binw = (chi - clo) / F(4096.0)
+            if not binw > 0:
+                break
+            b = np.clip(((cs - clo) * (F(1.0) / binw)).astype(np.int64), 0, 4095)
+            hist = np.bincount(b.ravel(), minlength=4096)
+            cum = np.cumsum(hist)
+            blo = int(np.searchsorted(cum, tol, side="right"))              # first bin whose cumulative count exceeds tol
+            cumr = np.cumsum(hist[::-1])
+            bhi = 4095 - int(np.searchsorted(cumr, tol, side="right"))
+            a_, b_ = clo + F(blo) * binw, clo + F(bhi + 1) * binw
+            if not (blo < 4096 and bhi >= 0 and b_ > a_):
+                break
+            cut_most = (b_ - a_) < F(0.25) * (chi - clo)
+            clo, chi = a_, b_
+            if not cut_most:
+                break
+        return clo, chi
+    clo, chi = clip_range(mean, lo, hi)
+    if clo > lo or chi < hi:
+        # something was cut: the column means it polluted are estimated again from values clamped into the cut, the range once more
+        mean2 = (np.clip(S, mean + clo, mean + chi).astype(F).sum(0, dtype=F) / F(len(S))).astype(F)
+        delta = F(np.abs(mean2 - mean).max())
+        mean = mean2
+        clo, chi = clip_range(mean, lo - delta, hi + delta)
     z0 = F(0.5) * clo + F(0.5) * chi
     return (mean + z0).astype(F), F(max(chi - z0, z0 - clo))
 
@@ -264,7 +278,10 @@ def test_one_outlier_value_costs_its_row_not_the_table():
     X2 = rng.random((n, d), dtype=F)
     X2[1234, 5] = F(1000.0)         # so far out that its row constant leaves the accumulator's range: the row is FORCED (always passes)
     m3 = mirror(X2, 0)
-    assert m3["forced"][1234] and m3["forced"].sum() == 1
+    assert m3["forced"][1234] and m3["forced"].sum() == 1 and m3["step"] < F(1.05) * clean["step"]   # (the range histogram refines itself)
+    X4 = rng.random((n, d), dtype=F)
+    X4[7, 7] = F(30000.0)
+    assert mirror(X4, 0)["step"] < F(1.05) * clean["step"]
     qi3, qs3 = query(q, m3, 0)
     dd3 = dist(q, X2, 0)
     thr3 = F(np.partition(dd3, n // 20)[n // 20])

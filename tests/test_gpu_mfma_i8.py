@@ -110,8 +110,8 @@ def test_auto_stops_paying_for_an_8_bit_pass_that_never_filters(amd):
     n, d, nq = 90_000, 256, 96
     # (r4's clipped grid + per-row margins serve a table with a FEW outliers - next test; what defeats ONE grid is a heavy tail in every
     # row: Cauchy values - whatever the grid, most rows are clamped somewhere and carry residuals as large as the distances)
-    X = np.clip(rng.standard_cauchy((n, d)), -1e5, 1e5).astype(np.float32)
-    Q = np.clip(rng.standard_cauchy((nq, d)), -1e5, 1e5).astype(np.float32)
+    X = np.clip(rng.standard_cauchy((n, d)), -1e4, 1e4).astype(np.float32)     # (inside the fp16 range: the fp16 pass can serve it)
+    Q = np.clip(rng.standard_cauchy((nq, d)), -1e4, 1e4).astype(np.float32)
     ix = amd.GpuIndex(d, 0)
     ix.attach_rows(X)
     ref = ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
@@ -152,14 +152,25 @@ def test_a_few_outlier_values_cost_their_rows_not_the_table(amd):
     X[777, 200] = -40.0
     X[60_000, 17] = 30_000.0      # forced: |R| / u beyond 2^29
     Q = rng.random((nq, d), dtype=np.float32)
+    clean = amd.GpuIndex(d, 0)          # the same table without the three values: what the filter passes there
+    Xc = X.copy()
+    Xc[4321, 3], Xc[777, 200], Xc[60_000, 17] = 0.5, 0.5, 0.5
+    clean.attach_rows(Xc)
+    clean.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_AUTO)
+    stc = clean.stats()
+    assert (stc["main_kernel_bits"], stc["i8_folded"]) == (8, 0), stc      # homogeneous rows: table-wide margin, no fold pass
+    clean.close()
     ix = amd.GpuIndex(d, 0)
     ix.attach_rows(X)
     ref = ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
     for it in range(3):
         same(ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_AUTO), ref, "auto %d" % it)
         st = ix.stats()
-        assert (st["main_kernel_bits"], st["i8_declined"], st["overflow_queries"]) == (8, 0, 0), (it, st)
-        assert st["rerank_rows"] < 400 * nq, st        # ... and it FILTERS (the forced row adds one candidate per query and stage)
+        assert (st["main_kernel_bits"], st["i8_declined"], st["overflow_queries"], st["i8_folded"]) == (8, 0, 0, 1), (it, st)
+        # ... and it FILTERS as if the outliers were not there (the forced row adds one candidate per query and stage)
+        # (the forced row is a candidate of every query in every stage, the two clamped rows of most; the batch's largest query norms
+        # instead of every query's own)
+        assert st["rerank_rows"] < 1.6 * stc["rerank_rows"] + 24 * nq, (st["rerank_rows"], stc["rerank_rows"])
     # queries that ARE the outlier rows (far outside the grid themselves: their batch's margins are as large as their residuals, the
     # lists overflow and the fp16 / stream engines answer - exactly): the rows are found
     Qo = np.stack([X[4321], X[777], X[60_000], X[60_000] + np.float32(0.01)] + [Q[i] for i in range(8)])

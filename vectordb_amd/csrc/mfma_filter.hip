@@ -92,6 +92,7 @@ struct HalfMirror {
   float step8 = 0.f;            // the grid: xh' = step8 * xi around mu8
   bool i8_trusted = false;      // the library's own choice has seen a batch through the 8-bit pass on this mirror (no probe needed)
   int64_t version8 = -1, n8 = 0, n_pad8 = 0, forced_rows8 = 0;
+  bool fold8 = false;           // exact-mode users fold per-row margins per batch (rows differ); else table-wide margin in the thresholds
   int d_pad8 = 0;
   bool i8_ok = false;
   int i8_overflows = 0;         // consecutive batches whose 8-bit pass overflowed its candidate lists (the fp16 pass then answered)
@@ -259,7 +260,10 @@ __global__ __launch_bounds__(256) void query_prep_kernel(const float* q, int64_t
 constexpr int CENTRE_SEG = 32;   // segments of the sample, summed in a fixed order: mu is bit-reproducible (the build's approximate
                                  // kNN keys depend on it, and two builds of one table must give the same graph)
 // partial column sums of sample rows r = (seg * per_seg + i) * stride, i < per_seg:  part[seg][col]
-__global__ __launch_bounds__(256) void colsum_kernel(const float* rows, int64_t n, int dim, int64_t stride, int64_t per_seg, float* part) {
+// (clamp_mean != null: every value is clamped into [clamp_mean[col] + clo, clamp_mean[col] + chi] first - the second, ROBUST estimate of the
+// column means: an outlier of 30 000 in a 65 536-row sample would otherwise move its column's centre by half the grid)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* rows, int64_t n, int dim, int64_t stride, int64_t per_seg, float* part, const float* clamp_mean,
+                                                     float clo, float chi) {
   __shared__ float red[4][64];
   const int col = blockIdx.x * 64 + (threadIdx.x & 63);
   const int sub = threadIdx.x >> 6;
@@ -268,7 +272,11 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* rows, int64_t 
   if (col < dim) {
     for (int64_t i = sub; i < per_seg; i += 4) {
       const int64_t r = (seg * per_seg + i) * stride;
-      if (r < n) s += rows[r * dim + col];
+      if (r < n) {
+        float v = rows[r * dim + col];
+        if (clamp_mean) v = fminf(fmaxf(v, clamp_mean[col] + clo), clamp_mean[col] + chi);
+        s += v;
+      }
     }
   }
   red[sub][threadIdx.x & 63] = s;
@@ -375,10 +383,7 @@ __global__ __launch_bounds__(256) void fold8_kernel(const int* acc0, const float
 }
 // after (re)quantising: scal8[6] = max |x'| bound (for the thresholds' fp32 slack); scal8f = scal8 with the two margin entries zeroed
 __global__ void scal_finish_kernel(float* scal8, float* scal8f) {
-  if (threadIdx.x == 0) {
-    scal8[6] = scal8[0] + scal8[1];
-    scal8[7] = 0.f;
-  }
+  if (threadIdx.x == 0) scal8[6] = scal8[0] + scal8[1];
   __syncthreads();
   if (threadIdx.x < 8) scal8f[threadIdx.x] = threadIdx.x < 2 ? 0.f : scal8[threadIdx.x];
 }
@@ -389,7 +394,7 @@ __global__ __launch_bounds__(256) void quant_mirror_kernel(const float* rows, in
                                                            float* hrow, u32* forced_count) {
   const int lane = lane_id();
   const int64_t nwaves = (int64_t)gridDim.x * 4;
-  float m_e1 = 0.f, m_nxh = 0.f, m_xn = 0.f, m_bad = 0.f, m_r = 0.f;
+  float m_e1 = 0.f, m_nxh = 0.f, m_xn = 0.f, m_bad = 0.f, m_r = 0.f, m_emin = __builtin_inff();
   const bool vec = (dim & 3) == 0 && ((reinterpret_cast<uintptr_t>(rows) & 15) == 0);
   for (int64_t r = row0 + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n_pad; r += nwaves) {
     signed char* dst = x8 + r * d_pad8;
@@ -458,6 +463,7 @@ __global__ __launch_bounds__(256) void quant_mirror_kernel(const float* rows, in
       if (forced) atomicAdd(forced_count, 1u);
     }
     if (forced) continue;
+    m_emin = fminf(m_emin, e1);
     m_e1 = fmaxf(m_e1, e1);
     m_nxh = fmaxf(m_nxh, nxh);
     m_xn = fmaxf(m_xn, s2);
@@ -469,6 +475,7 @@ __global__ __launch_bounds__(256) void quant_mirror_kernel(const float* rows, in
     atomic_max_pos(&scal8[2], m_xn);
     if (m_bad != 0.f) atomic_max_pos(&scal8[3], 1.f);
     atomic_max_pos(&scal8[4], m_r);
+    atomicMin(reinterpret_cast<unsigned int*>(&scal8[7]), __float_as_uint(m_emin));   // (smallest residual norm of a tested row: non-negative floats order like their bits)
   }
 }
 
@@ -738,7 +745,8 @@ static int32_t ensure_mirror8(Index& ix) {
     const int64_t sampled = std::min<int64_t>((n + stride - 1) / stride, per_seg * CENTRE_SEG);
     DevBuf part;
     if (!part.reserve((size_t)CENTRE_SEG * dim * 4)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory for the 8-bit mirror");
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((dim + 63) / 64), CENTRE_SEG), dim3(256), 0, s, ix.d_rows_, n, dim, stride, per_seg, part.as<float>());
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((dim + 63) / 64), CENTRE_SEG), dim3(256), 0, s, ix.d_rows_, n, dim, stride, per_seg, part.as<float>(),
+                       (const float*)nullptr, 0.f, 0.f);
     hipLaunchKernelGGL(colmean_kernel, dim3((unsigned)((d_pad8 + 255) / 256)), dim3(256), 0, s, part.as<float>(), dim, d_pad8, 1.f / (float)sampled, m.mu8.as<float>());
     hipLaunchKernelGGL(minmax_kernel, dim3((unsigned)std::min<int64_t>((n + 3) / 4, 8192)), dim3(256), 0, s, ix.d_rows_, n, dim, m.mu8.as<float>(), m.scal8.as<u32>());
     er = hipMemcpyAsync(m.h_scal8, m.scal8.p, 32, hipMemcpyDeviceToHost, s);
@@ -750,41 +758,81 @@ static int32_t ensure_mirror8(Index& ix) {
     const float lo = host_ord2f(omin), hi = host_ord2f(omax);
     m.i8_ok = m.h_scal8[3] == 0.f && omin <= omax && hi > lo && std::isfinite(lo) && std::isfinite(hi) && std::isfinite(hi - lo);
     float clo = lo, chi = hi;
-    if (m.i8_ok) {   // clip both tails of the SAMPLE's x - mean at max(2, 1e-7 x values) values (centre_hist_kernel)
-      const float binw = (hi - lo) / 4096.f;
+    auto clip_range = [&]() -> int32_t {
+    // clip both tails of the SAMPLE's x - mean at max(2, 1e-7 x values) values (centre_hist_kernel); where the cut removes most of the
+    // range - an outlier thousands of grid widths away leaves the bulk in ONE bin - the histogram is taken again inside the cut (values
+    // outside fall into the edge bins), up to three times
+    for (int round = 0; m.i8_ok && round < 3; ++round) {
+      const float binw = (chi - clo) / 4096.f;
+      if (!(binw > 0.f) || !std::isfinite(1.f / binw)) break;
       std::vector<u32> hh(4096);
       er = hipMemsetAsync(m.hist.p, 0, (4096 + 8) * 4, s);
       if (er != hipSuccess) return ix.hip_fail(er, "memset");
-      if (binw > 0.f && std::isfinite(1.f / binw)) {
-        hipLaunchKernelGGL(centre_hist_kernel, dim3((unsigned)std::min<int64_t>(sampled, 4096)), dim3(256), 0, s, ix.d_rows_, n, dim, stride, sampled, m.mu8.as<float>(),
-                           lo, 1.f / binw, m.hist.as<u32>());
-        er = hipMemcpyAsync(hh.data(), m.hist.p, 4096 * 4, hipMemcpyDeviceToHost, s);
-        if (er == hipSuccess) er = hipStreamSynchronize(s);
-        if (er != hipSuccess) return ix.hip_fail(er, "8-bit mirror: value histogram");
-        const unsigned long long tol = std::max<unsigned long long>(2ull, (unsigned long long)(1e-7 * (double)sampled * (double)dim));
-        unsigned long long cum = 0;
-        int blo = 0, bhi = 4095;
-        for (blo = 0; blo < 4096; ++blo) {
-          cum += hh[(size_t)blo];
-          if (cum > tol) break;
-        }
-        cum = 0;
-        for (bhi = 4095; bhi >= 0; --bhi) {
-          cum += hh[(size_t)bhi];
-          if (cum > tol) break;
-        }
-        const float a = lo + (float)blo * binw, b = lo + (float)(bhi + 1) * binw;
-        if (blo < 4096 && bhi >= 0 && b > a) {
-          clo = a;
-          chi = b;
-        }
+      hipLaunchKernelGGL(centre_hist_kernel, dim3((unsigned)std::min<int64_t>(sampled, 4096)), dim3(256), 0, s, ix.d_rows_, n, dim, stride, sampled, m.mu8.as<float>(),
+                         clo, 1.f / binw, m.hist.as<u32>());
+      er = hipMemcpyAsync(hh.data(), m.hist.p, 4096 * 4, hipMemcpyDeviceToHost, s);
+      if (er == hipSuccess) er = hipStreamSynchronize(s);
+      if (er != hipSuccess) return ix.hip_fail(er, "8-bit mirror: value histogram");
+      const unsigned long long tol = std::max<unsigned long long>(2ull, (unsigned long long)(1e-7 * (double)sampled * (double)dim));
+      unsigned long long cum = 0;
+      int blo = 0, bhi = 4095;
+      for (blo = 0; blo < 4096; ++blo) {
+        cum += hh[(size_t)blo];
+        if (cum > tol) break;
       }
+      cum = 0;
+      for (bhi = 4095; bhi >= 0; --bhi) {
+        cum += hh[(size_t)bhi];
+        if (cum > tol) break;
+      }
+      const float a = clo + (float)blo * binw, b = clo + (float)(bhi + 1) * binw;
+      if (!(blo < 4096 && bhi >= 0 && b > a)) break;
+      const bool cut_most = (b - a) < 0.25f * (chi - clo);
+      clo = a;
+      chi = b;
+      if (!cut_most) break;
+    }
+    return EPS_OK;
+    };
+    {
+      int32_t rc = clip_range();
+      if (rc != EPS_OK) return rc;
+      if (m.i8_ok && (clo > lo || chi < hi)) {
+        // something was cut: the column means it polluted are estimated again from values clamped into the cut (same fixed summation
+        // order), and the range once more around the new means (the first range, widened by the largest move of a mean, bounds it)
+        DevBuf mean1;
+        std::vector<float> h1((size_t)dim), h2((size_t)dim);
+        if (!mean1.reserve((size_t)d_pad8 * 4)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory for the 8-bit mirror");
+        er = hipMemcpyAsync(mean1.p, m.mu8.p, (size_t)d_pad8 * 4, hipMemcpyDeviceToDevice, s);
+        if (er != hipSuccess) return ix.hip_fail(er, "memcpy");
+        hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((dim + 63) / 64), CENTRE_SEG), dim3(256), 0, s, ix.d_rows_, n, dim, stride, per_seg, part.as<float>(),
+                           mean1.as<float>(), clo, chi);
+        hipLaunchKernelGGL(colmean_kernel, dim3((unsigned)((d_pad8 + 255) / 256)), dim3(256), 0, s, part.as<float>(), dim, d_pad8, 1.f / (float)sampled, m.mu8.as<float>());
+        er = hipMemcpyAsync(h1.data(), mean1.p, (size_t)dim * 4, hipMemcpyDeviceToHost, s);
+        if (er == hipSuccess) er = hipMemcpyAsync(h2.data(), m.mu8.p, (size_t)dim * 4, hipMemcpyDeviceToHost, s);
+        if (er == hipSuccess) er = hipStreamSynchronize(s);
+        if (er != hipSuccess) return ix.hip_fail(er, "8-bit mirror: column means");
+        float delta = 0.f;
+        for (int c = 0; c < dim; ++c) delta = std::max(delta, std::fabs(h2[(size_t)c] - h1[(size_t)c]));
+        clo = lo - delta;
+        chi = hi + delta;
+        rc = clip_range();
+        if (rc != EPS_OK) return rc;
+      }
+    }
+    if (m.i8_ok) {
+      er = hipMemsetAsync(m.hist.p, 0, (4096 + 8) * 4, s);   // ([4096]: the forced-row counter of the quantising pass)
+      if (er != hipSuccess) return ix.hip_fail(er, "memset");
     }
     const float z0 = m.i8_ok ? 0.5f * clo + 0.5f * chi : 0.f;
     const float half = m.i8_ok ? std::max(chi - z0, z0 - clo) : 127.f;
     m.step8 = half / 127.f;
     if (m.i8_ok && !(m.step8 > 0.f && std::isfinite(1.f / (m.step8 * m.step8)))) m.i8_ok = false;
-    if (m.i8_ok) hipLaunchKernelGGL(mu_finish_kernel, dim3(1), dim3(64), 0, s, m.mu8.as<float>(), dim, z0, m.scal8.as<float>());
+    if (m.i8_ok) {
+      hipLaunchKernelGGL(mu_finish_kernel, dim3(1), dim3(64), 0, s, m.mu8.as<float>(), dim, z0, m.scal8.as<float>());
+      er = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(m.scal8.as<u32>() + 7), 0x7F800000, 1, s);   // min residual norm: +inf
+      if (er != hipSuccess) return ix.hip_fail(er, "memset");
+    }
   }
   if (m.i8_ok) {
     const float u = (ix.metric_ == 0 ? 2.f : 1.f) * m.step8 * m.step8;
@@ -802,6 +850,11 @@ static int32_t ensure_mirror8(Index& ix) {
     // a non-finite value, or a table most of whose row constants leave the accumulator's range (IP / COSINE far from the origin: |mu . x'| / step^2):
     // the fp16 engine serves this table
     if (m.h_scal8[3] != 0.f || (double)forced > 0.01 * (double)n) m.i8_ok = false;
+    // Per-row margins are folded per batch only where rows DIFFER: a forced row, or a residual norm beyond 1.5 x the smallest (a clamped
+    // value somewhere).  On homogeneous tables (every row a plain rounding residual: within a few per cent of each other) the table-wide
+    // margin in the thresholds is as tight, keeps every query's own norms, and costs no pass over the rows (10M rows: 40 us per batch).
+    m.fold8 = forced > 0 || m.h_scal8[0] > 1.5f * m.h_scal8[7] || (getenv("EPS_MFMA_FOLD") && atoi(getenv("EPS_MFMA_FOLD")) != 0);
+    if (getenv("EPS_MFMA_FOLD") && atoi(getenv("EPS_MFMA_FOLD")) == 0 && forced == 0) m.fold8 = false;
     m.extended_rows8 += extend ? n - row0 : 0;
   }
   if (!m.i8_ok) {   // nothing of it is used: give the memory back
@@ -833,8 +886,8 @@ int32_t quant8_view(Index& ix, Quant8View* v) {
   v->x8 = m.x8.as<signed char>();
   // (what the traversal kernels read: the start values with the CURRENT batch's per-row margins folded in - quant8_queries below folds
   // them after every query preparation - and the maxima whose two margin entries are zero: their thresholds carry no margin)
-  v->acc0 = m.acc0b.as<int>();
-  v->scal8 = m.scal8f.as<float>();
+  v->acc0 = m.fold8 ? m.acc0b.as<int>() : m.acc0.as<int>();
+  v->scal8 = m.fold8 ? m.scal8f.as<float>() : m.scal8.as<float>();
   v->mu = m.mu8.as<float>();
   v->d_pad8 = m.d_pad8;
   v->step = m.step8;
@@ -846,10 +899,13 @@ int32_t quant8_view(Index& ix, Quant8View* v) {
 void quant8_queries(Index& ix, const Quant8View& v, const float* dq, int64_t nq, signed char* q8, float* qstat) {
   HalfMirror& m = *ix.mirror_;
   Prep8Extra px;
-  px.qmax = m.qmax.as<u32>();
-  (void)hipMemsetAsync(m.qmax.p, 0, 8, ix.stream_);
+  if (m.fold8) {
+    px.qmax = m.qmax.as<u32>();
+    (void)hipMemsetAsync(m.qmax.p, 0, 8, ix.stream_);
+  }
   hipLaunchKernelGGL(query_prep8_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, ix.stream_, dq, nq, nq, (int)ix.dim_, v.d_pad8, v.mu, v.step,
                      1.f / v.step, ix.metric_, q8, qstat, px);
+  if (m.fold8)
   hipLaunchKernelGGL(fold8_kernel, dim3((unsigned)std::min<int64_t>((m.n_pad8 + 255) / 256, 8192)), dim3(256), 0, ix.stream_, m.acc0.as<int>(), m.erow.as<float>(),
                      m.hrow.as<float>(), m.n8, m.n_pad8, m.qmax.as<u32>(), ix.metric_ == 0 ? 2.f : 1.f, 1.f / v.u, m.acc0b.as<int>());
 }
@@ -922,7 +978,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   const bool gsync_env = !(getenv("EPS_MFMA_GROUPSYNC") && atoi(getenv("EPS_MFMA_GROUPSYNC")) == 0);
   const bool prep_does_it_all = i8 && version >= 7;   // fragment-major copy + prologue inside query_prep8_kernel: two launches less per call
   hipError_t er_ = hipSuccess;
-  const bool fold = i8 && !approx;   // exact mode: per-row margins folded into the start values, thresholds without margin
+  const bool fold = i8 && !approx && m.fold8;   // exact mode on a table whose rows differ: per-row margins folded into the start values, thresholds without margin
   if (i8) {
     Prep8Extra px;
     if (fold) {
@@ -943,6 +999,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
     }
     hipLaunchKernelGGL(query_prep8_kernel, dim3((unsigned)((b_pad + 3) / 4)), dim3(256), 0, s, dq, nq, b_pad, (int)ix.dim_, m.d_pad8, m.mu8.as<float>(), m.step8,
                        1.f / m.step8, ix.metric_, m.q8.as<signed char>(), m.qstat.as<float>(), px);
+    if (fold) ix.stats_.i8_folded = 1;
     if (fold)
       hipLaunchKernelGGL(fold8_kernel, dim3((unsigned)std::min<int64_t>((m.n_pad8 + 255) / 256, 8192)), dim3(256), 0, s, m.acc0.as<int>(), m.erow.as<float>(),
                          m.hrow.as<float>(), m.n8, m.n_pad8, m.qmax.as<u32>(), ix.metric_ == 0 ? 2.f : 1.f, 1.f / u8, m.acc0b.as<int>());

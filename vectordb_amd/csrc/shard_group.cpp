@@ -351,6 +351,7 @@ class ShardGroup : public IndexBase {
       t.main_kernel_queries = std::max(t.main_kernel_queries, s.main_kernel_queries);
       t.main_kernel_bits = std::max(t.main_kernel_bits, s.main_kernel_bits);
       t.i8_declined += s.i8_declined;
+      t.i8_folded += s.i8_folded;
       t.filter_ms_all = std::max(t.filter_ms_all, s.filter_ms_all);
       t.filter_rows_all += s.filter_rows_all;
     }
