@@ -100,6 +100,41 @@ def test_i8_engine_on_other_distributions(amd, kind):
     ix.close()
 
 
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_a_handful_of_queries_takes_the_short_chain_and_the_split_rerank(amd, monkeypatch, metric):
+    """r4: 1 ... 16 queries per call run the fused launch chain (query preparation + fragment copy + start state in one launch, seed
+    selection straight into the candidate lists by a 16-wavefront workgroup, finalisation in the last re-rank, 3 stages up to 4
+    queries) and every re-rank spread over 8 workgroups per query with a last-arrival merge: the same bits as the stream scan, with
+    deletions and a filter, for k = 1 / 10 / 100, and the same with the split re-rank switched off."""
+    n, d = 150_000, 192
+    X, Q = data(n, d, 71), data(16, d, 72)
+    X[5000:5040] = X[4999]                      # ties: equal distances, ordered by id
+    if metric == 1:
+        X = amd.normalize_rows(X, only_if_nonzero=True)
+        Q = amd.normalize_rows(Q, only_if_nonzero=False)
+    Q[1] = X[5010]
+    idc = np.arange(n, dtype=np.int32)
+    for split in ("1", "0"):
+        monkeypatch.setenv("EPS_RERANK_SPLIT", split)
+        ix = amd.GpuIndex(d, metric)
+        ix.attach_rows(X)
+        for setup in ("plain", "deleted + filter"):
+            if setup != "plain":
+                ix.set_deleted(bitset(n, range(3, n, 11)))
+                ix.set_int_filter(idc, ">=", 1000)
+            for nq in (1, 2, 3, 4, 5, 16):
+                for k in (1, 10, 100):
+                    a = ix.search(Q[:nq], k, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
+                    st = ix.stats()
+                    assert st["main_kernel_bits"] == 8 and st["overflow_queries"] == 0, (split, setup, nq, k, st)
+                    same(a, ix.search(Q[:nq], k, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM), "split %s %s nq %d k %d" % (split, setup, nq, k))
+            # the same call many times: the arrival counters are back at zero after every launch
+            first = ix.search(Q[:2], 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
+            for _ in range(20):
+                same(ix.search(Q[:2], 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8), first, "repeat")
+        ix.close()
+
+
 def test_auto_stops_paying_for_an_8_bit_pass_that_never_filters(amd):
     """A table the 8-bit bound cannot filter (heavy-tailed values in every row).  r4: the library's own choice PROBES the
     8-bit pass on the first batch it sends through a mirror - the candidate count of the first, smallest stage predicts the others -

@@ -140,11 +140,13 @@ void launch_flat_scan(const FlatScanArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // merge the `lists` key slots of each query (per-wave sorted lists, or an unsorted candidate list) into its top-k.
 // One block per query.
-template <int KPL>
-__global__ __launch_bounds__(256) void merge_lists_kernel(const u64* partial, int lists, int k, u64* run_keys,
+// NW wavefronts per query: 4 for batches, 16 for a handful of queries (a single query's 4096 seed keys: 4 rounds instead of 16)
+template <int KPL, int NW>
+__global__ __launch_bounds__(NW * 64) void merge_lists_kernel(const u64* partial, int lists, int k, u64* run_keys,
                                                           int merge_run, const u32* counts, FilterSpec vis, u64 id_stride, u32 id_head,
                                                           u32* seed_cand, int seed_cap, u32* seed_cnt) {
-  __shared__ u64 sh[4][KPL * 64];
+  __shared__ u64 sh[NW][KPL * 64];
+  constexpr int NT = NW * 64;
   const int64_t q = blockIdx.x;
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
@@ -160,8 +162,8 @@ __global__ __launch_bounds__(256) void merge_lists_kernel(const u64* partial, in
     thr[0] = run_keys[q * k + (k - 1)];
     if (wave == 0) L[0].load(run_keys + q * k, k);
   }
-  const int rounded = (total + 255) & ~255;
-  for (int i = threadIdx.x; i < rounded; i += 256) {
+  const int rounded = (total + NT - 1) / NT * NT;
+  for (int i = threadIdx.x; i < rounded; i += NT) {
     const u64 key = i < total ? src[i] : KEY_EMPTY;
     if (id_stride) {   // seed selection over a SAMPLE: entry ids are sample indices (seed_row maps them to rows)
       const bool ok = key != KEY_EMPTY && row_visible(vis, seed_row(key_id(key), id_head, id_stride), key_dist(key));
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(256) void merge_lists_kernel(const u64* partial, in
   L[0].store(&sh[wave][0], k);
   __syncthreads();
   if (wave == 0) {
-    for (int w = 1; w < 4; ++w) {
+    for (int w = 1; w < NW; ++w) {
       for (int e0 = 0; e0 < k; e0 += 64) {
         const int e = e0 + lane;
         const u64 key = e < k ? sh[w][e] : KEY_EMPTY;
@@ -204,10 +206,15 @@ void launch_merge_lists(const u64* partial, int lists, int k, int64_t nq, u64* r
   const FilterSpec vis = visible ? *visible : no_filter();
   if (nq <= 0) return;
   const int kpl = pick_kpl(k);
+  const bool wide = nq <= 64 && kpl <= 2;
 #define EPS_CASE(KPL_) \
   if (kpl == KPL_) {   \
-    hipLaunchKernelGGL((merge_lists_kernel<KPL_>), dim3((unsigned)nq), dim3(256), 0, s, partial, lists, k, run_keys, merge_run ? 1 : 0, counts, vis, id_stride, id_head, \
-                       seed_cand, seed_cap, seed_cnt);                                                                                                  \
+    if (wide && KPL_ <= 2)                                                                                                                                       \
+      hipLaunchKernelGGL((merge_lists_kernel<(KPL_ <= 2 ? KPL_ : 1), 16>), dim3((unsigned)nq), dim3(1024), 0, s, partial, lists, k, run_keys, merge_run ? 1 : 0, counts, vis, \
+                         id_stride, id_head, seed_cand, seed_cap, seed_cnt);                                                                                      \
+    else                                                                                                                                                         \
+      hipLaunchKernelGGL((merge_lists_kernel<KPL_, 4>), dim3((unsigned)nq), dim3(256), 0, s, partial, lists, k, run_keys, merge_run ? 1 : 0, counts, vis, id_stride, id_head, \
+                         seed_cand, seed_cap, seed_cnt);                                                                                                          \
     return;            \
   }
   EPS_CASE(1) EPS_CASE(2) EPS_CASE(4) EPS_CASE(8) EPS_CASE(16)
@@ -315,8 +322,146 @@ __global__ __launch_bounds__(NW * 64) void rerank_kernel(RerankArgs a) {
   }
 }
 
+// the same over several workgroups per query (RerankArgs::parts): blockIdx.x = q * parts + part
+template <int KPL, bool VEC4>
+__global__ __launch_bounds__(256) void rerank_split_kernel(RerankArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [qstride] query, then 4 lists
+  constexpr int NW = 4, NT = 256;
+  __shared__ u32 last_flag;
+  const int dim = a.dim;
+  const int qstride = (dim + 3) & ~3;
+  u64* sh = reinterpret_cast<u64*>(smem + qstride);
+  const int64_t q = blockIdx.x / a.parts;
+  const int part = (int)(blockIdx.x % a.parts);
+  for (int i = threadIdx.x; i < qstride; i += NT) smem[i] = i < dim ? a.queries[q * dim + i] : 0.f;
+  __syncthreads();
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const int G = group_lanes(dim, VEC4);
+  const int RPW = 64 / G;
+  const int g = lane / G;
+  const int t = lane & (G - 1);
+  constexpr int U = 4;
+  const u32 cnt_raw = a.cand_count[q];
+  u32 cnt = cnt_raw;
+  if (cnt > (u32)a.cap) cnt = (u32)a.cap;
+  const u32* cand = a.cand + q * (int64_t)a.cap;
+  // this workgroup's share: candidates [c_lo, c_hi)
+  const u32 share = (cnt + (u32)a.parts - 1) / (u32)a.parts;
+  const u32 c_lo = (u32)part * share;
+  const u32 c_hi = c_lo + share < cnt ? c_lo + share : cnt;
+
+  WaveTopK<KPL> L[1];
+  u64 thr[1];
+  L[0].init();
+  thr[0] = a.run_keys[q * a.k + (a.k - 1)];   // (the running k-th best bounds every share)
+  for (u32 c0 = c_lo + wave * RPW * U; c0 < c_hi; c0 += NW * RPW * U) {
+    const float* rp[U];
+    u32 id[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const u32 ci = c0 + u * RPW + g;
+      ok[u] = ci < c_hi;
+      id[u] = cand[ok[u] ? ci : c_hi - 1];
+      rp[u] = a.rows + (int64_t)id[u] * dim;
+    }
+    float acc[U][1];
+    row_dists<U, 1, VEC4>(rp, smem, qstride, dim, a.metric, G, acc);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const u64 key = make_key(finish_dist(a.metric, acc[u][0]), id[u]);
+      offer<1, KPL>(L, thr, 0, key, ok[u] && t == 0, a.f, a.k, true);
+    }
+  }
+  L[0].store(sh + wave * (KPL * 64), a.k);
+  __syncthreads();
+  FilterSpec nof = {nullptr, nullptr, 0, 0, 0, 0};
+  if (wave == 0) {   // this workgroup's k best -> its slot
+    for (int w = 1; w < NW; ++w)
+      for (int e0 = 0; e0 < a.k; e0 += 64) {
+        const int e = e0 + lane;
+        const u64 key = e < a.k ? sh[w * (KPL * 64) + e] : KEY_EMPTY;
+        offer<1, KPL>(L, thr, 0, key, key != KEY_EMPTY, nof, a.k, true);
+      }
+    L[0].store(a.part_keys + (q * a.parts + part) * (int64_t)a.k, a.k);
+  }
+  // publish, and find out whether this workgroup is the last of its query (agent-scope release on the stores above, acquire for the
+  // other workgroups' slots: they may have been written through another XCD's L2)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const u32 ticket = __hip_atomic_fetch_add(&a.part_done[q], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    last_flag = ticket == (u32)a.parts - 1 ? 1u : 0u;
+    __threadfence();
+  }
+  __syncthreads();
+  if (!last_flag) return;
+  if (wave == 0) {
+    L[0].load(a.run_keys + q * a.k, a.k);
+    thr[0] = L[0].entry(a.k - 1);
+    for (int p = 0; p < a.parts; ++p)
+      for (int e0 = 0; e0 < a.k; e0 += 64) {
+        const int e = e0 + lane;
+        const u64 key = e < a.k ? __builtin_nontemporal_load(a.part_keys + (q * a.parts + p) * (int64_t)a.k + e) : KEY_EMPTY;
+        offer<1, KPL>(L, thr, 0, key, key != KEY_EMPTY, nof, a.k, true);
+      }
+    L[0].store(a.run_keys + q * a.k, a.k);
+    if (lane == 0) a.part_done[q] = 0;
+    if (a.fin_ids) {
+      int c = 0;
+#pragma unroll
+      for (int r = 0; r < KPL; ++r) {
+        const int e = r * 64 + lane;
+        const u64 key = L[0].key[r];
+        const bool valid = e < a.k && key != KEY_EMPTY;
+        if (e < a.k) {
+          a.fin_ids[q * a.k + e] = valid ? (int64_t)key_id(key) * a.fin_stride + a.fin_base : -1;
+          a.fin_dist[q * a.k + e] = valid ? key_dist(key) : __builtin_inff();
+        }
+        c += __popcll(__ballot(valid));
+      }
+      if (a.fin_counts && lane == 0) a.fin_counts[q] = c;
+    }
+    if (a.fuse) {
+      const u64 kth = L[0].entry(a.k - 1);
+      if (a.gsync && q == 0)
+        for (int i = lane; i < 256; i += 64) a.gsync[i] = 0;
+      if (lane == 0) {
+        if (a.fuse & 1) {
+          if (cnt_raw > (u32)a.cap) atomicAdd(a.overflow, 1u);
+          atomicAdd(a.total, (unsigned long long)cnt);
+        }
+        a.cand_count[q] = 0;
+        if (a.T_next) {
+          const float* qs = a.qstat + q * 4;
+          if (a.bits == 8) {
+            static_cast<int*>(a.T_next)[q] = kth == KEY_EMPTY ? -(1 << 30) : stage_threshold8(key_dist(kth), qs, a.scal, a.metric, a.u, a.slack, 0);
+          } else {
+            static_cast<float*>(a.T_next)[q] = kth == KEY_EMPTY ? 3.0e38f : stage_threshold16(key_dist(kth), qs, a.scal, a.metric, a.slack, 0);
+          }
+        }
+      }
+    }
+  }
+}
+
 void launch_rerank(const RerankArgs& a, hipStream_t s) {
   if (a.nq <= 0) return;
+  if (a.parts > 1 && a.part_keys && a.part_done && pick_kpl(a.k) <= 2) {
+    const bool v4 = (a.dim % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.rows) & 15) == 0);
+    const int kp = pick_kpl(a.k);
+    const size_t sm = (size_t)((a.dim + 3) & ~3) * sizeof(float) + (size_t)4 * kp * 64 * sizeof(u64);
+    const dim3 grid((unsigned)(a.nq * a.parts));
+    if (kp == 1) {
+      if (v4) hipLaunchKernelGGL((rerank_split_kernel<1, true>), grid, dim3(256), sm, s, a);
+      else hipLaunchKernelGGL((rerank_split_kernel<1, false>), grid, dim3(256), sm, s, a);
+    } else {
+      if (v4) hipLaunchKernelGGL((rerank_split_kernel<2, true>), grid, dim3(256), sm, s, a);
+      else hipLaunchKernelGGL((rerank_split_kernel<2, false>), grid, dim3(256), sm, s, a);
+    }
+    return;
+  }
   const bool vec4 = (a.dim % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.rows) & 15) == 0);
   const int kpl = pick_kpl(a.k);
   const int nw = (a.nq <= 64 && kpl <= 4) ? 16 : 4;

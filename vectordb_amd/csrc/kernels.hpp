@@ -68,6 +68,12 @@ struct RerankArgs {
   float* fin_dist = nullptr;
   int32_t* fin_counts = nullptr;
   int64_t fin_base = 0, fin_stride = 1;
+  // a handful of queries (r4): a query's candidates are spread over `parts` workgroups (one workgroup gathering a stage's ~150 rows of
+  // 3 KB is ~20 us of a single-query call); each writes its k best to part_keys[q][part][k], the last to arrive (part_done[q], agent-scope
+  // release / acquire) merges them with the running list and does the bookkeeping above.  parts <= 1: one workgroup per query.
+  int parts = 0;
+  u64* part_keys = nullptr;
+  u32* part_done = nullptr;   // [nq], zero between launches (the last workgroup zeroes it again)
 };
 void launch_rerank(const RerankArgs& a, hipStream_t s);
 

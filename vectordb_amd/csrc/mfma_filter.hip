@@ -72,6 +72,7 @@ struct HalfMirror {
   DevBuf cand;     // u32 [b][cap]
   DevBuf cnt;      // u32 [b] + overflow counter at [b]
   DevBuf seedc;    // u32 [b][k]: rows of the k best seeds of every query (the seed stage's candidate lists)
+  DevBuf partk, partd;   // a handful of queries: per-workgroup partial top-k lists of the split re-rank [b][8][k], arrival counters [b] (zero between launches)
   // 8-bit mirror (first-pass operand of the filter, see above)
   DevBuf x8;       // int8 [n_pad8][d_pad8]
   DevBuf acc0;     // int32 [n_pad8]: accumulator start of every row = ceil(-R/u) + 1 (-2^30 on padding rows)
@@ -1130,6 +1131,20 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   ra.u = u8;
   ra.slack = 0.f;   // (set below, with the stages)
   ra.gsync = m.gsync.as<u32>();
+  if (!approx && nq <= 16 && k <= 128 && getenv("EPS_RERANK_SPLIT") && atoi(getenv("EPS_RERANK_SPLIT")) != 0) {
+    // a handful of queries: every re-rank spread over 8 workgroups per query (RerankArgs::parts).  Opt-in: measured, it takes 5 us off a
+    // 340 us single-query call (profiles/r4_single_query_latency.txt) - a re-rank of ~150 rows is a chain of dependent latencies, not a
+    // bandwidth problem - and is not worth a cross-workgroup hand-off on the default path
+    const bool fresh = m.partd.cap < (size_t)nq * 4;
+    if (!m.partk.reserve((size_t)nq * 8 * k * 8) || !m.partd.reserve((size_t)64 * 4)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory (scratch)");
+    if (fresh) {
+      const hipError_t e0 = hipMemsetAsync(m.partd.p, 0, m.partd.cap, s);
+      if (e0 != hipSuccess) return ix.hip_fail(e0, "memset");
+    }
+    ra.parts = 8;
+    ra.part_keys = m.partk.as<u64>();
+    ra.part_done = m.partd.as<u32>();
+  }
 
   const int bm = BM3;   // every kernel generation works on 256-row tiles
   const size_t shm = version >= 7 ? V7_LDS_BYTES : 2 * 65536 + 2 * 256 * sizeof(float);
