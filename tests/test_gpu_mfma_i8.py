@@ -174,6 +174,27 @@ def test_auto_stops_paying_for_an_8_bit_pass_that_never_filters(amd):
         del os.environ["EPS_MFMA_PROBE"]
 
 
+def test_a_selective_filter_does_not_talk_the_library_out_of_the_8_bit_pass(amd):
+    """The probe judges the BOUND by the first stage's candidate count - but a filter that lets 0.3 % of the rows through inflates every
+    list by 1 / 0.003 whatever the bound is worth.  Such a first batch may be answered by another engine (exactly), yet it must not decide
+    for the mirror: the next unfiltered batch runs the 8-bit pass."""
+    n, d, nq = 120_000, 128, 70
+    X, Q = data(n, d, 51), data(nq, d, 52)
+    idc = np.arange(n, dtype=np.int32)
+    ix = amd.GpuIndex(d, 0)
+    ix.attach_rows(X)
+    ix.set_int_filter(idc, "<", n // 300)
+    a = ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_AUTO)       # the mirror's FIRST batch: probed under the filter
+    same(a, ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM), "filtered first batch")
+    assert (a[0] < n // 300).all()
+    ix.set_int_filter(None, None, 0)
+    b = ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_AUTO)
+    st = ix.stats()
+    assert (st["main_kernel_bits"], st["i8_declined"], st["overflow_queries"]) == (8, 0, 0), st
+    same(b, ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM), "unfiltered second batch")
+    ix.close()
+
+
 def test_a_few_outlier_values_cost_their_rows_not_the_table(amd):
     """r4: the grid is clipped to the bulk of the values and every row carries its own residual norms, folded per batch into its
     accumulator start value.  One value of 100 in a U[0,1) table (r3 / early r4: grid stretched 100 x, 8-bit pass useless, fp16 pass

@@ -1347,7 +1347,10 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
         if (er == hipSuccess) er = hipStreamSynchronize(s);
         if (er != hipSuccess) return ix.hip_fail(er, "MFMA filter (probe)");
         if (hp.overflow || hp.total > (unsigned long long)nq * (unsigned long long)cap / 6) {
-          m.i8_overflows = 3;   // declined for this mirror (re-attaching rows re-arms it; EPS_FLAT_MFMA_I8 still forces it)
+          // declined for this mirror (re-attaching rows re-arms it; EPS_FLAT_MFMA_I8 still forces it) - unless a deleted bitset or a filter is
+          // active: a selective filter inflates the lists by 1 / (its pass fraction) whatever the bound is worth, so such a batch only
+          // decides for itself and the next one probes again
+          if (!(fs.deleted || fs.column || fs.prog)) m.i8_overflows = 3;
           ix.stats_.i8_declined += 1;
           return flat_mfma_search_slice(ix, dq, nq, k, run_keys, approx, 1, 16, false);
         }
