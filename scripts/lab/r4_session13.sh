@@ -1,7 +1,12 @@
 #!/bin/bash
-# r4 GPU session 13: the manifold set at 10M x 768 on the graph path (centred prefilter), then BASELINE configs[2] through the bindings (query_batch -> epsdrop::SearchBatch, rebuild on a side index)
-R=${GRAFT_REPO_ROOT:-.}
-cd $R
-bash scripts/run_10m_manifold_r4.sh > gpurun_out/r4m.log 2>&1
-cut -c1-330 gpurun_out/r4m/graph_10M_manifold.jsonl; cut -c1-330 gpurun_out/r4m/graph_10M_manifold_prefilter_off.jsonl; cut -c1-500 gpurun_out/r4m/bench_graph_10M_manifold.json; tail -8 gpurun_out/r4m/graph_10M_manifold_build.txt
-TAG=r4_module_10M EPS_MODULE_REBUILD=1 bash scripts/module_10m.sh
+# r4 session 13: the one-pass search of a handful of queries (stream8_kernel.hpp): exactness tests, then single-query latency at 1M x 768
+cd ${GRAFT_REPO_ROOT:-.}
+mkdir -p gpurun_out/r4s13
+timeout 500 python -m pytest tests/test_gpu_mfma_i8.py -m gpu -x -q -k "one_pass or one_to_four or handful" > gpurun_out/r4s13/pytest.txt 2>&1
+tail -15 gpurun_out/r4s13/pytest.txt
+for v in 1 0; do
+  echo "EPS_FLAT_ONE_PASS=$v $(EPS_FLAT_ONE_PASS=$v timeout 200 python scripts/prof_single_query.py 2>/dev/null | tail -1)" | tee -a gpurun_out/r4s13/latency.txt
+done
+for w in 1 4; do
+  echo "EPS_S8_WG_PER_CU=$w $(EPS_S8_WG_PER_CU=$w timeout 200 python scripts/prof_single_query.py 2>/dev/null | tail -1)" | tee -a gpurun_out/r4s13/latency.txt
+done

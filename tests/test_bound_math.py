@@ -289,3 +289,54 @@ def test_one_outlier_value_costs_its_row_not_the_table():
     folded = (dot3 + fold(m3, [qs3]) >= threshold(thr3, qs3, m3, 0, slack_of(d), folded=True))
     tablewide = (dot3 + m3["acc0"] >= threshold(thr3, qs3, m3, 0, slack_of(d)))
     assert folded[dd3 <= thr3].all() and folded[1234] and folded.mean() < 0.16 and tablewide[(dd3 <= thr3) & ~m3["forced"]].all()
+
+
+def upper_bound(acc, qs, m, metric, slack):
+    """stream8_ub (vectordb_amd/csrc/stream8_kernel.hpp): the exact fp32 distance of a row whose accumulator is `acc` is AT MOST this - the
+    Cauchy-Schwarz margin bounds |exact - approximate| on both sides.  The one-pass search of a handful of queries keeps the accumulators
+    of k rows and uses the largest of their upper bounds where the staged chain uses the k-th best exact key."""
+    sc = m["scal"]
+    margin = m["s"] * (qs["nq"] * sc["e1max"] + qs["eq"] * sc["nxhmax"])
+    dapx = F(qs["Cq"] - m["u"] * F(acc))
+    if metric == 0:
+        scale = abs(dapx) + margin + F(2.0) * abs(qs["Cq"]) + F(2.0) * sc["rmax"]
+    else:
+        qn = F(np.sqrt(qs["qn2"]))
+        scale = abs(dapx) + margin + F(1.0) + qn * (F(np.sqrt(sc["xnmax"])) + sc["mun"]) + sc["mun"] * sc["xcmax"] + abs(qs["Cq"]) + sc["rmax"]
+    return F(dapx + margin + F(2.0) * F(slack) * scale + F(4.0) * m["u"])
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_upper_bound_of_the_approximate_key(case, metric):
+    """(i) every tested row's exact distance is at most the upper bound of its accumulator; (ii) the consequence the one-pass search relies
+    on: with T = threshold(max upper bound of ANY k rows), every row of the exact top-k passes acc >= T."""
+    rng = np.random.default_rng(abs(hash((case, metric, "ub"))) % (1 << 31))
+    n, d, k = 3000, 96, 10
+    X = CASES[case](rng, n, d)
+    if metric == 1:
+        X /= np.linalg.norm(X, axis=1, keepdims=True)
+    mu, half = col_centre(X, sample=slice(0, None, 5))
+    m = mirror(X, metric, mu=mu, step=half / F(127.0))
+    if m["forced"].mean() > 0.01:
+        pytest.skip("row constants beyond int32: no 8-bit mirror for this table")
+    slack = slack_of(d)
+    ok = ~m["forced"]
+    for qk in range(10):
+        q = X[rng.integers(n)] + F(0.05) * rng.standard_normal(d).astype(F) if qk % 3 else CASES[case](rng, 1, d)[0] * F(2.0) - F(0.5)
+        if metric == 1:
+            q = q / np.linalg.norm(q)
+        q = q.astype(F)
+        qi, qs = query(q, m, metric)
+        acc = (m["xi"].astype(np.int64) @ qi.astype(np.int64)) + m["acc0"]
+        exact = dist(q, X, metric)
+        ub = np.array([upper_bound(int(a), qs, m, metric, slack) for a in acc[ok]], dtype=F)
+        assert (exact[ok] <= ub).all(), (case, metric, float((exact[ok] - ub).max()))
+        # any k tested rows (here: k random ones, and the k with the largest accumulators) bound the k-th best exact distance
+        order = np.argsort(exact, kind="stable")
+        for pick in (rng.choice(np.flatnonzero(ok), k, replace=False), np.flatnonzero(ok)[np.argsort(-acc[ok], kind="stable")[:k]]):
+            thr = max(upper_bound(int(a), qs, m, metric, slack) for a in acc[pick])
+            assert thr >= exact[order[k - 1]] or not ok[order[:k]].all()
+            T = threshold(thr, qs, m, metric, slack)
+            top = order[:k]
+            assert (acc[top][ok[top]] >= T).all(), (case, metric)

@@ -101,6 +101,76 @@ def test_i8_engine_on_other_distributions(amd, kind):
 
 
 @pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("d", [192, 768, 1000])
+def test_one_to_four_queries_are_one_pass_over_the_mirror(amd, monkeypatch, metric, d):
+    """r4 (stream8_kernel.hpp): up to 4 queries with k <= 16 are answered by ONE streaming pass over the 8-bit mirror (shared table of the
+    best accumulators seen -> pass threshold from their UPPER bounds), one selection against the final table and one exact re-rank: the
+    same bits as the stream scan - rows of 2 / 3 / 4 x 256 bytes, ties ordered by id, queries that ARE rows, with a deleted bitset and a
+    filter, repeated calls (the table is reset per call) - and `one_pass` in the stats says which form ran.  Larger k, more queries or
+    EPS_FLAT_ONE_PASS=0 take the staged chain."""
+    n = 200_003 if d < 700 else 90_000     # (a last chunk that is not full)
+    X, Q = data(n, d, 171 + d), data(4, d, 172 + d)
+    X[5000:5040] = X[4999]
+    if metric == 1:
+        X = amd.normalize_rows(X, only_if_nonzero=True)
+        Q = amd.normalize_rows(Q, only_if_nonzero=False)
+    Q[1] = X[5010]
+    idc = np.arange(n, dtype=np.int32)
+    ix = amd.GpuIndex(d, metric)
+    ix.attach_rows(X)
+    for setup in ("plain", "deleted + filter"):
+        if setup != "plain":
+            ix.set_deleted(bitset(n, range(3, n, 11)))
+            ix.set_int_filter(idc, ">=", 1000)
+        for nq in (1, 2, 3, 4):
+            for k in (1, 10, 16):
+                for rep in range(2):
+                    a = ix.search(Q[:nq], k, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
+                    st = ix.stats()
+                    assert (st["one_pass"], st["main_kernel_bits"], st["overflow_queries"]) == (1, 8, 0), (setup, nq, k, st)
+                    assert st["rerank_rows"] < nq * 2000, st     # the junk of the first microseconds is dropped before any row is read
+                    same(a, ix.search(Q[:nq], k, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM), "%s nq %d k %d" % (setup, nq, k))
+        a = ix.search(Q[:2], 17, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
+        assert ix.stats()["one_pass"] == 0
+        same(a, ix.search(Q[:2], 17, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM), "k 17")
+    monkeypatch.setenv("EPS_FLAT_ONE_PASS", "0")
+    a = ix.search(Q[:1], 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
+    assert ix.stats()["one_pass"] == 0
+    monkeypatch.delenv("EPS_FLAT_ONE_PASS")
+    same(a, ix.search(Q[:1], 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8), "chain vs one pass")
+    assert ix.stats()["one_pass"] == 1
+    ix.close()
+
+
+def test_one_pass_search_survives_adversarial_order_and_selective_deletion(amd):
+    """rows sorted from far to near (the table of best accumulators is always behind: nearly every row passes -> the raw list overflows -> the
+    staged chain answers), 99.9 % of the rows deleted (only visible rows may enter the table), fewer visible rows than k: the answer is
+    the stream scan's whatever ran."""
+    rng = np.random.default_rng(5)
+    n, d = 200_000, 256
+    q0 = rng.random((1, d), dtype=np.float32)
+    X = rng.random((n, d), dtype=np.float32)
+    X = np.ascontiguousarray(X[np.argsort(-((X - q0) ** 2).sum(1))])
+    Q = (q0 + 0.01 * rng.random((2, d), dtype=np.float32)).astype(np.float32)
+    ix = amd.GpuIndex(d, 0)
+    ix.attach_rows(X)
+    for _ in range(3):
+        same(ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8), ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM), "adversarial order")
+    ix.close()
+    X, Q = data(n, d, 220), data(3, d, 221)
+    ix = amd.GpuIndex(d, 0)
+    ix.attach_rows(X)
+    for keep_every in (1000, 40_000):    # 200 visible rows; 5 visible rows (< k)
+        dele = np.ones(n, dtype=bool)
+        dele[::keep_every] = False
+        ix.set_deleted(bitset(n, np.flatnonzero(dele)))
+        a = ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
+        same(a, ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM), "keep every %d" % keep_every)
+        assert (a[2] == min(10, len(range(0, n, keep_every)))).all(), a[2]
+    ix.close()
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
 def test_a_handful_of_queries_takes_the_short_chain_and_the_split_rerank(amd, monkeypatch, metric):
     """r4: 1 ... 16 queries per call run the fused launch chain (query preparation + fragment copy + start state in one launch, seed
     selection straight into the candidate lists by a 16-wavefront workgroup, finalisation in the last re-rank, 3 stages up to 4

@@ -29,12 +29,15 @@ def test_filter_kernels_do_not_spill(tmp_path):
         if m and name:
             usage[name][m.group(1)] = int(m.group(2))
     v7 = {k: v for k, v in usage.items() if "mfma_filter_kernel_v7" in k}
-    assert len(v7) == 12, list(usage)   # {128, 256}-query tiles x {ids, keys, dense} epilogues x {fp16, int8} operands
+    # {128, 256}-query tiles x {ids, keys, dense} epilogues x {fp16, int8} operands + the two 128-row-tile forms (two workgroups per CU)
+    assert len(v7) == 14, list(usage)
     for k, u in v7.items():
         assert u["ScratchSize [bytes/lane]"] == 0, (k, u)
         # r4 (EPS_V7_VI = 7): 7 of the 8 row blocks' accumulators live in arch VGPRs (the epilogue reads them in place), the operand
         # fragments and the last row block in the accumulator file; one wavefront per SIMD either way
         assert 64 <= u["AGPRs"] <= 200 and u["VGPRs"] <= 256 and u["Occupancy [waves/SIMD]"] >= 1, (k, u)
+        if "ELi4EEE" in k:   # NRB = 4: must fit two wavefronts per SIMD (128 arch + 128 accumulator-file registers), or the form is pointless
+            assert u["AGPRs"] <= 128 and u["VGPRs"] <= 128 and u["Occupancy [waves/SIMD]"] >= 2, (k, u)
     for k, u in usage.items():
         if "mfma_filter_kernel_v3" in k:
             assert u["ScratchSize [bytes/lane]"] == 0, (k, u)

@@ -59,7 +59,7 @@ class SearchStats(C.Structure):
                 ("overflow_queries", C.c_int64), ("kernel_ms", C.c_double), ("main_kernel_ms", C.c_double),
                 ("main_kernel_launches", C.c_int64), ("main_kernel_rows", C.c_int64),
                 ("main_kernel_queries", C.c_int64), ("main_kernel_bits", C.c_int64),
-                ("filter_ms_all", C.c_double), ("filter_rows_all", C.c_int64), ("i8_folded", C.c_int64), ("i8_declined", C.c_int64)]
+                ("filter_ms_all", C.c_double), ("filter_rows_all", C.c_int64), ("i8_folded", C.c_int64), ("i8_declined", C.c_int64), ("one_pass", C.c_int64)]
 
 
 class EpsillaError(RuntimeError):

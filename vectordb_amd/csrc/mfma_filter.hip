@@ -50,6 +50,7 @@
 
 #include "index.hpp"
 #include "mfma_kernels.hpp"
+#include "stream8_kernel.hpp"
 
 namespace eps {
 
@@ -97,6 +98,10 @@ struct HalfMirror {
   int d_pad8 = 0;
   bool i8_ok = false;
   int i8_overflows = 0;         // consecutive batches whose 8-bit pass overflowed its candidate lists (the fp16 pass then answered)
+  // r4, a handful of queries in one pass (stream8_kernel.hpp): the shared best-accumulator tables + raw candidate counters, the raw lists
+  DevBuf s8g, s8raw;            // table slots + sub-list counters (S8_TABLE_WORDS);  u64 [4][16][S8_RAW_CAP]
+  int64_t s8_declined_version = -1;   // rows version on which the one-pass form overflowed twice in a row (the staged chain serves it)
+  int s8_overflows = 0;
   int64_t extended_rows8 = 0;
   int64_t version = -1;
   int64_t n = 0, n_pad = 0;
@@ -494,6 +499,7 @@ struct Prep8Extra {
   u32 cntv = 0;
   u32* gsync = nullptr;        // prologue: 256 group counters = 0
   u32* qmax = nullptr;         // [2] (zeroed by the caller): atomicMax of the float bits of |q'| and |q' - qh'| over the batch (fold8_kernel reads them)
+  int* s8g = nullptr;          // one-pass form (stream8_kernel.hpp): table slots = empty, raw candidate counters = 0
 };
 __global__ __launch_bounds__(256) void query_prep8_kernel(const float* q, int64_t nq, int64_t b_pad, int dim, int d_pad8, const float* mu, float step, float inv_step,
                                                           int metric, signed char* q8, float* qstat, Prep8Extra x) {
@@ -501,6 +507,10 @@ __global__ __launch_bounds__(256) void query_prep8_kernel(const float* q, int64_
     for (int64_t i = threadIdx.x; x.T2 && i < x.n2; i += 256) x.T2[i] = x.Tv;
     for (int64_t i = threadIdx.x; x.cnt && i < nq + 8; i += 256) x.cnt[i] = i < nq ? x.cntv : 0u;
     if (x.gsync) x.gsync[threadIdx.x] = 0;
+    if (x.s8g) {   // (only the words in use: the slots of the call's queries, the sub-list counters)
+      for (int i = threadIdx.x; i < (int)nq * S8_SLOTS; i += 256) x.s8g[i * S8_SLOT_STRIDE] = S8_EMPTY;
+      if (threadIdx.x < 4 * S8_SUBLISTS) x.s8g[4 * S8_SLOTS * S8_SLOT_STRIDE + threadIdx.x * S8_CNT_STRIDE] = 0;
+    }
   }
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= b_pad) return;
@@ -935,6 +945,146 @@ bool flat_mfma_profitable(const Index& ix, int64_t nq, int k) {
   return filter_s < stream_s;
 }
 
+// A handful of queries (<= 4, k <= 16) in ONE pass over the 8-bit mirror: stream8_kernel.hpp.  *done = false: not applicable to this call,
+// or a list overflowed - the staged chain below answers it (results are bit-identical either way: both end in the same exact re-rank).
+constexpr int S8_RAW_CAP = 2048;   // entries per raw sub-list (16 per query)
+static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k, u64* run_keys, bool* done) {
+  *done = false;
+  HalfMirror& m = *ix.mirror_;
+  const int64_t n = ix.scan_limit_ >= 0 ? std::min(ix.scan_limit_, ix.n_rows_) : ix.n_rows_;
+  const int pieces = m.d_pad8 / 256;
+  if (getenv("EPS_FLAT_ONE_PASS") && atoi(getenv("EPS_FLAT_ONE_PASS")) == 0) return EPS_OK;
+  if (nq < 1 || nq > 4 || k < 1 || k > 16 || m.fold8 || n < 65536 || n > m.n8 || m.d_pad8 % 256 != 0 || pieces < 2 || pieces > 4) return EPS_OK;
+  if (m.s8_declined_version == ix.rows_version_) return EPS_OK;
+  const FilterSpec fs = ix.filter_spec();
+  if (fs.prog && fs.prog_use_dist) return EPS_OK;   // (a filter on the distance itself: only the re-rank knows it)
+  hipStream_t s = ix.stream_;
+  const int cap = std::max(4096, 64 * k);
+  if (!m.qstat.reserve((size_t)4 * 16) || !m.q8.reserve((size_t)4 * m.d_pad8) || !m.cand.reserve((size_t)nq * cap * 8) || !m.cnt.reserve((size_t)(nq + 4) * 4 + 16) ||
+      !m.s8g.reserve((size_t)S8_TABLE_WORDS * 4) || !m.s8raw.reserve((size_t)4 * S8_SUBLISTS * S8_RAW_CAP * 8))
+    return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory (scratch)");
+  u32* cnt = m.cnt.as<u32>();
+  u32* overflow = cnt + nq;
+  unsigned long long* total = reinterpret_cast<unsigned long long*>(cnt + nq + 2);
+  if ((reinterpret_cast<uintptr_t>(total) & 7) != 0) total = reinterpret_cast<unsigned long long*>(cnt + nq + 3);
+  const float u8 = (ix.metric_ == 0 ? 2.f : 1.f) * m.step8 * m.step8;
+  const float rerank_slack = std::max(8e-6f, 2.f * (3.f * ((float)((ix.dim_ + 63) / 64 * 64) / 64.f + 6.f) + 6.f) * 5.9604645e-8f);
+  Prep8Extra px;
+  px.cnt = cnt;     // candidate counts, overflow and total counters = 0
+  px.cntv = 0;
+  px.s8g = m.s8g.as<int>();
+  hipLaunchKernelGGL(query_prep8_kernel, dim3(1), dim3(256), 0, s, dq, nq, (int64_t)4, (int)ix.dim_, m.d_pad8, m.mu8.as<float>(), m.step8, 1.f / m.step8, ix.metric_,
+                     m.q8.as<signed char>(), m.qstat.as<float>(), px);
+  Stream8Args a;
+  a.x8 = m.x8.as<signed char>();
+  a.acc0 = m.acc0.as<int>();
+  a.n = n;
+  a.d_pad8 = m.d_pad8;
+  a.q8 = m.q8.as<signed char>();
+  a.qstat = m.qstat.as<float>();
+  a.scal = m.scal8.as<float>();
+  a.nq = (int)nq;
+  a.k = k;
+  a.metric = ix.metric_;
+  a.u = u8;
+  a.slack = rerank_slack;
+  a.G = m.s8g.as<int>();
+  a.raw_cnt = m.s8g.as<u32>() + 4 * S8_SLOTS * S8_SLOT_STRIDE;
+  a.raw = m.s8raw.as<u64>();
+  a.raw_cap = S8_RAW_CAP;
+  a.f = fs;
+  a.ablate = getenv("EPS_S8_ABLATE") ? atoi(getenv("EPS_S8_ABLATE")) : 0;   // (lab)
+  int cus = m.num_cus;
+  if (!cus) {
+    hipDeviceProp_t prop;
+    cus = hipGetDeviceProperties(&prop, ix.device_) == hipSuccess ? prop.multiProcessorCount : 256;
+  }
+  static const int wg_per_cu = getenv("EPS_S8_WG_PER_CU") ? std::max(1, atoi(getenv("EPS_S8_WG_PER_CU"))) : 2;
+  const dim3 grid((unsigned)std::min<int64_t>((int64_t)cus * wg_per_cu, (n + 63) / 64)), block(256);
+  // (no event pair around the pass: a record between two dependent launches costs this chain 5-10 us each; kernel_ms covers the call)
+#define EPS_S8_LAUNCH(P_)                                                                      \
+  do {                                                                                         \
+    if (nq == 1) hipLaunchKernelGGL((stream8_kernel<P_, 1>), grid, block, 0, s, a);            \
+    else if (nq == 2) hipLaunchKernelGGL((stream8_kernel<P_, 2>), grid, block, 0, s, a);       \
+    else hipLaunchKernelGGL((stream8_kernel<P_, 4>), grid, block, 0, s, a);                    \
+  } while (0)
+  if (pieces == 2) EPS_S8_LAUNCH(2);
+  else if (pieces == 3) EPS_S8_LAUNCH(3);
+  else EPS_S8_LAUNCH(4);
+#undef EPS_S8_LAUNCH
+  hipLaunchKernelGGL(stream8_select_kernel, dim3((unsigned)nq), dim3(256), 0, s, a, m.cand.as<u32>(), cap, cnt, run_keys, overflow);
+  RerankArgs ra;
+  ra.rows = ix.d_rows_;
+  ra.dim = (int)ix.dim_;
+  ra.metric = ix.metric_;
+  ra.queries = dq;
+  ra.nq = nq;
+  ra.k = k;
+  ra.f = fs;
+  ra.cand = m.cand.as<u32>();
+  ra.cand_count = cnt;
+  ra.cap = cap;
+  ra.run_keys = run_keys;
+  ra.fuse = 1;                 // (counts only: overflow / total)
+  ra.overflow = overflow;
+  ra.total = total;
+  ra.T_next = nullptr;
+  ra.qstat = m.qstat.as<float>();
+  ra.scal = m.scal8.as<float>();
+  ra.bits = 8;
+  ra.u = u8;
+  ra.slack = rerank_slack;
+  ra.gsync = nullptr;
+  const bool fin_here = ix.pre_sync_ && nq == ix.pre_sync_nq_ && ix.fin_ids_ != nullptr;
+  if (fin_here) {
+    ra.fin_ids = ix.fin_ids_;
+    ra.fin_dist = ix.fin_dist_;
+    ra.fin_counts = ix.fin_cnt_;
+    ra.fin_base = ix.id_base_;
+    ra.fin_stride = ix.id_stride_;
+  }
+  launch_rerank(ra, s);
+  if (fin_here) (void)hipEventRecord(ix.ev1_, s);
+  hipError_t er = hipGetLastError();
+  if (er != hipSuccess) return ix.hip_fail(er, "one-pass flat search launch");
+  struct {
+    u32 overflow, pad;
+    unsigned long long total;
+  } h = {0, 0, 0};
+  if (!fin_here && ix.pre_sync_ && nq == ix.pre_sync_nq_) ix.pre_sync_();
+  er = hipMemcpyAsync(&h.overflow, overflow, 4, hipMemcpyDeviceToHost, s);
+  if (er == hipSuccess) er = hipMemcpyAsync(&h.total, total, 8, hipMemcpyDeviceToHost, s);
+  if (er == hipSuccess) er = hipStreamSynchronize(s);
+  if (er != hipSuccess) return ix.hip_fail(er, "one-pass flat search");
+  if (getenv("EPS_DEBUG")) {
+    std::vector<u32> hc((size_t)S8_TABLE_WORDS);
+    (void)hipMemcpy(hc.data(), m.s8g.p, hc.size() * 4, hipMemcpyDeviceToHost);
+    for (int64_t q = 0; q < nq; ++q) {
+      unsigned long long raw = 0;
+      int filled = 0;
+      for (int i = 0; i < S8_SUBLISTS; ++i) raw += hc[4 * S8_SLOTS * S8_SLOT_STRIDE + (q * S8_SUBLISTS + i) * S8_CNT_STRIDE];
+      for (int i = 0; i < S8_SLOTS; ++i) filled += (int)hc[(q * S8_SLOTS + i) * S8_SLOT_STRIDE] != S8_EMPTY;
+      fprintf(stderr, "[eps one pass] query %lld: %llu raw candidates, %d of 64 slots filled, re-ranked (all queries) %llu, overflow %u\n", (long long)q, raw, filled, h.total, h.overflow);
+    }
+  }
+  if (h.overflow) {   // (too loose a bound for this table, or a filter that leaves fewer than k rows visible: the staged chain answers)
+    ix.result_finalized_ = false;
+    if (!(fs.deleted || fs.column || fs.prog) && ++m.s8_overflows >= 2) m.s8_declined_version = ix.rows_version_;
+    return EPS_OK;
+  }
+  m.s8_overflows = 0;
+  if (fin_here) ix.result_finalized_ = true;
+  ix.stats_.rerank_rows += (int64_t)h.total;
+  ix.stats_.dist_evals += nq * n;
+  ix.stats_.main_kernel_launches = 0;   // (not timed on its own)
+  ix.stats_.main_kernel_rows = n;
+  ix.stats_.main_kernel_queries = nq;
+  ix.stats_.main_kernel_bits = 8;
+  ix.stats_.one_pass = 1;
+  *done = true;
+  return EPS_OK;
+}
+
 int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u64* run_keys, bool approx, int cap_scale, int bits, bool auto_bits) {
   // operand width of the filter pass: 8 = int8 mirror (when the table fits its grid), 16 = fp16 mirror
   bool i8 = bits == 8;
@@ -946,6 +1096,11 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
     // batch: after three in a row the library's own choice stops paying for the 8-bit pass first (an explicit EPS_FLAT_MFMA_I8
     // request still gets it; re-attaching rows re-arms it)
     if (!ix.mirror_->i8_ok || (auto_bits && ix.mirror_->i8_overflows >= 3)) i8 = false;
+  }
+  if (i8 && !approx && cap_scale == 1 && nq <= 4) {
+    bool done = false;
+    rc = flat_stream8_slice(ix, dq, nq, k, run_keys, &done);
+    if (rc != EPS_OK || done) return rc;
   }
   if (!i8) {
     rc = ensure_mirror(ix);
@@ -1161,9 +1316,12 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
                            reinterpret_cast<const void*>(mfma_filter_kernel_v7<2, FM_DENSE, true>), reinterpret_cast<const void*>(mfma_filter_kernel_v7<1, FM_IDS, true>),
                            reinterpret_cast<const void*>(mfma_filter_kernel_v7<1, FM_KEYS, true>), reinterpret_cast<const void*>(mfma_filter_kernel_v7<1, FM_DENSE, true>)})
       (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)V7_LDS_BYTES);
+    for (const void* fn : {reinterpret_cast<const void*>(mfma_filter_kernel_v7<2, FM_IDS, true, 4>), reinterpret_cast<const void*>(mfma_filter_kernel_v7<2, FM_KEYS, true, 4>)})
+      (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v7_lds_bytes(4));
   }
   const int num_cus = m.num_cus;
   const bool narrow_env = !(getenv("EPS_MFMA_NARROW") && atoi(getenv("EPS_MFMA_NARROW")) == 0);
+  const bool two_per_cu = getenv("EPS_MFMA_TWO_PER_CU") && atoi(getenv("EPS_MFMA_TWO_PER_CU")) != 0;   // (lab until measured)
   auto launch_filter = [&](const FilterArgs& f) {
     {
       FilterArgs f3 = f;
@@ -1182,6 +1340,13 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
         if (nq <= 128 && narrow_env) {   // one 128-query tile: half the padded MFMA work, the pass streams the mirror
           f3.tiles_q = 1;
           if (i8) EPS_V7_LAUNCH(1, true); else EPS_V7_LAUNCH(1, false);
+        } else if (i8 && mode != FM_DENSE && two_per_cu) {
+          // r4: 128-row tiles, two workgroups per CU (see the kernel: NRB = 4)
+          f3.tile0 *= 2;
+          f3.ntiles *= 2;
+          const dim3 grid2((unsigned)num_cus * 2);
+          if (mode == FM_KEYS) hipLaunchKernelGGL((mfma_filter_kernel_v7<2, FM_KEYS, true, 4>), grid2, block, v7_lds_bytes(4), s, f3);
+          else hipLaunchKernelGGL((mfma_filter_kernel_v7<2, FM_IDS, true, 4>), grid2, block, v7_lds_bytes(4), s, f3);
         } else {
           if (i8) EPS_V7_LAUNCH(2, true); else EPS_V7_LAUNCH(2, false);
         }

@@ -111,6 +111,15 @@ template <> struct V7Op<true> {
 #ifndef EPS_V7_VI
 #define EPS_V7_VI 7
 #endif
+#ifndef EPS_V7_EARLYINIT
+#define EPS_V7_EARLYINIT 0   // lab: next tile's start values loaded inside the epilogue (see the kernel; measured no gain, profiles/r4_flat_ab_epilogue_late.txt)
+#endif
+#ifndef EPS_V7_FLUSHFLAG
+#define EPS_V7_FLUSHFLAG 0   // lab: the pending list looked at only after a tile that appended to it (measured no gain, same file)
+#endif
+#ifndef EPS_V7_GROUP
+#define EPS_V7_GROUP 2       // row blocks per epilogue test: the maxima of GROUP x JQ blocks share one compare + branch (see the kernel)
+#endif
 #ifndef EPS_V7_HITMASK
 #define EPS_V7_HITMASK 1   // FM_IDS hit blocks: per-lane bit mask of the passing values instead of 16 exec-masked branches (see the kernel)
 #endif
@@ -384,20 +393,37 @@ __global__ __launch_bounds__(512, 2) void mfma_filter_kernel_v3(FilterArgs a) {
 // end of the kernel); only a hit that finds the list full takes the direct path.
 enum { FM_IDS = 0, FM_KEYS = 1, FM_DENSE = 2 };
 constexpr int V7_CAPW = 128;   // entries of a wavefront's pending-candidate list
-constexpr size_t V7_LDS_BYTES = 4 * 32768 + 2 * 256 * sizeof(float) + 4096 + 64 + 4 * V7_CAPW * (8 + 4);
+constexpr size_t v7_lds_bytes(int nrb) { return (size_t)4 * nrb * 4096 + 2 * 256 * sizeof(float) + 4096 + 64 + 4 * V7_CAPW * (8 + 4); }
+constexpr size_t V7_LDS_BYTES = v7_lds_bytes(8);
 
 // I8 (8-bit operands): a.xh / a.qf hold int8 [..][2 * d_pad] (d_pad counts 2-byte units in both forms), a.base_s the int32 accumulator
 // start of every row, a.T the int32 pass thresholds (a row passes iff its accumulator >= T), a.s the (negative) key units per
 // accumulator unit, a.qstat[q][3] the query's constant of the approximate distance = a.s * accumulator + constant.
-template <int JQ, int MODE, bool I8 = false>
-__global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
+// NRB (r4) = 32-row blocks per wavefront = rows per tile / 32.  8: the form described above, one workgroup per CU (a wavefront owns all 512
+// registers of its SIMD lane).  4: 128-row tiles, half the accumulators (all of them in arch VGPRs), query fragments single-buffered, 16-KB
+// ring slots - a wavefront fits 256 registers and a workgroup 78 KB of LDS, so TWO workgroups share a CU: while one is in its tile head /
+// epilogue (18 % of a tile, matrix pipe idle) or waits at a barrier, the other one's MFMAs run.  The LDS read volume per MFMA is v7's (a row
+// fragment still feeds two MFMAs); the query fragments are loaded twice as often per MFMA (L2 traffic x 1.5).  a.tile0 / a.ntiles count
+// tiles of 32 NRB rows.
+template <int JQ, int MODE, bool I8 = false, int NRB = 8>
+__global__ __launch_bounds__(256, NRB == 8 ? 1 : 2) void mfma_filter_kernel_v7(FilterArgs a) {
+  static_assert(NRB == 8 || (NRB == 4 && JQ == 2 && I8 && MODE != FM_DENSE), "row blocks per wavefront");
+  constexpr int TR = 32 * NRB;            // rows per tile
+  constexpr int FBUF = NRB == 8 ? 2 : 1;  // K-steps of query fragments held in registers
+  constexpr int NPIECE = NRB;             // LDS-DMA pieces (32 rows x 128 B) per K-step
+#ifndef EPS_V7_VI4
+#define EPS_V7_VI4 2
+#endif
+  // row blocks whose accumulators live in arch VGPRs.  With AGPRs in use hipcc splits a wavefront's register budget evenly (NRB = 4: 128 arch
+  // + 128 accumulator-file registers): two blocks (64) + everything else in the arch half, two blocks + the 64 fragment registers in the other
+  constexpr int VI = NRB == 8 ? EPS_V7_VI : (EPS_V7_VI > 0 ? EPS_V7_VI4 : 0);
   typedef V7Op<I8> OP;
   typedef typename OP::frag frag_t;
   typedef typename OP::accv acc_t;
   typedef typename OP::scalar thr_t;
   constexpr int QT = 128 * JQ;   // queries per tile
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  constexpr int ASLOT = 32768;  // 256 rows x 128 B
+  constexpr int ASLOT = TR * 128;  // TR rows x 128 B
   constexpr int RING = 4;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -428,7 +454,7 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
   // (a 64-bit division per tile is ~150 scalar instructions on this machine, and the tile loop had two)
   auto tile_rt = [&](int ri) { return (int64_t)xcd + 8 * (rg + (int64_t)ri * G); };
   auto tile_qt = [&](int qi) { return qslot + qi * QTB; };
-  auto rows_of = [&](int ri) { return a.xh + (a.tile0 + tile_rt(ri)) * 256 * (int64_t)ldk; };
+  auto rows_of = [&](int ri) { return a.xh + (a.tile0 + tile_rt(ri)) * TR * (int64_t)ldk; };
   // fragment stream of this wavefront's first 32-query block; the second block follows at + (ldk/16)*512 halfs
   auto frags_of = [&](int qi) { return a.qf + ((int64_t)(tile_qt(qi) * (4 * JQ) + wave * JQ) * (ldk / 16)) * 512; };
   auto advance = [&](int& ri, int& qi) { if (++qi == nqt) { qi = 0; ++ri; } };
@@ -436,7 +462,8 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
   u32 lane16, lane4;
   const u32 lds_base = (u32)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
   auto issue_base = [&](int ri, int par) {  // pre-scaled |x|^2 column of row tile ri -> base_lds[par] (64 rows per wavefront)
-    const float* pb = a.base_s + (a.tile0 + tile_rt(ri)) * 256 + wave * 64;
+    if (wave * 64 >= TR) return;   // (NRB = 4: the first two wavefronts; the others' VMEM counts run one behind, which only makes their waits stricter)
+    const float* pb = a.base_s + (a.tile0 + tile_rt(ri)) * TR + wave * 64;
     const u32 m0v = lds_base + RING * ASLOT + (u32)((par * 256 + wave * 64) * 4);
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : : "v"(lane4), "s"(pb), "s"(m0v) : "memory");
   };
@@ -460,9 +487,9 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
     asm volatile("global_load_lds_dwordx4 %0, %1" : : "v"(g_off0), "s"(sb) : "memory");
   };
 
-  acc_t acc[8][JQ];
-  frag_t fb[2][4][JQ];
-  frag_t fa[2][8];
+  acc_t acc[NRB][JQ];
+  frag_t fb[FBUF][4][JQ];
+  frag_t fa[2][NRB];
   int64_t qj[JQ];
   // Tq = T/s: a row passes iff acc >= Tq (s < 0); cj: approx-mode constant of the query.  Per-lane constants of the
   // query tile: parked in LDS and read back at each epilogue - as registers they would be live across the K loop, get
@@ -490,7 +517,7 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
   };
   lane_values();
 
-  const int64_t a_stride = (int64_t)8 * G * 256 * ldk;   // halfs between consecutive row tiles of this workgroup
+  const int64_t a_stride = (int64_t)8 * G * TR * ldk;   // halfs between consecutive row tiles of this workgroup
   int ri_c = 0, qi_c = 0;        // tile t
   int ri_n = 0, qi_n = 0;        // tile t + 1
   advance(ri_n, qi_n);
@@ -502,6 +529,9 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
   u32* wcnt = reinterpret_cast<u32*>(lds + RING * ASLOT + 2048 + 4096) + wave * 4;
   u64* wbuf = reinterpret_cast<u64*>(lds + RING * ASLOT + 2048 + 4096 + 64) + wave * V7_CAPW;
   float* wkey = reinterpret_cast<float*>(lds + RING * ASLOT + 2048 + 4096 + 64 + 4 * V7_CAPW * 8) + wave * V7_CAPW;
+  // (the same counter as an LDS-address-space volatile: through the generic pointer the per-tile look at it was a FLAT load + vmcnt(0), which
+  // drained the LDS-DMA ring once per tile)
+  volatile __attribute__((address_space(3))) u32* wcnt_lds = (volatile __attribute__((address_space(3))) u32*)wcnt;
   if (MODE != FM_DENSE && lane == 0) *wcnt = 0;
   auto append = [&](int64_t qq, u32 row, float dapx) __attribute__((always_inline)) {   // straight to the global list
     const u32 slot_c = atomicAdd(&a.cnt[qq], 1u);
@@ -513,13 +543,13 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
   auto flush = [&]() __attribute__((always_inline)) {
     u32 ln;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
-    u32 n = *reinterpret_cast<volatile u32*>(wcnt);
+    u32 n = *wcnt_lds;
     n = n < (u32)V7_CAPW ? n : (u32)V7_CAPW;
     for (u32 e = ln; e < n; e += 64) {
       const u64 v = wbuf[e];
       append((int64_t)(v >> 32), (u32)v, MODE == FM_KEYS ? wkey[e] : 0.f);
     }
-    if (ln == 0) *reinterpret_cast<volatile u32*>(wcnt) = 0;
+    if (ln == 0) *wcnt_lds = 0;
   };
   const bool rendezvous = a.group_sync && a.tiles_q <= per_xcd;   // (then nqt == 1 for every member of the group)
   u32* gs_ctr = a.group_sync + (xcd * G + rg);
@@ -529,33 +559,39 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
   issue_base(0, 0);
   // prologue = the issue groups of the imaginary steps -3, -2, -1 (16 operations each from -2 on)
 #pragma unroll
-  for (int it = 0; it < 8; ++it) issue_piece(A_t, 0, it);
+  for (int it = 0; it < NPIECE; ++it) issue_piece(A_t, 0, it);
 #pragma unroll
-  for (int it = 0; it < 8; ++it) issue_piece(A_t + 64, ASLOT, it);
+  for (int it = 0; it < NPIECE; ++it) issue_piece(A_t + 64, ASLOT, it);
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
     EPS_GLOAD_B128(fb[0][kk][0], lane16, B_t + kk * 512, 0);
     if (JQ == 2) EPS_GLOAD_B128(fb[0][kk][JQ - 1], lane16, B_t + jstride + kk * 512, 0);
   }
 #pragma unroll
-  for (int it = 0; it < 8; ++it) issue_piece(A_t + 128, 2 * ASLOT, it);
+  for (int it = 0; it < NPIECE; ++it) issue_piece(A_t + 128, 2 * ASLOT, it);
+  if (FBUF == 2) {
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) {
-    EPS_GLOAD_B128(fb[1][kk][0], lane16, B_t + 2048 + kk * 512, 0);
-    if (JQ == 2) EPS_GLOAD_B128(fb[1][kk][JQ - 1], lane16, B_t + jstride + 2048 + kk * 512, 0);
+    for (int kk = 0; kk < 4; ++kk) {
+      EPS_GLOAD_B128(fb[FBUF - 1][kk][0], lane16, B_t + 2048 + kk * 512, 0);
+      if (JQ == 2) EPS_GLOAD_B128(fb[FBUF - 1][kk][JQ - 1], lane16, B_t + jstride + 2048 + kk * 512, 0);
+    }
+    if (JQ == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // slots 0 and 1 + fragments of step 0
+    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // (slot 2's pieces may stay in flight)
   }
-  if (JQ == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // slots 0 and 1 + fragments of step 0
-  else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   EPS_DS_READ_B128(fa[0][0], faddr[0], 0);
   EPS_DS_READ_B128(fa[0][1], faddr[0], 4096);
   EPS_DS_READ_B128(fa[0][2], faddr[0], 8192);
   EPS_DS_READ_B128(fa[0][3], faddr[0], 12288);
-  EPS_DS_READ_B128(fa[0][4], faddr[0], 16384);
-  EPS_DS_READ_B128(fa[0][5], faddr[0], 20480);
-  EPS_DS_READ_B128(fa[0][6], faddr[0], 24576);
-  EPS_DS_READ_B128(fa[0][7], faddr[0], 28672);
+  if (NRB == 8) {
+    EPS_DS_READ_B128(fa[0][NRB - 4], faddr[0], 16384);
+    EPS_DS_READ_B128(fa[0][NRB - 3], faddr[0], 20480);
+    EPS_DS_READ_B128(fa[0][NRB - 2], faddr[0], 24576);
+    EPS_DS_READ_B128(fa[0][NRB - 1], faddr[0], 28672);
+  }
 
   // One wavefront per SIMD: after every pair of MFMAs (64 cycles of matrix pipe) exactly one other instruction is
   // issued in its shadow - the LDS read of the row fragment that the same pair will need in the NEXT sub-step
@@ -566,12 +602,12 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
   // next, 64-bit address arithmetic) they sat between the barrier and the first MFMA of every step.
   const _Float16* pA_run = A_t + 3 * 64;          // KT >= 4
   int akt_run = 3;
-  const _Float16* pB_run = B_t + (int64_t)2 * 2048;
-  int bkt_run = 2;
+  const _Float16* pB_run = B_t + (int64_t)FBUF * 2048;   // (NRB = 4: one step ahead, reloaded in place one sub-step after use)
+  int bkt_run = FBUF;
   u32 sA_run = 0, sN_run = ASLOT, sD_run = 3 * ASLOT;   // slot being multiplied, the next one, the one being filled (byte offsets)
   u32 ad_run = faddr[1];                                // LDS address of the first sub-step's fragment reads (slot 0)
   auto step = [&](auto U, auto FIRST) __attribute__((always_inline)) {
-    constexpr int rb = decltype(U)::value;
+    constexpr int rb = decltype(U)::value % FBUF;
     constexpr bool first = decltype(FIRST)::value;   // first K-step of a tile: only acc[.][0] holds the base column
     const u32 sA = sA_run, sN = sN_run, sD = sD_run;
     const _Float16* pA = pA_run;
@@ -583,23 +619,31 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
     for (int kk = 0; kk < 4; ++kk) {
       const int cur = kk & 1, nxt = cur ^ 1;
       const u32 ad = ad_run;      // LDS address of this sub-step's fragment reads (the NEXT sub-step's operands)
+      if (FBUF == 1 && kk > 0) {
+        // single-buffered query fragments: this sub-step's pair was reloaded one K-step ago, in the sub-step after its use.  VMEM
+        // operations of a step, in issue order: p0 | F00 p1 F01 | F10 p2 F11 | F20 p3 F21 | F30 F31 (p = LDS-DMA piece, Fkj = fragment
+        // of sub-step k, query block j): what may still be in flight when F(kk, 1) of the previous step must have landed
+        if (kk == 3) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < NRB; ++i) {
         // An MFMA occupies the pipe for 32 cycles and the next one cannot issue before that, so EACH of the two leaves
         // ~28 cycles (about five issue slots) in which the wavefront can issue something else for free: the LDS read and
         // the scalar preparation of the pair's VMEM instruction go behind the first, the VMEM instruction itself (every
         // other pair: one query-fragment load or one LDS-DMA piece) alone behind the second.
         const bool has_frag = (i == 1 || i == 3) && kk > 0 && (i >> 1) < JQ;   // fragments of the PREVIOUS sub-step's slot, for two steps from now
-        const bool has_dma = (i == 5 || i == 7);
+        const bool has_dma = NRB == 8 ? (i == 5 || i == 7) : i == 2;
         const _Float16* vsrc = nullptr;
-        asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
+        if (NRB == 8) asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
 #if EPS_V7_VI > 0
         if (JQ == 2 && first && kk == 0) {   // D != C: the second block's accumulator is born from the first block's initial value
-          if (i < EPS_V7_VI) V7Asm<I8>::v2(acc[i][JQ - 1], fa[cur][i], fb[rb][kk][JQ - 1], acc[i][0]);
+          if (i < VI) V7Asm<I8>::v2(acc[i][JQ - 1], fa[cur][i], fb[rb][kk][JQ - 1], acc[i][0]);
           else V7Asm<I8>::a2(acc[i][JQ - 1], fa[cur][i], fb[rb][kk][JQ - 1], acc[i][0]);
         } else {
-          if (i < EPS_V7_VI) V7Asm<I8>::v(acc[i][0], fa[cur][i], fb[rb][kk][0]);
+          if (i < VI) V7Asm<I8>::v(acc[i][0], fa[cur][i], fb[rb][kk][0]);
           else V7Asm<I8>::a_(acc[i][0], fa[cur][i], fb[rb][kk][0]);
         }
 #else
@@ -616,24 +660,24 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
             case 1: EPS_DS_READ_B128(fa[nxt][1], ad, 4096); break;
             case 2: EPS_DS_READ_B128(fa[nxt][2], ad, 8192); break;
             case 3: EPS_DS_READ_B128(fa[nxt][3], ad, 12288); break;
-            case 4: EPS_DS_READ_B128(fa[nxt][4], ad, 16384); break;
-            case 5: EPS_DS_READ_B128(fa[nxt][5], ad, 20480); break;
-            case 6: EPS_DS_READ_B128(fa[nxt][6], ad, 24576); break;
-            default: EPS_DS_READ_B128(fa[nxt][7], ad, 28672); break;
+            case 4: EPS_DS_READ_B128(fa[nxt][NRB - 4], ad, 16384); break;
+            case 5: EPS_DS_READ_B128(fa[nxt][NRB - 3], ad, 20480); break;
+            case 6: EPS_DS_READ_B128(fa[nxt][NRB - 2], ad, 24576); break;
+            default: EPS_DS_READ_B128(fa[nxt][NRB - 1], ad, 28672); break;
           }
         }
         if (has_frag) {
           vsrc = pB + (i >> 1) * jstride + (kk - 1) * 512;
           asm volatile("" : "+s"(vsrc));
         } else if (has_dma) {
-          vsrc = prep_piece(pA, sD, kk * 2 + (i >> 1) - 2);
+          vsrc = prep_piece(pA, sD, NRB == 8 ? kk * 2 + (i >> 1) - 2 : kk);
         }
-        if (i == 7) {   // the next sub-step's read address (kk = 3: the next K-step's first sub-step, in the slot after this one)
+        if (i == NRB - 1) {   // the next sub-step's read address (kk = 3: the next K-step's first sub-step, in the slot after this one)
           u32 adn = faddr[(kk + 2) & 3] + (kk < 2 ? sA : sN);
           asm volatile("" : "+v"(adn));
           ad_run = adn;
         }
-        if (kk == 3 && i == 6) {   // the next step's cursors
+        if (kk == 3 && i == NRB - 2) {   // the next step's cursors
           akt_nx = akt_run + 1;
           pA_nx = pA + 64;
           if (akt_nx == KT) {
@@ -651,10 +695,10 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
 #if EPS_V7_VI > 0
         if (JQ == 2) {
           if (first && kk == 0) {
-            if (i < EPS_V7_VI) V7Asm<I8>::v(acc[i][0], fa[cur][i], fb[rb][kk][0]);
+            if (i < VI) V7Asm<I8>::v(acc[i][0], fa[cur][i], fb[rb][kk][0]);
             else V7Asm<I8>::a_(acc[i][0], fa[cur][i], fb[rb][kk][0]);
           } else {
-            if (i < EPS_V7_VI) V7Asm<I8>::v(acc[i][JQ - 1], fa[cur][i], fb[rb][kk][JQ - 1]);
+            if (i < VI) V7Asm<I8>::v(acc[i][JQ - 1], fa[cur][i], fb[rb][kk][JQ - 1]);
             else V7Asm<I8>::a_(acc[i][JQ - 1], fa[cur][i], fb[rb][kk][JQ - 1]);
           }
         }
@@ -682,7 +726,8 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
     sA_run = sN;
     sN_run = (sN + ASLOT) & (RING * ASLOT - 1);
     sD_run = sA;
-    if (JQ == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // this step's 8 DMA pieces + 4 JQ fragment loads may stay in flight
+    if (FBUF == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // (F01 of this step has landed: the next step's first sub-step reads it)
+    else if (JQ == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // this step's 8 DMA pieces + 4 JQ fragment loads may stay in flight
     else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -695,7 +740,7 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
 #ifdef EPS_V7_PROF
     const unsigned long long pf_t0 = __builtin_readcyclecounter();
 #endif
-    const int64_t row0 = (a.tile0 + tile_rt(ri_c)) * 256;
+    const int64_t row0 = (a.tile0 + tile_rt(ri_c)) * TR;
     const int64_t qbase = (int64_t)tile_qt(qi_c) * QT + wave * (32 * JQ);   // scalar
     lane_values();
     ad_run = faddr[1] + sA_run;   // (re-derived with the lane values: nothing lane-dependent lives across the epilogue)
@@ -729,31 +774,40 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
       }
     }
     if (t + 1 < ntile) issue_base(ri_n, (int)((t + 1) & 1));
-    {   // acc[i][0] <- the pre-scaled |x|^2 column of the tile (hipcc reads it from LDS straight into the AGPRs here; moved
-        // into the previous tile's epilogue it goes through VGPRs + 100 v_accvgpr_write instead)
-      const int kh4 = (int)(lane16 >> 7) & 4;     // = 4 * khalf
-      const float* bl0 = base_lds + (t & 1) * 256;
+    // acc[i][0] <- the pre-scaled |x|^2 column (8-bit: the rows' start values) of the tile.  r4 (EPS_V7_EARLYINIT): the row blocks whose
+    // accumulators live in arch VGPRs get the NEXT tile's start values at the end of their own epilogue iteration - the LDS reads go
+    // straight into the registers the block just vacated and land under the remaining blocks' tests - so the tile head only initialises the
+    // first tile and the blocks in the accumulator file (there hipcc would go through VGPRs + v_accvgpr_write).
+    auto init_block = [&](int i, int par, int kh4) __attribute__((always_inline)) {   // (i: a constant after unrolling)
+      const float* bl0 = base_lds + par * 256;
+      const int rbase = i * 32 + kh4;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int rbase = i * 32 + kh4;
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          if (I8) {
-            const int4 bv = *reinterpret_cast<const int4*>(&bl0[rbase + 8 * gq]);
-            acc[i][0][4 * gq + 0] = bv.x;
-            acc[i][0][4 * gq + 1] = bv.y;
-            acc[i][0][4 * gq + 2] = bv.z;
-            acc[i][0][4 * gq + 3] = bv.w;
-          } else {
-            const float4 bv = *reinterpret_cast<const float4*>(&bl0[rbase + 8 * gq]);
-            acc[i][0][4 * gq + 0] = bv.x;
-            acc[i][0][4 * gq + 1] = bv.y;
-            acc[i][0][4 * gq + 2] = bv.z;
-            acc[i][0][4 * gq + 3] = bv.w;
-          }
+      for (int gq = 0; gq < 4; ++gq) {
+        if (I8) {
+          const int4 bv = *reinterpret_cast<const int4*>(&bl0[rbase + 8 * gq]);
+          acc[i][0][4 * gq + 0] = bv.x;
+          acc[i][0][4 * gq + 1] = bv.y;
+          acc[i][0][4 * gq + 2] = bv.z;
+          acc[i][0][4 * gq + 3] = bv.w;
+        } else {
+          const float4 bv = *reinterpret_cast<const float4*>(&bl0[rbase + 8 * gq]);
+          acc[i][0][4 * gq + 0] = bv.x;
+          acc[i][0][4 * gq + 1] = bv.y;
+          acc[i][0][4 * gq + 2] = bv.z;
+          acc[i][0][4 * gq + 3] = bv.w;
         }
-        __builtin_amdgcn_sched_barrier(0);   // one row block at a time: hoisting all 64 reads costs spills
       }
+    };
+    {
+      const int kh4 = (int)(lane16 >> 7) & 4;     // = 4 * khalf
+#define EPS_INIT_AT_HEAD(I_)                                                                        \
+  if (!EPS_V7_EARLYINIT || t == 0 || (I_) >= VI) {                                           \
+    init_block((I_), (int)(t & 1), kh4);                                                            \
+    __builtin_amdgcn_sched_barrier(0); /* one row block at a time: hoisting all 64 reads costs spills */ \
+  }
+      EPS_INIT_AT_HEAD(0) EPS_INIT_AT_HEAD(1) EPS_INIT_AT_HEAD(2) EPS_INIT_AT_HEAD(3)
+      if (NRB == 8) { EPS_INIT_AT_HEAD(NRB - 4) EPS_INIT_AT_HEAD(NRB - 3) EPS_INIT_AT_HEAD(NRB - 2) EPS_INIT_AT_HEAD(NRB - 1) }
+#undef EPS_INIT_AT_HEAD
     }
 #ifdef EPS_V7_PROF
     const unsigned long long pf_t1 = __builtin_readcyclecounter();
@@ -818,6 +872,7 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
     // taken on the common path; only a tile in which something passed (one in six at the last stage of a 10M-row scan) runs the
     // per-block code, and only it can have filled the pending list, so the flush check moves there too.
     bool tile_hit = true;
+    bool tile_appended = false;   // (wave-uniform: set where a block passed) the pending list can only have grown in such a tile
 #if EPS_V7_TILE
     if (I8 && MODE != FM_DENSE) {
       bool h = false;
@@ -825,10 +880,10 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
       for (int j = 0; j < JQ; ++j) {
         int p0 = (int)acc[0][j][0], p1 = (int)acc[0][j][1], p2 = (int)acc[0][j][2], p3 = (int)acc[0][j][3];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NRB; ++i) {
 #pragma unroll
           for (int r = (i == 0 ? 4 : 0); r < 16; r += 4) {
-            if (i < EPS_V7_VI) {
+            if (i < VI) {
               const int a0 = (int)acc[i][j][r], a1 = (int)acc[i][j][r + 1], a2 = (int)acc[i][j][r + 2], a3 = (int)acc[i][j][r + 3];
               p0 = p0 > a0 ? p0 : a0;
               p1 = p1 > a1 ? p1 : a1;
@@ -860,13 +915,38 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
 #if EPS_V7_TILE && EPS_V7_VI > 0 && EPS_V7_VI < 8
     if (I8 && MODE != FM_DENSE) {   // (the blocks in the accumulator file become "new" values here, or hipcc copies them out on the common path)
 #pragma unroll
-      for (int i = EPS_V7_VI; i < 8; ++i)
+      for (int i = VI; i < NRB; ++i)
 #pragma unroll
         for (int j = 0; j < JQ; ++j) asm volatile("" : "+a"(acc[i][j]));
     }
 #endif
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i0 = 0; i0 < NRB; i0 += EPS_V7_GROUP) {
+    // r4 (EPS_V7_GROUP > 1): the maxima of GROUP row blocks x JQ query blocks are combined per query column and tested ONCE - one compare
+    // pair + one untaken branch per group instead of one per block (lab ablation: the 16 compare + branch pairs cost the launch 3 %);
+    // unlike the tile-level test nothing is computed twice: a group that passes re-uses its blocks' maxima for the per-block tests
+    thr_t mxg[EPS_V7_GROUP][JQ];
+    bool group_hit = true;
+    if (EPS_V7_GROUP > 1 && MODE != FM_DENSE) {
+      bool h = false;
+#pragma unroll
+      for (int j = 0; j < JQ; ++j) {
+        __builtin_amdgcn_sched_barrier(0);
+        thr_t gm = mxg[0][j] = OP::max16(acc[i0][j]);
+#pragma unroll
+        for (int ii = 1; ii < EPS_V7_GROUP; ++ii) {
+          __builtin_amdgcn_sched_barrier(0);
+          mxg[ii][j] = OP::max16(acc[i0 + ii][j]);
+          gm = gm > mxg[ii][j] ? gm : mxg[ii][j];
+        }
+        h |= gm >= Tq[j];
+      }
+      group_hit = __any(h);
+    }
+    if (EPS_V7_GROUP == 1 || MODE == FM_DENSE || __builtin_expect(group_hit, 0)) {
+#pragma unroll
+    for (int ii = 0; ii < EPS_V7_GROUP; ++ii) {
+      const int i = i0 + ii;
       const int rbase = i * 32 + kh4e;
 #pragma unroll
       for (int j = 0; j < JQ; ++j) {
@@ -881,7 +961,7 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
               const bool nan = dapx != dapx;
               if (a.metric == 0) dapx = fmaxf(dapx, 0.f);
               if (row < a.row_hi)
-                a.cand_keys[qq * (int64_t)a.cap + (row - a.tile0 * 256)] =
+                a.cand_keys[qq * (int64_t)a.cap + (row - a.tile0 * TR)] =
                     nan ? KEY_EMPTY : make_key(dapx, (u32)row);
             }
           }
@@ -891,7 +971,7 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
 #if defined(EPS_V7_ABL) && (EPS_V7_ABL & 1)
         continue;   // lab ablation: no epilogue work at all (results are wrong; what the whole epilogue costs)
 #endif
-        const thr_t mx = OP::max16(acc[i][j]);
+        const thr_t mx = EPS_V7_GROUP > 1 ? mxg[ii][j] : OP::max16(acc[i][j]);
 #if defined(EPS_V7_ABL) && (EPS_V7_ABL & 2)
         asm volatile("" ::"v"(mx));   // lab ablation: maxima computed, never compared (what compare + branch + hit path cost)
         continue;
@@ -907,6 +987,7 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
 #endif
           // (rare) everything the hit path needs is derived behind this opaque copy of the lane id, or hipcc hoists the
           // address arithmetic of all 16 blocks into the common path
+          tile_appended = true;
           int l31h = l31e, rbh = rbase;
           asm volatile("" : "+v"(l31h), "+v"(rbh));
           const int64_t qq = qbase + j * 32 + l31h;
@@ -968,9 +1049,20 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_kernel_v7(FilterArgs a) {
         }
       }
     }
+    }   // group_hit
+#if EPS_V7_EARLYINIT
+    // (the group's row blocks are done with: their first accumulators take the next tile's start values now)
+#pragma unroll
+    for (int ii = 0; ii < EPS_V7_GROUP; ++ii)
+      if (i0 + ii < VI && t + 1 < ntile) {
+        __builtin_amdgcn_sched_barrier(0);
+        init_block(i0 + ii, (int)((t + 1) & 1), kh4e);
+      }
+#endif
+    }
 #if !(defined(EPS_V7_ABL) && (EPS_V7_ABL & 4))   // (lab ablation: no flush check)
-    if (MODE != FM_DENSE) {
-      if (*reinterpret_cast<volatile u32*>(wcnt) >= (u32)(V7_CAPW / 2)) flush();
+    if (MODE != FM_DENSE && (!EPS_V7_FLUSHFLAG || tile_appended)) {
+      if (*wcnt_lds >= (u32)(V7_CAPW / 2)) flush();
     }
 #endif
     }   // tile_hit

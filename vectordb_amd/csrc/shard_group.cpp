@@ -352,6 +352,7 @@ class ShardGroup : public IndexBase {
       t.main_kernel_bits = std::max(t.main_kernel_bits, s.main_kernel_bits);
       t.i8_declined += s.i8_declined;
       t.i8_folded += s.i8_folded;
+      t.one_pass += s.one_pass;
       t.filter_ms_all = std::max(t.filter_ms_all, s.filter_ms_all);
       t.filter_rows_all += s.filter_rows_all;
     }

@@ -1,0 +1,305 @@
+// Exact flat search of a HANDFUL of queries (<= 4) in ONE pass over the 8-bit mirror (r4; BASELINE configs[1]: one query per call).
+//
+// What it replaces: for a few queries the staged MFMA chain of mfma_filter.hip is a GEMM-shaped answer to a GEMV-shaped problem - a
+// single-query call was 9 dependent launches (query prep, seed pass, seed selection, seed re-rank, 3 x (filter stage + re-rank)), 0.33 ms
+// of which only the last stage's 0.12 ms was the unavoidable pass over the mirror (profiles/r4_single_query_latency.txt).  Here the pass
+// IS the call: every wavefront streams its share of the mirror (HBM-bound: d_pad8 bytes + 4 per row, v_dot4_i32_i8, no matrix cores),
+// and what the stages were for - a pass threshold that tightens as the scan proceeds - lives in a 16-entry table per query in device
+// memory that all wavefronts share:
+//
+//   G[q][0..64)  slot j = the largest accumulator (= approximate key, larger = closer) any visible row with hash(row) mod 64 = j has
+//                shown so far (INT_MIN = empty slot), kept by one fire-and-forget atomicMax per offer - no lock, no compare-and-swap
+//                loop.  The k largest slots are k DISTINCT rows, and whatever k rows they are, the k-th best EXACT distance of the
+//                result is at most the largest upper bound among them: ub(acc) = C[q] - u acc + margin (the Cauchy-Schwarz margin of
+//                stage_threshold8, which bounds |exact - approximate| in BOTH directions;
+//                tests/test_bound_math.py::test_upper_bound_of_the_approximate_key).  With 64 slots for k <= 16 the k-th largest slot
+//                ends within a few ranks of the k-th best row.  Every slot has its own 256 bytes: device-scope atomics on ONE address
+//                are served one after the other, ~50 ns each on this machine (measured: the first versions of this kernel - a 16-entry
+//                table in one cache line, offered to by 4096 wavefronts at start - spent 0.2 ms there), on 64 lines they overlap.
+//   pass test    a row is a candidate iff acc >= stage_threshold8(ub(k-th largest slot)) - the same arithmetic every filter stage
+//                uses, with the k-th best exact key replaced by that upper bound.  Slots only grow, a stale read only loosens the test.
+//
+// Candidates are appended as (acc, row) pairs, one atomic per wavefront and iteration.  Early in the pass the table is loose and lets
+// junk through (every wavefront first offers ONE row of its first chunk to the empty table and only then starts testing, which bounds the
+// junk to a few hundred entries); stream8_select_kernel drops it against the FINAL table without touching a
+// row, and the ordinary re-rank kernel (flat_kernels.hip) computes the survivors' exact fp32 distances, applies the deleted bitset /
+// filter, and writes the caller-visible result.  Overflow of either list is reported through the re-rank's overflow counter and the
+// caller repeats the batch on the staged chain.  Rows with a FORCED start value (mfma_filter.hip: ACC_FORCE) are always candidates and
+// never enter the table.
+#pragma once
+#include "device_common.hpp"
+#include "kernels.hpp"
+
+namespace eps {
+
+struct Stream8Args {
+  const signed char* x8;   // [n_pad8][d_pad8]
+  const int* acc0;         // [n_pad8]
+  int64_t n;               // rows to scan
+  int d_pad8;
+  const signed char* q8;   // [>= nq][d_pad8] row-major
+  const float* qstat;      // [>= nq][4]
+  const float* scal;       // the mirror's maxima (HalfMirror::scal8)
+  int nq, k, metric;
+  float u, slack;
+  int* G;                  // [4][64] slots, S8_SLOT_STRIDE ints apart
+  u32* raw_cnt;            // [4][16] sub-list counters, S8_CNT_STRIDE words apart (one list per 16th of the wavefronts: again one address each)
+  u64* raw;                // [4][16][raw_cap]: (acc << 32) | row
+  int raw_cap;             // entries per sub-list
+  int ablate;              // lab (EPS_S8_ABLATE): 1 = no table, no test - the bare stream + dot products (results are wrong)
+  FilterSpec f;
+};
+
+constexpr int S8_FORCE_LIMIT = 0x30000000;   // (= TQ_MAX8: accumulators at or above it belong to forced rows)
+constexpr int S8_EMPTY = -2147483647 - 1;
+constexpr int S8_SLOTS = 64, S8_SLOT_STRIDE = 64, S8_SUBLISTS = 16, S8_CNT_STRIDE = 32;   // (strides in 4-byte words)
+constexpr int S8_TABLE_WORDS = 4 * S8_SLOTS * S8_SLOT_STRIDE + 4 * S8_SUBLISTS * S8_CNT_STRIDE;
+
+// upper bound of the exact fp32 distance of a row whose accumulator is `acc` (see the header; mirrors stage_threshold8 term by term)
+__device__ __forceinline__ float stream8_ub(int acc, const float* qs, const float* sc, int metric, float u, float slack) {
+  const float qn2 = qs[0], nqc = qs[1], eq = qs[2], Cq = qs[3];
+  const float e1max = sc[0], nxhmax = sc[1], xnmax = sc[2], rmax = sc[4], mun = sc[5], xcmax = sc[6];
+  const float s = metric == 0 ? 2.f : 1.f;
+  const float margin = s * (nqc * e1max + eq * nxhmax);
+  const float dapx = Cq - u * (float)acc;
+  const float scale = metric == 0 ? fabsf(dapx) + margin + 2.f * fabsf(Cq) + 2.f * rmax
+                                  : fabsf(dapx) + margin + 1.f + sqrtf(qn2) * (sqrtf(xnmax) + mun) + mun * xcmax + fabsf(Cq) + rmax;
+  // (the start value is ceil(-R/u) + 1: up to two units above the real quotient; (float)acc and the product round once each)
+  return dapx + margin + 2.f * slack * scale + 4.f * u;
+}
+
+// pass threshold of query q from the table: its k-th largest slot (one wavefront, one slot per lane; every lane gets the result)
+__device__ __forceinline__ int stream8_threshold(const Stream8Args& a, int q, int lane, int& gkth) {
+  const int v = __hip_atomic_load(a.G + (q * S8_SLOTS + lane) * S8_SLOT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int rank = 0;   // slots that order before this lane's (larger value, or equal and lower lane)
+  for (int i = 0; i < 64; ++i) {
+    const int w = __builtin_amdgcn_readlane(v, i);
+    rank += (w > v || (w == v && i < lane)) ? 1 : 0;
+  }
+  const unsigned long long m = __ballot(rank == a.k - 1);
+  const int kth = __builtin_amdgcn_readlane(v, __ffsll((long long)m) - 1);
+  gkth = kth;
+  if (kth == S8_EMPTY) return -(1 << 30);   // fewer than k slots filled so far: everything passes
+  return stage_threshold8(stream8_ub(kth, a.qstat + q * 4, a.scal, a.metric, a.u, a.slack), a.qstat + q * 4, a.scal, a.metric, a.u, a.slack, 0);
+}
+
+__device__ __noinline__ void stream8_offer(const Stream8Args& a, int q, int acc, u32 row) {   // (one lane; rare)
+  if (!row_visible(a.f, row)) return;   // (only rows the result may contain bound it)
+  const u32 slot = ((row * 2654435761u) >> 12) & (u32)(S8_SLOTS - 1);
+  (void)__hip_atomic_fetch_max(a.G + (q * S8_SLOTS + (int)slot) * S8_SLOT_STRIDE, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// sum over the 16 lanes of a DPP row (every lane gets it): two quad permutes, then half-row and row mirrors - 4 VALU instructions, no LDS
+// (__shfl_xor compiles to ds_bpermute: 16 LDS round trips per step of this kernel)
+__device__ __forceinline__ int row16_sum(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);   // row_half_mirror: the other quad of the same 8 lanes
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);   // row_mirror: the other half of the row
+  return v;
+}
+
+// PIECES = d_pad8 / 256: a row is PIECES x 256 bytes, 16 lanes x 16 bytes each; four rows per wavefront and step, U steps in flight.
+// The table is READ by one wavefront per workgroup, every fourth iteration, and handed to the other three through LDS: read by every
+// wavefront in every iteration (4096 cache-bypassing loads of one 64-byte line per round) the loads queued up at that line's memory
+// channel for ~20 us per iteration - the first version of this kernel ran at 2.1 TB/s because of it.
+template <int PIECES, int NQ>
+__global__ __launch_bounds__(256) void stream8_kernel(Stream8Args a) {
+  constexpr int U = PIECES <= 3 ? 4 : 2;
+  constexpr int CH = 4 * U;   // rows per wavefront and iteration
+  __shared__ int T_s[4], gkth_s[4];
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const int g = lane >> 4, t = lane & 15;
+  const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t W = (int64_t)gridDim.x * 4;
+
+  int4 qv[NQ][PIECES];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int p = 0; p < PIECES; ++p)
+      qv[q][p] = q < a.nq ? *reinterpret_cast<const int4*>(a.q8 + (int64_t)q * a.d_pad8 + p * 256 + t * 16) : make_int4(0, 0, 0, 0);
+
+  auto dots = [&](const int4 (&xv)[PIECES], int a0v, int (&out)[NQ]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      int d = 0;
+#pragma unroll
+      for (int p = 0; p < PIECES; ++p) {
+        d = __builtin_amdgcn_sdot4(xv[p].x, qv[q][p].x, d, false);
+        d = __builtin_amdgcn_sdot4(xv[p].y, qv[q][p].y, d, false);
+        d = __builtin_amdgcn_sdot4(xv[p].z, qv[q][p].z, d, false);
+        d = __builtin_amdgcn_sdot4(xv[p].w, qv[q][p].w, d, false);
+      }
+      out[q] = row16_sum(d) + a0v;
+    }
+  };
+  auto refresh = [&]() __attribute__((always_inline)) {   // (one wavefront: the table -> this workgroup's thresholds)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      if (q < a.nq) {
+        int gm;
+        const int Tq = stream8_threshold(a, q, lane, gm);
+        if (lane == 0) {
+          T_s[q] = Tq;
+          gkth_s[q] = gm;
+        }
+      }
+    }
+  };
+
+  auto load_chunk = [&](int64_t base, int4 (&xv)[U][PIECES], int (&a0)[U]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int uu = 0; uu < U; ++uu) {
+      int64_t r = base + uu * 4 + g;
+      r = r < a.n ? r : a.n - 1;
+      const signed char* p0 = a.x8 + r * a.d_pad8 + t * 16;
+#pragma unroll
+      for (int p = 0; p < PIECES; ++p) xv[uu][p] = *reinterpret_cast<const int4*>(p0 + p * 256);
+      a0[uu] = a.acc0[r];
+    }
+  };
+  // candidates of one chunk: appended (one atomic per wavefront, query and step), offered to the table where they beat its k-th slot
+  auto test_chunk = [&](int64_t base, const int (&acc)[U][NQ]) __attribute__((always_inline)) {
+    if (a.ablate & 1) {   // (keeps the loads and the arithmetic alive)
+      int x = 0;
+#pragma unroll
+      for (int uu = 0; uu < U; ++uu)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) x ^= acc[uu][q];
+      if (x == 0x7fffffff && base == -5) a.raw[0] = 1;
+      return;
+    }
+    int T[NQ], gkth[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      T[q] = q < a.nq ? *reinterpret_cast<volatile int*>(&T_s[q]) : 2147483647;
+      gkth[q] = q < a.nq ? *reinterpret_cast<volatile int*>(&gkth_s[q]) : 2147483647;
+    }
+    bool any = false;
+#pragma unroll
+    for (int uu = 0; uu < U; ++uu)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) any |= (acc[uu][q] >= T[q] || acc[uu][q] > gkth[q]) && base + uu * 4 + g < a.n;
+    if (!__ballot(any && t == 0)) return;   // (the common step ends here)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      if (q >= a.nq) continue;
+#pragma unroll
+      for (int uu = 0; uu < U; ++uu) {
+        const int64_t row = base + uu * 4 + g;
+        const bool live = t == 0 && row < a.n;
+        const int v = acc[uu][q];
+        const bool pass = live && v >= T[q];
+        const unsigned long long mask = __ballot(pass);
+        if (mask) {
+          const int cntw = __popcll(mask);
+          const int leader = __ffsll((long long)mask) - 1;
+          u32 slot0 = 0;
+          const int sub = q * S8_SUBLISTS + (int)(wid & (S8_SUBLISTS - 1));
+          if (lane == leader) slot0 = atomicAdd(a.raw_cnt + sub * S8_CNT_STRIDE, (u32)cntw);
+          slot0 = __shfl(slot0, leader);
+          if (pass) {
+            const u32 slot = slot0 + (u32)__popcll(mask & ((1ull << lane) - 1ull));
+            if (slot < (u32)a.raw_cap) a.raw[(int64_t)sub * a.raw_cap + slot] = ((u64)(u32)v << 32) | (u32)row;
+          }
+        }
+        // the table (a row offered twice lands in the same slot: still distinct rows)
+        if (live && v > gkth[q] && v < S8_FORCE_LIMIT) stream8_offer(a, q, v, (u32)row);
+      }
+    }
+  };
+
+  const int64_t first = wid * CH, stride = W * CH;
+  int4 xa[U][PIECES], xb[U][PIECES];
+  int a0a[U], a0b[U];
+  int acc[U][NQ];
+  if (first < a.n) load_chunk(first, xa, a0a);
+  if (first + stride < a.n) load_chunk(first + stride, xb, a0b);
+  // ---- the first chunk feeds the empty table before anything is tested: ONE row per wavefront (the chunks are spread over the whole
+  // mirror) is offered, the workgroup's first thresholds are read from what has arrived, and only then the chunk is tested - so the table
+  // holds the best of a few thousand rows before the first candidate is appended
+  if (first < a.n) {
+#pragma unroll
+    for (int uu = 0; uu < U; ++uu) dots(xa[uu], a0a[uu], acc[uu]);
+    // the best of the wavefront's 4 U rows (per query): one offer per wavefront, of a row that beat 15 others
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      if (q >= a.nq || (a.ablate & 1)) continue;
+      int bv = S8_EMPTY, br = 0;
+#pragma unroll
+      for (int uu = 0; uu < U; ++uu) {
+        const int v = acc[uu][q];
+        const bool better = first + uu * 4 + g < a.n && v < S8_FORCE_LIMIT && v > bv;
+        br = better ? uu * 4 + g : br;
+        bv = better ? v : bv;
+      }
+#pragma unroll
+      for (int o = 16; o < 64; o <<= 1) {
+        const int ov = __shfl_xor(bv, o), orow = __shfl_xor(br, o);
+        const bool better = ov > bv;
+        br = better ? orow : br;
+        bv = better ? ov : bv;
+      }
+      if (lane == 0 && bv != S8_EMPTY) stream8_offer(a, q, bv, (u32)(first + br));
+    }
+  }
+  if (!(a.ablate & 1)) {
+    __syncthreads();
+    if (wave == 0) refresh();
+    __syncthreads();
+  }
+  if (first < a.n) test_chunk(first, acc);
+  // ---- the stream, two chunks in flight per wavefront: the loads of chunk i + 2 are issued before chunk i + 1 is multiplied
+  int it = 1;
+  for (int64_t base = first + stride; base < a.n; base += 2 * stride, it += 2) {
+    if (base + stride < a.n) load_chunk(base + stride, xa, a0a);
+    // the thresholds are read again after 2, 4, 8 chunks (the table tightens fastest at the start: a stale threshold there is what lets
+    // junk into the lists) and then every 8, the four wavefronts in turn (the refresher waits for 64 cache-bypassing loads)
+    if ((it == 1 || it == 3 || (it & 7) == 7) && wave == ((it >> 1) & 3) && !(a.ablate & 3)) refresh();   // (every 8 chunks, the four wavefronts in turn: the refresher waits for 64 cache-bypassing loads)
+#pragma unroll
+    for (int uu = 0; uu < U; ++uu) dots(xb[uu], a0b[uu], acc[uu]);
+    test_chunk(base, acc);
+    if (base + stride >= a.n) break;
+    if (base + 2 * stride < a.n) load_chunk(base + 2 * stride, xb, a0b);
+#pragma unroll
+    for (int uu = 0; uu < U; ++uu) dots(xa[uu], a0a[uu], acc[uu]);
+    test_chunk(base + stride, acc);
+  }
+}
+
+// one workgroup per query: candidates that still pass against the FINAL table -> the re-rank's list; the running result = empty
+__global__ __launch_bounds__(256) void stream8_select_kernel(Stream8Args a, u32* cand, int cap, u32* cnt, u64* run_keys, u32* overflow) {
+  __shared__ u32 kept, lost;
+  __shared__ int Tfin;
+  const int q = blockIdx.x;
+  if (threadIdx.x == 0) kept = lost = 0;
+  if (threadIdx.x < 64) {
+    int gm;
+    const int T = stream8_threshold(a, q, (int)threadIdx.x, gm);
+    if (threadIdx.x == 0) Tfin = T;
+  }
+  for (int i = threadIdx.x; i < a.k; i += 256) run_keys[(int64_t)q * a.k + i] = KEY_EMPTY;
+  __syncthreads();
+  const int T = Tfin;
+  // 16 threads per sub-list (the 16 counters are read at once: the kernel is a chain of dependent latencies, not work)
+  const int sub = q * S8_SUBLISTS + (int)(threadIdx.x >> 4);
+  const u32 have = a.raw_cnt[sub * S8_CNT_STRIDE];
+  const u32 n_raw = have < (u32)a.raw_cap ? have : (u32)a.raw_cap;
+  if (have > (u32)a.raw_cap) lost = 1;
+  for (u32 i = threadIdx.x & 15; i < n_raw; i += 16) {
+    const u64 e = a.raw[(int64_t)sub * a.raw_cap + i];
+    if ((int)(u32)(e >> 32) >= T) {
+      const u32 slot = atomicAdd(&kept, 1u);
+      if (slot < (u32)cap) cand[(int64_t)q * cap + slot] = (u32)e;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    cnt[q] = kept;   // (> cap: the re-rank counts the query as overflowed and reads the cap entries that exist)
+    if (lost) atomicAdd(overflow, 1u);   // a raw list lost entries: the caller repeats the batch on the staged chain
+  }
+}
+
+}  // namespace eps
