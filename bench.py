@@ -305,6 +305,20 @@ def config_c2(amd, torch, args, X, qlast, dev, stream, local_rank, cpu, graph_in
                                   torch.empty((64,), dtype=torch.int32, device=dev)), mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)   # builds the 8-bit mirror
     gpu["mfma_i8"], r8 = latency(ix, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
     gpu["mfma_i8"]["recall_at_10"] = recall_of(r8, gt1)
+    gpu["mfma_i8"]["one_pass"] = int(ix.stats().get("one_pass", 0))   # r4: 1 = ONE streaming pass over the 8-bit mirror + one re-rank (stream8_kernel)
+    if gpu["mfma_i8"]["one_pass"]:
+        # the pass itself against the HBM roofline: timed in a second run (an event pair around it costs the untimed call ~10 us)
+        os.environ["EPS_ONE_PASS_TIMED"] = "1"
+        try:
+            timed, _ = latency(ix, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
+        finally:
+            del os.environ["EPS_ONE_PASS_TIMED"]
+        if timed["main_kernel_ms"]:
+            row_bytes = (d + 255) // 256 * 256 + 4          # the mirror's row pitch + the row's int32 start value
+            ach = n1 * row_bytes / (timed["main_kernel_ms"] * 1e-3) / 1e9
+            gpu["mfma_i8"]["roofline"] = {"bound": "hbm", "kernel": "stream8_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                          "kernel_ms": timed["main_kernel_ms"], "algorithmic_bytes": n1 * row_bytes,
+                                          "note": "one pass over the 8-bit mirror (%d bytes per row) + 4 bytes of start value per row; timed run p50 %.3f ms" % (row_bytes - 4, timed["p50_ms"])}
     gpu["auto"], ra = latency(ix, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_AUTO)
     gpu["auto"]["recall_at_10"] = recall_of(ra, gt1)
     if graph_index is not None:

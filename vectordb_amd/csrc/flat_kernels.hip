@@ -8,6 +8,7 @@
 // Only candidates that would enter the top-k touch the deleted bitset / filter column, so the
 // algorithmic HBM traffic is N*dim*4 bytes per query group.
 #include "kernels.hpp"
+#include "stream8_kernel.hpp"
 
 namespace eps {
 
@@ -244,7 +245,22 @@ __global__ __launch_bounds__(NW * 64) void rerank_kernel(RerankArgs a) {
   const int g = lane / G;
   const int t = lane & (G - 1);
   constexpr int U = 4;
-  const u32 cnt_raw = a.cand_count[q];
+  __shared__ u32 s8_kept, s8_lost;
+  __shared__ int s8_T;
+  if (a.s8_G) {   // one-pass search: the selection step in front of the re-rank (stream8_kernel.hpp)
+    if (threadIdx.x == 0) s8_kept = s8_lost = 0;
+    if (wave == 0) {
+      int gk;
+      const int T = stream8_threshold_of(a.s8_G + q * (S8_SLOTS * S8_SLOT_STRIDE), a.k, a.qstat + q * 4, a.scal, a.metric, a.u, a.slack, lane, gk);
+      if (lane == 0) s8_T = T;
+    }
+    __syncthreads();
+    stream8_select<NT>(s8_T, a.s8_counts + q * (int64_t)a.s8_waves, a.s8_lists + q * (int64_t)a.s8_waves * S8_WAVE_CAP, a.s8_waves, a.s8_cand + q * (int64_t)a.cap,
+                       a.cap, &s8_kept, &s8_lost);
+    __syncthreads();
+    if (threadIdx.x == 0 && s8_lost) atomicAdd(a.overflow, 1u);   // a wavefront's list lost entries: the caller repeats the batch on the staged chain
+  }
+  const u32 cnt_raw = a.s8_G ? s8_kept : a.cand_count[q];
   u32 cnt = cnt_raw;
   if (cnt > (u32)a.cap) cnt = (u32)a.cap;
   const u32* cand = a.cand + q * (int64_t)a.cap;
@@ -252,8 +268,8 @@ __global__ __launch_bounds__(NW * 64) void rerank_kernel(RerankArgs a) {
   WaveTopK<KPL> L[1];
   u64 thr[1];
   L[0].init();
-  thr[0] = a.run_keys[q * a.k + (a.k - 1)];
-  if (wave == 0) L[0].load(a.run_keys + q * a.k, a.k);
+  thr[0] = a.s8_G ? KEY_EMPTY : a.run_keys[q * a.k + (a.k - 1)];
+  if (wave == 0 && !a.s8_G) L[0].load(a.run_keys + q * a.k, a.k);
 
   for (u32 c0 = wave * RPW * U; c0 < cnt; c0 += NW * RPW * U) {
     const float* rp[U];

@@ -74,6 +74,14 @@ struct RerankArgs {
   int parts = 0;
   u64* part_keys = nullptr;
   u32* part_done = nullptr;   // [nq], zero between launches (the last workgroup zeroes it again)
+  // one-pass search of a handful of queries (stream8_kernel.hpp): the launch first SELECTS its candidates - the entries of the pass's
+  // per-wavefront lists that still pass against the final table of best accumulators - into `cand` (written through s8_cand), starts
+  // from an empty running list, and counts a lost list entry as an overflow.  s8_G == null: an ordinary re-rank
+  const int* s8_G = nullptr;        // [nq][64 slots]
+  const u32* s8_counts = nullptr;   // [nq][s8_waves]
+  const u64* s8_lists = nullptr;    // [nq][s8_waves][16]
+  int s8_waves = 0;
+  u32* s8_cand = nullptr;           // = cand
 };
 void launch_rerank(const RerankArgs& a, hipStream_t s);
 

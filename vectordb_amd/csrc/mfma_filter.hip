@@ -99,7 +99,7 @@ struct HalfMirror {
   bool i8_ok = false;
   int i8_overflows = 0;         // consecutive batches whose 8-bit pass overflowed its candidate lists (the fp16 pass then answered)
   // r4, a handful of queries in one pass (stream8_kernel.hpp): the shared best-accumulator tables + raw candidate counters, the raw lists
-  DevBuf s8g, s8raw;            // table slots + sub-list counters (S8_TABLE_WORDS);  u64 [4][16][S8_RAW_CAP]
+  DevBuf s8g, s8raw;            // table slots (S8_TABLE_WORDS) + per-wavefront candidate counts;  u64 [nq][waves][S8_WAVE_CAP]
   int64_t s8_declined_version = -1;   // rows version on which the one-pass form overflowed twice in a row (the staged chain serves it)
   int s8_overflows = 0;
   int64_t extended_rows8 = 0;
@@ -509,7 +509,6 @@ __global__ __launch_bounds__(256) void query_prep8_kernel(const float* q, int64_
     if (x.gsync) x.gsync[threadIdx.x] = 0;
     if (x.s8g) {   // (only the words in use: the slots of the call's queries, the sub-list counters)
       for (int i = threadIdx.x; i < (int)nq * S8_SLOTS; i += 256) x.s8g[i * S8_SLOT_STRIDE] = S8_EMPTY;
-      if (threadIdx.x < 4 * S8_SUBLISTS) x.s8g[4 * S8_SLOTS * S8_SLOT_STRIDE + threadIdx.x * S8_CNT_STRIDE] = 0;
     }
   }
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -947,7 +946,6 @@ bool flat_mfma_profitable(const Index& ix, int64_t nq, int k) {
 
 // A handful of queries (<= 4, k <= 16) in ONE pass over the 8-bit mirror: stream8_kernel.hpp.  *done = false: not applicable to this call,
 // or a list overflowed - the staged chain below answers it (results are bit-identical either way: both end in the same exact re-rank).
-constexpr int S8_RAW_CAP = 2048;   // entries per raw sub-list (16 per query)
 static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k, u64* run_keys, bool* done) {
   *done = false;
   HalfMirror& m = *ix.mirror_;
@@ -957,11 +955,11 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
   if (nq < 1 || nq > 4 || k < 1 || k > 16 || m.fold8 || n < 65536 || n > m.n8 || m.d_pad8 % 256 != 0 || pieces < 2 || pieces > 4) return EPS_OK;
   if (m.s8_declined_version == ix.rows_version_) return EPS_OK;
   const FilterSpec fs = ix.filter_spec();
-  if (fs.prog && fs.prog_use_dist) return EPS_OK;   // (a filter on the distance itself: only the re-rank knows it)
+  if (fs.column || fs.prog) return EPS_OK;   // (attribute filters / filter programs: the staged chain; a deleted bitset is handled here)
   hipStream_t s = ix.stream_;
   const int cap = std::max(4096, 64 * k);
   if (!m.qstat.reserve((size_t)4 * 16) || !m.q8.reserve((size_t)4 * m.d_pad8) || !m.cand.reserve((size_t)nq * cap * 8) || !m.cnt.reserve((size_t)(nq + 4) * 4 + 16) ||
-      !m.s8g.reserve((size_t)S8_TABLE_WORDS * 4) || !m.s8raw.reserve((size_t)4 * S8_SUBLISTS * S8_RAW_CAP * 8))
+      !m.s8g.reserve((size_t)S8_TABLE_WORDS * 4 + (size_t)4 * S8_MAX_WAVES * 4) || !m.s8raw.reserve((size_t)nq * S8_MAX_WAVES * S8_WAVE_CAP * 8))
     return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory (scratch)");
   u32* cnt = m.cnt.as<u32>();
   u32* overflow = cnt + nq;
@@ -989,9 +987,8 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
   a.u = u8;
   a.slack = rerank_slack;
   a.G = m.s8g.as<int>();
-  a.raw_cnt = m.s8g.as<u32>() + 4 * S8_SLOTS * S8_SLOT_STRIDE;
+  a.raw_cnt = m.s8g.as<u32>() + S8_TABLE_WORDS;
   a.raw = m.s8raw.as<u64>();
-  a.raw_cap = S8_RAW_CAP;
   a.f = fs;
   a.ablate = getenv("EPS_S8_ABLATE") ? atoi(getenv("EPS_S8_ABLATE")) : 0;   // (lab)
   int cus = m.num_cus;
@@ -1000,8 +997,12 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
     cus = hipGetDeviceProperties(&prop, ix.device_) == hipSuccess ? prop.multiProcessorCount : 256;
   }
   static const int wg_per_cu = getenv("EPS_S8_WG_PER_CU") ? std::max(1, atoi(getenv("EPS_S8_WG_PER_CU"))) : 2;
-  const dim3 grid((unsigned)std::min<int64_t>((int64_t)cus * wg_per_cu, (n + 63) / 64)), block(256);
-  // (no event pair around the pass: a record between two dependent launches costs this chain 5-10 us each; kernel_ms covers the call)
+  const dim3 grid((unsigned)std::min<int64_t>(std::min<int64_t>((int64_t)cus * wg_per_cu, S8_MAX_WAVES / 4), (n + 63) / 64)), block(256);
+  a.waves = (int)grid.x * 4;
+  // (no event pair around the pass by default: a record between two dependent launches costs this chain 5-10 us each; kernel_ms covers
+  // the call.  EPS_ONE_PASS_TIMED=1 - bench.py's roofline leg - records the pair: main_kernel_ms = the pass)
+  const bool timed = getenv("EPS_ONE_PASS_TIMED") && atoi(getenv("EPS_ONE_PASS_TIMED")) != 0;
+  if (timed) (void)hipEventRecord(ix.evk0_, s);
 #define EPS_S8_LAUNCH(P_)                                                                      \
   do {                                                                                         \
     if (nq == 1) hipLaunchKernelGGL((stream8_kernel<P_, 1>), grid, block, 0, s, a);            \
@@ -1012,7 +1013,7 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
   else if (pieces == 3) EPS_S8_LAUNCH(3);
   else EPS_S8_LAUNCH(4);
 #undef EPS_S8_LAUNCH
-  hipLaunchKernelGGL(stream8_select_kernel, dim3((unsigned)nq), dim3(256), 0, s, a, m.cand.as<u32>(), cap, cnt, run_keys, overflow);
+  if (timed) (void)hipEventRecord(ix.evk1_, s);
   RerankArgs ra;
   ra.rows = ix.d_rows_;
   ra.dim = (int)ix.dim_;
@@ -1035,6 +1036,11 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
   ra.u = u8;
   ra.slack = rerank_slack;
   ra.gsync = nullptr;
+  ra.s8_G = a.G;                 // (the launch selects its candidates from the pass's lists first)
+  ra.s8_counts = a.raw_cnt;
+  ra.s8_lists = a.raw;
+  ra.s8_waves = a.waves;
+  ra.s8_cand = m.cand.as<u32>();
   const bool fin_here = ix.pre_sync_ && nq == ix.pre_sync_nq_ && ix.fin_ids_ != nullptr;
   if (fin_here) {
     ra.fin_ids = ix.fin_ids_;
@@ -1052,31 +1058,40 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
     unsigned long long total;
   } h = {0, 0, 0};
   if (!fin_here && ix.pre_sync_ && nq == ix.pre_sync_nq_) ix.pre_sync_();
-  er = hipMemcpyAsync(&h.overflow, overflow, 4, hipMemcpyDeviceToHost, s);
-  if (er == hipSuccess) er = hipMemcpyAsync(&h.total, total, 8, hipMemcpyDeviceToHost, s);
+  // (both counters in ONE small copy: every copy is a trip through the DMA queue at the end of a 0.2 ms call)
+  u32 hraw[6] = {0, 0, 0, 0, 0, 0};
+  const size_t span = (size_t)(reinterpret_cast<const char*>(total) + 8 - reinterpret_cast<const char*>(overflow));
+  er = hipMemcpyAsync(hraw, overflow, span, hipMemcpyDeviceToHost, s);
   if (er == hipSuccess) er = hipStreamSynchronize(s);
   if (er != hipSuccess) return ix.hip_fail(er, "one-pass flat search");
+  h.overflow = hraw[0];
+  memcpy(&h.total, reinterpret_cast<const char*>(hraw) + (span - 8), 8);
   if (getenv("EPS_DEBUG")) {
-    std::vector<u32> hc((size_t)S8_TABLE_WORDS);
+    std::vector<u32> hc((size_t)S8_TABLE_WORDS + (size_t)4 * S8_MAX_WAVES);
     (void)hipMemcpy(hc.data(), m.s8g.p, hc.size() * 4, hipMemcpyDeviceToHost);
     for (int64_t q = 0; q < nq; ++q) {
       unsigned long long raw = 0;
+      u32 most = 0;
       int filled = 0;
-      for (int i = 0; i < S8_SUBLISTS; ++i) raw += hc[4 * S8_SLOTS * S8_SLOT_STRIDE + (q * S8_SUBLISTS + i) * S8_CNT_STRIDE];
+      for (int w = 0; w < a.waves; ++w) {
+        raw += hc[S8_TABLE_WORDS + q * a.waves + w];
+        most = std::max(most, hc[S8_TABLE_WORDS + q * a.waves + w]);
+      }
       for (int i = 0; i < S8_SLOTS; ++i) filled += (int)hc[(q * S8_SLOTS + i) * S8_SLOT_STRIDE] != S8_EMPTY;
-      fprintf(stderr, "[eps one pass] query %lld: %llu raw candidates, %d of 64 slots filled, re-ranked (all queries) %llu, overflow %u\n", (long long)q, raw, filled, h.total, h.overflow);
+      fprintf(stderr, "[eps one pass] query %lld: %llu raw candidates (at most %u in one wavefront's list of %d), %d of 64 slots filled, re-ranked (all queries) %llu, overflow %u\n",
+              (long long)q, raw, most, S8_WAVE_CAP, filled, h.total, h.overflow);
     }
   }
   if (h.overflow) {   // (too loose a bound for this table, or a filter that leaves fewer than k rows visible: the staged chain answers)
     ix.result_finalized_ = false;
-    if (!(fs.deleted || fs.column || fs.prog) && ++m.s8_overflows >= 2) m.s8_declined_version = ix.rows_version_;
+    if (!fs.deleted && ++m.s8_overflows >= 2) m.s8_declined_version = ix.rows_version_;
     return EPS_OK;
   }
   m.s8_overflows = 0;
   if (fin_here) ix.result_finalized_ = true;
   ix.stats_.rerank_rows += (int64_t)h.total;
   ix.stats_.dist_evals += nq * n;
-  ix.stats_.main_kernel_launches = 0;   // (not timed on its own)
+  ix.stats_.main_kernel_launches = timed ? 1 : 0;   // (0: not timed on its own)
   ix.stats_.main_kernel_rows = n;
   ix.stats_.main_kernel_queries = nq;
   ix.stats_.main_kernel_bits = 8;

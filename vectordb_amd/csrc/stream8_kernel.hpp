@@ -19,9 +19,11 @@
 //   pass test    a row is a candidate iff acc >= stage_threshold8(ub(k-th largest slot)) - the same arithmetic every filter stage
 //                uses, with the k-th best exact key replaced by that upper bound.  Slots only grow, a stale read only loosens the test.
 //
-// Candidates are appended as (acc, row) pairs, one atomic per wavefront and iteration.  Early in the pass the table is loose and lets
+// Candidates are appended as (acc, row) pairs to a PRIVATE list per wavefront (16 entries; an append through a shared counter is a
+// returning device-scope atomic - microseconds during which that wavefront issues no loads - and the kernel ends with its slowest
+// wavefront: the shared-counter version lost ~20 us of a 160 us pass to some 500 of them).  Early in the pass the table is loose and lets
 // junk through (every wavefront first offers ONE row of its first chunk to the empty table and only then starts testing, which bounds the
-// junk to a few hundred entries); stream8_select_kernel drops it against the FINAL table without touching a
+// junk to a few hundred entries); the selection step (below) drops it against the FINAL table without touching a
 // row, and the ordinary re-rank kernel (flat_kernels.hip) computes the survivors' exact fp32 distances, applies the deleted bitset /
 // filter, and writes the caller-visible result.  Overflow of either list is reported through the re-rank's overflow counter and the
 // caller repeats the batch on the staged chain.  Rows with a FORCED start value (mfma_filter.hip: ACC_FORCE) are always candidates and
@@ -43,17 +45,20 @@ struct Stream8Args {
   int nq, k, metric;
   float u, slack;
   int* G;                  // [4][64] slots, S8_SLOT_STRIDE ints apart
-  u32* raw_cnt;            // [4][16] sub-list counters, S8_CNT_STRIDE words apart (one list per 16th of the wavefronts: again one address each)
-  u64* raw;                // [4][16][raw_cap]: (acc << 32) | row
-  int raw_cap;             // entries per sub-list
-  int ablate;              // lab (EPS_S8_ABLATE): 1 = no table, no test - the bare stream + dot products (results are wrong)
+  u32* raw_cnt;            // [4][waves]: entries every wavefront of the grid found (written once, when it ends)
+  u64* raw;                // [4][waves][S8_WAVE_CAP]: (acc << 32) | row - a private list per wavefront: no atomic, nothing to wait for
+  int waves;               // wavefronts of the grid (<= S8_MAX_WAVES)
+  int ablate;              // lab (EPS_S8_ABLATE; results are wrong): 1 = no table, no test - the bare stream + dot products; 2 = no periodic
+                           // re-read of the table; 4 = no start-up (offer, barriers, first read), tests against "nothing passes"; 8 = the
+                           // start-up as it is, then tests against "nothing passes"
   FilterSpec f;
 };
 
 constexpr int S8_FORCE_LIMIT = 0x30000000;   // (= TQ_MAX8: accumulators at or above it belong to forced rows)
 constexpr int S8_EMPTY = -2147483647 - 1;
-constexpr int S8_SLOTS = 64, S8_SLOT_STRIDE = 64, S8_SUBLISTS = 16, S8_CNT_STRIDE = 32;   // (strides in 4-byte words)
-constexpr int S8_TABLE_WORDS = 4 * S8_SLOTS * S8_SLOT_STRIDE + 4 * S8_SUBLISTS * S8_CNT_STRIDE;
+constexpr int S8_SLOTS = 64, S8_SLOT_STRIDE = 64;   // (stride in 4-byte words)
+constexpr int S8_TABLE_WORDS = 4 * S8_SLOTS * S8_SLOT_STRIDE;
+constexpr int S8_WAVE_CAP = 16, S8_MAX_WAVES = 8192;
 
 // upper bound of the exact fp32 distance of a row whose accumulator is `acc` (see the header; mirrors stage_threshold8 term by term)
 __device__ __forceinline__ float stream8_ub(int acc, const float* qs, const float* sc, int metric, float u, float slack) {
@@ -68,23 +73,28 @@ __device__ __forceinline__ float stream8_ub(int acc, const float* qs, const floa
   return dapx + margin + 2.f * slack * scale + 4.f * u;
 }
 
-// pass threshold of query q from the table: its k-th largest slot (one wavefront, one slot per lane; every lane gets the result)
-__device__ __forceinline__ int stream8_threshold(const Stream8Args& a, int q, int lane, int& gkth) {
-  const int v = __hip_atomic_load(a.G + (q * S8_SLOTS + lane) * S8_SLOT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// pass threshold of a query from its table G: the k-th largest slot (one wavefront, one slot per lane; every lane gets the result)
+__device__ __forceinline__ int stream8_threshold_of(const int* G, int k, const float* qs, const float* sc, int metric, float u, float slack, int lane, int& gkth) {
+  const int v = __hip_atomic_load(G + lane * S8_SLOT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   int rank = 0;   // slots that order before this lane's (larger value, or equal and lower lane)
   for (int i = 0; i < 64; ++i) {
     const int w = __builtin_amdgcn_readlane(v, i);
     rank += (w > v || (w == v && i < lane)) ? 1 : 0;
   }
-  const unsigned long long m = __ballot(rank == a.k - 1);
+  const unsigned long long m = __ballot(rank == k - 1);
   const int kth = __builtin_amdgcn_readlane(v, __ffsll((long long)m) - 1);
   gkth = kth;
   if (kth == S8_EMPTY) return -(1 << 30);   // fewer than k slots filled so far: everything passes
-  return stage_threshold8(stream8_ub(kth, a.qstat + q * 4, a.scal, a.metric, a.u, a.slack), a.qstat + q * 4, a.scal, a.metric, a.u, a.slack, 0);
+  return stage_threshold8(stream8_ub(kth, qs, sc, metric, u, slack), qs, sc, metric, u, slack, 0);
+}
+__device__ __forceinline__ int stream8_threshold(const Stream8Args& a, int q, int lane, int& gkth) {
+  return stream8_threshold_of(a.G + q * S8_SLOTS * S8_SLOT_STRIDE, a.k, a.qstat + q * 4, a.scal, a.metric, a.u, a.slack, lane, gkth);
 }
 
-__device__ __noinline__ void stream8_offer(const Stream8Args& a, int q, int acc, u32 row) {   // (one lane; rare)
-  if (!row_visible(a.f, row)) return;   // (only rows the result may contain bound it)
+__device__ __forceinline__ void stream8_offer(const Stream8Args& a, int q, int acc, u32 row) {   // (one lane; rare)
+  // only rows the result may contain bound it.  The deleted bitset is tested here; calls with an attribute filter or a filter program
+  // take the staged chain (evaluating them in this kernel means a function call, i.e. scratch memory for every wavefront of the pass)
+  if (a.f.deleted && ((a.f.deleted[row >> 3] >> (row & 7)) & 1)) return;
   const u32 slot = ((row * 2654435761u) >> 12) & (u32)(S8_SLOTS - 1);
   (void)__hip_atomic_fetch_max(a.G + (q * S8_SLOTS + (int)slot) * S8_SLOT_STRIDE, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -160,7 +170,10 @@ __global__ __launch_bounds__(256) void stream8_kernel(Stream8Args a) {
       a0[uu] = a.acc0[r];
     }
   };
-  // candidates of one chunk: appended (one atomic per wavefront, query and step), offered to the table where they beat its k-th slot
+  u32 mine[NQ];   // entries of this wavefront's private candidate lists (wave-uniform)
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) mine[q] = 0;
+  // candidates of one chunk: appended to the wavefront's own list, offered to the table where they beat its k-th slot
   auto test_chunk = [&](int64_t base, const int (&acc)[U][NQ]) __attribute__((always_inline)) {
     if (a.ablate & 1) {   // (keeps the loads and the arithmetic alive)
       int x = 0;
@@ -194,16 +207,11 @@ __global__ __launch_bounds__(256) void stream8_kernel(Stream8Args a) {
         const bool pass = live && v >= T[q];
         const unsigned long long mask = __ballot(pass);
         if (mask) {
-          const int cntw = __popcll(mask);
-          const int leader = __ffsll((long long)mask) - 1;
-          u32 slot0 = 0;
-          const int sub = q * S8_SUBLISTS + (int)(wid & (S8_SUBLISTS - 1));
-          if (lane == leader) slot0 = atomicAdd(a.raw_cnt + sub * S8_CNT_STRIDE, (u32)cntw);
-          slot0 = __shfl(slot0, leader);
           if (pass) {
-            const u32 slot = slot0 + (u32)__popcll(mask & ((1ull << lane) - 1ull));
-            if (slot < (u32)a.raw_cap) a.raw[(int64_t)sub * a.raw_cap + slot] = ((u64)(u32)v << 32) | (u32)row;
+            const u32 slot = mine[q] + (u32)__popcll(mask & ((1ull << lane) - 1ull));
+            if (slot < (u32)S8_WAVE_CAP) a.raw[((int64_t)q * a.waves + wid) * S8_WAVE_CAP + slot] = ((u64)(u32)v << 32) | (u32)row;
           }
+          mine[q] += (u32)__popcll(mask);
         }
         // the table (a row offered twice lands in the same slot: still distinct rows)
         if (live && v > gkth[q] && v < S8_FORCE_LIMIT) stream8_offer(a, q, v, (u32)row);
@@ -226,7 +234,7 @@ __global__ __launch_bounds__(256) void stream8_kernel(Stream8Args a) {
     // the best of the wavefront's 4 U rows (per query): one offer per wavefront, of a row that beat 15 others
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      if (q >= a.nq || (a.ablate & 1)) continue;
+      if (q >= a.nq || (a.ablate & 5)) continue;
       int bv = S8_EMPTY, br = 0;
 #pragma unroll
       for (int uu = 0; uu < U; ++uu) {
@@ -245,9 +253,23 @@ __global__ __launch_bounds__(256) void stream8_kernel(Stream8Args a) {
       if (lane == 0 && bv != S8_EMPTY) stream8_offer(a, q, bv, (u32)(first + br));
     }
   }
-  if (!(a.ablate & 1)) {
+  if (!(a.ablate & 5)) {
     __syncthreads();
-    if (wave == 0) refresh();
+    // (the offers are fire-and-forget atomics: a workgroup that gets here before k slots have been filled by anyone would test its
+    // first chunk against "everything passes"; it waits for them, a few microseconds at most - bounded, then it takes what there is)
+    if (wave == 0)
+      for (int spin = 0; spin < 48; ++spin) {
+        refresh();
+        bool ready = true;
+        for (int q = 0; q < a.nq; ++q) ready &= *reinterpret_cast<volatile int*>(&gkth_s[q]) != S8_EMPTY;
+        if (ready) break;
+        __builtin_amdgcn_s_sleep(16);
+      }
+    __syncthreads();
+  }
+  if (a.ablate & 12) {
+    __syncthreads();
+    if (threadIdx.x < 4) T_s[threadIdx.x] = gkth_s[threadIdx.x] = 2147483647;
     __syncthreads();
   }
   if (first < a.n) test_chunk(first, acc);
@@ -257,7 +279,7 @@ __global__ __launch_bounds__(256) void stream8_kernel(Stream8Args a) {
     if (base + stride < a.n) load_chunk(base + stride, xa, a0a);
     // the thresholds are read again after 2, 4, 8 chunks (the table tightens fastest at the start: a stale threshold there is what lets
     // junk into the lists) and then every 8, the four wavefronts in turn (the refresher waits for 64 cache-bypassing loads)
-    if ((it == 1 || it == 3 || (it & 7) == 7) && wave == ((it >> 1) & 3) && !(a.ablate & 3)) refresh();   // (every 8 chunks, the four wavefronts in turn: the refresher waits for 64 cache-bypassing loads)
+    if ((it == 1 || it == 3 || (it & 7) == 7) && wave == ((it >> 1) & 3) && !(a.ablate & 15)) refresh();   // (every 8 chunks, the four wavefronts in turn: the refresher waits for 64 cache-bypassing loads)
 #pragma unroll
     for (int uu = 0; uu < U; ++uu) dots(xb[uu], a0b[uu], acc[uu]);
     test_chunk(base, acc);
@@ -267,38 +289,37 @@ __global__ __launch_bounds__(256) void stream8_kernel(Stream8Args a) {
     for (int uu = 0; uu < U; ++uu) dots(xa[uu], a0a[uu], acc[uu]);
     test_chunk(base + stride, acc);
   }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+    if (q < a.nq && lane == 0) a.raw_cnt[(int64_t)q * a.waves + wid] = mine[q];
 }
 
-// one workgroup per query: candidates that still pass against the FINAL table -> the re-rank's list; the running result = empty
-__global__ __launch_bounds__(256) void stream8_select_kernel(Stream8Args a, u32* cand, int cap, u32* cnt, u64* run_keys, u32* overflow) {
-  __shared__ u32 kept, lost;
-  __shared__ int Tfin;
-  const int q = blockIdx.x;
-  if (threadIdx.x == 0) kept = lost = 0;
-  if (threadIdx.x < 64) {
-    int gm;
-    const int T = stream8_threshold(a, q, (int)threadIdx.x, gm);
-    if (threadIdx.x == 0) Tfin = T;
-  }
-  for (int i = threadIdx.x; i < a.k; i += 256) run_keys[(int64_t)q * a.k + i] = KEY_EMPTY;
-  __syncthreads();
-  const int T = Tfin;
-  // 16 threads per sub-list (the 16 counters are read at once: the kernel is a chain of dependent latencies, not work)
-  const int sub = q * S8_SUBLISTS + (int)(threadIdx.x >> 4);
-  const u32 have = a.raw_cnt[sub * S8_CNT_STRIDE];
-  const u32 n_raw = have < (u32)a.raw_cap ? have : (u32)a.raw_cap;
-  if (have > (u32)a.raw_cap) lost = 1;
-  for (u32 i = threadIdx.x & 15; i < n_raw; i += 16) {
-    const u64 e = a.raw[(int64_t)sub * a.raw_cap + i];
-    if ((int)(u32)(e >> 32) >= T) {
-      const u32 slot = atomicAdd(&kept, 1u);
-      if (slot < (u32)cap) cand[(int64_t)q * cap + slot] = (u32)e;
+// The selection step - candidates that still pass against the FINAL table go to the re-rank's list, the rest (the junk of the first
+// microseconds) is dropped without touching a row - runs as the prologue of the re-rank kernel (flat_kernels.hip, RerankArgs::s8_G): one
+// launch less in a chain of four.  `lists` = the wavefronts' private lists of this query, `counts` their lengths.
+template <int NT>
+__device__ __forceinline__ void stream8_select(int T, const u32* counts, const u64* lists, int waves, u32* cand, int cap, u32* kept, u32* lost) {
+  for (int w0 = 0; w0 < waves; w0 += 4 * NT) {   // (four wavefronts' counts per thread first: independent loads)
+    u32 have[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int w = w0 + (int)threadIdx.x + j * NT;
+      have[j] = w < waves ? counts[w] : 0u;
     }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    cnt[q] = kept;   // (> cap: the re-rank counts the query as overflowed and reads the cap entries that exist)
-    if (lost) atomicAdd(overflow, 1u);   // a raw list lost entries: the caller repeats the batch on the staged chain
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (!have[j]) continue;
+      const int w = w0 + (int)threadIdx.x + j * NT;
+      if (have[j] > (u32)S8_WAVE_CAP) *lost = 1;
+      const u32 n_raw = have[j] < (u32)S8_WAVE_CAP ? have[j] : (u32)S8_WAVE_CAP;
+      for (u32 i = 0; i < n_raw; ++i) {
+        const u64 e = lists[(int64_t)w * S8_WAVE_CAP + i];
+        if ((int)(u32)(e >> 32) >= T) {
+          const u32 slot = atomicAdd(kept, 1u);
+          if (slot < (u32)cap) cand[slot] = (u32)e;
+        }
+      }
+    }
   }
 }
 
