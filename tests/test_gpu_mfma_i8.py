@@ -106,8 +106,8 @@ def test_one_to_four_queries_are_one_pass_over_the_mirror(amd, monkeypatch, metr
     """r4 (stream8_kernel.hpp): up to 4 queries with k <= 16 are answered by ONE streaming pass over the 8-bit mirror (shared table of the
     best accumulators seen -> pass threshold from their UPPER bounds), one selection against the final table and one exact re-rank: the
     same bits as the stream scan - rows of 2 / 3 / 4 x 256 bytes, ties ordered by id, queries that ARE rows, with a deleted bitset,
-    repeated calls (the table is reset per call) - and `one_pass` in the stats says which form ran.  Larger k, more queries, an attribute
-    filter or EPS_FLAT_ONE_PASS=0 take the staged chain."""
+    and an int-column filter, repeated calls (the table is reset per call) - and `one_pass` in the stats says which form ran.  Larger k,
+    more queries, a filter program or EPS_FLAT_ONE_PASS=0 take the staged chain."""
     n = 200_003 if d < 700 else 90_000     # (a last chunk that is not full)
     X, Q = data(n, d, 171 + d), data(4, d, 172 + d)
     X[5000:5040] = X[4999]
@@ -118,23 +118,26 @@ def test_one_to_four_queries_are_one_pass_over_the_mirror(amd, monkeypatch, metr
     idc = np.arange(n, dtype=np.int32)
     ix = amd.GpuIndex(d, metric)
     ix.attach_rows(X)
-    for setup in ("plain", "deleted", "deleted + filter"):
+    for setup in ("plain", "deleted", "deleted + filter", "deleted + filter program"):
         if setup == "deleted":
             ix.set_deleted(bitset(n, range(3, n, 11)))
         if setup == "deleted + filter":
-            ix.set_int_filter(idc, ">=", 1000)     # (attribute filters take the staged chain: same bits)
+            ix.set_int_filter(idc, ">=", 1000)
+        if setup == "deleted + filter program":     # (filter programs take the staged chain: same bits)
+            ix.set_int_filter(None, ">=", 0)
+            ix.set_filter_program([("i32", 0), ("const", 1000), (">=",)], rows=idc.view(np.uint8).reshape(n, 4), stride=4)
         for nq in (1, 2, 3, 4):
             for k in (1, 10, 16):
                 for rep in range(2):
                     a = ix.search(Q[:nq], k, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
                     st = ix.stats()
-                    assert (st["one_pass"], st["main_kernel_bits"], st["overflow_queries"]) == (0 if "filter" in setup else 1, 8, 0), (setup, nq, k, st)
+                    assert (st["one_pass"], st["main_kernel_bits"], st["overflow_queries"]) == (0 if "program" in setup else 1, 8, 0), (setup, nq, k, st)
                     assert st["rerank_rows"] < nq * 2000, st     # the junk of the first microseconds is dropped before any row is read
                     same(a, ix.search(Q[:nq], k, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM), "%s nq %d k %d" % (setup, nq, k))
         a = ix.search(Q[:2], 17, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
         assert ix.stats()["one_pass"] == 0
         same(a, ix.search(Q[:2], 17, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM), "k 17")
-    ix.set_int_filter(None, ">=", 0)
+    ix.set_filter_program(None)
     monkeypatch.setenv("EPS_FLAT_ONE_PASS", "0")
     a = ix.search(Q[:1], 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
     assert ix.stats()["one_pass"] == 0

@@ -79,7 +79,7 @@ struct RerankArgs {
   // from an empty running list, and counts a lost list entry as an overflow.  s8_G == null: an ordinary re-rank
   const int* s8_G = nullptr;        // [nq][64 slots]
   const u32* s8_counts = nullptr;   // [nq][s8_waves]
-  const u64* s8_lists = nullptr;    // [nq][s8_waves][16]
+  const u64* s8_lists = nullptr;    // [nq][s8_waves][S8_WAVE_CAP]
   int s8_waves = 0;
   u32* s8_cand = nullptr;           // = cand
 };

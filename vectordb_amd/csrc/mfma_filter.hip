@@ -955,7 +955,7 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
   if (nq < 1 || nq > 4 || k < 1 || k > 16 || m.fold8 || n < 65536 || n > m.n8 || m.d_pad8 % 256 != 0 || pieces < 2 || pieces > 4) return EPS_OK;
   if (m.s8_declined_version == ix.rows_version_) return EPS_OK;
   const FilterSpec fs = ix.filter_spec();
-  if (fs.column || fs.prog) return EPS_OK;   // (attribute filters / filter programs: the staged chain; a deleted bitset is handled here)
+  if (fs.prog) return EPS_OK;   // (filter programs: the staged chain; a deleted bitset and an int-column filter are handled in the pass)
   hipStream_t s = ix.stream_;
   const int cap = std::max(4096, 64 * k);
   if (!m.qstat.reserve((size_t)4 * 16) || !m.q8.reserve((size_t)4 * m.d_pad8) || !m.cand.reserve((size_t)nq * cap * 8) || !m.cnt.reserve((size_t)(nq + 4) * 4 + 16) ||
@@ -1066,7 +1066,7 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
   if (er != hipSuccess) return ix.hip_fail(er, "one-pass flat search");
   h.overflow = hraw[0];
   memcpy(&h.total, reinterpret_cast<const char*>(hraw) + (span - 8), 8);
-  if (getenv("EPS_DEBUG")) {
+  if (getenv("EPS_DEBUG") || (h.overflow && getenv("EPS_DEBUG_ONE_PASS_OVERFLOW"))) {
     std::vector<u32> hc((size_t)S8_TABLE_WORDS + (size_t)4 * S8_MAX_WAVES);
     (void)hipMemcpy(hc.data(), m.s8g.p, hc.size() * 4, hipMemcpyDeviceToHost);
     for (int64_t q = 0; q < nq; ++q) {
@@ -1084,7 +1084,7 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
   }
   if (h.overflow) {   // (too loose a bound for this table, or a filter that leaves fewer than k rows visible: the staged chain answers)
     ix.result_finalized_ = false;
-    if (!fs.deleted && ++m.s8_overflows >= 2) m.s8_declined_version = ix.rows_version_;
+    if (!(fs.deleted || fs.column) && ++m.s8_overflows >= 2) m.s8_declined_version = ix.rows_version_;
     return EPS_OK;
   }
   m.s8_overflows = 0;

@@ -19,7 +19,7 @@
 //   pass test    a row is a candidate iff acc >= stage_threshold8(ub(k-th largest slot)) - the same arithmetic every filter stage
 //                uses, with the k-th best exact key replaced by that upper bound.  Slots only grow, a stale read only loosens the test.
 //
-// Candidates are appended as (acc, row) pairs to a PRIVATE list per wavefront (16 entries; an append through a shared counter is a
+// Candidates are appended as (acc, row) pairs to a PRIVATE list per wavefront (32 entries; an append through a shared counter is a
 // returning device-scope atomic - microseconds during which that wavefront issues no loads - and the kernel ends with its slowest
 // wavefront: the shared-counter version lost ~20 us of a 160 us pass to some 500 of them).  Early in the pass the table is loose and lets
 // junk through (every wavefront first offers ONE row of its first chunk to the empty table and only then starts testing, which bounds the
@@ -58,7 +58,7 @@ constexpr int S8_FORCE_LIMIT = 0x30000000;   // (= TQ_MAX8: accumulators at or a
 constexpr int S8_EMPTY = -2147483647 - 1;
 constexpr int S8_SLOTS = 64, S8_SLOT_STRIDE = 64;   // (stride in 4-byte words)
 constexpr int S8_TABLE_WORDS = 4 * S8_SLOTS * S8_SLOT_STRIDE;
-constexpr int S8_WAVE_CAP = 16, S8_MAX_WAVES = 8192;
+constexpr int S8_WAVE_CAP = 32, S8_MAX_WAVES = 8192;   // (32: a run of identical rows - 16 of them in one chunk - must not fill a list by itself)
 
 // upper bound of the exact fp32 distance of a row whose accumulator is `acc` (see the header; mirrors stage_threshold8 term by term)
 __device__ __forceinline__ float stream8_ub(int acc, const float* qs, const float* sc, int metric, float u, float slack) {
@@ -92,9 +92,12 @@ __device__ __forceinline__ int stream8_threshold(const Stream8Args& a, int q, in
 }
 
 __device__ __forceinline__ void stream8_offer(const Stream8Args& a, int q, int acc, u32 row) {   // (one lane; rare)
-  // only rows the result may contain bound it.  The deleted bitset is tested here; calls with an attribute filter or a filter program
-  // take the staged chain (evaluating them in this kernel means a function call, i.e. scratch memory for every wavefront of the pass)
-  if (a.f.deleted && ((a.f.deleted[row >> 3] >> (row & 7)) & 1)) return;
+  // only rows the result may contain bound it.  The deleted bitset and the `int column <op> constant` filter are tested here (straight
+  // code); calls with a filter PROGRAM take the staged chain (its evaluator in this kernel means a function call, i.e. scratch memory
+  // for every wavefront of the pass)
+  FilterSpec f = a.f;
+  f.prog = nullptr;
+  if (!row_visible(f, row)) return;
   const u32 slot = ((row * 2654435761u) >> 12) & (u32)(S8_SLOTS - 1);
   (void)__hip_atomic_fetch_max(a.G + (q * S8_SLOTS + (int)slot) * S8_SLOT_STRIDE, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
