@@ -147,6 +147,27 @@ def test_one_to_four_queries_are_one_pass_over_the_mirror(amd, monkeypatch, metr
     ix.close()
 
 
+def test_auto_builds_the_mirror_for_single_query_traffic_after_a_few_calls(amd):
+    """FLAT_AUTO on a table without a mirror: single queries run the fp32 stream scan (no HBM spent on a mirror for a caller that may ask
+    once), and from the 17th call on the same rows the 8-bit mirror is built and the one-pass search answers - same bits either way;
+    re-attaching rows starts the count again."""
+    n, d = 120_000, 256
+    X, Q = data(n, d, 310), data(40, d, 311)
+    ix = amd.GpuIndex(d, 0)
+    ix.attach_rows(X)
+    ref = ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
+    for attach in range(2):
+        seen = []
+        for i in range(24):
+            r = ix.search(Q[i:i + 1], 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_AUTO)
+            st = ix.stats()
+            seen.append((st["main_kernel_bits"], st["one_pass"]))
+            assert np.array_equal(r[0][0], ref[0][i]) and np.array_equal(r[1][0], ref[1][i]), (attach, i)
+        assert seen[:16] == [(32, 0)] * 16 and seen[17:] == [(8, 1)] * 7, seen
+        ix.attach_rows(X)
+    ix.close()
+
+
 def test_one_pass_search_survives_adversarial_order_and_selective_deletion(amd):
     """rows sorted from far to near (the table of best accumulators is always behind: nearly every row passes -> the raw list overflows -> the
     staged chain answers), 99.9 % of the rows deleted (only visible rows may enter the table), fewer visible rows than k: the answer is

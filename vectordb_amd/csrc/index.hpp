@@ -131,6 +131,10 @@ class Index : public IndexBase {
   bool rows_owned_ = false;
   int64_t n_rows_ = 0;
   int64_t rows_version_ = 0;  // bumped on attach/append (invalidates the fp16 mirror)
+  // FLAT_AUTO, single-query traffic on a table without a mirror: calls seen on this rows version (flat_mfma_profitable: after a few of
+  // them the 8-bit mirror is worth its HBM - the one-pass search answers such a call in a third of the stream scan's time)
+  mutable int64_t small_calls_version_ = -1;
+  mutable int small_calls_ = 0;
   int64_t scan_limit_ = -1;   // >= 0: flat engines scan rows [0, scan_limit_) only (graph build over a prefix)
 
   int64_t id_base_ = 0, id_stride_ = 1;

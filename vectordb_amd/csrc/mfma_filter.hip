@@ -102,6 +102,7 @@ struct HalfMirror {
   DevBuf s8g, s8raw;            // table slots (S8_TABLE_WORDS) + per-wavefront candidate counts;  u64 [nq][waves][S8_WAVE_CAP]
   int64_t s8_declined_version = -1;   // rows version on which the one-pass form overflowed twice in a row (the staged chain serves it)
   int s8_overflows = 0;
+  int s8_cus = 0;               // CUs of the device (grid of the one-pass kernel)
   int64_t extended_rows8 = 0;
   int64_t version = -1;
   int64_t n = 0, n_pad = 0;
@@ -933,14 +934,26 @@ bool flat_mfma_profitable(const Index& ix, int64_t nq, int k) {
   const bool have8 = known8 && m->i8_ok;
   const bool can16 = !have16 || m->fp16_range_ok;
   if (known8 && !have8 && !can16) return false;                 // neither mirror can serve this table
-  if (nq < 8 && !have8 && !have16) return false;                // do not spend HBM on a mirror for single-query traffic alone
+  // up to 4 queries, k <= 16, rows of <= 1024 bytes: the one-pass search (stream8_kernel.hpp) - one pass over d_pad8 + 4 bytes per row
+  const bool one_pass_shape = nq <= 4 && k <= 16 && ix.dim_ <= 1024 && !(getenv("EPS_FLAT_ONE_PASS") && atoi(getenv("EPS_FLAT_ONE_PASS")) == 0);
+  if (nq < 8 && !have8 && !have16) {
+    // single-query traffic alone does not get a mirror (n x d bytes of HBM + a pass over the table to build it) at once: r4, after 16 such
+    // calls on the same rows it does, where the one-pass search can use it (0.20 ms instead of 0.62 ms per call at 1M x 768)
+    if (ix.small_calls_version_ != ix.rows_version_) {
+      ix.small_calls_version_ = ix.rows_version_;
+      ix.small_calls_ = 0;
+    }
+    if (!one_pass_shape || known8 || ++ix.small_calls_ <= 16) return false;
+  }
   const bool use8 = have8 || !known8;                            // (an 8-bit mirror would be built first)
   const double rows = (double)ix.n_rows_, d = (double)ix.dim_;
   const double op_bytes = use8 ? std::max(512.0, std::ceil(d / 256.0) * 256.0) : std::ceil(d / 128.0) * 256.0;   // operand bytes per row
   const double rate = use8 ? 2.0e15 : 1.2e15;                    // matrix rate the filter kernel reaches
   const double dp = use8 ? op_bytes : op_bytes / 2.0;
   const double stream_s = std::ceil((double)nq / 4.0) * rows * d * 4.0 / 6.0e12 + 0.2e-3;
-  const double filter_s = 0.35e-3 + std::max(rows * op_bytes / 5.0e12, 2.0 * 128.0 * std::ceil((double)nq / 128.0) * rows * dp / rate);
+  const double filter_s = (use8 && one_pass_shape && !(have8 && m->fold8))
+                              ? 0.07e-3 + rows * (std::ceil(d / 256.0) * 256.0 + 4.0) / 5.7e12
+                              : 0.35e-3 + std::max(rows * op_bytes / 5.0e12, 2.0 * 128.0 * std::ceil((double)nq / 128.0) * rows * dp / rate);
   return filter_s < stream_s;
 }
 
@@ -991,11 +1004,11 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
   a.raw = m.s8raw.as<u64>();
   a.f = fs;
   a.ablate = getenv("EPS_S8_ABLATE") ? atoi(getenv("EPS_S8_ABLATE")) : 0;   // (lab)
-  int cus = m.num_cus;
-  if (!cus) {
+  if (!m.s8_cus) {   // (once per mirror: the query costs more than the search)
     hipDeviceProp_t prop;
-    cus = hipGetDeviceProperties(&prop, ix.device_) == hipSuccess ? prop.multiProcessorCount : 256;
+    m.s8_cus = hipGetDeviceProperties(&prop, ix.device_) == hipSuccess ? std::max(8, prop.multiProcessorCount) : 256;
   }
+  const int cus = m.s8_cus;
   static const int wg_per_cu = getenv("EPS_S8_WG_PER_CU") ? std::max(1, atoi(getenv("EPS_S8_WG_PER_CU"))) : 2;
   const dim3 grid((unsigned)std::min<int64_t>(std::min<int64_t>((int64_t)cus * wg_per_cu, S8_MAX_WAVES / 4), (n + 63) / 64)), block(256);
   a.waves = (int)grid.x * 4;
