@@ -111,12 +111,8 @@ template <> struct V7Op<true> {
 #ifndef EPS_V7_VI
 #define EPS_V7_VI 7
 #endif
-#ifndef EPS_V7_EARLYINIT
-#define EPS_V7_EARLYINIT 0   // lab: next tile's start values loaded inside the epilogue (see the kernel; measured no gain, profiles/r4_flat_ab_epilogue_late.txt)
-#endif
-#ifndef EPS_V7_FLUSHFLAG
-#define EPS_V7_FLUSHFLAG 0   // lab: the pending list looked at only after a tile that appended to it (measured no gain, same file)
-#endif
+// (tried and dropped, profiles/r4_flat_ab_epilogue_late.txt: the next tile's start values loaded at the end of a row block's own epilogue
+// iteration; the pending-list flush check only after a tile that appended - no measurable difference either way)
 #ifndef EPS_V7_GROUP
 #define EPS_V7_GROUP 2       // row blocks per epilogue test: the maxima of GROUP x JQ blocks share one compare + branch (see the kernel)
 #endif
@@ -774,10 +770,7 @@ __global__ __launch_bounds__(256, NRB == 8 ? 1 : 2) void mfma_filter_kernel_v7(F
       }
     }
     if (t + 1 < ntile) issue_base(ri_n, (int)((t + 1) & 1));
-    // acc[i][0] <- the pre-scaled |x|^2 column (8-bit: the rows' start values) of the tile.  r4 (EPS_V7_EARLYINIT): the row blocks whose
-    // accumulators live in arch VGPRs get the NEXT tile's start values at the end of their own epilogue iteration - the LDS reads go
-    // straight into the registers the block just vacated and land under the remaining blocks' tests - so the tile head only initialises the
-    // first tile and the blocks in the accumulator file (there hipcc would go through VGPRs + v_accvgpr_write).
+    // acc[i][0] <- the pre-scaled |x|^2 column (8-bit: the rows' start values) of the tile
     auto init_block = [&](int i, int par, int kh4) __attribute__((always_inline)) {   // (i: a constant after unrolling)
       const float* bl0 = base_lds + par * 256;
       const int rbase = i * 32 + kh4;
@@ -801,7 +794,7 @@ __global__ __launch_bounds__(256, NRB == 8 ? 1 : 2) void mfma_filter_kernel_v7(F
     {
       const int kh4 = (int)(lane16 >> 7) & 4;     // = 4 * khalf
 #define EPS_INIT_AT_HEAD(I_)                                                                        \
-  if (!EPS_V7_EARLYINIT || t == 0 || (I_) >= VI) {                                           \
+  {                                                                                                 \
     init_block((I_), (int)(t & 1), kh4);                                                            \
     __builtin_amdgcn_sched_barrier(0); /* one row block at a time: hoisting all 64 reads costs spills */ \
   }
@@ -872,7 +865,6 @@ __global__ __launch_bounds__(256, NRB == 8 ? 1 : 2) void mfma_filter_kernel_v7(F
     // taken on the common path; only a tile in which something passed (one in six at the last stage of a 10M-row scan) runs the
     // per-block code, and only it can have filled the pending list, so the flush check moves there too.
     bool tile_hit = true;
-    bool tile_appended = false;   // (wave-uniform: set where a block passed) the pending list can only have grown in such a tile
 #if EPS_V7_TILE
     if (I8 && MODE != FM_DENSE) {
       bool h = false;
@@ -987,7 +979,6 @@ __global__ __launch_bounds__(256, NRB == 8 ? 1 : 2) void mfma_filter_kernel_v7(F
 #endif
           // (rare) everything the hit path needs is derived behind this opaque copy of the lane id, or hipcc hoists the
           // address arithmetic of all 16 blocks into the common path
-          tile_appended = true;
           int l31h = l31e, rbh = rbase;
           asm volatile("" : "+v"(l31h), "+v"(rbh));
           const int64_t qq = qbase + j * 32 + l31h;
@@ -1050,18 +1041,9 @@ __global__ __launch_bounds__(256, NRB == 8 ? 1 : 2) void mfma_filter_kernel_v7(F
       }
     }
     }   // group_hit
-#if EPS_V7_EARLYINIT
-    // (the group's row blocks are done with: their first accumulators take the next tile's start values now)
-#pragma unroll
-    for (int ii = 0; ii < EPS_V7_GROUP; ++ii)
-      if (i0 + ii < VI && t + 1 < ntile) {
-        __builtin_amdgcn_sched_barrier(0);
-        init_block(i0 + ii, (int)((t + 1) & 1), kh4e);
-      }
-#endif
     }
 #if !(defined(EPS_V7_ABL) && (EPS_V7_ABL & 4))   // (lab ablation: no flush check)
-    if (MODE != FM_DENSE && (!EPS_V7_FLUSHFLAG || tile_appended)) {
+    if (MODE != FM_DENSE) {
       if (*wcnt_lds >= (u32)(V7_CAPW / 2)) flush();
     }
 #endif
