@@ -20,7 +20,7 @@ Q = torch.rand((4096, d), generator=g, device="cuda")
 ix = amd.GpuIndex(d, 0).use_torch_stream()
 ix.attach_rows(X)
 out = []
-for nq in (1, 4, 8, 16, 32, 64, 128, 256):
+for nq in (1, 2, 4, 5, 8, 16, 32, 64, 128, 256):
     o = (torch.empty((nq, 10), dtype=torch.int64, device="cuda"), torch.empty((nq, 10), device="cuda"), torch.empty((nq,), dtype=torch.int32, device="cuda"))
     ix.search(Q[:nq], 10, out=o, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
     torch.cuda.synchronize()
