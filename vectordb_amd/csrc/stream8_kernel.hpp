@@ -4,7 +4,7 @@
 // single-query call was 9 dependent launches (query prep, seed pass, seed selection, seed re-rank, 3 x (filter stage + re-rank)), 0.33 ms
 // of which only the last stage's 0.12 ms was the unavoidable pass over the mirror (profiles/r4_single_query_latency.txt).  Here the pass
 // IS the call: every wavefront streams its share of the mirror (HBM-bound: d_pad8 bytes + 4 per row, v_dot4_i32_i8, no matrix cores),
-// and what the stages were for - a pass threshold that tightens as the scan proceeds - lives in a 16-entry table per query in device
+// and what the stages were for - a pass threshold that tightens as the scan proceeds - lives in a 64-slot table per query in device
 // memory that all wavefronts share:
 //
 //   G[q][0..64)  slot j = the largest accumulator (= approximate key, larger = closer) any visible row with hash(row) mod 64 = j has
@@ -22,10 +22,10 @@
 // Candidates are appended as (acc, row) pairs to a PRIVATE list per wavefront (32 entries; an append through a shared counter is a
 // returning device-scope atomic - microseconds during which that wavefront issues no loads - and the kernel ends with its slowest
 // wavefront: the shared-counter version lost ~20 us of a 160 us pass to some 500 of them).  Early in the pass the table is loose and lets
-// junk through (every wavefront first offers ONE row of its first chunk to the empty table and only then starts testing, which bounds the
+// junk through (every wavefront first offers the BEST row of its first chunk to the empty table and only then starts testing, which bounds the
 // junk to a few hundred entries); the selection step (below) drops it against the FINAL table without touching a
 // row, and the ordinary re-rank kernel (flat_kernels.hip) computes the survivors' exact fp32 distances, applies the deleted bitset /
-// filter, and writes the caller-visible result.  Overflow of either list is reported through the re-rank's overflow counter and the
+// int-column filter (calls with a compiled filter PROGRAM take the staged chain), and writes the caller-visible result.  Overflow of either list is reported through the re-rank's overflow counter and the
 // caller repeats the batch on the staged chain.  Rows with a FORCED start value (mfma_filter.hip: ACC_FORCE) are always candidates and
 // never enter the table.
 #pragma once
@@ -44,9 +44,9 @@ struct Stream8Args {
   const float* scal;       // the mirror's maxima (HalfMirror::scal8)
   int nq, k, metric;
   float u, slack;
-  int* G;                  // [4][64] slots, S8_SLOT_STRIDE ints apart
-  u32* raw_cnt;            // [4][waves]: entries every wavefront of the grid found (written once, when it ends)
-  u64* raw;                // [4][waves][S8_WAVE_CAP]: (acc << 32) | row - a private list per wavefront: no atomic, nothing to wait for
+  int* G;                  // [nq][64] slots, S8_SLOT_STRIDE ints apart
+  u32* raw_cnt;            // [nq][waves]: entries every wavefront of the grid found (written once, when it ends)
+  u64* raw;                // [nq][waves][S8_WAVE_CAP]: (acc << 32) | row - a private list per wavefront: no atomic, nothing to wait for
   int waves;               // wavefronts of the grid (<= S8_MAX_WAVES)
   int ablate;              // lab (EPS_S8_ABLATE; results are wrong): 1 = no table, no test - the bare stream + dot products; 2 = no periodic
                            // re-read of the table; 4 = no start-up (offer, barriers, first read), tests against "nothing passes"; 8 = the
