@@ -46,6 +46,75 @@ TRAFFIC_REF = {
 }
 
 
+def power_leg(torch, step, queries, seconds, device_index):
+    """The same step, back to back for `seconds`, while a thread samples the GPU's shader clock and socket power (amdsmi, in-process):
+    what the dominant kernel's roofline fraction has to be read against on a board that runs it at its power limit.  Outside the timed
+    region of the contract line; None where the SMI library cannot be used."""
+    import threading
+    try:
+        import amdsmi
+        amdsmi.amdsmi_init()
+        h = amdsmi.amdsmi_get_processor_handles()[device_index]
+    except Exception as e:   # noqa: BLE001
+        return {"failed": repr(e)[:200]}
+    clk, pw, stop = [], [], threading.Event()
+
+    def num(v):
+        try:
+            return float(v)
+        except Exception:   # noqa: BLE001
+            return None
+
+    def sample():
+        while not stop.is_set():
+            try:
+                c = num(amdsmi.amdsmi_get_clock_info(h, amdsmi.AmdSmiClkType.GFX).get("clk"))
+                pi = amdsmi.amdsmi_get_power_info(h)
+                w = num(pi.get("current_socket_power"))
+                if w is None or w <= 0:
+                    w = num(pi.get("average_socket_power"))
+                if c:
+                    clk.append(c)
+                if w:
+                    pw.append(w)
+            except Exception:   # noqa: BLE001
+                pass
+            stop.wait(0.02)
+    out = {}
+    try:
+        try:
+            lim = num(amdsmi.amdsmi_get_power_info(h).get("power_limit"))
+            out["power_limit_w"] = (lim / 1e6 if lim and lim > 1e5 else lim)   # (reported in microwatts by this library version)
+        except Exception:   # noqa: BLE001
+            pass
+        th = threading.Thread(target=sample, daemon=True)
+        torch.cuda.synchronize()
+        th.start()
+        t0 = time.perf_counter()
+        steps = 0
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(10):
+                step(queries[steps % len(queries)])
+                steps += 1
+            torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        stop.set()
+        th.join(1.0)
+        half = len(clk) // 2     # (the second half of the run: the clock has settled under the cap by then)
+        out.update({"steps": steps, "seconds": el, "ms_per_step_sustained": 1e3 * el / steps, "samples": len(clk),
+                    "sclk_mhz_under_load": float(np.median(clk[half:])) if clk else None,
+                    "socket_power_w_under_load": float(np.median(pw[len(pw) // 2:])) if pw else None})
+    except Exception as e:   # noqa: BLE001
+        out["failed"] = repr(e)[:200]
+    finally:
+        stop.set()
+        try:
+            amdsmi.amdsmi_shut_down()
+        except Exception:   # noqa: BLE001
+            pass
+    return out
+
+
 def traffic_ref(key):
     import hashlib
     r = dict(TRAFFIC_REF[key])
@@ -86,6 +155,8 @@ def parse():
     ap.add_argument("--recall-queries", type=int, default=1024)
     ap.add_argument("--graph-rows", type=int, default=1_000_000, help="rows of the secondary traversal measurement (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline legs (0 = skip)")
+    ap.add_argument("--power-seconds", type=float, default=2.0, help="N = 1: after the timed region the same step runs back to back for this long while the shader clock and "
+                    "socket power are sampled (roofline.under_load; 0 = skip)")
     ap.add_argument("--scale", default="rows", choices=["queries", "rows"])
     ap.add_argument("--inproc", action="store_true", help="N > 1 in ONE process: eps_index_create_sharded over devices 0..N-1 (the form the single-process "
                                                           "reference DBMS uses), per-shard lists merged on the caller's device; no torch.distributed")
@@ -681,6 +752,8 @@ def main():
     main_ms = ix.kernel_times(64)[-args.steps:]
     st = ix.stats()
     got_i = out_i.clone()
+    # clock and power under this workload (N = 1, after the timed region): the filter kernel runs against the board's power limit
+    power = power_leg(torch, step, queries, args.power_seconds, local_rank) if (world == 1 and rank == 0 and args.power_seconds > 0) else None
 
     # ---- recall@10 of the last batch: exact ground truth from the fp32 direct-form stream scan (an independent code path
     # of the library, itself pinned to the oracle by the tests) for --recall-queries queries, and a torch fp32 scan for 16
@@ -813,6 +886,14 @@ def main():
             roof["sustained_peak_measured"] = sus
             roof["frac_of_sustained"] = roof["achieved"] / sus
             roof["fp16_equivalent"] = {"what": "the same algorithmic flops against the fp16 dense MFMA peak (the r2 line's roof)", "frac": roof["achieved"] / MFMA_F16_PEAK_TF}
+        if power is not None:
+            roof["under_load"] = power
+            if used_mfma and args.mode == "flat" and power.get("sclk_mhz_under_load") and roof.get("operand_bits") == 8:
+                # the dense peak assumes the 2.4 GHz boost clock; what the matrix pipe could deliver at the clock the board sustains
+                # under THIS kernel's power draw (nothing else about the kernel changed), and the step's work against it
+                at_clk = MFMA_I8_PEAK_TOPS * power["sclk_mhz_under_load"] / 2400.0
+                roof["under_load"]["peak_at_that_clock"] = at_clk
+                roof["under_load"]["whole_step_frac_of_peak_at_that_clock"] = 2.0 * b * n * d / (power["ms_per_step_sustained"] * 1e-3) / 1e12 / at_clk
         roof["kernel_ms_per_step"] = kernel_ms * (b / kq if used_mfma and args.mode == "flat" else 1.0)   # all slices of a step
         roof["kernel_ms_per_launch"] = kernel_ms
         roof["timed_launches"] = len(main_ms)
