@@ -135,8 +135,8 @@ MFMA_I8_SUSTAINED_TOPS = 3424.0  # measured: v_mfma_i32_32x32x32_i8 alone on byt
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rows", type=int, default=10_000_000, help="rows per GPU (--scale rows) or in total (--scale queries)")
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--batch", type=int, default=1024)
