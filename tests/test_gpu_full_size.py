@@ -91,6 +91,12 @@ def test_configs2_10M_x_768_L2_batch_1024_matches_the_reference_bruteforce(amd, 
     assert all(len(set(r.tolist())) == K for r in ids)
     tie = np.diff(dd, axis=1) == 0
     assert (np.diff(ids, axis=1)[tie] > 0).all()          # equal distances are ordered by id (Candidate::operator<)
+    # r4: the same table asked ONE vector at a time (what TableMVP::Search does; the one-pass search of stream8_kernel.hpp at full size, or
+    # the staged chain where it hands over): the batch's answers, bit for bit, hence the reference's
+    for q in range(3):
+        t1 = {**t, "Q": t["Q"][q:q + 1]}
+        i1, d1, c1, _ = _search(amd, t1, ix, 1, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_AUTO)
+        assert np.array_equal(i1[0], ids[q]) and np.array_equal(d1[0], dd[q]) and c1[0] == K, q
     ix.close()
 
 
