@@ -63,7 +63,10 @@ def test_lockstep_workers_match_oracle(amd, oracle, monkeypatch, T, L, I, prefil
 
 
 @pytest.mark.parametrize("metric", [0, 1, 2])
-@pytest.mark.parametrize("n,d,T,L", [(20000, 128, 1, 500), (20000, 100, 4, 200), (6000, 768, 4, 500), (6000, 1030, 2, 300), (20000, 19, 1, 64)])
+@pytest.mark.parametrize("n,d,T,L", [(20000, 128, 1, 500), (20000, 100, 4, 200), (6000, 768, 4, 500), (6000, 1030, 2, 300), (20000, 19, 1, 64),
+                                     # r5, the fused distance phase (one wavefront per fp32 row: d > 128, d % 4 == 0): rows shorter than one
+                                     # round of mirror pieces, exactly one, and rows that need more than three fp32 pieces per lane
+                                     (8000, 132, 2, 200), (6000, 256, 4, 300), (6000, 768, 1, 300), (5000, 772, 3, 200), (4000, 1536, 4, 200)])
 def test_prefilter_is_invisible(amd, monkeypatch, n, d, T, L, metric):
     """Step d0 (traverse2_kernel.hpp): a neighbour is dropped on its 8-bit mirror row only when that row PROVES dist > bound, so
     the walk - queue contents, distances, evaluation and expansion counts - is the same bit for bit with the prefilter off and
