@@ -379,11 +379,11 @@ def config_c2(amd, torch, args, X, qlast, dev, stream, local_rank, cpu, graph_in
     gpu["mfma_i8"]["one_pass"] = int(ix.stats().get("one_pass", 0))   # r4: 1 = ONE streaming pass over the 8-bit mirror + one re-rank (stream8_kernel)
     if gpu["mfma_i8"]["one_pass"]:
         # the pass itself against the HBM roofline: timed in a second run (an event pair around it costs the untimed call ~10 us)
-        os.environ["EPS_ONE_PASS_TIMED"] = "1"
+        amd.set_tuning("EPS_ONE_PASS_TIMED", "1")
         try:
             timed, _ = latency(ix, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
         finally:
-            del os.environ["EPS_ONE_PASS_TIMED"]
+            amd.set_tuning("EPS_ONE_PASS_TIMED", None)
         if timed["main_kernel_ms"]:
             row_bytes = (d + 255) // 256 * 256 + 4          # the mirror's row pitch + the row's int32 start value
             ach = n1 * row_bytes / (timed["main_kernel_ms"] * 1e-3) / 1e9

@@ -320,6 +320,19 @@ int32_t eps_merge_topk(const float* dist, const int64_t* ids, int32_t shards, in
 int32_t eps_merge_topk_packed(const void* gathered, int64_t shard_stride_bytes, int64_t dist_offset_bytes, int32_t shards,
                               int64_t nq, int32_t k, float* out_dist, int64_t* out_ids, int32_t device, void* hip_stream);
 
+/* Engine-selection switches.  The library reads NO environment variable: what used to be lab switches are entries of one
+ * process-wide table that only this call writes (name, value as text; value == NULL removes the entry; name == NULL empties
+ * the table).  No entry changes a result - they pick between engines that return the same bits (tests/ run every answer
+ * through both sides of each) or turn diagnostics on:
+ *   EPS_DEBUG (stage log on stderr), EPS_TRV_PROF (traversal phase profile on stderr),
+ *   EPS_TRV_PREFILTER 0|1 (8-bit lower-bound test of the traversal), EPS_TRV_WAVES 4|8|16, EPS_TRV_PER_CU, EPS_TRV_LDS_KB,
+ *   EPS_FLAT_ONE_PASS 0|1, EPS_ONE_PASS_TIMED, EPS_S8_WG_PER_CU, EPS_RERANK_SPLIT, EPS_MFMA_BITS 8|16, EPS_MFMA_MAX_BATCH,
+ *   EPS_MFMA_PROBE, EPS_MFMA_SEED, EPS_MFMA_GROUPSYNC, EPS_MFMA_SYNC_SHIFT, EPS_MFMA_STAGES, EPS_MFMA_KERNEL, EPS_MFMA_NARROW,
+ *   EPS_MFMA_TWO_PER_CU, EPS_MFMA_FOLD, EPS_MFMA_MANTISSA, EPS_BUILD_BLOCK, EPS_BUILD_VISITED, EPS_BUILD_PREFILTER.
+ * Switches that make answers WRONG on purpose (kernel ablations for profiling) exist only in a lab build (-DEPS_LAB), which
+ * also falls back to the environment for names the table does not hold.  Returns EPS_OK. */
+int32_t eps_set_tuning(const char* name, const char* value);
+
 #ifdef __cplusplus
 }
 #endif

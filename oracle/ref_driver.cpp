@@ -29,7 +29,6 @@
 #include "db/execution/vec_search_executor.hpp"
 #include "db/index/index.hpp"
 #include "db/vector.hpp"
-#ifndef EPS_DROPIN  // the drop-in build (dropin/Makefile) has no reference-internal executor/index code to expose
 #include "db/index/distances.hpp"
 #include "db/index/knn/knn.hpp"
 #include "db/index/nsg/nsg.hpp"
@@ -38,13 +37,11 @@
 #include "utils/concurrent_bitset.hpp"
 
 namespace vectordb { namespace engine { namespace index { extern unsigned int seed; } } }  // nsg.cpp:19
-#endif
 
 using vectordb::engine::ANNGraphSegment;
 using vectordb::engine::execution::VecSearchExecutor;
 namespace meta = vectordb::engine::meta;
 
-#ifndef EPS_DROPIN
 namespace {
 meta::MetricType ToMetric(int m) {
   // 0 = EUCLIDEAN, 1 = COSINE, 2 = DOT_PRODUCT  (same numbering as include/epsilla_gfx950.h)
@@ -406,197 +403,5 @@ double ref_pool_search(void* graph, float* rows, int64_t d, int metric, int E, i
   return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
-#endif  // !EPS_DROPIN
-#ifdef EPS_DROPIN
-#include "epsdrop/search_batch.hpp"
-extern "C" {
-#endif
-
-// ---------------------------------------------------------------- DBServer (JSON level)
-void ref_config(int intra_query_threads, int search_queue_size, int rebuild_threads, int prefilter, int executors) {
-  auto& c = vectordb::globalConfig;
-  if (intra_query_threads > 0) c.setIntraQueryThreads(intra_query_threads);
-  if (search_queue_size > 0) c.setSearchQueueSize(search_queue_size);
-  if (rebuild_threads > 0) c.setRebuildThreads(rebuild_threads);
-  if (prefilter >= 0) c.PreFilter.store(prefilter != 0);
-  if (executors > 0) c.setNumExecutorPerField(executors);
-}
-// DBServer::is_leader_ is not initialised by the constructor; the reference's own tests call
-// SetLeader(true) before LoadDB whenever they Rebuild (test/engine/db/db_server.cpp:810,946,1088).
-void* ref_db_new() {
-  auto* s = new vectordb::engine::DBServer();
-  s->SetLeader(true);
-  return s;
-}
-void ref_db_set_leader(void* h, int leader) { static_cast<vectordb::engine::DBServer*>(h)->SetLeader(leader != 0); }
-void ref_db_free(void* h) { delete static_cast<vectordb::engine::DBServer*>(h); }
-int ref_db_load(void* h, const char* name, const char* path, int64_t scale, int wal) {
-  std::unordered_map<std::string, std::string> headers;
-  return static_cast<vectordb::engine::DBServer*>(h)->LoadDB(name, path, scale, wal != 0, headers).code();
-}
-int ref_db_create_table(void* h, const char* db, const char* schema_json) {
-  size_t id = 0;
-  return static_cast<vectordb::engine::DBServer*>(h)->CreateTable(db, std::string(schema_json), id).code();
-}
-int ref_db_insert(void* h, const char* db, const char* table, const char* records_json) {
-  vectordb::Json j;
-  if (!j.LoadFromString(records_json)) return -1;
-  std::unordered_map<std::string, std::string> headers;
-  return static_cast<vectordb::engine::DBServer*>(h)->Insert(db, table, j, headers).code();
-}
-int ref_db_delete(void* h, const char* db, const char* table, const char* pk_json, const char* filter) {
-  vectordb::Json j;
-  if (!j.LoadFromString(pk_json)) return -1;
-  return static_cast<vectordb::engine::DBServer*>(h)->Delete(db, table, j, filter).code();
-}
-int ref_db_rebuild(void* h) {
-  try {
-    return static_cast<vectordb::engine::DBServer*>(h)->Rebuild().code();
-  } catch (const std::exception& e) {
-    fprintf(stderr, "Rebuild failed: %s\n", e.what());
-    return vectordb::INFRA_UNEXPECTED_ERROR;
-  }
-}
-int ref_db_swap_executors(void* h) { return static_cast<vectordb::engine::DBServer*>(h)->SwapExecutors().code(); }
-// fields_csv: comma separated response fields.  Result JSON is written into out (NUL terminated,
-// truncated to cap).  Returns the Status code.
-int ref_db_search(void* h, const char* db, const char* table, const char* field, const char* fields_csv, float* q,
-                  int64_t d, int64_t limit, const char* filter, int with_distance, char* out, int64_t cap) {
-  std::string f(field);
-  std::vector<std::string> fields;
-  std::string cur;
-  for (const char* p = fields_csv; *p; ++p) {
-    if (*p == ',') {
-      if (!cur.empty()) fields.push_back(cur);
-      cur.clear();
-    } else {
-      cur.push_back(*p);
-    }
-  }
-  if (!cur.empty()) fields.push_back(cur);
-  vectordb::Json result, facets_cfg, facets;
-  facets_cfg.LoadFromString("[]");
-  vectordb::Status st;
-  std::string s;
-  try {
-    st = static_cast<vectordb::engine::DBServer*>(h)->Search(db, table, f, fields, d, q, limit, result, filter,
-                                                             with_distance != 0, facets_cfg, facets);
-    s = st.ok() ? result.DumpToString() : st.message();
-  } catch (const std::exception& e) {  // the gfx950 executor throws on infrastructure failures (no device)
-    st = vectordb::Status(vectordb::INFRA_UNEXPECTED_ERROR, e.what());
-    s = e.what();
-  }
-  if (cap > 0) {
-    size_t n = std::min<size_t>(s.size(), (size_t)cap - 1);
-    memcpy(out, s.data(), n);
-    out[n] = 0;
-  }
-  return st.code();
-}
-
-#ifdef EPS_DROPIN
-// The drop-in's C++-level batched entry (include/epsdrop/search_batch.hpp): nq vectors, ONE device batch; result = JSON array of nq
-// arrays of records.  Only in the drop-in build (the reference has no batched entry to compare with: the test compares it with nq
-// ref_db_search calls on both builds).
-int ref_db_search_batch(void* h, const char* db, const char* table, const char* field, const char* fields_csv, float* q, int64_t nq,
-                        int64_t d, int64_t limit, const char* filter, int with_distance, char* out, int64_t cap) {
-  std::vector<std::string> fields;
-  std::string cur;
-  for (const char* p = fields_csv; *p; ++p) {
-    if (*p == ',') {
-      if (!cur.empty()) fields.push_back(cur);
-      cur.clear();
-    } else {
-      cur.push_back(*p);
-    }
-  }
-  if (!cur.empty()) fields.push_back(cur);
-  vectordb::Json result;
-  vectordb::Status st = epsdrop::SearchBatch(*static_cast<vectordb::engine::DBServer*>(h), db, table, field, fields, q, nq, d, limit, result, filter,
-                                             with_distance != 0);
-  const std::string s = st.ok() ? result.DumpToString() : st.message();
-  if (cap > 0) {
-    size_t n = std::min<size_t>(s.size(), (size_t)cap - 1);
-    memcpy(out, s.data(), n);
-    out[n] = 0;
-  }
-  return st.code();
-}
-#endif
-
-// DBServer::Project (the "get" path: VecSearchExecutor::SearchByAttribute underneath, no vector arithmetic).
-int ref_db_get(void* h, const char* db, const char* table, const char* fields_csv, const char* pk_json, const char* filter,
-               int64_t skip, int64_t limit, char* out, int64_t cap) {
-  std::vector<std::string> fields;
-  std::string cur;
-  for (const char* p = fields_csv; *p; ++p) {
-    if (*p == ',') {
-      if (!cur.empty()) fields.push_back(cur);
-      cur.clear();
-    } else {
-      cur.push_back(*p);
-    }
-  }
-  if (!cur.empty()) fields.push_back(cur);
-  vectordb::Json pks, result, facets_cfg, facets;
-  pks.LoadFromString(pk_json && *pk_json ? pk_json : "[]");
-  facets_cfg.LoadFromString("[]");
-  vectordb::Status st;
-  std::string s;
-  try {
-    st = static_cast<vectordb::engine::DBServer*>(h)->Project(db, table, fields, pks, filter, skip, limit, result, facets_cfg, facets);
-    s = st.ok() ? result.DumpToString() : st.message();
-  } catch (const std::exception& e) {
-    st = vectordb::Status(vectordb::INFRA_UNEXPECTED_ERROR, e.what());
-    s = e.what();
-  }
-  if (cap > 0) {
-    size_t n = std::min<size_t>(s.size(), (size_t)cap - 1);
-    memcpy(out, s.data(), n);
-    out[n] = 0;
-  }
-  return st.code();
-}
-
-// nq single-vector DBServer::Search calls issued from `threads` client threads (what concurrent REST requests do);
-// first_ids[q] = "ID" of the best hit of query q (or -1).  Returns elapsed seconds, or -1 on error.
-double ref_db_search_mt_filter(void* h, const char* db, const char* table, const char* field, float* queries, int64_t nq, int64_t d,
-                               int64_t limit, int threads, const char* filter, int64_t* first_ids) {
-  const std::string flt(filter ? filter : "");
-  auto* srv = static_cast<vectordb::engine::DBServer*>(h);
-  std::atomic<int64_t> next{0};
-  std::atomic<int> bad{0};
-  auto worker = [&]() {
-    std::string f(field);
-    std::vector<std::string> fields{"ID"};
-    for (;;) {
-      const int64_t q = next.fetch_add(1);
-      if (q >= nq) break;
-      vectordb::Json result, facets_cfg, facets;
-      facets_cfg.LoadFromString("[]");
-      try {
-        auto st = srv->Search(db, table, f, fields, d, queries + q * d, limit, result, flt, true, facets_cfg, facets);
-        if (!st.ok()) bad++;
-        first_ids[q] = result.GetSize() > 0 ? result.GetArrayElement(0).GetInt("ID") : -1;
-      } catch (const std::exception&) {
-        bad++;
-        first_ids[q] = -1;
-      }
-    }
-  };
-  auto t0 = std::chrono::steady_clock::now();
-  std::vector<std::thread> pool;
-  for (int t = 0; t < threads; ++t) pool.emplace_back(worker);
-  for (auto& t : pool) t.join();
-  const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-  return bad.load() ? -1.0 : sec;
-}
-
-double ref_db_search_mt(void* h, const char* db, const char* table, const char* field, float* queries, int64_t nq, int64_t d,
-                        int64_t limit, int threads, int64_t* first_ids) {
-  return ref_db_search_mt_filter(h, db, table, field, queries, nq, d, limit, threads, "", first_ids);
-}
-
-int ref_omp_max_threads() { return omp_get_max_threads(); }
-
 }  // extern "C"
+// (the DBServer-level entry points - ref_db_* - are dropin/db_driver.cpp, compiled into this library over the reference's own DBServer)

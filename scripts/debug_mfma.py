@@ -1,5 +1,6 @@
 import sys, os, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("EPS_TUNING_FROM_ENV", "1")   # (scripts steer the library's engine switches through the environment: vectordb_amd/_lib.py)
 import vectordb_amd as amd
 def run(n, d, nq, k=10):
     g = torch.Generator(device="cuda").manual_seed(42)

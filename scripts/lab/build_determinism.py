@@ -1,5 +1,7 @@
+import os
 import sys, numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+os.environ.setdefault("EPS_TUNING_FROM_ENV", "1")   # (scripts steer the library's engine switches through the environment: vectordb_amd/_lib.py)
 import vectordb_amd as amd
 from helpers import data
 for n, d in ((60000, 256), (80000, 32), (80000, 256)):

@@ -1,7 +1,9 @@
+import os
 """device SelectEdge (prune_kernel) vs the oracle on identical pools at several dimensions, repeated (race hunting)"""
 import sys
 import numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+os.environ.setdefault("EPS_TUNING_FROM_ENV", "1")   # (scripts steer the library's engine switches through the environment: vectordb_amd/_lib.py)
 import vectordb_amd as amd
 from helpers import data
 from oracle.pyoracle import Oracle

@@ -1,6 +1,7 @@
 import os, sys, time, json
 import numpy as np, torch
 sys.path.insert(0, os.getcwd())
+os.environ.setdefault("EPS_TUNING_FROM_ENV", "1")   # (scripts steer the library's engine switches through the environment: vectordb_amd/_lib.py)
 import vectordb_amd as amd
 n,d=1_000_000,768
 g=torch.Generator(device="cuda").manual_seed(42)

@@ -8,6 +8,9 @@ try:  # torch bundles its own HIP runtime; it must be the first one loaded in a 
 except ImportError:
     pass
 
+# the library reads no environment variable; the suite steers its engine A/Bs through the environment, so the Python wrapper is asked to forward
+# the documented switches (vectordb_amd/_lib.py TUNING_NAMES -> eps_set_tuning) before every call
+os.environ["EPS_TUNING_FROM_ENV"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -129,3 +129,37 @@ def test_traversal_gather_bytes_accounting():
     extra = (off["dist_evals"] - seeds) * (768 + 4.0)
     assert amd.traversal_gather_bytes(allpass, d, deg, seeds) == amd.traversal_gather_bytes(off, d, deg, seeds) + extra
     assert amd.traversal_gather_bytes(dict(off, rerank_rows=1), 100, deg, 0) > 0     # d not a multiple of 16: mirror row rounded up to 112
+
+
+def test_product_library_reads_no_environment_and_ships_no_ablation(built):
+    """a production library must not change its behaviour - let alone its answers - because of an environment variable.
+    The product .so imports no getenv at all (its engine switches are entries of the eps_set_tuning table), and the kernel-ablation
+    switches, which make answers wrong on purpose, exist in lab builds (-DEPS_LAB) only."""
+    import subprocess
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", built], capture_output=True, text=True).stdout
+    assert not re.search(r"\b(secure_)?getenv\b", undefined), [ln for ln in undefined.splitlines() if "getenv" in ln]
+    blob = open(built, "rb").read()
+    for s in (b"EPS_S8_ABLATE", b"EPS_MFMA_ABLATE", b"EPS_V7_ABL"):
+        assert s not in blob, s
+    src = ""
+    for f in os.listdir(os.path.join(ROOT, "vectordb_amd", "csrc")):
+        src += open(os.path.join(ROOT, "vectordb_amd", "csrc", f), errors="ignore").read()
+    # the only getenv left in the sources is the lab build's fallback inside tune_env
+    assert len(re.findall(r"\bgetenv\(", src)) == 1 and "#ifdef EPS_LAB\n  return getenv(name);" in src
+
+
+def test_tuning_table(built):
+    from vectordb_amd import _lib
+    L = _lib.load()
+    assert L.eps_set_tuning(b"EPS_TRV_PREFILTER", b"1") == 0
+    assert L.eps_set_tuning(b"EPS_TRV_PREFILTER", None) == 0
+    assert L.eps_set_tuning(None, None) == 0
+
+
+def test_dropin_builds_without_the_oracle_directory():
+    """the drop-in (dropin/Makefile) must not reach into oracle/ (test infrastructure): its stand-in headers and its C entry points are its own"""
+    mk = open(os.path.join(ROOT, "dropin", "Makefile")).read()
+    assert "oracle" not in re.sub(r"#.*", "", mk)
+    for f in os.listdir(os.path.join(ROOT, "dropin")):
+        if f.endswith((".cpp", ".hpp")):
+            assert not re.search(r"#include\s+[\"<][^\">]*oracle", open(os.path.join(ROOT, "dropin", f)).read()), f

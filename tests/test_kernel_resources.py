@@ -73,4 +73,7 @@ def test_traversal_kernel_keeps_four_waves_per_simd(tmp_path):
     for k, u in trv.items():
         assert u["VGPRs"] <= 128 and u["Occupancy [waves/SIMD]"] >= 4, (k, u)
         with_prefilter = "ELb1EEEvNS_8Trv2ArgsE" in k or k.rstrip(">").endswith("true")
-        assert u["ScratchSize [bytes/lane]"] <= (64 if with_prefilter else 0), (k, u)
+        # r5 (3 mirror rows x 3 pieces and 3 fp32 rows x 3 pieces in flight per lane group): 9 dwords in the form every batch search runs
+        # (float4 rows, 4 wavefronts, queues in LDS), at most 21 in the forms with the queues in HBM / scalar row loads
+        hot = k.startswith("_ZN3eps16traverse2_kernelILb1ELi4ELb0ELb1E")
+        assert u["ScratchSize [bytes/lane]"] <= ((48 if hot else 96) if with_prefilter else 0), (k, u)

@@ -8,6 +8,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libepsilla_gfx950.so")
 
 EPS_OK = 0
+_lib = None
+_proxy = None
 EPS_USER_ERROR = 30000
 EPS_INFRA_UNEXPECTED_ERROR = 40001
 EPS_DB_UNEXPECTED_ERROR = 50001
@@ -26,8 +28,66 @@ EXPORTS = [
     "eps_index_append_rows", "eps_index_attach_shard_rows", "eps_index_clone_rows", "eps_index_row_count", "eps_index_load_table", "eps_index_set_id_map", "eps_index_set_deleted",
     "eps_index_set_int_filter", "eps_index_set_filter_program", "eps_index_set_filter_program_ex", "eps_index_search_walk", "eps_index_select_edges", "eps_index_inter_insert", "eps_index_knn_graph", "eps_index_link", "eps_index_build", "eps_index_set_graph", "eps_index_graph_info",
     "eps_index_get_graph", "eps_index_save_graph", "eps_index_load_graph", "eps_index_search",
-    "eps_index_last_stats", "eps_index_kernel_times", "eps_normalize_rows", "eps_merge_topk", "eps_merge_topk_packed",
+    "eps_index_last_stats", "eps_index_kernel_times", "eps_normalize_rows", "eps_merge_topk", "eps_merge_topk_packed", "eps_set_tuning",
 ]
+
+# Engine-selection switches of the library (eps_set_tuning, include/epsilla_gfx950.h).  The library itself reads no environment
+# variable; the test-suite and the lab scripts, which steer A/B runs through the environment, opt in with EPS_TUNING_FROM_ENV=1 and this
+# wrapper then forwards the names below from os.environ to the library's table before every call.
+TUNING_NAMES = (
+    "EPS_DEBUG", "EPS_TRV_PROF", "EPS_TRV_PREFILTER", "EPS_TRV_WAVES", "EPS_TRV_WIDE", "EPS_TRV_PER_CU", "EPS_TRV_LDS_KB", "EPS_FLAT_ONE_PASS",
+    "EPS_ONE_PASS_TIMED", "EPS_DEBUG_ONE_PASS_OVERFLOW", "EPS_S8_WG_PER_CU", "EPS_RERANK_SPLIT", "EPS_MFMA_BITS", "EPS_MFMA_MAX_BATCH",
+    "EPS_MFMA_PROBE", "EPS_MFMA_SEED", "EPS_MFMA_GROUPSYNC", "EPS_MFMA_SYNC_SHIFT", "EPS_MFMA_STAGES", "EPS_MFMA_KERNEL", "EPS_MFMA_NARROW",
+    "EPS_MFMA_TWO_PER_CU", "EPS_MFMA_FOLD", "EPS_MFMA_MANTISSA", "EPS_BUILD_BLOCK", "EPS_BUILD_VISITED", "EPS_BUILD_PREFILTER", "EPS_S8_ABLATE",
+)
+_forwarded = {}
+
+
+def set_tuning(name, value):
+    """eps_set_tuning: value None removes the entry; name None empties the table."""
+    L = load()
+    L.eps_set_tuning(None if name is None else name.encode(), None if value is None else str(value).encode())
+    if name is None:
+        _forwarded.clear()
+    else:
+        _forwarded.pop(name, None)
+
+
+def sync_tuning():
+    """Forwards the switches found in the environment (EPS_TUNING_FROM_ENV=1 only: tests, lab scripts)."""
+    if os.environ.get("EPS_TUNING_FROM_ENV") != "1" or _lib is None:
+        return
+    env = os.environ
+    for name in TUNING_NAMES:
+        v = env.get(name)
+        if _forwarded.get(name) != v:
+            _lib.eps_set_tuning(name.encode(), None if v is None else v.encode())
+            if v is None:
+                _forwarded.pop(name, None)
+            else:
+                _forwarded[name] = v
+
+
+class _Synced:
+    """The loaded library; calls that may consult a switch forward the environment first (see sync_tuning)."""
+    _SYNC = frozenset(("eps_index_search", "eps_index_search_walk", "eps_index_build", "eps_index_knn_graph", "eps_index_link",
+                       "eps_index_attach_rows", "eps_index_append_rows", "eps_index_set_graph", "eps_index_load_graph"))
+
+    def __init__(self, cdll):
+        object.__setattr__(self, "_cdll", cdll)
+        fwd = os.environ.get("EPS_TUNING_FROM_ENV") == "1"
+        for name in EXPORTS:
+            f = getattr(cdll, name)
+            if fwd and name in self._SYNC:
+                def call(*a, _f=f):
+                    sync_tuning()
+                    return _f(*a)
+                object.__setattr__(self, name, call)
+            else:
+                object.__setattr__(self, name, f)
+
+    def __getattr__(self, name):
+        return getattr(self._cdll, name)
 
 
 class SearchParams(C.Structure):
@@ -68,14 +128,11 @@ class EpsillaError(RuntimeError):
         self.code = code
 
 
-_lib = None
-
-
 def load():
     """Loads the shared library (no GPU needed for this step) and declares every prototype."""
     global _lib
     if _lib is not None:
-        return _lib
+        return _synced()
     try:
         # torch ships its own HIP runtime; when both live in one process it must be the first one loaded,
         # otherwise torch finds "no ROCm-capable device".  torch is plumbing here (device memory / streams).
@@ -127,8 +184,16 @@ def load():
     L.eps_merge_topk.argtypes = [vp, vp, i32, i64, i32, vp, vp, i32, vp]
     L.eps_index_kernel_times.argtypes = [vp, C.POINTER(C.c_double), i32]
     L.eps_merge_topk_packed.argtypes = [vp, i64, i64, i32, i64, i32, vp, vp, i32, vp]
+    L.eps_set_tuning.argtypes = [C.c_char_p, C.c_char_p]
     for name in EXPORTS:
         if getattr(L, name).restype is C.c_int:
             getattr(L, name).restype = i32
     _lib = L
-    return L
+    return _synced()
+
+
+def _synced():
+    global _proxy
+    if _proxy is None:
+        _proxy = _Synced(_lib)
+    return _proxy

@@ -439,7 +439,7 @@ int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp, const Buil
   if (K <= 0 || R <= 0 || Ls <= 0 || K + 1 > 1024 || R > 512)
     return ix.fail(EPS_USER_ERROR, "build: unsupported parameters (need 0 < knng < 1024, 0 < out_degree <= 512)");
   const bool vec4 = (dim % 4 == 0) && ((reinterpret_cast<uintptr_t>(ix.d_rows_) & 15) == 0);
-  const bool debug = getenv("EPS_DEBUG") != nullptr;
+  const bool debug = tune_env("EPS_DEBUG") != nullptr;
   struct EventPair {   // released on every return path
     hipEvent_t a = nullptr, b = nullptr;
     ~EventPair() {
@@ -468,7 +468,7 @@ int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp, const Buil
   // error is a small fraction of the gap between the K-th and the 128-th neighbour; tests/test_gpu_build.py measures the recall).
   DevBuf knn, run, runA, candA, cntA;
   const int k1 = K + 1;
-  static const int64_t B = getenv("EPS_BUILD_BLOCK") ? std::max(256, atoi(getenv("EPS_BUILD_BLOCK"))) : 2048;   // queries per kNN pass
+  static const int64_t B = tune_env("EPS_BUILD_BLOCK") ? std::max(256, atoi(tune_env("EPS_BUILD_BLOCK"))) : 2048;   // queries per kNN pass
   const bool use_mfma = n >= 65536;
   const int kA = (int)std::min<int64_t>(n, std::max(k1, 128));
   if (!knn.reserve((size_t)n * K * 4) || !run.reserve((size_t)B * k1 * 8)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "build: out of device memory (kNN graph)");
@@ -575,7 +575,7 @@ int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp, const Buil
   //                  10M rows, where the memsets and the HBM atomics cost +20 s of Link: 56 s vs 36 s)
   //   EPS_BUILD_VISITED=lds      the r1 table of 8192 slots in LDS: a third of the searches at 1M x 768 fill it (5.4 k
   //                  evaluations instead of 5.8 k); same recall
-  const char* vis_env = getenv("EPS_BUILD_VISITED");
+  const char* vis_env = tune_env("EPS_BUILD_VISITED");
   const bool bitmap_vis = vis_env && std::strcmp(vis_env, "bitmap") == 0;
   const bool ghash_vis = !bitmap_vis && !(vis_env && std::strcmp(vis_env, "lds") == 0);
   constexpr int GHASH_SLOTS = 32768;
@@ -602,7 +602,7 @@ int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp, const Buil
   // just scanned; EPS_BUILD_PREFILTER=0 turns it off (A/B - the graph is the same either way)
   Quant8View q8v;
   bool prefilter = dim >= 128;
-  if (const char* e = getenv("EPS_BUILD_PREFILTER")) prefilter = atoi(e) != 0;
+  if (const char* e = tune_env("EPS_BUILD_PREFILTER")) prefilter = atoi(e) != 0;
   DevBuf q8b, qstat8b;
   if (prefilter) {
     const int32_t rc = quant8_view(ix, &q8v);
@@ -693,7 +693,7 @@ int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp, const Buil
     ta.queries = ix.d_rows_ + v0 * dim;
     if (prefilter) quant8_queries(ix, q8v, ta.queries, nb, q8b.as<signed char>(), qstat8b.as<float>());
     HIPCHK(launch_link_search(nb));
-    if (v0 == 0 && prefilter && !getenv("EPS_BUILD_PREFILTER") && n > NB) {
+    if (v0 == 0 && prefilter && !tune_env("EPS_BUILD_PREFILTER") && n > NB) {
       // judged on the first batch: where more than 60 % of the neighbour evaluations still read the fp32 row (distances small
       // against the table's value range: clustered / low intrinsic dimension) the 8-bit test is pure overhead - off for the rest
       unsigned long long hc[4] = {0, 0, 0, 0};

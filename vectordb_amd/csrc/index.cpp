@@ -9,9 +9,46 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <deque>
+#include <mutex>
 #include <new>
+#include <string>
+#include <unordered_map>
 
 namespace eps {
+
+// ------------------------------------------------------------------------------------------------ engine-selection switches
+// (eps_set_tuning).  Values are interned and never freed, so a pointer handed out stays valid while another thread replaces the entry.
+namespace {
+std::mutex g_tune_mu;
+std::unordered_map<std::string, const char*> g_tune;
+std::deque<std::string> g_tune_values;
+}  // namespace
+const char* tune_env(const char* name) {
+  {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    if (!g_tune.empty()) {
+      auto it = g_tune.find(name);
+      if (it != g_tune.end()) return it->second;
+    }
+  }
+#ifdef EPS_LAB
+  return getenv(name);
+#else
+  return nullptr;
+#endif
+}
+static void tune_set(const char* name, const char* value) {
+  std::lock_guard<std::mutex> lk(g_tune_mu);
+  if (!name) {
+    g_tune.clear();
+  } else if (!value) {
+    g_tune.erase(name);
+  } else {
+    g_tune_values.emplace_back(value);
+    g_tune[name] = g_tune_values.back().c_str();
+  }
+}
 
 // ------------------------------------------------------------------------------------------------ utils
 DevBuf::~DevBuf() { release(); }
@@ -1100,6 +1137,11 @@ int32_t eps_merge_topk_packed(const void* gathered, int64_t shard_stride_bytes, 
   eps::launch_merge_shards(reinterpret_cast<const float*>(base + dist_offset_bytes), reinterpret_cast<const int64_t*>(base), shards, nq, k,
                            out_dist, out_ids, static_cast<hipStream_t>(stream), shard_stride_bytes);
   return hipGetLastError() == hipSuccess ? EPS_OK : EPS_INFRA_UNEXPECTED_ERROR;
+}
+
+int32_t eps_set_tuning(const char* name, const char* value) {
+  eps::tune_set(name, value);
+  return EPS_OK;
 }
 
 }  // extern "C"

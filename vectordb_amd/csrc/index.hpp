@@ -26,6 +26,10 @@ struct DevBuf {  // growable device allocation
   T* as() const { return static_cast<T*>(p); }
 };
 
+// Engine-selection switches (eps_set_tuning, include/epsilla_gfx950.h): the value of `name` in the process-wide table, or null.  The
+// product library never reads the environment; a lab build (-DEPS_LAB) falls back to getenv for names the table does not hold.
+const char* tune_env(const char* name);
+
 struct BuildStage;   // stage-level entry of the graph build (below)
 struct Quant8View {   // the table's 8-bit mirror as other kernels see it (mfma_filter.hip)
   const signed char* x8 = nullptr;
@@ -34,6 +38,8 @@ struct Quant8View {   // the table's 8-bit mirror as other kernels see it (mfma_
   const float* mu = nullptr;   // [d_pad8] the grid's centre (one value per column)
   int d_pad8 = 0;
   float step = 1.f, u = 1.f;
+  int64_t epoch8 = 0;     // counts the mirror's (re)builds: row constants copied elsewhere (the graph's edge constants) are stale when it moves
+  bool per_batch = false; // acc0 carries per-batch margins (fold8): it changes with every batch of queries
 };
 struct HalfMirror;   // fp16 mirror + per-row bounds for the MFMA filter engine (mfma_filter.hip)
 struct GraphDev;     // device CSR + traversal scratch (traverse.hip)

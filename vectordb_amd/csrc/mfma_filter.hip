@@ -94,6 +94,7 @@ struct HalfMirror {
   float step8 = 0.f;            // the grid: xh' = step8 * xi around mu8
   bool i8_trusted = false;      // the library's own choice has seen a batch through the 8-bit pass on this mirror (no probe needed)
   int64_t version8 = -1, n8 = 0, n_pad8 = 0, forced_rows8 = 0;
+  int64_t epoch8 = 0;           // full (re)builds of the 8-bit mirror (an extension keeps the grid and every existing row's constant)
   bool fold8 = false;           // exact-mode users fold per-row margins per batch (rows differ); else table-wide margin in the thresholds
   int d_pad8 = 0;
   bool i8_ok = false;
@@ -674,7 +675,7 @@ static int32_t ensure_mirror(Index& ix) {
   HalfMirror& m = *ix.mirror_;
   const int64_t n = ix.n_rows_;
   if (m.drop < 0) {   // EPS_MFMA_MANTISSA = mantissa bits the fp16 operands keep (10 = plain fp16); fixed per mirror
-    const char* e = getenv("EPS_MFMA_MANTISSA");
+    const char* e = tune_env("EPS_MFMA_MANTISSA");
     const int keep = e ? std::min(10, std::max(2, atoi(e))) : EPS_MFMA_MANTISSA_DEFAULT;
     m.drop = 10 - keep;
   }
@@ -864,8 +865,8 @@ static int32_t ensure_mirror8(Index& ix) {
     // Per-row margins are folded per batch only where rows DIFFER: a forced row, or a residual norm beyond 1.5 x the smallest (a clamped
     // value somewhere).  On homogeneous tables (every row a plain rounding residual: within a few per cent of each other) the table-wide
     // margin in the thresholds is as tight, keeps every query's own norms, and costs no pass over the rows (10M rows: 40 us per batch).
-    m.fold8 = forced > 0 || m.h_scal8[0] > 1.5f * m.h_scal8[7] || (getenv("EPS_MFMA_FOLD") && atoi(getenv("EPS_MFMA_FOLD")) != 0);
-    if (getenv("EPS_MFMA_FOLD") && atoi(getenv("EPS_MFMA_FOLD")) == 0 && forced == 0) m.fold8 = false;
+    m.fold8 = forced > 0 || m.h_scal8[0] > 1.5f * m.h_scal8[7] || (tune_env("EPS_MFMA_FOLD") && atoi(tune_env("EPS_MFMA_FOLD")) != 0);
+    if (tune_env("EPS_MFMA_FOLD") && atoi(tune_env("EPS_MFMA_FOLD")) == 0 && forced == 0) m.fold8 = false;
     m.extended_rows8 += extend ? n - row0 : 0;
   }
   if (!m.i8_ok) {   // nothing of it is used: give the memory back
@@ -878,6 +879,7 @@ static int32_t ensure_mirror8(Index& ix) {
   if (!extend) {
     m.i8_overflows = 0;
     m.i8_trusted = false;
+    m.epoch8 += 1;
   }
   m.n8 = n;
   m.n_pad8 = n_pad;
@@ -903,6 +905,8 @@ int32_t quant8_view(Index& ix, Quant8View* v) {
   v->d_pad8 = m.d_pad8;
   v->step = m.step8;
   v->u = (ix.metric_ == 0 ? 2.f : 1.f) * m.step8 * m.step8;
+  v->epoch8 = m.epoch8;
+  v->per_batch = m.fold8;
   return EPS_OK;
 }
 
@@ -935,7 +939,7 @@ bool flat_mfma_profitable(const Index& ix, int64_t nq, int k) {
   const bool can16 = !have16 || m->fp16_range_ok;
   if (known8 && !have8 && !can16) return false;                 // neither mirror can serve this table
   // up to 4 queries, k <= 16, rows of <= 1024 bytes: the one-pass search (stream8_kernel.hpp) - one pass over d_pad8 + 4 bytes per row
-  const bool one_pass_shape = nq <= 4 && k <= 16 && ix.dim_ <= 1024 && !(getenv("EPS_FLAT_ONE_PASS") && atoi(getenv("EPS_FLAT_ONE_PASS")) == 0);
+  const bool one_pass_shape = nq <= 4 && k <= 16 && ix.dim_ <= 1024 && !(tune_env("EPS_FLAT_ONE_PASS") && atoi(tune_env("EPS_FLAT_ONE_PASS")) == 0);
   if (nq < 8 && !have8 && !have16) {
     // single-query traffic alone does not get a mirror (n x d bytes of HBM + a pass over the table to build it) at once: r4, after 16 such
     // calls on the same rows it does, where the one-pass search can use it (0.20 ms instead of 0.62 ms per call at 1M x 768)
@@ -964,7 +968,7 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
   HalfMirror& m = *ix.mirror_;
   const int64_t n = ix.scan_limit_ >= 0 ? std::min(ix.scan_limit_, ix.n_rows_) : ix.n_rows_;
   const int pieces = m.d_pad8 / 256;
-  if (getenv("EPS_FLAT_ONE_PASS") && atoi(getenv("EPS_FLAT_ONE_PASS")) == 0) return EPS_OK;
+  if (tune_env("EPS_FLAT_ONE_PASS") && atoi(tune_env("EPS_FLAT_ONE_PASS")) == 0) return EPS_OK;
   if (nq < 1 || nq > 4 || k < 1 || k > 16 || m.fold8 || n < 65536 || n > m.n8 || m.d_pad8 % 256 != 0 || pieces < 2 || pieces > 4) return EPS_OK;
   if (m.s8_declined_version == ix.rows_version_) return EPS_OK;
   const FilterSpec fs = ix.filter_spec();
@@ -1003,18 +1007,22 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
   a.raw_cnt = m.s8g.as<u32>() + S8_TABLE_WORDS;
   a.raw = m.s8raw.as<u64>();
   a.f = fs;
-  a.ablate = getenv("EPS_S8_ABLATE") ? atoi(getenv("EPS_S8_ABLATE")) : 0;   // (lab)
+#ifdef EPS_LAB   // (kernel ablations make answers wrong on purpose: lab builds only)
+  a.ablate = tune_env("EPS_S8_ABLATE") ? atoi(tune_env("EPS_S8_ABLATE")) : 0;
+#else
+  a.ablate = 0;
+#endif
   if (!m.s8_cus) {   // (once per mirror: the query costs more than the search)
     hipDeviceProp_t prop;
     m.s8_cus = hipGetDeviceProperties(&prop, ix.device_) == hipSuccess ? std::max(8, prop.multiProcessorCount) : 256;
   }
   const int cus = m.s8_cus;
-  static const int wg_per_cu = getenv("EPS_S8_WG_PER_CU") ? std::max(1, atoi(getenv("EPS_S8_WG_PER_CU"))) : 2;
+  static const int wg_per_cu = tune_env("EPS_S8_WG_PER_CU") ? std::max(1, atoi(tune_env("EPS_S8_WG_PER_CU"))) : 2;
   const dim3 grid((unsigned)std::min<int64_t>(std::min<int64_t>((int64_t)cus * wg_per_cu, S8_MAX_WAVES / 4), (n + 63) / 64)), block(256);
   a.waves = (int)grid.x * 4;
   // (no event pair around the pass by default: a record between two dependent launches costs this chain 5-10 us each; kernel_ms covers
   // the call.  EPS_ONE_PASS_TIMED=1 - bench.py's roofline leg - records the pair: main_kernel_ms = the pass)
-  const bool timed = getenv("EPS_ONE_PASS_TIMED") && atoi(getenv("EPS_ONE_PASS_TIMED")) != 0;
+  const bool timed = tune_env("EPS_ONE_PASS_TIMED") && atoi(tune_env("EPS_ONE_PASS_TIMED")) != 0;
   if (timed) (void)hipEventRecord(ix.evk0_, s);
 #define EPS_S8_LAUNCH(P_)                                                                      \
   do {                                                                                         \
@@ -1079,7 +1087,7 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
   if (er != hipSuccess) return ix.hip_fail(er, "one-pass flat search");
   h.overflow = hraw[0];
   memcpy(&h.total, reinterpret_cast<const char*>(hraw) + (span - 8), 8);
-  if (getenv("EPS_DEBUG") || (h.overflow && getenv("EPS_DEBUG_ONE_PASS_OVERFLOW"))) {
+  if (tune_env("EPS_DEBUG") || (h.overflow && tune_env("EPS_DEBUG_ONE_PASS_OVERFLOW"))) {
     std::vector<u32> hc((size_t)S8_TABLE_WORDS + (size_t)4 * S8_MAX_WAVES);
     (void)hipMemcpy(hc.data(), m.s8g.p, hc.size() * 4, hipMemcpyDeviceToHost);
     for (int64_t q = 0; q < nq; ++q) {
@@ -1149,17 +1157,17 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
       !m.cnt.reserve((size_t)(nq + 4) * 4 + 16) || !m.seedc.reserve((size_t)nq * k * 4) || !(i8 ? m.q8.reserve((size_t)b_pad * m.d_pad8) : m.qh.reserve((size_t)b_pad * m.d_pad * 2)))
     return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory (scratch)");
   // kernel choice: v5 / v7 want K-steps in pairs (d_pad % 128 == 0, >= 256); other shapes stay on v3
-  const char* ver_s = getenv("EPS_MFMA_KERNEL");   // 3 | 7 (A/B); v7 needs K-steps in pairs, other shapes stay on v3
+  const char* ver_s = tune_env("EPS_MFMA_KERNEL");   // 3 | 7 (A/B); v7 needs K-steps in pairs, other shapes stay on v3
   const int version_env = (ver_s && atoi(ver_s) == 3 && !i8) ? 3 : 7;
   const int version = (version_env == 7 && (d_pad_h % 128 != 0 || d_pad_h < 256)) ? 3 : version_env;   // (the 8-bit mirror is padded for v7)
   if (version >= 7 && !m.qf.reserve((size_t)b_pad * d_pad_h * 2)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory (scratch)");
   if (!m.gsync.reserve(1024)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory (scratch)");
   // (what the staging below decides, needed here already: the 8-bit query preparation also lays down a seeded call's start state)
   const int64_t S0 = std::max<int64_t>(4096, (int64_t)(32 * k + ROWPAD - 1) / ROWPAD * ROWPAD);
-  const bool seed_env = !(getenv("EPS_MFMA_SEED") && atoi(getenv("EPS_MFMA_SEED")) == 0);
+  const bool seed_env = !(tune_env("EPS_MFMA_SEED") && atoi(tune_env("EPS_MFMA_SEED")) == 0);
   const bool seeded = seed_env && n > 4 * S0;   // with a filter the seeds are the k best VISIBLE head rows
   const bool prologue = seeded && version >= 7;   // one launch resets everything a seeded call starts from
-  const bool gsync_env = !(getenv("EPS_MFMA_GROUPSYNC") && atoi(getenv("EPS_MFMA_GROUPSYNC")) == 0);
+  const bool gsync_env = !(tune_env("EPS_MFMA_GROUPSYNC") && atoi(tune_env("EPS_MFMA_GROUPSYNC")) == 0);
   const bool prep_does_it_all = i8 && version >= 7;   // fragment-major copy + prologue inside query_prep8_kernel: two launches less per call
   hipError_t er_ = hipSuccess;
   const bool fold = i8 && !approx && m.fold8;   // exact mode on a table whose rows differ: per-row margins folded into the start values, thresholds without margin
@@ -1211,7 +1219,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
     // overhead (launch tails + one re-rank launch, ~0.1 ms at 10M rows).  A candidate costs its wavefront ~900 cycles in the
     // filter's epilogue and 3 KB of gather in the re-rank, so the looser 8-bit bound wants more, smaller steps (measured at
     // 10M x 768, batch 1024: EPS_MFMA_STAGES sweep in profiles/r3_stage_sweep.txt).
-    const char* st_env = getenv("EPS_MFMA_STAGES");
+    const char* st_env = tune_env("EPS_MFMA_STAGES");
     // Few queries (<= 64): 4 stages.  A call is then a chain of short dependent launches (profiles/r3_single_query_timeline.txt: one
     // query on 1M x 768 = 400 us of back-to-back kernels, 185 us of them the filter stages streaming the mirror once, 110 us seven
     // one-workgroup re-ranks), and two re-ranks less beat the longer lists: scripts/lab/stages_by_batch.py, 1M x 768, p50 ms at
@@ -1279,7 +1287,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   fa.cnt = cnt;
   fa.cap = cap;
   fa.group_sync = nullptr;
-  fa.sync_shift = getenv("EPS_MFMA_SYNC_SHIFT") ? std::min(8, std::max(0, atoi(getenv("EPS_MFMA_SYNC_SHIFT")))) : 2;
+  fa.sync_shift = tune_env("EPS_MFMA_SYNC_SHIFT") ? std::min(8, std::max(0, atoi(tune_env("EPS_MFMA_SYNC_SHIFT")))) : 2;
   fa.dense = 0;
   fa.ablate = 0;
   fa.prof = nullptr;
@@ -1314,7 +1322,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   ra.u = u8;
   ra.slack = 0.f;   // (set below, with the stages)
   ra.gsync = m.gsync.as<u32>();
-  if (!approx && nq <= 16 && k <= 128 && getenv("EPS_RERANK_SPLIT") && atoi(getenv("EPS_RERANK_SPLIT")) != 0) {
+  if (!approx && nq <= 16 && k <= 128 && tune_env("EPS_RERANK_SPLIT") && atoi(tune_env("EPS_RERANK_SPLIT")) != 0) {
     // a handful of queries: every re-rank spread over 8 workgroups per query (RerankArgs::parts).  Opt-in: measured, it takes 5 us off a
     // 340 us single-query call (profiles/r4_single_query_latency.txt) - a re-rank of ~150 rows is a chain of dependent latencies, not a
     // bandwidth problem - and is not worth a cross-workgroup hand-off on the default path
@@ -1348,8 +1356,8 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
       (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v7_lds_bytes(4));
   }
   const int num_cus = m.num_cus;
-  const bool narrow_env = !(getenv("EPS_MFMA_NARROW") && atoi(getenv("EPS_MFMA_NARROW")) == 0);
-  const bool two_per_cu = getenv("EPS_MFMA_TWO_PER_CU") && atoi(getenv("EPS_MFMA_TWO_PER_CU")) != 0;   // (lab until measured)
+  const bool narrow_env = !(tune_env("EPS_MFMA_NARROW") && atoi(tune_env("EPS_MFMA_NARROW")) == 0);
+  const bool two_per_cu = tune_env("EPS_MFMA_TWO_PER_CU") && atoi(tune_env("EPS_MFMA_TWO_PER_CU")) != 0;   // (lab until measured)
   auto launch_filter = [&](const FilterArgs& f) {
     {
       FilterArgs f3 = f;
@@ -1457,7 +1465,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   }
   bool first = true;
   bool fin_done = false;
-  const bool probe = i8 && auto_bits && !approx && seeded && !m.i8_trusted && bounds.size() > 3 && !(getenv("EPS_MFMA_PROBE") && atoi(getenv("EPS_MFMA_PROBE")) == 0);
+  const bool probe = i8 && auto_bits && !approx && seeded && !m.i8_trusted && bounds.size() > 3 && !(tune_env("EPS_MFMA_PROBE") && atoi(tune_env("EPS_MFMA_PROBE")) == 0);
   for (size_t st = 0; st + 1 < bounds.size(); ++st) {
     const int64_t lo = bounds[st], hi = bounds[st + 1];
     {
@@ -1497,7 +1505,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
     }
     if (biggest) (void)hipEventRecord(ix.evk1_, s);
     if (!fused) hipLaunchKernelGGL(stage_counts_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, cnt, nq, cap, overflow, total);
-    if (getenv("EPS_DEBUG")) {
+    if (tune_env("EPS_DEBUG")) {
       std::vector<u32> hc((size_t)nq);
       std::vector<float> hT((size_t)nq);
       std::vector<u64> hk((size_t)nq * k);
@@ -1602,10 +1610,10 @@ int32_t flat_mfma_search(Index& ix, const float* dq, int64_t nq, int k, u64* run
   if (ix.n_rows_ <= 0) return ix.flat_stream(dq, nq, k, 0, 0, run_keys, false);   // (nothing to mirror)
   const bool auto_bits = bits != 8 && bits != 16;
   if (auto_bits) {   // the library's choice: 8-bit first pass unless switched off (EPS_MFMA_BITS=16, A/B) - tables it cannot serve fall back by themselves
-    const char* e = getenv("EPS_MFMA_BITS");
+    const char* e = tune_env("EPS_MFMA_BITS");
     bits = (e && atoi(e) == 16) ? 16 : 8;
   }
-  const int64_t slice = getenv("EPS_MFMA_MAX_BATCH") ? std::max(256, atoi(getenv("EPS_MFMA_MAX_BATCH"))) : 2048;
+  const int64_t slice = tune_env("EPS_MFMA_MAX_BATCH") ? std::max(256, atoi(tune_env("EPS_MFMA_MAX_BATCH"))) : 2048;
   if (nq <= slice) return flat_mfma_search_slice(ix, dq, nq, k, run_keys, approx, 1, bits, auto_bits);
   for (int64_t q0 = 0; q0 < nq; q0 += slice) {   // the counters in ix.stats_ accumulate over the slices
     const int32_t rc = flat_mfma_search_slice(ix, dq + q0 * ix.dim_, std::min(slice, nq - q0), k, run_keys + q0 * k, approx, 1, bits, auto_bits);

@@ -34,6 +34,14 @@
 
 namespace eps {
 
+// kernel ablations (profiling; the answers are wrong) exist in lab builds only: in the product they compile away
+#ifdef EPS_LAB
+#define S8_ABLATE (a.ablate)
+#else
+#define S8_ABLATE 0
+#endif
+
+
 struct Stream8Args {
   const signed char* x8;   // [n_pad8][d_pad8]
   const int* acc0;         // [n_pad8]
@@ -178,7 +186,7 @@ __global__ __launch_bounds__(256) void stream8_kernel(Stream8Args a) {
   for (int q = 0; q < NQ; ++q) mine[q] = 0;
   // candidates of one chunk: appended to the wavefront's own list, offered to the table where they beat its k-th slot
   auto test_chunk = [&](int64_t base, const int (&acc)[U][NQ]) __attribute__((always_inline)) {
-    if (a.ablate & 1) {   // (keeps the loads and the arithmetic alive)
+    if (S8_ABLATE & 1) {   // (keeps the loads and the arithmetic alive)
       int x = 0;
 #pragma unroll
       for (int uu = 0; uu < U; ++uu)
@@ -237,7 +245,7 @@ __global__ __launch_bounds__(256) void stream8_kernel(Stream8Args a) {
     // the best of the wavefront's 4 U rows (per query): one offer per wavefront, of a row that beat 15 others
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      if (q >= a.nq || (a.ablate & 5)) continue;
+      if (q >= a.nq || (S8_ABLATE & 5)) continue;
       int bv = S8_EMPTY, br = 0;
 #pragma unroll
       for (int uu = 0; uu < U; ++uu) {
@@ -256,7 +264,7 @@ __global__ __launch_bounds__(256) void stream8_kernel(Stream8Args a) {
       if (lane == 0 && bv != S8_EMPTY) stream8_offer(a, q, bv, (u32)(first + br));
     }
   }
-  if (!(a.ablate & 5)) {
+  if (!(S8_ABLATE & 5)) {
     __syncthreads();
     // (the offers are fire-and-forget atomics: a workgroup that gets here before k slots have been filled by anyone would test its
     // first chunk against "everything passes"; it waits for them, a few microseconds at most - bounded, then it takes what there is)
@@ -270,7 +278,7 @@ __global__ __launch_bounds__(256) void stream8_kernel(Stream8Args a) {
       }
     __syncthreads();
   }
-  if (a.ablate & 12) {
+  if (S8_ABLATE & 12) {
     __syncthreads();
     if (threadIdx.x < 4) T_s[threadIdx.x] = gkth_s[threadIdx.x] = 2147483647;
     __syncthreads();
@@ -282,7 +290,7 @@ __global__ __launch_bounds__(256) void stream8_kernel(Stream8Args a) {
     if (base + stride < a.n) load_chunk(base + stride, xa, a0a);
     // the thresholds are read again after 2, 4, 8 chunks (the table tightens fastest at the start: a stale threshold there is what lets
     // junk into the lists) and then every 8, the four wavefronts in turn (the refresher waits for 64 cache-bypassing loads)
-    if ((it == 1 || it == 3 || (it & 7) == 7) && wave == ((it >> 1) & 3) && !(a.ablate & 15)) refresh();   // (every 8 chunks, the four wavefronts in turn: the refresher waits for 64 cache-bypassing loads)
+    if ((it == 1 || it == 3 || (it & 7) == 7) && wave == ((it >> 1) & 3) && !(S8_ABLATE & 15)) refresh();   // (every 8 chunks, the four wavefronts in turn: the refresher waits for 64 cache-bypassing loads)
 #pragma unroll
     for (int uu = 0; uu < U; ++uu) dots(xb[uu], a0b[uu], acc[uu]);
     test_chunk(base, acc);

@@ -38,6 +38,11 @@ struct GraphDev {
   DevBuf counters;   // unsigned long long [2]
   DevBuf tail;       // u64 [nq][k] brute-force tail lists
   DevBuf q8, qstat8;       // prefilter: the batch on the mirror's grid, signed char [nq][d_pad8], float [nq][4]
+  // r5, edge constants: the mirror's row constant (acc0) of every neighbour, stored in the adjacency list's layout ([n][fixed_deg] int32), so that
+  // an expansion gets the constants of its neighbours in the access that fetches the list and the prefilter gathers nothing but the mirror rows.
+  // Valid for one build of the mirror (acc0_epoch); not used while the mirror folds per-batch margins into the constants.
+  DevBuf nbr_acc0;
+  int64_t acc0_epoch = -1;
   // the prefilter pays only where the 8-bit bound settles most neighbours (uniform-like value distributions: 82 % at 10M x 768);
   // where distances are small against the table's value range (clustered / low intrinsic dimension) most rows pass it and it is
   // pure overhead.  Judged on what the kernel counts: two consecutive searches in which more than 60 % of the neighbour evaluations
@@ -55,6 +60,7 @@ int32_t graph_upload(Index& ix) {
   g.init_L = -1;
   g.pf_strikes = 0;
   g.pf_off = false;
+  g.acc0_epoch = -1;
   const int64_t n = ix.n_indexed_;
   if (n <= 0) return EPS_OK;
   const int64_t e = ix.h_off_[n];
@@ -206,6 +212,14 @@ __global__ __launch_bounds__(64) void post_kernel(PostArgs a) {
   for (int i = res + lane; i < a.k; i += 64) a.run_keys[q * a.k + i] = KEY_EMPTY;
 }
 
+// edge constants: out[e] = acc0[nbr[e]] (0 on the padding of a list)
+__global__ void edge_acc0_kernel(const u32* nbr, const int* acc0, int* out, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const u32 v = nbr[i];
+    out[i] = v == 0xFFFFFFFFu ? 0 : acc0[v];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ host
 template <bool VEC4, int NW, bool QG, bool PF>
 static void launch_trv2(const Trv2Args& a, int slots, size_t shm, hipStream_t s) {
@@ -268,7 +282,7 @@ int32_t graph_search_impl(Index& ix, const float* dq, int64_t nq, int k, const e
   // the fp32 row and the table is beyond the caches; the filtered traversal logs EVERY evaluated distance, so it cannot skip any.
   // EPS_TRV_PREFILTER=0/1 overrides (A/B, small-table tests).
   bool prefilter = !filtered && ix.dim_ >= 128 && n >= 65536 && !g.pf_off;
-  const char* pf_env = getenv("EPS_TRV_PREFILTER");
+  const char* pf_env = tune_env("EPS_TRV_PREFILTER");
   if (pf_env) prefilter = !filtered && atoi(pf_env) != 0;
   Quant8View q8v;
   if (prefilter) {
@@ -281,27 +295,42 @@ int32_t graph_search_impl(Index& ix, const float* dq, int64_t nq, int k, const e
     }
     prefilter = q8v.x8 != nullptr;
   }
+  // edge constants (see GraphDev): fixed-stride lists, constants that do not change per batch, and room for one more copy of the lists
+  const int* nbr_acc0 = nullptr;
+  if (prefilter && g.fixed_deg > 0 && !q8v.per_batch) {
+    const int64_t total = n * g.fixed_deg;
+    if (g.acc0_epoch != q8v.epoch8) {
+      if (g.nbr_acc0.reserve((size_t)total * 4)) {
+        hipLaunchKernelGGL(edge_acc0_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 65536)), dim3(256), 0, ix.stream_, g.nbr.as<u32>(), q8v.acc0,
+                           g.nbr_acc0.as<int>(), total);
+        g.acc0_epoch = q8v.epoch8;
+      } else {
+        (void)hipGetLastError();   // (an optimisation: without it the kernel gathers acc0[id] as before)
+      }
+    }
+    if (g.acc0_epoch == q8v.epoch8) nbr_acc0 = g.nbr_acc0.as<int>();
+  }
   const size_t lds_need = traverse2_lds_bytes((int)ix.dim_, T, (int)Lq, qtot, dp, false, prefilter);
   // r3 (scripts/lab/trv_large_l2.sh, bench_random_graph.py): for BATCHES that band is better served with the queues in HBM and 8
   // wavefronts per query, two queries per CU (T = 4, L = 2000, batch 1024: 1M x 768 46.6 -> 39.4 ms, 10M-row proxy 56.8 -> 49.3 ms;
   // 4 wavefronts 64.6, 16 wavefronts 66.1), and 8 wavefronts also beat the 4 that queues in HBM used to get (L = 4000: 126.6 ->
   // 93.6 ms, L = 8000: 350.8 -> 246.7 ms).  A handful of queries (<= 256, latency) keeps the one-workgroup-per-CU form.
-  const size_t lds_limit = getenv("EPS_TRV_LDS_KB") ? (size_t)std::max(16, atoi(getenv("EPS_TRV_LDS_KB"))) * 1024
+  const size_t lds_limit = tune_env("EPS_TRV_LDS_KB") ? (size_t)std::max(16, atoi(tune_env("EPS_TRV_LDS_KB"))) * 1024
                                                      : (nq <= 256 ? (size_t)150 * 1024 : (size_t)80 * 1024);   // (A/B knob)
   const bool qglobal = lds_need > lds_limit;
   const bool one_per_cu = !qglobal && lds_need > (size_t)80 * 1024;
   const size_t shm = traverse2_lds_bytes((int)ix.dim_, T, (int)Lq, qtot, dp, qglobal, prefilter);
   // few queries: 16 wavefronts per query (latency); many queries: fewer per query (throughput, more queries per CU)
-  const char* waves_s = getenv("EPS_TRV_WAVES");
+  const char* waves_s = tune_env("EPS_TRV_WAVES");
   int nw = waves_s ? atoi(waves_s) : ((nq <= 256 || one_per_cu) ? 16 : (qglobal ? 8 : 4));
-  if (const char* wide_s = getenv("EPS_TRV_WIDE")) nw = atoi(wide_s) != 0 ? 16 : 4;   // (older switch)
+  if (const char* wide_s = tune_env("EPS_TRV_WIDE")) nw = atoi(wide_s) != 0 ? 16 : 4;   // (older switch)
   if (nw != 4 && nw != 8 && nw != 16) nw = 4;
   hipDeviceProp_t prop;
   er = hipGetDeviceProperties(&prop, ix.device_);
   if (er != hipSuccess) return ix.hip_fail(er, "device properties");
   const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   int per_cu = (int)std::min<size_t>((size_t)(16 / nw), (size_t)(160 * 1024) / shm);   // 4 wavefronts per SIMD at this register use (~104 VGPRs)
-  if (const char* pc = getenv("EPS_TRV_PER_CU")) per_cu = std::max(1, atoi(pc));
+  if (const char* pc = tune_env("EPS_TRV_PER_CU")) per_cu = std::max(1, atoi(pc));
   if (per_cu < 1) per_cu = 1;
   const int64_t words = (n + 31) / 32;
   int64_t slots = std::min<int64_t>(nq, (int64_t)cus * per_cu);
@@ -327,7 +356,7 @@ int32_t graph_search_impl(Index& ix, const float* dq, int64_t nq, int k, const e
   g.vis_dirty = true;   // until this search has completed
   er = hipMemsetAsync(g.counters.p, 0, 256, s);
   if (er != hipSuccess) return ix.hip_fail(er, "memset");
-  const bool prof = getenv("EPS_TRV_PROF") != nullptr;
+  const bool prof = tune_env("EPS_TRV_PROF") != nullptr;
 
   Trv2Args a;
   a.rows = ix.d_rows_;
@@ -360,6 +389,7 @@ int32_t graph_search_impl(Index& ix, const float* dq, int64_t nq, int k, const e
   a.elog_cap = (int)ecap;
   a.x8 = prefilter ? q8v.x8 : nullptr;
   a.acc0 = q8v.acc0;
+  a.nbr_acc0 = nbr_acc0;
   a.scal8 = q8v.scal8;
   a.d_pad8 = q8v.d_pad8;
   a.u8 = q8v.u;

@@ -63,6 +63,10 @@ struct Trv2Args {
   // without it (the proof is the flat engine's: device_common.hpp stage_threshold8).  x8 == null: off.
   const signed char* x8;         // [n_pad][d_pad8]
   const int* acc0;               // [n_pad]
+  // r5: the row constants of a node's neighbours stored WITH its adjacency list ([n][fixed_deg], same layout as nbr): an expansion reads them
+  // in the same access as the list, and the prefilter finds them in LDS instead of gathering 4 scattered bytes per evaluation (what bounds
+  // the kernel is the number of scattered locations per evaluation, profiles/r5_traverse_lab_10M_proxy.txt).  null: gather acc0[id].
+  const int* nbr_acc0;
   const float* scal8;            // the mirror's table-wide bounds (residual, |xh|, |x|^2, -, |R|)
   const signed char* q8;         // [nq][d_pad8] the queries on the same grid
   const float* qstat8;           // [nq][4] |q|^2, |q|, |q - qh|, C + c
@@ -73,11 +77,14 @@ struct Trv2Args {
 #ifndef EPS_TRV_U
 #define EPS_TRV_U 4   // rows in flight per lane group in the distance phases
 #endif
+#ifndef EPS_TRV_UPF
+#define EPS_TRV_UPF 3  // prefilter form of the kernel: fp32 rows in flight per lane group (seeds, survivors of step d0) ...
+#endif
 #ifndef EPS_TRV_NL
-#define EPS_TRV_NL 1   // 16-byte pieces of an fp32 row a lane has in flight in the prefilter form of the kernel (row_dists, device_common.hpp; 3 measured: mixed)
+#define EPS_TRV_NL 3   // ... and 16-byte pieces of each (row_dists, device_common.hpp).  r5: 3 x 3 (4 x 1 until r4; profiles/r5_traverse_lab_10M_proxy.txt)
 #endif
 #ifndef EPS_TRV_U8
-#define EPS_TRV_U8 2   // prefilter: mirror rows in flight per lane group ...
+#define EPS_TRV_U8 3   // prefilter: mirror rows in flight per lane group (2 until r4) ...
 #endif
 #ifndef EPS_TRV_NL8
 #define EPS_TRV_NL8 3  // ... and 16-byte pieces of each per lane
@@ -144,6 +151,8 @@ __global__ __launch_bounds__(NW * 64, PF ? 4 : 1) void traverse2_kernel(Trv2Args
   u32* eraw = eid + ecap;                                                   // [ecap] 1 = this slot's atomicOr set the bit
   u32* work = eraw + ecap;                                                  // [ecap] ids to evaluate, per worker segment
   int* npos = reinterpret_cast<int*>(work + ecap);                          // [ecap] insert positions
+  int* eacc = reinterpret_cast<int*>(newk);                                 // PF, nbr_acc0: [ecap] row constant per edge slot (steps b-c; `newk` is written from step d on)
+  int* wacc = eacc + ecap;                                                  //               [ecap] ... per entry of `work` (steps c-d0)
   const int H = a.hslots;                                                   // ownership table slots (power of two; 0 when T == 1)
   u32* hid = reinterpret_cast<u32*>(npos + ecap);                           // [H] node id, TRV2_NONE = empty
   int* hmin = reinterpret_cast<int*>(hid + H);                              // [H] lowest edge slot that met the node this step
@@ -183,7 +192,7 @@ __global__ __launch_bounds__(NW * 64, PF ? 4 : 1) void traverse2_kernel(Trv2Args
   const int RPW = 64 / G;
   const int g = lane / G;
   const int t = lane & (G - 1);
-  constexpr int U = EPS_TRV_U;
+  constexpr int U = PF ? EPS_TRV_UPF : EPS_TRV_U;
   const int64_t slot = blockIdx.x;
   u32* vis = a.visited + slot * a.words;
   u32* vlog = a.vlog + slot * (int64_t)a.vcap;
@@ -407,6 +416,7 @@ __global__ __launch_bounds__(NW * 64, PF ? 4 : 1) void traverse2_kernel(Trv2Args
           if (j < s_deg[w]) {
             const int64_t rowbase = a.fixed_deg > 0 ? (int64_t)node * a.fixed_deg : a.off[node];
             nb = a.nbr[rowbase + j];
+            if (PF && a.nbr_acc0) eacc[e] = a.nbr_acc0[rowbase + j];
           }
           u32 raw = 0;
           if (nb != TRV2_NONE) {
@@ -471,6 +481,7 @@ __global__ __launch_bounds__(NW * 64, PF ? 4 : 1) void traverse2_kernel(Trv2Args
             while (w < T - 1 && e >= s_eoff[w + 1]) ++w;
             const int pos = atomicAdd(&s_wcnt[w], 1);
             work[s_eoff[w] + pos] = nb;
+            if (PF && a.nbr_acc0) wacc[s_eoff[w] + pos] = eacc[e];
             const int ls = atomicAdd(&sh[2], 1);
             if (ls < a.vcap) vlog[ls] = nb; else sh[7] = 1;
           }
@@ -518,7 +529,7 @@ __global__ __launch_bounds__(NW * 64, PF ? 4 : 1) void traverse2_kernel(Trv2Args
               wslot[u] = ok ? ((w << 16) | sl) : -1;
               const u32 id = work[sl];
               rp8[u] = a.x8 + (int64_t)id * a.d_pad8;
-              a0[u] = t8 == 0 ? a.acc0[id] : 0;    // (in flight with the row pieces)
+              a0[u] = t8 == 0 ? (a.nbr_acc0 ? wacc[sl] : a.acc0[id]) : 0;    // (gathered: in flight with the row pieces)
               dot[u] = 0;
             }
 #pragma unroll 1
