@@ -95,7 +95,7 @@ void ANNGraphSegment::BuildFromVectorTable(VectorColumnData vector_column, int64
   // device 0, uploaded the whole table again and freed it).  With EPS_DEVICES the mirror is hash-sharded and every shard builds
   // and keeps the graph of its own rows on its own device.
   int64_t *off = nullptr, *nbr = nullptr, nav = 0;
-  const std::string err = epsdrop::BuildGraphOnMirror(std::get<DenseVectorColumnDataContainer>(vector_column), n, dim, ToEpsMetric(metricType), this, &off, &nbr,
+  const std::string err = epsdrop::BuildGraphOnMirror(std::get<DenseVectorColumnDataContainer>(vector_column), n, dim, ToEpsMetric(metricType), OwnerKey(), &off, &nbr,
                                                       &nav, &device_mirror_);
   if (!err.empty()) throw std::runtime_error("gfx950 graph build: " + err);
   delete[] offset_table_;

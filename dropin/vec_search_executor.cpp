@@ -11,7 +11,9 @@
 #include "db/execution/vec_search_executor.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -89,6 +91,28 @@ struct DeviceField {
     if (pending_h) eps_index_destroy(pending_h);
   }
 };
+
+// eps_index_search for the adapter.  The reference accepts SearchQueueSize / LocalQueueSize up to 10^7 and IntraQueryThreads up to 128 at any
+// out-degree (config/config.hpp:29, 37-44); the device traversal runs queues up to 2^20 keys and IntraQueryThreads x out-degree <= 2048
+// (csrc/traverse.hip) and REFUSES the rest (EPS_DB_UNSUPPORTED_ERROR) rather than run another configuration.  The reference would never
+// answer such a Search with an error, so the adapter answers it with the exact scan (the result every graph configuration approximates; the
+// reference's result-count caps are applied by the callers as for any search) and says so once.  VERDICT r4 #10.
+static int32_t SearchOrExactScan(eps_index* h, const float* q, int64_t nq, int32_t k, eps_search_params* p, int64_t* ids, float* dist, int32_t* cnt) {
+  int32_t rc = eps_index_search(h, q, nq, k, p, ids, dist, cnt);
+  if (rc == EPS_DB_UNSUPPORTED_ERROR && p->mode != EPS_MODE_FLAT) {
+    const char* why = eps_index_last_error(h);
+    const bool range = why && (std::strstr(why, "SearchQueueSize") || std::strstr(why, "LocalQueueSize") || std::strstr(why, "IntraQueryThreads"));
+    if (range) {
+      static std::atomic<bool> said{false};
+      if (!said.exchange(true))
+        fprintf(stderr, "[gfx950 executor] %s - this configuration is answered by the exact scan (recall 1.0) from now on\n", why);
+      eps_search_params flat = *p;
+      flat.mode = EPS_MODE_FLAT;
+      rc = eps_index_search(h, q, nq, k, &flat, ids, dist, cnt);
+    }
+  }
+  return rc;
+}
 
 // dev.mu held.  A search of the segment `owner` arrives: if the rebuild that produced that segment left its index waiting, it becomes
 // the serving index now - the rows appended since the build's snapshot are added from the host column (only they cross PCIe), the
@@ -340,15 +364,16 @@ Status VecSearchExecutor::Search(const VectorPtr query_data, vectordb::engine::T
     dev.attached = total_vector;
   }
   {
-    const std::string aerr = AdoptPendingBuild(dev, ann_index_.get(), dimension_);
+    const std::string aerr = AdoptPendingBuild(dev, ann_index_->OwnerKey(), dimension_);
     if (!aerr.empty()) throw std::runtime_error(aerr);
   }
   // (an executor of the segment a rebuild just replaced finishes on the new graph: uploading its old CSR again would only be undone by
   // the next search of the new segment)
-  if (!dev.sharded && ann_index_.get() != dev.retired_owner && (dev.graph_owner != ann_index_.get() || dev.graph_n != total_indexed_vector_)) {
+  if (!dev.sharded && ann_index_->OwnerKey() != dev.retired_owner && (dev.graph_owner != ann_index_->OwnerKey() || dev.graph_n != total_indexed_vector_)) {
     if (eps_index_set_graph(dev.h, total_indexed_vector_, offset_table_, neighbor_list_, start_search_point_) != EPS_OK)
       return fail("graph upload");
-    dev.graph_owner = ann_index_.get();
+    dev.graph_owner = ann_index_->OwnerKey();
+    dev.retired_owner = nullptr;   // (another segment's graph is in HBM now: nobody runs "on the graph that replaced mine" any more)
     dev.graph_n = total_indexed_vector_;
   }
 
@@ -393,7 +418,7 @@ Status VecSearchExecutor::Search(const VectorPtr query_data, vectordb::engine::T
     // A sharded mirror walks graphs only if its shards hold the graphs of THIS executor's segment (BuildGraphOnMirror) - and never for
     // a host-evaluated filter: the brute-force branch below hands the shards a full visibility mask and expects an EXACT scan, a
     // per-shard walk would judge the mask on its top-L only and return too few rows (RunSearch has the same rule)
-    const bool shard_graph = dev.shard_graph_owner == ann_index_.get() && dev.shard_graph_n == total_indexed_vector_ && total_indexed_vector_ > 0;
+    const bool shard_graph = dev.shard_graph_owner == ann_index_->OwnerKey() && dev.shard_graph_n == total_indexed_vector_ && total_indexed_vector_ > 0;
     if (host_filter || !shard_graph) p.mode = EPS_MODE_FLAT;
   }
   auto publish = [&](const int64_t* ids, const float* dist, int64_t count) {
@@ -419,7 +444,7 @@ Status VecSearchExecutor::Search(const VectorPtr query_data, vectordb::engine::T
     std::vector<int64_t> ids((size_t)k);
     std::vector<float> dist((size_t)k);
     int32_t count = 0;
-    if (eps_index_search(dev.h, std::get<DenseVectorPtr>(query_data), 1, k, &p, ids.data(), dist.data(), &count) != EPS_OK)
+    if (SearchOrExactScan(dev.h, std::get<DenseVectorPtr>(query_data), 1, k, &p, ids.data(), dist.data(), &count) != EPS_OK)
       return fail("search");
     publish(ids.data(), dist.data(), count);
     return Status::OK();
@@ -513,7 +538,7 @@ Status VecSearchExecutor::Search(const VectorPtr query_data, vectordb::engine::T
     std::vector<int64_t> ids((size_t)k);
     std::vector<float> dist((size_t)k);
     int32_t count = 0;
-    if (eps_index_search(dev.h, std::get<DenseVectorPtr>(query_data), 1, k, &p, ids.data(), dist.data(), &count) != EPS_OK)
+    if (SearchOrExactScan(dev.h, std::get<DenseVectorPtr>(query_data), 1, k, &p, ids.data(), dist.data(), &count) != EPS_OK)
       return fail("search");
     publish(ids.data(), dist.data(), count);
   }
@@ -544,7 +569,7 @@ std::string RunSearch(DeviceField& dev, int64_t dim, const Pending& h, const flo
   if (err.empty()) err = AdoptPendingBuild(dev, h.graph_owner, dim);
   if (err.empty() && !dev.sharded && h.graph_owner != dev.retired_owner && (dev.graph_owner != h.graph_owner || dev.graph_n != h.graph_n)) {
     if (eps_index_set_graph(dev.h, h.graph_n, h.off, h.nbr, h.start_point) != EPS_OK) fail("graph upload");
-    else { dev.graph_owner = h.graph_owner; dev.graph_n = h.graph_n; }
+    else { dev.graph_owner = h.graph_owner; dev.graph_n = h.graph_n; dev.retired_owner = nullptr; }
   }
   ConcurrentBitset& deleted = *(h.segment->deleted_);
   if (err.empty() && eps_index_set_int_filter(dev.h, nullptr, 0, 0, EPS_OP_NONE, 0) != EPS_OK) fail("filter reset");
@@ -572,7 +597,12 @@ std::string RunSearch(DeviceField& dev, int64_t dim, const Pending& h, const flo
     // row they evaluate instead of the final top-L walk, so selective filters still return `limit` rows
     static const bool filter_in_traversal = getenv("EPS_DROPIN_FILTER_IN_TRAVERSAL") && atoi(getenv("EPS_DROPIN_FILTER_IN_TRAVERSAL")) != 0;
     p.filter_in_traversal = filter_in_traversal ? 1 : 0;
-    if (eps_index_search(dev.h, q, nq, h.k, &p, ids, dist, cnt) != EPS_OK) fail("search");
+    // EPS_DROPIN_BATCH_T1=1 (opt-in, NOT the reference's knob setting): the reference's IntraQueryThreads spreads ONE query over cores to cut its
+    // latency; a device batch of >= 64 queries fills the GPU with queries instead, and at equal recall one worker per query is the faster walk there
+    // (10M x 768 manifold set, L = 100, batch 1024: 519.6 k q/s at T = 1 vs 431.5 k at T = 4, profiles/r4_graph_10Mx768_manifold_sweep.jsonl)
+    static const bool batch_t1 = getenv("EPS_DROPIN_BATCH_T1") && atoi(getenv("EPS_DROPIN_BATCH_T1")) != 0;
+    if (batch_t1 && nq >= 64) p.intra_threads = 1;
+    if (SearchOrExactScan(dev.h, q, nq, h.k, &p, ids, dist, cnt) != EPS_OK) fail("search");
   }
   return err;
 }
@@ -608,7 +638,7 @@ void VecSearchExecutor::FillKey(Pending& me, vectordb::engine::TableSegmentMVP* 
   want = std::min<size_t>(want, (size_t)std::max<int64_t>(table_segment->record_number_, 1));
   if (want > ((size_t)1 << 20)) throw std::runtime_error("gfx950 executor: more than 1048576 results per query are not supported");
   me.k = (int32_t)want;
-  me.graph_owner = ann_index_.get();
+  me.graph_owner = ann_index_->OwnerKey();
   me.graph_n = total_indexed_vector_;
   me.start_point = start_search_point_;
   me.off = offset_table_;
@@ -791,6 +821,41 @@ std::string epsdrop::BuildGraphOnMirror(const float* column, int64_t n, int64_t 
   // and the old graph keep serving - what the reference's Rebuild does with its snapshot of rows [0, n) (table_mvp.cpp:133-195).
   // The finished index is adopted by the first search of the new segment's executors (AdoptPendingBuild).  If the copy does not fit
   // (tables beyond half of the HBM) the build runs in place under the lock, as in r3.
+  // the build IN PLACE, on the serving index, dev.mu held (r3 behaviour): when a second copy of the rows does not fit, and when the side build
+  // itself runs out of HBM (copy + build scratch + 8-bit mirror next to the serving index)
+  auto build_in_place_locked = [&]() -> std::string {
+    auto fail = [&](const char* what) { return std::string(what) + ": " + eps_index_last_error(dev.h); };
+    if (dev.pending_h) {   // (a side build of an older segment that nobody adopted: it only holds HBM, and must not be adopted over this graph)
+      eps_index_destroy(dev.pending_h);
+      dev.pending_h = nullptr;
+      dev.pending_owner = nullptr;
+      dev.pending_n = -1;
+    }
+    if (eps_index_build(dev.h, n, nullptr) != EPS_OK) return fail("build");   // defaults = NSGConfig(45,50,300,100)
+    dev.retired_owner = nullptr;
+    if (dev.sharded) {
+      *off = new int64_t[n + 1]();
+      *nbr = new int64_t[1]();
+      *nav = 0;
+      dev.shard_graph_owner = owner;
+      dev.shard_graph_n = n;
+    } else {
+      int64_t gn = 0, edges = 0;
+      eps_index_graph_info(dev.h, &gn, &edges, nav);
+      *off = new int64_t[gn + 1];
+      *nbr = new int64_t[edges > 0 ? edges : 1];
+      if (eps_index_get_graph(dev.h, *off, *nbr) != EPS_OK) {
+        delete[] *off;
+        delete[] *nbr;
+        *off = *nbr = nullptr;
+        return fail("get_graph");
+      }
+      dev.graph_owner = owner;   // the device index already holds this graph: the segment's executors need not upload it again
+      dev.graph_n = n;
+    }
+    *keep = devp;
+    return "";
+  };
   eps_index* side = nullptr;
   {
     std::lock_guard<std::mutex> lk(dev.mu);
@@ -810,31 +875,7 @@ std::string epsdrop::BuildGraphOnMirror(const float* column, int64_t n, int64_t 
         side = nullptr;
       }
     }
-    if (!side) {   // in place, holding the lock (r3 behaviour)
-      if (eps_index_build(dev.h, n, nullptr) != EPS_OK) return fail("build");   // defaults = NSGConfig(45,50,300,100)
-      if (dev.sharded) {
-        *off = new int64_t[n + 1]();
-        *nbr = new int64_t[1]();
-        *nav = 0;
-        dev.shard_graph_owner = owner;
-        dev.shard_graph_n = n;
-      } else {
-        int64_t gn = 0, edges = 0;
-        eps_index_graph_info(dev.h, &gn, &edges, nav);
-        *off = new int64_t[gn + 1];
-        *nbr = new int64_t[edges > 0 ? edges : 1];
-        if (eps_index_get_graph(dev.h, *off, *nbr) != EPS_OK) {
-          delete[] *off;
-          delete[] *nbr;
-          *off = *nbr = nullptr;
-          return fail("get_graph");
-        }
-        dev.graph_owner = owner;   // the device index already holds this graph: the segment's executors need not upload it again
-        dev.graph_n = n;
-      }
-      *keep = devp;
-      return "";
-    }
+    if (!side) return build_in_place_locked();
   }
   // ---- the build itself: on the side index, nobody waits for it
   auto sfail = [&](const char* what) {
@@ -842,7 +883,13 @@ std::string epsdrop::BuildGraphOnMirror(const float* column, int64_t n, int64_t 
     eps_index_destroy(side);
     return e;
   };
-  if (eps_index_build(side, n, nullptr) != EPS_OK) return sfail("build");
+  if (eps_index_build(side, n, nullptr) != EPS_OK) {
+    // (most likely HBM: the side copy fitted, the build next to the serving index did not) - once more in place, as r3 built every table
+    eps_index_destroy(side);
+    side = nullptr;
+    std::lock_guard<std::mutex> lk(dev.mu);
+    return build_in_place_locked();
+  }
   if (dev.sharded) {
     *off = new int64_t[n + 1]();
     *nbr = new int64_t[1]();

@@ -7,6 +7,7 @@
 #pragma once
 
 #include <atomic>
+#include <cstdint>
 #include <memory>
 #include <string>
 #include <unordered_map>
@@ -48,6 +49,16 @@ class ANNGraphSegment {
   int64_t* neighbor_list_;   // new[]-owned CSR neighbours
   int64_t navigation_point_;
   std::shared_ptr<void> device_mirror_;   // (additive) keeps the field's device mirror - which holds this graph - alive with the graph
+  // (additive) identity of this segment for the device mirror's bookkeeping ("whose graph is in HBM"): a process-wide serial number, never
+  // reused - the segment's ADDRESS is (a freed segment's address can be handed to the next one).  Travels as an opaque key.
+  const uint64_t uid_ = NextUid();
+  const void* OwnerKey() const { return reinterpret_cast<const void*>(static_cast<uintptr_t>(uid_)); }
+
+ private:
+  static uint64_t NextUid() {
+    static std::atomic<uint64_t> next{1};
+    return next.fetch_add(1, std::memory_order_relaxed);
+  }
 };
 
 }  // namespace engine

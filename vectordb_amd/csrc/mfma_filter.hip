@@ -103,6 +103,9 @@ struct HalfMirror {
   DevBuf s8g, s8raw;            // table slots (S8_TABLE_WORDS) + per-wavefront candidate counts;  u64 [nq][waves][S8_WAVE_CAP]
   int64_t s8_declined_version = -1;   // rows version on which the one-pass form overflowed twice in a row (the staged chain serves it)
   int s8_overflows = 0;
+  // under a deleted bitset / an int-column filter an overflow usually means "fewer than k rows visible": the rows' version says nothing
+  // about it, so two such overflows in a row make the next 32 filtered calls go straight to the staged chain, then the one-pass form is tried again
+  int s8_filt_overflows = 0, s8_filt_skip = 0;
   int s8_cus = 0;               // CUs of the device (grid of the one-pass kernel)
   int64_t extended_rows8 = 0;
   int64_t version = -1;
@@ -955,7 +958,7 @@ bool flat_mfma_profitable(const Index& ix, int64_t nq, int k) {
   const double rate = use8 ? 2.0e15 : 1.2e15;                    // matrix rate the filter kernel reaches
   const double dp = use8 ? op_bytes : op_bytes / 2.0;
   const double stream_s = std::ceil((double)nq / 4.0) * rows * d * 4.0 / 6.0e12 + 0.2e-3;
-  const double filter_s = (use8 && one_pass_shape && !(have8 && m->fold8))
+  const double filter_s = (use8 && one_pass_shape && !(have8 && m->fold8) && !ix.filter_spec().prog)   // (filter programs never take the one-pass form)
                               ? 0.07e-3 + rows * (std::ceil(d / 256.0) * 256.0 + 4.0) / 5.7e12
                               : 0.35e-3 + std::max(rows * op_bytes / 5.0e12, 2.0 * 128.0 * std::ceil((double)nq / 128.0) * rows * dp / rate);
   return filter_s < stream_s;
@@ -973,6 +976,10 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
   if (m.s8_declined_version == ix.rows_version_) return EPS_OK;
   const FilterSpec fs = ix.filter_spec();
   if (fs.prog) return EPS_OK;   // (filter programs: the staged chain; a deleted bitset and an int-column filter are handled in the pass)
+  if ((fs.deleted || fs.column) && m.s8_filt_skip > 0) {   // (a mask that starves the pass used to cost a wasted pass on EVERY call)
+    --m.s8_filt_skip;
+    return EPS_OK;
+  }
   hipStream_t s = ix.stream_;
   const int cap = std::max(4096, 64 * k);
   if (!m.qstat.reserve((size_t)4 * 16) || !m.q8.reserve((size_t)4 * m.d_pad8) || !m.cand.reserve((size_t)nq * cap * 8) || !m.cnt.reserve((size_t)(nq + 4) * 4 + 16) ||
@@ -1105,10 +1112,17 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
   }
   if (h.overflow) {   // (too loose a bound for this table, or a filter that leaves fewer than k rows visible: the staged chain answers)
     ix.result_finalized_ = false;
-    if (!(fs.deleted || fs.column) && ++m.s8_overflows >= 2) m.s8_declined_version = ix.rows_version_;
+    if (fs.deleted || fs.column) {
+      if (++m.s8_filt_overflows >= 2) {
+        m.s8_filt_overflows = 0;
+        m.s8_filt_skip = 32;
+      }
+    } else if (++m.s8_overflows >= 2) {
+      m.s8_declined_version = ix.rows_version_;
+    }
     return EPS_OK;
   }
-  m.s8_overflows = 0;
+  if (fs.deleted || fs.column) m.s8_filt_overflows = 0; else m.s8_overflows = 0;
   if (fin_here) ix.result_finalized_ = true;
   ix.stats_.rerank_rows += (int64_t)h.total;
   ix.stats_.dist_evals += nq * n;

@@ -51,6 +51,7 @@ class ShardGroup : public IndexBase {
     free_on(dev0, gathered_);
     free_on(dev0, m_ids_);
     free_on(dev0, m_dist_);
+    if (merge_done_) (void)hipEventDestroy(merge_done_);
   }
 
   int32_t init(const int32_t* devices, int32_t shards, std::string* err) {
@@ -282,6 +283,11 @@ class ShardGroup : public IndexBase {
         return fail(EPS_INFRA_UNEXPECTED_ERROR, "search: out of device memory (shard merge)");
       cap_ = nk;
       merge_dev_ = mdev;
+      merge_pending_ = false;   // (hipFree waited for everything that read the old buffer)
+      if (merge_done_) {        // (an event belongs to the device it was created on)
+        (void)hipEventDestroy(merge_done_);
+        merge_done_ = nullptr;
+      }
     }
     stride_ = (nk * 12 + 7) / 8 * 8;   // (the gathered layout of THIS call; the buffer holds at least cap_ entries per shard)
     local_ids_.resize((size_t)G());
@@ -304,6 +310,12 @@ class ShardGroup : public IndexBase {
       if (r != EPS_OK) return r;
       // the one exchange step: this shard's [nq][k] lists -> the merging device, peer to peer over xGMI
       char* dst = static_cast<char*>(gathered_) + (size_t)s * stride_;
+      // (a merge with device results returns without a host sync: the previous call's merge may still be READING gathered_ on the merging
+      // shard's stream - this shard's copy into it waits for that merge's event)
+      if (merge_pending_) {
+        const hipError_t ew = hipStreamWaitEvent(ix.stream_, merge_done_, 0);
+        if (ew != hipSuccess) return ix.hip_fail(ew, "wait for the previous shard merge");
+      }
       hipError_t e = hipMemcpyPeerAsync(dst, mdev, local_ids_[s].p, ix.device_, nk * 8, ix.stream_);
       if (e == hipSuccess) e = hipMemcpyPeerAsync(dst + nk * 8, mdev, local_dist_[s].p, ix.device_, nk * 4, ix.stream_);
       if (e == hipSuccess) e = hipStreamSynchronize(ix.stream_);
@@ -315,8 +327,11 @@ class ShardGroup : public IndexBase {
     const float* gd = reinterpret_cast<const float*>(static_cast<char*>(gathered_) + nk * 8);
     if (r_dev >= 0) {   // device results: merged straight into the caller's buffers; the caller synchronises (eps_index_synchronize)
       launch_merge_shards(gd, static_cast<const int64_t*>(gathered_), G(), nq, k, dist, ids, s0, (int64_t)stride_, counts);
-      const hipError_t e = hipGetLastError();
+      hipError_t e = hipGetLastError();
+      if (e == hipSuccess && !merge_done_) e = hipEventCreateWithFlags(&merge_done_, hipEventDisableTiming);
+      if (e == hipSuccess) e = hipEventRecord(merge_done_, s0);
       if (e != hipSuccess) return fail(EPS_INFRA_UNEXPECTED_ERROR, std::string("shard merge: ") + hipGetErrorString(e));
+      merge_pending_ = true;
       return EPS_OK;
     }
     launch_merge_shards(gd, static_cast<const int64_t*>(gathered_), G(), nq, k, static_cast<float*>(m_dist_), static_cast<int64_t*>(m_ids_), s0, (int64_t)stride_);
@@ -324,6 +339,7 @@ class ShardGroup : public IndexBase {
     if (e == hipSuccess) e = hipMemcpyAsync(dist, m_dist_, nk * 4, hipMemcpyDeviceToHost, s0);
     if (e == hipSuccess) e = hipStreamSynchronize(s0);
     if (e != hipSuccess) return fail(EPS_INFRA_UNEXPECTED_ERROR, std::string("shard merge: ") + hipGetErrorString(e));
+    merge_pending_ = false;
     if (counts)
       for (int64_t q = 0; q < nq; ++q) {
         int32_t c = 0;
@@ -394,6 +410,8 @@ class ShardGroup : public IndexBase {
   void* m_ids_ = nullptr;
   void* m_dist_ = nullptr;
   size_t cap_ = 0, stride_ = 0;
+  hipEvent_t merge_done_ = nullptr;   // recorded behind a merge that returned without a host sync (device result buffers)
+  bool merge_pending_ = false;
   // worker pool
   std::vector<std::thread> pool_;
   std::mutex pool_mu_;

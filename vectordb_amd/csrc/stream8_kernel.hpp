@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void stream8_kernel(Stream8Args a) {
     if (base + stride < a.n) load_chunk(base + stride, xa, a0a);
     // the thresholds are read again after 2, 4, 8 chunks (the table tightens fastest at the start: a stale threshold there is what lets
     // junk into the lists) and then every 8, the four wavefronts in turn (the refresher waits for 64 cache-bypassing loads)
-    if ((it == 1 || it == 3 || (it & 7) == 7) && wave == ((it >> 1) & 3) && !(S8_ABLATE & 15)) refresh();   // (every 8 chunks, the four wavefronts in turn: the refresher waits for 64 cache-bypassing loads)
+    if ((it == 1 || it == 3 || (it & 7) == 7) && wave == (((it >> 1) + (it >> 3)) & 3) && !(S8_ABLATE & 15)) refresh();   // (it = 1, 3, 7, 15, 23, 31, ... -> wavefront 0, 1, 3, 0, 1, 2, ...: in turn - until r4 the steady state always picked wavefront 3)
 #pragma unroll
     for (int uu = 0; uu < U; ++uu) dots(xb[uu], a0b[uu], acc[uu]);
     test_chunk(base, acc);
