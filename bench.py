@@ -157,10 +157,12 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline legs (0 = skip)")
     ap.add_argument("--power-seconds", type=float, default=2.0, help="N = 1: after the timed region the same step runs back to back for this long while the shader clock and "
                     "socket power are sampled (roofline.under_load; 0 = skip)")
+    ap.add_argument("--no-e2e", dest="e2e", action="store_false", help="skip the end-to-end (host -> host, pipelined) repetition of the timed steps")
     ap.add_argument("--scale", default="rows", choices=["queries", "rows"])
     ap.add_argument("--inproc", action="store_true", help="N > 1 in ONE process: eps_index_create_sharded over devices 0..N-1 (the form the single-process "
                                                           "reference DBMS uses), per-shard lists merged on the caller's device; no torch.distributed")
-    ap.add_argument("--configs", default="c2,c4,secondary", help="further BASELINE configs measured into the line's `configs` object at N = 1: c2 (1M x 768, batch 1, latency), "
+    ap.add_argument("--configs", default="c1,c2,c4,secondary,embedding", help="further BASELINE configs measured into the line's `configs` object at N = 1: c1 (configs[0]: 100k x 128 through both "
+                                                     "`epsilla` modules), embedding (unit-norm Gaussian rows with dominant dimensions, COSINE, on the --rows table), c2 (1M x 768, batch 1, latency), "
                                                      "c4 (COSINE + ID < N filter on the --rows table, batch --batch), secondary (SURVEY 8d clustered set + the manifold set at --graph-rows: "
                                                      "flat and graph legs); 'none' skips them")
     return ap.parse_args()
@@ -255,7 +257,7 @@ class CpuBaseline:
         return {"value": done * rows.shape[0] / sec / self.n, "unit": "queries/s", "cores": 1, "kind": "port",
                 "sample": "%d scalar scans of a %d-row sample, scaled to %d rows (oracle/_ref absent)" % (done, rows.shape[0], self.n)}
 
-    def bruteforce(self, Qh, k, gt_ids, budget_s, rows=None, metric=0):
+    def bruteforce(self, Qh, k, gt_ids, budget_s, rows=None, metric=0, gpu_ids=None):
         """leg "bruteforce": VecSearchExecutor::BruteForceSearch (:717-768) over the first `rows` rows, OpenMP over all cores -
         exact, so it is the reference's answer at recall >= 0.999 whenever its traversal needs a queue so long that it evaluates
         most of the table (uniform data: profiles/r2_graph_*.jsonl)"""
@@ -271,7 +273,9 @@ class CpuBaseline:
         qps = (nbq - 1) / float(np.sum(sec[1:])) if nbq > 1 else 1.0 / float(sec[0])   # first query pays the scratch allocation
         return {"leg": "bruteforce", "what": "reference VecSearchExecutor::BruteForceSearch over %d x %d rows, %d OpenMP threads" % (n, d, threads),
                 "qps": qps, "queries": nbq, "p50_ms": 1e3 * float(np.median(sec[1:] if nbq > 1 else sec)), "p99_ms": 1e3 * float(np.max(sec[1:] if nbq > 1 else sec)),
-                "recall_at_10": recall_of(ids, gt_ids[:nbq]) if gt_ids is not None else None, "evals_per_query": n, "effective_GBps": qps * n * d * 4 / 1e9}
+                "recall_at_10": recall_of(ids, gt_ids[:nbq]) if gt_ids is not None else None, "evals_per_query": n, "effective_GBps": qps * n * d * 4 / 1e9,
+                # the GPU's answers for the same queries (the timed path's last step), position by position against the reference's own
+                "gpu_headline_answers_equal": (int(sum(bool(np.array_equal(ids[i], gpu_ids[i])) for i in range(nbq))) if gpu_ids is not None else None)}
 
     def distance_scan(self, Qh, k, gt_ids, budget_s):
         """the distance phase of that brute force on its own (GetDistFunc under `omp parallel for`, :729-735) + an O(n) top-k
@@ -321,13 +325,13 @@ class CpuBaseline:
                 "visible_rows": int(cnt[0]), "recall_at_10": recall_of(ids, gt_ids[:len(sec)]) if gt_ids is not None else None}
 
 
-def cpu_baseline(cpu, args, X, Q, gt_ids, graph, budget_s):
+def cpu_baseline(cpu, args, X, Q, gt_ids, graph, budget_s, gpu_ids=None):
     """the `cpu_baseline` object of the headline line (BASELINE configs[2]): legs bruteforce / distance_scan_only / graph"""
     n, d, k = cpu.n, cpu.d, args.k
     if cpu.ref is None:
         return cpu.port(X, Q, budget_s)
     Qh = Q.cpu().numpy()
-    legs = [cpu.bruteforce(Qh, k, gt_ids, budget_s * 0.6), cpu.distance_scan(Qh, k, gt_ids, budget_s * 0.1)]
+    legs = [cpu.bruteforce(Qh, k, gt_ids, budget_s * 0.6, gpu_ids=gpu_ids), cpu.distance_scan(Qh, k, gt_ids, budget_s * 0.1)]
     if graph is not None:
         legs.append(cpu.graph(graph, Qh, k, args.L if args.mode == "graph" else 500, budget_s * 0.3))
     # the baseline of record is the best path the REFERENCE itself offers at recall >= 0.999 on the full table
@@ -355,16 +359,17 @@ def config_c2(amd, torch, args, X, qlast, dev, stream, local_rank, cpu, graph_in
         for i in range(3):
             index.search(qlast[i:i + 1], k, out=o, **kw)
         torch.cuda.synchronize()
-        lat, res = [], []
+        lat, res, one = [], [], 0
         for i in range(nq1):
             t0 = time.perf_counter()
             index.search(qlast[i:i + 1], k, out=o, **kw)
             torch.cuda.synchronize()
             lat.append(time.perf_counter() - t0)
             res.append(o[0][0].cpu().numpy().copy())
+            one += int(index.stats().get("one_pass", 0))
         km = index.kernel_times(64)
         return {"p50_ms": 1e3 * float(np.median(lat)), "p99_ms": 1e3 * float(np.percentile(lat, 99)), "qps": nq1 / float(np.sum(lat)), "queries": nq1,
-                "main_kernel_ms": float(np.median(km)) if km else None}, np.stack(res)
+                "main_kernel_ms": float(np.median(km)) if km else None, "one_pass_calls": one}, np.stack(res)
     gpu = {}
     gpu["stream"], gt1 = latency(ix, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
     if gpu["stream"]["main_kernel_ms"]:
@@ -377,6 +382,8 @@ def config_c2(amd, torch, args, X, qlast, dev, stream, local_rank, cpu, graph_in
     gpu["mfma_i8"], r8 = latency(ix, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
     gpu["mfma_i8"]["recall_at_10"] = recall_of(r8, gt1)
     gpu["mfma_i8"]["one_pass"] = int(ix.stats().get("one_pass", 0))   # r4: 1 = ONE streaming pass over the 8-bit mirror + one re-rank (stream8_kernel)
+    # r5: how many of the leg's calls the one-pass form answered; the others overflowed a wavefront's list and were answered by the staged chain
+    gpu["mfma_i8"]["one_pass_fallbacks"] = gpu["mfma_i8"]["queries"] - gpu["mfma_i8"]["one_pass_calls"]
     if gpu["mfma_i8"]["one_pass"]:
         # the pass itself against the HBM roofline: timed in a second run (an event pair around it costs the untimed call ~10 us)
         amd.set_tuning("EPS_ONE_PASS_TIMED", "1")
@@ -466,6 +473,92 @@ def config_c4(amd, torch, args, X, qlast, dev, stream, local_rank, cpu):
         except Exception as e:
             out["cpu_reference"] = {"failed": repr(e)}
     del Xn
+    return out
+
+
+def config_c1(args):
+    """BASELINE configs[0]: 100k x 128 VECTOR_FLOAT EUCLIDEAN through engine/bindings - the `epsilla` CPython module
+    (bindings/python/interface.cpp:260-331, unmodified in both builds): insert() in 1000-row JSON batches, 1000 query() calls, k = 10.
+    Two modules, each in a process of its own (scripts/epsilla_module_driver.py): the reference's own build (oracle/_ref/pymod: the CPU
+    engine) and the drop-in build (dropin/_build: the same binding over libepsilla_gfx950).  The binding never rebuilds, so both answer
+    with the exact scan; the answers are compared id by id."""
+    import subprocess
+    import tempfile
+    drv = os.path.join(ROOT, "scripts", "epsilla_module_driver.py")
+    mods = (("reference_cpu", os.path.join(ROOT, "oracle", "_ref", "pymod")), ("gfx950_dropin", os.path.join(ROOT, "dropin", "_build")))
+    out = {"workload": "100k x 128 EUCLIDEAN through the `epsilla` CPython module: insert() in 1000-row JSON batches, 1000 sequential query() calls (one host vector in, "
+                       "a list of dicts out), k=10; per call everything included (JSON, GIL, H2D / D2H on the GPU side)"}
+    answers = {}
+    for name, mdir in mods:
+        if not os.path.exists(os.path.join(mdir, "epsilla.so")):
+            out[name] = {"skipped": "%s/epsilla.so is not built" % os.path.relpath(mdir, ROOT)}
+            continue
+        with tempfile.TemporaryDirectory() as td:
+            t0 = time.perf_counter()
+            r = subprocess.run([sys.executable, drv, mdir, os.path.join(td, "db"), "c1", "100000", "128", "1000"], capture_output=True, text=True, timeout=420, cwd=ROOT)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("EPSILLA_JSON ")]
+            if r.returncode != 0 or not line:
+                out[name] = {"failed": (r.stderr or r.stdout)[-400:]}
+                continue
+            j = json.loads(line[-1][len("EPSILLA_JSON "):])
+            answers[name] = j["flat"].pop("results")
+            leg = {"module": j.get("module"), "insert_s": j["insert_s"], "query": j["flat"], "process_s": time.perf_counter() - t0}
+            if "graph" in j:   # (drop-in only: its additive rebuild() + query_batch(); the reference binding has neither, interface.h:22-32)
+                j["graph"].pop("results", None)
+                j["query_batch"].pop("results", None)
+                leg["after_rebuild"] = {"rebuild_s": j.get("rebuild_s"), "query": j["graph"], "query_batch": j["query_batch"]}
+            out[name] = leg
+    if len(answers) == 2:
+        a, g = answers["reference_cpu"], answers["gfx950_dropin"]
+        out["same_ids"] = int(sum(x[0] == y[0] for x, y in zip(a, g)))
+        out["queries"] = len(a)
+        out["max_rel_distance_error"] = float(max(max((abs(u - v) / max(abs(u), 1e-12) for u, v in zip(x[1], y[1])), default=0.0) for x, y in zip(a, g)))
+        if out["reference_cpu"]["query"]["qps"]:
+            out["gpu_over_cpu"] = out["gfx950_dropin"]["query"]["qps"] / out["reference_cpu"]["query"]["qps"]
+    return out
+
+
+def config_embedding_like(amd, torch, args, X, dev, stream, local_rank):
+    """The shape learned embeddings have and the U[0,1) recipe does not: unit-norm rows, Gaussian coordinates, a few
+    dominant dimensions (the first 8 coordinates carry 4 x the scale of the rest), COSINE.  Written IN PLACE over the headline table (this leg
+    runs last).  What it asks of the 8-bit first pass: the grid must cover coordinates of very different spread; the bench line says which
+    operand width served the batch, how many rows reached the fp32 re-rank, and the recall against the fp32 stream scan."""
+    n, d, k, b = X.shape[0], args.dim, args.k, args.batch
+    g = torch.Generator(device=dev).manual_seed(77)
+    scale = torch.ones((d,), dtype=torch.float32, device=dev)
+    scale[:8] = 4.0
+    for s in range(0, n, 1 << 19):
+        e = min(n, s + (1 << 19))
+        X[s:e] = torch.randn((e - s, d), generator=g, device=dev, dtype=torch.float32) * scale
+    amd.normalize_rows(X, only_if_nonzero=True, device=local_rank, stream=stream)
+    Q = torch.randn((b, d), generator=torch.Generator(device=dev).manual_seed(78), device=dev, dtype=torch.float32) * scale
+    amd.normalize_rows(Q, only_if_nonzero=False, device=local_rank, stream=stream)
+    torch.cuda.synchronize()
+    ix = amd.GpuIndex(d, "COSINE", device=local_rank)
+    ix.set_stream(stream)
+    ix.attach_rows(X)
+    o = (torch.empty((b, k), dtype=torch.int64, device=dev), torch.empty((b, k), dtype=torch.float32, device=dev), torch.empty((b,), dtype=torch.int32, device=dev))
+    for _ in range(3):
+        ix.search(Q, k, out=o, mode=amd.MODE_FLAT)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        ix.search(Q, k, out=o, mode=amd.MODE_FLAT)
+    torch.cuda.synchronize()
+    sec = (time.perf_counter() - t0) / 5
+    st = ix.stats()
+    km = ix.kernel_times(5)
+    got = o[0].cpu().numpy().copy()
+    nrec = min(128, b)
+    g2 = (torch.empty((nrec, k), dtype=torch.int64, device=dev), torch.empty((nrec, k), dtype=torch.float32, device=dev), torch.empty((nrec,), dtype=torch.int32, device=dev))
+    ix.search(Q[:nrec], k, out=g2, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
+    torch.cuda.synchronize()
+    out = {"workload": "%dM x %d COSINE, unit-norm rows with Gaussian coordinates, 8 dominant dimensions (4 x scale), k=%d, batch=%d, exact flat scan (the library's engine choice)"
+                       % (n // 1_000_000, d, k, b),
+           "qps": b / sec, "ms_per_step": 1e3 * sec, "recall_at_10": recall_of(got[:nrec], g2[0].cpu().numpy()), "recall_check": "%d queries vs the fp32 stream scan" % nrec,
+           "operand_bits": int(st.get("main_kernel_bits", 0)), "rerank_rows_per_query": st["rerank_rows"] / float(b), "overflow_queries": st["overflow_queries"],
+           "main_kernel_ms": float(np.median(km)) if km else None}
+    ix.close()
     return out
 
 
@@ -710,24 +803,36 @@ def main():
             ix.save_graph(args.save_graph)
         skw.update(intra_threads=args.T, master_queue=args.L, local_queue=args.L)
 
-    # one packed result buffer per rank: ids int64[b][k] then dist f32[b][k]; the search writes straight into it
-    pack = torch.empty(((b * k * 12 + 7) // 8 * 8,), dtype=torch.uint8, device=dev)
-    ids = pack[: b * k * 8].view(torch.int64).view(b, k)
-    dd = pack[b * k * 8: b * k * 12].view(torch.float32).view(b, k)
+    # one packed result buffer per rank: ids int64[b][k] then dist f32[b][k]; the search writes straight into it.  Two of everything
+    # (slot = step & 1): the end-to-end run copies step i's results to the host while step i + 1 computes
+    pack_n = (b * k * 12 + 7) // 8 * 8
+    packs = [torch.empty((pack_n,), dtype=torch.uint8, device=dev) for _ in range(2)]
+    idss = [p_[: b * k * 8].view(torch.int64).view(b, k) for p_ in packs]
+    dds = [p_[b * k * 8: b * k * 12].view(torch.float32).view(b, k) for p_ in packs]
     cnt = torch.empty((b,), dtype=torch.int32, device=dev)
+    pack, ids, dd = packs[0], idss[0], dds[0]
+    xev = []   # N > 1: (before all-gather, after all-gather, after merge) event triples of the timed steps
     if world > 1:
-        gathered = torch.empty((world, pack.numel()), dtype=torch.uint8, device=dev)
-        m_d = torch.empty((b, k), dtype=torch.float32, device=dev)
-        m_i = torch.empty((b, k), dtype=torch.int64, device=dev)
+        gathered = torch.empty((world, pack_n), dtype=torch.uint8, device=dev)
+        m_ds = [torch.empty((b, k), dtype=torch.float32, device=dev) for _ in range(2)]
+        m_is = [torch.empty((b, k), dtype=torch.int64, device=dev) for _ in range(2)]
 
-    def step(q):
-        ix.search(q, k, out=(ids, dd, cnt), **skw)
+    def step(q, slot=0, timed=False):
+        ix.search(q, k, out=(idss[slot], dds[slot], cnt), **skw)
         if world > 1:
             # the one exchange step of the path: ONE all-gather of the packed per-shard top-k, then a k-way merge
-            all_gather(gathered, pack)
-            amd.merge_topk_packed(gathered, pack.numel(), b * k * 8, world, b, k, m_d, m_i, device=local_rank, stream=stream)
-            return m_d, m_i
-        return dd, ids
+            if timed:
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                ev[0].record()
+            all_gather(gathered, packs[slot])
+            if timed:
+                ev[1].record()
+            amd.merge_topk_packed(gathered, pack_n, b * k * 8, world, b, k, m_ds[slot], m_is[slot], device=local_rank, stream=stream)
+            if timed:
+                ev[2].record()
+                xev.append(ev)
+            return m_ds[slot], m_is[slot]
+        return dds[slot], idss[slot]
 
     for w in range(args.warmup):
         step(queries[w])
@@ -737,7 +842,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        out_d, out_i = step(queries[args.warmup + s])
+        out_d, out_i = step(queries[args.warmup + s], 0, True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -747,13 +852,96 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    got_i = out_i.clone()
     # device time of the dominant kernel of every timed step: hipEvent pairs the library recorded on this stream, read
     # back only now (no host sync inside the timed region)
     main_ms = ix.kernel_times(64)[-args.steps:]
     st = ix.stats()
-    got_i = out_i.clone()
+    xchg_us = [(e[0].elapsed_time(e[1]) * 1e3, e[1].elapsed_time(e[2]) * 1e3) for e in xev]
+
+    # ---- the same steps END TO END ("QPS end-to-end including H2D of queries and D2H of results"; the reference's entry takes a
+    # host vector per call, table_mvp.cpp:359-380): every batch starts in (pinned) host memory and its ids / distances end in host memory,
+    # inside the timed region.  The copies run on a second stream: batch i + 1 goes up and batch i - 1's results come down while batch i
+    # computes.  `value` stays the device-resident rate (the contract: inputs resident in HBM); this one is reported beside it.
+    e2e = None
+    if args.e2e:
+        cs = torch.cuda.Stream(device=dev)
+        main_s = torch.cuda.current_stream()
+        nst = args.steps
+        qh = [torch.empty((b, d), dtype=torch.float32).pin_memory() for _ in range(nst)]
+        for s in range(nst):
+            qh[s].copy_(queries[args.warmup + s])
+        rh_i = [torch.empty((b, k), dtype=torch.int64).pin_memory() for _ in range(nst)]
+        rh_d = [torch.empty((b, k), dtype=torch.float32).pin_memory() for _ in range(nst)]
+        dq = [torch.empty((b, d), dtype=torch.float32, device=dev) for _ in range(2)]
+        ev_up = [torch.cuda.Event() for _ in range(2)]
+        ev_done = [torch.cuda.Event() for _ in range(2)]
+        ev_down = [torch.cuda.Event() for _ in range(2)]
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.cuda.stream(cs):
+            dq[0].copy_(qh[0], non_blocking=True)
+            ev_up[0].record(cs)
+        for s in range(nst):
+            cur = s & 1
+            if s + 1 < nst:
+                with torch.cuda.stream(cs):
+                    cs.wait_event(ev_done[1 - cur])      # (step s - 1 read dq[1 - cur])
+                    dq[1 - cur].copy_(qh[s + 1], non_blocking=True)
+                    ev_up[1 - cur].record(cs)
+            main_s.wait_event(ev_up[cur])
+            main_s.wait_event(ev_down[cur])              # (step s - 2's results have left this slot's buffers)
+            o_d, o_i = step(dq[cur], cur)
+            ev_done[cur].record(main_s)
+            with torch.cuda.stream(cs):
+                cs.wait_event(ev_done[cur])
+                rh_i[s].copy_(o_i, non_blocking=True)
+                rh_d[s].copy_(o_d, non_blocking=True)
+                ev_down[cur].record(cs)
+        cs.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el2 = time.perf_counter() - t0
+        t = torch.tensor([el2], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el2 = float(t.item())
+        same = bool((rh_i[nst - 1] == got_i.cpu()).all())   # (same queries as the device-resident run's last step: the same answer, now in host memory)
+        # ... and one call with plain (pageable) host buffers straight through the C ABI, nothing overlapped: what a caller that does no staging gets
+        qn = qh[nst - 1].numpy().copy()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            ix.search(qn, k, **skw)
+        un = (time.perf_counter() - t1) / 3
+        e2e = {"value": b * nst / el2, "unit": "queries/s", "ms_per_step": 1e3 * el2 / nst, "frac_of_device_resident": elapsed / el2,
+               "last_step_equals_device_resident_run": same,
+               "what": "host (pinned) queries -> H2D -> eps_index_search%s -> D2H -> host ids + distances, all inside the timed region; copies on a second stream, "
+                       "two slots (batch i + 1 up / batch i - 1 down under batch i)" % (" -> all-gather -> merge" if world > 1 else ""),
+               "unpipelined_host_pointers": {"ms_per_step": 1e3 * un, "value": b / un,
+                                             "what": "eps_index_search called with pageable host pointers (this rank's shard only), no staging, no overlap: the library's own hipMemcpy path"}}
     # clock and power under this workload (N = 1, after the timed region): the filter kernel runs against the board's power limit
     power = power_leg(torch, step, queries, args.power_seconds, local_rank) if (world == 1 and rank == 0 and args.power_seconds > 0) else None
+
+    # ---- N > 1: what proves that N ranks on N devices took part (the driver's SCALE run cannot be watched from here)
+    ranks_info = None
+    if world > 1:
+        props = torch.cuda.get_device_properties(local_rank)
+        mine = {"rank": rank, "local_rank": local_rank, "device_ordinal": int(torch.cuda.current_device()), "device_name": torch.cuda.get_device_name(local_rank),
+                "device_uuid": str(getattr(props, "uuid", "")), "pci_bus_id": int(getattr(props, "pci_bus_id", -1)), "pid": os.getpid(),
+                "main_kernel_ms": float(np.mean(main_ms)) if main_ms else None, "search_rows": int(n),
+                "all_gather_us_mean": float(np.mean([x[0] for x in xchg_us])) if xchg_us else None,
+                "merge_us_mean": float(np.mean([x[1] for x in xchg_us])) if xchg_us else None}
+        ranks_info = [None] * world
+        dist.all_gather_object(ranks_info, mine)
+        if backend == "nccl":
+            seen = set((r_["device_ordinal"], r_["device_uuid"], r_["pci_bus_id"]) for r_ in ranks_info)
+            if len(seen) != world:
+                raise SystemExit("bench.py: %d ranks under nccl but only %d distinct devices: %r" % (world, len(seen), ranks_info))
 
     # ---- recall@10 of the last batch: exact ground truth from the fp32 direct-form stream scan (an independent code path
     # of the library, itself pinned to the oracle by the tests) for --recall-queries queries, and a torch fp32 scan for 16
@@ -900,8 +1088,10 @@ def main():
         res = {
             "metric": "QPS @ recall@10>=0.999, 10Mx768 L2",
             "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": ("weak" if world > 1 else None),
             "vs_baseline": None,
+            "value_device_resident": qps,   # (= value: queries generated on the device, results left there - the contract's timed region)
+            "end_to_end": e2e,              # the same steps host -> host, copies overlapped; None with --no-e2e
             "dtype": ("f32 (exact fp32 distances; the batched scan runs %s as a lower-bound filter, survivors re-ranked in fp32)"
                       % ("an int8 MFMA pass (int32 accumulation) over an 8-bit mirror of the rows" if int(st.get("main_kernel_bits", 0)) == 8 else
                          "an fp16 MFMA pass (fp32 accumulation) over a half mirror of the rows" if int(st.get("main_kernel_bits", 0)) == 16 else "no matrix pass"))
@@ -922,6 +1112,17 @@ def main():
                       "expansions_per_query": st["expansions"] / float(b), "overflow_queries": st["overflow_queries"]},
             "work_rate": {"value": qps * n * world, "unit": "query*rows/s"},
         }
+        if world > 1:
+            # one all-gather of pack_n bytes per rank and step (12 B x k x batch), then a k-way merge on every rank
+            res["exchange"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "collective": "all_gather_into_tensor" if backend == "nccl" else "all_gather (host staged)",
+                               "bytes_per_rank_per_step": int(pack_n), "bytes_gathered_per_rank_per_step": int(pack_n * world),
+                               "all_gather_us_per_step": [round(x[0], 1) for x in xchg_us], "merge_us_per_step": [round(x[1], 1) for x in xchg_us],
+                               "all_gather_us_mean": float(np.mean([x[0] for x in xchg_us])) if xchg_us else None,
+                               "merge_us_mean": float(np.mean([x[1] for x in xchg_us])) if xchg_us else None,
+                               "ranks": ranks_info,
+                               "distinct_devices": len(set((r_["device_ordinal"], r_["device_uuid"], r_["pci_bus_id"]) for r_ in ranks_info)),
+                               "merged_answer_check": "recall_at_10 above = the merged top-k of the last step against the MERGED exact fp32 stream scans of every shard (and, for 16 queries, "
+                                                      "against torch fp32 scans of every shard merged the same way): recall_check"}
         if build_s is not None:
             res["graph_build_s"] = build_s
         if secondary:
@@ -930,7 +1131,8 @@ def main():
         if args.cpu_seconds > 0 and world == 1:
             try:
                 cpu = CpuBaseline(torch, X)
-                res["cpu_baseline"] = cpu_baseline(cpu, args, X, qlast, gt, graph_for_cpu, args.cpu_seconds)
+                res["cpu_baseline"] = cpu_baseline(cpu, args, X, qlast, gt, graph_for_cpu, args.cpu_seconds,
+                                                   gpu_ids=(got_i.cpu().numpy() if args.mode == "flat" else None))
                 res["gpu_over_cpu"] = qps / res["cpu_baseline"]["value"] if res["cpu_baseline"].get("value") else None
             except Exception as e:  # the baseline is a report, never a dependency of the product path
                 res["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": os.cpu_count(), "kind": "reference",
@@ -949,6 +1151,11 @@ def main():
                     res["configs"]["c4_cosine_id_filter_b1024"] = config_c4(amd, torch, args, X, qlast, dev, stream, local_rank, cpu)
                 except Exception as e:
                     res["configs"]["c4_cosine_id_filter_b1024"] = {"failed": repr(e)}
+            if "c1" in want:
+                try:
+                    res["configs"]["c1_100kx128_bindings"] = config_c1(args)
+                except Exception as e:
+                    res["configs"]["c1_100kx128_bindings"] = {"failed": repr(e)}
             if "secondary" in want and args.graph_rows and args.graph_rows <= n:
                 for kind in ("clustered", "manifold"):   # (last: the CPU legs overwrite the head of the host copy of the table)
                     try:
@@ -957,6 +1164,12 @@ def main():
                         res["configs"]["secondary_%s_%dx%d" % (kind, args.graph_rows, d)] = {"failed": repr(e)}
         if cpu is not None:
             cpu.close()
+        if "embedding" in want and world == 1:   # (last: it overwrites the table in place)
+            try:
+                ix.close()
+                res["configs"]["embedding_like_%dMx%d" % (n // 1_000_000, d)] = config_embedding_like(amd, torch, args, X, dev, stream, local_rank)
+            except Exception as e:
+                res["configs"]["embedding_like_%dMx%d" % (n // 1_000_000, d)] = {"failed": repr(e)}
         print(json.dumps(res))
     if ix2 is not None:
         ix2.close()

@@ -35,6 +35,14 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
         assert key in cb, key
     assert cb["kind"] in ("reference", "port")
     assert d["recall_at_10"] >= 0.999
+    # r5: N = 1 lines carry no scaling claim; the same steps end to end (host queries in, host results out, copies overlapped) beside the
+    # device-resident value (the contract's timed region), and the reference's own BruteForceSearch answers compared with the GPU's
+    assert d["scaling"] is None and d["value_device_resident"] == d["value"]
+    e = d["end_to_end"]
+    assert e["last_step_equals_device_resident_run"] is True and e["value"] > 0 and e["unpipelined_host_pointers"]["value"] > 0
+    if cb["kind"] == "reference":
+        bf = [l for l in cb["legs"] if l["leg"] == "bruteforce"][0]
+        assert bf["gpu_headline_answers_equal"] == bf["queries"], bf
 
 
 @pytest.mark.gpu
@@ -54,6 +62,7 @@ def test_bench_two_ranks_on_one_gpu_merge_equals_unsharded_scan():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak"
     assert "rows_total=300000" in d["config"]["workload"]
     assert d["recall_at_10"] == 1.0 and d["recall_check"]["ground_truth_vs_torch_fp32_scan"] == 1.0
+    _check_exchange(d, 2, 96, 10)
 
 
 @pytest.mark.gpu
@@ -71,6 +80,24 @@ def test_bench_eight_ranks_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 8 and d["scaling"] == "weak" and "rows_total=640000" in d["config"]["workload"]
     assert d["recall_at_10"] == 1.0 and d["recall_check"]["ground_truth_vs_torch_fp32_scan"] == 1.0
+    _check_exchange(d, 8, 64, 10)
+
+
+def _check_exchange(d, world, batch, k):
+    """r5: an N > 1 line proves by itself that N ranks took part and what the one exchange step cost: backend, world size,
+    every rank's device, the all-gather and merge times of every timed step, the bytes a rank contributes (12 B x k x batch)."""
+    x = d["exchange"]
+    assert x["world_size"] == world and x["backend"] in ("gloo", "nccl")
+    assert x["bytes_per_rank_per_step"] == (batch * k * 12 + 7) // 8 * 8 and x["bytes_gathered_per_rank_per_step"] == world * x["bytes_per_rank_per_step"]
+    assert len(x["all_gather_us_per_step"]) == d["steps"] == len(x["merge_us_per_step"]) and all(v >= 0 for v in x["merge_us_per_step"])
+    assert x["all_gather_us_mean"] is not None and x["merge_us_mean"] > 0
+    assert sorted(r["rank"] for r in x["ranks"]) == list(range(world))
+    assert len(set(r["pid"] for r in x["ranks"])) == world
+    for r in x["ranks"]:
+        assert r["device_name"] and r["main_kernel_ms"] is not None and r["search_rows"] > 0
+    e = d["end_to_end"]
+    assert e["last_step_equals_device_resident_run"] is True and 0 < e["value"] and 0 < e["frac_of_device_resident"] < 1.5
+    assert d["value_device_resident"] == d["value"]
 
 
 def test_bench_refuses_a_world_size_that_is_not_gpus():
