@@ -1,6 +1,6 @@
 #!/bin/bash
-# r5 session 5: edge constants (acc0 of the neighbours stored with the adjacency list): exactness, then the proxy A/B against the r4 kernel
+# r5 session 7: LDS-only step barriers + read-ahead of the next step's adjacency lists: exactness, then the proxy A/B
 cd ${GRAFT_REPO_ROOT:-.}
 export EPS_TUNING_FROM_ENV=1
 timeout 600 python -m pytest tests/test_gpu_traverse.py -m gpu -x -q -k "lockstep or invisible or outside or outlier or local_queue or visited or edge_cases or switches" 2>&1 | tail -5 | cut -c1-300
-bash scripts/lab/r5_trv_ab.sh r5s5 "f0e0 ec ec_u83 ec_p6u2 ec_u4 f0e0 ec" "4:500,1:500,1:100,4:100" ec
+bash scripts/lab/r5_trv_ab.sh r5s7 "e0full early e0 efull e0full early" "4:500,1:500,1:100,4:100" early

@@ -2,6 +2,7 @@
 # r5: traversal kernel variants (scripts/lab/_ab/<name>.so, build_trv_variants.sh) on the 10M x 768 random-graph proxy.
 #   usage: r5_trv_ab.sh outdir "v1 v2 ..." ["T:L,T:L"] [profile-variant ...]
 cd ${GRAFT_REPO_ROOT:-.}
+export EPS_TUNING_FROM_ENV=1
 O=gpurun_out/$1; shift
 V="$1"; shift
 C="${1:-4:500,1:500,1:100,4:100}"; shift
