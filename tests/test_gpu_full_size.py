@@ -169,3 +169,79 @@ def test_configs3_10M_x_768_cosine_with_id_filter_matches_the_reference_prefilte
         for q in range(len(qh)):
             assert_topk_match(ids[q], dd[q], rid[q], rd[q], what="configs[3] %d%% q%d" % (int(sel * 100), q))
     ix.close()
+
+
+def test_configs1_1M_x_768_one_query_per_call_matches_the_reference_bruteforce(amd, ref, oracle):
+    """BASELINE configs[1] itself: 1M x 768 L2, k = 10, ONE query per eps_index_search call, 200 calls in a row - the one-pass
+    search of csrc/stream8_kernel.hpp (one streaming pass over the 8-bit mirror, a racy shared table of the best accumulators, one exact
+    re-rank) at the size the config names, pinned DIRECTLY to the compiled reference: every answer position-wise against the reference's
+    BruteForceSearch (vec_search_executor.cpp:717-768) on the same rows; the same with `ID < N` at 50 % and 1 % against the reference's
+    PreFilterBruteForceSearch (:770-831, its own parser and ExprEvaluator); and with a deleted bitset against the C oracle's restatement
+    (bit-exact against the reference, tests/test_oracle_vs_ref.py).  `one_pass` must be 1 on every plain call - a call that overflowed a
+    wavefront's list and was answered by the staged chain is counted and must not happen on this data."""
+    import torch
+    from helpers import bitset
+    from oracle.pyoracle import make_filter
+    n, nq = 1_000_000, 200
+    dev = torch.device("cuda", 0)
+    X = torch.rand((n, D), generator=torch.Generator(device=dev).manual_seed(42), device=dev)
+    Q = torch.rand((nq, D), generator=torch.Generator(device=dev).manual_seed(43), device=dev)
+    threads = int(ref.L.ref_omp_max_threads())
+    arr, ptr = ref.alloc_rows(n, D, threads)
+    try:
+        arr[:] = X.cpu().numpy()
+        Qh = Q.cpu().numpy()
+        ix = amd.GpuIndex(D, "EUCLIDEAN", device=0).use_torch_stream()
+        ix.attach_rows(X)
+        o = (torch.empty((1, K), dtype=torch.int64, device=dev), torch.empty((1, K), dtype=torch.float32, device=dev), torch.empty((1,), dtype=torch.int32, device=dev))
+
+        def one_by_one(queries):
+            ids, dd, one = [], [], 0
+            for i in queries:
+                ix.search(Q[i:i + 1], K, out=o, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
+                ix.synchronize()
+                st = ix.stats()
+                assert st["main_kernel_bits"] == 8, st
+                one += st["one_pass"]
+                ids.append(o[0][0].cpu().numpy().copy())
+                dd.append(o[1][0].cpu().numpy().copy())
+                assert int(o[2][0]) == K
+            return ids, dd, one
+        # ---- plain: 200 sequential single-query calls
+        ids, dd, one = one_by_one(range(nq))
+        assert one == nq, "%d of %d calls fell back to the staged chain" % (nq - one, nq)
+        rid, rd, sec = ref.bruteforce_many(ptr, n, D, Qh, K, metric=0, threads=threads)
+        for q in range(nq):
+            assert_topk_match(ids[q], dd[q], rid[q], rd[q], what="configs[1] q%d" % q)
+        # ---- a deleted bitset (every 7th row and the 40 best answers of query 0): the oracle's BruteForceSearch with the same bitset
+        gone = sorted(set(range(5, n, 7)) | set(int(v) for v in ref.bruteforce_many(ptr, n, D, Qh[:1], 40, metric=0, threads=threads)[0][0]))
+        gone_set = set(gone)
+        bits = bitset(n, gone)
+        ix.set_deleted(bits)
+        ids, dd, one = one_by_one(range(3))
+        assert one == 3
+        flt, keep = make_filter(deleted=bits)
+        Xh = arr[:n]
+        for q in range(3):
+            oid, od = oracle.topk_flat(0, Xh, Qh[q], K, flt=flt)
+            assert not (set(ids[q].tolist()) & gone_set)
+            assert_topk_match(ids[q], dd[q], oid, od, what="configs[1] deleted q%d" % q)
+        ix.set_deleted(None)
+        # ---- `ID < N`: the int-column filter is evaluated inside the pass; the reference evaluates its expression tree before the distances
+        idc = torch.arange(n, dtype=torch.int32, device=dev)
+        idc_host = np.arange(n, dtype=np.int32)
+        for bound, nf in ((n // 2, 8), (n // 100, 4)):
+            ix.set_int_filter(idc, "<", bound)
+            ids, dd, one = one_by_one(range(nf))
+            # (50 %: the pass answers every call; 1 %: visible rows are too rare for the table of best accumulators to tighten in time - the
+            # pass overflows, the staged chain answers, and after two such calls the filtered calls skip the pass: the same exact answer)
+            assert one == nf or bound < n // 10, (bound, one)
+            rid, rd, rcnt, sec = ref.prefilter_many(ptr, n, D, idc_host, "ID < %d" % bound, Qh[:nf], K, metric=0, threads=threads)
+            assert (rcnt == bound).all()
+            for q in range(nf):
+                assert (ids[q] < bound).all()
+                assert_topk_match(ids[q], dd[q], rid[q], rd[q], what="configs[1] ID < %d q%d" % (bound, q))
+        ix.set_int_filter(None, "<", 0)
+        ix.close()
+    finally:
+        ref.free_rows(ptr)

@@ -102,7 +102,7 @@ def test_i8_engine_on_other_distributions(amd, kind):
 
 @pytest.mark.parametrize("metric", [0, 1, 2])
 @pytest.mark.parametrize("d", [192, 768, 1000])
-def test_one_to_four_queries_are_one_pass_over_the_mirror(amd, monkeypatch, metric, d):
+def test_one_to_four_queries_are_one_pass_over_the_mirror(amd, oracle, monkeypatch, metric, d):
     """r4 (stream8_kernel.hpp): up to 4 queries with k <= 16 are answered by ONE streaming pass over the 8-bit mirror (shared table of the
     best accumulators seen -> pass threshold from their UPPER bounds), one selection against the final table and one exact re-rank: the
     same bits as the stream scan - rows of 2 / 3 / 4 x 256 bytes, ties ordered by id, queries that ARE rows, with a deleted bitset,
@@ -118,11 +118,22 @@ def test_one_to_four_queries_are_one_pass_over_the_mirror(amd, monkeypatch, metr
     idc = np.arange(n, dtype=np.int32)
     ix = amd.GpuIndex(d, metric)
     ix.attach_rows(X)
+    from oracle.pyoracle import make_filter
     for setup in ("plain", "deleted", "deleted + filter", "deleted + filter program"):
         if setup == "deleted":
             ix.set_deleted(bitset(n, range(3, n, 11)))
         if setup == "deleted + filter":
             ix.set_int_filter(idc, ">=", 1000)
+        # r5: the one-pass form against the ORACLE directly (the C restatement of BruteForceSearch, itself bit-exact against the compiled
+        # reference: tests/test_oracle_vs_ref.py), not only against the library's own stream engine
+        if "program" not in setup:
+            flt, keep = make_filter(deleted=bitset(n, range(3, n, 11)) if setup != "plain" else None, attr=idc if "filter" in setup else None,
+                                    op=">=" if "filter" in setup else None, value=1000)
+            got = ix.search(Q[:2], 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
+            assert ix.stats()["one_pass"] == 1
+            for qi in range(2):
+                rid, rd = oracle.topk_flat(metric, X, Q[qi], 10, flt=flt if setup != "plain" else None)
+                assert_topk_match(got[0][qi], got[1][qi], rid, rd, what="one pass vs oracle, %s q%d" % (setup, qi))
         if setup == "deleted + filter program":     # (filter programs take the staged chain: same bits)
             ix.set_int_filter(None, ">=", 0)
             ix.set_filter_program([("i32", 0), ("const", 1000), (">=",)], rows=idc.view(np.uint8).reshape(n, 4), stride=4)
