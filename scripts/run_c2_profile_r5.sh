@@ -1,9 +1,10 @@
 #!/bin/bash
 # ONE gpurun call: BASELINE configs[1] (1M x 768, one query per call) - the one-pass search under rocprofv3: kernel stats + HBM traffic of the pass
 set -x
+export EPS_TUNING_FROM_ENV=1
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r4c2
+O=$R/gpurun_out/r5c2
 mkdir -p $O
 (timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_stats -o stats -- python $R/scripts/prof_single_query.py 1000000 768 > $O/prof_stats.log 2>&1)
 (timeout 600 rocprofv3 --pmc FETCH_SIZE -d $O/prof_fetch -o fetch -- python $R/scripts/prof_single_query.py 1000000 768 > $O/prof_fetch.log 2>&1)

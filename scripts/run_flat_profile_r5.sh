@@ -1,9 +1,10 @@
 #!/bin/bash
 # ONE gpurun call: the headline line (10M x 768, batch 1024, exact flat scan) + rocprofv3 kernel stats + PMC passes of the same command
 set -x
+export EPS_TUNING_FROM_ENV=1
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r4flat
+O=$R/gpurun_out/r5flat
 mkdir -p $O
 cd $R
 STEPS=${STEPS:-20}
