@@ -34,12 +34,16 @@ def _close_evals(ev_gpu, ev_or, what=""):
 
 @pytest.mark.parametrize("T,L,I", [(2, 500, 15), (4, 500, 15), (4, 100, 15), (4, 500, 1), (4, 500, 3), (8, 300, 15), (3, 64, 2),
                                    (16, 500, 15), (1, 500, 1), (1, 100, 4), (17, 500, 15), (24, 300, 4), (32, 500, 15)])
-@pytest.mark.parametrize("prefilter", ["0", "1"])
+@pytest.mark.parametrize("prefilter", ["0", "1", "1+stamps"])
 def test_lockstep_workers_match_oracle(amd, oracle, monkeypatch, T, L, I, prefilter):
     """(prefilter: the 8-bit lower-bound test ahead of the fp32 rows, forced off / on - the same bits either way.)
     IntraQueryThreads = T workers with local queues, PickTopMToWorkers, GlobalSyncInterval = I and
     MergeAllQueuesToMaster: the device result equals the oracle's SearchImpl under the lockstep interleaving - the whole
     master queue (ids, distances) and the number of distance evaluations."""
+    # (r5 "+stamps": the visited set as generation stamps - one atomicMax per edge, nothing reset - instead of bitmap + undo log; batches get it by
+    # default where HBM allows, these 24-query calls only when asked)
+    monkeypatch.setenv("EPS_TRV_VISITED", "stamps" if "stamps" in prefilter else "bitmap")
+    prefilter = prefilter[0]
     monkeypatch.setenv("EPS_TRV_PREFILTER", prefilter)
     z, off, nbr, nav = _golden_graph()
     X, Q = data(2000, 32, 42), data(24, 32, 47)
@@ -261,7 +265,10 @@ def test_visited_bitmaps_are_clean_between_searches(amd, oracle):
     ix = amd.GpuIndex(32, 0)
     ix.attach_rows(X)
     ix.set_graph(off, nbr, nav)
-    for rep, (T, nq) in enumerate([(1, 3000), (4, 7), (1, 300), (4, 3000), (1, 16)]):
+    for rep, (T, nq) in enumerate([(1, 3000), (4, 7), (1, 300), (4, 3000), (1, 16), (4, 3000), (1, 300)]):
+        os.environ["EPS_TRV_VISITED"] = "bitmap" if rep >= 5 else "stamps" if rep in (1, 2) else ""   # (r5: stamps by default for batches; both forms, switching between them)
+        if not os.environ["EPS_TRV_VISITED"]:
+            del os.environ["EPS_TRV_VISITED"]
         ids, dist, cnt = ix.search(Q[:nq], 10, mode=amd.MODE_GRAPH, intra_threads=T)
         if T == 1:
             for qi in range(nq):
@@ -269,6 +276,7 @@ def test_visited_bitmaps_are_clean_between_searches(amd, oracle):
         else:
             for qi in range(16, nq):
                 assert np.array_equal(ids[qi], ids[qi % 16]), (rep, qi)
+    os.environ.pop("EPS_TRV_VISITED", None)
     ix.close()
 
 

@@ -32,6 +32,10 @@ struct GraphDev {
   int64_t vis_slots = 0, vis_words = 0;
   bool vis_dirty = true;   // a failed launch may have left bits behind: re-zero before the next search
   DevBuf vlog;       // u32 [slots][vcap] undo log of the visited set
+  // r5: visited set by generation stamp (Trv2Args::gens) where HBM allows - u32 [slots][n], zero-initialised once; gen_last = the last stamp handed out
+  DevBuf gens;
+  int64_t gens_slots = 0, gens_n = 0;
+  uint32_t gen_last = 0;
   DevBuf qglobal;    // u64 [slots][qtot] queues of large-L searches
   DevBuf auxglobal;  // int [slots][2*Lq]
   DevBuf queue;      // u64 [nq][L]
@@ -342,18 +346,43 @@ int32_t graph_search_impl(Index& ix, const float* dq, int64_t nq, int k, const e
   // (large T x I, high degree) reports it and the search is repeated with a log that holds them all (ecap_min, below)
   const int64_t ecap_plan = std::min<int64_t>(n, std::max<int64_t>(std::max<int64_t>(16384, 64 * L), ecap_min));
   const int64_t slice = std::max<int64_t>(1, std::min<int64_t>(nq, ((int64_t)2 << 30) / (std::max<int64_t>(L, p.filter_in_traversal ? ecap_plan : 0) * 8)));
-  if (!g.visited.reserve((size_t)slots * words * 4) || !g.vlog.reserve((size_t)slots * vcap * 4) ||
+  // visited set: generation stamps (one atomicMax per edge, no reset) when 4 bytes per node and slot fit comfortably - a quarter of the free HBM
+  // and at most 64 GB, batches only - else the bitmap with its undo log.  EPS_TRV_VISITED=bitmap|stamps overrides (A/B, tests).
+  bool stamps = false;
+  {
+    const size_t need = (size_t)slots * (size_t)n * 4;
+    size_t free_b = 0, total_b = 0;
+    const bool have = (g.gens_slots >= slots && g.gens_n == n && g.gens.p);
+    if (have) stamps = true;
+    else if (!qglobal && nq >= 64 && hipMemGetInfo(&free_b, &total_b) == hipSuccess && need <= free_b / 4 && need <= ((size_t)64 << 30)) stamps = true;
+    if (const char* ve = tune_env("EPS_TRV_VISITED")) stamps = std::strcmp(ve, "stamps") == 0 ? true : (std::strcmp(ve, "bitmap") == 0 ? false : stamps);
+    if (stamps && !have) {
+      g.gens.release();
+      if (g.gens.reserve(need)) {
+        er = hipMemsetAsync(g.gens.p, 0, need, s);
+        if (er != hipSuccess) return ix.hip_fail(er, "memset visited stamps");
+        g.gens_slots = slots;
+        g.gens_n = n;
+        g.gen_last = 0;
+      } else {
+        (void)hipGetLastError();
+        g.gens_slots = g.gens_n = 0;
+        stamps = false;   // (no room: the bitmap)
+      }
+    }
+  }
+  if ((!stamps && (!g.visited.reserve((size_t)slots * words * 4) || !g.vlog.reserve((size_t)slots * vcap * 4))) ||
       !g.queue.reserve((size_t)slice * L * 8) || !g.counters.reserve(256) ||
       (qglobal && (!g.qglobal.reserve((size_t)slots * qtot * 8) || !g.auxglobal.reserve((size_t)slots * 2 * Lq * 4))))
     return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "search: out of device memory (traversal scratch)");
-  if (g.vis_dirty || g.vis_slots < slots || g.vis_words != words) {
+  if (!stamps && (g.vis_dirty || g.vis_slots < slots || g.vis_words != words)) {
     // (re)establish the invariant the kernel maintains: every slot's bitmap is all-zero between searches
     er = hipMemsetAsync(g.visited.p, 0, g.visited.cap, s);
     if (er != hipSuccess) return ix.hip_fail(er, "memset visited");
     g.vis_slots = (int64_t)(g.visited.cap / ((size_t)words * 4));
     g.vis_words = words;
   }
-  g.vis_dirty = true;   // until this search has completed
+  if (!stamps) g.vis_dirty = true;   // until this search has completed (stamps need no such care: a half-finished walk leaves only old stamps behind)
   er = hipMemsetAsync(g.counters.p, 0, 256, s);
   if (er != hipSuccess) return ix.hip_fail(er, "memset");
   const bool prof = tune_env("EPS_TRV_PROF") != nullptr;
@@ -380,6 +409,9 @@ int32_t graph_search_impl(Index& ix, const float* dq, int64_t nq, int k, const e
   a.words = words;
   a.vlog = g.vlog.as<u32>();
   a.vcap = vcap;
+  a.gens = stamps ? g.gens.as<u32>() : nullptr;
+  a.gens_n = n;
+  a.gen_base = 0;
   a.counters = g.counters.as<unsigned long long>();
   a.prof = prof ? g.counters.as<unsigned long long>() + 8 : nullptr;
   if (filtered && k > 1024) return ix.fail(EPS_DB_UNSUPPORTED_ERROR, "search: filter_in_traversal returns at most 1024 rows per query");
@@ -447,6 +479,16 @@ int32_t graph_search_impl(Index& ix, const float* dq, int64_t nq, int k, const e
       a.elog_cnt = g.elog_cnt.as<u32>();
     }
     const int sl = (int)std::min<int64_t>(slots, cnt);
+    if (stamps) {   // the stamps this launch hands out: one per query of a slot; a wrap-around of the 32-bit counter starts over from a zeroed table
+      const uint32_t per_slot = (uint32_t)((cnt + sl - 1) / sl);
+      if (g.gen_last > 0xFFFFFFF0u - per_slot) {
+        er = hipMemsetAsync(g.gens.p, 0, (size_t)g.gens_slots * (size_t)g.gens_n * 4, s);
+        if (er != hipSuccess) return ix.hip_fail(er, "memset visited stamps");
+        g.gen_last = 0;
+      }
+      a.gen_base = g.gen_last;
+      g.gen_last += per_slot;
+    }
 #define EPS_TRV_LAUNCH(V4, NW_)                                        \
   do {                                                                 \
     if (qglobal) {                                                     \
@@ -486,7 +528,7 @@ int32_t graph_search_impl(Index& ix, const float* dq, int64_t nq, int k, const e
   er = hipMemcpyAsync(h, g.counters.p, sizeof(h), hipMemcpyDeviceToHost, s);
   if (er == hipSuccess) er = hipStreamSynchronize(s);
   if (er != hipSuccess) return ix.hip_fail(er, "traversal");
-  g.vis_dirty = false;
+  if (!stamps) g.vis_dirty = false;
   if (filtered && h[5] > 0) {
     // some query evaluated more rows than its log holds; the evaluations that were dropped are the LATE ones - the closest.  Repeat
     // with a log sized for the longest walk seen (bounded by n: a walk evaluates a row at most once)

@@ -49,6 +49,13 @@ struct Trv2Args {
   int64_t words;
   u32* vlog;            // [slots][vcap] undo log
   int vcap;
+  // r5, visited set by GENERATION STAMP instead of bitmap + undo log (where HBM allows: 4 bytes per node and slot): gens[slot][node] holds the stamp of
+  // the last query of this slot that reached the node; a query's stamp is gen_base + its ordinal in the slot, so "visited" is `old stamp == mine`,
+  // test-and-set is ONE atomicMax, and nothing is reset at the end of a walk (the reset's ~evaluations scattered writes were 5 % of the launch at
+  // 10M x 768: profiles/r5_traverse_lab_10M_proxy.txt session 4).  null: the bitmap.
+  u32* gens;
+  int64_t gens_n;       // nodes per slot
+  u32 gen_base;         // stamps of this launch: gen_base + 1 + (q - slot) / slots
   u64* out_queue;       // [nq][L] final master queues
   unsigned long long* counters;  // [0] distance evaluations, [1] expansions, [2] steps, [3] rounds, [4] fp32 rows read in step d
   unsigned long long* prof;      // optional [16]: shader-clock ticks per phase summed over the workgroups (EPS_TRV_PROF)
@@ -194,8 +201,9 @@ __global__ __launch_bounds__(NW * 64, PF ? 4 : 1) void traverse2_kernel(Trv2Args
   const int t = lane & (G - 1);
   constexpr int U = PF ? EPS_TRV_UPF : EPS_TRV_U;
   const int64_t slot = blockIdx.x;
-  u32* vis = a.visited + slot * a.words;
-  u32* vlog = a.vlog + slot * (int64_t)a.vcap;
+  u32* vis = a.gens ? nullptr : a.visited + slot * a.words;
+  u32* vlog = a.gens ? nullptr : a.vlog + slot * (int64_t)a.vcap;
+  u32* gen = a.gens ? a.gens + slot * a.gens_n : nullptr;
   u64* qbase = QGLOBAL ? a.qglobal + slot * a.qtot : qlds;
   int* aux = QGLOBAL ? a.auxglobal + slot * (int64_t)(2 * Lq) : auxl;
   u64* master = qbase + (int64_t)(T - 1) * Lq;
@@ -225,9 +233,10 @@ __global__ __launch_bounds__(NW * 64, PF ? 4 : 1) void traverse2_kernel(Trv2Args
       hmin[i] = 0x7FFFFFFF;
     }
     for (int i = L + tid; i < a.Lp2; i += NT) master[i] = KEY_EMPTY;
+    const u32 stamp = a.gen_base + 1u + (u32)((q - slot) / gridDim.x);
     for (int i = tid; i < L; i += NT) {
       const u32 id = a.init_ids[i];
-      atomicOr(&vis[id >> 5], 1u << (id & 31));
+      if (gen) atomicMax(&gen[id], stamp); else atomicOr(&vis[id >> 5], 1u << (id & 31));
     }
     __syncthreads();
     for (int c0 = wave * RPW * U; c0 < L; c0 += NW * RPW * U) {
@@ -421,7 +430,7 @@ __global__ __launch_bounds__(NW * 64, PF ? 4 : 1) void traverse2_kernel(Trv2Args
           u32 raw = 0;
           if (nb != TRV2_NONE) {
             const u32 bit = 1u << (nb & 31);
-            raw = (atomicOr(&vis[nb >> 5], bit) & bit) ? 0u : 1u;
+            raw = gen ? (atomicMax(&gen[nb], stamp) < stamp ? 1u : 0u) : ((atomicOr(&vis[nb >> 5], bit) & bit) ? 0u : 1u);
             if (raw && T > 1) {   // publish "this node became visited in this step" for the ownership resolution below
               u32 hs = (nb * 2654435761u) & (u32)(H - 1);
               while (true) {
@@ -482,8 +491,10 @@ __global__ __launch_bounds__(NW * 64, PF ? 4 : 1) void traverse2_kernel(Trv2Args
             const int pos = atomicAdd(&s_wcnt[w], 1);
             work[s_eoff[w] + pos] = nb;
             if (PF && a.nbr_acc0) wacc[s_eoff[w] + pos] = eacc[e];
-            const int ls = atomicAdd(&sh[2], 1);
-            if (ls < a.vcap) vlog[ls] = nb; else sh[7] = 1;
+            if (!gen) {
+              const int ls = atomicAdd(&sh[2], 1);
+              if (ls < a.vcap) vlog[ls] = nb; else sh[7] = 1;
+            }
           }
         }
         __syncthreads();
@@ -805,7 +816,9 @@ __global__ __launch_bounds__(NW * 64, PF ? 4 : 1) void traverse2_kernel(Trv2Args
       }
     }
     const int nlog = sh[2];
-    if (sh[7] || nlog > a.vcap) {
+    if (gen) {
+      // (nothing to undo: the next query of this slot carries a larger stamp)
+    } else if (sh[7] || nlog > a.vcap) {
       for (int64_t i = tid; i < a.words; i += NT) vis[i] = 0;
     } else {
       for (int i = tid; i < L; i += NT) vis[a.init_ids[i] >> 5] = 0;
