@@ -803,10 +803,10 @@ def main():
             ix.save_graph(args.save_graph)
         skw.update(intra_threads=args.T, master_queue=args.L, local_queue=args.L)
 
-    # one packed result buffer per rank: ids int64[b][k] then dist f32[b][k]; the search writes straight into it.  Two of everything
-    # (slot = step & 1): the end-to-end run copies step i's results to the host while step i + 1 computes
+    # one packed result buffer per rank: ids int64[b][k] then dist f32[b][k]; the search writes straight into it.  Three of everything
+    # (slot = step % 3): the end-to-end run copies step i's results to the host while steps i + 1, i + 2 compute
     pack_n = (b * k * 12 + 7) // 8 * 8
-    packs = [torch.empty((pack_n,), dtype=torch.uint8, device=dev) for _ in range(2)]
+    packs = [torch.empty((pack_n,), dtype=torch.uint8, device=dev) for _ in range(3)]
     idss = [p_[: b * k * 8].view(torch.int64).view(b, k) for p_ in packs]
     dds = [p_[b * k * 8: b * k * 12].view(torch.float32).view(b, k) for p_ in packs]
     cnt = torch.empty((b,), dtype=torch.int32, device=dev)
@@ -814,8 +814,8 @@ def main():
     xev = []   # N > 1: (before all-gather, after all-gather, after merge) event triples of the timed steps
     if world > 1:
         gathered = torch.empty((world, pack_n), dtype=torch.uint8, device=dev)
-        m_ds = [torch.empty((b, k), dtype=torch.float32, device=dev) for _ in range(2)]
-        m_is = [torch.empty((b, k), dtype=torch.int64, device=dev) for _ in range(2)]
+        m_ds = [torch.empty((b, k), dtype=torch.float32, device=dev) for _ in range(3)]
+        m_is = [torch.empty((b, k), dtype=torch.int64, device=dev) for _ in range(3)]
 
     def step(q, slot=0, timed=False):
         ix.search(q, k, out=(idss[slot], dds[slot], cnt), **skw)
@@ -873,27 +873,32 @@ def main():
             qh[s].copy_(queries[args.warmup + s])
         rh_i = [torch.empty((b, k), dtype=torch.int64).pin_memory() for _ in range(nst)]
         rh_d = [torch.empty((b, k), dtype=torch.float32).pin_memory() for _ in range(nst)]
-        dq = [torch.empty((b, d), dtype=torch.float32, device=dev) for _ in range(2)]
-        ev_up = [torch.cuda.Event() for _ in range(2)]
-        ev_done = [torch.cuda.Event() for _ in range(2)]
-        ev_down = [torch.cuda.Event() for _ in range(2)]
+        # three slots, queries TWO steps ahead: a copy issued while a long kernel holds every CU (the traversal: one launch of ~8 ms) is served in the
+        # gap between two searches, so it needs a whole step of lead to be ready in time (with one step of lead the traversal's end-to-end rate
+        # was 0.82 of the device-resident one, the flat scan's - many short launches - 0.97; scripts/lab/e2e_dbg.py)
+        dq = [torch.empty((b, d), dtype=torch.float32, device=dev) for _ in range(3)]
+        ev_up = [torch.cuda.Event() for _ in range(3)]
+        ev_done = [torch.cuda.Event() for _ in range(3)]
+        ev_down = [torch.cuda.Event() for _ in range(3)]
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         with torch.cuda.stream(cs):
-            dq[0].copy_(qh[0], non_blocking=True)
-            ev_up[0].record(cs)
+            for s in range(min(2, nst)):
+                dq[s].copy_(qh[s], non_blocking=True)
+                ev_up[s].record(cs)
         for s in range(nst):
-            cur = s & 1
-            if s + 1 < nst:
+            cur = s % 3
+            if s + 2 < nst:
+                nxt = (s + 2) % 3
                 with torch.cuda.stream(cs):
-                    cs.wait_event(ev_done[1 - cur])      # (step s - 1 read dq[1 - cur])
-                    dq[1 - cur].copy_(qh[s + 1], non_blocking=True)
-                    ev_up[1 - cur].record(cs)
+                    cs.wait_event(ev_done[nxt])          # (step s - 1 read dq[nxt])
+                    dq[nxt].copy_(qh[s + 2], non_blocking=True)
+                    ev_up[nxt].record(cs)
             main_s.wait_event(ev_up[cur])
-            main_s.wait_event(ev_down[cur])              # (step s - 2's results have left this slot's buffers)
+            main_s.wait_event(ev_down[cur])              # (step s - 3's results have left this slot's buffers)
             o_d, o_i = step(dq[cur], cur)
             ev_done[cur].record(main_s)
             with torch.cuda.stream(cs):
@@ -921,7 +926,7 @@ def main():
         e2e = {"value": b * nst / el2, "unit": "queries/s", "ms_per_step": 1e3 * el2 / nst, "frac_of_device_resident": elapsed / el2,
                "last_step_equals_device_resident_run": same,
                "what": "host (pinned) queries -> H2D -> eps_index_search%s -> D2H -> host ids + distances, all inside the timed region; copies on a second stream, "
-                       "two slots (batch i + 1 up / batch i - 1 down under batch i)" % (" -> all-gather -> merge" if world > 1 else ""),
+                       "three slots (batch i + 2 up / batch i - 1 down under batch i)" % (" -> all-gather -> merge" if world > 1 else ""),
                "unpipelined_host_pointers": {"ms_per_step": 1e3 * un, "value": b / un,
                                              "what": "eps_index_search called with pageable host pointers (this rank's shard only), no staging, no overlap: the library's own hipMemcpy path"}}
     # clock and power under this workload (N = 1, after the timed region): the filter kernel runs against the board's power limit

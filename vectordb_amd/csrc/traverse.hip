@@ -347,14 +347,14 @@ int32_t graph_search_impl(Index& ix, const float* dq, int64_t nq, int k, const e
   const int64_t ecap_plan = std::min<int64_t>(n, std::max<int64_t>(std::max<int64_t>(16384, 64 * L), ecap_min));
   const int64_t slice = std::max<int64_t>(1, std::min<int64_t>(nq, ((int64_t)2 << 30) / (std::max<int64_t>(L, p.filter_in_traversal ? ecap_plan : 0) * 8)));
   // visited set: generation stamps (one atomicMax per edge, no reset) when 4 bytes per node and slot fit comfortably - a quarter of the free HBM
-  // and at most 64 GB, batches only - else the bitmap with its undo log.  EPS_TRV_VISITED=bitmap|stamps overrides (A/B, tests).
+  // and at most 64 GB - else the bitmap with its undo log.  EPS_TRV_VISITED=bitmap|stamps overrides (A/B, tests).
   bool stamps = false;
   {
     const size_t need = (size_t)slots * (size_t)n * 4;
     size_t free_b = 0, total_b = 0;
     const bool have = (g.gens_slots >= slots && g.gens_n == n && g.gens.p);
     if (have) stamps = true;
-    else if (!qglobal && nq >= 64 && hipMemGetInfo(&free_b, &total_b) == hipSuccess && need <= free_b / 4 && need <= ((size_t)64 << 30)) stamps = true;
+    else if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need <= free_b / 4 && need <= ((size_t)64 << 30)) stamps = true;
     if (const char* ve = tune_env("EPS_TRV_VISITED")) stamps = std::strcmp(ve, "stamps") == 0 ? true : (std::strcmp(ve, "bitmap") == 0 ? false : stamps);
     if (stamps && !have) {
       g.gens.release();
