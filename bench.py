@@ -860,53 +860,33 @@ def main():
     xchg_us = [(e[0].elapsed_time(e[1]) * 1e3, e[1].elapsed_time(e[2]) * 1e3) for e in xev]
 
     # ---- the same steps END TO END ("QPS end-to-end including H2D of queries and D2H of results"; the reference's entry takes a
-    # host vector per call, table_mvp.cpp:359-380): every batch starts in (pinned) host memory and its ids / distances end in host memory,
-    # inside the timed region.  The copies run on a second stream: batch i + 1 goes up and batch i - 1's results come down while batch i
-    # computes.  `value` stays the device-resident rate (the contract: inputs resident in HBM); this one is reported beside it.
+    # host vector per call, table_mvp.cpp:359-380): every batch starts in host memory and its ids / distances end in host memory,
+    # inside the timed region.  `value` stays the device-resident rate (the contract: inputs resident in HBM); this one is reported beside it.
     e2e = None
     if args.e2e:
-        cs = torch.cuda.Stream(device=dev)
-        main_s = torch.cuda.current_stream()
+        # Through the C ABI's own host path: eps_index_search with HOST query and result pointers - the library copies the batch up, searches, copies
+        # the ids / distances down, inside the call (csrc/index.cpp) - exactly what the drop-in's VecSearchExecutor hands it.  Staging by the caller
+        # on a second stream was measured and dropped (scripts/lab/e2e_dbg.py; the three-slot form of profiles/r5_bench_graph_10Mx768_manifold_T4_L100.json):
+        # a copy that runs CONCURRENTLY with the traversal's one long launch - 1024 workgroups that fill every CU exactly once - takes a workgroup
+        # slot from it and the launch runs a second round (0.71-0.82 of the device-resident rate; 0.93-0.97 through the library's path), and for the
+        # flat scan's chain of short launches both forms measure the same (0.97).
         nst = args.steps
-        qh = [torch.empty((b, d), dtype=torch.float32).pin_memory() for _ in range(nst)]
-        for s in range(nst):
-            qh[s].copy_(queries[args.warmup + s])
-        rh_i = [torch.empty((b, k), dtype=torch.int64).pin_memory() for _ in range(nst)]
-        rh_d = [torch.empty((b, k), dtype=torch.float32).pin_memory() for _ in range(nst)]
-        # three slots, queries TWO steps ahead: a copy issued while a long kernel holds every CU (the traversal: one launch of ~8 ms) is served in the
-        # gap between two searches, so it needs a whole step of lead to be ready in time (with one step of lead the traversal's end-to-end rate
-        # was 0.82 of the device-resident one, the flat scan's - many short launches - 0.97; scripts/lab/e2e_dbg.py)
-        dq = [torch.empty((b, d), dtype=torch.float32, device=dev) for _ in range(3)]
-        ev_up = [torch.cuda.Event() for _ in range(3)]
-        ev_done = [torch.cuda.Event() for _ in range(3)]
-        ev_down = [torch.cuda.Event() for _ in range(3)]
+        qn = [queries[args.warmup + s].cpu().numpy() for s in range(nst)]
+        rh_i = [torch.empty((b, k), dtype=torch.int64).pin_memory() for _ in range(nst)] if world > 1 else None
+        rh_d = [torch.empty((b, k), dtype=torch.float32).pin_memory() for _ in range(nst)] if world > 1 else None
+        last = None
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        with torch.cuda.stream(cs):
-            for s in range(min(2, nst)):
-                dq[s].copy_(qh[s], non_blocking=True)
-                ev_up[s].record(cs)
         for s in range(nst):
-            cur = s % 3
-            if s + 2 < nst:
-                nxt = (s + 2) % 3
-                with torch.cuda.stream(cs):
-                    cs.wait_event(ev_done[nxt])          # (step s - 1 read dq[nxt])
-                    dq[nxt].copy_(qh[s + 2], non_blocking=True)
-                    ev_up[nxt].record(cs)
-            main_s.wait_event(ev_up[cur])
-            main_s.wait_event(ev_down[cur])              # (step s - 3's results have left this slot's buffers)
-            o_d, o_i = step(dq[cur], cur)
-            ev_done[cur].record(main_s)
-            with torch.cuda.stream(cs):
-                cs.wait_event(ev_done[cur])
-                rh_i[s].copy_(o_i, non_blocking=True)
+            if world == 1:
+                last = ix.search(qn[s], k, **skw)                # host in, host out
+            else:
+                o_d, o_i = step(qn[s], s % 3)                    # host queries in; the per-shard lists meet on the devices (all-gather, merge) ...
+                rh_i[s].copy_(o_i, non_blocking=True)            # ... and the merged answer comes down
                 rh_d[s].copy_(o_d, non_blocking=True)
-                ev_down[cur].record(cs)
-        cs.synchronize()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -916,19 +896,13 @@ def main():
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el2 = float(t.item())
-        same = bool((rh_i[nst - 1] == got_i.cpu()).all())   # (same queries as the device-resident run's last step: the same answer, now in host memory)
-        # ... and one call with plain (pageable) host buffers straight through the C ABI, nothing overlapped: what a caller that does no staging gets
-        qn = qh[nst - 1].numpy().copy()
-        t1 = time.perf_counter()
-        for _ in range(3):
-            ix.search(qn, k, **skw)
-        un = (time.perf_counter() - t1) / 3
+        last_ids = last[0] if world == 1 else rh_i[nst - 1].numpy()
+        same = bool((last_ids == got_i.cpu().numpy()).all())   # (the same queries as the device-resident run's last step: the same answer, now in host memory)
         e2e = {"value": b * nst / el2, "unit": "queries/s", "ms_per_step": 1e3 * el2 / nst, "frac_of_device_resident": elapsed / el2,
                "last_step_equals_device_resident_run": same,
-               "what": "host (pinned) queries -> H2D -> eps_index_search%s -> D2H -> host ids + distances, all inside the timed region; copies on a second stream, "
-                       "three slots (batch i + 2 up / batch i - 1 down under batch i)" % (" -> all-gather -> merge" if world > 1 else ""),
-               "unpipelined_host_pointers": {"ms_per_step": 1e3 * un, "value": b / un,
-                                             "what": "eps_index_search called with pageable host pointers (this rank's shard only), no staging, no overlap: the library's own hipMemcpy path"}}
+               "what": "eps_index_search with HOST query%s pointers (pageable numpy): H2D of the batch, the search%s, D2H of ids + distances, all inside the call and "
+                       "inside the timed region; no caller-side staging (see the comment in bench.py for the staged form that measured worse)"
+                       % ((" and result", "") if world == 1 else ("", ", all-gather, merge"))}
     # clock and power under this workload (N = 1, after the timed region): the filter kernel runs against the board's power limit
     power = power_leg(torch, step, queries, args.power_seconds, local_rank) if (world == 1 and rank == 0 and args.power_seconds > 0) else None
 

@@ -23,6 +23,9 @@
 #undef PyInit_epsilla
 
 #include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 
@@ -249,6 +252,8 @@ static PyObject* eps_query_batch(PyObject* self, PyObject* args, PyObject* kwarg
   // (epsdrop::SearchBatch, include/epsdrop/search_batch.hpp)
   std::string err;
   epsdrop::BatchHits hits;
+  static const bool timing = getenv("EPS_DROPIN_TIMING") && atoi(getenv("EPS_DROPIN_TIMING")) != 0;   // (phase times of every call on stderr)
+  const auto t_args = std::chrono::steady_clock::now();
   Py_BEGIN_ALLOW_THREADS
   try {
     for (auto& f : fields) {   // (TableMVP::Search checks the response fields before it searches, table_mvp.cpp:310-314)
@@ -267,6 +272,7 @@ static PyObject* eps_query_batch(PyObject* self, PyObject* args, PyObject* kwarg
     PyErr_SetString(PyExc_Exception, err.c_str());
     return NULL;
   }
+  const auto t_search = std::chrono::steady_clock::now();
   std::shared_ptr<vectordb::engine::TableMVP> table = hits.table;
   std::vector<int64_t>& ids = hits.ids;
   std::vector<float>& dist = hits.dist;
@@ -319,6 +325,11 @@ static PyObject* eps_query_batch(PyObject* self, PyObject* args, PyObject* kwarg
     Py_DECREF(out);
     if (!PyErr_Occurred()) PyErr_SetString(PyExc_Exception, "query_batch: projection failed");
     return NULL;
+  }
+  if (timing) {
+    const auto t_end = std::chrono::steady_clock::now();
+    fprintf(stderr, "[epsilla.query_batch] %lld vectors: search (lookups + H2D + device + D2H) %.3f ms, projection to Python objects %.3f ms\n", (long long)nq,
+            1e3 * std::chrono::duration<double>(t_search - t_args).count(), 1e3 * std::chrono::duration<double>(t_end - t_search).count());
   }
   return Py_BuildValue("(iN)", 0, out);
 }

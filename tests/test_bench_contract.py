@@ -35,11 +35,11 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
         assert key in cb, key
     assert cb["kind"] in ("reference", "port")
     assert d["recall_at_10"] >= 0.999
-    # r5: N = 1 lines carry no scaling claim; the same steps end to end (host queries in, host results out, copies overlapped) beside the
+    # r5: N = 1 lines carry no scaling claim; the same steps end to end (host queries in, host results out, inside the timed region) beside the
     # device-resident value (the contract's timed region), and the reference's own BruteForceSearch answers compared with the GPU's
     assert d["scaling"] is None and d["value_device_resident"] == d["value"]
     e = d["end_to_end"]
-    assert e["last_step_equals_device_resident_run"] is True and e["value"] > 0 and e["unpipelined_host_pointers"]["value"] > 0
+    assert e["last_step_equals_device_resident_run"] is True and e["value"] > 0
     if cb["kind"] == "reference":
         bf = [l for l in cb["legs"] if l["leg"] == "bruteforce"][0]
         assert bf["gpu_headline_answers_equal"] == bf["queries"], bf

@@ -295,9 +295,12 @@ class GpuIndex:
             if queries.ndim == 1:
                 queries = queries[None, :]
             nq = queries.shape[0]
-            ids = np.empty((nq, k), np.int64)
-            dist = np.empty((nq, k), np.float32)
-            counts = np.empty(nq, np.int32)
+            if out is not None:   # (host queries, caller-provided result buffers - host or device: the C ABI takes either side independently)
+                ids, dist, counts = out
+            else:
+                ids = np.empty((nq, k), np.int64)
+                dist = np.empty((nq, k), np.float32)
+                counts = np.empty(nq, np.int32)
         assert queries.shape[1] == self.dim
         self._check(self.L.eps_index_search(self.h, _ptr(queries), nq, k, C.byref(p), _ptr(ids), _ptr(dist), _ptr(counts)))
         return ids, dist, counts
