@@ -13,6 +13,7 @@
 //   load_db_scaled(db_name, db_path, vector_scale, wal_enabled=True) -> int
 //                                                      load_db with the table capacity the REST API calls vectorScale
 //   query_batch(table_name, query_field, query_vectors, response_fields, limit, filter, with_distance)
+//       [, as_arrays=False]                            (r5) as_arrays=True: (int, {field: ndarray[N][limit], "@distance": float32[N][limit], "@count": int32[N]})
 //       -> (int, list[list[dict]])                     query() for N vectors (a 2-D float32 / float64 buffer such as a NumPy
 //                                                      array, or a list of lists): ONE eps_index_search with nq = N through
 //                                                      VecSearchExecutor::SearchBatch, one projection pass; element q of the
@@ -27,6 +28,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <thread>
 
 static PyObject* eps_rebuild(PyObject* self, PyObject* args, PyObject* kwargs) {
@@ -174,12 +176,12 @@ PyObject* RowToDict(vectordb::engine::TableSegmentMVP& seg, const std::vector<Fi
 
 static PyObject* eps_query_batch(PyObject* self, PyObject* args, PyObject* kwargs) {
   (void)self;
-  static const char* keywords[] = {"table_name", "query_field", "query_vectors", "response_fields", "limit", "filter", "with_distance", NULL};
+  static const char* keywords[] = {"table_name", "query_field", "query_vectors", "response_fields", "limit", "filter", "with_distance", "as_arrays", NULL};
   const char *tableNamePtr, *queryFieldPtr, *queryFilterPtr;
-  int limit, withDistance;
+  int limit, withDistance, asArrays = 0;
   PyObject *queryVectors, *responseFields;
-  if (!PyArg_ParseTupleAndKeywords(args, kwargs, "ssOOisp", (char**)keywords, &tableNamePtr, &queryFieldPtr, &queryVectors, &responseFields,
-                                   &limit, &queryFilterPtr, &withDistance))
+  if (!PyArg_ParseTupleAndKeywords(args, kwargs, "ssOOisp|p", (char**)keywords, &tableNamePtr, &queryFieldPtr, &queryVectors, &responseFields,
+                                   &limit, &queryFilterPtr, &withDistance, &asArrays))
     return NULL;
   if (!PyList_Check(responseFields)) {
     PyErr_SetString(PyExc_Exception, "response_fields must be a list");
@@ -278,6 +280,84 @@ static PyObject* eps_query_batch(PyObject* self, PyObject* args, PyObject* kwarg
   std::vector<float>& dist = hits.dist;
   std::vector<int32_t>& counts = hits.counts;
   const int32_t width = hits.width;
+
+  // ---- as_arrays=True (r5): the answer as NumPy arrays instead of nq x limit dicts - one [nq][limit] array per requested numeric field,
+  // "@distance" float32 [nq][limit] (+inf beyond a query's count), "@count" int32 [nq].  Creating and later freeing 10 240 dicts is 1.1 ms of
+  // an 8.6 ms batch at 10M x 768 (profiles/r5_module_query_batch_10Mx768_phases.txt); the arrays cost microseconds.
+  if (asArrays) {
+    using vectordb::engine::meta::FieldType;
+    std::vector<FieldPlan> plan;
+    if (!PlanFields(*table, fields, plan)) {
+      PyErr_SetString(PyExc_Exception, "query_batch(as_arrays=True): response_fields must be numeric or BOOL fields");
+      return NULL;
+    }
+    PyObject* np = PyImport_ImportModule("numpy");
+    if (!np) return NULL;
+    PyObject* result = PyDict_New();
+    auto& seg = *table->table_segment_;
+    const Py_ssize_t total = (Py_ssize_t)nq * limit;
+    auto put = [&](const char* key, const void* data, size_t bytes, const char* dtype, bool matrix) -> bool {
+      PyObject* b = PyBytes_FromStringAndSize(static_cast<const char*>(data), (Py_ssize_t)bytes);
+      PyObject* a = b ? PyObject_CallMethod(np, "frombuffer", "Os", b, dtype) : NULL;
+      Py_XDECREF(b);
+      if (a && matrix) {
+        PyObject* r = PyObject_CallMethod(a, "reshape", "nn", (Py_ssize_t)nq, (Py_ssize_t)limit);
+        Py_DECREF(a);
+        a = r;
+      }
+      const bool ok2 = a && PyDict_SetItemString(result, key, a) == 0;
+      Py_XDECREF(a);
+      return ok2;
+    };
+    bool ok2 = result != NULL;
+    std::vector<int32_t> cnts((size_t)nq);
+    for (Py_ssize_t q = 0; q < nq; ++q) cnts[(size_t)q] = (int32_t)std::max<int64_t>(0, std::min<int64_t>(counts[(size_t)q], limit));
+    for (auto& p : plan) {
+      if (!ok2) break;
+      if (p.type == FieldType::STRING || p.type == FieldType::VECTOR_FLOAT || p.type == FieldType::VECTOR_DOUBLE) {
+        PyErr_SetString(PyExc_Exception, "query_batch(as_arrays=True): response_fields must be numeric or BOOL fields");
+        ok2 = false;
+        break;
+      }
+      const bool is_float = p.type == FieldType::FLOAT || p.type == FieldType::DOUBLE;
+      std::vector<int64_t> iv(is_float ? 0 : (size_t)total, -1);
+      std::vector<double> fv(is_float ? (size_t)total : 0, std::numeric_limits<double>::quiet_NaN());
+      for (Py_ssize_t q = 0; q < nq; ++q)
+        for (int32_t i = 0; i < cnts[(size_t)q]; ++i) {
+          const char* at = seg.attribute_table_ + p.offset + ids[(size_t)q * width + i] * seg.primitive_offset_;
+          const size_t o = (size_t)q * limit + i;
+          switch (p.type) {
+            case FieldType::INT1: { int8_t x; std::memcpy(&x, at, 1); iv[o] = x; break; }
+            case FieldType::INT2: { int16_t x; std::memcpy(&x, at, 2); iv[o] = x; break; }
+            case FieldType::INT4: { int32_t x; std::memcpy(&x, at, 4); iv[o] = x; break; }
+            case FieldType::INT8: { int64_t x; std::memcpy(&x, at, 8); iv[o] = x; break; }
+            case FieldType::BOOL: { bool x; std::memcpy(&x, at, 1); iv[o] = x ? 1 : 0; break; }
+            case FieldType::FLOAT: { float x; std::memcpy(&x, at, 4); fv[o] = x; break; }
+            default: { double x; std::memcpy(&x, at, 8); fv[o] = x; }
+          }
+        }
+      ok2 = is_float ? put(p.name.c_str(), fv.data(), fv.size() * 8, "float64", true) : put(p.name.c_str(), iv.data(), iv.size() * 8, "int64", true);
+    }
+    if (ok2 && withDistance) {
+      std::vector<float> dv((size_t)total, std::numeric_limits<float>::infinity());
+      for (Py_ssize_t q = 0; q < nq; ++q)
+        for (int32_t i = 0; i < cnts[(size_t)q]; ++i) dv[(size_t)q * limit + i] = dist[(size_t)q * width + i];
+      ok2 = put("@distance", dv.data(), dv.size() * 4, "float32", true);
+    }
+    if (ok2) ok2 = put("@count", cnts.data(), cnts.size() * 4, "int32", false);
+    Py_DECREF(np);
+    if (!ok2) {
+      Py_XDECREF(result);
+      if (!PyErr_Occurred()) PyErr_SetString(PyExc_Exception, "query_batch(as_arrays=True): could not build the arrays");
+      return NULL;
+    }
+    if (timing) {
+      const auto t_end = std::chrono::steady_clock::now();
+      fprintf(stderr, "[epsilla.query_batch] %lld vectors: search (lookups + H2D + device + D2H) %.3f ms, arrays %.3f ms\n", (long long)nq,
+              1e3 * std::chrono::duration<double>(t_search - t_args).count(), 1e3 * std::chrono::duration<double>(t_end - t_search).count());
+    }
+    return Py_BuildValue("(iN)", 0, result);
+  }
 
   // ---- projection, once for the whole batch
   PyObject* out = PyList_New(nq);

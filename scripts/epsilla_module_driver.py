@@ -82,6 +82,17 @@ if what == "bulk":
             assert code == 0 and len(resp) == nq
             out["batch"][flt] = {"qps": nq / sec, "ms_per_batch": 1e3 * sec, "queries": nq, "batches": batches,
                                  "results": [[[r["ID"] for r in rr], [r["@distance"] for r in rr]] for rr in resp[:64]]}
+            # r5: the same batch answered as NumPy arrays (no per-row Python objects)
+            code, arr = epsilla.query_batch(query_vectors=Q, filter=flt, as_arrays=True, **kw)
+            t0 = time.perf_counter()
+            for _ in range(batches):
+                code, arr = epsilla.query_batch(query_vectors=Q, filter=flt, as_arrays=True, **kw)
+            sec = (time.perf_counter() - t0) / batches
+            same = all([r["ID"] for r in resp[i]] == arr["ID"][i][:arr["@count"][i]].tolist() and
+                       np.allclose([r["@distance"] for r in resp[i]], arr["@distance"][i][:arr["@count"][i]], rtol=1e-6, atol=0) for i in range(len(resp)))
+            out["batch_arrays"] = out.get("batch_arrays", {})
+            out["batch_arrays"][flt] = {"qps": nq / sec, "ms_per_batch": 1e3 * sec, "equals_the_dict_form": bool(same), "shapes": [list(arr["ID"].shape), list(arr["@distance"].shape), list(arr["@count"].shape)],
+                                        "dtypes": [str(arr["ID"].dtype), str(arr["@distance"].dtype), str(arr["@count"].dtype)]}
         code, resp2 = epsilla.query_batch(query_vectors=[q.tolist() for q in Q[:8]], filter="", **kw)   # list-of-lists form
         out["batch"]["lists"] = [[[r["ID"] for r in rr], [r["@distance"] for r in rr]] for rr in resp2]
         code, resp3 = epsilla.query_batch(query_vectors=Q[:4].astype(np.float64), filter="", table_name="T", query_field="V", response_fields=[],

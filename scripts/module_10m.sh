@@ -18,6 +18,7 @@ for f in ('', 'ID < %d' % (rows//2)):
     b=o['batch'][f]
     s['query_batch filter %r' % f]={'qps':b['qps'],'ms_per_batch':b['ms_per_batch'],'queries':b['queries'],'batches':b['batches'],
       'equals_query()_on_first_16':all(o['single'][f]['results'][i][0]==b['results'][i][0] for i in range(16))}
+    if 'batch_arrays' in o: s['query_batch(as_arrays=True) filter %r' % f]=o['batch_arrays'][f]
 if 'graph' in o:
     s['rebuild() on the device mirror, seconds'] = o['rebuild_s']
     s['query_batch after rebuild (graph traversal, the reference\'s defaults)'] = o['graph']

@@ -116,6 +116,9 @@ def test_gfx950_module_query_batch_is_one_device_batch_and_equals_single_queries
     for i in range(4):
         assert out["batch"][""]["results"][i][0] == out["numpy_top10"][i], i
     assert out["batch"]["lists"] == out["batch"][""]["results"][:8]
+    for flt in ("", "ID < %d" % (rows // 2)):    # r5: as_arrays=True returns the same answer as NumPy arrays
+        a = out["batch_arrays"][flt]
+        assert a["equals_the_dict_form"] and a["shapes"] == [[nq, 10], [nq, 10], [nq]] and a["dtypes"] == ["int64", "float32", "int32"], a
     assert out["batch"]["all_fields_keys"] == ["ID", "V"]
     assert out["batch"]["all_fields_ids"] == [r[0][:3] for r in out["batch"][""]["results"][:4]]
     if _have(REF_DIR):   # the reference's own module over the same files
