@@ -193,6 +193,16 @@ __device__ __forceinline__ int stage_threshold8(float thr, const float* qs, cons
   return (int)v;
 }
 
+// sum over the 16 lanes of a DPP row (every lane gets it): two quad permutes, then half-row and row mirrors - 4 VALU instructions, no LDS
+// (__shfl_xor compiles to ds_bpermute: 16 LDS round trips per step of this kernel)
+__device__ __forceinline__ int row16_sum(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);   // row_half_mirror: the other quad of the same 8 lanes
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);   // row_mirror: the other half of the row
+  return v;
+}
+
 // Seed sample of the MFMA engine: sample entry i is table row i for the first `head` entries (the head of the table), then
 // rows spread evenly over the rest: head + ((i - head) * stride >> 32), stride = (rest rows / rest entries) in 32.32.
 __host__ __device__ __forceinline__ u32 seed_row(u32 i, u32 head, u64 stride) {

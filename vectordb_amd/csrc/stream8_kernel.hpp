@@ -110,16 +110,6 @@ __device__ __forceinline__ void stream8_offer(const Stream8Args& a, int q, int a
   (void)__hip_atomic_fetch_max(a.G + (q * S8_SLOTS + (int)slot) * S8_SLOT_STRIDE, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// sum over the 16 lanes of a DPP row (every lane gets it): two quad permutes, then half-row and row mirrors - 4 VALU instructions, no LDS
-// (__shfl_xor compiles to ds_bpermute: 16 LDS round trips per step of this kernel)
-__device__ __forceinline__ int row16_sum(int v) {
-  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
-  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
-  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);   // row_half_mirror: the other quad of the same 8 lanes
-  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);   // row_mirror: the other half of the row
-  return v;
-}
-
 // PIECES = d_pad8 / 256: a row is PIECES x 256 bytes, 16 lanes x 16 bytes each; four rows per wavefront and step, U steps in flight.
 // The table is READ by one wavefront per workgroup, every fourth iteration, and handed to the other three through LDS: read by every
 // wavefront in every iteration (4096 cache-bypassing loads of one 64-byte line per round) the loads queued up at that line's memory

@@ -566,9 +566,14 @@ __global__ __launch_bounds__(NW * 64, PF ? 4 : 1) void traverse2_kernel(Trv2Args
                 }
               }
             }
-            for (int o = G8 >> 1; o > 0; o >>= 1) {
+            if (G8 == 16) {   // (one DPP row per mirror row - d in (512, 768]: 4 VALU instructions per sum instead of 4 LDS-crossbar round trips; integer sums, any order)
 #pragma unroll
-              for (int u = 0; u < U8; ++u) dot[u] += __shfl_xor(dot[u], o);
+              for (int u = 0; u < U8; ++u) dot[u] = row16_sum(dot[u]);
+            } else {
+              for (int o = G8 >> 1; o > 0; o >>= 1) {
+#pragma unroll
+                for (int u = 0; u < U8; ++u) dot[u] += __shfl_xor(dot[u], o);
+              }
             }
 #pragma unroll
             for (int u = 0; u < U8; ++u)

@@ -302,9 +302,14 @@ __global__ __launch_bounds__(NW * 64) void traverse_kernel(TraverseArgs a) {
               }
             }
           }
-          for (int o = G8 >> 1; o > 0; o >>= 1) {
+          if (G8 == 16) {   // (one DPP row per mirror row: device_common.hpp row16_sum; integer sums, any order)
 #pragma unroll
-            for (int u = 0; u < U8; ++u) dot[u] += __shfl_xor(dot[u], o);
+            for (int u = 0; u < U8; ++u) dot[u] = row16_sum(dot[u]);
+          } else {
+            for (int o = G8 >> 1; o > 0; o >>= 1) {
+#pragma unroll
+              for (int u = 0; u < U8; ++u) dot[u] += __shfl_xor(dot[u], o);
+            }
           }
 #pragma unroll
           for (int u = 0; u < U8; ++u)
