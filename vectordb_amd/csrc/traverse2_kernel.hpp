@@ -160,6 +160,7 @@ __global__ __launch_bounds__(NW * 64, PF ? 4 : 1) void traverse2_kernel(Trv2Args
   int* npos = reinterpret_cast<int*>(work + ecap);                          // [ecap] insert positions
   int* eacc = reinterpret_cast<int*>(newk);                                 // PF, nbr_acc0: [ecap] row constant per edge slot (steps b-c; `newk` is written from step d on)
   int* wacc = eacc + ecap;                                                  //               [ecap] ... per entry of `work` (steps c-d0)
+  u32* wwk = reinterpret_cast<u32*>(sorted);                                // PF: [ecap] worker of every entry of `work` (steps c-d0; `sorted` is written in step e)
   const int H = a.hslots;                                                   // ownership table slots (power of two; 0 when T == 1)
   u32* hid = reinterpret_cast<u32*>(npos + ecap);                           // [H] node id, TRV2_NONE = empty
   int* hmin = reinterpret_cast<int*>(hid + H);                              // [H] lowest edge slot that met the node this step
@@ -358,8 +359,8 @@ __global__ __launch_bounds__(NW * 64, PF ? 4 : 1) void traverse2_kernel(Trv2Args
       while (true) {
         // a. every worker with iterations left takes its first unchecked candidate at or after k_uc (:632-672).  One
         //    wavefront per worker (ballot over 64 queue positions at a time), the workers side by side.
-        if (tid == 0) sh[3] = 0;
-        __syncthreads();
+        // (sh[3] "somebody selected" and sh[10] "nodes to evaluate" are zero here: zeroed with the query's scratch, and again at the end of every step -
+        // r5: a barrier of this workgroup costs ~0.4 us among 16 wavefronts per CU, a step had 17 of them, a T = 1 step lasts 17 us)
         for (int w = wave; w < T; w += NW) {
           u64* qw = qbase + (int64_t)w * Lq;
           const int size = s_size[w];
@@ -393,18 +394,24 @@ __global__ __launch_bounds__(NW * 64, PF ? 4 : 1) void traverse2_kernel(Trv2Args
             }
             s_wcnt[w] = 0;
             s_nnew[w] = 0;
+            if (T == 1) {   // (one worker: its edge offsets need no prefix over the others)
+              s_eoff[0] = 0;
+              s_eoff[1] = (s_deg[0] + 7) & ~7;
+            }
           }
         }
         __syncthreads();
-        if (tid == 0) {
-          int acc = 0;
-          for (int w = 0; w < T; ++w) {   // segments start on multiples of 8 edge slots (the rank sort reads 8 keys at a time)
-            s_eoff[w] = acc;
-            acc += (s_deg[w] + 7) & ~7;
+        if (T > 1) {
+          if (tid == 0) {
+            int acc = 0;
+            for (int w = 0; w < T; ++w) {   // segments start on multiples of 8 edge slots (the rank sort reads 8 keys at a time)
+              s_eoff[w] = acc;
+              acc += (s_deg[w] + 7) & ~7;
+            }
+            s_eoff[T] = acc;
           }
-          s_eoff[T] = acc;
+          __syncthreads();
         }
-        __syncthreads();
         TRV2_LAP(2)
         if (!sh[3]) break;   // uniform: nobody expanded -> the round is over
         ++steps;
@@ -431,13 +438,19 @@ __global__ __launch_bounds__(NW * 64, PF ? 4 : 1) void traverse2_kernel(Trv2Args
           if (nb != TRV2_NONE) {
             const u32 bit = 1u << (nb & 31);
             raw = gen ? (atomicMax(&gen[nb], stamp) < stamp ? 1u : 0u) : ((atomicOr(&vis[nb >> 5], bit) & bit) ? 0u : 1u);
-            if (raw && T > 1) {   // publish "this node became visited in this step" for the ownership resolution below
+            if (T > 1) {
+              // ownership (step c) in the same pass (r5: it was a publish pass, a bid pass and a resolve pass): EVERY edge slot enters its node
+              // into the step's table and bids for it with its index; the slot whose test-and-set made the node visited also sets the entry's top
+              // bit ("became visited in THIS step").  After one barrier: the lowest bidder of a node with that bit owns it.
               u32 hs = (nb * 2654435761u) & (u32)(H - 1);
               while (true) {
                 const u32 old = atomicCAS(&hid[hs], TRV2_NONE, nb);
-                if (old == TRV2_NONE || old == nb) break;
+                if (old == TRV2_NONE || (old & 0x7FFFFFFFu) == nb) break;
                 hs = (hs + 1) & (u32)(H - 1);
               }
+              atomicMin(&hmin[hs], e);
+              if (raw) atomicOr(&hid[hs], 0x80000000u);
+              npos[e] = (int)hs;   // (insert positions are not live before step f)
             }
           }
           eid[e] = nb;
@@ -449,23 +462,6 @@ __global__ __launch_bounds__(NW * 64, PF ? 4 : 1) void traverse2_kernel(Trv2Args
         //    reference's sequential `if (is_visited[nb]) continue; is_visited[nb] = true;`, :403-406, under the
         //    lockstep schedule); which edge slot's atomicOr happened to win is irrelevant.  Every edge slot whose node
         //    became visited in this step bids with its index, the lowest index owns the node.
-        if (T > 1) {
-          for (int e = tid; e < etot; e += NT) {
-            const u32 nb = eid[e];
-            if (nb == TRV2_NONE) continue;
-            u32 hs = (nb * 2654435761u) & (u32)(H - 1);
-            while (true) {
-              const u32 v = hid[hs];
-              if (v == nb) {
-                atomicMin(&hmin[hs], e);
-                break;
-              }
-              if (v == TRV2_NONE) break;
-              hs = (hs + 1) & (u32)(H - 1);
-            }
-          }
-          __syncthreads();
-        }
         for (int e = tid; e < etot; e += NT) {
           const u32 nb = eid[e];
           bool mine = false;
@@ -473,29 +469,33 @@ __global__ __launch_bounds__(NW * 64, PF ? 4 : 1) void traverse2_kernel(Trv2Args
             if (T == 1) {
               mine = eraw[e] != 0;
             } else {
-              u32 hs = (nb * 2654435761u) & (u32)(H - 1);
-              while (true) {
-                const u32 v = hid[hs];
-                if (v == nb) {
-                  mine = hmin[hs] == e;
-                  break;
-                }
-                if (v == TRV2_NONE) break;
-                hs = (hs + 1) & (u32)(H - 1);
-              }
+              const int hs = npos[e];
+              mine = hmin[hs] == e && (hid[hs] >> 31) != 0;
             }
           }
           if (mine) {
             int w = 0;
             while (w < T - 1 && e >= s_eoff[w + 1]) ++w;
-            const int pos = atomicAdd(&s_wcnt[w], 1);
-            work[s_eoff[w] + pos] = nb;
-            if (PF && a.nbr_acc0) wacc[s_eoff[w] + pos] = eacc[e];
+            if (PF) {
+              // prefilter form (r5): ONE list of the step's nodes to evaluate, whatever worker they belong to - the mirror-row passes index it
+              // directly (they used to map every item to (worker, offset) through the per-worker counts: T - 1 dependent LDS reads per row)
+              const int pos = atomicAdd(&sh[10], 1);
+              work[pos] = nb;
+              wwk[pos] = (u32)w;
+              if (a.nbr_acc0) wacc[pos] = eacc[e];
+            } else {
+              const int pos = atomicAdd(&s_wcnt[w], 1);
+              work[s_eoff[w] + pos] = nb;
+            }
             if (!gen) {
               const int ls = atomicAdd(&sh[2], 1);
               if (ls < a.vcap) vlog[ls] = nb; else sh[7] = 1;
             }
           }
+        }
+        if (pf) {   // (step d0's threshold and survivor counters: laid down here, under this step's barrier)
+          if (tid == 0) sh[9] = stage_threshold8(bound, qst, a.scal8, a.metric, a.u8, a.slack8, 0);
+          if (tid < T) s_pcnt[tid] = 0;
         }
         __syncthreads();
         if (T > 1)   // leave the ownership table empty for the next step
@@ -507,18 +507,18 @@ __global__ __launch_bounds__(NW * 64, PF ? 4 : 1) void traverse2_kernel(Trv2Args
         // d. distances of all surviving neighbours (every wavefront, 16 B/lane row loads); candidates beyond the
         //    bound are dropped (`dist > dist_bound`, :427)
         int nwork = 0;
-        for (int w = 0; w < T; ++w) nwork += s_wcnt[w];
+        if (PF) nwork = sh[10];
+        else
+          for (int w = 0; w < T; ++w) nwork += s_wcnt[w];
         evals += nwork;
         const u32* wk = work;
+        const int* cntp = s_wcnt;
         if (pf) {
           // d0. 8-bit lower bound first: dot(xi, qi) + acc0[x] >= Tq(bound) is NECESSARY for dist <= bound (the integer dot product is
           //     exact, the row constant and the quantisation residuals are on the safe side of the threshold), so only the rows that
           //     pass are worth their 4 d bytes.  Survivors are compacted per worker; everything downstream sees the smaller lists.
-          if (tid == 0) sh[9] = stage_threshold8(bound, qst, a.scal8, a.metric, a.u8, a.slack8, 0);
-          if (tid < T) s_pcnt[tid] = 0;
-          __syncthreads();
           const int Tq = sh[9];
-          u32* surv = reinterpret_cast<u32*>(npos);   // (insert positions are not live before step f)
+          u32* surv = reinterpret_cast<u32*>(sorted) + ecap;   // (the second half of `sorted`: written in step e only)
           const int g8 = lane / G8, t8 = lane & (G8 - 1);
           // G8 lanes per row, every lane NL8 16-byte pieces of it 16*G8 bytes apart (one instruction covers 16*G8 contiguous bytes
           // of each of its 64/G8 rows); U8 rows per lane group: U8*NL8 loads in flight per lane, 64/G8*U8 rows per wavefront and pass
@@ -530,14 +530,8 @@ __global__ __launch_bounds__(NW * 64, PF ? 4 : 1) void traverse2_kernel(Trv2Args
               int ci = c0 + u * RPW8 + g8;
               const bool ok = ci < nwork;
               if (!ok) ci = nwork - 1;
-              int w = 0, base = 0;
-              for (; w < T - 1; ++w) {
-                const int c = s_wcnt[w];
-                if (ci < base + c) break;
-                base += c;
-              }
-              const int sl = s_eoff[w] + (ci - base);
-              wslot[u] = ok ? ((w << 16) | sl) : -1;
+              const int sl = ci;
+              wslot[u] = ok ? sl : -1;
               const u32 id = work[sl];
               rp8[u] = a.x8 + (int64_t)id * a.d_pad8;
               a0[u] = t8 == 0 ? (a.nbr_acc0 ? wacc[sl] : a.acc0[id]) : 0;    // (gathered: in flight with the row pieces)
@@ -578,21 +572,20 @@ __global__ __launch_bounds__(NW * 64, PF ? 4 : 1) void traverse2_kernel(Trv2Args
 #pragma unroll
             for (int u = 0; u < U8; ++u)
               if (wslot[u] >= 0 && t8 == 0 && dot[u] + a0[u] >= Tq) {
-                const int sl = wslot[u] & 0xFFFF, w = wslot[u] >> 16;
+                const int sl = wslot[u], w = (int)wwk[sl];
                 const int pp = atomicAdd(&s_pcnt[w], 1);
                 surv[s_eoff[w] + pp] = work[sl];
               }
           }
           __syncthreads();
-          if (tid < T) s_wcnt[tid] = s_pcnt[tid];
-          __syncthreads();
           wk = surv;
+          cntp = s_pcnt;   // (what every later phase of the step counts a worker's keys by)
           nwork = 0;
-          for (int w = 0; w < T; ++w) nwork += s_wcnt[w];
+          for (int w = 0; w < T; ++w) nwork += cntp[w];
         }
         fetched += nwork;
         if (tid < T) {   // pad every segment's keys to a multiple of 8 with EMPTY (sorts last, never counted)
-          const int c = s_wcnt[tid];
+          const int c = cntp[tid];
           for (int p = c; p < ((c + 7) & ~7); ++p) newk[s_eoff[tid] + p] = KEY_EMPTY;
         }
         for (int c0 = wave * RPW * U; c0 < nwork; c0 += NW * RPW * U) {
@@ -607,7 +600,7 @@ __global__ __launch_bounds__(NW * 64, PF ? 4 : 1) void traverse2_kernel(Trv2Args
             if (!ok[u]) ci = nwork - 1;
             int w = 0, base = 0;   // item ci -> (worker, index in its segment)
             for (; w < T - 1; ++w) {
-              const int c = s_wcnt[w];
+              const int c = cntp[w];
               if (ci < base + c) break;
               base += c;
             }
@@ -641,7 +634,7 @@ __global__ __launch_bounds__(NW * 64, PF ? 4 : 1) void traverse2_kernel(Trv2Args
           if (e < etot) {
             while (w < T - 1 && e >= s_eoff[w + 1]) ++w;
             const int j = e - s_eoff[w];
-            const int cnt = s_wcnt[w];
+            const int cnt = cntp[w];
             if (j < cnt) {
               const u64* seg = newk + s_eoff[w];
               const u64 mine = seg[j];
@@ -689,9 +682,12 @@ __global__ __launch_bounds__(NW * 64, PF ? 4 : 1) void traverse2_kernel(Trv2Args
           const bool moves = nnew > 0 && pmin < cap && size > 0;
           const int top = moves ? ((size - 1) / CW) * CW : 0;
           const int nchunks = moves ? (top / CW - pmin / CW + 1) : 0;
-          if (tg == 0 && nchunks > 0) atomicMax(&sh[0], nchunks);
-          __syncthreads();
-          const int maxchunks = sh[0];
+          int maxchunks = 1;
+          if (L > CW || Lq > CW) {   // (queues longer than one chunk per worker: the workers agree on the trip count; else one predicated trip)
+            if (tg == 0 && nchunks > 0) atomicMax(&sh[0], nchunks);
+            __syncthreads();
+            maxchunks = sh[0];
+          }
           // old entries at positions >= pmin move right by the number of new keys ordered before them; chunks from the tail so
           // that nothing unread is overwritten
           for (int it = 0; it < maxchunks; ++it) {
@@ -722,6 +718,10 @@ __global__ __launch_bounds__(NW * 64, PF ? 4 : 1) void traverse2_kernel(Trv2Args
             const int r = (nnew > 0 && pmin < cap) ? pmin : cap;
             const int kuc = s_selpos[w];
             s_kuc[w] = r <= kuc ? r : kuc + 1;   // (:661-665)
+          }
+          if (tid == 0) {   // (for the next step's select, see there)
+            sh[3] = 0;
+            sh[10] = 0;
           }
           __syncthreads();
         }
