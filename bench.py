@@ -866,7 +866,7 @@ def main():
     if args.e2e:
         # Through the C ABI's own host path: eps_index_search with HOST query and result pointers - the library copies the batch up, searches, copies
         # the ids / distances down, inside the call (csrc/index.cpp) - exactly what the drop-in's VecSearchExecutor hands it.  Staging by the caller
-        # on a second stream was measured and dropped (scripts/lab/e2e_dbg.py; the three-slot form of profiles/r5_bench_graph_10Mx768_manifold_T4_L100.json):
+        # on a second stream was measured and dropped (scripts/lab/e2e_dbg.py; a two- and a three-slot form of this loop at 10M x 768):
         # a copy that runs CONCURRENTLY with the traversal's one long launch - 1024 workgroups that fill every CU exactly once - takes a workgroup
         # slot from it and the launch runs a second round (0.71-0.82 of the device-resident rate; 0.93-0.97 through the library's path), and for the
         # flat scan's chain of short launches both forms measure the same (0.97).
