@@ -469,3 +469,26 @@ def test_filter_in_traversal_returns_limit_rows_where_the_reference_starves(amd,
           % (L, rcnt.mean(), rec_ref, k, rec_flt))
     assert rec_flt >= rec_ref and rec_flt >= 0.3
     ix.close()
+
+
+def test_visited_stamps_survive_the_wrap_of_their_counter(amd, monkeypatch):
+    """r5: the visited set as generation stamps (u32 per node and slot; a query's stamp = a per-graph counter that only grows).  When the counter would pass
+    2^32 the table is zeroed and the count starts over: searches on both sides of that point return what the bitmap form returns."""
+    z, off, nbr, nav = _golden_graph()
+    X, Q = data(2000, 32, 42), data(700, 32, 48)
+    monkeypatch.setenv("EPS_TRV_VISITED", "bitmap")
+    ix = amd.GpuIndex(32, 0)
+    ix.attach_rows(X)
+    ix.set_graph(off, nbr, nav)
+    want = [ix.search(Q[:n_], 10, mode=amd.MODE_GRAPH, intra_threads=T) for n_, T in ((700, 1), (700, 4), (33, 4), (700, 1))]
+    ix.close()
+    monkeypatch.setenv("EPS_TRV_VISITED", "stamps")
+    monkeypatch.setenv("EPS_TRV_STAMP_START", str(0xFFFFFFF0 - 5))    # 700 queries on <= 700 slots: a handful of stamps per launch - the third launch wraps
+    ix = amd.GpuIndex(32, 0)
+    ix.attach_rows(X)
+    ix.set_graph(off, nbr, nav)
+    for (n_, T), w in zip(((700, 1), (700, 4), (33, 4), (700, 1)), want):
+        for rep in range(3):
+            got = ix.search(Q[:n_], 10, mode=amd.MODE_GRAPH, intra_threads=T)
+            assert np.array_equal(got[0], w[0]) and np.array_equal(got[1], w[1]) and np.array_equal(got[2], w[2]), (n_, T, rep)
+    ix.close()

@@ -364,6 +364,7 @@ int32_t graph_search_impl(Index& ix, const float* dq, int64_t nq, int k, const e
         g.gens_slots = slots;
         g.gens_n = n;
         g.gen_last = 0;
+        if (const char* st0 = tune_env("EPS_TRV_STAMP_START")) g.gen_last = (uint32_t)strtoul(st0, nullptr, 0);   // (tests: the 32-bit counter's wrap-around)
       } else {
         (void)hipGetLastError();
         g.gens_slots = g.gens_n = 0;
