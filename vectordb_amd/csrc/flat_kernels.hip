@@ -259,6 +259,8 @@ __global__ __launch_bounds__(NW * 64) void rerank_kernel(RerankArgs a) {
                        a.cap, &s8_kept, &s8_lost);
     __syncthreads();
     if (threadIdx.x == 0 && s8_lost) atomicAdd(a.overflow, 1u);   // a wavefront's list lost entries: the caller repeats the batch on the staged chain
+    if (a.s8_reset && threadIdx.x < S8_SLOTS)   // (the table has been read - threshold and selection above; the next call finds it empty)
+      const_cast<int*>(a.s8_G)[(q * S8_SLOTS + threadIdx.x) * S8_SLOT_STRIDE] = S8_EMPTY;
   }
   const u32 cnt_raw = a.s8_G ? s8_kept : a.cand_count[q];
   u32 cnt = cnt_raw;
@@ -331,6 +333,22 @@ __global__ __launch_bounds__(NW * 64) void rerank_kernel(RerankArgs a) {
             static_cast<int*>(a.T_next)[q] = kth == KEY_EMPTY ? -(1 << 30) : stage_threshold8(key_dist(kth), qs, a.scal, a.metric, a.u, a.slack, 0);
           } else {
             static_cast<float*>(a.T_next)[q] = kth == KEY_EMPTY ? 3.0e38f : stage_threshold16(key_dist(kth), qs, a.scal, a.metric, a.slack, 0);
+          }
+        }
+        if (a.pub) {   // (lane 0 of wavefront 0 issued every one of this block's counter updates above)
+          __threadfence();
+          if (atomicAdd(a.pub_ticket, 1u) == gridDim.x - 1) {
+            const u32 ov = atomicAdd(a.overflow, 0u);
+            const unsigned long long tot = atomicAdd(a.total, 0ull);
+            a.pub[0] = ov;
+            a.pub[2] = (u32)tot;
+            a.pub[3] = (u32)(tot >> 32);
+            __threadfence_system();
+            if (a.s8_reset) {   // (every block has finished with the counters: each took its ticket after its last update)
+              *a.overflow = 0u;
+              *a.total = 0ull;
+              *a.pub_ticket = 0u;
+            }
           }
         }
       }

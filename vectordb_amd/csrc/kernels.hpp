@@ -82,6 +82,11 @@ struct RerankArgs {
   const u64* s8_lists = nullptr;    // [nq][s8_waves][S8_WAVE_CAP]
   int s8_waves = 0;
   u32* s8_cand = nullptr;           // = cand
+  // one-pass form: the block that finishes last (ticket) copies overflow / total to host-mapped words [0] = overflow, [2..3] = total, so the
+  // caller needs no device-to-host copy after the launch (a copy is a trip through the DMA queue at the end of a 0.2 ms call)
+  u32* pub = nullptr;               // host-mapped [4], or null
+  u32* pub_ticket = nullptr;        // device word, zero at launch
+  int s8_reset = 0;                 // 1: the launch leaves the one-pass state as the next call needs it (table slots empty, counters zero): no prep launch then
 };
 void launch_rerank(const RerankArgs& a, hipStream_t s);
 

@@ -107,6 +107,21 @@ struct HalfMirror {
   // about it, so two such overflows in a row make the next 32 filtered calls go straight to the staged chain, then the one-pass form is tried again
   int s8_filt_overflows = 0, s8_filt_skip = 0;
   int s8_cus = 0;               // CUs of the device (grid of the one-pass kernel)
+  // r5: the call's two result counters land in host-mapped memory (written by the last block of the re-rank launch), read after the stream
+  // sync: no device-to-host copy at the end of a 0.2 ms call
+  struct HostWords {
+    u32* p = nullptr;
+    ~HostWords() { if (p) (void)hipHostFree(p); }
+    bool get() {
+      if (!p && hipHostMalloc(reinterpret_cast<void**>(&p), 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
+      return p != nullptr;
+    }
+  } s8_pub;
+  // r5: the re-rank launch of a one-pass call leaves the table slots empty and the counters zero (RerankArgs::s8_reset), and the pass quantises its
+  // queries itself - the next call is TWO launches, no prep launch.  s8_clean_* = the buffers that state lives in; anything else that writes
+  // them (the staged chain's counters, a reallocation, a failed call) clears it and the next call starts with the prep launch again
+  const void* s8_clean_cnt = nullptr;
+  const void* s8_clean_g = nullptr;
   int64_t extended_rows8 = 0;
   int64_t version = -1;
   int64_t n = 0, n_pad = 0;
@@ -510,10 +525,10 @@ __global__ __launch_bounds__(256) void query_prep8_kernel(const float* q, int64_
                                                           int metric, signed char* q8, float* qstat, Prep8Extra x) {
   if (blockIdx.x == 0) {   // the seeded call's start state (nothing in this launch reads it)
     for (int64_t i = threadIdx.x; x.T2 && i < x.n2; i += 256) x.T2[i] = x.Tv;
-    for (int64_t i = threadIdx.x; x.cnt && i < nq + 8; i += 256) x.cnt[i] = i < nq ? x.cntv : 0u;
+    for (int64_t i = threadIdx.x; x.cnt && i < (x.s8g ? 12 : nq + 8); i += 256) x.cnt[i] = i < nq ? x.cntv : 0u;
     if (x.gsync) x.gsync[threadIdx.x] = 0;
-    if (x.s8g) {   // (only the words in use: the slots of the call's queries, the sub-list counters)
-      for (int i = threadIdx.x; i < (int)nq * S8_SLOTS; i += 256) x.s8g[i * S8_SLOT_STRIDE] = S8_EMPTY;
+    if (x.s8g) {   // (the slots of all four queries and 12 counter words, whatever nq: the state the re-rank of a one-pass call restores - s8_reset)
+      for (int i = threadIdx.x; i < 4 * S8_SLOTS; i += 256) x.s8g[i * S8_SLOT_STRIDE] = S8_EMPTY;
     }
   }
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -985,18 +1000,26 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
   if (!m.qstat.reserve((size_t)4 * 16) || !m.q8.reserve((size_t)4 * m.d_pad8) || !m.cand.reserve((size_t)nq * cap * 8) || !m.cnt.reserve((size_t)(nq + 4) * 4 + 16) ||
       !m.s8g.reserve((size_t)S8_TABLE_WORDS * 4 + (size_t)4 * S8_MAX_WAVES * 4) || !m.s8raw.reserve((size_t)nq * S8_MAX_WAVES * S8_WAVE_CAP * 8))
     return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory (scratch)");
+  // (cnt: nq + 8 <= 12 words in use here; DevBuf::reserve never hands out less than 256 bytes)
   u32* cnt = m.cnt.as<u32>();
   u32* overflow = cnt + nq;
   unsigned long long* total = reinterpret_cast<unsigned long long*>(cnt + nq + 2);
   if ((reinterpret_cast<uintptr_t>(total) & 7) != 0) total = reinterpret_cast<unsigned long long*>(cnt + nq + 3);
   const float u8 = (ix.metric_ == 0 ? 2.f : 1.f) * m.step8 * m.step8;
   const float rerank_slack = std::max(8e-6f, 2.f * (3.f * ((float)((ix.dim_ + 63) / 64 * 64) / 64.f + 6.f) + 6.f) * 5.9604645e-8f);
-  Prep8Extra px;
-  px.cnt = cnt;     // candidate counts, overflow and total counters = 0
-  px.cntv = 0;
-  px.s8g = m.s8g.as<int>();
-  hipLaunchKernelGGL(query_prep8_kernel, dim3(1), dim3(256), 0, s, dq, nq, (int64_t)4, (int)ix.dim_, m.d_pad8, m.mu8.as<float>(), m.step8, 1.f / m.step8, ix.metric_,
-                     m.q8.as<signed char>(), m.qstat.as<float>(), px);
+  const bool host_words = !(tune_env("EPS_S8_HOST_WORDS") && atoi(tune_env("EPS_S8_HOST_WORDS")) == 0) && m.s8_pub.get();   // (A/B switch)
+  const bool two_launches = host_words && !(tune_env("EPS_S8_TWO_LAUNCHES") && atoi(tune_env("EPS_S8_TWO_LAUNCHES")) == 0) && !tune_env("EPS_DEBUG");  // (A/B switch; the debug log reads the table after the call)
+  // (3-4 queries keep the prep launch: next to four queries' slices and two chunks in flight the in-kernel form does not fit 256 registers)
+  const bool clean = two_launches && nq <= 2 && m.s8_clean_cnt == m.cnt.p && m.s8_clean_g == m.s8g.p;
+  m.s8_clean_cnt = m.s8_clean_g = nullptr;   // (set again when this call has come back)
+  if (!clean) {
+    Prep8Extra px;
+    px.cnt = cnt;     // candidate counts, overflow and total counters = 0
+    px.cntv = 0;
+    px.s8g = m.s8g.as<int>();
+    hipLaunchKernelGGL(query_prep8_kernel, dim3(1), dim3(256), 0, s, dq, nq, (int64_t)4, (int)ix.dim_, m.d_pad8, m.mu8.as<float>(), m.step8, 1.f / m.step8, ix.metric_,
+                       m.q8.as<signed char>(), m.qstat.as<float>(), px);
+  }
   Stream8Args a;
   a.x8 = m.x8.as<signed char>();
   a.acc0 = m.acc0.as<int>();
@@ -1014,6 +1037,12 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
   a.raw_cnt = m.s8g.as<u32>() + S8_TABLE_WORDS;
   a.raw = m.s8raw.as<u64>();
   a.f = fs;
+  a.qf32 = dq;
+  a.mu = m.mu8.as<float>();
+  a.qstat_out = m.qstat.as<float>();
+  a.dim = (int)ix.dim_;
+  a.step = m.step8;
+  a.inv_step = 1.f / m.step8;
 #ifdef EPS_LAB   // (kernel ablations make answers wrong on purpose: lab builds only)
   a.ablate = tune_env("EPS_S8_ABLATE") ? atoi(tune_env("EPS_S8_ABLATE")) : 0;
 #else
@@ -1031,16 +1060,22 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
   // the call.  EPS_ONE_PASS_TIMED=1 - bench.py's roofline leg - records the pair: main_kernel_ms = the pass)
   const bool timed = tune_env("EPS_ONE_PASS_TIMED") && atoi(tune_env("EPS_ONE_PASS_TIMED")) != 0;
   if (timed) (void)hipEventRecord(ix.evk0_, s);
-#define EPS_S8_LAUNCH(P_)                                                                      \
-  do {                                                                                         \
-    if (nq == 1) hipLaunchKernelGGL((stream8_kernel<P_, 1>), grid, block, 0, s, a);            \
-    else if (nq == 2) hipLaunchKernelGGL((stream8_kernel<P_, 2>), grid, block, 0, s, a);       \
-    else hipLaunchKernelGGL((stream8_kernel<P_, 4>), grid, block, 0, s, a);                    \
+#define EPS_S8_LAUNCH_(P_, PREP_)                                                                    \
+  do {                                                                                               \
+    if (nq == 1) hipLaunchKernelGGL((stream8_kernel<P_, 1, PREP_>), grid, block, 0, s, a);           \
+    else if (nq == 2) hipLaunchKernelGGL((stream8_kernel<P_, 2, PREP_>), grid, block, 0, s, a);      \
+    else hipLaunchKernelGGL((stream8_kernel<P_, 4, false>), grid, block, 0, s, a);                   \
+  } while (0)
+#define EPS_S8_LAUNCH(P_)                    \
+  do {                                       \
+    if (clean) EPS_S8_LAUNCH_(P_, true);     \
+    else EPS_S8_LAUNCH_(P_, false);          \
   } while (0)
   if (pieces == 2) EPS_S8_LAUNCH(2);
   else if (pieces == 3) EPS_S8_LAUNCH(3);
   else EPS_S8_LAUNCH(4);
 #undef EPS_S8_LAUNCH
+#undef EPS_S8_LAUNCH_
   if (timed) (void)hipEventRecord(ix.evk1_, s);
   RerankArgs ra;
   ra.rows = ix.d_rows_;
@@ -1069,6 +1104,11 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
   ra.s8_lists = a.raw;
   ra.s8_waves = a.waves;
   ra.s8_cand = m.cand.as<u32>();
+  if (host_words) {
+    ra.pub = m.s8_pub.p;
+    ra.pub_ticket = cnt + nq + 6;   // (zeroed by the prep launch with the other counters: cnt[nq .. nq + 8))
+    ra.s8_reset = two_launches ? 1 : 0;
+  }
   const bool fin_here = ix.pre_sync_ && nq == ix.pre_sync_nq_ && ix.fin_ids_ != nullptr;
   if (fin_here) {
     ra.fin_ids = ix.fin_ids_;
@@ -1089,11 +1129,23 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
   // (both counters in ONE small copy: every copy is a trip through the DMA queue at the end of a 0.2 ms call)
   u32 hraw[6] = {0, 0, 0, 0, 0, 0};
   const size_t span = (size_t)(reinterpret_cast<const char*>(total) + 8 - reinterpret_cast<const char*>(overflow));
-  er = hipMemcpyAsync(hraw, overflow, span, hipMemcpyDeviceToHost, s);
-  if (er == hipSuccess) er = hipStreamSynchronize(s);
-  if (er != hipSuccess) return ix.hip_fail(er, "one-pass flat search");
-  h.overflow = hraw[0];
-  memcpy(&h.total, reinterpret_cast<const char*>(hraw) + (span - 8), 8);
+  if (host_words) {
+    er = hipStreamSynchronize(s);
+    if (er != hipSuccess) return ix.hip_fail(er, "one-pass flat search");
+    const volatile u32* hp = m.s8_pub.p;
+    h.overflow = hp[0];
+    h.total = (unsigned long long)hp[2] | ((unsigned long long)hp[3] << 32);
+    if (two_launches) {   // (the launch left slots and counters as the next call needs them)
+      m.s8_clean_cnt = m.cnt.p;
+      m.s8_clean_g = m.s8g.p;
+    }
+  } else {
+    er = hipMemcpyAsync(hraw, overflow, span, hipMemcpyDeviceToHost, s);
+    if (er == hipSuccess) er = hipStreamSynchronize(s);
+    if (er != hipSuccess) return ix.hip_fail(er, "one-pass flat search");
+    h.overflow = hraw[0];
+    memcpy(&h.total, reinterpret_cast<const char*>(hraw) + (span - 8), 8);
+  }
   if (tune_env("EPS_DEBUG") || (h.overflow && tune_env("EPS_DEBUG_ONE_PASS_OVERFLOW"))) {
     std::vector<u32> hc((size_t)S8_TABLE_WORDS + (size_t)4 * S8_MAX_WAVES);
     (void)hipMemcpy(hc.data(), m.s8g.p, hc.size() * 4, hipMemcpyDeviceToHost);
@@ -1273,6 +1325,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   ix.stats_.main_kernel_launches = 0;
 
   u32* cnt = m.cnt.as<u32>();
+  m.s8_clean_cnt = nullptr;   // (the chain's counters live where the one-pass form keeps its own)
   u32* seed_cand_buf = m.seedc.as<u32>();
   u32* seed_cnt_buf = cnt;   // (merge_lists reads a query's seed count before it writes the candidate count there; the re-rank zeroes it)
   u32* overflow = cnt + nq;                                                    // [1]

@@ -56,6 +56,13 @@ struct Stream8Args {
   u32* raw_cnt;            // [nq][waves]: entries every wavefront of the grid found (written once, when it ends)
   u64* raw;                // [nq][waves][S8_WAVE_CAP]: (acc << 32) | row - a private list per wavefront: no atomic, nothing to wait for
   int waves;               // wavefronts of the grid (<= S8_MAX_WAVES)
+  // r5, PREP instantiations: the launch quantises its queries itself (one wavefront per query, every workgroup for itself: 3 KB from L2) -
+  // no query-prep launch in front of the pass.  Workgroup 0 leaves the queries' constants in qstat_out for the re-rank launch.
+  const float* qf32 = nullptr;   // [nq][dim] the queries as given
+  const float* mu = nullptr;     // [d_pad8] the grid's centre
+  float* qstat_out = nullptr;    // = qstat, writable
+  int dim = 0;
+  float step = 1.f, inv_step = 1.f;
   int ablate;              // lab (EPS_S8_ABLATE; results are wrong): 1 = no table, no test - the bare stream + dot products; 2 = no periodic
                            // re-read of the table; 4 = no start-up (offer, barriers, first read), tests against "nothing passes"; 8 = the
                            // start-up as it is, then tests against "nothing passes"
@@ -95,8 +102,50 @@ __device__ __forceinline__ int stream8_threshold_of(const int* G, int k, const f
   if (kth == S8_EMPTY) return -(1 << 30);   // fewer than k slots filled so far: everything passes
   return stage_threshold8(stream8_ub(kth, qs, sc, metric, u, slack), qs, sc, metric, u, slack, 0);
 }
-__device__ __forceinline__ int stream8_threshold(const Stream8Args& a, int q, int lane, int& gkth) {
-  return stream8_threshold_of(a.G + q * S8_SLOTS * S8_SLOT_STRIDE, a.k, a.qstat + q * 4, a.scal, a.metric, a.u, a.slack, lane, gkth);
+
+// one query, one wavefront: the arithmetic of query_prep8_kernel (mfma_filter.hip) term by term, the bytes to `dst`, the four constants to `qs`
+__device__ __forceinline__ void stream8_prep_query(const float* src, int dim, int d_pad8, const float* mu, float step, float inv_step, int metric, int lane,
+                                                   signed char* dst, float* qs, float* qs2) {
+  float s2 = 0.f, e2 = 0.f, c2 = 0.f, qm = 0.f;
+  for (int c = lane * 4; c < d_pad8; c += 256) {
+    u32 packed = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (c + e < dim) {
+        const float xv = src[c + e];
+        const float m = mu[c + e];
+        const float dx = xv - m;
+        const int qi = quant8(dx, 0.f, inv_step);
+        const float res = fmaf(-step, (float)qi, dx);
+        packed |= (u32)(qi & 255) << (8 * e);
+        s2 = fmaf(xv, xv, s2);
+        c2 = fmaf(dx, dx, c2);
+        e2 = fmaf(res, res, e2);
+        qm = fmaf(xv, m, qm);
+      }
+    }
+    *reinterpret_cast<u32*>(dst + c) = packed;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    s2 += __shfl_xor(s2, o);
+    e2 += __shfl_xor(e2, o);
+    c2 += __shfl_xor(c2, o);
+    qm += __shfl_xor(qm, o);
+  }
+  if (lane == 0) {
+    const float nqc = sqrtf(c2) * 1.000001f, eqc = sqrtf(e2) * 1.00001f + 1.2e-7f * sqrtf(c2);
+    const float v3 = metric == 0 ? c2 : (metric == 1 ? 1.f - qm : -qm);
+    qs[0] = s2;
+    qs[1] = nqc;
+    qs[2] = eqc;
+    qs[3] = v3;
+    if (qs2) {
+      qs2[0] = s2;
+      qs2[1] = nqc;
+      qs2[2] = eqc;
+      qs2[3] = v3;
+    }
+  }
 }
 
 __device__ __forceinline__ void stream8_offer(const Stream8Args& a, int q, int acc, u32 row) {   // (one lane; rare)
@@ -114,11 +163,13 @@ __device__ __forceinline__ void stream8_offer(const Stream8Args& a, int q, int a
 // The table is READ by one wavefront per workgroup, every fourth iteration, and handed to the other three through LDS: read by every
 // wavefront in every iteration (4096 cache-bypassing loads of one 64-byte line per round) the loads queued up at that line's memory
 // channel for ~20 us per iteration - the first version of this kernel ran at 2.1 TB/s because of it.
-template <int PIECES, int NQ>
-__global__ __launch_bounds__(256) void stream8_kernel(Stream8Args a) {
+template <int PIECES, int NQ, bool PREP>
+__global__ __launch_bounds__(256, 2) void stream8_kernel(Stream8Args a) {
   constexpr int U = PIECES <= 3 ? 4 : 2;
   constexpr int CH = 4 * U;   // rows per wavefront and iteration
   __shared__ int T_s[4], gkth_s[4];
+  __shared__ __attribute__((aligned(16))) signed char q8_s[PREP ? NQ * PIECES * 256 : 16];
+  __shared__ float qstat_s[16];
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
   const int g = lane >> 4, t = lane & 15;
@@ -126,11 +177,30 @@ __global__ __launch_bounds__(256) void stream8_kernel(Stream8Args a) {
   const int64_t W = (int64_t)gridDim.x * 4;
 
   int4 qv[NQ][PIECES];
+  if (!PREP) {
 #pragma unroll
-  for (int q = 0; q < NQ; ++q)
+    for (int q = 0; q < NQ; ++q)
 #pragma unroll
-    for (int p = 0; p < PIECES; ++p)
-      qv[q][p] = q < a.nq ? *reinterpret_cast<const int4*>(a.q8 + (int64_t)q * a.d_pad8 + p * 256 + t * 16) : make_int4(0, 0, 0, 0);
+      for (int p = 0; p < PIECES; ++p)
+        qv[q][p] = q < a.nq ? *reinterpret_cast<const int4*>(a.q8 + (int64_t)q * a.d_pad8 + p * 256 + t * 16) : make_int4(0, 0, 0, 0);
+  }
+
+  // (PREP) the queries' bytes and constants, computed by the workgroup for itself; where registers allow (<= 2 queries) AFTER the first loads
+  // have been issued, so that the quantisation runs under their latency
+  static_assert(!PREP || NQ <= 2, "3-4 queries: the prep launch (registers)");
+  constexpr bool PREP_LATE = true;
+  auto prep = [&]() __attribute__((always_inline)) {
+    if (wave < NQ && wave < a.nq)
+      stream8_prep_query(a.qf32 + (int64_t)wave * a.dim, a.dim, PIECES * 256, a.mu, a.step, a.inv_step, a.metric, lane, q8_s + wave * (PIECES * 256), qstat_s + wave * 4,
+                         blockIdx.x == 0 ? a.qstat_out + wave * 4 : nullptr);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int p = 0; p < PIECES; ++p)
+        qv[q][p] = q < a.nq ? *reinterpret_cast<const int4*>(q8_s + q * (PIECES * 256) + p * 256 + t * 16) : make_int4(0, 0, 0, 0);
+  };
+  if (PREP && !PREP_LATE) prep();
 
   auto dots = [&](const int4 (&xv)[PIECES], int a0v, int (&out)[NQ]) __attribute__((always_inline)) {
 #pragma unroll
@@ -151,7 +221,10 @@ __global__ __launch_bounds__(256) void stream8_kernel(Stream8Args a) {
     for (int q = 0; q < NQ; ++q) {
       if (q < a.nq) {
         int gm;
-        const int Tq = stream8_threshold(a, q, lane, gm);
+        float qs[4];   // (by value: a pointer that may be LDS or global is a flat pointer)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) qs[i] = PREP ? qstat_s[q * 4 + i] : a.qstat[q * 4 + i];
+        const int Tq = stream8_threshold_of(a.G + q * S8_SLOTS * S8_SLOT_STRIDE, a.k, qs, a.scal, a.metric, a.u, a.slack, lane, gm);
         if (lane == 0) {
           T_s[q] = Tq;
           gkth_s[q] = gm;
@@ -226,6 +299,7 @@ __global__ __launch_bounds__(256) void stream8_kernel(Stream8Args a) {
   int acc[U][NQ];
   if (first < a.n) load_chunk(first, xa, a0a);
   if (first + stride < a.n) load_chunk(first + stride, xb, a0b);
+  if (PREP && PREP_LATE) prep();
   // ---- the first chunk feeds the empty table before anything is tested: ONE row per wavefront (the chunks are spread over the whole
   // mirror) is offered, the workgroup's first thresholds are read from what has arrived, and only then the chunk is tested - so the table
   // holds the best of a few thousand rows before the first candidate is appended
