@@ -14,6 +14,7 @@
 #include <new>
 #include <string>
 #include <unordered_map>
+#include <unordered_set>
 
 namespace eps {
 
@@ -22,7 +23,7 @@ namespace eps {
 namespace {
 std::mutex g_tune_mu;
 std::unordered_map<std::string, const char*> g_tune;
-std::deque<std::string> g_tune_values;
+std::unordered_set<std::string> g_tune_values;   // (interned: a value set a million times is stored once; element addresses are stable)
 }  // namespace
 const char* tune_env(const char* name) {
   {
@@ -45,8 +46,7 @@ static void tune_set(const char* name, const char* value) {
   } else if (!value) {
     g_tune.erase(name);
   } else {
-    g_tune_values.emplace_back(value);
-    g_tune[name] = g_tune_values.back().c_str();
+    g_tune[name] = g_tune_values.emplace(value).first->c_str();
   }
 }
 
