@@ -172,7 +172,15 @@ class Index : public IndexBase {
   HalfMirror* mirror_ = nullptr;
 
   // scratch
-  DevBuf q_buf_, partial_buf_, run_buf_, ids_buf_, dist_buf_, cnt_buf_, tmp_buf_, page_buf_;
+  DevBuf q_buf_, partial_buf_, run_buf_, out_buf_, tmp_buf_, page_buf_;   // out_buf_: [ids | distances | counts] of a call with host result pointers
+  // r5: that block goes to the host in ONE copy into page-locked memory and is split there (three pageable device-to-host copies staged separately
+  // cost a batch of 1024 ~0.1 ms and a single-vector call three trips through the DMA queue)
+  struct HostBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    ~HostBuf();
+    bool reserve(size_t bytes);
+  } h_out_, h_q_;   // (h_q_: host queries are copied to page-locked memory first, then DMA'd: the runtime's own path for pageable sources is slower)
   hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
   // main-kernel event pairs of the last KRING search calls (read back after a run without a sync inside it);
   // evk0_/evk1_ alias the pair of the call in progress
