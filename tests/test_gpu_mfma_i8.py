@@ -158,6 +158,39 @@ def test_one_to_four_queries_are_one_pass_over_the_mirror(amd, oracle, monkeypat
     ix.close()
 
 
+@pytest.mark.parametrize("switches", [{}, {"EPS_S8_TWO_LAUNCHES": "0"}, {"EPS_S8_HOST_WORDS": "0"}, {"EPS_HOST_STAGING": "0"}])
+def test_one_pass_call_forms_return_the_same_bits(amd, monkeypatch, switches):
+    """r5: a one-pass call is two launches (the pass quantises its queries itself, the re-rank leaves table and counters clean for the next call) and
+    its two result counters reach the host through host-mapped words; host-pointer calls get their results in one page-locked copy.  Every form
+    against the stream engine, over calls that alternate query counts (1, 2 take the two-launch form, 3, 4 the prep launch), k, a staged-chain call
+    in between (it uses the same counter block) and host / device pointers."""
+    import torch
+    for k_, v in switches.items():
+        monkeypatch.setenv(k_, v)
+    n, d = 120_011, 768
+    X, Q = data(n, d, 901), data(8, d, 902)
+    Q[2] = X[777]
+    ix = amd.GpuIndex(d, 0)
+    ix.attach_rows(X)
+    want = {}
+    for nq in (1, 2, 3, 4, 8):
+        for k in (1, 10):
+            want[nq, k] = ix.search(Q[:nq], k, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
+    Qd = torch.from_numpy(Q).cuda()
+    order = [(1, 10), (1, 10), (2, 1), (4, 10), (1, 1), (8, 10), (1, 10), (3, 10), (2, 10), (1, 10)]
+    for rep in range(3):
+        for nq, k in order:
+            a = ix.search(Q[:nq], k, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
+            st = ix.stats()
+            assert st["one_pass"] == (1 if nq <= 4 else 0) and st["overflow_queries"] == 0, (switches, nq, k, st)
+            same(a, want[nq, k], "%s host nq %d k %d" % (switches, nq, k))
+            o = (torch.empty((nq, k), dtype=torch.int64, device="cuda"), torch.empty((nq, k), device="cuda"), torch.empty((nq,), dtype=torch.int32, device="cuda"))
+            ix.search(Qd[:nq], k, out=o, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
+            torch.cuda.synchronize()
+            same((o[0].cpu().numpy(), o[1].cpu().numpy(), o[2].cpu().numpy()), want[nq, k], "%s device nq %d k %d" % (switches, nq, k))
+    ix.close()
+
+
 def test_auto_builds_the_mirror_for_single_query_traffic_after_a_few_calls(amd):
     """FLAT_AUTO on a table without a mirror: single queries run the fp32 stream scan (no HBM spent on a mirror for a caller that may ask
     once), and from the 17th call on the same rows the 8-bit mirror is built and the one-pass search answers - same bits either way;
