@@ -102,14 +102,14 @@ def test_i8_engine_on_other_distributions(amd, kind):
 
 @pytest.mark.parametrize("metric", [0, 1, 2])
 @pytest.mark.parametrize("d", [192, 768, 1000])
-def test_one_to_four_queries_are_one_pass_over_the_mirror(amd, oracle, monkeypatch, metric, d):
-    """r4 (stream8_kernel.hpp): up to 4 queries with k <= 16 are answered by ONE streaming pass over the 8-bit mirror (shared table of the
+def test_one_to_sixteen_queries_are_one_pass_over_the_mirror(amd, oracle, monkeypatch, metric, d):
+    """r4 (stream8_kernel.hpp; r5: 5..16 queries by the same pass on the matrix cores, stream8m_kernel): up to 16 queries with k <= 16 are answered by ONE streaming pass over the 8-bit mirror (shared table of the
     best accumulators seen -> pass threshold from their UPPER bounds), one selection against the final table and one exact re-rank: the
     same bits as the stream scan - rows of 2 / 3 / 4 x 256 bytes, ties ordered by id, queries that ARE rows, with a deleted bitset,
     and an int-column filter, repeated calls (the table is reset per call) - and `one_pass` in the stats says which form ran.  Larger k,
     more queries, a filter program or EPS_FLAT_ONE_PASS=0 take the staged chain."""
     n = 200_003 if d < 700 else 90_000     # (a last chunk that is not full)
-    X, Q = data(n, d, 171 + d), data(4, d, 172 + d)
+    X, Q = data(n, d, 171 + d), data(16, d, 172 + d)
     X[5000:5040] = X[4999]
     if metric == 1:
         X = amd.normalize_rows(X, only_if_nonzero=True)
@@ -137,7 +137,7 @@ def test_one_to_four_queries_are_one_pass_over_the_mirror(amd, oracle, monkeypat
         if setup == "deleted + filter program":     # (filter programs take the staged chain: same bits)
             ix.set_int_filter(None, ">=", 0)
             ix.set_filter_program([("i32", 0), ("const", 1000), (">=",)], rows=idc.view(np.uint8).reshape(n, 4), stride=4)
-        for nq in (1, 2, 3, 4):
+        for nq in (1, 2, 3, 4, 5, 8, 13, 16, 1):     # (.. and back to one: whatever state a call leaves behind serves the next)
             for k in (1, 10, 16):
                 for rep in range(2):
                     a = ix.search(Q[:nq], k, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
@@ -182,7 +182,7 @@ def test_one_pass_call_forms_return_the_same_bits(amd, monkeypatch, switches):
         for nq, k in order:
             a = ix.search(Q[:nq], k, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
             st = ix.stats()
-            assert st["one_pass"] == (1 if nq <= 4 else 0) and st["overflow_queries"] == 0, (switches, nq, k, st)
+            assert st["one_pass"] == 1 and st["overflow_queries"] == 0, (switches, nq, k, st)
             same(a, want[nq, k], "%s host nq %d k %d" % (switches, nq, k))
             o = (torch.empty((nq, k), dtype=torch.int64, device="cuda"), torch.empty((nq, k), device="cuda"), torch.empty((nq,), dtype=torch.int32, device="cuda"))
             ix.search(Qd[:nq], k, out=o, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)

@@ -525,10 +525,12 @@ __global__ __launch_bounds__(256) void query_prep8_kernel(const float* q, int64_
                                                           int metric, signed char* q8, float* qstat, Prep8Extra x) {
   if (blockIdx.x == 0) {   // the seeded call's start state (nothing in this launch reads it)
     for (int64_t i = threadIdx.x; x.T2 && i < x.n2; i += 256) x.T2[i] = x.Tv;
-    for (int64_t i = threadIdx.x; x.cnt && i < (x.s8g ? 12 : nq + 8); i += 256) x.cnt[i] = i < nq ? x.cntv : 0u;
+    for (int64_t i = threadIdx.x; x.cnt && i < (x.s8g ? S8_MAX_Q + 8 : nq + 8); i += 256) x.cnt[i] = i < nq ? x.cntv : 0u;
     if (x.gsync) x.gsync[threadIdx.x] = 0;
-    if (x.s8g) {   // (the slots of all four queries and 12 counter words, whatever nq: the state the re-rank of a one-pass call restores - s8_reset)
-      for (int i = threadIdx.x; i < 4 * S8_SLOTS; i += 256) x.s8g[i * S8_SLOT_STRIDE] = S8_EMPTY;
+    if (x.s8g) {   // (the slots of the call's queries - at least of the first four: a later call of 1-2 queries that skips this launch relies on its own
+                   // slots being empty, and the re-rank of every call restores exactly the slots it used - and S8_MAX_Q + 8 counter words)
+      const int qinit = nq > 4 ? (int)nq : 4;
+      for (int i = threadIdx.x; i < qinit * S8_SLOTS; i += 256) x.s8g[i * S8_SLOT_STRIDE] = S8_EMPTY;
     }
   }
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -957,7 +959,7 @@ bool flat_mfma_profitable(const Index& ix, int64_t nq, int k) {
   const bool can16 = !have16 || m->fp16_range_ok;
   if (known8 && !have8 && !can16) return false;                 // neither mirror can serve this table
   // up to 4 queries, k <= 16, rows of <= 1024 bytes: the one-pass search (stream8_kernel.hpp) - one pass over d_pad8 + 4 bytes per row
-  const bool one_pass_shape = nq <= 4 && k <= 16 && ix.dim_ <= 1024 && !(tune_env("EPS_FLAT_ONE_PASS") && atoi(tune_env("EPS_FLAT_ONE_PASS")) == 0);
+  const bool one_pass_shape = nq <= S8_MAX_Q && k <= 16 && ix.dim_ <= 1024 && !(tune_env("EPS_FLAT_ONE_PASS") && atoi(tune_env("EPS_FLAT_ONE_PASS")) == 0);
   if (nq < 8 && !have8 && !have16) {
     // single-query traffic alone does not get a mirror (n x d bytes of HBM + a pass over the table to build it) at once: r4, after 16 such
     // calls on the same rows it does, where the one-pass search can use it (0.20 ms instead of 0.62 ms per call at 1M x 768)
@@ -987,7 +989,8 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
   const int64_t n = ix.scan_limit_ >= 0 ? std::min(ix.scan_limit_, ix.n_rows_) : ix.n_rows_;
   const int pieces = m.d_pad8 / 256;
   if (tune_env("EPS_FLAT_ONE_PASS") && atoi(tune_env("EPS_FLAT_ONE_PASS")) == 0) return EPS_OK;
-  if (nq < 1 || nq > 4 || k < 1 || k > 16 || m.fold8 || n < 65536 || n > m.n8 || m.d_pad8 % 256 != 0 || pieces < 2 || pieces > 4) return EPS_OK;
+  const int max_q = tune_env("EPS_S8_MAX_Q") ? std::min(S8_MAX_Q, std::max(1, atoi(tune_env("EPS_S8_MAX_Q")))) : S8_MAX_Q;   // (A/B switch: 4 = the r4 form, 5+ queries on the staged chain)
+  if (nq < 1 || nq > max_q || k < 1 || k > 16 || m.fold8 || n < 65536 || n > m.n8 || m.d_pad8 % 256 != 0 || pieces < 2 || pieces > 4) return EPS_OK;
   if (m.s8_declined_version == ix.rows_version_) return EPS_OK;
   const FilterSpec fs = ix.filter_spec();
   if (fs.prog) return EPS_OK;   // (filter programs: the staged chain; a deleted bitset and an int-column filter are handled in the pass)
@@ -997,8 +1000,8 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
   }
   hipStream_t s = ix.stream_;
   const int cap = std::max(4096, 64 * k);
-  if (!m.qstat.reserve((size_t)4 * 16) || !m.q8.reserve((size_t)4 * m.d_pad8) || !m.cand.reserve((size_t)nq * cap * 8) || !m.cnt.reserve((size_t)(nq + 4) * 4 + 16) ||
-      !m.s8g.reserve((size_t)S8_TABLE_WORDS * 4 + (size_t)4 * S8_MAX_WAVES * 4) || !m.s8raw.reserve((size_t)nq * S8_MAX_WAVES * S8_WAVE_CAP * 8))
+  if (!m.qstat.reserve((size_t)S8_MAX_Q * 16) || !m.q8.reserve((size_t)S8_MAX_Q * m.d_pad8) || !m.cand.reserve((size_t)nq * cap * 8) || !m.cnt.reserve((size_t)(nq + 4) * 4 + 16) ||
+      !m.s8g.reserve((size_t)S8_TABLE_WORDS * 4 + (size_t)S8_MAX_Q * S8_MAX_WAVES * 4) || !m.s8raw.reserve((size_t)nq * S8_MAX_WAVES * S8_WAVE_CAP * 8))
     return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory (scratch)");
   // (cnt: nq + 8 <= 12 words in use here; DevBuf::reserve never hands out less than 256 bytes)
   u32* cnt = m.cnt.as<u32>();
@@ -1017,7 +1020,7 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
     px.cnt = cnt;     // candidate counts, overflow and total counters = 0
     px.cntv = 0;
     px.s8g = m.s8g.as<int>();
-    hipLaunchKernelGGL(query_prep8_kernel, dim3(1), dim3(256), 0, s, dq, nq, (int64_t)4, (int)ix.dim_, m.d_pad8, m.mu8.as<float>(), m.step8, 1.f / m.step8, ix.metric_,
+    hipLaunchKernelGGL(query_prep8_kernel, dim3(nq > 4 ? 4 : 1), dim3(256), 0, s, dq, nq, (int64_t)(nq > 4 ? 16 : 4), (int)ix.dim_, m.d_pad8, m.mu8.as<float>(), m.step8, 1.f / m.step8, ix.metric_,
                        m.q8.as<signed char>(), m.qstat.as<float>(), px);
   }
   Stream8Args a;
@@ -1071,7 +1074,11 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
     if (clean) EPS_S8_LAUNCH_(P_, true);     \
     else EPS_S8_LAUNCH_(P_, false);          \
   } while (0)
-  if (pieces == 2) EPS_S8_LAUNCH(2);
+  if (nq > 4) {   // 5..16 queries: the same pass on the matrix cores
+    if (pieces == 2) hipLaunchKernelGGL((stream8m_kernel<2>), grid, block, 0, s, a);
+    else if (pieces == 3) hipLaunchKernelGGL((stream8m_kernel<3>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((stream8m_kernel<4>), grid, block, 0, s, a);
+  } else if (pieces == 2) EPS_S8_LAUNCH(2);
   else if (pieces == 3) EPS_S8_LAUNCH(3);
   else EPS_S8_LAUNCH(4);
 #undef EPS_S8_LAUNCH
@@ -1147,7 +1154,7 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
     memcpy(&h.total, reinterpret_cast<const char*>(hraw) + (span - 8), 8);
   }
   if (tune_env("EPS_DEBUG") || (h.overflow && tune_env("EPS_DEBUG_ONE_PASS_OVERFLOW"))) {
-    std::vector<u32> hc((size_t)S8_TABLE_WORDS + (size_t)4 * S8_MAX_WAVES);
+    std::vector<u32> hc((size_t)S8_TABLE_WORDS + (size_t)S8_MAX_Q * S8_MAX_WAVES);
     (void)hipMemcpy(hc.data(), m.s8g.p, hc.size() * 4, hipMemcpyDeviceToHost);
     for (int64_t q = 0; q < nq; ++q) {
       unsigned long long raw = 0;
@@ -1199,7 +1206,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
     // request still gets it; re-attaching rows re-arms it)
     if (!ix.mirror_->i8_ok || (auto_bits && ix.mirror_->i8_overflows >= 3)) i8 = false;
   }
-  if (i8 && !approx && cap_scale == 1 && nq <= 4) {
+  if (i8 && !approx && cap_scale == 1 && nq <= S8_MAX_Q) {
     bool done = false;
     rc = flat_stream8_slice(ix, dq, nq, k, run_keys, &done);
     if (rc != EPS_OK || done) return rc;

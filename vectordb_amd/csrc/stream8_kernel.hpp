@@ -72,7 +72,8 @@ struct Stream8Args {
 constexpr int S8_FORCE_LIMIT = 0x30000000;   // (= TQ_MAX8: accumulators at or above it belong to forced rows)
 constexpr int S8_EMPTY = -2147483647 - 1;
 constexpr int S8_SLOTS = 64, S8_SLOT_STRIDE = 64;   // (stride in 4-byte words)
-constexpr int S8_TABLE_WORDS = 4 * S8_SLOTS * S8_SLOT_STRIDE;
+constexpr int S8_MAX_Q = 16;   // queries of a one-pass call: <= 4 on v_dot4 (stream8_kernel), 5..16 on the matrix cores (stream8m_kernel, r5)
+constexpr int S8_TABLE_WORDS = S8_MAX_Q * S8_SLOTS * S8_SLOT_STRIDE;
 constexpr int S8_WAVE_CAP = 32, S8_MAX_WAVES = 8192;   // (32: a run of identical rows - 16 of them in one chunk - must not fill a list by itself)
 
 // upper bound of the exact fp32 distance of a row whose accumulator is `acc` (see the header; mirrors stage_threshold8 term by term)
@@ -167,7 +168,7 @@ template <int PIECES, int NQ, bool PREP>
 __global__ __launch_bounds__(256, 2) void stream8_kernel(Stream8Args a) {
   constexpr int U = PIECES <= 3 ? 4 : 2;
   constexpr int CH = 4 * U;   // rows per wavefront and iteration
-  __shared__ int T_s[4], gkth_s[4];
+  __shared__ int T_s[4], gkth_s[4];   // (this kernel: <= 4 queries)
   __shared__ __attribute__((aligned(16))) signed char q8_s[PREP ? NQ * PIECES * 256 : 16];
   __shared__ float qstat_s[16];
   const int lane = lane_id();
@@ -367,6 +368,137 @@ __global__ __launch_bounds__(256, 2) void stream8_kernel(Stream8Args a) {
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
     if (q < a.nq && lane == 0) a.raw_cnt[(int64_t)q * a.waves + wid] = mine[q];
+}
+
+// ---- 5..16 queries in one pass (r5).  Four queries' slices are what a lane's registers hold next to two chunks in flight; beyond that the
+// v_dot4 form falls off (r4: slices in LDS 0.64 ms at 8 queries, two passes side by side 0.38; r5: eight slices in registers at one
+// wavefront per SIMD 0.39-0.46 - the staged chain's 0.36 ms was the best of them).  A handful of queries x 16 rows IS a small matrix
+// product, and v_mfma_i32_16x16x64_i8 computes 16 rows x 16 query columns x 64 bytes of K in one instruction - 12 per 16-row block
+// at 768 bytes per row, ~11 us of matrix pipe for a 1M-row table - so the pass stays what the single-query pass is: HBM-bound.
+//   operands  lane l = (column c = l % 16, K group g = l / 16) supplies bytes [64 j + 16 g, +16) of ROW base + c (A) and of QUERY c (B, resident:
+//             12 x 4 registers; queries >= nq are zero rows of q8) for MFMA j; the K order is the same on both sides, so the sum is the plain
+//             dot product.  A block's 12 loads cover 16 consecutive rows = 12 KB of the mirror completely (64 bytes per row and instruction).
+//   results   lane l holds rows base + 4 g + {0, 1, 2, 3} of column c, started from acc0[row]: one compare per value against the column's
+//             threshold (T_s[c]), the common block ends at one ballot.
+// Table, thresholds, private candidate lists and the selection + re-rank behind the pass are stream8_kernel's (above), per query.
+template <int PIECES>
+__global__ __launch_bounds__(256, 2) void stream8m_kernel(Stream8Args a) {
+  constexpr int KS = PIECES * 4;   // MFMAs per 16-row block
+  __shared__ int T_s[S8_MAX_Q], gkth_s[S8_MAX_Q];
+  __shared__ u32 mine_s[4][S8_MAX_Q];   // entries of each wavefront's private list, per query
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const int col = lane & 15, kg = lane >> 4;
+  const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t W = (int64_t)gridDim.x * 4;
+  if (lane < S8_MAX_Q) mine_s[wave][lane] = 0;
+
+  i32x4 qv[KS];
+#pragma unroll
+  for (int j = 0; j < KS; ++j) qv[j] = *reinterpret_cast<const i32x4*>(a.q8 + (int64_t)col * a.d_pad8 + j * 64 + kg * 16);
+
+  auto load_block = [&](int64_t base, i32x4 (&xv)[KS], i32x4& c0) __attribute__((always_inline)) {
+    int64_t r = base + col;
+    r = r < a.n ? r : a.n - 1;
+    const signed char* p0 = a.x8 + r * a.d_pad8 + kg * 16;
+#pragma unroll
+    for (int j = 0; j < KS; ++j) xv[j] = *reinterpret_cast<const i32x4*>(p0 + j * 64);
+    c0 = *reinterpret_cast<const i32x4*>(a.acc0 + base + 4 * kg);   // (acc0 has n_pad8 >= n rounded up to 256 entries; base is a multiple of 16)
+  };
+  auto dots = [&](const i32x4 (&xv)[KS], const i32x4& c0) __attribute__((always_inline)) {
+    i32x4 acc = c0;
+#pragma unroll
+    for (int j = 0; j < KS; ++j) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(xv[j], qv[j], acc, 0, 0, 0);
+    return acc;
+  };
+  // the table -> thresholds: wavefront w serves the queries q = w, w + 4, ... (a refresh of 16 queries by one wavefront would cost it ~2 k instructions)
+  auto refresh = [&]() __attribute__((always_inline)) {
+    for (int q = wave; q < a.nq; q += 4) {
+      int gm;
+      const int Tq = stream8_threshold_of(a.G + q * S8_SLOTS * S8_SLOT_STRIDE, a.k, a.qstat + q * 4, a.scal, a.metric, a.u, a.slack, lane, gm);
+      if (lane == 0) {
+        *reinterpret_cast<volatile int*>(&T_s[q]) = Tq;
+        *reinterpret_cast<volatile int*>(&gkth_s[q]) = gm;
+      }
+    }
+  };
+  auto test_block = [&](int64_t base, const i32x4& acc) __attribute__((always_inline)) {
+    const int T = col < a.nq ? *reinterpret_cast<volatile int*>(&T_s[col]) : 2147483647;
+    const int gk = col < a.nq ? *reinterpret_cast<volatile int*>(&gkth_s[col]) : 2147483647;
+    const int64_t row0 = base + 4 * kg;
+    bool any = false;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) any |= (acc[r] >= T || acc[r] > gk) && row0 + r < a.n;
+    if (!__ballot(any)) return;   // (the common block ends here)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t row = row0 + r;
+      const int v = acc[r];
+      const bool live = row < a.n && col < a.nq;
+      unsigned long long m = __ballot(live && v >= T);
+      while (m) {   // (rare) one entry at a time: the lane it belongs to appends it to ITS query's list of this wavefront
+        const int i = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const int q = i & 15;
+        const u32 slot = *reinterpret_cast<volatile u32*>(&mine_s[wave][q]);
+        if (lane == i) {
+          if (slot < (u32)S8_WAVE_CAP) a.raw[((int64_t)q * a.waves + wid) * S8_WAVE_CAP + slot] = ((u64)(u32)v << 32) | (u32)row;
+          *reinterpret_cast<volatile u32*>(&mine_s[wave][q]) = slot + 1;
+        }
+      }
+      if (live && v > gk && v < S8_FORCE_LIMIT) stream8_offer(a, col, v, (u32)row);
+    }
+  };
+
+  constexpr int CH = 16;
+  const int64_t first = wid * CH, stride = W * CH;
+  i32x4 xa[KS], xb[KS], ca, cb;
+  if (first < a.n) load_block(first, xa, ca);
+  if (first + stride < a.n) load_block(first + stride, xb, cb);
+  i32x4 acc = {S8_EMPTY, S8_EMPTY, S8_EMPTY, S8_EMPTY};
+  // ---- the first block feeds the empty table before anything is tested: per query the best of the wavefront's 16 rows is offered
+  if (first < a.n) {
+    acc = dots(xa, ca);
+    int bv = S8_EMPTY, br = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool better = first + 4 * kg + r < a.n && acc[r] < S8_FORCE_LIMIT && acc[r] > bv;
+      br = better ? 4 * kg + r : br;
+      bv = better ? acc[r] : bv;
+    }
+#pragma unroll
+    for (int o = 16; o < 64; o <<= 1) {
+      const int ov = __shfl_xor(bv, o), orow = __shfl_xor(br, o);
+      const bool better = ov > bv;
+      br = better ? orow : br;
+      bv = better ? ov : bv;
+    }
+    if (kg == 0 && col < a.nq && bv != S8_EMPTY) stream8_offer(a, col, bv, (u32)(first + br));
+  }
+  __syncthreads();
+  // (as in stream8_kernel: a workgroup that gets here before k slots of a query have been filled by anyone waits for them - bounded)
+  for (int spin = 0; spin < 48; ++spin) {
+    refresh();
+    bool ready = true;
+    for (int q = wave; q < a.nq; q += 4) ready &= *reinterpret_cast<volatile int*>(&gkth_s[q]) != S8_EMPTY;
+    if (ready) break;
+    __builtin_amdgcn_s_sleep(16);
+  }
+  __syncthreads();
+  if (first < a.n) test_block(first, acc);
+  // ---- the stream, two blocks in flight per wavefront
+  int it = 1;
+  for (int64_t base = first + stride; base < a.n; base += 2 * stride, it += 2) {
+    if (base + stride < a.n) load_block(base + stride, xa, ca);
+    if (it == 1 || it == 3 || (it & 7) == 7) refresh();   // (every wavefront its own queries; a stale threshold only loosens the test)
+    acc = dots(xb, cb);
+    test_block(base, acc);
+    if (base + stride >= a.n) break;
+    if (base + 2 * stride < a.n) load_block(base + 2 * stride, xb, cb);
+    acc = dots(xa, ca);
+    test_block(base + stride, acc);
+  }
+  if (lane < a.nq) a.raw_cnt[(int64_t)lane * a.waves + wid] = *reinterpret_cast<volatile u32*>(&mine_s[wave][lane]);
 }
 
 // The selection step - candidates that still pass against the FINAL table go to the re-rank's list, the rest (the junk of the first
