@@ -343,10 +343,10 @@ def test_upper_bound_of_the_approximate_key(case, metric):
 
 
 @pytest.mark.parametrize("metric", [0, 1, 2])
-@pytest.mark.parametrize("k", [1, 10, 16])
+@pytest.mark.parametrize("k", [1, 10, 16, 17, 40, 64])
 def test_one_pass_table_never_loses_a_row_of_the_answer(metric, k):
-    """The one-pass search's table as stream8_kernel.hpp keeps it: 64 slots, slot = ((row * 2654435761) >> 12) & 63 holds the largest
-    accumulator among the VISIBLE rows hashed to it; the pass threshold = threshold(upper bound of the k-th largest slot).  Whatever
+    """The one-pass search's table as stream8_kernel.hpp keeps it: 64 slots (r5: 128 for k = 17..64), slot = ((row * 2654435761) >> 12) & 63
+    (& 127) holds the largest accumulator among the VISIBLE rows hashed to it; the pass threshold = threshold(upper bound of the k-th largest slot).  Whatever
     subset of the rows has been offered when a row is tested (the table only tightens: here the empty table, a tenth of the rows, all of
     them), every visible row of the exact top-k passes - and against the final table not many more rows do than against the threshold of
     the exact k-th distance itself."""
@@ -360,7 +360,8 @@ def test_one_pass_table_never_loses_a_row_of_the_answer(metric, k):
     m = mirror(X, metric, mu=mu, step=half / F(127.0))
     slack = slack_of(d)
     visible = rng.random(n) > 0.2                        # a deleted bitset
-    slot = ((np.arange(n, dtype=np.uint64) * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF)) >> np.uint64(12) & np.uint64(63)
+    slots = 64 if k <= 16 else 128
+    slot = ((np.arange(n, dtype=np.uint64) * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF)) >> np.uint64(12) & np.uint64(slots - 1)
     for qk in range(6):
         q = (X[105] if qk == 0 else X[rng.integers(n)] + F(0.05) * rng.standard_normal(d).astype(F)).astype(F)
         if metric == 1:
@@ -370,7 +371,7 @@ def test_one_pass_table_never_loses_a_row_of_the_answer(metric, k):
         exact = dist(q, X, metric)
         order = [i for i in np.lexsort((np.arange(n), exact)) if visible[i]][:k]     # the answer: (distance, id) order over visible rows
         for offered in (np.zeros(n, bool), (np.arange(n) % 10 == 0), np.ones(n, bool)):
-            table = np.full(64, -(1 << 31), dtype=np.int64)
+            table = np.full(slots, -(1 << 31), dtype=np.int64)
             for i in np.flatnonzero(offered & visible):
                 table[slot[i]] = max(table[slot[i]], acc[i])
             kth = np.sort(table)[::-1][k - 1]

@@ -251,7 +251,7 @@ __global__ __launch_bounds__(NW * 64) void rerank_kernel(RerankArgs a) {
     if (threadIdx.x == 0) s8_kept = s8_lost = 0;
     if (wave == 0) {
       int gk;
-      const int T = stream8_threshold_of(a.s8_G + q * (S8_SLOTS * S8_SLOT_STRIDE), a.k, a.qstat + q * 4, a.scal, a.metric, a.u, a.slack, lane, gk);
+      const int T = stream8_threshold_of(a.s8_G + q * (a.s8_slots * S8_SLOT_STRIDE), a.k, a.qstat + q * 4, a.scal, a.metric, a.u, a.slack, lane, gk, a.s8_slots);
       if (lane == 0) s8_T = T;
     }
     __syncthreads();
@@ -259,8 +259,8 @@ __global__ __launch_bounds__(NW * 64) void rerank_kernel(RerankArgs a) {
                        a.cap, &s8_kept, &s8_lost);
     __syncthreads();
     if (threadIdx.x == 0 && s8_lost) atomicAdd(a.overflow, 1u);   // a wavefront's list lost entries: the caller repeats the batch on the staged chain
-    if (a.s8_reset && threadIdx.x < S8_SLOTS)   // (the table has been read - threshold and selection above; the next call finds it empty)
-      const_cast<int*>(a.s8_G)[(q * S8_SLOTS + threadIdx.x) * S8_SLOT_STRIDE] = S8_EMPTY;
+    if (a.s8_reset && (int)threadIdx.x < a.s8_slots)   // (the table has been read - threshold and selection above; the next call finds it empty)
+      const_cast<int*>(a.s8_G)[(q * a.s8_slots + threadIdx.x) * S8_SLOT_STRIDE] = S8_EMPTY;
   }
   const u32 cnt_raw = a.s8_G ? s8_kept : a.cand_count[q];
   u32 cnt = cnt_raw;

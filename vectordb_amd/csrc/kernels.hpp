@@ -77,7 +77,8 @@ struct RerankArgs {
   // one-pass search of a handful of queries (stream8_kernel.hpp): the launch first SELECTS its candidates - the entries of the pass's
   // per-wavefront lists that still pass against the final table of best accumulators - into `cand` (written through s8_cand), starts
   // from an empty running list, and counts a lost list entry as an overflow.  s8_G == null: an ordinary re-rank
-  const int* s8_G = nullptr;        // [nq][64 slots]
+  const int* s8_G = nullptr;        // [nq][s8_slots]
+  int s8_slots = 64;                // 64 (k <= 16) | 128 (k = 17..64): Stream8Args::slots
   const u32* s8_counts = nullptr;   // [nq][s8_waves]
   const u64* s8_lists = nullptr;    // [nq][s8_waves][S8_WAVE_CAP]
   int s8_waves = 0;

@@ -101,11 +101,15 @@ struct HalfMirror {
   int i8_overflows = 0;         // consecutive batches whose 8-bit pass overflowed its candidate lists (the fp16 pass then answered)
   // r4, a handful of queries in one pass (stream8_kernel.hpp): the shared best-accumulator tables + raw candidate counters, the raw lists
   DevBuf s8g, s8raw;            // table slots (S8_TABLE_WORDS) + per-wavefront candidate counts;  u64 [nq][waves][S8_WAVE_CAP]
-  int64_t s8_declined_version = -1;   // rows version on which the one-pass form overflowed twice in a row (the staged chain serves it)
-  int s8_overflows = 0;
+  DevBuf s8mask;                // r5: u8 [(n + 7) / 8] - a call's compiled filter PROGRAM (and bitset, and column test) evaluated once per row into
+                                // one bitset (bit set = row invisible), which the pass and its re-rank then read as a deleted bitset
+  // rows version on which the one-pass form overflowed twice in a row (the staged chain serves it); [0]: k <= 16, [1]: k = 17..64 - a larger k
+  // passes more rows against the same lists, and must not talk the table out of the form for the small-k traffic
+  int64_t s8_declined_version[2] = {-1, -1};
+  int s8_overflows[2] = {0, 0};
   // under a deleted bitset / an int-column filter an overflow usually means "fewer than k rows visible": the rows' version says nothing
   // about it, so two such overflows in a row make the next 32 filtered calls go straight to the staged chain, then the one-pass form is tried again
-  int s8_filt_overflows = 0, s8_filt_skip = 0;
+  int s8_filt_overflows[2] = {0, 0}, s8_filt_skip[2] = {0, 0};   // (per k class, as above)
   int s8_cus = 0;               // CUs of the device (grid of the one-pass kernel)
   // r5: the call's two result counters land in host-mapped memory (written by the last block of the re-rank launch), read after the stream
   // sync: no device-to-host copy at the end of a 0.2 ms call
@@ -520,6 +524,7 @@ struct Prep8Extra {
   u32* gsync = nullptr;        // prologue: 256 group counters = 0
   u32* qmax = nullptr;         // [2] (zeroed by the caller): atomicMax of the float bits of |q'| and |q' - qh'| over the batch (fold8_kernel reads them)
   int* s8g = nullptr;          // one-pass form (stream8_kernel.hpp): table slots = empty, raw candidate counters = 0
+  int s8_slots = S8_SLOTS;     // slots per query of that call (64 | 128)
 };
 __global__ __launch_bounds__(256) void query_prep8_kernel(const float* q, int64_t nq, int64_t b_pad, int dim, int d_pad8, const float* mu, float step, float inv_step,
                                                           int metric, signed char* q8, float* qstat, Prep8Extra x) {
@@ -530,7 +535,7 @@ __global__ __launch_bounds__(256) void query_prep8_kernel(const float* q, int64_
     if (x.s8g) {   // (the slots of the call's queries - at least of the first four: a later call of 1-2 queries that skips this launch relies on its own
                    // slots being empty, and the re-rank of every call restores exactly the slots it used - and S8_MAX_Q + 8 counter words)
       const int qinit = nq > 4 ? (int)nq : 4;
-      for (int i = threadIdx.x; i < qinit * S8_SLOTS; i += 256) x.s8g[i * S8_SLOT_STRIDE] = S8_EMPTY;
+      for (int i = threadIdx.x; i < qinit * x.s8_slots; i += 256) x.s8g[i * S8_SLOT_STRIDE] = S8_EMPTY;
     }
   }
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -595,6 +600,24 @@ __global__ __launch_bounds__(256) void query_prep8_kernel(const float* q, int64_
 // stage_threshold8 / stage_threshold16).  Also resets what the launch accumulates into (candidate counts, group arrival counters).
 // In exact mode a stage's re-rank computes the next stage's thresholds itself (RerankArgs::fuse); these kernels serve the
 // approx mode (kNN build), the unseeded staging, and the padding entries.
+// One-pass calls under a compiled filter PROGRAM (r5): the pass itself cannot call the evaluator (a function call = scratch memory for every
+// wavefront of an HBM-bound stream), and it does not have to - whether a row is visible does not depend on the query, so the whole predicate
+// (deleted bitset, int-column test, program; @distance = 0 as PreFilterBruteForceSearch evaluates it, vec_search_executor.cpp:795) is
+// evaluated ONCE per row into a bitset in the deleted bitset's layout (bit i of byte i >> 3 set = row i is NOT visible) by this launch,
+// and pass + re-rank read that.  One thread per byte: 8 rows, n x stride bytes of attribute rows read once (1M rows x 16 B = 3 us).
+__global__ __launch_bounds__(256) void filter_mask_kernel(FilterSpec f, int64_t n, uint8_t* mask) {
+  const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (b * 8 >= n) return;
+  u32 bits = 0;
+#pragma unroll 1
+  for (int i = 0; i < 8; ++i) {
+    const int64_t r = b * 8 + i;
+    const bool visible = r < n && row_visible(f, (u32)r, 0.f);
+    bits |= (visible ? 0u : 1u) << i;
+  }
+  mask[b] = (uint8_t)bits;
+}
+
 __global__ void threshold8_kernel(const u64* run_keys, int k, int64_t nq, int64_t b_pad, const float* qstat, const float* scal8, int metric,
                                   float u, int* T, u32* cnt, u32* gsync, float slack, int approx, int pad_only) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -958,8 +981,8 @@ bool flat_mfma_profitable(const Index& ix, int64_t nq, int k) {
   const bool have8 = known8 && m->i8_ok;
   const bool can16 = !have16 || m->fp16_range_ok;
   if (known8 && !have8 && !can16) return false;                 // neither mirror can serve this table
-  // up to 4 queries, k <= 16, rows of <= 1024 bytes: the one-pass search (stream8_kernel.hpp) - one pass over d_pad8 + 4 bytes per row
-  const bool one_pass_shape = nq <= S8_MAX_Q && k <= 16 && ix.dim_ <= 1024 && !(tune_env("EPS_FLAT_ONE_PASS") && atoi(tune_env("EPS_FLAT_ONE_PASS")) == 0);
+  // up to 16 queries, k <= 64, rows of <= 1024 bytes: the one-pass search (stream8_kernel.hpp) - one pass over d_pad8 + 4 bytes per row
+  const bool one_pass_shape = nq <= S8_MAX_Q && k <= S8_MAX_K && ix.dim_ <= 1024 && !(tune_env("EPS_FLAT_ONE_PASS") && atoi(tune_env("EPS_FLAT_ONE_PASS")) == 0);
   if (nq < 8 && !have8 && !have16) {
     // single-query traffic alone does not get a mirror (n x d bytes of HBM + a pass over the table to build it) at once: r4, after 16 such
     // calls on the same rows it does, where the one-pass search can use it (0.20 ms instead of 0.62 ms per call at 1M x 768)
@@ -975,13 +998,13 @@ bool flat_mfma_profitable(const Index& ix, int64_t nq, int k) {
   const double rate = use8 ? 2.0e15 : 1.2e15;                    // matrix rate the filter kernel reaches
   const double dp = use8 ? op_bytes : op_bytes / 2.0;
   const double stream_s = std::ceil((double)nq / 4.0) * rows * d * 4.0 / 6.0e12 + 0.2e-3;
-  const double filter_s = (use8 && one_pass_shape && !(have8 && m->fold8) && !ix.filter_spec().prog)   // (filter programs never take the one-pass form)
+  const double filter_s = (use8 && one_pass_shape && !(have8 && m->fold8))   // (r5: filter programs take the one-pass form too - behind one mask launch)
                               ? 0.07e-3 + rows * (std::ceil(d / 256.0) * 256.0 + 4.0) / 5.7e12
                               : 0.35e-3 + std::max(rows * op_bytes / 5.0e12, 2.0 * 128.0 * std::ceil((double)nq / 128.0) * rows * dp / rate);
   return filter_s < stream_s;
 }
 
-// A handful of queries (<= 4, k <= 16) in ONE pass over the 8-bit mirror: stream8_kernel.hpp.  *done = false: not applicable to this call,
+// A handful of queries (<= 16, k <= 64) in ONE pass over the 8-bit mirror: stream8_kernel.hpp.  *done = false: not applicable to this call,
 // or a list overflowed - the staged chain below answers it (results are bit-identical either way: both end in the same exact re-rank).
 static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k, u64* run_keys, bool* done) {
   *done = false;
@@ -990,19 +1013,34 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
   const int pieces = m.d_pad8 / 256;
   if (tune_env("EPS_FLAT_ONE_PASS") && atoi(tune_env("EPS_FLAT_ONE_PASS")) == 0) return EPS_OK;
   const int max_q = tune_env("EPS_S8_MAX_Q") ? std::min(S8_MAX_Q, std::max(1, atoi(tune_env("EPS_S8_MAX_Q")))) : S8_MAX_Q;   // (A/B switch: 4 = the r4 form, 5+ queries on the staged chain)
-  if (nq < 1 || nq > max_q || k < 1 || k > 16 || m.fold8 || n < 65536 || n > m.n8 || m.d_pad8 % 256 != 0 || pieces < 2 || pieces > 4) return EPS_OK;
-  if (m.s8_declined_version == ix.rows_version_) return EPS_OK;
-  const FilterSpec fs = ix.filter_spec();
-  if (fs.prog) return EPS_OK;   // (filter programs: the staged chain; a deleted bitset and an int-column filter are handled in the pass)
-  if ((fs.deleted || fs.column) && m.s8_filt_skip > 0) {   // (a mask that starves the pass used to cost a wasted pass on EVERY call)
-    --m.s8_filt_skip;
+  const int max_k = tune_env("EPS_S8_MAX_K") ? std::min(S8_MAX_K, std::max(1, atoi(tune_env("EPS_S8_MAX_K")))) : S8_MAX_K;   // (A/B switch: 16 = the r4 range, larger k on the staged chain)
+  if (nq < 1 || nq > max_q || k < 1 || k > max_k || m.fold8 || n < 65536 || n > m.n8 || m.d_pad8 % 256 != 0 || pieces < 2 || pieces > 4) return EPS_OK;
+  const int kclass = k <= 16 ? 0 : 1;
+  if (m.s8_declined_version[kclass] == ix.rows_version_) return EPS_OK;
+  FilterSpec fs = ix.filter_spec();
+  // a compiled filter program: evaluated once per row into a bitset (filter_mask_kernel) that pass and re-rank read as a deleted bitset.  Only
+  // where the predicate does not depend on the candidate's distance (Index::search sends programs that read @distance outside a pre-filter
+  // call to the stream engine before they get here; checked again, the staged chain evaluates per candidate)
+  const bool masked = fs.prog != nullptr;
+  if (masked && ix.prog_uses_dist_ && !ix.prefilter_call_) return EPS_OK;
+  if (masked && tune_env("EPS_S8_FILTER_PROGRAMS") && atoi(tune_env("EPS_S8_FILTER_PROGRAMS")) == 0) return EPS_OK;   // (A/B switch: programs on the staged chain, as until r4)
+  const bool filtered = fs.deleted || fs.column || masked;
+  if (filtered && m.s8_filt_skip[kclass] > 0) {   // (a mask that starves the pass used to cost a wasted pass on EVERY call)
+    --m.s8_filt_skip[kclass];
     return EPS_OK;
   }
   hipStream_t s = ix.stream_;
   const int cap = std::max(4096, 64 * k);
   if (!m.qstat.reserve((size_t)S8_MAX_Q * 16) || !m.q8.reserve((size_t)S8_MAX_Q * m.d_pad8) || !m.cand.reserve((size_t)nq * cap * 8) || !m.cnt.reserve((size_t)(nq + 4) * 4 + 16) ||
-      !m.s8g.reserve((size_t)S8_TABLE_WORDS * 4 + (size_t)S8_MAX_Q * S8_MAX_WAVES * 4) || !m.s8raw.reserve((size_t)nq * S8_MAX_WAVES * S8_WAVE_CAP * 8))
+      !m.s8g.reserve((size_t)S8_TABLE_WORDS * 4 + (size_t)S8_MAX_Q * S8_MAX_WAVES * 4) || !m.s8raw.reserve((size_t)nq * S8_MAX_WAVES * S8_WAVE_CAP * 8) ||
+      (masked && !m.s8mask.reserve((size_t)(n + 7) / 8 + 16)))
     return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory (scratch)");
+  if (masked) {   // (every call: the caller's bitset and attribute rows are used in place and may have changed since the last one)
+    fs.prog_use_dist = 0;
+    hipLaunchKernelGGL(filter_mask_kernel, dim3((unsigned)(((n + 7) / 8 + 255) / 256)), dim3(256), 0, s, fs, n, m.s8mask.as<uint8_t>());
+    fs = no_filter();
+    fs.deleted = m.s8mask.as<uint8_t>();
+  }
   // (cnt: nq + 8 <= 12 words in use here; DevBuf::reserve never hands out less than 256 bytes)
   u32* cnt = m.cnt.as<u32>();
   u32* overflow = cnt + nq;
@@ -1013,14 +1051,19 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
   const bool host_words = !(tune_env("EPS_S8_HOST_WORDS") && atoi(tune_env("EPS_S8_HOST_WORDS")) == 0) && m.s8_pub.get();   // (A/B switch)
   const bool two_launches = host_words && !(tune_env("EPS_S8_TWO_LAUNCHES") && atoi(tune_env("EPS_S8_TWO_LAUNCHES")) == 0) && !tune_env("EPS_DEBUG");  // (A/B switch; the debug log reads the table after the call)
   // (3-4 queries keep the prep launch: next to four queries' slices and two chunks in flight the in-kernel form does not fit 256 registers)
-  const bool clean = two_launches && nq <= 2 && m.s8_clean_cnt == m.cnt.p && m.s8_clean_g == m.s8g.p;
+  // (k = 17..64: 128 slots per query in the same table - a layout of its own, so such a call always starts with the prep launch, which empties
+  // the slots it uses, and never leaves the "clean" state behind)
+  const int slots = k <= 16 ? S8_SLOTS : S8_SLOTS_WIDE;
+  const bool mfma_form = nq > 4 || (slots != S8_SLOTS && nq > 2);   // stream8m_kernel (16 query columns: the prep launch lays down 16 rows, zeros beyond nq)
+  const bool clean = two_launches && nq <= 2 && slots == S8_SLOTS && m.s8_clean_cnt == m.cnt.p && m.s8_clean_g == m.s8g.p;
   m.s8_clean_cnt = m.s8_clean_g = nullptr;   // (set again when this call has come back)
   if (!clean) {
     Prep8Extra px;
     px.cnt = cnt;     // candidate counts, overflow and total counters = 0
     px.cntv = 0;
     px.s8g = m.s8g.as<int>();
-    hipLaunchKernelGGL(query_prep8_kernel, dim3(nq > 4 ? 4 : 1), dim3(256), 0, s, dq, nq, (int64_t)(nq > 4 ? 16 : 4), (int)ix.dim_, m.d_pad8, m.mu8.as<float>(), m.step8, 1.f / m.step8, ix.metric_,
+    px.s8_slots = slots;
+    hipLaunchKernelGGL(query_prep8_kernel, dim3(mfma_form ? 4 : 1), dim3(256), 0, s, dq, nq, (int64_t)(mfma_form ? 16 : 4), (int)ix.dim_, m.d_pad8, m.mu8.as<float>(), m.step8, 1.f / m.step8, ix.metric_,
                        m.q8.as<signed char>(), m.qstat.as<float>(), px);
   }
   Stream8Args a;
@@ -1037,6 +1080,7 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
   a.u = u8;
   a.slack = rerank_slack;
   a.G = m.s8g.as<int>();
+  a.slots = slots;
   a.raw_cnt = m.s8g.as<u32>() + S8_TABLE_WORDS;
   a.raw = m.s8raw.as<u64>();
   a.f = fs;
@@ -1074,7 +1118,17 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
     if (clean) EPS_S8_LAUNCH_(P_, true);     \
     else EPS_S8_LAUNCH_(P_, false);          \
   } while (0)
-  if (nq > 4) {   // 5..16 queries: the same pass on the matrix cores
+  if (slots != S8_SLOTS && nq <= 2) {   // k = 17..64, 1-2 queries: the v_dot4 pass with two slots per lane
+#define EPS_S8_WIDE(P_)                                                                                   \
+  do {                                                                                                    \
+    if (nq == 1) hipLaunchKernelGGL((stream8_kernel<P_, 1, false, true>), grid, block, 0, s, a);          \
+    else hipLaunchKernelGGL((stream8_kernel<P_, 2, false, true>), grid, block, 0, s, a);                  \
+  } while (0)
+    if (pieces == 2) EPS_S8_WIDE(2);
+    else if (pieces == 3) EPS_S8_WIDE(3);
+    else EPS_S8_WIDE(4);
+#undef EPS_S8_WIDE
+  } else if (mfma_form) {   // 5..16 queries (and 3-4 with k > 16): the same pass on the matrix cores
     if (pieces == 2) hipLaunchKernelGGL((stream8m_kernel<2>), grid, block, 0, s, a);
     else if (pieces == 3) hipLaunchKernelGGL((stream8m_kernel<3>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((stream8m_kernel<4>), grid, block, 0, s, a);
@@ -1107,6 +1161,7 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
   ra.slack = rerank_slack;
   ra.gsync = nullptr;
   ra.s8_G = a.G;                 // (the launch selects its candidates from the pass's lists first)
+  ra.s8_slots = slots;
   ra.s8_counts = a.raw_cnt;
   ra.s8_lists = a.raw;
   ra.s8_waves = a.waves;
@@ -1114,7 +1169,7 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
   if (host_words) {
     ra.pub = m.s8_pub.p;
     ra.pub_ticket = cnt + nq + 6;   // (zeroed by the prep launch with the other counters: cnt[nq .. nq + 8))
-    ra.s8_reset = two_launches ? 1 : 0;
+    ra.s8_reset = two_launches && slots == S8_SLOTS ? 1 : 0;
   }
   const bool fin_here = ix.pre_sync_ && nq == ix.pre_sync_nq_ && ix.fin_ids_ != nullptr;
   if (fin_here) {
@@ -1142,7 +1197,7 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
     const volatile u32* hp = m.s8_pub.p;
     h.overflow = hp[0];
     h.total = (unsigned long long)hp[2] | ((unsigned long long)hp[3] << 32);
-    if (two_launches) {   // (the launch left slots and counters as the next call needs them)
+    if (two_launches && slots == S8_SLOTS) {   // (the launch left slots and counters as the next call needs them)
       m.s8_clean_cnt = m.cnt.p;
       m.s8_clean_g = m.s8g.p;
     }
@@ -1164,24 +1219,24 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
         raw += hc[S8_TABLE_WORDS + q * a.waves + w];
         most = std::max(most, hc[S8_TABLE_WORDS + q * a.waves + w]);
       }
-      for (int i = 0; i < S8_SLOTS; ++i) filled += (int)hc[(q * S8_SLOTS + i) * S8_SLOT_STRIDE] != S8_EMPTY;
-      fprintf(stderr, "[eps one pass] query %lld: %llu raw candidates (at most %u in one wavefront's list of %d), %d of 64 slots filled, re-ranked (all queries) %llu, overflow %u\n",
+      for (int i = 0; i < slots; ++i) filled += (int)hc[(q * slots + i) * S8_SLOT_STRIDE] != S8_EMPTY;
+      fprintf(stderr, "[eps one pass] query %lld: %llu raw candidates (at most %u in one wavefront's list of %d), %d of the slots filled, re-ranked (all queries) %llu, overflow %u\n",
               (long long)q, raw, most, S8_WAVE_CAP, filled, h.total, h.overflow);
     }
   }
   if (h.overflow) {   // (too loose a bound for this table, or a filter that leaves fewer than k rows visible: the staged chain answers)
     ix.result_finalized_ = false;
-    if (fs.deleted || fs.column) {
-      if (++m.s8_filt_overflows >= 2) {
-        m.s8_filt_overflows = 0;
-        m.s8_filt_skip = 32;
+    if (filtered) {
+      if (++m.s8_filt_overflows[kclass] >= 2) {
+        m.s8_filt_overflows[kclass] = 0;
+        m.s8_filt_skip[kclass] = 32;
       }
-    } else if (++m.s8_overflows >= 2) {
-      m.s8_declined_version = ix.rows_version_;
+    } else if (++m.s8_overflows[kclass] >= 2) {
+      m.s8_declined_version[kclass] = ix.rows_version_;
     }
     return EPS_OK;
   }
-  if (fs.deleted || fs.column) m.s8_filt_overflows = 0; else m.s8_overflows = 0;
+  if (filtered) m.s8_filt_overflows[kclass] = 0; else m.s8_overflows[kclass] = 0;
   if (fin_here) ix.result_finalized_ = true;
   ix.stats_.rerank_rows += (int64_t)h.total;
   ix.stats_.dist_evals += nq * n;

@@ -1,4 +1,5 @@
-// Exact flat search of a HANDFUL of queries (<= 4) in ONE pass over the 8-bit mirror (r4; BASELINE configs[1]: one query per call).
+// Exact flat search of a HANDFUL of queries (<= 4 on v_dot4; r5: 5..16 on the matrix cores, k <= 64) in ONE pass over the 8-bit mirror (r4; BASELINE
+// configs[1]: one query per call).
 //
 // What it replaces: for a few queries the staged MFMA chain of mfma_filter.hip is a GEMM-shaped answer to a GEMV-shaped problem - a
 // single-query call was 9 dependent launches (query prep, seed pass, seed selection, seed re-rank, 3 x (filter stage + re-rank)), 0.33 ms
@@ -13,7 +14,9 @@
 //                result is at most the largest upper bound among them: ub(acc) = C[q] - u acc + margin (the Cauchy-Schwarz margin of
 //                stage_threshold8, which bounds |exact - approximate| in BOTH directions;
 //                tests/test_bound_math.py::test_upper_bound_of_the_approximate_key).  With 64 slots for k <= 16 the k-th largest slot
-//                ends within a few ranks of the k-th best row.  Every slot has its own 256 bytes: device-scope atomics on ONE address
+//                ends within a few ranks of the k-th best row; r5: k = 17..64 use 128 slots (Stream8Args::slots; the k-th largest of S
+//                hash buckets' maxima is the row of rank ~ S ln(S / (S - k)): rank 89 for k = 64 of 128, where 64 slots would give the
+//                worst bucket's best row, rank ~300, and four times the candidates).  Every slot has its own 256 bytes: device-scope atomics on ONE address
 //                are served one after the other, ~50 ns each on this machine (measured: the first versions of this kernel - a 16-entry
 //                table in one cache line, offered to by 4096 wavefronts at start - spent 0.2 ms there), on 64 lines they overlap.
 //   pass test    a row is a candidate iff acc >= stage_threshold8(ub(k-th largest slot)) - the same arithmetic every filter stage
@@ -52,7 +55,8 @@ struct Stream8Args {
   const float* scal;       // the mirror's maxima (HalfMirror::scal8)
   int nq, k, metric;
   float u, slack;
-  int* G;                  // [nq][64] slots, S8_SLOT_STRIDE ints apart
+  int* G;                  // [nq][slots] slots, S8_SLOT_STRIDE ints apart
+  int slots = 64;          // S8_SLOTS (k <= 16) | S8_SLOTS_WIDE (k = 17..64)
   u32* raw_cnt;            // [nq][waves]: entries every wavefront of the grid found (written once, when it ends)
   u64* raw;                // [nq][waves][S8_WAVE_CAP]: (acc << 32) | row - a private list per wavefront: no atomic, nothing to wait for
   int waves;               // wavefronts of the grid (<= S8_MAX_WAVES)
@@ -71,9 +75,10 @@ struct Stream8Args {
 
 constexpr int S8_FORCE_LIMIT = 0x30000000;   // (= TQ_MAX8: accumulators at or above it belong to forced rows)
 constexpr int S8_EMPTY = -2147483647 - 1;
-constexpr int S8_SLOTS = 64, S8_SLOT_STRIDE = 64;   // (stride in 4-byte words)
+constexpr int S8_SLOTS = 64, S8_SLOTS_WIDE = 128, S8_SLOT_STRIDE = 64;   // (stride in 4-byte words)
+constexpr int S8_MAX_K = 64;   // k of a one-pass call: <= 16 with 64 slots per query, 17..64 with 128 (r5)
 constexpr int S8_MAX_Q = 16;   // queries of a one-pass call: <= 4 on v_dot4 (stream8_kernel), 5..16 on the matrix cores (stream8m_kernel, r5)
-constexpr int S8_TABLE_WORDS = S8_MAX_Q * S8_SLOTS * S8_SLOT_STRIDE;
+constexpr int S8_TABLE_WORDS = S8_MAX_Q * S8_SLOTS_WIDE * S8_SLOT_STRIDE;
 constexpr int S8_WAVE_CAP = 32, S8_MAX_WAVES = 8192;   // (32: a run of identical rows - 16 of them in one chunk - must not fill a list by itself)
 
 // upper bound of the exact fp32 distance of a row whose accumulator is `acc` (see the header; mirrors stage_threshold8 term by term)
@@ -89,19 +94,51 @@ __device__ __forceinline__ float stream8_ub(int acc, const float* qs, const floa
   return dapx + margin + 2.f * slack * scale + 4.f * u;
 }
 
-// pass threshold of a query from its table G: the k-th largest slot (one wavefront, one slot per lane; every lane gets the result)
-__device__ __forceinline__ int stream8_threshold_of(const int* G, int k, const float* qs, const float* sc, int metric, float u, float slack, int lane, int& gkth) {
+// pass threshold of a query from its table G: the k-th largest slot (one wavefront, one slot per lane - two with 128 slots; every lane gets
+// the result).  Slots are ordered by (value descending, slot index ascending): exactly one of them has rank k - 1.
+__device__ __forceinline__ int stream8_threshold_of(const int* G, int k, const float* qs, const float* sc, int metric, float u, float slack, int lane, int& gkth,
+                                                    int slots = S8_SLOTS, int* filled = nullptr) {
   const int v = __hip_atomic_load(G + lane * S8_SLOT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  int rank = 0;   // slots that order before this lane's (larger value, or equal and lower lane)
-  for (int i = 0; i < 64; ++i) {
-    const int w = __builtin_amdgcn_readlane(v, i);
-    rank += (w > v || (w == v && i < lane)) ? 1 : 0;
+  int kth;
+  if (filled) *filled = __popcll(__ballot(v != S8_EMPTY));   // (the start-up wait only; folds away elsewhere)
+  if (slots == S8_SLOTS) {
+    int rank = 0;   // slots that order before this lane's (larger value, or equal and lower lane)
+    for (int i = 0; i < 64; ++i) {
+      const int w = __builtin_amdgcn_readlane(v, i);
+      rank += (w > v || (w == v && i < lane)) ? 1 : 0;
+    }
+    const unsigned long long m = __ballot(rank == k - 1);
+    kth = __builtin_amdgcn_readlane(v, __ffsll((long long)m) - 1);
+  } else {   // 128 slots: lane l holds slots l and l + 64
+    const int v1 = __hip_atomic_load(G + (lane + 64) * S8_SLOT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (filled) *filled += __popcll(__ballot(v1 != S8_EMPTY));
+    int r0 = 0, r1 = 0;
+    for (int i = 0; i < 64; ++i) {
+      const int w0 = __builtin_amdgcn_readlane(v, i), w1 = __builtin_amdgcn_readlane(v1, i);
+      r0 += ((w0 > v || (w0 == v && i < lane)) ? 1 : 0) + (w1 > v ? 1 : 0);                        // (slot i + 64 never precedes slot `lane` on a tie)
+      r1 += (w0 >= v1 ? 1 : 0) + ((w1 > v1 || (w1 == v1 && i < lane)) ? 1 : 0);                    // (slot i always precedes slot lane + 64 on a tie)
+    }
+    const unsigned long long m0 = __ballot(r0 == k - 1), m1 = __ballot(r1 == k - 1);
+    kth = m0 ? __builtin_amdgcn_readlane(v, __ffsll((long long)m0) - 1) : __builtin_amdgcn_readlane(v1, m1 ? __ffsll((long long)m1) - 1 : 63);   // (1 <= k <= 128: one of the two is set)
   }
-  const unsigned long long m = __ballot(rank == k - 1);
-  const int kth = __builtin_amdgcn_readlane(v, __ffsll((long long)m) - 1);
   gkth = kth;
   if (kth == S8_EMPTY) return -(1 << 30);   // fewer than k slots filled so far: everything passes
   return stage_threshold8(stream8_ub(kth, qs, sc, metric, u, slack), qs, sc, metric, u, slack, 0);
+}
+
+// The start-up wait (both kernels below).  A workgroup reads its first thresholds once the table holds enough of the wavefronts' first
+// offers.  "Enough" was k filled slots until r5 - but the k-th largest of EXACTLY k filled slots is the WORST row offered so far, and once in
+// a few thousand calls that is a below-median row: a workgroup that read the table at that moment let most of its rows through, and on a
+// small table (90 000 rows = 3 chunks per wavefront, no refresh in time) a 32-entry list overflowed and the staged chain had to repeat the
+// call (found by scripts/lab/dbg_wide2.py: 1 call in 5040, "37 in one wavefront's list of 32").  Now: max(2 k, k + 8) filled slots (capped at
+// 7/8 of the table: a third of the rows visible leaves a slot or two of 128 empty for good) - the k-th largest of twice as many offers is a
+// median offer, not the worst - and when k are there but the rest does not come (a filter that leaves few rows visible) three more looks,
+// then the wavefront takes what there is.
+constexpr int S8_STARTUP_GRACE = 3;
+__device__ __forceinline__ int stream8_startup_need(int k, int slots) {
+  const int want = 2 * k > k + 8 ? 2 * k : k + 8;
+  const int most = slots - slots / 8;
+  return want < most ? want : most;
 }
 
 // one query, one wavefront: the arithmetic of query_prep8_kernel (mfma_filter.hip) term by term, the bytes to `dst`, the four constants to `qs`
@@ -156,16 +193,20 @@ __device__ __forceinline__ void stream8_offer(const Stream8Args& a, int q, int a
   FilterSpec f = a.f;
   f.prog = nullptr;
   if (!row_visible(f, row)) return;
-  const u32 slot = ((row * 2654435761u) >> 12) & (u32)(S8_SLOTS - 1);
-  (void)__hip_atomic_fetch_max(a.G + (q * S8_SLOTS + (int)slot) * S8_SLOT_STRIDE, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const u32 slot = ((row * 2654435761u) >> 12) & (u32)(a.slots - 1);
+  (void)__hip_atomic_fetch_max(a.G + (q * a.slots + (int)slot) * S8_SLOT_STRIDE, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // PIECES = d_pad8 / 256: a row is PIECES x 256 bytes, 16 lanes x 16 bytes each; four rows per wavefront and step, U steps in flight.
 // The table is READ by one wavefront per workgroup, every fourth iteration, and handed to the other three through LDS: read by every
 // wavefront in every iteration (4096 cache-bypassing loads of one 64-byte line per round) the loads queued up at that line's memory
 // channel for ~20 us per iteration - the first version of this kernel ran at 2.1 TB/s because of it.
-template <int PIECES, int NQ, bool PREP>
+// WIDE: the 128-slot table of k = 17..64 (a compile-time choice here: the second slot per lane costs the refresh ~10 registers, which the
+// 3-4-query forms do not have - those calls run stream8m_kernel, where the slot count is a run-time value)
+template <int PIECES, int NQ, bool PREP, bool WIDE = false>
 __global__ __launch_bounds__(256, 2) void stream8_kernel(Stream8Args a) {
+  static_assert(!WIDE || (NQ <= 2 && !PREP), "128 slots: 1-2 queries behind the prep launch");
+  constexpr int SLOTS = WIDE ? S8_SLOTS_WIDE : S8_SLOTS;
   constexpr int U = PIECES <= 3 ? 4 : 2;
   constexpr int CH = 4 * U;   // rows per wavefront and iteration
   __shared__ int T_s[4], gkth_s[4];   // (this kernel: <= 4 queries)
@@ -225,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void stream8_kernel(Stream8Args a) {
         float qs[4];   // (by value: a pointer that may be LDS or global is a flat pointer)
 #pragma unroll
         for (int i = 0; i < 4; ++i) qs[i] = PREP ? qstat_s[q * 4 + i] : a.qstat[q * 4 + i];
-        const int Tq = stream8_threshold_of(a.G + q * S8_SLOTS * S8_SLOT_STRIDE, a.k, qs, a.scal, a.metric, a.u, a.slack, lane, gm);
+        const int Tq = stream8_threshold_of(a.G + q * SLOTS * S8_SLOT_STRIDE, a.k, qs, a.scal, a.metric, a.u, a.slack, lane, gm, SLOTS);
         if (lane == 0) {
           T_s[q] = Tq;
           gkth_s[q] = gm;
@@ -333,14 +374,31 @@ __global__ __launch_bounds__(256, 2) void stream8_kernel(Stream8Args a) {
     __syncthreads();
     // (the offers are fire-and-forget atomics: a workgroup that gets here before k slots have been filled by anyone would test its
     // first chunk against "everything passes"; it waits for them, a few microseconds at most - bounded, then it takes what there is)
-    if (wave == 0)
+    if (wave == 0) {
+      const int need = stream8_startup_need(a.k, SLOTS);
+      int grace = 0;
       for (int spin = 0; spin < 48; ++spin) {
-        refresh();
-        bool ready = true;
-        for (int q = 0; q < a.nq; ++q) ready &= *reinterpret_cast<volatile int*>(&gkth_s[q]) != S8_EMPTY;
-        if (ready) break;
+        int state = 2;   // 0: a query has fewer than k slots filled, 1: k but not `need`, 2: every query has what it needs
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          if (q < a.nq) {
+            int gm, filled;
+            float qs[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) qs[i] = PREP ? qstat_s[q * 4 + i] : a.qstat[q * 4 + i];
+            const int Tq = stream8_threshold_of(a.G + q * SLOTS * S8_SLOT_STRIDE, a.k, qs, a.scal, a.metric, a.u, a.slack, lane, gm, SLOTS, &filled);
+            if (lane == 0) {
+              T_s[q] = Tq;
+              gkth_s[q] = gm;
+            }
+            const int sq = gm == S8_EMPTY ? 0 : (filled >= need ? 2 : 1);
+            state = sq < state ? sq : state;
+          }
+        }
+        if (state == 2 || (state == 1 && ++grace > S8_STARTUP_GRACE)) break;
         __builtin_amdgcn_s_sleep(16);
       }
+    }
     __syncthreads();
   }
   if (S8_ABLATE & 12) {
@@ -415,7 +473,7 @@ __global__ __launch_bounds__(256, 2) void stream8m_kernel(Stream8Args a) {
   auto refresh = [&]() __attribute__((always_inline)) {
     for (int q = wave; q < a.nq; q += 4) {
       int gm;
-      const int Tq = stream8_threshold_of(a.G + q * S8_SLOTS * S8_SLOT_STRIDE, a.k, a.qstat + q * 4, a.scal, a.metric, a.u, a.slack, lane, gm);
+      const int Tq = stream8_threshold_of(a.G + q * a.slots * S8_SLOT_STRIDE, a.k, a.qstat + q * 4, a.scal, a.metric, a.u, a.slack, lane, gm, a.slots);
       if (lane == 0) {
         *reinterpret_cast<volatile int*>(&T_s[q]) = Tq;
         *reinterpret_cast<volatile int*>(&gkth_s[q]) = gm;
@@ -477,12 +535,24 @@ __global__ __launch_bounds__(256, 2) void stream8m_kernel(Stream8Args a) {
   }
   __syncthreads();
   // (as in stream8_kernel: a workgroup that gets here before k slots of a query have been filled by anyone waits for them - bounded)
-  for (int spin = 0; spin < 48; ++spin) {
-    refresh();
-    bool ready = true;
-    for (int q = wave; q < a.nq; q += 4) ready &= *reinterpret_cast<volatile int*>(&gkth_s[q]) != S8_EMPTY;
-    if (ready) break;
-    __builtin_amdgcn_s_sleep(16);
+  {
+    const int need = stream8_startup_need(a.k, a.slots);
+    int grace = 0;
+    for (int spin = 0; spin < 48; ++spin) {
+      int state = 2;   // (of this wavefront's queries: see stream8_kernel)
+      for (int q = wave; q < a.nq; q += 4) {
+        int gm, filled;
+        const int Tq = stream8_threshold_of(a.G + q * a.slots * S8_SLOT_STRIDE, a.k, a.qstat + q * 4, a.scal, a.metric, a.u, a.slack, lane, gm, a.slots, &filled);
+        if (lane == 0) {
+          *reinterpret_cast<volatile int*>(&T_s[q]) = Tq;
+          *reinterpret_cast<volatile int*>(&gkth_s[q]) = gm;
+        }
+        const int sq = gm == S8_EMPTY ? 0 : (filled >= need ? 2 : 1);
+        state = sq < state ? sq : state;
+      }
+      if (state == 2 || (state == 1 && ++grace > S8_STARTUP_GRACE)) break;
+      __builtin_amdgcn_s_sleep(16);
+    }
   }
   __syncthreads();
   if (first < a.n) test_block(first, acc);
