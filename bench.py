@@ -402,6 +402,43 @@ def config_c2(amd, torch, args, X, qlast, dev, stream, local_rank, cpu, graph_in
     if graph_index is not None:
         gpu["graph_T4_L500"], rg = latency(graph_index, mode=amd.MODE_GRAPH, intra_threads=4, master_queue=500, local_queue=500)
         gpu["graph_T4_L500"]["recall_at_10"] = recall_of(rg, gt1)
+
+    # r5 (late): the one-pass form beyond configs[1]'s own shape - k = 64 (128 table slots per query) and a compiled filter program (evaluated once per
+    # row into a bitset by one launch in front of the pass) - one query per call, each answer compared with the fp32 stream engine's under the same setting
+    def probe(kk, calls=100, check=10):
+        oo = (torch.empty((1, kk), dtype=torch.int64, device=dev), torch.empty((1, kk), dtype=torch.float32, device=dev), torch.empty((1,), dtype=torch.int32, device=dev))
+        rr = (torch.empty_like(oo[0]), torch.empty_like(oo[1]), torch.empty_like(oo[2]))
+        for i in range(3):
+            ix.search(qlast[i:i + 1], kk, out=oo, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
+        torch.cuda.synchronize()
+        lat, one, same = [], 0, 0
+        for i in range(calls):
+            t0 = time.perf_counter()
+            ix.search(qlast[i:i + 1], kk, out=oo, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t0)
+            one += int(ix.stats().get("one_pass", 0))
+            if i < check:
+                ix.search(qlast[i:i + 1], kk, out=rr, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
+                torch.cuda.synchronize()
+                same += int(torch.equal(oo[0], rr[0]) and torch.equal(oo[1], rr[1]))
+        return {"k": kk, "p50_ms": 1e3 * float(np.median(lat)), "p99_ms": 1e3 * float(np.percentile(lat, 99)), "queries": calls, "one_pass_calls": one,
+                "answers_equal_to_the_stream_engine": "%d of %d" % (same, check)}
+    try:
+        wide = {"what": "one query per call on the one-pass form beyond k <= 16 / no filter program (r5); p50 issue -> sync, inputs in HBM"}
+        wide["k64"] = probe(64)
+        attr = torch.arange(n1, dtype=torch.int32, device=dev).view(torch.uint8).reshape(n1, 4)
+        ix.set_filter_program([("i32", 0), ("const", 3), ("%",), ("const", 1), ("=",)], attr, stride=4)
+        wide["filter_program_id_mod_3_eq_1_k%d" % k] = probe(k)
+        amd.set_tuning("EPS_S8_FILTER_PROGRAMS", "0")
+        try:
+            wide["filter_program_id_mod_3_eq_1_k%d_staged_chain" % k] = probe(k, calls=40, check=0)
+        finally:
+            amd.set_tuning("EPS_S8_FILTER_PROGRAMS", None)
+        ix.set_filter_program(None)
+        out["one_pass_widened"] = wide
+    except Exception as e:
+        out["one_pass_widened"] = {"failed": repr(e)}
     ix.close()
     exact = [v for v in gpu.values() if v["recall_at_10"] >= 0.999]
     out["gpu"] = gpu

@@ -166,7 +166,7 @@ typedef struct eps_search_stats {
   int64_t filter_rows_all;  /* rows those launches covered, summed (x main_kernel_queries = the call's matrix work)              */
   int64_t i8_folded;        /* 1: the 8-bit pass of this call ran with per-row margins folded into the rows' start values (a table whose rows differ: clamped / forced outlier rows; r4) */
   int64_t i8_declined;      /* 1: this call probed the 8-bit pass on this table, found its bound too loose for the data and ran the fp16 pass (r4) */
-  int64_t one_pass;         /* 1: a handful of queries (<= 4, k <= 16) answered by ONE streaming pass over the 8-bit mirror + one re-rank (stream8_kernel.hpp) instead of the staged filter chain (r4) */
+  int64_t one_pass;         /* 1: a handful of queries (<= 16, k <= 64; a deleted bitset, an int-column test or a compiled filter program) answered by ONE streaming pass over the 8-bit mirror + one re-rank (stream8_kernel.hpp) instead of the staged filter chain (r4) */
 } eps_search_stats;
 
 void eps_default_search_params(eps_search_params* p);
