@@ -326,7 +326,7 @@ int32_t eps_merge_topk_packed(const void* gathered, int64_t shard_stride_bytes, 
  * through both sides of each) or turn diagnostics on:
  *   EPS_DEBUG (stage log on stderr), EPS_TRV_PROF (traversal phase profile on stderr),
  *   EPS_TRV_PREFILTER 0|1 (8-bit lower-bound test of the traversal), EPS_TRV_VISITED bitmap|stamps, EPS_TRV_STAMP_START, EPS_TRV_WAVES 4|8|16, EPS_TRV_PER_CU, EPS_TRV_LDS_KB,
- *   EPS_FLAT_ONE_PASS 0|1, EPS_ONE_PASS_TIMED, EPS_S8_WG_PER_CU, EPS_S8_HOST_WORDS 0|1, EPS_S8_TWO_LAUNCHES 0|1, EPS_S8_MAX_Q 1..16, EPS_S8_MAX_K 1..64, EPS_S8_FILTER_PROGRAMS 0|1, EPS_HOST_STAGING 0|1, EPS_RERANK_SPLIT, EPS_MFMA_BITS 8|16, EPS_MFMA_MAX_BATCH,
+ *   EPS_FLAT_ONE_PASS 0|1, EPS_ONE_PASS_TIMED, EPS_S8_WG_PER_CU, EPS_S8_HOST_WORDS 0|1, EPS_S8_TWO_LAUNCHES 0|1, EPS_S8_MAX_Q 1..16, EPS_S8_MAX_K 1..64, EPS_S8_FILTER_PROGRAMS 0|1, EPS_S8_RERANK 0|1, EPS_HOST_STAGING 0|1, EPS_RERANK_SPLIT, EPS_MFMA_BITS 8|16, EPS_MFMA_MAX_BATCH,
  *   EPS_MFMA_PROBE, EPS_MFMA_SEED, EPS_MFMA_GROUPSYNC, EPS_MFMA_SYNC_SHIFT, EPS_MFMA_STAGES, EPS_MFMA_KERNEL, EPS_MFMA_NARROW,
  *   EPS_MFMA_TWO_PER_CU, EPS_MFMA_FOLD, EPS_MFMA_MANTISSA, EPS_BUILD_BLOCK, EPS_BUILD_VISITED, EPS_BUILD_PREFILTER.
  * Switches that make answers WRONG on purpose (kernel ablations for profiling) exist only in a lab build (-DEPS_LAB), which

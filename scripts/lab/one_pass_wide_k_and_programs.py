@@ -60,4 +60,15 @@ for what, prog in (("no filter", None), ("filter program  id %% 3 = 1", [("i32",
                     amd.set_tuning(a, None)
                 line.append("%s %.3f (%d, %d)" % (name, ms, one, rr))
             print("%-28s k %2d  queries %2d:  %s" % (what, k, nq, "   ".join(line)), flush=True)
+ix.set_filter_program(None)
+print("the call's tail: s8_rerank_kernel (default) against rerank_kernel with the selection prologue (EPS_S8_RERANK=0), p50 ms per call")
+for k in (10, 64):
+    for nq in (1, 2, 4, 8, 16):
+        line = []
+        for name, v in (("s8_rerank", None), ("rerank", "0"), ("s8_rerank", None), ("rerank", "0")):
+            amd.set_tuning("EPS_S8_RERANK", v)
+            ms, one, rr = p50(nq, k)
+            line.append("%s %.3f" % (name, ms))
+        amd.set_tuning("EPS_S8_RERANK", None)
+        print("k %2d  queries %2d:  %s" % (k, nq, "   ".join(line)), flush=True)
 ix.close()

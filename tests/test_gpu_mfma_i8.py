@@ -182,6 +182,32 @@ def test_one_to_sixteen_queries_are_one_pass_over_the_mirror(amd, oracle, monkey
     ix.close()
 
 
+@pytest.mark.parametrize("metric", [0, 2])
+def test_one_pass_tail_on_rows_that_are_not_a_multiple_of_four_floats(amd, metric):
+    """r5 (late): the one-pass call's own re-rank (s8_rerank_kernel: flat selection through LDS, every piece of a row in flight at once, the k
+    best by rank) in its scalar-load form - d = 333: rows are not 16-byte multiples - against the stream engine; k up
+    to 64, a run of identical rows (equal distances: ordered by id), EPS_S8_RERANK=0 (rerank_kernel with the selection prologue) the same bits."""
+    n, d = 70_001, 333
+    X, Q = data(n, d, 77), data(16, d, 78)
+    X[3000:3030] = X[2999]
+    Q[0] = X[3010]
+    ix = amd.GpuIndex(d, metric)
+    ix.attach_rows(X)
+    for nq in (1, 2, 5, 16):
+        for k in (1, 10, 40, 64):
+            want = ix.search(Q[:nq], k, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
+            a = ix.search(Q[:nq], k, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
+            assert ix.stats()["one_pass"] == 1 or metric != 0, (nq, k)
+            same(a, want, "d 333 nq %d k %d" % (nq, k))
+            os.environ["EPS_S8_RERANK"] = "0"
+            try:
+                b = ix.search(Q[:nq], k, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
+            finally:
+                del os.environ["EPS_S8_RERANK"]
+            same(b, want, "d 333 nq %d k %d (rerank_kernel)" % (nq, k))
+    ix.close()
+
+
 def test_filter_programs_take_the_one_pass_form_behind_a_mask(amd):
     """r5: a call under a compiled filter program (packed attribute rows {i32 id; f32 price; u8 flag; pad; f64 w}) is the one-pass search too:
     filter_mask_kernel evaluates the predicate once per row (with the deleted bitset) into a bitset, pass and re-rank read that.  Against numpy
@@ -241,10 +267,12 @@ def test_filter_programs_take_the_one_pass_form_behind_a_mask(amd):
     ix.close()
 
 
-@pytest.mark.parametrize("switches", [{}, {"EPS_S8_TWO_LAUNCHES": "0"}, {"EPS_S8_HOST_WORDS": "0"}, {"EPS_HOST_STAGING": "0"}])
+@pytest.mark.parametrize("switches", [{}, {"EPS_S8_TWO_LAUNCHES": "0"}, {"EPS_S8_HOST_WORDS": "0"}, {"EPS_HOST_STAGING": "0"}, {"EPS_S8_RERANK": "0"},
+                                      {"EPS_S8_RERANK": "0", "EPS_S8_TWO_LAUNCHES": "0"}])
 def test_one_pass_call_forms_return_the_same_bits(amd, monkeypatch, switches):
     """r5: a one-pass call is two launches (the pass quantises its queries itself, the re-rank leaves table and counters clean for the next call) and
-    its two result counters reach the host through host-mapped words; host-pointer calls get their results in one page-locked copy.  Every form
+    its two result counters reach the host through host-mapped words; host-pointer calls get their results in one page-locked copy; the call's tail is
+    s8_rerank_kernel (r5, late; EPS_S8_RERANK=0: rerank_kernel with the selection prologue).  Every form
     against the stream engine, over calls that alternate query counts (1, 2 take the two-launch form, 3, 4 the prep launch), k, a staged-chain call
     in between (it uses the same counter block) and host / device pointers."""
     import torch

@@ -356,6 +356,184 @@ __global__ __launch_bounds__(NW * 64) void rerank_kernel(RerankArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The re-rank of a ONE-PASS call (stream8_kernel.hpp; r5, late): the same result as rerank_kernel with s8_G set - selection against the final
+// table, exact fp32 distances of the survivors, the k best by (distance, id), the call's bookkeeping - laid out for what this launch is: the tail
+// of a 0.18 ms call, one workgroup per query, 50-500 candidates.  rerank_kernel spent ~25 us there (83 us at k = 64) of which little was
+// memory time: a chain of waits (query to LDS | table -> threshold | list counts | list entries | candidates through global memory | a
+// row's three 16-byte pieces per lane one round trip after the other | 15 per-wavefront lists merged one entry at a time).  Here
+//  * everything that does not depend on the threshold is in flight before it is computed (the query, the lists' counts);
+//  * the survivors' ids stay in LDS;
+//  * a row's pieces are all issued before the first is used (row_dists<.., NL = 3>: the fmas run in the same order, the sums are the
+//    stream engine's bit for bit);
+//  * the k best are found by RANK: every key is compared with every other (LDS broadcast reads), a key of rank r < k goes to slot r.  Keys are
+//    unique ((distance, row) with every row in exactly one list), so the ranks are a permutation.
+// Up to S8R_CAP survivors per query (more: the overflow counter, i.e. the staged chain repeats the call - as with `cap` before).
+constexpr int S8R_CAP = 4096, S8R_SRC = 2 * S8R_CAP;   // (survivors per query; raw list entries per query: more than that is a call for the staged chain)
+template <bool VEC4>
+__global__ __launch_bounds__(1024) void s8_rerank_kernel(RerankArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [qstride] query, then u64 keys[S8R_CAP]
+  constexpr int NT = 1024, NW = 16, U = 4;   // (U x NL = 12 pieces of 16 bytes per lane in flight; 98 registers of the 128 that 1024 threads leave each)
+  __shared__ u32 ids_s[S8R_CAP];
+  __shared__ u64 best_s[64];
+  __shared__ u32 kept_s, lost_s, wtot_s[16];
+  __shared__ int T_s;
+  const int dim = a.dim;
+  const int qstride = (dim + 3) & ~3;
+  u64* keys_s = reinterpret_cast<u64*>(smem + qstride);
+  const int64_t q = blockIdx.x;
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  // ---- in flight before the threshold exists: the query, this thread's share of the lists' counts (<= S8_MAX_WAVES / NT = 8 lists)
+  const float q0v = (int)threadIdx.x < dim ? a.queries[q * dim + threadIdx.x] : 0.f;
+  const u32* counts = a.s8_counts + q * (int64_t)a.s8_waves;
+  const u64* lists = a.s8_lists + q * (int64_t)a.s8_waves * S8_WAVE_CAP;
+  u32 have[S8_MAX_WAVES / NT];
+#pragma unroll
+  for (int j = 0; j < S8_MAX_WAVES / NT; ++j) {
+    const int w = (int)threadIdx.x + j * NT;
+    have[j] = w < a.s8_waves ? counts[w] : 0u;
+  }
+  if (threadIdx.x == 0) kept_s = lost_s = 0;
+  if (threadIdx.x < 64) best_s[threadIdx.x] = KEY_EMPTY;
+  // this thread's lists laid end to end: where its entries start in the flat order of all raw entries (block-wide exclusive scan)
+  u32 mine_n = 0;
+  bool lost = false;
+#pragma unroll
+  for (int j = 0; j < S8_MAX_WAVES / NT; ++j) {
+    lost |= have[j] > (u32)S8_WAVE_CAP;
+    have[j] = have[j] < (u32)S8_WAVE_CAP ? have[j] : (u32)S8_WAVE_CAP;
+    mine_n += have[j];
+  }
+  u32 incl = mine_n;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const u32 v = __shfl_up(incl, o);
+    incl += lane >= o ? v : 0u;
+  }
+  if (lane == 63) wtot_s[wave] = incl;
+  if (wave == 0) {
+    int gk;
+    const int T = stream8_threshold_of(a.s8_G + q * (a.s8_slots * S8_SLOT_STRIDE), a.k, a.qstat + q * 4, a.scal, a.metric, a.u, a.slack, lane, gk, a.s8_slots);
+    if (lane == 0) T_s = T;
+  }
+  if ((int)threadIdx.x < qstride) smem[threadIdx.x] = q0v;
+  for (int i = threadIdx.x + NT; i < qstride; i += NT) smem[i] = i < dim ? a.queries[q * dim + i] : 0.f;
+  __syncthreads();
+  // ---- selection, flat: one LDS word per raw entry says where it lives, then every entry is ONE independent load (a thread walking its own list
+  // pays a memory round trip per entry - the lists of a k = 64 call hold up to ~20)
+  u32* src_s = reinterpret_cast<u32*>(keys_s);   // (S8R_SRC words: the keys' space, not yet in use)
+  u32 total_raw = 0, off = incl - mine_n;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    const u32 tw = wtot_s[w];
+    total_raw += tw;
+    off += w < wave ? tw : 0u;
+  }
+  if (lost || total_raw > (u32)S8R_SRC) lost_s = 1;
+#pragma unroll
+  for (int j = 0; j < S8_MAX_WAVES / NT; ++j) {
+    const u32 w = threadIdx.x + (u32)j * NT;
+    for (u32 i = 0; i < have[j]; ++i, ++off)
+      if (off < (u32)S8R_SRC) src_s[off] = w * (u32)S8_WAVE_CAP + i;
+  }
+  __syncthreads();
+  const int T = T_s;
+  total_raw = total_raw < (u32)S8R_SRC ? total_raw : (u32)S8R_SRC;
+  for (u32 e0 = threadIdx.x; e0 < total_raw; e0 += NT) {
+    const u64 e = lists[src_s[e0]];
+    if ((int)(u32)(e >> 32) >= T) {
+      const u32 slot = atomicAdd(&kept_s, 1u);
+      if (slot < (u32)S8R_CAP) ids_s[slot] = (u32)e;
+    }
+  }
+  __syncthreads();
+  if (a.s8_reset && (int)threadIdx.x < a.s8_slots)   // (the table has been read: the next call finds it empty)
+    const_cast<int*>(a.s8_G)[(q * a.s8_slots + threadIdx.x) * S8_SLOT_STRIDE] = S8_EMPTY;
+  const u32 cnt_raw = kept_s;
+  const u32 cnt = cnt_raw < (u32)S8R_CAP ? cnt_raw : (u32)S8R_CAP;
+  // ---- exact fp32 distances: G lanes per row, U rows per wavefront in flight, every piece of a row issued at once
+  const int G = group_lanes(dim, VEC4);
+  const int RPW = 64 / G;
+  const int g = lane / G;
+  const int t = lane & (G - 1);
+  for (u32 c0 = wave * RPW * U; c0 < cnt; c0 += NW * RPW * U) {
+    const float* rp[U];
+    u32 id[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const u32 ci = c0 + u * RPW + g;
+      ok[u] = ci < cnt;
+      id[u] = ids_s[ok[u] ? ci : cnt - 1];
+      rp[u] = a.rows + (int64_t)id[u] * dim;
+    }
+    float acc[U][1];
+    row_dists<U, 1, VEC4, 3>(rp, smem, qstride, dim, a.metric, G, acc);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (ok[u] && t == 0) {
+        const float dist = finish_dist(a.metric, acc[u][0]);
+        keys_s[c0 + u * RPW + g] = row_visible(a.f, id[u], dist) ? make_key(dist, id[u]) : KEY_EMPTY;   // (rows the filter hides sort last)
+      }
+    }
+  }
+  if (threadIdx.x < 8 && cnt + threadIdx.x < ((cnt + 7u) & ~7u)) keys_s[cnt + threadIdx.x] = KEY_EMPTY;
+  __syncthreads();
+  // ---- the k best by rank (8 keys per step, no early exit: the LDS reads of a step are independent - one latency per 8 keys, not per key)
+  for (u32 ci = threadIdx.x; ci < cnt; ci += NT) {
+    const u64 mine = keys_s[ci];
+    if (mine == KEY_EMPTY) continue;
+    int rank = 0;
+    for (u32 j0 = 0; j0 < cnt; j0 += 8) {
+#pragma unroll
+      for (u32 jj = 0; jj < 8; ++jj) {
+        const u64 o = keys_s[j0 + jj];   // (padded with KEY_EMPTY up to a multiple of 8)
+        rank += (o < mine || (o == mine && j0 + jj < ci)) ? 1 : 0;
+      }
+    }
+    if (rank < a.k) best_s[rank] = mine;
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  // ---- the query's result and the call's bookkeeping (rerank_kernel's, KPL = 1)
+  const u64 key = lane < a.k ? best_s[lane] : KEY_EMPTY;
+  if (lane < a.k) a.run_keys[q * a.k + lane] = key;
+  const bool valid = lane < a.k && key != KEY_EMPTY;
+  if (a.fin_ids) {
+    if (lane < a.k) {
+      a.fin_ids[q * a.k + lane] = valid ? (int64_t)key_id(key) * a.fin_stride + a.fin_base : -1;
+      a.fin_dist[q * a.k + lane] = valid ? key_dist(key) : __builtin_inff();
+    }
+    const int c = __popcll(__ballot(valid));
+    if (a.fin_counts && lane == 0) a.fin_counts[q] = c;
+  }
+  if (lane == 0) {
+    if (lost_s) atomicAdd(a.overflow, 1u);   // a wavefront's list lost entries: the caller repeats the batch on the staged chain
+    if (a.fuse & 1) {
+      if (cnt_raw > (u32)S8R_CAP || cnt_raw > (u32)a.cap) atomicAdd(a.overflow, 1u);
+      atomicAdd(a.total, (unsigned long long)cnt);
+    }
+    a.cand_count[q] = 0;
+    if (a.pub) {   // (lane 0 of wavefront 0 issued every one of this block's counter updates above)
+      __threadfence();
+      if (atomicAdd(a.pub_ticket, 1u) == gridDim.x - 1) {
+        const u32 ov = atomicAdd(a.overflow, 0u);
+        const unsigned long long tot = atomicAdd(a.total, 0ull);
+        a.pub[0] = ov;
+        a.pub[2] = (u32)tot;
+        a.pub[3] = (u32)(tot >> 32);
+        __threadfence_system();
+        if (a.s8_reset) {   // (every block has finished with the counters: each took its ticket after its last update)
+          *a.overflow = 0u;
+          *a.total = 0ull;
+          *a.pub_ticket = 0u;
+        }
+      }
+    }
+  }
+}
+
 // the same over several workgroups per query (RerankArgs::parts): blockIdx.x = q * parts + part
 template <int KPL, bool VEC4>
 __global__ __launch_bounds__(256) void rerank_split_kernel(RerankArgs a) {
@@ -482,6 +660,13 @@ __global__ __launch_bounds__(256) void rerank_split_kernel(RerankArgs a) {
 
 void launch_rerank(const RerankArgs& a, hipStream_t s) {
   if (a.nq <= 0) return;
+  if (a.s8_G && a.s8_fast && pick_kpl(a.k) == 1 && a.s8_waves <= S8_MAX_WAVES && !a.T_next && !a.gsync) {   // a one-pass call's tail
+    const bool v4 = (a.dim % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.rows) & 15) == 0);
+    const size_t sm = (size_t)((a.dim + 3) & ~3) * sizeof(float) + (size_t)S8R_CAP * sizeof(u64);
+    if (v4) hipLaunchKernelGGL((s8_rerank_kernel<true>), dim3((unsigned)a.nq), dim3(1024), sm, s, a);
+    else hipLaunchKernelGGL((s8_rerank_kernel<false>), dim3((unsigned)a.nq), dim3(1024), sm, s, a);
+    return;
+  }
   if (a.parts > 1 && a.part_keys && a.part_done && pick_kpl(a.k) <= 2) {
     const bool v4 = (a.dim % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.rows) & 15) == 0);
     const int kp = pick_kpl(a.k);

@@ -87,6 +87,7 @@ struct RerankArgs {
   // caller needs no device-to-host copy after the launch (a copy is a trip through the DMA queue at the end of a 0.2 ms call)
   u32* pub = nullptr;               // host-mapped [4], or null
   u32* pub_ticket = nullptr;        // device word, zero at launch
+  int s8_fast = 0;                  // 1: s8_rerank_kernel (r5, late: the one-pass call's own re-rank); 0: rerank_kernel's s8 prologue (A/B)
   int s8_reset = 0;                 // 1: the launch leaves the one-pass state as the next call needs it (table slots empty, counters zero): no prep launch then
 };
 void launch_rerank(const RerankArgs& a, hipStream_t s);

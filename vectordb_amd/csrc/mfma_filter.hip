@@ -1162,6 +1162,7 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
   ra.gsync = nullptr;
   ra.s8_G = a.G;                 // (the launch selects its candidates from the pass's lists first)
   ra.s8_slots = slots;
+  ra.s8_fast = !(tune_env("EPS_S8_RERANK") && atoi(tune_env("EPS_S8_RERANK")) == 0);   // (A/B switch: 0 = rerank_kernel with the selection prologue, as until r5)
   ra.s8_counts = a.raw_cnt;
   ra.s8_lists = a.raw;
   ra.s8_waves = a.waves;
