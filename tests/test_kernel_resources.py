@@ -84,3 +84,33 @@ def test_traversal_kernel_keeps_four_waves_per_simd(tmp_path):
         # (float4 rows, 4 wavefronts, queues in LDS), at most 21 in the forms with the queues in HBM / scalar row loads
         hot = k.startswith("_ZN3eps16traverse2_kernelILb1ELi4ELb0ELb1E")
         assert u["ScratchSize [bytes/lane]"] <= ((48 if hot else 96) if with_prefilter else 0), (k, u)
+
+
+@pytest.mark.skipif(not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")), reason="needs hipcc")
+def test_one_pass_tail_kernel_fits_a_full_workgroup(tmp_path):
+    """s8_rerank_kernel (r5) is launched with 1024 threads per workgroup - 128 registers per lane at most - and keeps 12 pieces of 16 bytes per lane
+    in flight (every piece of four rows at once): no scratch, and its LDS (ids, keys, the query, the rank slots) stays under the 64 KB a workgroup
+    gets by default.  The re-rank kernels the batched stages use (KPL = 1, 2) stay free of scratch as well."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-I" + os.path.join(ROOT, "include"),
+                        "-c", os.path.join(ROOT, "vectordb_amd", "csrc", "flat_kernels.hip"), "-o", str(tmp_path / "fk.o"),
+                        "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    usage, name = {}, None
+    for line in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            usage[name] = {}
+        m = re.search(r"(VGPRs|ScratchSize \[bytes/lane\]|LDS Size \[bytes/block\]): (\d+)", line)
+        if m and name:
+            usage[name][m.group(1)] = int(m.group(2))
+    tail = {k: v for k, v in usage.items() if "s8_rerank_kernel" in k}
+    assert len(tail) == 2, list(usage)
+    for k, u in tail.items():
+        assert u["ScratchSize [bytes/lane]"] == 0 and u["VGPRs"] <= 128, (k, u)
+        # static LDS (ids + rank slots + counters) + the dynamic part the launch asks for: the query (<= 4 KB at d <= 1024) + 4096 keys of 8 bytes
+        assert u["LDS Size [bytes/block]"] + 4096 + 4096 * 8 <= 65536, (k, u)
+    for k, u in usage.items():
+        if ("rerank_kernelILi1ELb1E" in k or "rerank_kernelILi2ELb1E" in k or "rerank_split_kernel" in k):
+            assert u["ScratchSize [bytes/lane]"] == 0, (k, u)
