@@ -130,7 +130,7 @@ __device__ __forceinline__ int stream8_threshold_of(const int* G, int k, const f
 // offers.  "Enough" was k filled slots until r5 - but the k-th largest of EXACTLY k filled slots is the WORST row offered so far, and once in
 // a few thousand calls that is a below-median row: a workgroup that read the table at that moment let most of its rows through, and on a
 // small table (90 000 rows = 3 chunks per wavefront, no refresh in time) a 32-entry list overflowed and the staged chain had to repeat the
-// call (found by scripts/lab/dbg_wide2.py: 1 call in 5040, "37 in one wavefront's list of 32").  Now: max(2 k, k + 8) filled slots (capped at
+// call (found by scripts/lab/one_pass_small_table_stress.py: 1 call in 5040, "37 in one wavefront's list of 32").  Now: max(2 k, k + 8) filled slots (capped at
 // 7/8 of the table: a third of the rows visible leaves a slot or two of 128 empty for good) - the k-th largest of twice as many offers is a
 // median offer, not the worst - and when k are there but the rest does not come (a filter that leaves few rows visible) three more looks,
 // then the wavefront takes what there is.
