@@ -383,3 +383,41 @@ def test_one_pass_table_never_loses_a_row_of_the_answer(metric, k):
         # (the table's threshold carries the margin twice - once up to the bound, once down to the test; on this toy table of normalised
         # 96-d rows the margin is most of the spread of the distances, so only the L2 case is held to a number)
         assert metric != 0 or passed <= 4 * best + 40 * k + 60, (metric, k, qk, passed, best)
+
+
+@pytest.mark.parametrize("k,slots", [(10, 64), (16, 64), (40, 128), (64, 128)])
+def test_start_up_wait_reads_a_median_offer_not_the_worst(k, slots):
+    """Why a workgroup of the one-pass search waits for max(2k, k + 8) filled table slots (capped at 7/8 of the table) before it reads its first
+    thresholds (stream8_startup_need, csrc/stream8_kernel.hpp), not for k: every wavefront offers the best of its first 16 rows, the offers land in
+    hash slots in no particular order, and the threshold is the k-th largest slot.  With EXACTLY k slots filled that is the worst row offered so far -
+    once in a few thousand calls a below-median row of the table, which lets most of a small table through (the stress loop that found it:
+    scripts/lab/one_pass_small_table_stress.py).  Simulated here: the quantile (0 = the best row of the table) of the row the first read would
+    take for the k-th best, over 4000 start-ups."""
+    rng = np.random.default_rng(k * 1000 + slots)
+    want = max(2 * k, k + 8)
+    need = min(want, slots - slots // 8)
+    assert k <= need <= slots
+    worst_old, worst_new = 0.0, 0.0
+    at_old, at_new = [], []
+    for trial in range(4000):
+        n_off = 2048
+        quant = rng.random((n_off, 16)).min(axis=1)          # the best of 16 rows, as a quantile of the table
+        slot = rng.integers(0, slots, n_off)
+        table = np.full(slots, np.inf)
+        filled = 0
+        seen_old = None
+        for i in range(n_off):
+            if table[slot[i]] == np.inf:
+                filled += 1
+            table[slot[i]] = min(table[slot[i]], quant[i])
+            if seen_old is None and filled >= k:
+                seen_old = np.sort(table)[k - 1]
+            if filled >= need:
+                at_new.append(np.sort(table)[k - 1])
+                break
+        at_old.append(seen_old)
+    at_old, at_new = np.array(at_old), np.array(at_new)
+    # the old rule's tail reaches rows a third of the way down the table and further; the new rule's stays in the best tenth, every time
+    assert at_old.max() > 0.3, at_old.max()
+    assert at_new.max() < 0.12, at_new.max()
+    assert np.median(at_new) < 0.5 * np.median(at_old)
