@@ -154,12 +154,13 @@ def test_one_to_sixteen_queries_are_one_pass_over_the_mirror(amd, oracle, monkey
                 for rep in range(2):
                     a = ix.search(Q[:nq], k, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
                     st = ix.stats()
-                    assert (st["main_kernel_bits"], st["overflow_queries"]) == (8, 0), (setup, nq, k, st)
                     # (k <= 16: always the one-pass form here.  Larger k passes more rows against the same candidate lists: on the BASELINE's shape -
                     # L2 - it must be the one-pass form as well; where the bound is loose against the spread - normalised rows - a call may hand over
-                    # to the staged chain, which must not cost the small-k calls after it their one-pass form)
+                    # to the staged chain (whose own lists may overflow into the fp16 pass: exact either way, checked below), which must not cost
+                    # the small-k calls after it their one-pass form)
                     assert st["one_pass"] == 1 or (k > 16 and metric != 0), (setup, nq, k, st)
                     if st["one_pass"]:
+                        assert (st["main_kernel_bits"], st["overflow_queries"]) == (8, 0), (setup, nq, k, st)
                         assert st["rerank_rows"] < nq * (2000 if k <= 16 else 4096), st     # the junk of the first microseconds is dropped before any row is read
                     same(a, ix.search(Q[:nq], k, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM), "%s nq %d k %d" % (setup, nq, k))
         a = ix.search(Q[:2], 65, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
