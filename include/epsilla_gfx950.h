@@ -167,6 +167,7 @@ typedef struct eps_search_stats {
   int64_t i8_folded;        /* 1: the 8-bit pass of this call ran with per-row margins folded into the rows' start values (a table whose rows differ: clamped / forced outlier rows; r4) */
   int64_t i8_declined;      /* 1: this call probed the 8-bit pass on this table, found its bound too loose for the data and ran the fp16 pass (r4) */
   int64_t one_pass;         /* 1: a handful of queries (<= 16, k <= 64; a deleted bitset, an int-column test or a compiled filter program) answered by ONE streaming pass over the 8-bit mirror + one re-rank (stream8_kernel.hpp) instead of the staged filter chain (r4) */
+  int64_t i8_rotated;       /* 1: the 8-bit pass of this call ran in the table's ROTATED frame: rows and queries quantised as R x, R a fixed orthogonal map (signs, a permutation, 256-point Walsh-Hadamard blocks) - distances do not change, the grid's step and with it the bound's margin shrink on tables whose energy sits in a few columns (unit-norm embedding rows); chosen per table when its mirror is built (r6) */
 } eps_search_stats;
 
 void eps_default_search_params(eps_search_params* p);
@@ -328,7 +329,8 @@ int32_t eps_merge_topk_packed(const void* gathered, int64_t shard_stride_bytes, 
  *   EPS_TRV_PREFILTER 0|1 (8-bit lower-bound test of the traversal), EPS_TRV_VISITED bitmap|stamps, EPS_TRV_STAMP_START, EPS_TRV_WAVES 4|8|16, EPS_TRV_PER_CU, EPS_TRV_LDS_KB,
  *   EPS_FLAT_ONE_PASS 0|1, EPS_ONE_PASS_TIMED, EPS_S8_WG_PER_CU, EPS_S8_HOST_WORDS 0|1, EPS_S8_TWO_LAUNCHES 0|1, EPS_S8_MAX_Q 1..16, EPS_S8_MAX_K 1..64, EPS_S8_FILTER_PROGRAMS 0|1, EPS_S8_RERANK 0|1, EPS_HOST_STAGING 0|1, EPS_RERANK_SPLIT, EPS_MFMA_BITS 8|16, EPS_MFMA_MAX_BATCH,
  *   EPS_MFMA_PROBE, EPS_MFMA_SEED, EPS_MFMA_GROUPSYNC, EPS_MFMA_SYNC_SHIFT, EPS_MFMA_STAGES, EPS_MFMA_KERNEL, EPS_MFMA_NARROW,
- *   EPS_MFMA_TWO_PER_CU, EPS_MFMA_FOLD, EPS_MFMA_MANTISSA, EPS_BUILD_BLOCK, EPS_BUILD_VISITED, EPS_BUILD_PREFILTER.
+ *   EPS_MFMA_TWO_PER_CU, EPS_MFMA_FOLD, EPS_MFMA_MANTISSA, EPS_BUILD_BLOCK, EPS_BUILD_VISITED, EPS_BUILD_PREFILTER,
+ *   EPS_MIRROR_ROTATE 0|1 (frame of the 8-bit grid: identity | rotated; unset = chosen per table when its mirror is first built; read at that moment only).
  * Switches that make answers WRONG on purpose (kernel ablations for profiling) exist only in a lab build (-DEPS_LAB), which
  * also falls back to the environment for names the table does not hold.  Returns EPS_OK. */
 int32_t eps_set_tuning(const char* name, const char* value);

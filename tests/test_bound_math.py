@@ -421,3 +421,189 @@ def test_start_up_wait_reads_a_median_offer_not_the_worst(k, slots):
     assert at_old.max() > 0.3, at_old.max()
     assert at_new.max() < 0.12, at_new.max()
     assert np.median(at_new) < 0.5 * np.median(at_old)
+
+
+# ------------------------------------------------------------------------------------------------ r6: the grid in a rotated frame
+# (device_common.hpp rot256_load, mfma_filter.hip ensure_mirror8).  Rows and queries are quantised as y = R x, R = blockdiag(H_256 / 16) . S . P
+# (a fixed permutation of the zero-padded columns, signs, a 256-point Walsh-Hadamard transform per 256-column block): R is exactly orthogonal,
+# distances do not change, and every y column is a signed mean of 256 values of the row - no column dominates, the step shrinks to what the
+# row's norm needs.  The transform runs in fp64, y - mu is rounded to fp32 once.
+def d_pad8_of(d):
+    return max(512, (d + 255) // 256 * 256)
+
+
+def rotation_table(d_pad8):
+    """the library's fixed sequence (splitmix64 seeded with the width): source column of every rotated-input position, and its sign"""
+    M = (1 << 64) - 1
+    st = [0x9E3779B97F4A7C15 ^ d_pad8]
+
+    def nxt():
+        st[0] = (st[0] + 0x9E3779B97F4A7C15) & M
+        z = st[0]
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        return z ^ (z >> 31)
+    sp = list(range(d_pad8))
+    for i in range(d_pad8 - 1, 0, -1):
+        j = nxt() % (i + 1)
+        sp[i], sp[j] = sp[j], sp[i]
+    neg = [bool(nxt() & 1) for _ in range(d_pad8)]
+    return np.array(sp), np.array(neg)
+
+
+def rotate_rows(X):
+    """fp64 image R x of every row, [n][d_pad8]: the butterflies in the kernel's order (two levels inside a lane's four values, six across lanes)"""
+    n, d = X.shape
+    dp = d_pad8_of(d)
+    src, neg = rotation_table(dp)
+    Z = np.zeros((n, dp), np.float64)
+    Z[:, :d] = X
+    Y = Z[:, src] * np.where(neg, -1.0, 1.0)
+    Y = Y.reshape(n, dp // 256, 256)
+    h = 1
+    while h < 256:
+        Y = Y.reshape(n, dp // 256, 256 // (2 * h), 2, h)
+        Y = np.stack([Y[:, :, :, 0, :] + Y[:, :, :, 1, :], Y[:, :, :, 0, :] - Y[:, :, :, 1, :]], axis=3)
+        Y = Y.reshape(n, dp // 256, 256)
+        h *= 2
+    return (Y * 0.0625).reshape(n, dp)
+
+
+def mirror_rot(X, metric, mu=None, step=None):
+    """mirror() in the rotated frame: x' = fl32(R x - mu) (ONE rounding), everything else as before; + 1e-12 |x| for the fp64 transform"""
+    Y = rotate_rows(X)
+    Y32 = Y.astype(F)
+    if mu is None:
+        mu, half = col_centre(Y32)
+        if step is None:
+            step = half / F(127.0)
+    xc = (Y - mu.astype(np.float64)).astype(F)
+    inv = F(1.0) / step
+    xi = np.clip(np.rint(xc * inv), -127, 127).astype(np.int32)
+    res = (xc - step * xi.astype(F)).astype(F)
+    xh = (step * xi.astype(F)).astype(F)
+    s = F(2.0) if metric == 0 else F(1.0)
+    u = s * step * step
+    x2c = (xc * xc).sum(1, dtype=F)
+    R = x2c if metric == 0 else -(mu * xc).sum(1, dtype=F)
+    a0 = np.ceil(-R / u) + 1
+    xn = (Y32 * Y32).sum(1, dtype=F)
+    erow = (np.sqrt((res * res).sum(1, dtype=F)) * F(1.00001) + F(1.2e-7) * np.sqrt(x2c) + F(1e-12) * np.sqrt(xn)).astype(F)
+    hrow = (np.sqrt((xh * xh).sum(1, dtype=F)) * F(1.00001)).astype(F)
+    forced = ~(np.abs(a0) < 536870912.0)
+    acc0 = np.where(forced, -(1 << 30), a0).astype(np.int64)
+    erow = np.where(forced, F(np.inf), erow).astype(F)
+    ok = ~forced
+    mx = lambda v: F(v[ok].max()) if ok.any() else F(0.0)
+    scal = dict(e1max=mx(erow), nxhmax=mx(hrow), xnmax=mx(xn), rmax=mx(np.abs(R)), mun=F(np.sqrt((mu * mu).sum(dtype=F)) * F(1.00001)))
+    scal["xcmax"] = F(scal["nxhmax"] + scal["e1max"])
+    return dict(mu=mu, step=step, inv=inv, xi=xi, acc0=acc0, u=u, s=s, scal=scal, erow=erow, hrow=hrow, forced=forced)
+
+
+def query_rot(q, m, metric):
+    y = rotate_rows(q[None, :])[0]
+    y32 = y.astype(F)
+    qc = (y - m["mu"].astype(np.float64)).astype(F)
+    qi = np.clip(np.rint(qc * m["inv"]), -127, 127).astype(np.int32)
+    res = (qc - m["step"] * qi.astype(F)).astype(F)
+    s2c = F((qc * qc).sum(dtype=F))
+    s2 = F((y32 * y32).sum(dtype=F))
+    qmu = F((y32 * m["mu"]).sum(dtype=F))
+    Cq = s2c if metric == 0 else ((F(1.0) - qmu) if metric == 1 else -qmu)
+    return qi, dict(qn2=s2, nq=F(np.sqrt(s2c) * F(1.000001)),
+                    eq=F(np.sqrt((res * res).sum(dtype=F)) * F(1.00001) + F(1.2e-7) * np.sqrt(s2c) + F(1e-12) * np.sqrt(s2)), Cq=F(Cq))
+
+
+def test_the_rotation_is_orthogonal_and_spreads_every_column():
+    rng = np.random.default_rng(21)
+    for d in (33, 256, 300, 768, 1000):
+        X = rng.standard_normal((40, d))
+        Y = rotate_rows(X)
+        assert Y.shape[1] == d_pad8_of(d)
+        assert np.allclose(Y @ Y.T, X @ X.T, rtol=0, atol=1e-11 * d)                # R^T R = I: every inner product survives
+        src, neg = rotation_table(d_pad8_of(d))
+        assert sorted(src.tolist()) == list(range(d_pad8_of(d))) and 0.3 < neg.mean() < 0.7
+        e = np.zeros((1, d))
+        e[0, d // 2] = 1.0                                                          # one column's energy lands on exactly one 256-block, evenly
+        y = rotate_rows(e)[0]
+        assert np.count_nonzero(y) == 256 and np.allclose(np.abs(y[y != 0]), 1.0 / 16.0)
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_rows_within_the_threshold_always_pass_the_8bit_test_in_the_rotated_frame(case, metric):
+    """the implication every user of the mirror relies on, for a table quantised in the rotated frame: same cases, same two forms of the test
+    (table-wide margin in the threshold; per-row margins folded into the start values), rows appended outside the grid included"""
+    rng = np.random.default_rng(abs(hash((case, metric, "rot"))) % (1 << 31))
+    n, d = 2500, 96
+    X = CASES[case](rng, n, d)
+    if metric == 1:
+        X /= np.linalg.norm(X, axis=1, keepdims=True)
+    m = mirror_rot(X, metric)
+    span = F(np.percentile(X, 99.9) - np.percentile(X, 0.1))
+    Xa = np.concatenate([X[:150] + F(0.2) * span * np.sign(rng.standard_normal((150, d))).astype(F), X[150:300]])
+    if metric == 1:
+        Xa /= np.linalg.norm(Xa, axis=1, keepdims=True)
+    rows2 = np.concatenate([X, Xa])
+    m2 = mirror_rot(rows2, metric, mu=m["mu"], step=m["step"])
+    slack = slack_of(d_pad8_of(d))
+    if m["forced"].mean() > 0.01:
+        pytest.skip("row constants beyond int32: no 8-bit mirror for this table")
+    worst = 1 << 40
+    for mm, rows in ((m, X), (m2, rows2)):
+        per_q = []
+        for qk in range(9):
+            q = rows[rng.integers(len(rows))] + F(0.05) * rng.standard_normal(d).astype(F) if qk % 3 else CASES[case](rng, 1, d)[0] * F(3.0) - F(1.0)
+            if metric == 1:
+                q = q / np.linalg.norm(q)
+            q = q.astype(F)
+            per_q.append((q,) + query_rot(q, mm, metric))
+        acc0f = fold(mm, [qs for _, _, qs in per_q])
+        for q, qi, qs in per_q:
+            dd = dist(q, rows, metric)                    # the distance in the ORIGINAL frame, fp32: what the re-rank computes
+            dot = mm["xi"].astype(np.int64) @ qi.astype(np.int64)
+            for frac in (0.001, 0.02, 0.3):
+                thr = F(np.partition(dd, int(frac * len(dd)))[int(frac * len(dd))])
+                inside = dd <= thr
+                Tq = threshold(thr, qs, mm, metric, slack)
+                assert ((dot + mm["acc0"])[inside & ~mm["forced"]] >= Tq).all(), (case, metric, frac, "table-wide margin")
+                Tf = threshold(thr, qs, mm, metric, slack, folded=True)
+                assert ((dot + acc0f)[inside] >= Tf).all(), (case, metric, frac, "folded per-row margins")
+                worst = min(worst, int(((dot + acc0f)[inside] - Tf).min()))
+    assert worst >= 0
+
+
+def _embedding_like(rng, n, d):
+    scale = np.ones(d, F)
+    scale[:8] = 4.0
+    X = rng.standard_normal((n, d)).astype(F) * scale
+    return (X / np.linalg.norm(X, axis=1, keepdims=True)).astype(F)
+
+
+def test_the_rotated_frame_is_what_embedding_like_rows_need_and_uniform_rows_do_not():
+    """bench.py's embedding-like set (unit-norm rows, 8 dominant dimensions of 768), COSINE.  In the identity frame the dominant columns set
+    the step for all 768 and the margin equals the spread of the distances (r5: the fp16 pass served such tables at half the matrix rate); in
+    the rotated frame the step is a third, and an order of magnitude fewer rows survive the same threshold.  U[0,1) rows fill the identity
+    grid evenly: there the rotated frame's step is ~2.9 x LARGER.  The library's rule (rotated iff step_r sqrt(d_pad8) < 0.75 step_i sqrt(d))
+    separates the two."""
+    rng = np.random.default_rng(31)
+    n, d, k = 20_000, 768, 10
+    X = _embedding_like(rng, n, d)
+    Q = _embedding_like(rng, 6, d)
+    mi = mirror(X, 1)
+    mr = mirror_rot(X, 1)
+    assert mr["step"] * np.sqrt(d_pad8_of(d)) < 0.5 * mi["step"] * np.sqrt(d)
+    assert mr["erow"].mean() < 0.45 * mi["erow"].mean()
+    passed = {"identity": 0, "rotated": 0}
+    for q in Q:
+        dd = dist(q, X, 1)
+        thr = F(np.partition(dd, k - 1)[k - 1])
+        for name, mm, (qi, qs) in (("identity", mi, query(q, mi, 1)), ("rotated", mr, query_rot(q, mr, 1))):
+            lhs = mm["xi"].astype(np.int64) @ qi.astype(np.int64) + mm["acc0"]
+            Tq = threshold(thr, qs, mm, 1, slack_of(d))
+            assert (lhs[dd <= thr] >= Tq).all()
+            passed[name] += int((lhs >= Tq).sum())
+    assert passed["rotated"] * 5 < passed["identity"], passed
+    U = rng.random((4000, d), dtype=F)
+    ui, ur = mirror(U, 0), mirror_rot(U, 0)
+    assert ur["step"] * np.sqrt(d_pad8_of(d)) > 2.0 * ui["step"] * np.sqrt(d)

@@ -172,6 +172,50 @@ __device__ __forceinline__ int quant8(float x, float z, float inv_step) {
   t = fminf(fmaxf(t, -127.f), 127.f);   // (rows appended after the grid was fixed may lie outside it: clamped, the residual grows, the bound stays valid)
   return (int)t;
 }
+// ---- r6: the 8-bit grid in a ROTATED frame.  The Cauchy-Schwarz margin of the 8-bit bound is (step x sqrt(columns / 12)) x the query's norm:
+// one step for the whole table, so a few columns that carry most of a row's energy (unit-norm embedding rows: 8 dominant dimensions of 768)
+// stretch the grid for all the others and the margin reaches the spread of the distances themselves - the 8-bit pass cannot filter and the
+// fp16 pass serves the table at half the matrix rate.  L2, dot and cosine do not change under an orthogonal map of rows AND queries, so
+// such a table is quantised as y = R x, R = blockdiag(H_256 / 16) . S . P: a fixed permutation P of the d_pad8 (zero-padded) columns,
+// signs S, and a 256-point Walsh-Hadamard transform per 256-column block.  R's entries are +-1/16: R is EXACTLY orthogonal as a real
+// matrix, so q.x = (Rq).(Rx) is an identity, not an approximation.  Every rotated column is a signed mean of 256 of the row's values: the
+// columns all have the same spread, nothing dominates, and the step shrinks to what the row's norm needs (embedding-like rows: 0.36 x,
+// 14 x fewer survivors per query; U[0,1) rows, which fill the grid evenly as they are: 2.9 x WORSE - so the frame is chosen per table,
+// when the mirror is first built, from the two steps measured on the same sample: ensure_mirror8).
+// Arithmetic: the transform runs in fp64 (8 add levels: error <= 8 x 2^-53 x 16 |x_block| per column, i.e. <= 1.5e-14 |x| for the row) and
+// y - mu is rounded to fp32 ONCE - the rounding the identity frame's x - mu has, and that its residual norm already carries
+// (+ 1.2e-7 sqrt(c2)); the fp64 remainder is added as + 1e-12 |x|.  Restated in numpy in tests/test_bound_math.py (rotate_rows).
+// sp[p]: source column of rotated-input position p, bit 31 = negative sign; positions whose source is >= dim read 0.
+// One wavefront per row; lane l holds positions c .. c + 3, c = block * 256 + 4 l: two butterfly levels in the lane, six across lanes.
+__device__ __forceinline__ void rot256_load(const float* src, int dim, const int* sp, int c, int lane, double xd[4]) {
+  const int4 s4 = *reinterpret_cast<const int4*>(sp + c);
+  const int ss[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int col = ss[e] & 0x7FFFFFFF;
+    const float v = col < dim ? src[col] : 0.f;
+    xd[e] = (double)(ss[e] < 0 ? -v : v);
+  }
+  {
+    const double a = xd[0] + xd[1], b = xd[0] - xd[1], cc = xd[2] + xd[3], d = xd[2] - xd[3];
+    xd[0] = a + cc;
+    xd[1] = b + d;
+    xd[2] = a - cc;
+    xd[3] = b - d;
+  }
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const bool up = (lane & o) != 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const double other = __shfl_xor(xd[e], o);
+      xd[e] = up ? other - xd[e] : xd[e] + other;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) xd[e] *= 0.0625;
+}
+
 // int8 operands: T in accumulator units (int32): a row passes iff dot + acc0 >= T.  thr: a distance; qs: |q|^2, |q - mu|, |q' - qh'|, C[q]
 // (query_prep8_kernel); sc: max |x' - xh'|, max |xh'|, max |x|^2, -, max |R|, |mu| (quant_mirror_kernel).  Restated in numpy, with the
 // implication it must guarantee, in tests/test_bound_math.py.

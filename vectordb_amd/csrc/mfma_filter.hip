@@ -92,6 +92,11 @@ struct HalfMirror {
   float h_scal8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   DevBuf mu8;      // float [d_pad8]: the grid's centre, one value per column (zeros beyond dim)
   float step8 = 0.f;            // the grid: xh' = step8 * xi around mu8
+  // r6: the grid's frame (device_common.hpp, rot256_load): rot8 = rows and queries are quantised as R x; sp8 = int32 [d_pad8], R's
+  // permutation and signs.  Chosen on the first build from the steps the two frames need on the same sample; kept when rows are appended.
+  bool rot8 = false;
+  DevBuf sp8;
+  float step8_identity = 0.f, step8_rotated = 0.f;   // what the choice saw (stats; 0 = that frame was not measured)
   bool i8_trusted = false;      // the library's own choice has seen a batch through the 8-bit pass on this mirror (no probe needed)
   int64_t version8 = -1, n8 = 0, n_pad8 = 0, forced_rows8 = 0;
   int64_t epoch8 = 0;           // full (re)builds of the 8-bit mirror (an extension keeps the grid and every existing row's constant)
@@ -324,7 +329,8 @@ __global__ void colmean_kernel(const float* part, int dim, int d_pad8, float inv
 }
 // value range of x - mean over the whole table (ordered-u32 images, so atomicMin / atomicMax work on them): scal8[6] = min,
 // scal8[7] = max; one wavefront per row, grid-stride
-__global__ __launch_bounds__(256) void minmax_kernel(const float* rows, int64_t n, int dim, const float* mean, u32* scal8) {
+template <bool ROT>
+__global__ __launch_bounds__(256) void minmax_kernel(const float* rows, int64_t n, int dim, const float* mean, u32* scal8, const int* sp, int d_pad8) {
   float lo = __builtin_inff(), hi = -__builtin_inff();
   bool bad = false;
   const int lane = lane_id();
@@ -332,7 +338,19 @@ __global__ __launch_bounds__(256) void minmax_kernel(const float* rows, int64_t 
   const bool vec = (dim & 3) == 0 && ((reinterpret_cast<uintptr_t>(rows) & 15) == 0);
   for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += nwaves) {
     const float* src = rows + r * dim;
-    if (vec) {
+    if (ROT) {   // the rotated frame (device_common.hpp, rot256_load): all d_pad8 columns carry values
+      for (int c = lane * 4; c < d_pad8; c += 256) {
+        double xd[4];
+        rot256_load(src, dim, sp, c, lane, xd);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float a = (float)(xd[e] - (double)mean[c + e]);
+          lo = fminf(lo, a);
+          hi = fmaxf(hi, a);
+          bad |= !(fabsf(a) < 3.0e38f);
+        }
+      }
+    } else if (vec) {
       for (int c = lane * 4; c < dim; c += 256) {
         const float4 v = *reinterpret_cast<const float4*>(src + c);
         const float4 m = *reinterpret_cast<const float4*>(mean + c);
@@ -396,6 +414,20 @@ __global__ __launch_bounds__(256) void centre_hist_kernel(const float* rows, int
   for (int i = threadIdx.x; i < 4096; i += 256)
     if (h[i]) atomicAdd(&hist[i], h[i]);
 }
+// the rotated frame's column statistics (means, histogram) come from the same kernels, run over the rotated images of the sample rows:
+// out[j][0 .. d_pad8) = R rows[j * stride], fp32 (statistics only: any centre and any step keep the bound valid)
+__global__ __launch_bounds__(256) void rot_sample_kernel(const float* rows, int64_t n, int dim, int64_t stride, int64_t sampled, int d_pad8, const int* sp, float* out) {
+  const int lane = lane_id();
+  for (int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); j < sampled; j += (int64_t)gridDim.x * 4) {
+    const int64_t r = j * stride;
+    if (r >= n) break;
+    for (int c = lane * 4; c < d_pad8; c += 256) {
+      double xd[4];
+      rot256_load(rows + r * dim, dim, sp, c, lane, xd);
+      *reinterpret_cast<float4*>(out + j * d_pad8 + c) = make_float4((float)xd[0], (float)xd[1], (float)xd[2], (float)xd[3]);
+    }
+  }
+}
 constexpr int ACC_FORCE = 0x38000000;   // start value of a row that must pass whatever the threshold (thresholds <= TQ_MAX8, |dot| < 2^27)
 // the batch's margins folded into the rows' start values: acc0b[x] = acc0[x] + ceil(|s| (Qn E[x] + Eq H[x]) / u) + 1, Qn / Eq = the batch's
 // largest |q'| / |q' - qh'| (>= every query's own margin for row x); forced rows and rows whose margin leaves the range: ACC_FORCE
@@ -419,9 +451,11 @@ __global__ void scal_finish_kernel(float* scal8, float* scal8f) {
 }
 
 // rows [row0, n_pad) are (re)written, as in half_mirror_kernel.  x' = x - mu;  metric 0: R = |x'|^2; otherwise R = -mu.x'.  u = |s| step^2.
+// ROT: the table's rotated frame (device_common.hpp, rot256_load) - x' = fl32(R x - mu), all d_pad8 columns carry values
+template <bool ROT>
 __global__ __launch_bounds__(256) void quant_mirror_kernel(const float* rows, int64_t row0, int64_t n, int64_t n_pad, int dim, int d_pad8, const float* mu, float step,
                                                            float inv_step, float inv_u, int metric, signed char* x8, int* acc0, float* scal8, float* erow,
-                                                           float* hrow, u32* forced_count) {
+                                                           float* hrow, u32* forced_count, const int* sp) {
   const int lane = lane_id();
   const int64_t nwaves = (int64_t)gridDim.x * 4;
   float m_e1 = 0.f, m_nxh = 0.f, m_xn = 0.f, m_bad = 0.f, m_r = 0.f, m_emin = __builtin_inff();
@@ -441,7 +475,12 @@ __global__ __launch_bounds__(256) void quant_mirror_kernel(const float* rows, in
     float s2 = 0.f, e2 = 0.f, h2 = 0.f, c2 = 0.f, mx = 0.f;
     for (int c = lane * 4; c < d_pad8; c += 256) {   // d_pad8 is a multiple of 256
       float xs[4] = {0.f, 0.f, 0.f, 0.f};
-      if (vec) {
+      double xd[4] = {0.0, 0.0, 0.0, 0.0};
+      if (ROT) {
+        rot256_load(src, dim, sp, c, lane, xd);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xs[e] = (float)xd[e];   // (enters |x|^2 only: a slack scale)
+      } else if (vec) {
         if (c < dim) {
           const float4 v = *reinterpret_cast<const float4*>(src + c);
           xs[0] = v.x; xs[1] = v.y; xs[2] = v.z; xs[3] = v.w;
@@ -455,8 +494,8 @@ __global__ __launch_bounds__(256) void quant_mirror_kernel(const float* rows, in
       u32 packed = 0;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        if (c + e < dim) {
-          const float dx = xs[e] - ms[e];                   // x'
+        if (ROT || c + e < dim) {
+          const float dx = ROT ? (float)(xd[e] - (double)ms[e]) : xs[e] - ms[e];   // x' (one rounding in either frame)
           const int xi = quant8(dx, 0.f, inv_step);
           const float res = fmaf(-step, (float)xi, dx);     // x' - xh'
           const float xh = step * (float)xi;
@@ -479,7 +518,7 @@ __global__ __launch_bounds__(256) void quant_mirror_kernel(const float* rows, in
     }
     const float R = metric == 0 ? c2 : -mx;
     const float a0 = ceilf(-R * inv_u) + 1.f;
-    const float e1 = sqrtf(e2) * 1.00001f + 1.2e-7f * sqrtf(c2);   // (+ the rounding of x - mu itself)
+    const float e1 = sqrtf(e2) * 1.00001f + 1.2e-7f * sqrtf(c2) + (ROT ? 1e-12f * sqrtf(s2) : 0.f);   // (+ the rounding of x - mu itself; ROT: + the fp64 transform's)
     const float nxh = sqrtf(h2) * 1.00001f;
     if (s2 != s2 || !(s2 < 3.0e38f)) m_bad = 1.f;
     // |acc0| must stay below 2^29 (the dot product adds < 2^27).  A row beyond that - an outlier far outside the clipped grid - is FORCED:
@@ -526,8 +565,9 @@ struct Prep8Extra {
   int* s8g = nullptr;          // one-pass form (stream8_kernel.hpp): table slots = empty, raw candidate counters = 0
   int s8_slots = S8_SLOTS;     // slots per query of that call (64 | 128)
 };
+template <bool ROT>
 __global__ __launch_bounds__(256) void query_prep8_kernel(const float* q, int64_t nq, int64_t b_pad, int dim, int d_pad8, const float* mu, float step, float inv_step,
-                                                          int metric, signed char* q8, float* qstat, Prep8Extra x) {
+                                                          int metric, signed char* q8, float* qstat, Prep8Extra x, const int* sp) {
   if (blockIdx.x == 0) {   // the seeded call's start state (nothing in this launch reads it)
     for (int64_t i = threadIdx.x; x.T2 && i < x.n2; i += 256) x.T2[i] = x.Tv;
     for (int64_t i = threadIdx.x; x.cnt && i < (x.s8g ? S8_MAX_Q + 8 : nq + 8); i += 256) x.cnt[i] = i < nq ? x.cntv : 0u;
@@ -559,12 +599,14 @@ __global__ __launch_bounds__(256) void query_prep8_kernel(const float* q, int64_
   float s2 = 0.f, e2 = 0.f, c2 = 0.f, qm = 0.f;
   for (int c = lane * 4; c < d_pad8; c += 256) {
     u32 packed = 0;
+    double xd[4] = {0.0, 0.0, 0.0, 0.0};
+    if (ROT) rot256_load(src, dim, sp, c, lane, xd);   // the query in the table's rotated frame
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      if (c + e < dim) {
-        const float xv = src[c + e];
+      if (ROT || c + e < dim) {
+        const float xv = ROT ? (float)xd[e] : src[c + e];
         const float m = mu[c + e];
-        const float dx = xv - m;
+        const float dx = ROT ? (float)(xd[e] - (double)m) : xv - m;
         const int qi = quant8(dx, 0.f, inv_step);
         const float res = fmaf(-step, (float)qi, dx);
         packed |= (u32)(qi & 255) << (8 * e);
@@ -584,7 +626,7 @@ __global__ __launch_bounds__(256) void query_prep8_kernel(const float* q, int64_
     qm += __shfl_xor(qm, o);
   }
   if (lane == 0) {
-    const float nqc = sqrtf(c2) * 1.000001f, eqc = sqrtf(e2) * 1.00001f + 1.2e-7f * sqrtf(c2);
+    const float nqc = sqrtf(c2) * 1.000001f, eqc = sqrtf(e2) * 1.00001f + 1.2e-7f * sqrtf(c2) + (ROT ? 1e-12f * sqrtf(s2) : 0.f);
     qstat[r * 4 + 0] = s2;
     qstat[r * 4 + 1] = nqc;
     qstat[r * 4 + 2] = eqc;
@@ -594,6 +636,13 @@ __global__ __launch_bounds__(256) void query_prep8_kernel(const float* q, int64_
       atomicMax(&x.qmax[1], __float_as_uint(eqc));
     }
   }
+}
+
+// (the frame is the mirror's: HalfMirror::rot8 / sp8)
+static void launch_query_prep8(dim3 grid, hipStream_t s, const int* sp, const float* q, int64_t nq, int64_t b_pad, int dim, int d_pad8, const float* mu, float step,
+                               int metric, signed char* q8, float* qstat, const Prep8Extra& x) {
+  if (sp) hipLaunchKernelGGL(query_prep8_kernel<true>, grid, dim3(256), 0, s, q, nq, b_pad, dim, d_pad8, mu, step, 1.f / step, metric, q8, qstat, x, sp);
+  else hipLaunchKernelGGL(query_prep8_kernel<false>, grid, dim3(256), 0, s, q, nq, b_pad, dim, d_pad8, mu, step, 1.f / step, metric, q8, qstat, x, (const int*)nullptr);
 }
 
 // T[j]: pass threshold of query j for the next filter launch, from the current k-th best key (formulas: device_common.hpp,
@@ -787,101 +836,170 @@ static int32_t ensure_mirror8(Index& ix) {
   }
   hipError_t er = hipSuccess;
   if (!extend) {
-    er = hipMemsetAsync(m.scal8.p, 0, 32, s);
-    if (er == hipSuccess) er = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(m.scal8.as<u32>() + 6), (int)0xFFFFFFFFu, 1, s);
-    if (er != hipSuccess) return ix.hip_fail(er, "memset");
     // centre: column means of up to 65 536 rows spread evenly over the table (any centre is valid, see above), summed in a fixed order
     const int64_t sample = std::min<int64_t>(n, 65536);
     const int64_t stride = std::max<int64_t>(1, n / sample);
     const int64_t per_seg = (sample + CENTRE_SEG - 1) / CENTRE_SEG;
     const int64_t sampled = std::min<int64_t>((n + stride - 1) / stride, per_seg * CENTRE_SEG);
-    DevBuf part;
-    if (!part.reserve((size_t)CENTRE_SEG * dim * 4)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory for the 8-bit mirror");
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((dim + 63) / 64), CENTRE_SEG), dim3(256), 0, s, ix.d_rows_, n, dim, stride, per_seg, part.as<float>(),
-                       (const float*)nullptr, 0.f, 0.f);
-    hipLaunchKernelGGL(colmean_kernel, dim3((unsigned)((d_pad8 + 255) / 256)), dim3(256), 0, s, part.as<float>(), dim, d_pad8, 1.f / (float)sampled, m.mu8.as<float>());
-    hipLaunchKernelGGL(minmax_kernel, dim3((unsigned)std::min<int64_t>((n + 3) / 4, 8192)), dim3(256), 0, s, ix.d_rows_, n, dim, m.mu8.as<float>(), m.scal8.as<u32>());
-    er = hipMemcpyAsync(m.h_scal8, m.scal8.p, 32, hipMemcpyDeviceToHost, s);
-    if (er == hipSuccess) er = hipStreamSynchronize(s);   // (also keeps `part` alive until its readers are done)
-    if (er != hipSuccess) return ix.hip_fail(er, "8-bit mirror: value range");
-    u32 omin, omax;
-    std::memcpy(&omin, &m.h_scal8[6], 4);
-    std::memcpy(&omax, &m.h_scal8[7], 4);
-    const float lo = host_ord2f(omin), hi = host_ord2f(omax);
-    m.i8_ok = m.h_scal8[3] == 0.f && omin <= omax && hi > lo && std::isfinite(lo) && std::isfinite(hi) && std::isfinite(hi - lo);
-    float clo = lo, chi = hi;
-    auto clip_range = [&]() -> int32_t {
-    // clip both tails of the SAMPLE's x - mean at max(2, 1e-7 x values) values (centre_hist_kernel); where the cut removes most of the
-    // range - an outlier thousands of grid widths away leaves the bulk in ONE bin - the histogram is taken again inside the cut (values
-    // outside fall into the edge bins), up to three times
-    for (int round = 0; m.i8_ok && round < 3; ++round) {
-      const float binw = (chi - clo) / 4096.f;
-      if (!(binw > 0.f) || !std::isfinite(1.f / binw)) break;
-      std::vector<u32> hh(4096);
-      er = hipMemsetAsync(m.hist.p, 0, (4096 + 8) * 4, s);
-      if (er != hipSuccess) return ix.hip_fail(er, "memset");
-      hipLaunchKernelGGL(centre_hist_kernel, dim3((unsigned)std::min<int64_t>(sampled, 4096)), dim3(256), 0, s, ix.d_rows_, n, dim, stride, sampled, m.mu8.as<float>(),
-                         clo, 1.f / binw, m.hist.as<u32>());
-      er = hipMemcpyAsync(hh.data(), m.hist.p, 4096 * 4, hipMemcpyDeviceToHost, s);
+    // r6: the frame.  0 = identity, 1 = rotated, otherwise the library's choice (both measured, below)
+    const char* rot_e = tune_env("EPS_MIRROR_ROTATE");
+    const int rot_mode = rot_e ? atoi(rot_e) : -1;
+    if (rot_mode != 0) {   // R's permutation and signs: a fixed sequence (splitmix64), the same for every table of this width
+      std::vector<int32_t> sp((size_t)d_pad8);
+      for (int i = 0; i < d_pad8; ++i) sp[(size_t)i] = i;
+      uint64_t st = 0x9E3779B97F4A7C15ull ^ (uint64_t)d_pad8;
+      auto next = [&st]() {
+        uint64_t z = (st += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+      };
+      for (int i = d_pad8 - 1; i > 0; --i) std::swap(sp[(size_t)i], sp[(size_t)(next() % (uint64_t)(i + 1))]);
+      for (int i = 0; i < d_pad8; ++i)
+        if (next() & 1ull) sp[(size_t)i] |= (int32_t)0x80000000u;
+      if (!m.sp8.reserve((size_t)d_pad8 * 4)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory for the 8-bit mirror");
+      er = hipMemcpyAsync(m.sp8.p, sp.data(), (size_t)d_pad8 * 4, hipMemcpyHostToDevice, s);
       if (er == hipSuccess) er = hipStreamSynchronize(s);
-      if (er != hipSuccess) return ix.hip_fail(er, "8-bit mirror: value histogram");
-      const unsigned long long tol = std::max<unsigned long long>(2ull, (unsigned long long)(1e-7 * (double)sampled * (double)dim));
-      unsigned long long cum = 0;
-      int blo = 0, bhi = 4095;
-      for (blo = 0; blo < 4096; ++blo) {
-        cum += hh[(size_t)blo];
-        if (cum > tol) break;
-      }
-      cum = 0;
-      for (bhi = 4095; bhi >= 0; --bhi) {
-        cum += hh[(size_t)bhi];
-        if (cum > tol) break;
-      }
-      const float a = clo + (float)blo * binw, b = clo + (float)(bhi + 1) * binw;
-      if (!(blo < 4096 && bhi >= 0 && b > a)) break;
-      const bool cut_most = (b - a) < 0.25f * (chi - clo);
-      clo = a;
-      chi = b;
-      if (!cut_most) break;
+      if (er != hipSuccess) return ix.hip_fail(er, "8-bit mirror: rotation table");
     }
-    return EPS_OK;
-    };
-    {
+    // One frame's grid: centre into `mu_out`, the clipped value range, whether the table fits one grid at all.  `rot`: measured on the
+    // rotated images of the sample rows (all d_pad8 columns carry values), the value range over the whole table through the transform.
+    struct Grid { bool ok = false; float z0 = 0.f, half = 127.f, step = 0.f; };
+    auto measure = [&](bool rot, DevBuf& mu_out, Grid* g) -> int32_t {
+      DevBuf part, rsample;
+      const float* srows = ix.d_rows_;
+      int64_t sn = n, sstride = stride;
+      int sdim = dim;
+      if (rot) {
+        if (!rsample.reserve((size_t)sampled * d_pad8 * 4)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory for the 8-bit mirror");
+        hipLaunchKernelGGL(rot_sample_kernel, dim3((unsigned)std::min<int64_t>((sampled + 3) / 4, 8192)), dim3(256), 0, s, ix.d_rows_, n, dim, stride, sampled, d_pad8,
+                           m.sp8.as<int>(), rsample.as<float>());
+        srows = rsample.as<float>();
+        sn = sampled;
+        sstride = 1;
+        sdim = d_pad8;
+      }
+      hipError_t e2 = hipMemsetAsync(m.scal8.p, 0, 32, s);
+      if (e2 == hipSuccess) e2 = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(m.scal8.as<u32>() + 6), (int)0xFFFFFFFFu, 1, s);
+      if (e2 != hipSuccess) return ix.hip_fail(e2, "memset");
+      if (!part.reserve((size_t)CENTRE_SEG * sdim * 4)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory for the 8-bit mirror");
+      hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((sdim + 63) / 64), CENTRE_SEG), dim3(256), 0, s, srows, sn, sdim, sstride, per_seg, part.as<float>(),
+                         (const float*)nullptr, 0.f, 0.f);
+      hipLaunchKernelGGL(colmean_kernel, dim3((unsigned)((d_pad8 + 255) / 256)), dim3(256), 0, s, part.as<float>(), sdim, d_pad8, 1.f / (float)sampled, mu_out.as<float>());
+      const unsigned mm_grid = (unsigned)std::min<int64_t>((n + 3) / 4, 8192);
+      if (rot) hipLaunchKernelGGL(minmax_kernel<true>, dim3(mm_grid), dim3(256), 0, s, ix.d_rows_, n, dim, mu_out.as<float>(), m.scal8.as<u32>(), m.sp8.as<int>(), d_pad8);
+      else hipLaunchKernelGGL(minmax_kernel<false>, dim3(mm_grid), dim3(256), 0, s, ix.d_rows_, n, dim, mu_out.as<float>(), m.scal8.as<u32>(), (const int*)nullptr, d_pad8);
+      e2 = hipMemcpyAsync(m.h_scal8, m.scal8.p, 32, hipMemcpyDeviceToHost, s);
+      if (e2 == hipSuccess) e2 = hipStreamSynchronize(s);   // (also keeps `part` alive until its readers are done)
+      if (e2 != hipSuccess) return ix.hip_fail(e2, "8-bit mirror: value range");
+      u32 omin, omax;
+      std::memcpy(&omin, &m.h_scal8[6], 4);
+      std::memcpy(&omax, &m.h_scal8[7], 4);
+      const float lo = host_ord2f(omin), hi = host_ord2f(omax);
+      g->ok = m.h_scal8[3] == 0.f && omin <= omax && hi > lo && std::isfinite(lo) && std::isfinite(hi) && std::isfinite(hi - lo);
+      float clo = lo, chi = hi;
+      auto clip_range = [&]() -> int32_t {
+      // clip both tails of the SAMPLE's x - mean at max(2, 1e-7 x values) values (centre_hist_kernel); where the cut removes most of the
+      // range - an outlier thousands of grid widths away leaves the bulk in ONE bin - the histogram is taken again inside the cut (values
+      // outside fall into the edge bins), up to three times
+      for (int round = 0; g->ok && round < 3; ++round) {
+        const float binw = (chi - clo) / 4096.f;
+        if (!(binw > 0.f) || !std::isfinite(1.f / binw)) break;
+        std::vector<u32> hh(4096);
+        hipError_t e3 = hipMemsetAsync(m.hist.p, 0, (4096 + 8) * 4, s);
+        if (e3 != hipSuccess) return ix.hip_fail(e3, "memset");
+        hipLaunchKernelGGL(centre_hist_kernel, dim3((unsigned)std::min<int64_t>(sampled, 4096)), dim3(256), 0, s, srows, sn, sdim, sstride, sampled, mu_out.as<float>(),
+                           clo, 1.f / binw, m.hist.as<u32>());
+        e3 = hipMemcpyAsync(hh.data(), m.hist.p, 4096 * 4, hipMemcpyDeviceToHost, s);
+        if (e3 == hipSuccess) e3 = hipStreamSynchronize(s);
+        if (e3 != hipSuccess) return ix.hip_fail(e3, "8-bit mirror: value histogram");
+        const unsigned long long tol = std::max<unsigned long long>(2ull, (unsigned long long)(1e-7 * (double)sampled * (double)sdim));
+        unsigned long long cum = 0;
+        int blo = 0, bhi = 4095;
+        for (blo = 0; blo < 4096; ++blo) {
+          cum += hh[(size_t)blo];
+          if (cum > tol) break;
+        }
+        cum = 0;
+        for (bhi = 4095; bhi >= 0; --bhi) {
+          cum += hh[(size_t)bhi];
+          if (cum > tol) break;
+        }
+        const float a = clo + (float)blo * binw, b = clo + (float)(bhi + 1) * binw;
+        if (!(blo < 4096 && bhi >= 0 && b > a)) break;
+        const bool cut_most = (b - a) < 0.25f * (chi - clo);
+        clo = a;
+        chi = b;
+        if (!cut_most) break;
+      }
+      return EPS_OK;
+      };
       int32_t rc = clip_range();
       if (rc != EPS_OK) return rc;
-      if (m.i8_ok && (clo > lo || chi < hi)) {
+      if (g->ok && (clo > lo || chi < hi)) {
         // something was cut: the column means it polluted are estimated again from values clamped into the cut (same fixed summation
         // order), and the range once more around the new means (the first range, widened by the largest move of a mean, bounds it)
         DevBuf mean1;
-        std::vector<float> h1((size_t)dim), h2((size_t)dim);
+        std::vector<float> h1((size_t)sdim), h2((size_t)sdim);
         if (!mean1.reserve((size_t)d_pad8 * 4)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory for the 8-bit mirror");
-        er = hipMemcpyAsync(mean1.p, m.mu8.p, (size_t)d_pad8 * 4, hipMemcpyDeviceToDevice, s);
-        if (er != hipSuccess) return ix.hip_fail(er, "memcpy");
-        hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((dim + 63) / 64), CENTRE_SEG), dim3(256), 0, s, ix.d_rows_, n, dim, stride, per_seg, part.as<float>(),
+        hipError_t e3 = hipMemcpyAsync(mean1.p, mu_out.p, (size_t)d_pad8 * 4, hipMemcpyDeviceToDevice, s);
+        if (e3 != hipSuccess) return ix.hip_fail(e3, "memcpy");
+        hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((sdim + 63) / 64), CENTRE_SEG), dim3(256), 0, s, srows, sn, sdim, sstride, per_seg, part.as<float>(),
                            mean1.as<float>(), clo, chi);
-        hipLaunchKernelGGL(colmean_kernel, dim3((unsigned)((d_pad8 + 255) / 256)), dim3(256), 0, s, part.as<float>(), dim, d_pad8, 1.f / (float)sampled, m.mu8.as<float>());
-        er = hipMemcpyAsync(h1.data(), mean1.p, (size_t)dim * 4, hipMemcpyDeviceToHost, s);
-        if (er == hipSuccess) er = hipMemcpyAsync(h2.data(), m.mu8.p, (size_t)dim * 4, hipMemcpyDeviceToHost, s);
-        if (er == hipSuccess) er = hipStreamSynchronize(s);
-        if (er != hipSuccess) return ix.hip_fail(er, "8-bit mirror: column means");
+        hipLaunchKernelGGL(colmean_kernel, dim3((unsigned)((d_pad8 + 255) / 256)), dim3(256), 0, s, part.as<float>(), sdim, d_pad8, 1.f / (float)sampled, mu_out.as<float>());
+        e3 = hipMemcpyAsync(h1.data(), mean1.p, (size_t)sdim * 4, hipMemcpyDeviceToHost, s);
+        if (e3 == hipSuccess) e3 = hipMemcpyAsync(h2.data(), mu_out.p, (size_t)sdim * 4, hipMemcpyDeviceToHost, s);
+        if (e3 == hipSuccess) e3 = hipStreamSynchronize(s);
+        if (e3 != hipSuccess) return ix.hip_fail(e3, "8-bit mirror: column means");
         float delta = 0.f;
-        for (int c = 0; c < dim; ++c) delta = std::max(delta, std::fabs(h2[(size_t)c] - h1[(size_t)c]));
+        for (int c = 0; c < sdim; ++c) delta = std::max(delta, std::fabs(h2[(size_t)c] - h1[(size_t)c]));
         clo = lo - delta;
         chi = hi + delta;
         rc = clip_range();
         if (rc != EPS_OK) return rc;
       }
+      g->z0 = g->ok ? 0.5f * clo + 0.5f * chi : 0.f;
+      g->half = g->ok ? std::max(chi - g->z0, g->z0 - clo) : 127.f;
+      g->step = g->half / 127.f;
+      if (g->ok && !(g->step > 0.f && std::isfinite(1.f / (g->step * g->step)))) g->ok = false;
+      return EPS_OK;
+    };
+    // The choice: a row's residual norm is ~ step x sqrt(columns that carry values / 12) in either frame - the identity frame quantises
+    // `dim` columns, the rotated one all d_pad8 - so the frame with the smaller product gives the tighter margin.  The rotated frame must
+    // win clearly (0.75): at equal margins the identity frame's query preparation is cheaper, and it is the frame every earlier round measured.
+    Grid gi, gr;
+    DevBuf mu_rot;
+    m.step8_identity = m.step8_rotated = 0.f;
+    if (rot_mode != 1) {
+      const int32_t rc = measure(false, m.mu8, &gi);
+      if (rc != EPS_OK) return rc;
+      m.step8_identity = gi.ok ? gi.step : 0.f;
     }
+    if (rot_mode != 0 && (rot_mode == 1 || gi.ok)) {
+      if (!mu_rot.reserve((size_t)d_pad8 * 4)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory for the 8-bit mirror");
+      const int32_t rc = measure(true, mu_rot, &gr);
+      if (rc != EPS_OK) return rc;
+      m.step8_rotated = gr.ok ? gr.step : 0.f;
+    }
+    m.rot8 = rot_mode == 1 || (rot_mode != 0 && gi.ok && gr.ok &&
+                               (double)gr.step * std::sqrt((double)d_pad8) < 0.75 * (double)gi.step * std::sqrt((double)dim));
+    const Grid& g = m.rot8 ? gr : gi;
+    if (m.rot8) {
+      er = hipMemcpyAsync(m.mu8.p, mu_rot.p, (size_t)d_pad8 * 4, hipMemcpyDeviceToDevice, s);
+      if (er == hipSuccess) er = hipStreamSynchronize(s);
+      if (er != hipSuccess) return ix.hip_fail(er, "memcpy");
+    }
+    m.i8_ok = g.ok;
+    er = hipMemsetAsync(m.scal8.p, 0, 32, s);
+    if (er != hipSuccess) return ix.hip_fail(er, "memset");
     if (m.i8_ok) {
       er = hipMemsetAsync(m.hist.p, 0, (4096 + 8) * 4, s);   // ([4096]: the forced-row counter of the quantising pass)
       if (er != hipSuccess) return ix.hip_fail(er, "memset");
     }
-    const float z0 = m.i8_ok ? 0.5f * clo + 0.5f * chi : 0.f;
-    const float half = m.i8_ok ? std::max(chi - z0, z0 - clo) : 127.f;
-    m.step8 = half / 127.f;
-    if (m.i8_ok && !(m.step8 > 0.f && std::isfinite(1.f / (m.step8 * m.step8)))) m.i8_ok = false;
+    const float z0 = g.z0;
+    m.step8 = g.step;
     if (m.i8_ok) {
-      hipLaunchKernelGGL(mu_finish_kernel, dim3(1), dim3(64), 0, s, m.mu8.as<float>(), dim, z0, m.scal8.as<float>());
+      hipLaunchKernelGGL(mu_finish_kernel, dim3(1), dim3(64), 0, s, m.mu8.as<float>(), m.rot8 ? d_pad8 : dim, z0, m.scal8.as<float>());
       er = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(m.scal8.as<u32>() + 7), 0x7F800000, 1, s);   // min residual norm: +inf
       if (er != hipSuccess) return ix.hip_fail(er, "memset");
     }
@@ -889,9 +1007,15 @@ static int32_t ensure_mirror8(Index& ix) {
   if (m.i8_ok) {
     const float u = (ix.metric_ == 0 ? 2.f : 1.f) * m.step8 * m.step8;
     const int64_t row0 = extend ? m.n8 : 0;
-    hipLaunchKernelGGL(quant_mirror_kernel, dim3((unsigned)std::min<int64_t>((n_pad - row0 + 3) / 4, 8192)), dim3(256), 0, s, ix.d_rows_, row0, n, n_pad,
-                       dim, d_pad8, m.mu8.as<float>(), m.step8, 1.f / m.step8, 1.f / u, ix.metric_, m.x8.as<signed char>(), m.acc0.as<int>(), m.scal8.as<float>(),
-                       m.erow.as<float>(), m.hrow.as<float>(), m.hist.as<u32>() + 4096);
+    const dim3 qgrid((unsigned)std::min<int64_t>((n_pad - row0 + 3) / 4, 8192));
+    if (m.rot8)
+      hipLaunchKernelGGL(quant_mirror_kernel<true>, qgrid, dim3(256), 0, s, ix.d_rows_, row0, n, n_pad, dim, d_pad8, m.mu8.as<float>(), m.step8, 1.f / m.step8, 1.f / u,
+                         ix.metric_, m.x8.as<signed char>(), m.acc0.as<int>(), m.scal8.as<float>(), m.erow.as<float>(), m.hrow.as<float>(), m.hist.as<u32>() + 4096,
+                         m.sp8.as<int>());
+    else
+      hipLaunchKernelGGL(quant_mirror_kernel<false>, qgrid, dim3(256), 0, s, ix.d_rows_, row0, n, n_pad, dim, d_pad8, m.mu8.as<float>(), m.step8, 1.f / m.step8, 1.f / u,
+                         ix.metric_, m.x8.as<signed char>(), m.acc0.as<int>(), m.scal8.as<float>(), m.erow.as<float>(), m.hrow.as<float>(), m.hist.as<u32>() + 4096,
+                         (const int*)nullptr);
     hipLaunchKernelGGL(scal_finish_kernel, dim3(1), dim3(64), 0, s, m.scal8.as<float>(), m.scal8f.as<float>());
     u32 forced = 0;
     er = hipMemcpyAsync(m.h_scal8, m.scal8.p, 32, hipMemcpyDeviceToHost, s);
@@ -958,8 +1082,8 @@ void quant8_queries(Index& ix, const Quant8View& v, const float* dq, int64_t nq,
     px.qmax = m.qmax.as<u32>();
     (void)hipMemsetAsync(m.qmax.p, 0, 8, ix.stream_);
   }
-  hipLaunchKernelGGL(query_prep8_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, ix.stream_, dq, nq, nq, (int)ix.dim_, v.d_pad8, v.mu, v.step,
-                     1.f / v.step, ix.metric_, q8, qstat, px);
+  launch_query_prep8(dim3((unsigned)((nq + 3) / 4)), ix.stream_, m.rot8 ? m.sp8.as<int>() : nullptr, dq, nq, nq, (int)ix.dim_, v.d_pad8, v.mu, v.step, ix.metric_, q8,
+                     qstat, px);
   if (m.fold8)
   hipLaunchKernelGGL(fold8_kernel, dim3((unsigned)std::min<int64_t>((m.n_pad8 + 255) / 256, 8192)), dim3(256), 0, ix.stream_, m.acc0.as<int>(), m.erow.as<float>(),
                      m.hrow.as<float>(), m.n8, m.n_pad8, m.qmax.as<u32>(), ix.metric_ == 0 ? 2.f : 1.f, 1.f / v.u, m.acc0b.as<int>());
@@ -1052,7 +1176,8 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
   // the slots it uses, and never leaves the "clean" state behind)
   const int slots = k <= 16 ? S8_SLOTS : S8_SLOTS_WIDE;
   const bool mfma_form = nq > 4 || (slots != S8_SLOTS && nq > 2);   // stream8m_kernel (16 query columns: the prep launch lays down 16 rows, zeros beyond nq)
-  const bool clean = two_launches && nq <= 2 && slots == S8_SLOTS && m.s8_clean_cnt == m.cnt.p && m.s8_clean_g == m.s8g.p;
+  // (a table in the rotated frame keeps the prep launch: the transform is its work, not the pass's)
+  const bool clean = two_launches && nq <= 2 && slots == S8_SLOTS && m.s8_clean_cnt == m.cnt.p && m.s8_clean_g == m.s8g.p && !m.rot8;
   m.s8_clean_cnt = m.s8_clean_g = nullptr;   // (set again when this call has come back)
   if (!clean) {
     Prep8Extra px;
@@ -1060,8 +1185,8 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
     px.cntv = 0;
     px.s8g = m.s8g.as<int>();
     px.s8_slots = slots;
-    hipLaunchKernelGGL(query_prep8_kernel, dim3(mfma_form ? 4 : 1), dim3(256), 0, s, dq, nq, (int64_t)(mfma_form ? 16 : 4), (int)ix.dim_, m.d_pad8, m.mu8.as<float>(), m.step8, 1.f / m.step8, ix.metric_,
-                       m.q8.as<signed char>(), m.qstat.as<float>(), px);
+    launch_query_prep8(dim3(mfma_form ? 4 : 1), s, m.rot8 ? m.sp8.as<int>() : nullptr, dq, nq, (int64_t)(mfma_form ? 16 : 4), (int)ix.dim_, m.d_pad8, m.mu8.as<float>(),
+                       m.step8, ix.metric_, m.q8.as<signed char>(), m.qstat.as<float>(), px);
   }
   Stream8Args a;
   a.x8 = m.x8.as<signed char>();
@@ -1243,6 +1368,7 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
   ix.stats_.main_kernel_queries = nq;
   ix.stats_.main_kernel_bits = 8;
   ix.stats_.one_pass = 1;
+  ix.stats_.i8_rotated = m.rot8 ? 1 : 0;
   *done = true;
   return EPS_OK;
 }
@@ -1315,9 +1441,10 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
         px.gsync = gsync_env ? m.gsync.as<u32>() : nullptr;
       }
     }
-    hipLaunchKernelGGL(query_prep8_kernel, dim3((unsigned)((b_pad + 3) / 4)), dim3(256), 0, s, dq, nq, b_pad, (int)ix.dim_, m.d_pad8, m.mu8.as<float>(), m.step8,
-                       1.f / m.step8, ix.metric_, m.q8.as<signed char>(), m.qstat.as<float>(), px);
+    launch_query_prep8(dim3((unsigned)((b_pad + 3) / 4)), s, m.rot8 ? m.sp8.as<int>() : nullptr, dq, nq, b_pad, (int)ix.dim_, m.d_pad8, m.mu8.as<float>(), m.step8,
+                       ix.metric_, m.q8.as<signed char>(), m.qstat.as<float>(), px);
     if (fold) ix.stats_.i8_folded = 1;
+    ix.stats_.i8_rotated = m.rot8 ? 1 : 0;
     if (fold)
       hipLaunchKernelGGL(fold8_kernel, dim3((unsigned)std::min<int64_t>((m.n_pad8 + 255) / 256, 8192)), dim3(256), 0, s, m.acc0.as<int>(), m.erow.as<float>(),
                          m.hrow.as<float>(), m.n8, m.n_pad8, m.qmax.as<u32>(), ix.metric_ == 0 ? 2.f : 1.f, 1.f / u8, m.acc0b.as<int>());
