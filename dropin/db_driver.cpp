@@ -21,6 +21,7 @@
 #include "config/config.hpp"
 #include "db/db_server.hpp"
 #ifdef EPS_DROPIN
+#include "epsdrop/insert_array.hpp"
 #include "epsdrop/search_batch.hpp"
 #endif
 
@@ -134,6 +135,45 @@ int ref_db_search_batch(void* h, const char* db, const char* table, const char* 
     size_t n = std::min<size_t>(s.size(), (size_t)cap - 1);
     memcpy(out, s.data(), n);
     out[n] = 0;
+  }
+  return st.code();
+}
+#endif
+
+#ifdef EPS_DROPIN
+// The drop-in's bulk ingest (include/epsdrop/insert_array.hpp) for ctypes callers: `ncols` columns; names[c] = schema field, kinds[c] =
+// epsdrop::ColumnView::Kind (0 i8, 1 i16, 2 i32, 3 i64, 4 u8, 5 f32, 6 f64, 7 strings), data[c] = the column's buffer (strings: n
+// NUL-terminated strings laid end to end), widths[c] = 1 or the vector dimension.  out2 = {inserted, skipped}.
+int ref_db_insert_array(void* h, const char* db, const char* table, int ncols, const char** names, const int* kinds, const void** data, const int64_t* widths,
+                        int64_t n, int upsert, int sync, int64_t* out2, char* msg, int64_t cap) {
+  std::vector<epsdrop::ColumnView> cols((size_t)ncols);
+  std::vector<std::vector<std::string>> strs((size_t)ncols);
+  for (int c = 0; c < ncols; ++c) {
+    cols[(size_t)c].name = names[c];
+    cols[(size_t)c].kind = (epsdrop::ColumnView::Kind)kinds[c];
+    cols[(size_t)c].width = widths[c];
+    if (kinds[c] == (int)epsdrop::ColumnView::STR) {
+      const char* p = static_cast<const char*>(data[c]);
+      for (int64_t i = 0; i < n; ++i) {
+        strs[(size_t)c].emplace_back(p);
+        p += strs[(size_t)c].back().size() + 1;
+      }
+      cols[(size_t)c].strings = &strs[(size_t)c];
+    } else {
+      cols[(size_t)c].data = data[c];
+    }
+  }
+  epsdrop::InsertArrayResult r;
+  vectordb::Status st = epsdrop::InsertArray(*static_cast<vectordb::engine::DBServer*>(h), db, table, cols, n, upsert != 0, sync != 0, &r);
+  if (out2) {
+    out2[0] = r.inserted;
+    out2[1] = r.skipped;
+  }
+  if (cap > 0) {
+    const std::string s = st.message();
+    size_t m = std::min<size_t>(s.size(), (size_t)cap - 1);
+    memcpy(msg, s.data(), m);
+    msg[m] = 0;
   }
   return st.code();
 }

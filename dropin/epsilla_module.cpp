@@ -18,7 +18,15 @@
 //                                                      array, or a list of lists): ONE eps_index_search with nq = N through
 //                                                      VecSearchExecutor::SearchBatch, one projection pass; element q of the
 //                                                      result equals query(..., query_vectors[q], ...)[1]
+//   insert_array(table_name, columns, upsert=False, sync=False) -> (int, {"inserted": n, "skipped": m})
+//                                                      (r6) insert() for n records given as COLUMNS - {field: 2-D float32 / float64 buffer}
+//                                                      for dense vector fields, {field: 1-D integer / float buffer} for primitive
+//                                                      fields, {field: list of str} for STRING fields: what TableSegmentMVP::Insert
+//                                                      would have stored for the same records (COSINE normalisation, duplicate
+//                                                      primary keys, capacity check), without a JSON document or a text WAL record
+//                                                      (epsdrop::InsertArray, include/epsdrop/insert_array.hpp)
 #define PyInit_epsilla PyInit_epsilla_reference_binding
+#include "epsdrop/insert_array.hpp"
 #include "epsdrop/search_batch.hpp"
 #include "bindings/python/interface.cpp"  // the reference's binding, from where it lies under $(REF)
 #undef PyInit_epsilla
@@ -29,6 +37,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <thread>
 
 static PyObject* eps_rebuild(PyObject* self, PyObject* args, PyObject* kwargs) {
@@ -414,9 +423,104 @@ static PyObject* eps_query_batch(PyObject* self, PyObject* args, PyObject* kwarg
   return Py_BuildValue("(iN)", 0, out);
 }
 
+// ---- insert_array: n records as column buffers (epsdrop::InsertArray) -----------------------------------------------------
+static PyObject* eps_insert_array(PyObject* self, PyObject* args, PyObject* kwargs) {
+  (void)self;
+  static const char* keywords[] = {"table_name", "columns", "upsert", "sync", NULL};
+  const char* tableNamePtr;
+  PyObject* columns;
+  int upsert = 0, sync = 0;
+  if (!PyArg_ParseTupleAndKeywords(args, kwargs, "sO|pp", (char**)keywords, &tableNamePtr, &columns, &upsert, &sync)) return NULL;
+  if (!PyDict_Check(columns)) {
+    PyErr_SetString(PyExc_Exception, "insert_array: columns must be a dict {field name: buffer | list of str}");
+    return NULL;
+  }
+  struct Held {
+    std::vector<Py_buffer> views;
+    ~Held() { for (auto& v : views) PyBuffer_Release(&v); }
+  } held;
+  held.views.reserve((size_t)PyDict_Size(columns));
+  std::vector<epsdrop::ColumnView> cols;
+  std::vector<std::unique_ptr<std::vector<std::string>>> strs;
+  int64_t n = -1;
+  PyObject *key, *value;
+  Py_ssize_t pos = 0;
+  auto bad = [&](const std::string& what) -> PyObject* {
+    PyErr_SetString(PyExc_Exception, ("insert_array: " + what).c_str());
+    return NULL;
+  };
+  while (PyDict_Next(columns, &pos, &key, &value)) {
+    if (!PyUnicode_Check(key)) return bad("column names must be str");
+    epsdrop::ColumnView c;
+    c.name = PyUnicode_AsUTF8(key);
+    int64_t rows = 0;
+    if (PyList_Check(value)) {   // a STRING column
+      rows = (int64_t)PyList_Size(value);
+      strs.emplace_back(new std::vector<std::string>());
+      strs.back()->reserve((size_t)rows);
+      for (Py_ssize_t i = 0; i < rows; ++i) {
+        PyObject* s = PyList_GET_ITEM(value, i);
+        if (!PyUnicode_Check(s)) return bad("column " + c.name + ": a list column holds str (numeric columns are buffers, e.g. NumPy arrays)");
+        Py_ssize_t len = 0;
+        const char* u = PyUnicode_AsUTF8AndSize(s, &len);
+        if (!u) return NULL;
+        strs.back()->emplace_back(u, (size_t)len);
+      }
+      c.kind = epsdrop::ColumnView::STR;
+      c.strings = strs.back().get();
+    } else {
+      Py_buffer view;
+      if (!PyObject_CheckBuffer(value) || PyObject_GetBuffer(value, &view, PyBUF_C_CONTIGUOUS | PyBUF_FORMAT) != 0) {
+        PyErr_Clear();
+        return bad("column " + c.name + ": a C-contiguous 1-D / 2-D buffer (NumPy array) or a list of str");
+      }
+      held.views.push_back(view);
+      const char* f = view.format ? view.format : "B";
+      if (*f == '<' || *f == '=' || *f == '@') ++f;
+      const std::string fmt = f;
+      if (fmt == "b") c.kind = epsdrop::ColumnView::I8;
+      else if (fmt == "h") c.kind = epsdrop::ColumnView::I16;
+      else if (fmt == "i" || (fmt == "l" && view.itemsize == 4)) c.kind = epsdrop::ColumnView::I32;
+      else if (fmt == "q" || (fmt == "l" && view.itemsize == 8)) c.kind = epsdrop::ColumnView::I64;
+      else if (fmt == "B" || fmt == "?") c.kind = epsdrop::ColumnView::U8;
+      else if (fmt == "f") c.kind = epsdrop::ColumnView::F32;
+      else if (fmt == "d") c.kind = epsdrop::ColumnView::F64;
+      else return bad("column " + c.name + ": element type '" + fmt + "' (int8/16/32/64, uint8, bool, float32, float64)");
+      if (view.ndim != 1 && view.ndim != 2) return bad("column " + c.name + ": 1-D (primitive field) or 2-D (dense vector field)");
+      rows = (int64_t)view.shape[0];
+      c.width = view.ndim == 2 ? (int64_t)view.shape[1] : 1;
+      c.data = view.buf;
+    }
+    if (n >= 0 && rows != n) return bad("columns of different lengths");
+    n = rows;
+    cols.push_back(c);
+  }
+  if (n < 0) n = 0;
+  const std::string tableName = tableNamePtr;
+  epsdrop::InsertArrayResult r;
+  int code = 0;
+  std::string err;
+  Py_BEGIN_ALLOW_THREADS
+  try {
+    const vectordb::Status st = epsdrop::InsertArray(*db, db_name, tableName, cols, n, upsert != 0, sync != 0, &r);
+    code = st.code();
+    if (!st.ok()) err = st.message().empty() ? std::string("insert_array failed") : st.message();
+  } catch (const std::exception& e) {
+    err = e.what();
+    if (err.empty()) err = "insert_array failed";
+  }
+  Py_END_ALLOW_THREADS
+  if (!err.empty()) {
+    PyErr_SetString(PyExc_Exception, err.c_str());
+    return NULL;
+  }
+  return Py_BuildValue("(i{s:L,s:L})", code, "inserted", (long long)r.inserted, "skipped", (long long)r.skipped);
+}
+
 static PyMethodDef EpsillaGfx950Methods[] = {
     {"rebuild", (PyCFunction)(void (*)(void))eps_rebuild, METH_VARARGS | METH_KEYWORDS, "build the ANN graphs now (additive: DBServer::Rebuild as leader)"},
     {"query_batch", (PyCFunction)(void (*)(void))eps_query_batch, METH_VARARGS | METH_KEYWORDS, "query() for N vectors in one device batch (additive)"},
+    {"insert_array", (PyCFunction)(void (*)(void))eps_insert_array, METH_VARARGS | METH_KEYWORDS, "insert() for n records given as column buffers (additive; no JSON, no text WAL record)"},
     {"load_db_scaled", (PyCFunction)(void (*)(void))eps_load_db_scaled, METH_VARARGS | METH_KEYWORDS, "load_db with the table capacity (the REST API's vectorScale) as an argument (additive)"},
     {NULL, NULL, 0, NULL}};
 

@@ -8,7 +8,12 @@ module directory first on sys.path:
   c1      BASELINE configs[0]: rows x dim inserted through insert() in 1000-row JSON batches, `queries` query() calls
   bulk    rows x dim written as the reference's own table files (vectordb_amd/segment_file.py) and loaded by the reference's
           loader (drop-in: load_db_scaled), then query() for the first 16 queries and query_batch() for all of them as ONE NumPy
-          matrix, unfiltered and with "ID < rows/2"; args: rows dim queries [metric] [batches]"""
+          matrix, unfiltered and with "ID < rows/2"; args: rows dim queries [metric] [batches]
+  ingest  (drop-in only, r6) the SAME records into table J through insert() (JSON, the reference's path) and into table A through
+          insert_array() (column buffers): one table with an INT key, INT / FLOAT / DOUBLE / BOOL / STRING attributes and three vector fields
+          (EUCLIDEAN, DOT_PRODUCT, COSINE) of `dim` columns; duplicate keys inside and across batches, deletes afterwards; then the same
+          query() / query_batch() calls on both, stored (normalised) vectors included in the response
+  ingest_big  (drop-in only) rows x dim through insert_array() in chunks of 1M rows into a table loaded with load_db_scaled: seconds, rows/s"""
 import json
 import sys
 import time
@@ -122,6 +127,127 @@ if what == "bulk":
         d = ((X.astype(np.float64) - q) ** 2).sum(1) if metric == "EUCLIDEAN" and rows <= 2_000_000 else None
         gt.append(None if d is None else np.argsort(d, kind="stable")[:10].tolist())
     out["numpy_top10"] = gt
+    print("EPSILLA_JSON " + json.dumps(out))
+    sys.exit(0)
+
+if what in ("ingest", "ingest_big"):
+    assert hasattr(epsilla, "insert_array"), "the drop-in module only"
+    if what == "ingest_big":
+        metric = sys.argv[7] if len(sys.argv) > 7 else "COSINE"
+        assert epsilla.load_db_scaled(db_name="db", db_path=db_path, vector_scale=rows + 1024, wal_enabled=False) == 0
+        epsilla.use_db(db_name="db")
+        create_table("T", [{"name": "ID", "dataType": "INT", "primaryKey": True},
+                           {"name": "V", "dataType": "VECTOR_FLOAT", "dimensions": dim, "metricType": metric}])
+        rng = np.random.default_rng(42)
+        chunk = 1 << 20
+        buf = np.empty((chunk, dim), np.float32)
+        gen_s = ins_s = 0.0
+        first = None
+        for s in range(0, rows, chunk):
+            m = min(chunk, rows - s)
+            t0 = time.perf_counter()
+            for a in range(0, m, 1 << 17):
+                buf[a:a + (1 << 17)] = rng.random((min(1 << 17, m - a), dim), dtype=np.float32)
+            if first is None:
+                first = buf[:64].copy()
+            gen_s += time.perf_counter() - t0
+            t0 = time.perf_counter()
+            code, r = epsilla.insert_array(table_name="T", columns={"ID": np.arange(s, s + m, dtype=np.int32), "V": buf[:m]})
+            ins_s += time.perf_counter() - t0
+            assert code == 0 and r == {"inserted": m, "skipped": 0}, (code, r)
+        out["rows"], out["dim"], out["metric"] = rows, dim, metric
+        out["generate_s"], out["insert_array_s"], out["rows_per_s"] = gen_s, ins_s, rows / ins_s
+        kw = dict(table_name="T", query_field="V", response_fields=["ID"], limit=10, with_distance=True)
+        t0 = time.perf_counter()
+        code, resp = epsilla.query(query_vector=first[0].tolist(), filter="", **kw)       # the first search uploads the table to the device
+        out["first_query_s"] = time.perf_counter() - t0
+        out["first_query_top"] = [resp[0]["ID"], resp[0]["@distance"]]
+        t0 = time.perf_counter()
+        code, arr = epsilla.query_batch(query_vectors=first, filter="", as_arrays=True, **kw)
+        out["batch64_s"] = time.perf_counter() - t0
+        out["batch64_self_hits"] = int((arr["ID"][:, 0] == np.arange(64)).sum())              # every query is a table row: its own nearest neighbour
+        print("EPSILLA_JSON " + json.dumps(out))
+        sys.exit(0)
+    assert epsilla.load_db(db_name="db", db_path=db_path) == 0
+    epsilla.use_db(db_name="db")
+    fields = [{"name": "ID", "dataType": "INT", "primaryKey": True}, {"name": "Tag", "dataType": "INT"}, {"name": "Score", "dataType": "FLOAT"},
+              {"name": "Weight", "dataType": "DOUBLE"}, {"name": "Flag", "dataType": "BOOL"}, {"name": "Name", "dataType": "STRING"},
+              {"name": "VL2", "dataType": "VECTOR_FLOAT", "dimensions": dim, "metricType": "EUCLIDEAN"},
+              {"name": "VIP", "dataType": "VECTOR_FLOAT", "dimensions": dim, "metricType": "DOT_PRODUCT"},
+              {"name": "VCOS", "dataType": "VECTOR_FLOAT", "dimensions": dim, "metricType": "COSINE"}]
+    create_table("J", [dict(f) for f in fields])
+    create_table("A", [dict(f) for f in fields])
+    rng = np.random.default_rng(42)
+    X = rng.random((rows, dim), dtype=np.float32) - np.float32(0.25)
+    X[7] = 0.0                                                      # a zero vector: COSINE leaves it alone (|v|^2 <= 1e-10)
+    X[8] = 1e-7                                                     # ... and one just below the rule's threshold
+    ids = np.arange(rows, dtype=np.int64)
+    ids[rows // 3] = 5                                              # duplicate keys: inside a batch, ...
+    ids[rows - 1] = 17                                              # ... across batches, and as the LAST record of the last batch
+    tag = rng.integers(0, 100, rows).astype(np.int32)
+    score = rng.random(rows, dtype=np.float32)
+    weight = rng.random(rows)
+    flag = rng.integers(0, 2, rows).astype(np.bool_)
+    names = ["n%d" % (i % 977) for i in range(rows)]
+    Q = np.random.default_rng(43).random((nq, dim), dtype=np.float32) - np.float32(0.25)
+    step = 1000
+    t0 = time.perf_counter()
+    codes = []
+    for s in range(0, rows, step):
+        e = min(rows, s + step)
+        codes.append(epsilla.insert(table_name="J", records=[
+            {"ID": int(ids[i]), "Tag": int(tag[i]), "Score": float(score[i]), "Weight": float(weight[i]), "Flag": bool(flag[i]), "Name": names[i],
+             "VL2": X[i].tolist(), "VIP": X[i].tolist(), "VCOS": X[i].tolist()} for i in range(s, e)]))
+    out["json_insert_s"] = time.perf_counter() - t0
+    out["json_codes_ok"] = all(c == 0 for c in codes)
+    t0 = time.perf_counter()
+    res = []
+    big = 7 * step                                                   # (different batch boundaries: the segment state must not depend on them)
+    for s in range(0, rows, big):
+        e = min(rows, s + big)
+        res.append(epsilla.insert_array(table_name="A", columns={
+            "ID": ids[s:e], "Tag": tag[s:e], "Score": score[s:e], "Weight": weight[s:e], "Flag": flag[s:e], "Name": names[s:e],
+            "VL2": X[s:e], "VIP": X[s:e].astype(np.float64), "VCOS": X[s:e]}))
+    out["array_insert_s"] = time.perf_counter() - t0
+    out["array_results"] = res
+    gone = [3, 11, int(ids[rows // 2]), int(ids[rows - 2])]
+    out["delete_codes"] = [epsilla.delete(table_name=t, primary_keys=gone) for t in ("J", "A")]
+    out["answers"] = {}
+    for t in ("J", "A"):
+        ans = {}
+        for field in ("VL2", "VIP", "VCOS"):
+            for flt in ("", "Tag < 50", "Flag = true AND Score < 0.5"):
+                rows_out = []
+                for q in Q[:8]:
+                    code, resp = epsilla.query(table_name=t, query_field=field, response_fields=["ID", "Tag", "Score", "Weight", "Flag", "Name", field],
+                                               query_vector=q.tolist(), filter=flt, limit=10, with_distance=True)
+                    rows_out.append([code, resp])
+                ans["query|%s|%s" % (field, flt)] = rows_out
+                code, resp = epsilla.query_batch(table_name=t, query_field=field, query_vectors=Q, response_fields=["ID"], limit=10, filter=flt,
+                                                 with_distance=True)
+                ans["batch|%s|%s" % (field, flt)] = [code, [[[r["ID"] for r in rr], [r["@distance"] for r in rr]] for rr in resp]]
+        out["answers"][t] = ans
+    # beyond the capacity (the binding loads databases with 150000 rows per table): both paths refuse, with the same text
+    over = 150001 - rows
+    try:
+        epsilla.insert_array(table_name="A", columns={
+            "ID": np.arange(10 ** 6, 10 ** 6 + over, dtype=np.int64), "Tag": np.zeros(over, np.int32), "Score": np.zeros(over, np.float32),
+            "Weight": np.zeros(over), "Flag": np.zeros(over, np.bool_), "Name": ["x"] * over, "VL2": np.zeros((over, dim), np.float32),
+            "VIP": np.zeros((over, dim), np.float32), "VCOS": np.zeros((over, dim), np.float32)})
+        out["capacity_error"] = None
+    except Exception as e:  # noqa: BLE001
+        out["capacity_error"] = str(e)
+    try:
+        epsilla.insert_array(table_name="A", columns={"ID": ids[:4]})
+        out["missing_field_error"] = None
+    except Exception as e:  # noqa: BLE001
+        out["missing_field_error"] = str(e)
+    code, r = epsilla.insert_array(table_name="A", columns={
+        "ID": np.array([5, 10 ** 7], np.int64), "Tag": np.array([1, 2], np.int32), "Score": np.zeros(2, np.float32), "Weight": np.zeros(2),
+        "Flag": np.ones(2, np.bool_), "Name": ["upserted", "new"], "VL2": Q[:2], "VIP": Q[:2], "VCOS": Q[:2]}, upsert=True)
+    out["upsert"] = [code, r]
+    code, resp = epsilla.query(table_name="A", query_field="VL2", response_fields=["ID", "Name"], query_vector=Q[0].tolist(), filter="", limit=2, with_distance=True)
+    out["after_upsert"] = resp
     print("EPSILLA_JSON " + json.dumps(out))
     sys.exit(0)
 

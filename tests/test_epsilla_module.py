@@ -162,3 +162,32 @@ except BaseException as e:
     else:
         assert "ANSWERED" not in out and ("REFUSED" in out or r.returncode != 0), out[-2000:]
         assert "gfx950" in out, out[-2000:]
+
+
+@pytest.mark.gpu
+def test_gfx950_module_insert_array_leaves_the_table_the_json_insert_leaves():
+    """insert_array() - records as column buffers - against the reference's own ingest (insert(): JSON ->
+    TableMVP::Insert -> TableSegmentMVP::Insert, engine/db/table_segment_mvp.cpp:455-808) on the same records in the same module: 100 000
+    records, three vector fields (EUCLIDEAN / DOT_PRODUCT / COSINE: rows normalised at insert exactly as :574-587, the zero vector left
+    alone), INT / FLOAT / DOUBLE / BOOL / STRING attributes, duplicate primary keys inside a batch, across batches and at the very end,
+    different batch boundaries on the two sides, deletes afterwards.  Every query() / query_batch() answer - ids, distances, attributes,
+    the stored vectors themselves - is identical; capacity and missing-field errors read like the reference's; upsert replaces a row."""
+    if not _have(GPU_DIR):
+        pytest.skip("dropin/_build/epsilla.so not built (make -C dropin)")
+    rows = 100_000
+    out = _run(GPU_DIR, "ingest", rows, 48, 40)
+    assert out["json_codes_ok"] and out["delete_codes"] == [0, 0]
+    ins = sum(r[1]["inserted"] for r in out["array_results"])
+    skp = sum(r[1]["skipped"] for r in out["array_results"])
+    assert all(r[0] == 0 for r in out["array_results"]) and (ins, skp) == (rows - 2, 2), out["array_results"]
+    J, A = out["answers"]["J"], out["answers"]["A"]
+    assert set(J) == set(A) and len(J) == 18
+    for key in J:
+        assert J[key] == A[key], key                     # (JSON round trip of the SAME floats on both sides: equality, not closeness)
+    some = J["query|VCOS|"][0][1]
+    assert len(some) == 10 and abs(sum(v * v for v in some[0]["VCOS"]) - 1.0) < 1e-5
+    assert out["capacity_error"] and "can hold up to 150000 records" in out["capacity_error"]
+    assert out["missing_field_error"] and "missing field: Tag" in out["missing_field_error"]
+    assert out["upsert"] == [0, {"inserted": 2, "skipped": 0}]
+    assert [r["Name"] for r in out["after_upsert"]] == ["upserted", "new"] or out["after_upsert"][0]["Name"] == "upserted"
+    assert out["array_insert_s"] < 0.2 * out["json_insert_s"], (out["array_insert_s"], out["json_insert_s"])

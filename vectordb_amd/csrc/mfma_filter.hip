@@ -110,11 +110,11 @@ struct HalfMirror {
                                 // one bitset (bit set = row invisible), which the pass and its re-rank then read as a deleted bitset
   // rows version on which the one-pass form overflowed twice in a row (the staged chain serves it); [0]: k <= 16, [1]: k = 17..64 - a larger k
   // passes more rows against the same lists, and must not talk the table out of the form for the small-k traffic
-  int64_t s8_declined_version[2] = {-1, -1};
-  int s8_overflows[2] = {0, 0};
+  int64_t s8_declined_version[4] = {-1, -1, -1, -1};
+  int s8_overflows[4] = {0, 0, 0, 0};
   // under a deleted bitset / an int-column filter an overflow usually means "fewer than k rows visible": the rows' version says nothing
   // about it, so two such overflows in a row make the next 32 filtered calls go straight to the staged chain, then the one-pass form is tried again
-  int s8_filt_overflows[2] = {0, 0}, s8_filt_skip[2] = {0, 0};   // (per k class, as above)
+  int s8_filt_overflows[4] = {0, 0, 0, 0}, s8_filt_skip[4] = {0, 0, 0, 0};   // (per class, as above)
   int s8_cus = 0;               // CUs of the device (grid of the one-pass kernel)
   // r5: the call's two result counters land in host-mapped memory (written by the last block of the re-rank launch), read after the stream
   // sync: no device-to-host copy at the end of a 0.2 ms call
@@ -958,6 +958,15 @@ static int32_t ensure_mirror8(Index& ix) {
         rc = clip_range();
         if (rc != EPS_OK) return rc;
       }
+      // Rotated frame: every column is a signed mean of 256 values - near-Gaussian tails, so the whole table's range is only ~1.2 x the range
+      // that leaves 1e-7 of the sample outside.  Taking it means NO row is clamped: all rows keep the plain rounding residual, the table-wide
+      // margin is as tight as per-row margins would be, nothing is folded per batch, and the one-pass search (which reads the rows' own start
+      // values, stream8_kernel.hpp) serves the table: 1M x 768 embedding-like rows, one query per call: 0.38 ms on the staged chain with
+      // folded margins (profiles/r6_rotated_frame_one_pass_1M.txt).  An outlier that would stretch the grid further than that keeps the cut.
+      if (rot && g->ok && (clo > lo || chi < hi) && (hi - lo) <= 1.35f * (chi - clo)) {
+        clo = lo;
+        chi = hi;
+      }
       g->z0 = g->ok ? 0.5f * clo + 0.5f * chi : 0.f;
       g->half = g->ok ? std::max(chi - g->z0, g->z0 - clo) : 127.f;
       g->step = g->half / 127.f;
@@ -1136,7 +1145,9 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
   const int max_q = tune_env("EPS_S8_MAX_Q") ? std::min(S8_MAX_Q, std::max(1, atoi(tune_env("EPS_S8_MAX_Q")))) : S8_MAX_Q;   // (A/B switch: 4 = the r4 form, 5+ queries on the staged chain)
   const int max_k = tune_env("EPS_S8_MAX_K") ? std::min(S8_MAX_K, std::max(1, atoi(tune_env("EPS_S8_MAX_K")))) : S8_MAX_K;   // (A/B switch: 16 = the r4 range, larger k on the staged chain)
   if (nq < 1 || nq > max_q || k < 1 || k > max_k || m.fold8 || n < 65536 || n > m.n8 || m.d_pad8 % 256 != 0 || pieces < 2 || pieces > 4) return EPS_OK;
-  const int kclass = k <= 16 ? 0 : 1;
+  // (r6: ... and per kernel form - five or more queries share one list budget per query and overflow on tables where one query does not:
+  // an 8-query batch must not talk the table out of the form for single-query traffic)
+  const int kclass = (k <= 16 ? 0 : 1) + (nq <= 4 ? 0 : 2);
   if (m.s8_declined_version[kclass] == ix.rows_version_) return EPS_OK;
   FilterSpec fs = ix.filter_spec();
   // a compiled filter program: evaluated once per row into a bitset (filter_mask_kernel) that pass and re-rank read as a deleted bitset.  Only
