@@ -800,6 +800,35 @@ def main():
         build()
     if world > 1:
         dist.barrier()
+    # r6: the exchange step of the measured path belongs to the LIBRARY (eps_exchange: its own RCCL communicator, ncclAllGather + k-way merge in one
+    # call).  torch.distributed only bootstraps it - the 128-byte unique id travels in one broadcast - and keeps the control plane (barriers, the
+    # max over ranks, the ranks' identity).  Ranks that share a device (EPS_BENCH_BACKEND=gloo: the one-GPU plumbing runs) cannot form an RCCL
+    # communicator; they keep the host-staged all-gather + eps_merge_topk_packed, and the line says so (exchange.collective).
+    xchg = None
+    xchg_note = None
+    if world > 1 and backend == "nccl" and os.environ.get("EPS_BENCH_EXCHANGE", "eps") == "eps":
+        box = [None]
+        if rank == 0:
+            try:
+                box[0] = amd.Exchange.unique_id()
+            except Exception as e:  # noqa: BLE001
+                box[0] = "failed: %r" % (e,)
+        dist.broadcast_object_list(box, src=0)
+        if isinstance(box[0], (bytes, bytearray)):
+            ok = 1
+            try:
+                xchg = amd.Exchange(rank, world, box[0], device=local_rank)
+            except Exception as e:  # noqa: BLE001
+                ok, xchg_note = 0, "eps_exchange_create failed on rank %d: %r" % (rank, e)
+            okt = torch.tensor([ok], dtype=torch.int32, device=torch.device("cuda", local_rank))
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            if int(okt.item()) == 0:   # (all ranks or none)
+                if xchg is not None:
+                    xchg.close()
+                xchg = None
+                xchg_note = xchg_note or "eps_exchange_create failed on another rank"
+        else:
+            xchg_note = "eps_exchange_unique_id %s" % (box[0],)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     n, d, b, k = args.rows, args.dim, args.batch, args.k
@@ -861,10 +890,15 @@ def main():
             if timed:
                 ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
                 ev[0].record()
-            all_gather(gathered, packs[slot])
-            if timed:
-                ev[1].record()
-            amd.merge_topk_packed(gathered, pack_n, b * k * 8, world, b, k, m_ds[slot], m_is[slot], device=local_rank, stream=stream)
+            if xchg is not None:   # one library call: ncclAllGather of the packed lists + the merge (its own hipEvents split the two)
+                xchg.allgather_merge(idss[slot], dds[slot], m_is[slot], m_ds[slot], stream=stream)
+                if timed:
+                    ev[1].record()
+            else:
+                all_gather(gathered, packs[slot])
+                if timed:
+                    ev[1].record()
+                amd.merge_topk_packed(gathered, pack_n, b * k * 8, world, b, k, m_ds[slot], m_is[slot], device=local_rank, stream=stream)
             if timed:
                 ev[2].record()
                 xev.append(ev)
@@ -895,6 +929,8 @@ def main():
     main_ms = ix.kernel_times(64)[-args.steps:]
     st = ix.stats()
     xchg_us = [(e[0].elapsed_time(e[1]) * 1e3, e[1].elapsed_time(e[2]) * 1e3) for e in xev]
+    if xchg is not None:   # (the library's own event triples of the timed steps: all-gather | merge)
+        xchg_us = xchg.times_us(64)[-args.steps:]
 
     # ---- the same steps END TO END ("QPS end-to-end including H2D of queries and D2H of results"; the reference's entry takes a
     # host vector per call, table_mvp.cpp:359-380): every batch starts in host memory and its ids / distances end in host memory,
@@ -1130,7 +1166,8 @@ def main():
         }
         if world > 1:
             # one all-gather of pack_n bytes per rank and step (12 B x k x batch), then a k-way merge on every rank
-            res["exchange"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "collective": "all_gather_into_tensor" if backend == "nccl" else "all_gather (host staged)",
+            res["exchange"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "collective": ("eps_exchange (rccl)" if xchg is not None else ("all_gather_into_tensor" if backend == "nccl" else "all_gather (host staged)")),
+                               "library": xchg.info() if xchg is not None else None, "fallback_reason": xchg_note,
                                "bytes_per_rank_per_step": int(pack_n), "bytes_gathered_per_rank_per_step": int(pack_n * world),
                                "all_gather_us_per_step": [round(x[0], 1) for x in xchg_us], "merge_us_per_step": [round(x[1], 1) for x in xchg_us],
                                "all_gather_us_mean": float(np.mean([x[0] for x in xchg_us])) if xchg_us else None,

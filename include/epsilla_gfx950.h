@@ -321,6 +321,29 @@ int32_t eps_merge_topk(const float* dist, const int64_t* ids, int32_t shards, in
 int32_t eps_merge_topk_packed(const void* gathered, int64_t shard_stride_bytes, int64_t dist_offset_bytes, int32_t shards,
                               int64_t nq, int32_t k, float* out_dist, int64_t* out_ids, int32_t device, void* hip_stream);
 
+/* ---- The exchange step of the sharded path, owned by the library (r6).  One process per GPU: every rank holds, for the whole
+ * batch, the top-k lists over ITS shard (global ids); eps_exchange_allgather_merge packs them as [ids int64[nq][k] | dist f32[nq][k]]
+ * (12 k nq bytes per rank), runs ONE ncclAllGather on the RCCL communicator the handle owns (xGMI inside a node) and merges the `world`
+ * sorted lists of every query by (dist, id) - every rank ends with the same global top-k in out_ids / out_dist.  Lists, results and the
+ * stream belong to the rank's device; the call is asynchronous on that stream.  RCCL is resolved at run time (dlopen; a copy the process
+ * already holds - PyTorch ships one - is the one used).  Bootstrap, the caller's only part: rank 0 fills 128 bytes with
+ * eps_exchange_unique_id and sends them to every rank (bench.py: a gloo broadcast), every rank calls eps_exchange_create (collective:
+ * returns when all `world` ranks have joined).  *out is set even on failure (its message: eps_exchange_last_error).  world <= 16.
+ * The reference has no counterpart (no sharding, SURVEY 8e "Semantics vs reference"): sharded exact top-k == unsharded exact top-k. */
+#define EPS_EXCHANGE_ID_BYTES 128
+typedef struct eps_exchange eps_exchange;
+int32_t eps_exchange_unique_id(void* id128);
+int32_t eps_exchange_create(int32_t rank, int32_t world, const void* id128, int32_t device, eps_exchange** out);
+int32_t eps_exchange_allgather_merge(eps_exchange* x, const int64_t* ids, const float* dist, int64_t nq, int32_t k, int64_t* out_ids, float* out_dist,
+                                     void* hip_stream);
+/* device time of the two parts - all-gather, merge - of the last calls (hipEvents on their stream, kept for 64 calls; waits for them):
+ * us_pairs[2 i], us_pairs[2 i + 1] for the oldest .. newest of min(calls, 64, max_calls) calls; returns how many (-1: failure) */
+int32_t eps_exchange_times(eps_exchange* x, double* us_pairs, int32_t max_calls);
+/* what the handle runs on: rank, world, RCCL's version number and the path of the library that answers */
+int32_t eps_exchange_info(eps_exchange* x, int32_t* rank, int32_t* world, int32_t* rccl_version, char* rccl_path, int64_t cap);
+const char* eps_exchange_last_error(eps_exchange* x);
+void eps_exchange_destroy(eps_exchange* x);
+
 /* Engine-selection switches.  The library reads NO environment variable: what used to be lab switches are entries of one
  * process-wide table that only this call writes (name, value as text; value == NULL removes the entry; name == NULL empties
  * the table).  No entry changes a result - they pick between engines that return the same bits (tests/ run every answer

@@ -429,7 +429,9 @@ def test_start_up_wait_reads_a_median_offer_not_the_worst(k, slots):
 # distances do not change, and every y column is a signed mean of 256 values of the row - no column dominates, the step shrinks to what the
 # row's norm needs.  The transform runs in fp64, y - mu is rounded to fp32 once.
 def d_pad8_of(d):
-    return max(512, (d + 255) // 256 * 256)
+    """the rotation's width: the row's columns rounded up to whole 256-column blocks (the mirror's row pitch is at least 512 bytes: columns beyond
+    the rotation's width stay zero and enter nothing)"""
+    return (d + 255) // 256 * 256
 
 
 def rotation_table(d_pad8):

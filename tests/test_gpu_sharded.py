@@ -220,3 +220,38 @@ def test_dropin_rebuild_builds_per_shard_graphs_on_the_mirror(tmp_path):
         assert any(x["ID"] >= n for rc, d in outs[1] for x in d) == any(x["ID"] >= n for rc, r in outs[0] for x in r)
     finally:
         os.environ.pop("EPS_DEVICES", None)
+
+
+def test_library_owned_exchange_on_rccl_world_of_one(amd):
+    """eps_exchange (include/epsilla_gfx950.h, r6): the library's own RCCL communicator, ncclAllGather of the packed lists, k-way merge.  One GPU on
+    this box, so the communicator has ONE rank (RCCL refuses two ranks on a device): that still runs the whole chain - dlopen of RCCL (the copy the
+    process already holds: torch's), unique id, ncclCommInitRank, the in-place / out-of-place all-gather, merge_shards_kernel, the event ring - and
+    the merged answer of a world of one is its own lists.  Several batch shapes, packed and separate buffers, -1 padded short lists."""
+    import torch
+    dev = torch.device("cuda", 0)
+    x = amd.Exchange(0, 1, amd.Exchange.unique_id(), device=0)
+    info = x.info()
+    assert info["world"] == 1 and info["rccl_version"] > 0 and "rccl" in info["rccl_library"], info
+    g = torch.Generator(device=dev).manual_seed(3)
+    for nq, k in ((1, 10), (7, 3), (1024, 10), (33, 100)):
+        dist = torch.sort(torch.rand((nq, k), generator=g, device=dev), dim=1).values
+        ids = torch.randint(0, 1 << 40, (nq, k), generator=g, device=dev, dtype=torch.int64)
+        if nq > 1:
+            ids[1, k // 2:] = -1                       # a short list: -1 beyond its count
+        pack = torch.empty(((nq * k * 12 + 7) // 8 * 8,), dtype=torch.uint8, device=dev)   # the packed layout bench.py searches into
+        p_ids = pack[: nq * k * 8].view(torch.int64).view(nq, k)
+        p_dd = pack[nq * k * 8: nq * k * 12].view(torch.float32).view(nq, k)
+        p_ids.copy_(ids)
+        p_dd.copy_(dist)
+        for a_ids, a_dd in ((ids, dist), (p_ids, p_dd)):
+            o_i = torch.full((nq, k), 7, dtype=torch.int64, device=dev)
+            o_d = torch.zeros((nq, k), dtype=torch.float32, device=dev)
+            x.allgather_merge(a_ids, a_dd, o_i, o_d, stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            want_i, want_d = ids.clone(), dist.clone()
+            if nq > 1:
+                want_d[1, k // 2:] = float("inf")
+            assert torch.equal(o_i, want_i) and torch.equal(o_d, want_d), (nq, k)
+    t = x.times_us(8)
+    assert len(t) == 8 and all(a >= 0 and b >= 0 for a, b in t)
+    x.close()

@@ -29,6 +29,8 @@ EXPORTS = [
     "eps_index_set_int_filter", "eps_index_set_filter_program", "eps_index_set_filter_program_ex", "eps_index_search_walk", "eps_index_select_edges", "eps_index_inter_insert", "eps_index_knn_graph", "eps_index_link", "eps_index_build", "eps_index_set_graph", "eps_index_graph_info",
     "eps_index_get_graph", "eps_index_save_graph", "eps_index_load_graph", "eps_index_search",
     "eps_index_last_stats", "eps_index_kernel_times", "eps_normalize_rows", "eps_merge_topk", "eps_merge_topk_packed", "eps_set_tuning",
+    "eps_exchange_unique_id", "eps_exchange_create", "eps_exchange_allgather_merge", "eps_exchange_times", "eps_exchange_info", "eps_exchange_last_error",
+    "eps_exchange_destroy",
 ]
 
 # Engine-selection switches of the library (eps_set_tuning, include/epsilla_gfx950.h).  The library itself reads no environment
@@ -190,6 +192,15 @@ def load():
     L.eps_index_kernel_times.argtypes = [vp, C.POINTER(C.c_double), i32]
     L.eps_merge_topk_packed.argtypes = [vp, i64, i64, i32, i64, i32, vp, vp, i32, vp]
     L.eps_set_tuning.argtypes = [C.c_char_p, C.c_char_p]
+    L.eps_exchange_unique_id.argtypes = [vp]
+    L.eps_exchange_create.argtypes = [i32, i32, vp, i32, C.POINTER(vp)]
+    L.eps_exchange_allgather_merge.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp]
+    L.eps_exchange_times.argtypes = [vp, C.POINTER(C.c_double), i32]
+    L.eps_exchange_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.c_char_p, i64]
+    L.eps_exchange_last_error.argtypes = [vp]
+    L.eps_exchange_last_error.restype = C.c_char_p
+    L.eps_exchange_destroy.argtypes = [vp]
+    L.eps_exchange_destroy.restype = None
     for name in EXPORTS:
         if getattr(L, name).restype is C.c_int:
             getattr(L, name).restype = i32

@@ -10,7 +10,7 @@ SRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib")
 OBJ = os.path.join(OUT, "obj")
 LIB = os.path.join(OUT, "libepsilla_gfx950.so")
-SOURCES = ["index.cpp", "shard_group.cpp", "flat_kernels.hip", "traverse.hip", "mfma_filter.hip", "graph_build.hip"]
+SOURCES = ["index.cpp", "shard_group.cpp", "exchange.cpp", "flat_kernels.hip", "traverse.hip", "mfma_filter.hip", "graph_build.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-I" + os.path.join(os.path.dirname(HERE), "include")]
 
@@ -61,7 +61,7 @@ def build(force=False, verbose=False):
         with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             list(ex.map(run, jobs))
     if jobs or not os.path.exists(LIB):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"])   # (-ldl: exchange.cpp resolves RCCL at run time)
     return LIB
 
 

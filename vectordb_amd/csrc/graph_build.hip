@@ -609,8 +609,8 @@ int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp, const Buil
     if (rc != EPS_OK) q8v = Quant8View();   // (optional: without the mirror the searches read the fp32 rows, the graph is the same)
     prefilter = q8v.x8 != nullptr;
   }
-  const size_t trv_shm = traverse_lds_bytes(dim, Lp2, true, prefilter);
-  const size_t trv_shm_bm = traverse_lds_bytes(dim, Lp2, false, prefilter);
+  const size_t trv_shm = traverse_lds_bytes(dim, Lp2, true, prefilter, q8v.cols8);
+  const size_t trv_shm_bm = traverse_lds_bytes(dim, Lp2, false, prefilter, q8v.cols8);
   const size_t prn_shm = prune_lds_bytes(dim, R);
   TraverseArgs ta;
   ta.rows = ix.d_rows_;
@@ -641,6 +641,7 @@ int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp, const Buil
   ta.q8 = nullptr;
   ta.qstat8 = nullptr;
   ta.d_pad8 = q8v.d_pad8;
+  ta.cols8 = q8v.cols8;
   ta.u8 = q8v.u;
   {
     const int G = group_lanes(dim, vec4);

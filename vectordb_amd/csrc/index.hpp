@@ -37,6 +37,8 @@ struct Quant8View {   // the table's 8-bit mirror as other kernels see it (mfma_
   const float* scal8 = nullptr;
   const float* mu = nullptr;   // [d_pad8] the grid's centre (one value per column)
   int d_pad8 = 0;
+  int cols8 = 0;          // columns of a mirror row that carry values: dim (identity frame), dim rounded up to 256 (rotated frame, r6) - what a kernel that reads
+                          // a row's leading bytes only (the traversal's prefilter) must cover
   float step = 1.f, u = 1.f;
   int64_t epoch8 = 0;     // counts the mirror's (re)builds: row constants copied elsewhere (the graph's edge constants) are stale when it moves
   bool per_batch = false; // acc0 carries per-batch margins (fold8): it changes with every batch of queries

@@ -95,6 +95,7 @@ struct HalfMirror {
   // r6: the grid's frame (device_common.hpp, rot256_load): rot8 = rows and queries are quantised as R x; sp8 = int32 [d_pad8], R's
   // permutation and signs.  Chosen on the first build from the steps the two frames need on the same sample; kept when rows are appended.
   bool rot8 = false;
+  int rot_w8 = 0;               // columns the rotation covers: dim rounded up to 256 (<= d_pad8; the columns beyond stay zero)
   DevBuf sp8;
   float step8_identity = 0.f, step8_rotated = 0.f;   // what the choice saw (stats; 0 = that frame was not measured)
   bool i8_trusted = false;      // the library's own choice has seen a batch through the 8-bit pass on this mirror (no probe needed)
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(256) void minmax_kernel(const float* rows, int64_t 
   const bool vec = (dim & 3) == 0 && ((reinterpret_cast<uintptr_t>(rows) & 15) == 0);
   for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += nwaves) {
     const float* src = rows + r * dim;
-    if (ROT) {   // the rotated frame (device_common.hpp, rot256_load): all d_pad8 columns carry values
+    if (ROT) {   // the rotated frame (device_common.hpp, rot256_load): d_pad8 here = the rotation's width
       for (int c = lane * 4; c < d_pad8; c += 256) {
         double xd[4];
         rot256_load(src, dim, sp, c, lane, xd);
@@ -451,11 +452,11 @@ __global__ void scal_finish_kernel(float* scal8, float* scal8f) {
 }
 
 // rows [row0, n_pad) are (re)written, as in half_mirror_kernel.  x' = x - mu;  metric 0: R = |x'|^2; otherwise R = -mu.x'.  u = |s| step^2.
-// ROT: the table's rotated frame (device_common.hpp, rot256_load) - x' = fl32(R x - mu), all d_pad8 columns carry values
+// ROT: the table's rotated frame (device_common.hpp, rot256_load) - x' = fl32(R x - mu); the first rot_w = ceil(dim / 256) * 256 columns carry values
 template <bool ROT>
 __global__ __launch_bounds__(256) void quant_mirror_kernel(const float* rows, int64_t row0, int64_t n, int64_t n_pad, int dim, int d_pad8, const float* mu, float step,
                                                            float inv_step, float inv_u, int metric, signed char* x8, int* acc0, float* scal8, float* erow,
-                                                           float* hrow, u32* forced_count, const int* sp) {
+                                                           float* hrow, u32* forced_count, const int* sp, int rot_w) {
   const int lane = lane_id();
   const int64_t nwaves = (int64_t)gridDim.x * 4;
   float m_e1 = 0.f, m_nxh = 0.f, m_xn = 0.f, m_bad = 0.f, m_r = 0.f, m_emin = __builtin_inff();
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(256) void quant_mirror_kernel(const float* rows, in
       float xs[4] = {0.f, 0.f, 0.f, 0.f};
       double xd[4] = {0.0, 0.0, 0.0, 0.0};
       if (ROT) {
-        rot256_load(src, dim, sp, c, lane, xd);
+        if (c < rot_w) rot256_load(src, dim, sp, c, lane, xd);   // (columns [rot_w, d_pad8): padding, zero codes)
 #pragma unroll
         for (int e = 0; e < 4; ++e) xs[e] = (float)xd[e];   // (enters |x|^2 only: a slack scale)
       } else if (vec) {
@@ -494,7 +495,7 @@ __global__ __launch_bounds__(256) void quant_mirror_kernel(const float* rows, in
       u32 packed = 0;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        if (ROT || c + e < dim) {
+        if (ROT ? c < rot_w : c + e < dim) {
           const float dx = ROT ? (float)(xd[e] - (double)ms[e]) : xs[e] - ms[e];   // x' (one rounding in either frame)
           const int xi = quant8(dx, 0.f, inv_step);
           const float res = fmaf(-step, (float)xi, dx);     // x' - xh'
@@ -567,7 +568,7 @@ struct Prep8Extra {
 };
 template <bool ROT>
 __global__ __launch_bounds__(256) void query_prep8_kernel(const float* q, int64_t nq, int64_t b_pad, int dim, int d_pad8, const float* mu, float step, float inv_step,
-                                                          int metric, signed char* q8, float* qstat, Prep8Extra x, const int* sp) {
+                                                          int metric, signed char* q8, float* qstat, Prep8Extra x, const int* sp, int rot_w) {
   if (blockIdx.x == 0) {   // the seeded call's start state (nothing in this launch reads it)
     for (int64_t i = threadIdx.x; x.T2 && i < x.n2; i += 256) x.T2[i] = x.Tv;
     for (int64_t i = threadIdx.x; x.cnt && i < (x.s8g ? S8_MAX_Q + 8 : nq + 8); i += 256) x.cnt[i] = i < nq ? x.cntv : 0u;
@@ -600,10 +601,10 @@ __global__ __launch_bounds__(256) void query_prep8_kernel(const float* q, int64_
   for (int c = lane * 4; c < d_pad8; c += 256) {
     u32 packed = 0;
     double xd[4] = {0.0, 0.0, 0.0, 0.0};
-    if (ROT) rot256_load(src, dim, sp, c, lane, xd);   // the query in the table's rotated frame
+    if (ROT && c < rot_w) rot256_load(src, dim, sp, c, lane, xd);   // the query in the table's rotated frame
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      if (ROT || c + e < dim) {
+      if (ROT ? c < rot_w : c + e < dim) {
         const float xv = ROT ? (float)xd[e] : src[c + e];
         const float m = mu[c + e];
         const float dx = ROT ? (float)(xd[e] - (double)m) : xv - m;
@@ -639,10 +640,10 @@ __global__ __launch_bounds__(256) void query_prep8_kernel(const float* q, int64_
 }
 
 // (the frame is the mirror's: HalfMirror::rot8 / sp8)
-static void launch_query_prep8(dim3 grid, hipStream_t s, const int* sp, const float* q, int64_t nq, int64_t b_pad, int dim, int d_pad8, const float* mu, float step,
+static void launch_query_prep8(dim3 grid, hipStream_t s, const int* sp, int rot_w, const float* q, int64_t nq, int64_t b_pad, int dim, int d_pad8, const float* mu, float step,
                                int metric, signed char* q8, float* qstat, const Prep8Extra& x) {
-  if (sp) hipLaunchKernelGGL(query_prep8_kernel<true>, grid, dim3(256), 0, s, q, nq, b_pad, dim, d_pad8, mu, step, 1.f / step, metric, q8, qstat, x, sp);
-  else hipLaunchKernelGGL(query_prep8_kernel<false>, grid, dim3(256), 0, s, q, nq, b_pad, dim, d_pad8, mu, step, 1.f / step, metric, q8, qstat, x, (const int*)nullptr);
+  if (sp) hipLaunchKernelGGL(query_prep8_kernel<true>, grid, dim3(256), 0, s, q, nq, b_pad, dim, d_pad8, mu, step, 1.f / step, metric, q8, qstat, x, sp, rot_w);
+  else hipLaunchKernelGGL(query_prep8_kernel<false>, grid, dim3(256), 0, s, q, nq, b_pad, dim, d_pad8, mu, step, 1.f / step, metric, q8, qstat, x, (const int*)nullptr, 0);
 }
 
 // T[j]: pass threshold of query j for the next filter launch, from the current k-th best key (formulas: device_common.hpp,
@@ -844,18 +845,20 @@ static int32_t ensure_mirror8(Index& ix) {
     // r6: the frame.  0 = identity, 1 = rotated, otherwise the library's choice (both measured, below)
     const char* rot_e = tune_env("EPS_MIRROR_ROTATE");
     const int rot_mode = rot_e ? atoi(rot_e) : -1;
+    const int W = (dim + 255) / 256 * 256;   // the rotation's width (the mirror pads rows to at least 512 bytes: those columns stay zero)
+    m.rot_w8 = W;
     if (rot_mode != 0) {   // R's permutation and signs: a fixed sequence (splitmix64), the same for every table of this width
-      std::vector<int32_t> sp((size_t)d_pad8);
-      for (int i = 0; i < d_pad8; ++i) sp[(size_t)i] = i;
-      uint64_t st = 0x9E3779B97F4A7C15ull ^ (uint64_t)d_pad8;
+      std::vector<int32_t> sp((size_t)d_pad8, 0);
+      for (int i = 0; i < W; ++i) sp[(size_t)i] = i;
+      uint64_t st = 0x9E3779B97F4A7C15ull ^ (uint64_t)W;
       auto next = [&st]() {
         uint64_t z = (st += 0x9E3779B97F4A7C15ull);
         z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
         z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
         return z ^ (z >> 31);
       };
-      for (int i = d_pad8 - 1; i > 0; --i) std::swap(sp[(size_t)i], sp[(size_t)(next() % (uint64_t)(i + 1))]);
-      for (int i = 0; i < d_pad8; ++i)
+      for (int i = W - 1; i > 0; --i) std::swap(sp[(size_t)i], sp[(size_t)(next() % (uint64_t)(i + 1))]);
+      for (int i = 0; i < W; ++i)
         if (next() & 1ull) sp[(size_t)i] |= (int32_t)0x80000000u;
       if (!m.sp8.reserve((size_t)d_pad8 * 4)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory for the 8-bit mirror");
       er = hipMemcpyAsync(m.sp8.p, sp.data(), (size_t)d_pad8 * 4, hipMemcpyHostToDevice, s);
@@ -871,13 +874,13 @@ static int32_t ensure_mirror8(Index& ix) {
       int64_t sn = n, sstride = stride;
       int sdim = dim;
       if (rot) {
-        if (!rsample.reserve((size_t)sampled * d_pad8 * 4)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory for the 8-bit mirror");
-        hipLaunchKernelGGL(rot_sample_kernel, dim3((unsigned)std::min<int64_t>((sampled + 3) / 4, 8192)), dim3(256), 0, s, ix.d_rows_, n, dim, stride, sampled, d_pad8,
+        if (!rsample.reserve((size_t)sampled * W * 4)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory for the 8-bit mirror");
+        hipLaunchKernelGGL(rot_sample_kernel, dim3((unsigned)std::min<int64_t>((sampled + 3) / 4, 8192)), dim3(256), 0, s, ix.d_rows_, n, dim, stride, sampled, W,
                            m.sp8.as<int>(), rsample.as<float>());
         srows = rsample.as<float>();
         sn = sampled;
         sstride = 1;
-        sdim = d_pad8;
+        sdim = W;
       }
       hipError_t e2 = hipMemsetAsync(m.scal8.p, 0, 32, s);
       if (e2 == hipSuccess) e2 = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(m.scal8.as<u32>() + 6), (int)0xFFFFFFFFu, 1, s);
@@ -887,7 +890,7 @@ static int32_t ensure_mirror8(Index& ix) {
                          (const float*)nullptr, 0.f, 0.f);
       hipLaunchKernelGGL(colmean_kernel, dim3((unsigned)((d_pad8 + 255) / 256)), dim3(256), 0, s, part.as<float>(), sdim, d_pad8, 1.f / (float)sampled, mu_out.as<float>());
       const unsigned mm_grid = (unsigned)std::min<int64_t>((n + 3) / 4, 8192);
-      if (rot) hipLaunchKernelGGL(minmax_kernel<true>, dim3(mm_grid), dim3(256), 0, s, ix.d_rows_, n, dim, mu_out.as<float>(), m.scal8.as<u32>(), m.sp8.as<int>(), d_pad8);
+      if (rot) hipLaunchKernelGGL(minmax_kernel<true>, dim3(mm_grid), dim3(256), 0, s, ix.d_rows_, n, dim, mu_out.as<float>(), m.scal8.as<u32>(), m.sp8.as<int>(), W);
       else hipLaunchKernelGGL(minmax_kernel<false>, dim3(mm_grid), dim3(256), 0, s, ix.d_rows_, n, dim, mu_out.as<float>(), m.scal8.as<u32>(), (const int*)nullptr, d_pad8);
       e2 = hipMemcpyAsync(m.h_scal8, m.scal8.p, 32, hipMemcpyDeviceToHost, s);
       if (e2 == hipSuccess) e2 = hipStreamSynchronize(s);   // (also keeps `part` alive until its readers are done)
@@ -974,7 +977,7 @@ static int32_t ensure_mirror8(Index& ix) {
       return EPS_OK;
     };
     // The choice: a row's residual norm is ~ step x sqrt(columns that carry values / 12) in either frame - the identity frame quantises
-    // `dim` columns, the rotated one all d_pad8 - so the frame with the smaller product gives the tighter margin.  The rotated frame must
+    // `dim` columns, the rotated one W = dim rounded up to 256 - so the frame with the smaller product gives the tighter margin.  The rotated frame must
     // win clearly (0.75): at equal margins the identity frame's query preparation is cheaper, and it is the frame every earlier round measured.
     Grid gi, gr;
     DevBuf mu_rot;
@@ -991,7 +994,7 @@ static int32_t ensure_mirror8(Index& ix) {
       m.step8_rotated = gr.ok ? gr.step : 0.f;
     }
     m.rot8 = rot_mode == 1 || (rot_mode != 0 && gi.ok && gr.ok &&
-                               (double)gr.step * std::sqrt((double)d_pad8) < 0.75 * (double)gi.step * std::sqrt((double)dim));
+                               (double)gr.step * std::sqrt((double)W) < 0.75 * (double)gi.step * std::sqrt((double)dim));
     const Grid& g = m.rot8 ? gr : gi;
     if (m.rot8) {
       er = hipMemcpyAsync(m.mu8.p, mu_rot.p, (size_t)d_pad8 * 4, hipMemcpyDeviceToDevice, s);
@@ -1008,7 +1011,7 @@ static int32_t ensure_mirror8(Index& ix) {
     const float z0 = g.z0;
     m.step8 = g.step;
     if (m.i8_ok) {
-      hipLaunchKernelGGL(mu_finish_kernel, dim3(1), dim3(64), 0, s, m.mu8.as<float>(), m.rot8 ? d_pad8 : dim, z0, m.scal8.as<float>());
+      hipLaunchKernelGGL(mu_finish_kernel, dim3(1), dim3(64), 0, s, m.mu8.as<float>(), m.rot8 ? W : dim, z0, m.scal8.as<float>());
       er = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(m.scal8.as<u32>() + 7), 0x7F800000, 1, s);   // min residual norm: +inf
       if (er != hipSuccess) return ix.hip_fail(er, "memset");
     }
@@ -1020,11 +1023,11 @@ static int32_t ensure_mirror8(Index& ix) {
     if (m.rot8)
       hipLaunchKernelGGL(quant_mirror_kernel<true>, qgrid, dim3(256), 0, s, ix.d_rows_, row0, n, n_pad, dim, d_pad8, m.mu8.as<float>(), m.step8, 1.f / m.step8, 1.f / u,
                          ix.metric_, m.x8.as<signed char>(), m.acc0.as<int>(), m.scal8.as<float>(), m.erow.as<float>(), m.hrow.as<float>(), m.hist.as<u32>() + 4096,
-                         m.sp8.as<int>());
+                         m.sp8.as<int>(), m.rot_w8);
     else
       hipLaunchKernelGGL(quant_mirror_kernel<false>, qgrid, dim3(256), 0, s, ix.d_rows_, row0, n, n_pad, dim, d_pad8, m.mu8.as<float>(), m.step8, 1.f / m.step8, 1.f / u,
                          ix.metric_, m.x8.as<signed char>(), m.acc0.as<int>(), m.scal8.as<float>(), m.erow.as<float>(), m.hrow.as<float>(), m.hist.as<u32>() + 4096,
-                         (const int*)nullptr);
+                         (const int*)nullptr, 0);
     hipLaunchKernelGGL(scal_finish_kernel, dim3(1), dim3(64), 0, s, m.scal8.as<float>(), m.scal8f.as<float>());
     u32 forced = 0;
     er = hipMemcpyAsync(m.h_scal8, m.scal8.p, 32, hipMemcpyDeviceToHost, s);
@@ -1076,6 +1079,7 @@ int32_t quant8_view(Index& ix, Quant8View* v) {
   v->scal8 = m.fold8 ? m.scal8f.as<float>() : m.scal8.as<float>();
   v->mu = m.mu8.as<float>();
   v->d_pad8 = m.d_pad8;
+  v->cols8 = m.rot8 ? m.rot_w8 : (int)ix.dim_;
   v->step = m.step8;
   v->u = (ix.metric_ == 0 ? 2.f : 1.f) * m.step8 * m.step8;
   v->epoch8 = m.epoch8;
@@ -1091,7 +1095,7 @@ void quant8_queries(Index& ix, const Quant8View& v, const float* dq, int64_t nq,
     px.qmax = m.qmax.as<u32>();
     (void)hipMemsetAsync(m.qmax.p, 0, 8, ix.stream_);
   }
-  launch_query_prep8(dim3((unsigned)((nq + 3) / 4)), ix.stream_, m.rot8 ? m.sp8.as<int>() : nullptr, dq, nq, nq, (int)ix.dim_, v.d_pad8, v.mu, v.step, ix.metric_, q8,
+  launch_query_prep8(dim3((unsigned)((nq + 3) / 4)), ix.stream_, m.rot8 ? m.sp8.as<int>() : nullptr, m.rot_w8, dq, nq, nq, (int)ix.dim_, v.d_pad8, v.mu, v.step, ix.metric_, q8,
                      qstat, px);
   if (m.fold8)
   hipLaunchKernelGGL(fold8_kernel, dim3((unsigned)std::min<int64_t>((m.n_pad8 + 255) / 256, 8192)), dim3(256), 0, ix.stream_, m.acc0.as<int>(), m.erow.as<float>(),
@@ -1196,7 +1200,7 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
     px.cntv = 0;
     px.s8g = m.s8g.as<int>();
     px.s8_slots = slots;
-    launch_query_prep8(dim3(mfma_form ? 4 : 1), s, m.rot8 ? m.sp8.as<int>() : nullptr, dq, nq, (int64_t)(mfma_form ? 16 : 4), (int)ix.dim_, m.d_pad8, m.mu8.as<float>(),
+    launch_query_prep8(dim3(mfma_form ? 4 : 1), s, m.rot8 ? m.sp8.as<int>() : nullptr, m.rot_w8, dq, nq, (int64_t)(mfma_form ? 16 : 4), (int)ix.dim_, m.d_pad8, m.mu8.as<float>(),
                        m.step8, ix.metric_, m.q8.as<signed char>(), m.qstat.as<float>(), px);
   }
   Stream8Args a;
@@ -1452,7 +1456,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
         px.gsync = gsync_env ? m.gsync.as<u32>() : nullptr;
       }
     }
-    launch_query_prep8(dim3((unsigned)((b_pad + 3) / 4)), s, m.rot8 ? m.sp8.as<int>() : nullptr, dq, nq, b_pad, (int)ix.dim_, m.d_pad8, m.mu8.as<float>(), m.step8,
+    launch_query_prep8(dim3((unsigned)((b_pad + 3) / 4)), s, m.rot8 ? m.sp8.as<int>() : nullptr, m.rot_w8, dq, nq, b_pad, (int)ix.dim_, m.d_pad8, m.mu8.as<float>(), m.step8,
                        ix.metric_, m.q8.as<signed char>(), m.qstat.as<float>(), px);
     if (fold) ix.stats_.i8_folded = 1;
     ix.stats_.i8_rotated = m.rot8 ? 1 : 0;

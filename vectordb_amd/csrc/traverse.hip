@@ -314,7 +314,7 @@ int32_t graph_search_impl(Index& ix, const float* dq, int64_t nq, int k, const e
     }
     if (g.acc0_epoch == q8v.epoch8) nbr_acc0 = g.nbr_acc0.as<int>();
   }
-  const size_t lds_need = traverse2_lds_bytes((int)ix.dim_, T, (int)Lq, qtot, dp, false, prefilter);
+  const size_t lds_need = traverse2_lds_bytes((int)ix.dim_, T, (int)Lq, qtot, dp, false, prefilter, q8v.cols8);
   // r3 (scripts/lab/trv_large_l2.sh, bench_random_graph.py): for BATCHES that band is better served with the queues in HBM and 8
   // wavefronts per query, two queries per CU (T = 4, L = 2000, batch 1024: 1M x 768 46.6 -> 39.4 ms, 10M-row proxy 56.8 -> 49.3 ms;
   // 4 wavefronts 64.6, 16 wavefronts 66.1), and 8 wavefronts also beat the 4 that queues in HBM used to get (L = 4000: 126.6 ->
@@ -323,7 +323,7 @@ int32_t graph_search_impl(Index& ix, const float* dq, int64_t nq, int k, const e
                                                      : (nq <= 256 ? (size_t)150 * 1024 : (size_t)80 * 1024);   // (A/B knob)
   const bool qglobal = lds_need > lds_limit;
   const bool one_per_cu = !qglobal && lds_need > (size_t)80 * 1024;
-  const size_t shm = traverse2_lds_bytes((int)ix.dim_, T, (int)Lq, qtot, dp, qglobal, prefilter);
+  const size_t shm = traverse2_lds_bytes((int)ix.dim_, T, (int)Lq, qtot, dp, qglobal, prefilter, q8v.cols8);
   // few queries: 16 wavefronts per query (latency); many queries: fewer per query (throughput, more queries per CU)
   const char* waves_s = tune_env("EPS_TRV_WAVES");
   int nw = waves_s ? atoi(waves_s) : ((nq <= 256 || one_per_cu) ? 16 : (qglobal ? 8 : 4));
@@ -425,6 +425,7 @@ int32_t graph_search_impl(Index& ix, const float* dq, int64_t nq, int k, const e
   a.nbr_acc0 = nbr_acc0;
   a.scal8 = q8v.scal8;
   a.d_pad8 = q8v.d_pad8;
+  a.cols8 = q8v.cols8;
   a.u8 = q8v.u;
   a.q8 = nullptr;
   a.qstat8 = nullptr;

@@ -78,6 +78,7 @@ struct Trv2Args {
   const signed char* q8;         // [nq][d_pad8] the queries on the same grid
   const float* qstat8;           // [nq][4] |q|^2, |q|, |q - qh|, C + c
   int d_pad8;
+  int cols8;                     // leading bytes of a mirror row that carry values (Quant8View::cols8: dim, or dim rounded up to 256 in the rotated frame)
   float u8, slack8;
 };
 
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(NW * 64, PF ? 4 : 1) void traverse2_kernel(Trv2Args
   const size_t pf_off = ((size_t)(reinterpret_cast<unsigned char*>(sh + SH) - smem_raw) + 15) & ~(size_t)15;
   float* qst = reinterpret_cast<float*>(smem_raw + pf_off);                // [4] |q|^2, |q|, |q - qh|, C + c
   signed char* sq8 = reinterpret_cast<signed char*>(qst + 4);               // [q8len]
-  const int q8len = trv2_q8len(dim);
+  const int q8len = trv2_q8len(a.cols8 > dim ? a.cols8 : dim);
   constexpr int U8 = EPS_TRV_U8, NL8 = EPS_TRV_NL8;
   int G8 = 4;
   while (G8 < 64 && G8 * 16 * NL8 < q8len) G8 <<= 1;                        // lanes per mirror row (NL8 pieces of 16 bytes each)
@@ -850,11 +851,11 @@ inline int traverse2_hash_slots(int T, int dp) {
   while (h < 2 * T * dp) h <<= 1;
   return h;
 }
-inline size_t traverse2_lds_bytes(int dim, int T, int Lq, int64_t qtot, int dp, bool qglobal, bool prefilter = false) {
+inline size_t traverse2_lds_bytes(int dim, int T, int Lq, int64_t qtot, int dp, bool qglobal, bool prefilter = false, int cols8 = 0) {
   const int qstride = (dim + 3) & ~3;
   const size_t ecap = (size_t)T * dp;
   return (size_t)qstride * 4 + (qglobal ? (size_t)TRV2_SB : (size_t)qtot) * 8 + ecap * (8 + 8 + 4 + 4 + 4 + 4) + (size_t)traverse2_hash_slots(T, dp) * 8 +
-         ((qglobal || T == 1) ? 0 : (size_t)2 * Lq * 4) + (size_t)trv2_sh_ints(T) * 4 + (prefilter ? (size_t)trv2_pf_bytes(dim) : 0);
+         ((qglobal || T == 1) ? 0 : (size_t)2 * Lq * 4) + (size_t)trv2_sh_ints(T) * 4 + (prefilter ? (size_t)trv2_pf_bytes(cols8 > dim ? cols8 : dim) : 0);
 }
 
 }  // namespace eps

@@ -38,6 +38,7 @@ struct TraverseArgs {
   const signed char* q8;   // [gridDim.x][d_pad8] this launch's queries on the mirror's grid
   const float* qstat8;     // [gridDim.x][4]
   int d_pad8;
+  int cols8;               // leading bytes of a mirror row that carry values (Quant8View::cols8)
   float u8, slack8;
 };
 
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(NW * 64) void traverse_kernel(TraverseArgs a) {
   const size_t pf_off = ((size_t)qstride * 4 + (size_t)a.Lp2 * 8 + TRV_CHUNK * 8 * 2 + TRV_CHUNK * 4 + 64 * 4 + ((HASHVIS && !a.ghash) ? TRV_HASH * 4 : 0) + 15) & ~(size_t)15;
   float* qst = reinterpret_cast<float*>(smem_raw + pf_off);      // [4]
   signed char* sq8 = reinterpret_cast<signed char*>(qst + 4);     // [q8len]
-  const int q8len = (dim + 15) & ~15;
+  const int q8len = ((a.cols8 > dim ? a.cols8 : dim) + 15) & ~15;
   constexpr int U8 = 2, NL8 = 3;
   int G8 = 4;
   while (G8 < 64 && G8 * 16 * NL8 < q8len) G8 <<= 1;
@@ -431,10 +432,10 @@ __global__ __launch_bounds__(NW * 64) void traverse_kernel(TraverseArgs a) {
 }
 
 
-inline size_t traverse_lds_bytes(int dim, int Lp2, bool hashvis, bool prefilter = false) {
+inline size_t traverse_lds_bytes(int dim, int Lp2, bool hashvis, bool prefilter = false, int cols8 = 0) {
   const int qstride = (dim + 3) & ~3;
   return (size_t)qstride * 4 + (size_t)Lp2 * 8 + TRV_CHUNK * 8 * 2 + TRV_CHUNK * 4 + 64 * 4 + (hashvis ? TRV_HASH * 4 : 0) +
-         (prefilter ? (size_t)(16 + 16 + ((dim + 15) & ~15)) : 0);
+         (prefilter ? (size_t)(16 + 16 + (((cols8 > dim ? cols8 : dim) + 15) & ~15)) : 0);
 }
 
 }  // namespace eps

@@ -340,6 +340,61 @@ def merge_topk_packed(gathered, shard_stride_bytes, dist_offset_bytes, shards, n
     return out_dist, out_ids
 
 
+class Exchange:
+    """eps_exchange (include/epsilla_gfx950.h): the sharded path's one exchange step - an RCCL all-gather of every rank's packed top-k lists and
+    the k-way merge - on a communicator the library owns.  Bootstrap: rank 0 calls Exchange.unique_id(), the 128 bytes reach every rank by the
+    caller's means, every rank constructs Exchange(rank, world, id_bytes, device) (collective)."""
+
+    @staticmethod
+    def unique_id():
+        L = lib.load()
+        buf = C.create_string_buffer(128)
+        rc = L.eps_exchange_unique_id(buf)
+        if rc != 0:
+            raise EpsillaError(rc, "eps_exchange_unique_id failed (RCCL not loadable?)")
+        return buf.raw
+
+    def __init__(self, rank, world, id_bytes, device=0):
+        self.L = lib.load()
+        assert len(id_bytes) == 128
+        self.h = C.c_void_p()
+        self.device = device
+        rc = self.L.eps_exchange_create(rank, world, C.c_char_p(bytes(id_bytes)), device, C.byref(self.h))
+        if rc != 0:
+            msg = self.L.eps_exchange_last_error(self.h).decode() if self.h else "eps_exchange_create failed"
+            if self.h:
+                self.L.eps_exchange_destroy(self.h)
+                self.h = None
+            raise EpsillaError(rc, msg)
+
+    def allgather_merge(self, ids, dist, out_ids, out_dist, stream=None):
+        """ids int64 [nq][k], dist float32 [nq][k] (this rank's lists, device tensors) -> out_ids / out_dist: the merged global top-k, on every rank"""
+        nq, k = ids.shape
+        rc = self.L.eps_exchange_allgather_merge(self.h, _ptr(ids), _ptr(dist), nq, k, _ptr(out_ids), _ptr(out_dist), C.c_void_p(stream) if stream else None)
+        if rc != 0:
+            raise EpsillaError(rc, self.L.eps_exchange_last_error(self.h).decode())
+        return out_ids, out_dist
+
+    def times_us(self, max_calls=64):
+        """[(all-gather us, merge us)] of the last calls, oldest first (waits for them)"""
+        buf = (C.c_double * (2 * max_calls))()
+        got = self.L.eps_exchange_times(self.h, buf, max_calls)
+        if got < 0:
+            raise EpsillaError(-1, "eps_exchange_times failed")
+        return [(buf[2 * i], buf[2 * i + 1]) for i in range(got)]
+
+    def info(self):
+        r, w, v = C.c_int32(), C.c_int32(), C.c_int32()
+        path = C.create_string_buffer(512)
+        self.L.eps_exchange_info(self.h, C.byref(r), C.byref(w), C.byref(v), path, 512)
+        return {"rank": r.value, "world": w.value, "rccl_version": v.value, "rccl_library": path.value.decode()}
+
+    def close(self):
+        if self.h:
+            self.L.eps_exchange_destroy(self.h)
+            self.h = None
+
+
 def normalize_rows(rows, only_if_nonzero=True, device=0, stream=None):
     """Normalize (db/vector.cpp:60-69) / insert-time normalisation (table_segment_mvp.cpp:574-587), in place."""
     L = lib.load()
