@@ -317,12 +317,13 @@ class CpuBaseline:
                 "qps": nqg / wall, "queries": nqg, "p50_ms": 1e3 * float(np.median(lat)), "p99_ms": 1e3 * float(np.percentile(lat, 99)),
                 "recall_at_10": recall_of(ids_g, ggt[:nqg]), "rows": gn}
 
-    def prefilter(self, idc_host, flt, Qh, k, metric, gt_ids=None):
+    def prefilter(self, idc_host, flt, Qh, k, metric, gt_ids=None, gpu_ids=None):
         """the reference's PreFilterBruteForceSearch (:770-831) with its own filter parser / ExprEvaluator (BASELINE configs[3])"""
         ids, ds, cnt, sec = self.ref.prefilter_many(self.ptr, self.n, self.d, idc_host, flt, Qh, k, metric=metric, threads=self.threads)
         return {"leg": "prefilter_bruteforce", "what": "reference PreFilterBruteForceSearch, filter %r, %d x %d rows, %d OpenMP threads" % (flt, self.n, self.d, self.threads),
                 "qps": len(sec) / float(np.sum(sec)), "queries": len(sec), "p50_ms": 1e3 * float(np.median(sec)), "p99_ms": 1e3 * float(np.max(sec)),
-                "visible_rows": int(cnt[0]), "recall_at_10": recall_of(ids, gt_ids[:len(sec)]) if gt_ids is not None else None}
+                "visible_rows": int(cnt[0]), "recall_at_10": recall_of(ids, gt_ids[:len(sec)]) if gt_ids is not None else None,
+                "gpu_headline_answers_equal": (int(sum(bool(np.array_equal(ids[i], gpu_ids[i])) for i in range(len(sec)))) if gpu_ids is not None else None)}
 
 
 def cpu_baseline(cpu, args, X, Q, gt_ids, graph, budget_s, gpu_ids=None):
@@ -446,7 +447,7 @@ def config_c2(amd, torch, args, X, qlast, dev, stream, local_rank, cpu, graph_in
     if cpu is not None and cpu.ref is not None:
         try:
             Qh = qlast[:64].cpu().numpy()
-            legs = [cpu.bruteforce(Qh, k, gt1, 4.0, rows=n1)]
+            legs = [cpu.bruteforce(Qh, k, gt1, 4.0, rows=n1, gpu_ids=r8)]   # (r8 = the one-pass engine's answers for the same queries: the leg's `value`)
             if graph_for_cpu is not None:
                 gg = (graph_for_cpu[0], graph_for_cpu[1], graph_for_cpu[2], graph_for_cpu[3], gt1)
                 legs.append(cpu.graph(gg, Qh, k, 500, 3.0, E=1, T=4))
@@ -478,7 +479,7 @@ def config_c4(amd, torch, args, X, qlast, dev, stream, local_rank, cpu):
     o = (torch.empty((b, k), dtype=torch.int64, device=dev), torch.empty((b, k), dtype=torch.float32, device=dev), torch.empty((b,), dtype=torch.int32, device=dev))
     g64 = (torch.empty((64, k), dtype=torch.int64, device=dev), torch.empty((64, k), dtype=torch.float32, device=dev), torch.empty((64,), dtype=torch.int32, device=dev))
     out["gpu"] = {}
-    gts = {}
+    gts, gots = {}, {}
     for sel in (0.5, 0.1, 0.9):
         bound = int(n * sel)
         ix.set_int_filter(idc, "<", bound)
@@ -495,6 +496,7 @@ def config_c4(amd, torch, args, X, qlast, dev, stream, local_rank, cpu):
         ix.search(Qn[:64], k, out=g64, flat_engine=amd.FLAT_STREAM, **kw)
         torch.cuda.synchronize()
         gts[sel] = g64[0].cpu().numpy().copy()
+        gots[sel] = got[:64]
         out["gpu"]["ID < %d (%d %%)" % (bound, int(sel * 100))] = {
             "qps": b / sec, "ms_per_step": 1e3 * sec, "recall_at_10": recall_of(got[:64], gts[sel]), "recall_check": "64 queries vs the fp32 stream engine with the same filter",
             "all_results_pass_the_filter": bool((got < bound).all()), "operand_bits": int(st.get("main_kernel_bits", 0)), "rerank_rows_per_query": st["rerank_rows"] / float(b),
@@ -505,7 +507,8 @@ def config_c4(amd, torch, args, X, qlast, dev, stream, local_rank, cpu):
             copy_s = cpu.load(Xn)
             idc_host = np.arange(n, dtype=np.int32)
             Qh = Qn[:2].cpu().numpy()
-            legs = [cpu.prefilter(idc_host, "ID < %d" % int(n * 0.5), Qh, k, 1, gts[0.5]), cpu.prefilter(idc_host, "ID < %d" % int(n * 0.1), Qh[:1], k, 1, gts[0.1])]
+            legs = [cpu.prefilter(idc_host, "ID < %d" % int(n * 0.5), Qh, k, 1, gts[0.5], gpu_ids=gots[0.5]),
+                    cpu.prefilter(idc_host, "ID < %d" % int(n * 0.1), Qh[:1], k, 1, gts[0.1], gpu_ids=gots[0.1])]
             out["cpu_reference"] = {"cores": cpu.threads, "legs": legs, "normalised_rows_copied_in_s": copy_s}
         except Exception as e:
             out["cpu_reference"] = {"failed": repr(e)}
@@ -653,7 +656,7 @@ def config_secondary(amd, torch, args, dev, stream, local_rank, cpu, kind):
             cpu.load(X1)
             Qh = Q1.cpu().numpy()
             off, nbr, nav = ix.get_graph()
-            legs = [cpu.bruteforce(Qh[:8], k, flat_ids, 2.0, rows=n1)]
+            legs = [cpu.bruteforce(Qh[:8], k, flat_ids, 2.0, rows=n1, gpu_ids=flat_ids)]
             for L in (100, 500):
                 legs.append(cpu.graph((off, nbr, nav, n1, flat_ids), Qh, k, L, 2.0))
             out["cpu_reference"] = {"cores": cpu.threads, "legs": legs}

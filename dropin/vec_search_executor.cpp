@@ -101,8 +101,7 @@ static int32_t SearchOrExactScan(eps_index* h, const float* q, int64_t nq, int32
   int32_t rc = eps_index_search(h, q, nq, k, p, ids, dist, cnt);
   if (rc == EPS_DB_UNSUPPORTED_ERROR && p->mode != EPS_MODE_FLAT) {
     const char* why = eps_index_last_error(h);
-    const bool range = why && (std::strstr(why, "SearchQueueSize") || std::strstr(why, "LocalQueueSize") || std::strstr(why, "IntraQueryThreads"));
-    if (range) {
+    if (eps_index_last_error_class(h) == EPS_ERRCLASS_DEVICE_RANGE) {   // (the library's own classification, not its wording: ADVICE r5)
       static std::atomic<bool> said{false};
       if (!said.exchange(true))
         fprintf(stderr, "[gfx950 executor] %s - this configuration is answered by the exact scan (recall 1.0) from now on\n", why);

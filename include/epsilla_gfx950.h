@@ -188,6 +188,14 @@ int32_t eps_index_create(int64_t dim, int32_t metric, int32_t device, eps_index*
 int32_t eps_index_create_sharded(int64_t dim, int32_t metric, const int32_t* devices, int32_t shards, eps_index** out);
 int32_t eps_index_destroy(eps_index* h);
 const char* eps_index_last_error(const eps_index* h);
+/* What kind of failure the last error was (r6; callers branch on this, never on the text).  EPS_ERRCLASS_DEVICE_RANGE: the request is valid for
+ * the reference (config/config.hpp:28-44 accepts SearchQueueSize / LocalQueueSize up to 10^7 and IntraQueryThreads up to 128 at any
+ * out-degree; VecSearchExecutor::Search, vec_search_executor.cpp:833-935, has no result cap) but lies outside what the device traversal runs
+ * (queues <= 2^20 keys, IntraQueryThreads x out-degree <= 2048, <= 1024 rows per query under filter_in_traversal or when a graph result is
+ * merged with an un-indexed tail): the same request with mode = EPS_MODE_FLAT is answered exactly, which is what the drop-in adapter does. */
+#define EPS_ERRCLASS_OTHER 0
+#define EPS_ERRCLASS_DEVICE_RANGE 1
+int32_t eps_index_last_error_class(const eps_index* h);
 
 /* use an existing HIP stream (hipStream_t passed as void*); NULL = the index's own non-blocking stream,
  * hipStreamLegacy ((void*)1) = the legacy default stream.  Device buffers handed to the index (rows, queries,

@@ -147,7 +147,8 @@ if what in ("ingest", "ingest_big"):
             m = min(chunk, rows - s)
             t0 = time.perf_counter()
             for a in range(0, m, 1 << 17):
-                buf[a:a + (1 << 17)] = rng.random((min(1 << 17, m - a), dim), dtype=np.float32)
+                c = min(1 << 17, m - a)
+                buf[a:a + c] = rng.random((c, dim), dtype=np.float32)
             if first is None:
                 first = buf[:64].copy()
             gen_s += time.perf_counter() - t0
@@ -228,7 +229,7 @@ if what in ("ingest", "ingest_big"):
                 ans["batch|%s|%s" % (field, flt)] = [code, [[[r["ID"] for r in rr], [r["@distance"] for r in rr]] for rr in resp]]
         out["answers"][t] = ans
     # beyond the capacity (the binding loads databases with 150000 rows per table): both paths refuse, with the same text
-    over = 150001 - rows
+    over = 150001 - rows + 2                                         # (two records were skipped as duplicates: rows - 2 are stored)
     try:
         epsilla.insert_array(table_name="A", columns={
             "ID": np.arange(10 ** 6, 10 ** 6 + over, dtype=np.int64), "Tag": np.zeros(over, np.int32), "Score": np.zeros(over, np.float32),

@@ -4,6 +4,8 @@ import ctypes
 import os
 import re
 
+import numpy as np
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -163,3 +165,31 @@ def test_dropin_builds_without_the_oracle_directory():
     for f in os.listdir(os.path.join(ROOT, "dropin")):
         if f.endswith((".cpp", ".hpp")):
             assert not re.search(r"#include\s+[\"<][^\">]*oracle", open(os.path.join(ROOT, "dropin", f)).read()), f
+
+
+def test_caller_provided_result_buffers_are_checked_before_the_c_abi_sees_them():
+    """GpuIndex.search(out=...) hands raw pointers to eps_index_search, which writes nq x k ids / distances and nq counts: a buffer of
+    another dtype, shape or layout is refused in Python (no index, no GPU needed: the check is a plain function)"""
+    from vectordb_amd.index import _check_out
+    _check_out(np.empty((3, 10), np.int64), "ids", (3, 10), "int64")
+    for bad in (np.empty((3, 10), np.int32), np.empty((3, 9), np.int64), np.empty((10, 3), np.int64).T, np.empty((3, 20), np.int64)[:, ::2]):
+        with pytest.raises(ValueError):
+            _check_out(bad, "ids", (3, 10), "int64")
+    import torch
+    _check_out(torch.empty((3, 10), dtype=torch.float32), "dist", (3, 10), "float32")
+    with pytest.raises(ValueError):
+        _check_out(torch.empty((3, 10), dtype=torch.float64), "dist", (3, 10), "float32")
+    with pytest.raises(ValueError):
+        _check_out(torch.empty((10, 3), dtype=torch.float32).t(), "dist", (3, 10), "float32")
+
+
+def test_error_class_is_part_of_the_abi(built):
+    """r6: callers branch on eps_index_last_error_class (EPS_ERRCLASS_DEVICE_RANGE), never on the wording of eps_index_last_error"""
+    import ctypes as C
+    from vectordb_amd import _lib
+    L = _lib.load()
+    assert L.eps_index_last_error_class(None) == 0
+    hdr = open(os.path.join(ROOT, "include", "epsilla_gfx950.h")).read()
+    assert "#define EPS_ERRCLASS_DEVICE_RANGE 1" in hdr
+    src = open(os.path.join(ROOT, "dropin", "vec_search_executor.cpp")).read()
+    assert "eps_index_last_error_class" in src and 'strstr(why' not in src

@@ -2,11 +2,14 @@
 COMPILED REFERENCE (oracle/_ref = the reference's own sources): position-wise ids, distances to 1e-4 - not set recall.
 
   configs[2]  L2: eps_index_search (EPS_FLAT_AUTO -> int8 matrix filter + fp32 re-rank) vs the reference's BruteForceSearch
-              (engine/db/execution/vec_search_executor.cpp:717-768) on 8 of the 1024 queries, the fp32 stream engine on 64, and
-              size-independent properties on all 1024 (sorted by (dist, id), unique ids, k results);
+              (engine/db/execution/vec_search_executor.cpp:717-768) on 32 of the 1024 queries, EVERY returned distance (1024 x 10) against the
+              reference's own distance function on that (row, query) pair (r6), the fp32 stream engine on 64, and size-independent
+              properties on all 1024 (sorted by (dist, id), unique ids, k results);
   configs[3]  COSINE on rows normalised as at insert (db/table_segment_mvp.cpp:574-587) + `ID < N` at 10 / 50 / 90 % selectivity
               (Config::PreFilter semantics) vs the reference's PreFilterBruteForceSearch (:770-831) driven by the reference's own
-              filter parser and ExprEvaluator, 2-3 queries per selectivity.
+              filter parser and ExprEvaluator, 2-3 queries per selectivity; every returned distance against the reference's function;
+  embedding-like (r6)  the same 10M rows overwritten with unit-norm Gaussian rows, 8 dominant columns (bench.py's `embedding_like` leg), COSINE:
+              the table the library moves to the ROTATED 8-bit frame; vs the reference's BruteForceSearch on 16 queries + all distances.
 
 The 10M-row table is generated on the device (seeded), copied once to page-aligned host memory for the reference (30.7 GB).
 Needs ~31 GB of host memory and ~45 GB of HBM; takes about a minute, most of it the reference's scans."""
@@ -60,6 +63,21 @@ def _to_host(t, tag):
     t["host"] = tag
 
 
+def _all_distances_are_the_references(ref, t, ids, dd, metric, what):
+    """every (row, query) pair the batch returned, through the reference's own distance function (GetDistFunc's choice for the
+    metric: L2Sqr / InnerProduct / CosineDistance, db/index/space_*.hpp) on the host copy of the rows - 1e-4 relative, as assert_topk_match"""
+    Qh = t["Q"][:ids.shape[0]].cpu().numpy()
+    arr = t["arr"]
+    worst = 0.0
+    for q in range(ids.shape[0]):
+        for j in range(ids.shape[1]):
+            want = ref.dist(metric, arr[int(ids[q, j])], Qh[q])
+            err = abs(float(dd[q, j]) - want) / max(abs(want), 1e-6)
+            worst = max(worst, err)
+            assert err <= 1e-4, (what, q, j, int(ids[q, j]), float(dd[q, j]), want)
+    return worst
+
+
 def _search(amd, t, ix, n_queries, **kw):
     torch = t["torch"]
     ids = torch.empty((n_queries, K), dtype=torch.int64, device=t["dev"])
@@ -78,10 +96,11 @@ def test_configs2_10M_x_768_L2_batch_1024_matches_the_reference_bruteforce(amd, 
     ids, dd, cnt, st = _search(amd, t, ix, B, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_AUTO)
     assert st["main_kernel_bits"] == 8 and st["overflow_queries"] == 0 and st["rerank_rows"] > 0, st   # the headline path itself
     # the reference, same rows, same queries
-    nref = 8
+    nref = 32
     rid, rd, sec = ref.bruteforce_many(t["ptr"], N, D, t["Q"][:nref].cpu().numpy(), K, metric=0, threads=t["threads"])
     for q in range(nref):
         assert_topk_match(ids[q], dd[q], rid[q], rd[q], what="configs[2] q%d" % q)
+    _all_distances_are_the_references(ref, t, ids, dd, 0, "configs[2]")
     # the fp32 stream engine (the library's other exact path), bit for bit on 64 queries
     sid, sd, scnt, _ = _search(amd, t, ix, 64, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
     assert np.array_equal(ids[:64], sid) and np.array_equal(dd[:64], sd)
@@ -168,6 +187,47 @@ def test_configs3_10M_x_768_cosine_with_id_filter_matches_the_reference_prefilte
         assert (rcnt == bound).all()
         for q in range(len(qh)):
             assert_topk_match(ids[q], dd[q], rid[q], rd[q], what="configs[3] %d%% q%d" % (int(sel * 100), q))
+        if sel == 0.1:
+            _all_distances_are_the_references(ref, t, ids, dd, 1, "configs[3] 10 %")
+    ix.close()
+
+
+def test_embedding_like_10M_x_768_cosine_stays_on_the_8_bit_pass_and_matches_the_reference_bruteforce(amd, ref, table):
+    """unit-norm Gaussian rows with 8 dominant columns - the table whose 8-bit bound was too loose in the row frame (the fp16
+    pass served it at half the rate) - at the headline's size.  The library's own choice (EPS_FLAT_AUTO) must be the 8-bit pass in the rotated
+    frame with no overflowing query, and the answers the reference's BruteForceSearch answers (vec_search_executor.cpp:717-768, COSINE on rows
+    normalised as at insert): 16 queries position-wise, every returned distance through the reference's CosineDistance, the fp32 stream
+    engine bit for bit on 64, properties on all 1024.  Runs after the configs[3] test: it overwrites the shared table."""
+    t = table
+    torch = t["torch"]
+    X, dev = t["X"], t["dev"]
+    g = torch.Generator(device=dev).manual_seed(77)
+    scale = torch.ones((D,), dtype=torch.float32, device=dev)
+    scale[:8] = 4.0
+    for s in range(0, N, 1 << 19):
+        e = min(N, s + (1 << 19))
+        X[s:e] = torch.randn((e - s, D), generator=g, device=dev, dtype=torch.float32) * scale
+    Q = torch.randn((B, D), generator=torch.Generator(device=dev).manual_seed(78), device=dev, dtype=torch.float32) * scale
+    amd.normalize_rows(X, only_if_nonzero=True, device=0, stream=torch.cuda.current_stream().cuda_stream)
+    amd.normalize_rows(Q, only_if_nonzero=False, device=0, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    t = {**t, "Q": Q, "host": None}
+    _to_host(t, "embedding")
+    table["host"] = "embedding"
+    ix = amd.GpuIndex(D, "COSINE", device=0).use_torch_stream()
+    ix.attach_rows(X)
+    ids, dd, cnt, st = _search(amd, t, ix, B, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_AUTO)
+    ids, dd, cnt, st = _search(amd, t, ix, B, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_AUTO)   # (the second call: past the table's first-call probe)
+    assert (st["main_kernel_bits"], st["i8_rotated"], st["overflow_queries"]) == (8, 1, 0), st
+    nref = 16
+    rid, rd, sec = ref.bruteforce_many(t["ptr"], N, D, Q[:nref].cpu().numpy(), K, metric=1, threads=t["threads"])
+    for q in range(nref):
+        assert_topk_match(ids[q], dd[q], rid[q], rd[q], what="embedding-like q%d" % q)
+    _all_distances_are_the_references(ref, t, ids, dd, 1, "embedding-like")
+    sid, sd, scnt, _ = _search(amd, t, ix, 64, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
+    assert np.array_equal(ids[:64], sid) and np.array_equal(dd[:64], sd)
+    assert (cnt == K).all() and (ids >= 0).all() and (ids < N).all() and (np.diff(dd, axis=1) >= 0).all()
+    assert all(len(set(r.tolist())) == K for r in ids)
     ix.close()
 
 

@@ -492,3 +492,41 @@ def test_visited_stamps_survive_the_wrap_of_their_counter(amd, monkeypatch):
             got = ix.search(Q[:n_], 10, mode=amd.MODE_GRAPH, intra_threads=T)
             assert np.array_equal(got[0], w[0]) and np.array_equal(got[1], w[1]) and np.array_equal(got[2], w[2]), (n_, T, rep)
     ix.close()
+
+
+def test_visited_stamp_table_is_reclaimable_scratch(amd, monkeypatch):
+    """the traversal's stamp table (4 bytes x nodes x slots; 41 GB at 10M rows x 1024 slots) only makes the walk faster, so
+    it must never be the reason ANOTHER allocation of the process fails.  With the device filled up to a few MB by a foreign allocation, a second
+    index's row upload cannot be served until the first index's stamp table is given back - DevBuf::reserve does that (scratch_reclaim,
+    csrc/index.cpp) and tries again; the first index then searches on (same answers: the table is re-created when there is room, the bitmap
+    serves where there is not)."""
+    import torch
+    monkeypatch.setenv("EPS_TRV_VISITED", "stamps")
+    n, d, nq = 60_000, 64, 512
+    X, Q = data(n, d, 5), data(nq, d, 6)
+    ix = amd.GpuIndex(d, 0)
+    ix.attach_rows(X)
+    ix.build(n)
+    first = ix.search(Q, 10, mode=amd.MODE_GRAPH, intra_threads=1)
+    ix.synchronize()
+    monkeypatch.delenv("EPS_TRV_VISITED")
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free_with_table, _ = torch.cuda.mem_get_info(0)
+    # a foreign allocation that leaves ~24 MB: less than the second index's rows (n x d x 4 = 15 MB + mirror ...) need in total, far less than the
+    # stamp table (>= 512 slots x 60000 nodes x 4 B = 123 MB) holds
+    hog = torch.empty((free_with_table - (24 << 20),), dtype=torch.uint8, device="cuda:0")
+    Y = data(300_000, d, 7)                           # 77 MB of rows: does not fit the 24 MB that are left
+    iy = amd.GpuIndex(d, 0)
+    iy.attach_rows(Y)                                 # -> hipMalloc fails -> the stamp table is taken back -> succeeds
+    got = iy.search(Q[:8], 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
+    del hog
+    torch.cuda.empty_cache()
+    ref = amd.GpuIndex(d, 0)
+    ref.attach_rows(Y)
+    want = ref.search(Q[:8], 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
+    assert np.array_equal(got[0], want[0])
+    again = ix.search(Q, 10, mode=amd.MODE_GRAPH, intra_threads=1)     # the first index, its table gone
+    assert np.array_equal(first[0], again[0]) and np.array_equal(first[1].view(np.uint32), again[1].view(np.uint32))
+    for h in (ix, iy, ref):
+        h.close()

@@ -24,7 +24,7 @@ OPS = {None: 0, "": 0, "<": 1, "<=": 2, "==": 3, "=": 3, ">=": 4, ">": 5, "!=": 
 
 EXPORTS = [
     "eps_default_search_params", "eps_default_build_params", "eps_index_create", "eps_index_create_sharded", "eps_index_destroy",
-    "eps_index_last_error", "eps_index_set_stream", "eps_index_synchronize", "eps_index_attach_rows",
+    "eps_index_last_error", "eps_index_last_error_class", "eps_index_set_stream", "eps_index_synchronize", "eps_index_attach_rows",
     "eps_index_append_rows", "eps_index_attach_shard_rows", "eps_index_clone_rows", "eps_index_row_count", "eps_index_load_table", "eps_index_set_id_map", "eps_index_set_deleted",
     "eps_index_set_int_filter", "eps_index_set_filter_program", "eps_index_set_filter_program_ex", "eps_index_search_walk", "eps_index_select_edges", "eps_index_inter_insert", "eps_index_knn_graph", "eps_index_link", "eps_index_build", "eps_index_set_graph", "eps_index_graph_info",
     "eps_index_get_graph", "eps_index_save_graph", "eps_index_load_graph", "eps_index_search",
@@ -160,6 +160,8 @@ def load():
     L.eps_index_destroy.argtypes = [vp]
     L.eps_index_last_error.argtypes = [vp]
     L.eps_index_last_error.restype = C.c_char_p
+    L.eps_index_last_error_class.argtypes = [vp]
+    L.eps_index_last_error_class.restype = C.c_int32
     L.eps_index_set_stream.argtypes = [vp, vp]
     L.eps_index_synchronize.argtypes = [vp]
     L.eps_index_attach_rows.argtypes = [vp, vp, i64]

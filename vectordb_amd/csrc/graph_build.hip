@@ -468,7 +468,7 @@ int32_t graph_build(Index& ix, int64_t n, const eps_build_params& bp, const Buil
   // error is a small fraction of the gap between the K-th and the 128-th neighbour; tests/test_gpu_build.py measures the recall).
   DevBuf knn, run, runA, candA, cntA;
   const int k1 = K + 1;
-  static const int64_t B = tune_env("EPS_BUILD_BLOCK") ? std::max(256, atoi(tune_env("EPS_BUILD_BLOCK"))) : 2048;   // queries per kNN pass
+  const int64_t B = std::max(256, tune_int("EPS_BUILD_BLOCK", 2048));   // queries per kNN pass
   const bool use_mfma = n >= 65536;
   const int kA = (int)std::min<int64_t>(n, std::max(k1, 128));
   if (!knn.reserve((size_t)n * K * 4) || !run.reserve((size_t)B * k1 * 8)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "build: out of device memory (kNN graph)");

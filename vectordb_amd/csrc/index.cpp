@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <deque>
+#include <vector>
 #include <mutex>
 #include <new>
 #include <string>
@@ -38,6 +39,10 @@ const char* tune_env(const char* name) {
 #else
   return nullptr;
 #endif
+}
+int tune_int(const char* name, int dflt) {
+  const char* e = tune_env(name);
+  return e ? atoi(e) : dflt;
 }
 static void tune_set(const char* name, const char* value) {
   std::lock_guard<std::mutex> lk(g_tune_mu);
@@ -74,22 +79,50 @@ bool Index::HostBuf::reserve(size_t bytes) {
   cap = want;
   return true;
 }
+namespace {
+std::mutex g_scratch_mu;
+std::vector<ScratchClaim*> g_scratch;
+}  // namespace
+ScratchClaim::ScratchClaim() {
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  g_scratch.push_back(this);
+}
+ScratchClaim::~ScratchClaim() {
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  g_scratch.erase(std::remove(g_scratch.begin(), g_scratch.end(), this), g_scratch.end());
+}
+size_t scratch_reclaim() {
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  size_t freed = 0;
+  for (ScratchClaim* c : g_scratch) {
+    if (!c->buf || !c->buf->p) continue;
+    if (c->busy.exchange(true)) continue;   // its owner is between "the table is there" and the launch that uses it (possibly this very thread)
+    freed += c->buf->cap;
+    c->buf->release();
+    c->busy.store(false);
+  }
+  return freed;
+}
 bool DevBuf::reserve(size_t bytes) {
   if (bytes <= cap) return true;
   release();
-  size_t want = bytes + bytes / 8 + 256;
-  if (hipMalloc(&p, want) != hipSuccess) {
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    size_t want = bytes + bytes / 8 + 256;
+    if (hipMalloc(&p, want) == hipSuccess) {
+      cap = want;
+      return true;
+    }
     (void)hipGetLastError();
     p = nullptr;
-    if (hipMalloc(&p, bytes) != hipSuccess) {
-      (void)hipGetLastError();
-      p = nullptr;
-      return false;
+    if (hipMalloc(&p, bytes) == hipSuccess) {
+      cap = bytes;
+      return true;
     }
-    want = bytes;
+    (void)hipGetLastError();
+    p = nullptr;
+    if (attempt == 0 && scratch_reclaim() == 0) break;   // nothing to give back: fail; else once more
   }
-  cap = want;
-  return true;
+  return false;
 }
 
 bool is_device_ptr(const void* p) {
@@ -638,7 +671,7 @@ int32_t Index::flat_stream(const float* dq, int64_t nq, int k, int64_t row_begin
   // More than 1024 results per query (the reference's BruteForceSearch has no cap: it sorts all n candidates,
   // vec_search_executor.cpp:756-767): pages of 1024 - page p is the scan's 1024 best keys ordered AFTER the last key of page
   // p-1 ((dist, id) keys are unique per row, so the pages are disjoint and their concatenation is the sorted answer).
-  if (merge_run) return fail(EPS_DB_UNSUPPORTED_ERROR, "search: merging into an existing result list of more than 1024 entries is not supported");
+  if (merge_run) return fail(EPS_DB_UNSUPPORTED_ERROR, "search: merging into an existing result list of more than 1024 entries is not supported", EPS_ERRCLASS_DEVICE_RANGE);
   if (!page_buf_.reserve((size_t)nq * 1024 * sizeof(u64))) return fail(EPS_INFRA_UNEXPECTED_ERROR, "search: out of device memory (result page)");
   for (int done = 0; done < k; done += 1024) {
     const int kc = std::min(1024, k - done);
@@ -726,7 +759,7 @@ int32_t Index::search(const float* queries, int64_t nq, int32_t k, const eps_sea
   if (!q_dev) {
     const size_t qb = (size_t)nq * dim_ * sizeof(float);
     if (!q_buf_.reserve(qb)) return fail(EPS_INFRA_UNEXPECTED_ERROR, "search: out of device memory (queries)");
-    const bool staging = !(tune_env("EPS_HOST_STAGING") && atoi(tune_env("EPS_HOST_STAGING")) == 0);   // (A/B switch)
+    const bool staging = !(tune_int("EPS_HOST_STAGING", 1) == 0);   // (A/B switch)
     if (staging && qb <= ((size_t)256 << 10) && h_q_.reserve(qb)) {   // (a few vectors: -30 us per call; a 3 MB batch: the runtime's pageable path measured faster than memcpy + DMA)
       // (the previous call's copy out of h_q_ has completed: every call with host queries ends in a stream sync or its results are device-side and
       // the caller orders the stream; a second call on the same index may not start before the first returns - one mutex per index)
@@ -835,7 +868,7 @@ int32_t Index::search(const float* queries, int64_t nq, int32_t k, const eps_sea
 
   if (!result_finalized_) finalize();
   if (!out_dev) {
-    if (!(tune_env("EPS_HOST_STAGING") && atoi(tune_env("EPS_HOST_STAGING")) == 0) && h_out_.reserve(out_bytes)) {   // one copy into page-locked memory, split on the host
+    if (!(tune_int("EPS_HOST_STAGING", 1) == 0) && h_out_.reserve(out_bytes)) {   // one copy into page-locked memory, split on the host
       HIP_TRY(hipMemcpyAsync(h_out_.p, d_ids, out_bytes, hipMemcpyDeviceToHost, stream_));
       HIP_TRY(hipStreamSynchronize(stream_));
       const char* h = static_cast<const char*>(h_out_.p);
@@ -990,6 +1023,7 @@ int32_t eps_index_destroy(eps_index* h) {
   }
 }
 const char* eps_index_last_error(const eps_index* h) { return h ? CIX(h)->last_error() : "null handle"; }
+int32_t eps_index_last_error_class(const eps_index* h) { return h ? CIX(h)->last_error_class() : EPS_ERRCLASS_OTHER; }
 int32_t eps_index_set_stream(eps_index* h, void* s) { GUARD(h, IX(h)->set_stream(s)); }
 int32_t eps_index_synchronize(eps_index* h) { GUARD(h, IX(h)->synchronize()); }
 int32_t eps_index_attach_rows(eps_index* h, const float* rows, int64_t n) { GUARD(h, IX(h)->attach_rows(rows, n)); }

@@ -3,6 +3,7 @@
 // engine/db/execution/vec_search_executor.hpp:30-74, engine/db/ann_graph_segment.hpp:22-55) with the
 // vector table, graph and scratch mirrored in HBM.
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -26,9 +27,25 @@ struct DevBuf {  // growable device allocation
   T* as() const { return static_cast<T*>(p); }
 };
 
+// Reclaimable scratch (r6): a device allocation that only makes a path faster (the traversal's visited stamps: 4 bytes x nodes x slots,
+// tens of GB) is registered here with a flag its owner holds while host code is about to launch kernels on it.  When ANY DevBuf::reserve of the
+// process fails, every registered buffer whose owner is not in that window is released (hipFree waits for the kernels already launched) and
+// the allocation is tried again; the owner finds its buffer gone at its next search and takes the form that needs no such table.
+struct ScratchClaim {
+  DevBuf* buf = nullptr;
+  std::atomic<bool> busy{false};
+  ScratchClaim();
+  ~ScratchClaim();
+  ScratchClaim(const ScratchClaim&) = delete;
+  ScratchClaim& operator=(const ScratchClaim&) = delete;
+};
+size_t scratch_reclaim();   // bytes released
+
 // Engine-selection switches (eps_set_tuning, include/epsilla_gfx950.h): the value of `name` in the process-wide table, or null.  The
 // product library never reads the environment; a lab build (-DEPS_LAB) falls back to getenv for names the table does not hold.
 const char* tune_env(const char* name);
+// the integer value of a switch, read ONCE (a second lookup may find the entry gone: eps_set_tuning is a process-wide runtime call), or `dflt`
+int tune_int(const char* name, int dflt);
 
 struct BuildStage;   // stage-level entry of the graph build (below)
 struct Quant8View {   // the table's 8-bit mirror as other kernels see it (mfma_filter.hip)
@@ -75,11 +92,14 @@ class IndexBase {
   virtual int32_t last_stats(eps_search_stats* out) = 0;
   virtual int kernel_times(double* ms_out, int cap) = 0;
   const char* last_error() const { return err_.c_str(); }
-  int32_t fail(int32_t code, const std::string& msg) {
+  int32_t last_error_class() const { return err_class_; }
+  int32_t fail(int32_t code, const std::string& msg, int32_t err_class = 0) {
     err_ = msg;
+    err_class_ = err_class;
     return code;
   }
   std::string err_;
+  int32_t err_class_ = 0;   // EPS_ERRCLASS_* of the last failure (eps_index_last_error_class)
 };
 
 class Index : public IndexBase {

@@ -1041,8 +1041,8 @@ static int32_t ensure_mirror8(Index& ix) {
     // Per-row margins are folded per batch only where rows DIFFER: a forced row, or a residual norm beyond 1.5 x the smallest (a clamped
     // value somewhere).  On homogeneous tables (every row a plain rounding residual: within a few per cent of each other) the table-wide
     // margin in the thresholds is as tight, keeps every query's own norms, and costs no pass over the rows (10M rows: 40 us per batch).
-    m.fold8 = forced > 0 || m.h_scal8[0] > 1.5f * m.h_scal8[7] || (tune_env("EPS_MFMA_FOLD") && atoi(tune_env("EPS_MFMA_FOLD")) != 0);
-    if (tune_env("EPS_MFMA_FOLD") && atoi(tune_env("EPS_MFMA_FOLD")) == 0 && forced == 0) m.fold8 = false;
+    m.fold8 = forced > 0 || m.h_scal8[0] > 1.5f * m.h_scal8[7] || (tune_int("EPS_MFMA_FOLD", 0) != 0);
+    if (tune_int("EPS_MFMA_FOLD", 1) == 0 && forced == 0) m.fold8 = false;
     m.extended_rows8 += extend ? n - row0 : 0;
   }
   if (!m.i8_ok) {   // nothing of it is used: give the memory back
@@ -1116,7 +1116,7 @@ bool flat_mfma_profitable(const Index& ix, int64_t nq, int k) {
   const bool can16 = !have16 || m->fp16_range_ok;
   if (known8 && !have8 && !can16) return false;                 // neither mirror can serve this table
   // up to 16 queries, k <= 64, rows of <= 1024 bytes: the one-pass search (stream8_kernel.hpp) - one pass over d_pad8 + 4 bytes per row
-  const bool one_pass_shape = nq <= S8_MAX_Q && k <= S8_MAX_K && ix.dim_ <= 1024 && !(tune_env("EPS_FLAT_ONE_PASS") && atoi(tune_env("EPS_FLAT_ONE_PASS")) == 0);
+  const bool one_pass_shape = nq <= S8_MAX_Q && k <= S8_MAX_K && ix.dim_ <= 1024 && !(tune_int("EPS_FLAT_ONE_PASS", 1) == 0);
   if (nq < 8 && !have8 && !have16) {
     // single-query traffic alone does not get a mirror (n x d bytes of HBM + a pass over the table to build it) at once: r4, after 16 such
     // calls on the same rows it does, where the one-pass search can use it (0.20 ms instead of 0.62 ms per call at 1M x 768)
@@ -1145,9 +1145,9 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
   HalfMirror& m = *ix.mirror_;
   const int64_t n = ix.scan_limit_ >= 0 ? std::min(ix.scan_limit_, ix.n_rows_) : ix.n_rows_;
   const int pieces = m.d_pad8 / 256;
-  if (tune_env("EPS_FLAT_ONE_PASS") && atoi(tune_env("EPS_FLAT_ONE_PASS")) == 0) return EPS_OK;
-  const int max_q = tune_env("EPS_S8_MAX_Q") ? std::min(S8_MAX_Q, std::max(1, atoi(tune_env("EPS_S8_MAX_Q")))) : S8_MAX_Q;   // (A/B switch: 4 = the r4 form, 5+ queries on the staged chain)
-  const int max_k = tune_env("EPS_S8_MAX_K") ? std::min(S8_MAX_K, std::max(1, atoi(tune_env("EPS_S8_MAX_K")))) : S8_MAX_K;   // (A/B switch: 16 = the r4 range, larger k on the staged chain)
+  if (tune_int("EPS_FLAT_ONE_PASS", 1) == 0) return EPS_OK;
+  const int max_q = std::min(S8_MAX_Q, std::max(1, tune_int("EPS_S8_MAX_Q", S8_MAX_Q)));   // (A/B switch: 4 = the r4 form, 5+ queries on the staged chain)
+  const int max_k = std::min(S8_MAX_K, std::max(1, tune_int("EPS_S8_MAX_K", S8_MAX_K)));   // (A/B switch: 16 = the r4 range, larger k on the staged chain)
   if (nq < 1 || nq > max_q || k < 1 || k > max_k || m.fold8 || n < 65536 || n > m.n8 || m.d_pad8 % 256 != 0 || pieces < 2 || pieces > 4) return EPS_OK;
   // (r6: ... and per kernel form - five or more queries share one list budget per query and overflow on tables where one query does not:
   // an 8-query batch must not talk the table out of the form for single-query traffic)
@@ -1159,7 +1159,7 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
   // call to the stream engine before they get here; checked again, the staged chain evaluates per candidate)
   const bool masked = fs.prog != nullptr;
   if (masked && ix.prog_uses_dist_ && !ix.prefilter_call_) return EPS_OK;
-  if (masked && tune_env("EPS_S8_FILTER_PROGRAMS") && atoi(tune_env("EPS_S8_FILTER_PROGRAMS")) == 0) return EPS_OK;   // (A/B switch: programs on the staged chain, as until r4)
+  if (masked && tune_int("EPS_S8_FILTER_PROGRAMS", 1) == 0) return EPS_OK;   // (A/B switch: programs on the staged chain, as until r4)
   const bool filtered = fs.deleted || fs.column || masked;
   if (filtered && m.s8_filt_skip[kclass] > 0) {   // (a mask that starves the pass used to cost a wasted pass on EVERY call)
     --m.s8_filt_skip[kclass];
@@ -1184,8 +1184,8 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
   if ((reinterpret_cast<uintptr_t>(total) & 7) != 0) total = reinterpret_cast<unsigned long long*>(cnt + nq + 3);
   const float u8 = (ix.metric_ == 0 ? 2.f : 1.f) * m.step8 * m.step8;
   const float rerank_slack = std::max(8e-6f, 2.f * (3.f * ((float)((ix.dim_ + 63) / 64 * 64) / 64.f + 6.f) + 6.f) * 5.9604645e-8f);
-  const bool host_words = !(tune_env("EPS_S8_HOST_WORDS") && atoi(tune_env("EPS_S8_HOST_WORDS")) == 0) && m.s8_pub.get();   // (A/B switch)
-  const bool two_launches = host_words && !(tune_env("EPS_S8_TWO_LAUNCHES") && atoi(tune_env("EPS_S8_TWO_LAUNCHES")) == 0) && !tune_env("EPS_DEBUG");  // (A/B switch; the debug log reads the table after the call)
+  const bool host_words = !(tune_int("EPS_S8_HOST_WORDS", 1) == 0) && m.s8_pub.get();   // (A/B switch)
+  const bool two_launches = host_words && !(tune_int("EPS_S8_TWO_LAUNCHES", 1) == 0) && !tune_env("EPS_DEBUG");  // (A/B switch; the debug log reads the table after the call)
   // (3-4 queries keep the prep launch: next to four queries' slices and two chunks in flight the in-kernel form does not fit 256 registers)
   // (k = 17..64: 128 slots per query in the same table - a layout of its own, so such a call always starts with the prep launch, which empties
   // the slots it uses, and never leaves the "clean" state behind)
@@ -1228,7 +1228,7 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
   a.step = m.step8;
   a.inv_step = 1.f / m.step8;
 #ifdef EPS_LAB   // (kernel ablations make answers wrong on purpose: lab builds only)
-  a.ablate = tune_env("EPS_S8_ABLATE") ? atoi(tune_env("EPS_S8_ABLATE")) : 0;
+  a.ablate = tune_int("EPS_S8_ABLATE", 0);
 #else
   a.ablate = 0;
 #endif
@@ -1237,12 +1237,12 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
     m.s8_cus = hipGetDeviceProperties(&prop, ix.device_) == hipSuccess ? std::max(8, prop.multiProcessorCount) : 256;
   }
   const int cus = m.s8_cus;
-  static const int wg_per_cu = tune_env("EPS_S8_WG_PER_CU") ? std::max(1, atoi(tune_env("EPS_S8_WG_PER_CU"))) : 2;
+  const int wg_per_cu = std::max(1, tune_int("EPS_S8_WG_PER_CU", 2));
   const dim3 grid((unsigned)std::min<int64_t>(std::min<int64_t>((int64_t)cus * wg_per_cu, S8_MAX_WAVES / 4), (n + 63) / 64)), block(256);
   a.waves = (int)grid.x * 4;
   // (no event pair around the pass by default: a record between two dependent launches costs this chain 5-10 us each; kernel_ms covers
   // the call.  EPS_ONE_PASS_TIMED=1 - bench.py's roofline leg - records the pair: main_kernel_ms = the pass)
-  const bool timed = tune_env("EPS_ONE_PASS_TIMED") && atoi(tune_env("EPS_ONE_PASS_TIMED")) != 0;
+  const bool timed = tune_int("EPS_ONE_PASS_TIMED", 0) != 0;
   if (timed) (void)hipEventRecord(ix.evk0_, s);
 #define EPS_S8_LAUNCH_(P_, PREP_)                                                                    \
   do {                                                                                               \
@@ -1299,7 +1299,7 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
   ra.gsync = nullptr;
   ra.s8_G = a.G;                 // (the launch selects its candidates from the pass's lists first)
   ra.s8_slots = slots;
-  ra.s8_fast = !(tune_env("EPS_S8_RERANK") && atoi(tune_env("EPS_S8_RERANK")) == 0);   // (A/B switch: 0 = rerank_kernel with the selection prologue, as until r5)
+  ra.s8_fast = !(tune_int("EPS_S8_RERANK", 1) == 0);   // (A/B switch: 0 = rerank_kernel with the selection prologue, as until r5)
   ra.s8_counts = a.raw_cnt;
   ra.s8_lists = a.raw;
   ra.s8_waves = a.waves;
@@ -1431,10 +1431,10 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   if (!m.gsync.reserve(1024)) return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory (scratch)");
   // (what the staging below decides, needed here already: the 8-bit query preparation also lays down a seeded call's start state)
   const int64_t S0 = std::max<int64_t>(4096, (int64_t)(32 * k + ROWPAD - 1) / ROWPAD * ROWPAD);
-  const bool seed_env = !(tune_env("EPS_MFMA_SEED") && atoi(tune_env("EPS_MFMA_SEED")) == 0);
+  const bool seed_env = !(tune_int("EPS_MFMA_SEED", 1) == 0);
   const bool seeded = seed_env && n > 4 * S0;   // with a filter the seeds are the k best VISIBLE head rows
   const bool prologue = seeded && version >= 7;   // one launch resets everything a seeded call starts from
-  const bool gsync_env = !(tune_env("EPS_MFMA_GROUPSYNC") && atoi(tune_env("EPS_MFMA_GROUPSYNC")) == 0);
+  const bool gsync_env = !(tune_int("EPS_MFMA_GROUPSYNC", 1) == 0);
   const bool prep_does_it_all = i8 && version >= 7;   // fragment-major copy + prologue inside query_prep8_kernel: two launches less per call
   hipError_t er_ = hipSuccess;
   const bool fold = i8 && !approx && m.fold8;   // exact mode on a table whose rows differ: per-row margins folded into the start values, thresholds without margin
@@ -1556,7 +1556,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   fa.cnt = cnt;
   fa.cap = cap;
   fa.group_sync = nullptr;
-  fa.sync_shift = tune_env("EPS_MFMA_SYNC_SHIFT") ? std::min(8, std::max(0, atoi(tune_env("EPS_MFMA_SYNC_SHIFT")))) : 2;
+  fa.sync_shift = std::min(8, std::max(0, tune_int("EPS_MFMA_SYNC_SHIFT", 2)));
   fa.dense = 0;
   fa.ablate = 0;
   fa.prof = nullptr;
@@ -1591,7 +1591,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   ra.u = u8;
   ra.slack = 0.f;   // (set below, with the stages)
   ra.gsync = m.gsync.as<u32>();
-  if (!approx && nq <= 16 && k <= 128 && tune_env("EPS_RERANK_SPLIT") && atoi(tune_env("EPS_RERANK_SPLIT")) != 0) {
+  if (!approx && nq <= 16 && k <= 128 && tune_int("EPS_RERANK_SPLIT", 0) != 0) {
     // a handful of queries: every re-rank spread over 8 workgroups per query (RerankArgs::parts).  Opt-in: measured, it takes 5 us off a
     // 340 us single-query call (profiles/r4_single_query_latency.txt) - a re-rank of ~150 rows is a chain of dependent latencies, not a
     // bandwidth problem - and is not worth a cross-workgroup hand-off on the default path
@@ -1625,8 +1625,8 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
       (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v7_lds_bytes(4));
   }
   const int num_cus = m.num_cus;
-  const bool narrow_env = !(tune_env("EPS_MFMA_NARROW") && atoi(tune_env("EPS_MFMA_NARROW")) == 0);
-  const bool two_per_cu = tune_env("EPS_MFMA_TWO_PER_CU") && atoi(tune_env("EPS_MFMA_TWO_PER_CU")) != 0;   // (lab until measured)
+  const bool narrow_env = !(tune_int("EPS_MFMA_NARROW", 1) == 0);
+  const bool two_per_cu = tune_int("EPS_MFMA_TWO_PER_CU", 0) != 0;   // (lab until measured)
   auto launch_filter = [&](const FilterArgs& f) {
     {
       FilterArgs f3 = f;
@@ -1734,7 +1734,7 @@ int32_t flat_mfma_search_slice(Index& ix, const float* dq, int64_t nq, int k, u6
   }
   bool first = true;
   bool fin_done = false;
-  const bool probe = i8 && auto_bits && !approx && seeded && !m.i8_trusted && bounds.size() > 3 && !(tune_env("EPS_MFMA_PROBE") && atoi(tune_env("EPS_MFMA_PROBE")) == 0);
+  const bool probe = i8 && auto_bits && !approx && seeded && !m.i8_trusted && bounds.size() > 3 && !(tune_int("EPS_MFMA_PROBE", 1) == 0);
   for (size_t st = 0; st + 1 < bounds.size(); ++st) {
     const int64_t lo = bounds[st], hi = bounds[st + 1];
     {
@@ -1882,7 +1882,7 @@ int32_t flat_mfma_search(Index& ix, const float* dq, int64_t nq, int k, u64* run
     const char* e = tune_env("EPS_MFMA_BITS");
     bits = (e && atoi(e) == 16) ? 16 : 8;
   }
-  const int64_t slice = tune_env("EPS_MFMA_MAX_BATCH") ? std::max(256, atoi(tune_env("EPS_MFMA_MAX_BATCH"))) : 2048;
+  const int64_t slice = std::max(256, tune_int("EPS_MFMA_MAX_BATCH", 2048));
   if (nq <= slice) return flat_mfma_search_slice(ix, dq, nq, k, run_keys, approx, 1, bits, auto_bits);
   for (int64_t q0 = 0; q0 < nq; q0 += slice) {   // the counters in ix.stats_ accumulate over the slices
     const int32_t rc = flat_mfma_search_slice(ix, dq + q0 * ix.dim_, std::min(slice, nq - q0), k, run_keys + q0 * k, approx, 1, bits, auto_bits);

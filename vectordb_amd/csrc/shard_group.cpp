@@ -119,7 +119,7 @@ class ShardGroup : public IndexBase {
       pool_fn_ = nullptr;
     }
     for (int s = 0; s < G(); ++s)
-      if (pool_rc_[s] != EPS_OK) return fail(pool_rc_[s], "shard " + std::to_string(s) + ": " + shard_[s]->last_error());
+      if (pool_rc_[s] != EPS_OK) return fail(pool_rc_[s], "shard " + std::to_string(s) + ": " + shard_[s]->last_error(), shard_[s]->last_error_class());
     return EPS_OK;
   }
 
@@ -146,7 +146,7 @@ class ShardGroup : public IndexBase {
                                       std::to_string(shard_[(size_t)shard]->device_));
     if (hipSetDevice(shard_[(size_t)shard]->device_) != hipSuccess) return fail(EPS_INFRA_UNEXPECTED_ERROR, "hipSetDevice");
     const int32_t rc = shard_[(size_t)shard]->attach_rows(rows, n_local);
-    if (rc != EPS_OK) return fail(rc, "shard " + std::to_string(shard) + ": " + shard_[(size_t)shard]->last_error());
+    if (rc != EPS_OK) return fail(rc, "shard " + std::to_string(shard) + ": " + shard_[(size_t)shard]->last_error(), shard_[(size_t)shard]->last_error_class());
     shard_rows_[(size_t)shard] = n_local;
     n_rows_ = 0;
     for (int64_t v : shard_rows_) n_rows_ += v;

@@ -36,6 +36,8 @@ struct GraphDev {
   DevBuf gens;
   int64_t gens_slots = 0, gens_n = 0;
   uint32_t gen_last = 0;
+  ScratchClaim gens_claim;   // r6: the table is reclaimable scratch (index.hpp) - any failed allocation of the process may take it back between searches
+  GraphDev() { gens_claim.buf = &gens; }
   DevBuf qglobal;    // u64 [slots][qtot] queues of large-L searches
   DevBuf auxglobal;  // int [slots][2*Lq]
   DevBuf queue;      // u64 [nq][L]
@@ -65,6 +67,11 @@ int32_t graph_upload(Index& ix) {
   g.pf_strikes = 0;
   g.pf_off = false;
   g.acc0_epoch = -1;
+  if (!g.gens_claim.busy.exchange(true)) {   // a new graph: the stamp table of the old one is given back (it is sized by the node count; the next search decides anew)
+    g.gens.release();
+    g.gens_slots = g.gens_n = 0;
+    g.gens_claim.busy.store(false);
+  }
   const int64_t n = ix.n_indexed_;
   if (n <= 0) return EPS_OK;
   const int64_t e = ix.h_off_[n];
@@ -246,12 +253,12 @@ int32_t graph_search_impl(Index& ix, const float* dq, int64_t nq, int k, const e
   if (L > n) L = n;  // the reference would spin forever in PrepareInitIds when L > n (see prepare_init_ids)
   // The reference accepts SearchQueueSize up to 10^7 and IntraQueryThreads up to 128 (config/config.hpp:28-44).  What the device
   // does not run it refuses - it never runs a different configuration than the one asked for.
-  if (L > ((int64_t)1 << 20)) return ix.fail(EPS_DB_UNSUPPORTED_ERROR, "search: SearchQueueSize > 1048576 is not supported (use the flat engines)");
+  if (L > ((int64_t)1 << 20)) return ix.fail(EPS_DB_UNSUPPORTED_ERROR, "search: SearchQueueSize > 1048576 is not supported (use the flat engines)", EPS_ERRCLASS_DEVICE_RANGE);
   int64_t Lq = p.local_queue;
   if (Lq > n) Lq = n;
-  if (Lq > ((int64_t)1 << 20)) return ix.fail(EPS_DB_UNSUPPORTED_ERROR, "search: LocalQueueSize > 1048576 is not supported (use the flat engines)");
+  if (Lq > ((int64_t)1 << 20)) return ix.fail(EPS_DB_UNSUPPORTED_ERROR, "search: LocalQueueSize > 1048576 is not supported (use the flat engines)", EPS_ERRCLASS_DEVICE_RANGE);
   const int T = p.intra_threads;
-  if (T > TRV2_MAXT) return ix.fail(EPS_DB_UNSUPPORTED_ERROR, "search: IntraQueryThreads > 128 is not supported (the reference's own limit, config/config.hpp:29)");
+  if (T > TRV2_MAXT) return ix.fail(EPS_DB_UNSUPPORTED_ERROR, "search: IntraQueryThreads > 128 is not supported (the reference's own limit, config/config.hpp:29)", EPS_ERRCLASS_DEVICE_RANGE);
   const int I = (int)std::min<int64_t>(p.sync_interval, 1 << 20);
   int Lp2 = 1;
   while (Lp2 < L) Lp2 <<= 1;
@@ -269,7 +276,7 @@ int32_t graph_search_impl(Index& ix, const float* dq, int64_t nq, int k, const e
   const int dp = (int)(((g.fixed_deg > 0 ? (int64_t)g.fixed_deg : std::max<int64_t>(g.max_degree, 1)) + 7) / 8 * 8);   // edge slots per worker and step
   if ((int64_t)T * dp > 2048)   // the T adjacency lists of one lockstep step share the workgroup's LDS
     return ix.fail(EPS_DB_UNSUPPORTED_ERROR, "search: IntraQueryThreads x maximum out-degree (rounded up to 8) > 2048 is not supported: " + std::to_string(T) + " x " +
-                                                 std::to_string(dp) + " (at the build's out-degree cap of 64: IntraQueryThreads <= 32)");
+                                                 std::to_string(dp) + " (at the build's out-degree cap of 64: IntraQueryThreads <= 32)", EPS_ERRCLASS_DEVICE_RANGE);
   const int64_t qtot = (int64_t)(T - 1) * Lq + Lp2;
   const bool vec4 = (ix.dim_ % 4 == 0) && ((reinterpret_cast<uintptr_t>(ix.d_rows_) & 15) == 0);
   // queues in LDS while a workgroup's working set leaves room for at least two workgroups per CU (the row gathers of
@@ -319,8 +326,8 @@ int32_t graph_search_impl(Index& ix, const float* dq, int64_t nq, int k, const e
   // wavefronts per query, two queries per CU (T = 4, L = 2000, batch 1024: 1M x 768 46.6 -> 39.4 ms, 10M-row proxy 56.8 -> 49.3 ms;
   // 4 wavefronts 64.6, 16 wavefronts 66.1), and 8 wavefronts also beat the 4 that queues in HBM used to get (L = 4000: 126.6 ->
   // 93.6 ms, L = 8000: 350.8 -> 246.7 ms).  A handful of queries (<= 256, latency) keeps the one-workgroup-per-CU form.
-  const size_t lds_limit = tune_env("EPS_TRV_LDS_KB") ? (size_t)std::max(16, atoi(tune_env("EPS_TRV_LDS_KB"))) * 1024
-                                                     : (nq <= 256 ? (size_t)150 * 1024 : (size_t)80 * 1024);   // (A/B knob)
+  const int lds_kb = tune_int("EPS_TRV_LDS_KB", 0);   // (A/B knob)
+  const size_t lds_limit = lds_kb > 0 ? (size_t)std::max(16, lds_kb) * 1024 : (nq <= 256 ? (size_t)150 * 1024 : (size_t)80 * 1024);
   const bool qglobal = lds_need > lds_limit;
   const bool one_per_cu = !qglobal && lds_need > (size_t)80 * 1024;
   const size_t shm = traverse2_lds_bytes((int)ix.dim_, T, (int)Lq, qtot, dp, qglobal, prefilter, q8v.cols8);
@@ -349,9 +356,16 @@ int32_t graph_search_impl(Index& ix, const float* dq, int64_t nq, int k, const e
   // visited set: generation stamps (one atomicMax per edge, no reset) when 4 bytes per node and slot fit comfortably - a quarter of the free HBM
   // and at most 64 GB - else the bitmap with its undo log.  EPS_TRV_VISITED=bitmap|stamps overrides (A/B, tests).
   bool stamps = false;
+  struct ClaimHold {   // from here to the return of this call the table is not reclaimable (the launches below use it)
+    std::atomic<bool>& b;
+    bool mine;
+    explicit ClaimHold(std::atomic<bool>& f) : b(f), mine(!f.exchange(true)) {}
+    ~ClaimHold() { if (mine) b.store(false); }
+  } hold(g.gens_claim.busy);
   {
     const size_t need = (size_t)slots * (size_t)n * 4;
     size_t free_b = 0, total_b = 0;
+    if (!g.gens.p) g.gens_slots = g.gens_n = 0;   // (taken back since the last search)
     const bool have = (g.gens_slots >= slots && g.gens_n == n && g.gens.p);
     if (have) stamps = true;
     else if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need <= free_b / 4 && need <= ((size_t)64 << 30)) stamps = true;
@@ -370,6 +384,10 @@ int32_t graph_search_impl(Index& ix, const float* dq, int64_t nq, int k, const e
         g.gens_slots = g.gens_n = 0;
         stamps = false;   // (no room: the bitmap)
       }
+    }
+    if (!stamps && g.gens.p) {   // the bitmap serves this search: a stale stamp table is not kept beside it
+      g.gens.release();
+      g.gens_slots = g.gens_n = 0;
     }
   }
   if ((!stamps && (!g.visited.reserve((size_t)slots * words * 4) || !g.vlog.reserve((size_t)slots * vcap * 4))) ||
@@ -415,7 +433,7 @@ int32_t graph_search_impl(Index& ix, const float* dq, int64_t nq, int k, const e
   a.gen_base = 0;
   a.counters = g.counters.as<unsigned long long>();
   a.prof = prof ? g.counters.as<unsigned long long>() + 8 : nullptr;
-  if (filtered && k > 1024) return ix.fail(EPS_DB_UNSUPPORTED_ERROR, "search: filter_in_traversal returns at most 1024 rows per query");
+  if (filtered && k > 1024) return ix.fail(EPS_DB_UNSUPPORTED_ERROR, "search: filter_in_traversal returns at most 1024 rows per query", EPS_ERRCLASS_DEVICE_RANGE);
   const int64_t ecap = filtered ? ecap_plan : 0;
   a.elog = nullptr;
   a.elog_cnt = nullptr;

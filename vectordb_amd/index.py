@@ -302,6 +302,10 @@ class GpuIndex:
                 dist = np.empty((nq, k), np.float32)
                 counts = np.empty(nq, np.int32)
         assert queries.shape[1] == self.dim
+        if out is not None:   # the C ABI writes nq x k ids / distances and nq counts through raw pointers: the buffers must be what it assumes
+            _check_out(ids, "ids", (nq, k), "int64")
+            _check_out(dist, "dist", (nq, k), "float32")
+            _check_out(counts, "counts", (nq,), "int32")
         self._check(self.L.eps_index_search(self.h, _ptr(queries), nq, k, C.byref(p), _ptr(ids), _ptr(dist), _ptr(counts)))
         return ids, dist, counts
 
@@ -315,6 +319,15 @@ class GpuIndex:
         s = SearchStats()
         self._check(self.L.eps_index_last_stats(self.h, C.byref(s)))
         return {f: getattr(s, f) for f, _ in SearchStats._fields_}
+
+
+def _check_out(a, name, shape, dtype):
+    """a caller-provided result buffer (NumPy array or device tensor): dtype, shape and C-contiguity, or a ValueError instead of an out-of-bounds write"""
+    got_dtype = str(a.dtype).replace("torch.", "")
+    contiguous = a.is_contiguous() if hasattr(a, "is_contiguous") else bool(a.flags["C_CONTIGUOUS"])
+    if got_dtype != dtype or tuple(a.shape) != tuple(shape) or not contiguous:
+        raise ValueError("search: out[%s] must be a C-contiguous %s array of shape %s, got %s %s%s"
+                         % (name, dtype, tuple(shape), got_dtype, tuple(a.shape), "" if contiguous else " (not contiguous)"))
 
 
 def traversal_gather_bytes(stats, dim, avg_degree, seed_evals=0):
