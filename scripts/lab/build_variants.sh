@@ -11,7 +11,7 @@ for spec in "$@"; do
   [ "$defs" == "$spec" ] && defs=""
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wall -Wno-unused-function -I$R/include $defs \
       -c $R/vectordb_amd/csrc/mfma_filter.hip -o $R/scripts/lab/_ab/mfma_filter_$name.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/scripts/lab/_ab/$name.so $OBJ/index.o $OBJ/shard_group.o $OBJ/flat_kernels.o $OBJ/traverse.o \
-      $R/scripts/lab/_ab/mfma_filter_$name.o $OBJ/graph_build.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/scripts/lab/_ab/$name.so $OBJ/index.o $OBJ/shard_group.o $OBJ/exchange.o $OBJ/flat_kernels.o $OBJ/traverse.o \
+      $R/scripts/lab/_ab/mfma_filter_$name.o $OBJ/graph_build.o -ldl
   echo "built scripts/lab/_ab/$name.so ($defs)"
 done

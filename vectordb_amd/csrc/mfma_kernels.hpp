@@ -365,6 +365,19 @@ __global__ __launch_bounds__(512, 2) void mfma_filter_kernel_v3(FilterArgs a) {
 #define EPS_DS_READ_B128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : EPS_FRAG_C(dst) : "v"(addr), "n"(off))
 #define EPS_GLOAD_B128(dst, voff, sbase, off) \
   asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : EPS_FRAG_C(dst) : "v"(voff), "s"(sbase), "n"(off))
+// r6 lab ablations of the operand transport (-DEPS_LAB -DEPS_V7_ABL=..., answers wrong by construction; scripts/lab/r6_headline_cap.sh):
+//   32  no LDS fragment reads (the row fragments keep the random bytes they are given at the start of the kernel)
+//   64  no global traffic in the K loop: no LDS-DMA pieces, no query-fragment loads, no start-value column
+// with 1 (no epilogue): 1 | 32 | 64 = the kernel's own MFMA stream and nothing else - the rate the matrix pipe sustains on this board under this
+// kernel's barriers and scalar code, i.e. what no operand schedule of this tile shape can exceed.
+#if defined(EPS_V7_ABL) && (EPS_V7_ABL & 32)
+#undef EPS_DS_READ_B128
+#define EPS_DS_READ_B128(dst, addr, off) asm volatile("" : EPS_FRAG_C(dst) : "v"(addr))
+#endif
+#if defined(EPS_V7_ABL) && (EPS_V7_ABL & 64)
+#undef EPS_GLOAD_B128
+#define EPS_GLOAD_B128(dst, voff, sbase, off) asm volatile("" : EPS_FRAG_C(dst) : "v"(voff), "s"(sbase))
+#endif
 
 // ------------------------------------------------------------------------------------------------ v7 kernel
 // (v5, the 8-wavefront predecessor of this kernel, lives in scripts/lab/lab_v5.hpp.)  Its operand transport - query
@@ -461,14 +474,18 @@ __global__ __launch_bounds__(256, NRB == 8 ? 1 : 2) void mfma_filter_kernel_v7(F
     if (wave * 64 >= TR) return;   // (NRB = 4: the first two wavefronts; the others' VMEM counts run one behind, which only makes their waits stricter)
     const float* pb = a.base_s + (a.tile0 + tile_rt(ri)) * TR + wave * 64;
     const u32 m0v = lds_base + RING * ASLOT + (u32)((par * 256 + wave * 64) * 4);
+#if !(defined(EPS_V7_ABL) && (EPS_V7_ABL & 64))
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : : "v"(lane4), "s"(pb), "s"(m0v) : "memory");
+#endif
   };
   // LDS-DMA, saddr form: 32-bit lane offset + scalar base, M0 = LDS address of lane 0's 16 bytes.  Hand-issued so the
   // compiler neither forms 64-bit VGPR addresses nor tracks these in its waitcnt model (see v5).
   auto issue_piece = [&](const _Float16* pA, u32 slot_off, int it) {   // pA: first row of the tile, at the K-step to fetch
     const _Float16* sb = pA + (int64_t)it * 32 * ldk;
     const u32 m0v = lds_base + slot_off + (it * 256 + wave * 64) * 16;
+#if !(defined(EPS_V7_ABL) && (EPS_V7_ABL & 64))
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(g_off0), "s"(sb), "s"(m0v) : "memory");
+#endif
   };
 
   // the same in two halves for the K loop: address + M0 behind one MFMA, the DMA instruction alone behind the next (the MFMA
@@ -480,7 +497,9 @@ __global__ __launch_bounds__(256, NRB == 8 ? 1 : 2) void mfma_filter_kernel_v7(F
     return sb;
   };
   auto fire_piece = [&](const _Float16* sb) __attribute__((always_inline)) {
+#if !(defined(EPS_V7_ABL) && (EPS_V7_ABL & 64))
     asm volatile("global_load_lds_dwordx4 %0, %1" : : "v"(g_off0), "s"(sb) : "memory");
+#endif
   };
 
   acc_t acc[NRB][JQ];
@@ -512,6 +531,25 @@ __global__ __launch_bounds__(256, NRB == 8 ? 1 : 2) void mfma_filter_kernel_v7(F
     for (int kk = 0; kk < 4; ++kk) faddr[kk] = lds_base + (u32)swz((int)(ln & 31), kk * 2 + (int)(ln >> 5)) * 16;
   };
   lane_values();
+#if defined(EPS_V7_ABL) && (EPS_V7_ABL & (32 | 64))
+  {   // the ablated transports leave operands where they are: give fragments and ring bytes that toggle like data (a zero operand runs the pipe at 2.4 GHz)
+    u32 h = (u32)tid * 2654435761u + (u32)blockIdx.x * 40503u + 12345u;
+    auto nx = [&]() { h ^= h << 13; h ^= h >> 17; h ^= h << 5; return h; };
+    for (int i = tid; i < RING * ASLOT / 4; i += 256) reinterpret_cast<u32*>(lds)[i] = nx();
+    typedef u32 __attribute__((ext_vector_type(4))) u32x4;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int i = 0; i < NRB; ++i) { u32x4 v = {nx(), nx(), nx(), nx()}; fa[c][i] = __builtin_bit_cast(frag_t, v); }
+#pragma unroll
+    for (int c = 0; c < FBUF; ++c)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int j = 0; j < JQ; ++j) { u32x4 v = {nx(), nx(), nx(), nx()}; fb[c][kk][j] = __builtin_bit_cast(frag_t, v); }
+    __syncthreads();
+  }
+#endif
 
   const int64_t a_stride = (int64_t)8 * G * TR * ldk;   // halfs between consecutive row tiles of this workgroup
   int ri_c = 0, qi_c = 0;        // tile t
