@@ -901,6 +901,17 @@ static int32_t ensure_mirror8(Index& ix) {
       const float lo = host_ord2f(omin), hi = host_ord2f(omax);
       g->ok = m.h_scal8[3] == 0.f && omin <= omax && hi > lo && std::isfinite(lo) && std::isfinite(hi) && std::isfinite(hi - lo);
       float clo = lo, chi = hi;
+      // (EPS_MIRROR_CLIP = e: cut 10^-e of the sample's values off each tail instead of 10^-7, and keep the cut in the rotated frame too - lab knob, r6)
+      const char* clip_e = tune_env("EPS_MIRROR_CLIP");
+      const bool clip_set = clip_e != nullptr;
+      // r6, rotated frame on a LARGE table (>= 4M rows): the cut is kept, at 10^-6 per tail.  Near-Gaussian columns put the whole table's range at
+      // ~6.3 sigma (10M x 768 values) while 10^-6 of them lie beyond 4.9 sigma: the step - and with it both terms of the margin - shrinks by a
+      // quarter, the 0.15 % of rows with a clamped value carry their own residual (folded per batch: 40 us), and a batch of 1024 queries on
+      // 10M x 768 embedding-like rows re-ranks 958 instead of 2186 rows per query: 8.80 -> 7.64 ms per step (10^-7: 7.87, 10^-5: 8.08 - clamped
+      // residuals start to dominate; profiles/r6_embedding_like_grid_cut.txt).  Smaller tables keep the whole range: no row is clamped, nothing
+      // is folded, and the one-pass search (which reads the rows' own start values) serves their single-query calls at half the staged chain's latency.
+      const bool large_rot = rot && n >= 4000000;
+      const double clip_frac = clip_set ? std::pow(10.0, -std::max(1.0, std::min(9.0, atof(clip_e)))) : (large_rot ? 1e-6 : 1e-7);
       auto clip_range = [&]() -> int32_t {
       // clip both tails of the SAMPLE's x - mean at max(2, 1e-7 x values) values (centre_hist_kernel); where the cut removes most of the
       // range - an outlier thousands of grid widths away leaves the bulk in ONE bin - the histogram is taken again inside the cut (values
@@ -916,7 +927,7 @@ static int32_t ensure_mirror8(Index& ix) {
         e3 = hipMemcpyAsync(hh.data(), m.hist.p, 4096 * 4, hipMemcpyDeviceToHost, s);
         if (e3 == hipSuccess) e3 = hipStreamSynchronize(s);
         if (e3 != hipSuccess) return ix.hip_fail(e3, "8-bit mirror: value histogram");
-        const unsigned long long tol = std::max<unsigned long long>(2ull, (unsigned long long)(1e-7 * (double)sampled * (double)sdim));
+        const unsigned long long tol = std::max<unsigned long long>(2ull, (unsigned long long)(clip_frac * (double)sampled * (double)sdim));
         unsigned long long cum = 0;
         int blo = 0, bhi = 4095;
         for (blo = 0; blo < 4096; ++blo) {
@@ -966,7 +977,7 @@ static int32_t ensure_mirror8(Index& ix) {
       // margin is as tight as per-row margins would be, nothing is folded per batch, and the one-pass search (which reads the rows' own start
       // values, stream8_kernel.hpp) serves the table: 1M x 768 embedding-like rows, one query per call: 0.38 ms on the staged chain with
       // folded margins (profiles/r6_rotated_frame_one_pass_1M.txt).  An outlier that would stretch the grid further than that keeps the cut.
-      if (rot && g->ok && (clo > lo || chi < hi) && (hi - lo) <= 1.35f * (chi - clo)) {
+      if (rot && g->ok && !clip_set && !large_rot && (clo > lo || chi < hi) && (hi - lo) <= 1.35f * (chi - clo)) {
         clo = lo;
         chi = hi;
       }

@@ -124,6 +124,7 @@ template <> struct V7Op<true> {
 #endif
 #if EPS_V7_VI > 0
 #define EPS_FRAG_C "=a"
+#define EPS_FRAG_RW "+a"
 template <bool I8> struct V7Asm;
 template <> struct V7Asm<true> {
   template <class A, class F> static __device__ __forceinline__ void v(A& acc, const F& a, const F& b) { asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(acc) : "a"(a), "a"(b)); }
@@ -139,6 +140,7 @@ template <> struct V7Asm<false> {
 };
 #else
 #define EPS_FRAG_C "=v"
+#define EPS_FRAG_RW "+v"
 #endif
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (row << 3) + (chunk ^ ((row >> 1) & 7)); }  // 16-B granule index
@@ -372,11 +374,11 @@ __global__ __launch_bounds__(512, 2) void mfma_filter_kernel_v3(FilterArgs a) {
 // kernel's barriers and scalar code, i.e. what no operand schedule of this tile shape can exceed.
 #if defined(EPS_V7_ABL) && (EPS_V7_ABL & 32)
 #undef EPS_DS_READ_B128
-#define EPS_DS_READ_B128(dst, addr, off) asm volatile("" : EPS_FRAG_C(dst) : "v"(addr))
+#define EPS_DS_READ_B128(dst, addr, off) asm volatile("" : EPS_FRAG_RW(dst) : "v"(addr))   /* (read-write: the fragment keeps the random bytes it was given) */
 #endif
 #if defined(EPS_V7_ABL) && (EPS_V7_ABL & 64)
 #undef EPS_GLOAD_B128
-#define EPS_GLOAD_B128(dst, voff, sbase, off) asm volatile("" : EPS_FRAG_C(dst) : "v"(voff), "s"(sbase))
+#define EPS_GLOAD_B128(dst, voff, sbase, off) asm volatile("" : EPS_FRAG_RW(dst) : "v"(voff), "s"(sbase))
 #endif
 
 // ------------------------------------------------------------------------------------------------ v7 kernel
