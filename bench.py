@@ -35,9 +35,9 @@ sys.path.insert(0, ROOT)
 # run: `roofline.traffic` is null here and `roofline.traffic_reference` names the committed profile of the same launch shape (file,
 # sha256 of the file as it lies in this tree, the bytes it shows, and which round's kernel it was taken on).
 TRAFFIC_REF = {
-    "mfma8": {"file": "profiles/r5_pmc_10Mx768_b1024.csv", "bytes_per_launch": (2 * 2753192 + 3823) * 1024.0, "algorithmic_bytes": 7280256 * 768.0,
-              "launch": "mfma_filter_kernel_v7<2, FM_IDS, int8>, 7,280,256 rows x 1024 queries (last of 6 stages), occurrence 11 of the PMC passes",
-              "taken_on": "r5 library (scripts/run_flat_profile_r5.sh; the filter kernel itself is r4's)"},
+    "mfma8": {"file": "profiles/r6_pmc_10Mx768_b1024.csv", "bytes_per_launch": (2 * 2752675 + 3866) * 1024.0, "algorithmic_bytes": 7280256 * 768.0,
+              "launch": "mfma_filter_kernel_v7<2, FM_IDS, int8, 8>, 7,280,256 rows x 1024 queries (last of 6 stages), occurrence 5 of the PMC passes (library kernels' rows only)",
+              "taken_on": "r6 library (scripts/run_flat_profile_r6.sh: PMC passes, then the line; the filter kernel itself is r4's)"},
     "mfma": {"file": "profiles/r2_pmc_10Mx768_b1024.csv", "bytes_per_launch": (2 * 7340245 + 7460) * 1024.0, "algorithmic_bytes": 9262720 * 1536.0,
              "launch": "mfma_filter_kernel_v7<2, FM_IDS> (fp16), 9,262,720 rows x 1024 queries", "taken_on": "r2 kernel"},
     "graph_T4_L500": {"file": "profiles/r5_traverse_10Mx768_pmc.csv", "bytes_per_launch": (2 * 19176716 + 1055271) * 1024.0, "algorithmic_bytes": 41.1e9,
