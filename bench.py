@@ -40,9 +40,9 @@ TRAFFIC_REF = {
               "taken_on": "r6 library (scripts/run_flat_profile_r6.sh: PMC passes, then the line; the filter kernel itself is r4's)"},
     "mfma": {"file": "profiles/r2_pmc_10Mx768_b1024.csv", "bytes_per_launch": (2 * 7340245 + 7460) * 1024.0, "algorithmic_bytes": 9262720 * 1536.0,
              "launch": "mfma_filter_kernel_v7<2, FM_IDS> (fp16), 9,262,720 rows x 1024 queries", "taken_on": "r2 kernel"},
-    "graph_T4_L500": {"file": "profiles/r5_traverse_10Mx768_pmc.csv", "bytes_per_launch": (2 * 19176716 + 1055271) * 1024.0, "algorithmic_bytes": 41.1e9,
+    "graph_T4_L500": {"file": "profiles/r6_traverse_10Mx768_pmc.csv", "bytes_per_launch": (2 * 19184815 + 1055271) * 1024.0, "algorithmic_bytes": 41.1e9,
                       "launch": "traverse2_kernel T=4 L=500 batch 1024, 10M-node device-built graph, 8-bit prefilter, edge constants, visited stamps (occurrences 0, 1)",
-                      "taken_on": "r5 kernel (scripts/run_10m_graph_r5.sh)"},
+                      "taken_on": "r6 library (scripts/run_10m_graph_r6.sh: PMC passes, then the line; the kernel is r5's)"},
 }
 
 

@@ -165,3 +165,37 @@ def test_traversal_prefilter_is_invisible_in_the_rotated_frame(amd, monkeypatch,
     assert a[3] == b[3] and a[4] == b[4]
     assert b[5] < b[3], (b[5], b[3])
     ix.close()
+
+
+@pytest.mark.parametrize("metric", [1, 0, 2])
+def test_rotated_frame_with_a_cut_grid_folds_the_clamped_rows_margins_and_stays_exact(amd, monkeypatch, metric):
+    """r6, late: on tables of 4M rows and more the rotated grid cuts 10^-6 of the values off each tail (profiles/r6_embedding_like_grid_cut.txt): rows
+    with a clamped value carry their own residual and the margins are folded per batch.  The same path at a size the suite can afford: the cut
+    forced by EPS_MIRROR_CLIP (10^-4: far more clamped rows than the shipped 10^-6) - folded margins, the 8-bit pass, the scan's answer bit for bit
+    for a batch and for single-query calls (which such a table answers on the staged chain), and the traversal's prefilter invisible on it."""
+    monkeypatch.setenv("EPS_MIRROR_ROTATE", "1")
+    monkeypatch.setenv("EPS_MIRROR_CLIP", "4")
+    n, d, nq = 200_000, 768, 200
+    X, Q = embedding_like(n, d, 15), embedding_like(nq, d, 16)
+    if metric == 0:
+        X, Q = X * 2.0, Q * 2.0
+    ix = amd.GpuIndex(d, metric)
+    ix.attach_rows(X)
+    ref = ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
+    for it in range(2):
+        same(ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8), ref, "batch %d" % it)
+        st = ix.stats()
+        assert (st["main_kernel_bits"], st["i8_rotated"], st["i8_folded"]) == (8, 1, 1), st
+    for q in range(3):
+        same(ix.search(Q[q:q + 1], 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8), tuple(r[q:q + 1] for r in ref), "single query %d" % q)
+    # the traversal's prefilter on the same mirror (per-batch start values, no edge constants)
+    ix.build(20_000)
+    res = {}
+    for pf in ("0", "1"):
+        monkeypatch.setenv("EPS_TRV_PREFILTER", pf)
+        ids, dist, cnt = ix.search(Q[:32], 50, mode=amd.MODE_GRAPH, intra_threads=4, master_queue=300, local_queue=300)
+        st = ix.stats()
+        res[pf] = (ids.copy(), dist.copy(), cnt.copy(), st["dist_evals"], st["expansions"])
+    a, b = res["0"], res["1"]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)) and np.array_equal(a[2], b[2]) and a[3:] == b[3:]
+    ix.close()

@@ -277,6 +277,13 @@ int32_t graph_search_impl(Index& ix, const float* dq, int64_t nq, int k, const e
   if ((int64_t)T * dp > 2048)   // the T adjacency lists of one lockstep step share the workgroup's LDS
     return ix.fail(EPS_DB_UNSUPPORTED_ERROR, "search: IntraQueryThreads x maximum out-degree (rounded up to 8) > 2048 is not supported: " + std::to_string(T) + " x " +
                                                  std::to_string(dp) + " (at the build's out-degree cap of 64: IntraQueryThreads <= 32)", EPS_ERRCLASS_DEVICE_RANGE);
+  // r6: the capacity a worker's queue is LAID OUT with.  Between two MergeAllQueuesToMaster calls (which empty it, :297-326) a worker's queue holds its
+  // share of the master's unchecked candidates - PickTopMToWorkers deals them round-robin, every T-th stays with the master: <= ceil(L / T) (:328-356) -
+  // plus what its <= I expansions of the round insert, <= out-degree each (:384-444).  A capacity above that bound never clamps an insert and never
+  // stops the dealing early, so the walk with LocalQueueSize = min(LocalQueueSize, bound) is the walk with LocalQueueSize, key for key
+  // (test_lockstep_workers_match_oracle holds whole queues against the oracle, which keeps the caller's value).  What it buys: T = 4, L = 2000
+  // needs 3 x 1460 + 2048 keys instead of 3 x 2000 + 2048 - the queues stay in LDS where the larger layout sent them to HBM.
+  if (T > 1) Lq = std::min<int64_t>(Lq, (L + T - 1) / T + (int64_t)I * dp);
   const int64_t qtot = (int64_t)(T - 1) * Lq + Lp2;
   const bool vec4 = (ix.dim_ % 4 == 0) && ((reinterpret_cast<uintptr_t>(ix.d_rows_) & 15) == 0);
   // queues in LDS while a workgroup's working set leaves room for at least two workgroups per CU (the row gathers of
