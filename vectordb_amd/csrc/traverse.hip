@@ -340,7 +340,10 @@ int32_t graph_search_impl(Index& ix, const float* dq, int64_t nq, int k, const e
   const size_t shm = traverse2_lds_bytes((int)ix.dim_, T, (int)Lq, qtot, dp, qglobal, prefilter, q8v.cols8);
   // few queries: 16 wavefronts per query (latency); many queries: fewer per query (throughput, more queries per CU)
   const char* waves_s = tune_env("EPS_TRV_WAVES");
-  int nw = waves_s ? atoi(waves_s) : ((nq <= 256 || one_per_cu) ? 16 : (qglobal ? 8 : 4));
+  // r6: LDS queues that leave room for only TWO workgroups per CU (40-80 KB: T = 4 from L ~ 600) get 8 wavefronts each - 16 per CU as with four small
+  // workgroups, and the step's T x degree rows spread over twice the lanes (10M x 768 proxy, batch 1024, T = 4: L = 700 14.3 -> 12.5 ms, L = 1000
+  // 18.8 -> 17.1, L = 2000 37.1 -> 33.3 where HBM queues took 42.5; 16 wavefronts: 17.1 / 23.4 / 45.7 - profiles/r6_traverse_large_queues_proxy.txt)
+  int nw = waves_s ? atoi(waves_s) : ((nq <= 256 || one_per_cu) ? 16 : ((qglobal || shm > (size_t)40 * 1024) ? 8 : 4));
   if (const char* wide_s = tune_env("EPS_TRV_WIDE")) nw = atoi(wide_s) != 0 ? 16 : 4;   // (older switch)
   if (nw != 4 && nw != 8 && nw != 16) nw = 4;
   hipDeviceProp_t prop;
