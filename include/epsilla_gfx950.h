@@ -362,8 +362,8 @@ void eps_exchange_destroy(eps_exchange* x);
  *   EPS_MFMA_PROBE, EPS_MFMA_SEED, EPS_MFMA_GROUPSYNC, EPS_MFMA_SYNC_SHIFT, EPS_MFMA_STAGES, EPS_MFMA_KERNEL, EPS_MFMA_NARROW,
  *   EPS_MFMA_TWO_PER_CU, EPS_MFMA_FOLD, EPS_MFMA_MANTISSA, EPS_BUILD_BLOCK, EPS_BUILD_VISITED, EPS_BUILD_PREFILTER,
  *   EPS_MIRROR_ROTATE 0|1 (frame of the 8-bit grid: identity | rotated; unset = chosen per table when its mirror is first built; read at that moment only),
- *   EPS_MIRROR_CLIP e (the grid cuts 10^-e of the sampled values off each tail, 1 <= e <= 9, in either frame; unset = 10^-7, rotated frame: the whole
- *   range below 4M rows, 10^-6 from there on; read when the mirror is first built).
+ *   EPS_MIRROR_CLIP e (the grid cuts 10^-e of the sampled values off each tail, 1 <= e <= 9, in either frame; unset = 10^-7, rotated frame 10^-6;
+ *   read when the mirror is first built), EPS_S8_FOLD 0|1 (the one-pass search on tables whose margins are folded per batch).
  * Switches that make answers WRONG on purpose (kernel ablations for profiling) exist only in a lab build (-DEPS_LAB), which
  * also falls back to the environment for names the table does not hold.  Returns EPS_OK. */
 int32_t eps_set_tuning(const char* name, const char* value);

@@ -625,3 +625,34 @@ def test_query_beyond_the_fp16_range_is_not_dropped(amd):
     for eng in (amd.FLAT_MFMA, amd.FLAT_MFMA_I8, amd.FLAT_AUTO):
         same(ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=eng), ref, "engine %d" % eng)
     ix.close()
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_one_pass_search_on_a_table_with_folded_margins(amd, metric):
+    """r6: ONE-PASS calls (1-16 queries per call, k up to 64) on a table whose rows differ - a clamped value, a forced row - so that its margins are
+    folded per batch: the per-row margins folded for the call's queries (fold8_kernel behind the prep launch), margin-free thresholds, offers of
+    `accumulator - 2 x the row's margin` (stream8_offer_value: the number whose upper bound holds for the row).  The scan's answer bit for bit, outlier
+    rows and outlier queries included; the forced row is a candidate of every call and never enters the slot table."""
+    rng = np.random.default_rng(27 + metric)
+    n, d = 120_000, 512
+    X = rng.random((n, d), dtype=np.float32)
+    X[4321, 3] = 100.0
+    X[777, 200] = -40.0
+    if metric == 0:
+        X[60_000, 17] = 30_000.0      # forced
+    Q = rng.random((16, d), dtype=np.float32)
+    Qo = np.stack([X[4321], X[777], X[60_000], X[5] + np.float32(0.01)] + [Q[i] for i in range(12)])
+    ix = amd.GpuIndex(d, metric)
+    ix.attach_rows(X)
+    ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
+    assert ix.stats()["i8_folded"] == 1, ix.stats()
+    served = 0
+    for nq1, k1 in ((1, 10), (2, 10), (4, 16), (8, 10), (16, 10), (1, 64), (3, 40)):
+        for qset in (Q, Qo):
+            got = ix.search(qset[:nq1], k1, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
+            st1 = ix.stats()
+            same(got, ix.search(qset[:nq1], k1, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM), "one-pass, folded margins: %d queries k=%d" % (nq1, k1))
+            served += st1["one_pass"]
+            assert not st1["one_pass"] or (st1["i8_folded"] == 1 and st1["main_kernel_bits"] == 8), st1
+    assert served >= 5, served      # (a call of outlier queries may overflow its lists and take the staged chain; regular queries must not)
+    ix.close()

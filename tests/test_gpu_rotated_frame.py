@@ -172,7 +172,8 @@ def test_rotated_frame_with_a_cut_grid_folds_the_clamped_rows_margins_and_stays_
     """r6, late: on tables of 4M rows and more the rotated grid cuts 10^-6 of the values off each tail (profiles/r6_embedding_like_grid_cut.txt): rows
     with a clamped value carry their own residual and the margins are folded per batch.  The same path at a size the suite can afford: the cut
     forced by EPS_MIRROR_CLIP (10^-4: far more clamped rows than the shipped 10^-6) - folded margins, the 8-bit pass, the scan's answer bit for bit
-    for a batch and for single-query calls (which such a table answers on the staged chain), and the traversal's prefilter invisible on it."""
+    for a batch and for single-query calls (one pass over the mirror, r6 late: offers carry `accumulator - 2 x margin`), and the traversal's prefilter
+    invisible on it."""
     monkeypatch.setenv("EPS_MIRROR_ROTATE", "1")
     monkeypatch.setenv("EPS_MIRROR_CLIP", "4")
     n, d, nq = 200_000, 768, 200
@@ -186,8 +187,12 @@ def test_rotated_frame_with_a_cut_grid_folds_the_clamped_rows_margins_and_stays_
         same(ix.search(Q, 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8), ref, "batch %d" % it)
         st = ix.stats()
         assert (st["main_kernel_bits"], st["i8_rotated"], st["i8_folded"]) == (8, 1, 1), st
-    for q in range(3):
+    one = 0
+    for q in range(6):   # (r6, late: the one-pass search serves such tables too - folded start values, margin-free thresholds)
         same(ix.search(Q[q:q + 1], 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8), tuple(r[q:q + 1] for r in ref), "single query %d" % q)
+        one += ix.stats()["one_pass"]
+    same(ix.search(Q[:8], 10, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8), tuple(r[:8] for r in ref), "8 queries per call")
+    assert one >= 1, one
     # the traversal's prefilter on the same mirror (per-batch start values, no edge constants)
     ix.build(20_000)
     res = {}

@@ -40,7 +40,7 @@ TUNING_NAMES = (
     "EPS_DEBUG", "EPS_TRV_PROF", "EPS_TRV_PREFILTER", "EPS_TRV_VISITED", "EPS_TRV_STAMP_START", "EPS_TRV_WAVES", "EPS_TRV_WIDE", "EPS_TRV_PER_CU", "EPS_TRV_LDS_KB", "EPS_FLAT_ONE_PASS",
     "EPS_ONE_PASS_TIMED", "EPS_DEBUG_ONE_PASS_OVERFLOW", "EPS_S8_WG_PER_CU", "EPS_S8_HOST_WORDS", "EPS_S8_MAX_Q", "EPS_S8_MAX_K", "EPS_S8_FILTER_PROGRAMS", "EPS_S8_RERANK", "EPS_HOST_STAGING", "EPS_S8_TWO_LAUNCHES", "EPS_RERANK_SPLIT", "EPS_MFMA_BITS", "EPS_MFMA_MAX_BATCH",
     "EPS_MFMA_PROBE", "EPS_MFMA_SEED", "EPS_MFMA_GROUPSYNC", "EPS_MFMA_SYNC_SHIFT", "EPS_MFMA_STAGES", "EPS_MFMA_KERNEL", "EPS_MFMA_NARROW",
-    "EPS_MFMA_TWO_PER_CU", "EPS_MFMA_FOLD", "EPS_MFMA_MANTISSA", "EPS_BUILD_BLOCK", "EPS_BUILD_VISITED", "EPS_BUILD_PREFILTER", "EPS_S8_ABLATE", "EPS_MIRROR_ROTATE", "EPS_MIRROR_CLIP",
+    "EPS_MFMA_TWO_PER_CU", "EPS_MFMA_FOLD", "EPS_MFMA_MANTISSA", "EPS_BUILD_BLOCK", "EPS_BUILD_VISITED", "EPS_BUILD_PREFILTER", "EPS_S8_ABLATE", "EPS_S8_FOLD", "EPS_MIRROR_ROTATE", "EPS_MIRROR_CLIP",
 )
 _forwarded = {}
 

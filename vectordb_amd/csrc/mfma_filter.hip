@@ -904,14 +904,14 @@ static int32_t ensure_mirror8(Index& ix) {
       // (EPS_MIRROR_CLIP = e: cut 10^-e of the sample's values off each tail instead of 10^-7, and keep the cut in the rotated frame too - lab knob, r6)
       const char* clip_e = tune_env("EPS_MIRROR_CLIP");
       const bool clip_set = clip_e != nullptr;
-      // r6, rotated frame on a LARGE table (>= 4M rows): the cut is kept, at 10^-6 per tail.  Near-Gaussian columns put the whole table's range at
-      // ~6.3 sigma (10M x 768 values) while 10^-6 of them lie beyond 4.9 sigma: the step - and with it both terms of the margin - shrinks by a
-      // quarter, the 0.15 % of rows with a clamped value carry their own residual (folded per batch: 40 us), and a batch of 1024 queries on
-      // 10M x 768 embedding-like rows re-ranks 958 instead of 2186 rows per query: 8.80 -> 7.64 ms per step (10^-7: 7.87, 10^-5: 8.08 - clamped
-      // residuals start to dominate; profiles/r6_embedding_like_grid_cut.txt).  Smaller tables keep the whole range: no row is clamped, nothing
-      // is folded, and the one-pass search (which reads the rows' own start values) serves their single-query calls at half the staged chain's latency.
-      const bool large_rot = rot && n >= 4000000;
-      const double clip_frac = clip_set ? std::pow(10.0, -std::max(1.0, std::min(9.0, atof(clip_e)))) : (large_rot ? 1e-6 : 1e-7);
+      // r6, rotated frame: the cut is kept, at 10^-6 per tail.  Near-Gaussian columns put the whole table's range at ~6.3 sigma (10M x 768 values)
+      // while 10^-6 of them lie beyond 4.9 sigma: the step - and with it both terms of the margin - shrinks by a quarter, the 0.15 % of rows with
+      // a clamped value carry their own residual (folded per batch: 40 us at 10M rows).  10M x 768 embedding-like rows, batch 1024: 958 instead of
+      // 2186 re-ranked rows per query, 8.80 -> 7.64 ms per step (10^-7: 7.87, 10^-5: 8.08 - clamped residuals start to dominate;
+      // profiles/r6_embedding_like_grid_cut.txt).  1M x 768, 1 / 3 / 8 / 16 queries per call (the one-pass search, which serves tables with
+      // folded margins since r6): 0.232 / 0.281 / 0.299 / 0.356 ms against 0.286 / 0.380 / 0.497 / 0.464 with the whole range
+      // (profiles/r6_rotated_frame_one_pass_1M.txt).
+      const double clip_frac = clip_set ? std::pow(10.0, -std::max(1.0, std::min(9.0, atof(clip_e)))) : (rot ? 1e-6 : 1e-7);
       auto clip_range = [&]() -> int32_t {
       // clip both tails of the SAMPLE's x - mean at max(2, 1e-7 x values) values (centre_hist_kernel); where the cut removes most of the
       // range - an outlier thousands of grid widths away leaves the bulk in ONE bin - the histogram is taken again inside the cut (values
@@ -971,15 +971,6 @@ static int32_t ensure_mirror8(Index& ix) {
         chi = hi + delta;
         rc = clip_range();
         if (rc != EPS_OK) return rc;
-      }
-      // Rotated frame: every column is a signed mean of 256 values - near-Gaussian tails, so the whole table's range is only ~1.2 x the range
-      // that leaves 1e-7 of the sample outside.  Taking it means NO row is clamped: all rows keep the plain rounding residual, the table-wide
-      // margin is as tight as per-row margins would be, nothing is folded per batch, and the one-pass search (which reads the rows' own start
-      // values, stream8_kernel.hpp) serves the table: 1M x 768 embedding-like rows, one query per call: 0.38 ms on the staged chain with
-      // folded margins (profiles/r6_rotated_frame_one_pass_1M.txt).  An outlier that would stretch the grid further than that keeps the cut.
-      if (rot && g->ok && !clip_set && !large_rot && (clo > lo || chi < hi) && (hi - lo) <= 1.35f * (chi - clo)) {
-        clo = lo;
-        chi = hi;
       }
       g->z0 = g->ok ? 0.5f * clo + 0.5f * chi : 0.f;
       g->half = g->ok ? std::max(chi - g->z0, g->z0 - clo) : 127.f;
@@ -1143,7 +1134,7 @@ bool flat_mfma_profitable(const Index& ix, int64_t nq, int k) {
   const double rate = use8 ? 2.0e15 : 1.2e15;                    // matrix rate the filter kernel reaches
   const double dp = use8 ? op_bytes : op_bytes / 2.0;
   const double stream_s = std::ceil((double)nq / 4.0) * rows * d * 4.0 / 6.0e12 + 0.2e-3;
-  const double filter_s = (use8 && one_pass_shape && !(have8 && m->fold8))   // (r5: filter programs take the one-pass form too - behind one mask launch)
+  const double filter_s = (use8 && one_pass_shape)   // (r5: filter programs take the one-pass form too - behind one mask launch; r6: so do tables with folded margins)
                               ? 0.07e-3 + rows * (std::ceil(d / 256.0) * 256.0 + 4.0) / 5.7e12
                               : 0.35e-3 + std::max(rows * op_bytes / 5.0e12, 2.0 * 128.0 * std::ceil((double)nq / 128.0) * rows * dp / rate);
   return filter_s < stream_s;
@@ -1159,7 +1150,11 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
   if (tune_int("EPS_FLAT_ONE_PASS", 1) == 0) return EPS_OK;
   const int max_q = std::min(S8_MAX_Q, std::max(1, tune_int("EPS_S8_MAX_Q", S8_MAX_Q)));   // (A/B switch: 4 = the r4 form, 5+ queries on the staged chain)
   const int max_k = std::min(S8_MAX_K, std::max(1, tune_int("EPS_S8_MAX_K", S8_MAX_K)));   // (A/B switch: 16 = the r4 range, larger k on the staged chain)
-  if (nq < 1 || nq > max_q || k < 1 || k > max_k || m.fold8 || n < 65536 || n > m.n8 || m.d_pad8 % 256 != 0 || pieces < 2 || pieces > 4) return EPS_OK;
+  if (nq < 1 || nq > max_q || k < 1 || k > max_k || n < 65536 || n > m.n8 || m.d_pad8 % 256 != 0 || pieces < 2 || pieces > 4) return EPS_OK;
+  // r6: tables whose margins are folded per batch (m.fold8: rows with a clamped value) take the form too - behind the prep launch and the fold
+  // launch (the margins depend on the call's queries), with margin-free thresholds and offers of `accumulator - 2 x the row's margin` (stream8_offer_value)
+  const bool fold = m.fold8 && tune_int("EPS_S8_FOLD", 1) != 0;   // (A/B switch: 0 = such tables on the staged chain, as until r6)
+  if (m.fold8 && !fold) return EPS_OK;
   // (r6: ... and per kernel form - five or more queries share one list budget per query and overflow on tables where one query does not:
   // an 8-query batch must not talk the table out of the form for single-query traffic)
   const int kclass = (k <= 16 ? 0 : 1) + (nq <= 4 ? 0 : 2);
@@ -1203,7 +1198,7 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
   const int slots = k <= 16 ? S8_SLOTS : S8_SLOTS_WIDE;
   const bool mfma_form = nq > 4 || (slots != S8_SLOTS && nq > 2);   // stream8m_kernel (16 query columns: the prep launch lays down 16 rows, zeros beyond nq)
   // (a table in the rotated frame keeps the prep launch: the transform is its work, not the pass's)
-  const bool clean = two_launches && nq <= 2 && slots == S8_SLOTS && m.s8_clean_cnt == m.cnt.p && m.s8_clean_g == m.s8g.p && !m.rot8;
+  const bool clean = two_launches && nq <= 2 && slots == S8_SLOTS && m.s8_clean_cnt == m.cnt.p && m.s8_clean_g == m.s8g.p && !m.rot8 && !fold;
   m.s8_clean_cnt = m.s8_clean_g = nullptr;   // (set again when this call has come back)
   if (!clean) {
     Prep8Extra px;
@@ -1211,17 +1206,26 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
     px.cntv = 0;
     px.s8g = m.s8g.as<int>();
     px.s8_slots = slots;
+    if (fold) {
+      px.qmax = m.qmax.as<u32>();
+      if (hipMemsetAsync(m.qmax.p, 0, 8, s) != hipSuccess) return ix.hip_fail(hipGetLastError(), "memset");
+    }
     launch_query_prep8(dim3(mfma_form ? 4 : 1), s, m.rot8 ? m.sp8.as<int>() : nullptr, m.rot_w8, dq, nq, (int64_t)(mfma_form ? 16 : 4), (int)ix.dim_, m.d_pad8, m.mu8.as<float>(),
                        m.step8, ix.metric_, m.q8.as<signed char>(), m.qstat.as<float>(), px);
+    if (fold)   // (16 bytes per row: 5 us at 1M rows, 40 us at 10M - where the pass itself takes 1.4 ms)
+      hipLaunchKernelGGL(fold8_kernel, dim3((unsigned)std::min<int64_t>((m.n_pad8 + 255) / 256, 8192)), dim3(256), 0, s, m.acc0.as<int>(), m.erow.as<float>(),
+                         m.hrow.as<float>(), m.n8, m.n_pad8, m.qmax.as<u32>(), ix.metric_ == 0 ? 2.f : 1.f, 1.f / u8, m.acc0b.as<int>());
   }
+  ix.stats_.i8_folded = fold ? 1 : 0;
   Stream8Args a;
   a.x8 = m.x8.as<signed char>();
-  a.acc0 = m.acc0.as<int>();
+  a.acc0 = fold ? m.acc0b.as<int>() : m.acc0.as<int>();
+  a.acc0_raw = fold ? m.acc0.as<int>() : nullptr;
   a.n = n;
   a.d_pad8 = m.d_pad8;
   a.q8 = m.q8.as<signed char>();
   a.qstat = m.qstat.as<float>();
-  a.scal = m.scal8.as<float>();
+  a.scal = fold ? m.scal8f.as<float>() : m.scal8.as<float>();   // (folded: the margin entries are zero - the margins are in the start values)
   a.nq = (int)nq;
   a.k = k;
   a.metric = ix.metric_;
@@ -1303,7 +1307,7 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
   ra.total = total;
   ra.T_next = nullptr;
   ra.qstat = m.qstat.as<float>();
-  ra.scal = m.scal8.as<float>();
+  ra.scal = a.scal;
   ra.bits = 8;
   ra.u = u8;
   ra.slack = rerank_slack;

@@ -47,7 +47,8 @@ namespace eps {
 
 struct Stream8Args {
   const signed char* x8;   // [n_pad8][d_pad8]
-  const int* acc0;         // [n_pad8]
+  const int* acc0;         // [n_pad8] the rows' start values as the pass adds them: the table's own, or (r6) those with the call's per-row margins folded in
+  const int* acc0_raw = nullptr;   // r6, folded calls only: the start values WITHOUT margins (see stream8_offer_value); null: acc0 carries none
   int64_t n;               // rows to scan
   int d_pad8;
   const signed char* q8;   // [>= nq][d_pad8] row-major
@@ -186,6 +187,14 @@ __device__ __forceinline__ void stream8_prep_query(const float* src, int dim, in
   }
 }
 
+// r6: one-pass calls on tables whose margins are folded per batch (rows with a clamped value carry their own residual: large rotated tables,
+// tables with outliers).  The pass then adds acc0 = raw + m (m = the row's margin for this call's queries, fold8_kernel) and tests
+// `dot + raw + m >= T` against MARGIN-FREE thresholds - the staged chain's folded test.  What a slot must hold is a number whose upper bound
+// ub(.) = C[q] - u (.) holds for the ROW it came from: exact <= C - u (dot + raw) + u m = C - u (dot + raw - m), i.e. the accumulator minus
+// TWICE the row's margin.  Offers are rare (a lane that beat the k-th slot): the two start values are read again here, not kept per chunk.
+__device__ __forceinline__ int stream8_offer_value(const Stream8Args& a, int acc, int64_t row) {
+  return a.acc0_raw ? acc - 2 * (a.acc0[row] - a.acc0_raw[row]) : acc;
+}
 __device__ __forceinline__ void stream8_offer(const Stream8Args& a, int q, int acc, u32 row) {   // (one lane; rare)
   // only rows the result may contain bound it.  The deleted bitset and the `int column <op> constant` filter are tested here (straight
   // code); calls with a filter PROGRAM take the staged chain (its evaluator in this kernel means a function call, i.e. scratch memory
@@ -330,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void stream8_kernel(Stream8Args a) {
           mine[q] += (u32)__popcll(mask);
         }
         // the table (a row offered twice lands in the same slot: still distinct rows)
-        if (live && v > gkth[q] && v < S8_FORCE_LIMIT) stream8_offer(a, q, v, (u32)row);
+        if (live && v > gkth[q] && v < S8_FORCE_LIMIT) stream8_offer(a, q, stream8_offer_value(a, v, row), (u32)row);
       }
     }
   };
@@ -367,7 +376,7 @@ __global__ __launch_bounds__(256, 2) void stream8_kernel(Stream8Args a) {
         br = better ? orow : br;
         bv = better ? ov : bv;
       }
-      if (lane == 0 && bv != S8_EMPTY) stream8_offer(a, q, bv, (u32)(first + br));
+      if (lane == 0 && bv != S8_EMPTY) stream8_offer(a, q, stream8_offer_value(a, bv, first + br), (u32)(first + br));
     }
   }
   if (!(S8_ABLATE & 5)) {
@@ -504,7 +513,7 @@ __global__ __launch_bounds__(256, 2) void stream8m_kernel(Stream8Args a) {
           *reinterpret_cast<volatile u32*>(&mine_s[wave][q]) = slot + 1;
         }
       }
-      if (live && v > gk && v < S8_FORCE_LIMIT) stream8_offer(a, col, v, (u32)row);
+      if (live && v > gk && v < S8_FORCE_LIMIT) stream8_offer(a, col, stream8_offer_value(a, v, row), (u32)row);
     }
   };
 
@@ -531,7 +540,7 @@ __global__ __launch_bounds__(256, 2) void stream8m_kernel(Stream8Args a) {
       br = better ? orow : br;
       bv = better ? ov : bv;
     }
-    if (kg == 0 && col < a.nq && bv != S8_EMPTY) stream8_offer(a, col, bv, (u32)(first + br));
+    if (kg == 0 && col < a.nq && bv != S8_EMPTY) stream8_offer(a, col, stream8_offer_value(a, bv, first + br), (u32)(first + br));
   }
   __syncthreads();
   // (as in stream8_kernel: a workgroup that gets here before k slots of a query have been filled by anyone waits for them - bounded)
