@@ -4,7 +4,7 @@
 set -x
 export EPS_TUNING_FROM_ENV=1
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r5m
+O=$R/gpurun_out/r6m
 mkdir -p $O
 cd $R
 (EPS_DEBUG=1 timeout 1500 python scripts/bench_graph.py --rows 10000000 --dim 768 --data manifold --L 50,100,200,500 --T 1,4 --reps 2 --save-graph /tmp/gm10m.bin > $O/graph_10M_manifold.jsonl 2> $O/graph_10M_manifold.err)

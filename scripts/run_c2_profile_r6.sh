@@ -4,7 +4,7 @@ set -x
 export EPS_TUNING_FROM_ENV=1
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r5c2
+O=$R/gpurun_out/r6c2
 mkdir -p $O
 (timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_stats -o stats -- python $R/scripts/prof_single_query.py 1000000 768 > $O/prof_stats.log 2>&1)
 (timeout 600 rocprofv3 --pmc FETCH_SIZE -d $O/prof_fetch -o fetch -- python $R/scripts/prof_single_query.py 1000000 768 > $O/prof_fetch.log 2>&1)

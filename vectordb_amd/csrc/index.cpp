@@ -96,10 +96,10 @@ size_t scratch_reclaim() {
   size_t freed = 0;
   for (ScratchClaim* c : g_scratch) {
     if (!c->buf || !c->buf->p) continue;
-    if (c->busy.exchange(true)) continue;   // its owner is between "the table is there" and the launch that uses it (possibly this very thread)
+    if (!c->try_enter()) continue;   // its owner is between "the table is there" and the launch that uses it (possibly this very thread)
     freed += c->buf->cap;
     c->buf->release();
-    c->busy.store(false);
+    c->leave();
   }
   return freed;
 }

@@ -4,6 +4,8 @@
 // vector table, graph and scratch mirrored in HBM.
 #pragma once
 #include <atomic>
+#include <thread>
+#include <mutex>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -33,11 +35,32 @@ struct DevBuf {  // growable device allocation
 // the allocation is tried again; the owner finds its buffer gone at its next search and takes the form that needs no such table.
 struct ScratchClaim {
   DevBuf* buf = nullptr;
-  std::atomic<bool> busy{false};
   ScratchClaim();
   ~ScratchClaim();
   ScratchClaim(const ScratchClaim&) = delete;
   ScratchClaim& operator=(const ScratchClaim&) = delete;
+  // The owner's window (from "is the table there?" to its last launch on it) and the reclaimer's release exclude each other.  enter(): the owner -
+  // WAITS for a release in progress on another thread; false = this thread is already inside (a nested call: nothing to take, nothing to give back).
+  // try_enter(): the reclaimer - never waits, never takes what its own thread is using.
+  bool enter() {
+    if (holder_.load() == std::this_thread::get_id()) return false;
+    mu_.lock();
+    holder_.store(std::this_thread::get_id());
+    return true;
+  }
+  bool try_enter() {
+    if (holder_.load() == std::this_thread::get_id() || !mu_.try_lock()) return false;
+    holder_.store(std::this_thread::get_id());
+    return true;
+  }
+  void leave() {
+    holder_.store(std::thread::id());
+    mu_.unlock();
+  }
+
+ private:
+  std::mutex mu_;
+  std::atomic<std::thread::id> holder_{};
 };
 size_t scratch_reclaim();   // bytes released
 

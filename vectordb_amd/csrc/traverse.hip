@@ -67,10 +67,10 @@ int32_t graph_upload(Index& ix) {
   g.pf_strikes = 0;
   g.pf_off = false;
   g.acc0_epoch = -1;
-  if (!g.gens_claim.busy.exchange(true)) {   // a new graph: the stamp table of the old one is given back (it is sized by the node count; the next search decides anew)
+  if (g.gens_claim.try_enter()) {   // a new graph: the stamp table of the old one is given back (it is sized by the node count; the next search decides anew)
     g.gens.release();
     g.gens_slots = g.gens_n = 0;
-    g.gens_claim.busy.store(false);
+    g.gens_claim.leave();
   }
   const int64_t n = ix.n_indexed_;
   if (n <= 0) return EPS_OK;
@@ -367,11 +367,11 @@ int32_t graph_search_impl(Index& ix, const float* dq, int64_t nq, int k, const e
   // and at most 64 GB - else the bitmap with its undo log.  EPS_TRV_VISITED=bitmap|stamps overrides (A/B, tests).
   bool stamps = false;
   struct ClaimHold {   // from here to the return of this call the table is not reclaimable (the launches below use it)
-    std::atomic<bool>& b;
+    ScratchClaim& c;
     bool mine;
-    explicit ClaimHold(std::atomic<bool>& f) : b(f), mine(!f.exchange(true)) {}
-    ~ClaimHold() { if (mine) b.store(false); }
-  } hold(g.gens_claim.busy);
+    explicit ClaimHold(ScratchClaim& cl) : c(cl), mine(cl.enter()) {}
+    ~ClaimHold() { if (mine) c.leave(); }
+  } hold(g.gens_claim);
   {
     const size_t need = (size_t)slots * (size_t)n * 4;
     size_t free_b = 0, total_b = 0;
