@@ -349,6 +349,19 @@ int32_t eps_exchange_allgather_merge(eps_exchange* x, const int64_t* ids, const 
 int32_t eps_exchange_times(eps_exchange* x, double* us_pairs, int32_t max_calls);
 /* what the handle runs on: rank, world, RCCL's version number and the path of the library that answers */
 int32_t eps_exchange_info(eps_exchange* x, int32_t* rank, int32_t* world, int32_t* rccl_version, char* rccl_path, int64_t cap);
+/* The b = 1 form of the same step ("for b=1 prefer direct P2P stores into a peer-mapped buffer + flag"; r6): for a handful of queries -
+ * nq * k * 12 <= 16 KB per rank - a collective costs more than the bytes it moves.  Every rank owns a MAILBOX in device memory that every peer maps
+ * (hipIpc); a call stores this rank's packed lists into every peer's mailbox, raises a flag there (release at system scope), waits on the device until
+ * all `world` flags of the OWN mailbox show the call's number, and merges - three small launches on the caller's stream, no collective, no host round
+ * trip.  Setup: eps_exchange_create_direct (no communicator; or an exchange made by eps_exchange_create), eps_exchange_mailbox_export on every rank
+ * (64 bytes), the host gathers the `world` handles by whatever it has, eps_exchange_mailbox_connect(x, handles[world][64]).  Ranks may share a device.
+ * A peer that does not deliver within ~10 s is reported by a later call (EPS_INFRA_UNEXPECTED_ERROR) instead of hanging the stream. */
+#define EPS_EXCHANGE_HANDLE_BYTES 64
+int32_t eps_exchange_create_direct(int32_t rank, int32_t world, int32_t device, eps_exchange** out);
+int32_t eps_exchange_mailbox_export(eps_exchange* x, void* handle64);
+int32_t eps_exchange_mailbox_connect(eps_exchange* x, const void* handles);
+int32_t eps_exchange_direct_merge(eps_exchange* x, const int64_t* ids, const float* dist, int64_t nq, int32_t k, int64_t* out_ids, float* out_dist,
+                                  void* hip_stream);
 const char* eps_exchange_last_error(eps_exchange* x);
 void eps_exchange_destroy(eps_exchange* x);
 

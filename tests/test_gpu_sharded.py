@@ -255,3 +255,30 @@ def test_library_owned_exchange_on_rccl_world_of_one(amd):
     t = x.times_us(8)
     assert len(t) == 8 and all(a >= 0 and b >= 0 for a, b in t)
     x.close()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_mailbox_exchange_between_processes(amd, world):
+    """"for b=1 prefer direct P2P stores into a peer-mapped buffer + flag" - between PROCESSES (r6; the one-process shard group had it
+    since r4).  `world` processes on this box's one GPU: every rank exports its mailbox (hipIpc), maps its peers', and every call stores its packed
+    lists into every peer's mailbox, raises a flag, waits on the device for all flags of its own mailbox and merges (eps_exchange_direct_merge) - no
+    collective, no host round trip.  60 calls of 1..100 queries, k 10..100, some left in flight so that consecutive calls overlap across ranks (the
+    two slot parities); every rank checks every merged answer against numpy.  (tests/workers/mailbox_rank.py)"""
+    import subprocess
+    import sys
+    port = 29610 + world
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "workers", "mailbox_rank.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), "60"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
+             for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o)
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and ("rank %d ok" % r) in o, (r, p.returncode, o[-1500:])

@@ -30,6 +30,7 @@ EXPORTS = [
     "eps_index_get_graph", "eps_index_save_graph", "eps_index_load_graph", "eps_index_search",
     "eps_index_last_stats", "eps_index_kernel_times", "eps_normalize_rows", "eps_merge_topk", "eps_merge_topk_packed", "eps_set_tuning",
     "eps_exchange_unique_id", "eps_exchange_create", "eps_exchange_allgather_merge", "eps_exchange_times", "eps_exchange_info", "eps_exchange_last_error",
+    "eps_exchange_create_direct", "eps_exchange_mailbox_export", "eps_exchange_mailbox_connect", "eps_exchange_direct_merge",
     "eps_exchange_destroy",
 ]
 
@@ -197,6 +198,10 @@ def load():
     L.eps_exchange_unique_id.argtypes = [vp]
     L.eps_exchange_create.argtypes = [i32, i32, vp, i32, C.POINTER(vp)]
     L.eps_exchange_allgather_merge.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp]
+    L.eps_exchange_create_direct.argtypes = [i32, i32, i32, C.POINTER(vp)]
+    L.eps_exchange_mailbox_export.argtypes = [vp, vp]
+    L.eps_exchange_mailbox_connect.argtypes = [vp, vp]
+    L.eps_exchange_direct_merge.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp]
     L.eps_exchange_times.argtypes = [vp, C.POINTER(C.c_double), i32]
     L.eps_exchange_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.c_char_p, i64]
     L.eps_exchange_last_error.argtypes = [vp]

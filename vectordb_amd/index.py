@@ -380,6 +380,47 @@ class Exchange:
                 self.h = None
             raise EpsillaError(rc, msg)
 
+    @classmethod
+    def direct(cls, rank, world, device=0):
+        """an exchange WITHOUT a communicator: the b = 1 form only (mailbox_export / mailbox_connect / direct_merge); ranks may share a device"""
+        self = cls.__new__(cls)
+        self.L = lib.load()
+        self.h = C.c_void_p()
+        self.device = device
+        self.world = world
+        rc = self.L.eps_exchange_create_direct(rank, world, device, C.byref(self.h))
+        if rc != 0:
+            msg = self.L.eps_exchange_last_error(self.h).decode() if self.h else "eps_exchange_create_direct failed"
+            if self.h:
+                self.L.eps_exchange_destroy(self.h)
+                self.h = None
+            raise EpsillaError(rc, msg)
+        return self
+
+    def mailbox_export(self):
+        """64 bytes: this rank's mailbox for its peers (hipIpc handle); gather all ranks' handles by your own means and pass them to mailbox_connect"""
+        buf = C.create_string_buffer(64)
+        rc = self.L.eps_exchange_mailbox_export(self.h, buf)
+        if rc != 0:
+            raise EpsillaError(rc, self.L.eps_exchange_last_error(self.h).decode())
+        return buf.raw
+
+    def mailbox_connect(self, handles):
+        """handles: every rank's 64 bytes, in rank order"""
+        blob = b"".join(bytes(h) for h in handles)
+        assert len(blob) == 64 * len(handles)
+        rc = self.L.eps_exchange_mailbox_connect(self.h, C.c_char_p(blob))
+        if rc != 0:
+            raise EpsillaError(rc, self.L.eps_exchange_last_error(self.h).decode())
+
+    def direct_merge(self, ids, dist, out_ids, out_dist, stream=None):
+        """the exchange step without a collective (<= 16 KB of lists per rank): peer stores + flag, device-side wait, merge"""
+        nq, k = ids.shape
+        rc = self.L.eps_exchange_direct_merge(self.h, _ptr(ids), _ptr(dist), nq, k, _ptr(out_ids), _ptr(out_dist), C.c_void_p(stream) if stream else None)
+        if rc != 0:
+            raise EpsillaError(rc, self.L.eps_exchange_last_error(self.h).decode())
+        return out_ids, out_dist
+
     def allgather_merge(self, ids, dist, out_ids, out_dist, stream=None):
         """ids int64 [nq][k], dist float32 [nq][k] (this rank's lists, device tensors) -> out_ids / out_dist: the merged global top-k, on every rank"""
         nq, k = ids.shape
