@@ -328,6 +328,26 @@ def main():
                 xchg_note = xchg_note or "eps_exchange_create failed on another rank"
         else:
             xchg_note = "eps_exchange_unique_id %s" % (box[0],)
+    # ... and for a handful of queries (<= 16 KB of lists per rank: --batch up to 136 at k = 10) its b = 1 form: no collective at all - peer stores into
+    # hipIpc-mapped mailboxes + flags (eps_exchange_direct_merge).  Works between ranks that share a device too, so the one-GPU gloo runs use it.
+    mbox = None
+    b_step = args.batch * (world if args.scale == "queries" else 1)
+    if world > 1 and b_step * args.k * 12 <= 16384 and os.environ.get("EPS_BENCH_EXCHANGE", "eps") in ("eps", "mailbox"):
+        ok = 1
+        try:
+            mbox = amd.Exchange.direct(rank, world, device=local_rank)
+            handles = [None] * world
+            dist.all_gather_object(handles, mbox.mailbox_export())
+            mbox.mailbox_connect(handles)
+        except Exception as e:  # noqa: BLE001
+            ok, xchg_note = 0, "eps_exchange mailbox setup failed on rank %d: %r" % (rank, e)
+        okt = torch.tensor([ok], dtype=torch.int32, device=torch.device("cuda", local_rank) if backend == "nccl" else "cpu")
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        if int(okt.item()) == 0:   # (all ranks or none)
+            if mbox is not None and ok:
+                mbox.close()
+            mbox = None
+            xchg_note = xchg_note or "eps_exchange mailbox setup failed on another rank"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     n, d, b, k = args.rows, args.dim, args.batch, args.k
@@ -389,7 +409,11 @@ def main():
             if timed:
                 ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
                 ev[0].record()
-            if xchg is not None:   # one library call: ncclAllGather of the packed lists + the merge (its own hipEvents split the two)
+            if mbox is not None:   # b = 1 form: peer stores + flag, device-side wait, merge - no collective
+                mbox.direct_merge(idss[slot], dds[slot], m_is[slot], m_ds[slot], stream=stream)
+                if timed:
+                    ev[1].record()
+            elif xchg is not None:   # one library call: ncclAllGather of the packed lists + the merge (its own hipEvents split the two)
                 xchg.allgather_merge(idss[slot], dds[slot], m_is[slot], m_ds[slot], stream=stream)
                 if timed:
                     ev[1].record()
@@ -428,7 +452,9 @@ def main():
     main_ms = ix.kernel_times(64)[-args.steps:]
     st = ix.stats()
     xchg_us = [(e[0].elapsed_time(e[1]) * 1e3, e[1].elapsed_time(e[2]) * 1e3) for e in xev]
-    if xchg is not None:   # (the library's own event triples of the timed steps: all-gather | merge)
+    if mbox is not None:   # (the library's own event triples of the timed steps: push + wait | merge)
+        xchg_us = mbox.times_us(64)[-args.steps:]
+    elif xchg is not None:   # (all-gather | merge)
         xchg_us = xchg.times_us(64)[-args.steps:]
 
     # ---- the same steps END TO END ("QPS end-to-end including H2D of queries and D2H of results"; the reference's entry takes a
@@ -665,7 +691,7 @@ def main():
         }
         if world > 1:
             # one all-gather of pack_n bytes per rank and step (12 B x k x batch), then a k-way merge on every rank
-            res["exchange"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "collective": ("eps_exchange (rccl)" if xchg is not None else ("all_gather_into_tensor" if backend == "nccl" else "all_gather (host staged)")),
+            res["exchange"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "collective": ("eps_exchange mailbox (peer stores + flag, no collective)" if mbox is not None else "eps_exchange (rccl)" if xchg is not None else ("all_gather_into_tensor" if backend == "nccl" else "all_gather (host staged)")),
                                "library": xchg.info() if xchg is not None else None, "fallback_reason": xchg_note,
                                "bytes_per_rank_per_step": int(pack_n), "bytes_gathered_per_rank_per_step": int(pack_n * world),
                                "all_gather_us_per_step": [round(x[0], 1) for x in xchg_us], "merge_us_per_step": [round(x[1], 1) for x in xchg_us],

@@ -63,6 +63,8 @@ def test_bench_two_ranks_on_one_gpu_merge_equals_unsharded_scan():
     assert "rows_total=300000" in d["config"]["workload"]
     assert d["recall_at_10"] == 1.0 and d["recall_check"]["ground_truth_vs_torch_fp32_scan"] == 1.0
     _check_exchange(d, 2, 96, 10)
+    # r6: 96 queries x 10 x 12 B fit a mailbox slot - the exchange step ran without a collective (peer stores + flag between the two processes)
+    assert "mailbox" in d["exchange"]["collective"], d["exchange"]["collective"]
 
 
 @pytest.mark.gpu
@@ -73,14 +75,15 @@ def test_bench_eight_ranks_on_one_gpu():
     env = dict(os.environ, EPS_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
                         "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
-                        "--rows", "80000", "--batch", "64", "--cpu-seconds", "0"], capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
+                        "--rows", "80000", "--batch", "160", "--cpu-seconds", "0"], capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 8 and d["scaling"] == "weak" and "rows_total=640000" in d["config"]["workload"]
     assert d["recall_at_10"] == 1.0 and d["recall_check"]["ground_truth_vs_torch_fp32_scan"] == 1.0
-    _check_exchange(d, 8, 64, 10)
+    _check_exchange(d, 8, 160, 10)
+    assert d["exchange"]["collective"] == "all_gather (host staged)"      # (160 queries: beyond a mailbox slot, and gloo ranks on one device cannot form an RCCL communicator)
 
 
 def _check_exchange(d, world, batch, k):
