@@ -110,7 +110,7 @@ def test_one_to_sixteen_queries_are_one_pass_over_the_mirror(amd, oracle, monkey
     repeated calls (the table is reset per call) - and `one_pass` in the stats says which form ran.  k > 64, more queries,
     EPS_FLAT_ONE_PASS=0, EPS_S8_MAX_K or (programs) EPS_S8_FILTER_PROGRAMS=0 take the staged chain."""
     n = 200_003 if d < 700 else 90_000     # (a last chunk that is not full)
-    X, Q = data(n, d, 171 + d), data(16, d, 172 + d)
+    X, Q = data(n, d, 171 + d), data(32, d, 172 + d)   # (r6: up to 32 queries per call - two 16-query column blocks on the matrix cores)
     X[5000:5040] = X[4999]
     if metric == 1:
         X = amd.normalize_rows(X, only_if_nonzero=True)
@@ -149,7 +149,7 @@ def test_one_to_sixteen_queries_are_one_pass_over_the_mirror(amd, oracle, monkey
             assert ix.stats()["one_pass"] == 0
             monkeypatch.delenv("EPS_S8_FILTER_PROGRAMS")
             same(chain, got, "filter program: chain vs one pass")
-        for nq in (1, 2, 3, 4, 5, 8, 13, 16, 1):     # (.. and back to one: whatever state a call leaves behind serves the next)
+        for nq in (1, 2, 3, 4, 5, 8, 13, 16, 17, 24, 32, 1):     # (.. and back to one: whatever state a call leaves behind serves the next)
             for k in (1, 10, 16, 17, 40, 64, 10):    # (r5: k = 17..64 on 128 table slots per query - a table layout of its own - and back)
                 for rep in range(2):
                     a = ix.search(Q[:nq], k, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)

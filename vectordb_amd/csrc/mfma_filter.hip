@@ -111,11 +111,11 @@ struct HalfMirror {
                                 // one bitset (bit set = row invisible), which the pass and its re-rank then read as a deleted bitset
   // rows version on which the one-pass form overflowed twice in a row (the staged chain serves it); [0]: k <= 16, [1]: k = 17..64 - a larger k
   // passes more rows against the same lists, and must not talk the table out of the form for the small-k traffic
-  int64_t s8_declined_version[4] = {-1, -1, -1, -1};
-  int s8_overflows[4] = {0, 0, 0, 0};
+  int64_t s8_declined_version[6] = {-1, -1, -1, -1, -1, -1};
+  int s8_overflows[6] = {0, 0, 0, 0, 0, 0};
   // under a deleted bitset / an int-column filter an overflow usually means "fewer than k rows visible": the rows' version says nothing
   // about it, so two such overflows in a row make the next 32 filtered calls go straight to the staged chain, then the one-pass form is tried again
-  int s8_filt_overflows[4] = {0, 0, 0, 0}, s8_filt_skip[4] = {0, 0, 0, 0};   // (per class, as above)
+  int s8_filt_overflows[6] = {0, 0, 0, 0, 0, 0}, s8_filt_skip[6] = {0, 0, 0, 0, 0, 0};   // (per class, as above)
   int s8_cus = 0;               // CUs of the device (grid of the one-pass kernel)
   // r5: the call's two result counters land in host-mapped memory (written by the last block of the re-rank launch), read after the stream
   // sync: no device-to-host copy at the end of a 0.2 ms call
@@ -1155,9 +1155,13 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
   // launch (the margins depend on the call's queries), with margin-free thresholds and offers of `accumulator - 2 x the row's margin` (stream8_offer_value)
   const bool fold = m.fold8 && tune_int("EPS_S8_FOLD", 1) != 0;   // (A/B switch: 0 = such tables on the staged chain, as until r6)
   if (m.fold8 && !fold) return EPS_OK;
+  // (17..32 queries, r6: the two-column-block pass beats the staged chain where a query leaves a few hundred candidates - 1M x 768 U[0,1): 17 / 24 / 32
+  // queries 0.235 / 0.254 / 0.281 ms against 0.38 - and loses where it leaves several times that: the same table of embedding-like rows 0.433 /
+  // 0.465 / 0.505 against 0.432 / 0.443 / 0.443 (profiles/r6_one_pass_17_to_32_queries.txt).  Tables with folded margins are the looser ones.)
+  if (nq > 16 && m.fold8 && tune_int("EPS_S8_MAX_Q", 0) == 0) return EPS_OK;
   // (r6: ... and per kernel form - five or more queries share one list budget per query and overflow on tables where one query does not:
   // an 8-query batch must not talk the table out of the form for single-query traffic)
-  const int kclass = (k <= 16 ? 0 : 1) + (nq <= 4 ? 0 : 2);
+  const int kclass = (k <= 16 ? 0 : 1) + (nq <= 4 ? 0 : (nq <= 16 ? 2 : 4));   // (r6: 17..32 queries - two column blocks - are a form of their own)
   if (m.s8_declined_version[kclass] == ix.rows_version_) return EPS_OK;
   FilterSpec fs = ix.filter_spec();
   // a compiled filter program: evaluated once per row into a bitset (filter_mask_kernel) that pass and re-rank read as a deleted bitset.  Only
@@ -1173,7 +1177,7 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
   }
   hipStream_t s = ix.stream_;
   const int cap = std::max(4096, 64 * k);
-  if (!m.qstat.reserve((size_t)S8_MAX_Q * 16) || !m.q8.reserve((size_t)S8_MAX_Q * m.d_pad8) || !m.cand.reserve((size_t)nq * cap * 8) || !m.cnt.reserve((size_t)(nq + 4) * 4 + 16) ||
+  if (!m.qstat.reserve((size_t)S8_MAX_Q * 16) || !m.q8.reserve((size_t)S8_MAX_Q * m.d_pad8) || !m.cand.reserve((size_t)nq * cap * 8) || !m.cnt.reserve((size_t)(S8_MAX_Q + 16) * 4) ||
       !m.s8g.reserve((size_t)S8_TABLE_WORDS * 4 + (size_t)S8_MAX_Q * S8_MAX_WAVES * 4) || !m.s8raw.reserve((size_t)nq * S8_MAX_WAVES * S8_WAVE_CAP * 8) ||
       (masked && !m.s8mask.reserve((size_t)(n + 7) / 8 + 16)))
     return ix.fail(EPS_INFRA_UNEXPECTED_ERROR, "MFMA engine: out of device memory (scratch)");
@@ -1210,7 +1214,8 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
       px.qmax = m.qmax.as<u32>();
       if (hipMemsetAsync(m.qmax.p, 0, 8, s) != hipSuccess) return ix.hip_fail(hipGetLastError(), "memset");
     }
-    launch_query_prep8(dim3(mfma_form ? 4 : 1), s, m.rot8 ? m.sp8.as<int>() : nullptr, m.rot_w8, dq, nq, (int64_t)(mfma_form ? 16 : 4), (int)ix.dim_, m.d_pad8, m.mu8.as<float>(),
+    const int prep_rows = mfma_form ? (nq > 16 ? 32 : 16) : 4;   // (the matrix form reads 16 / 32 query rows: zeros beyond nq)
+    launch_query_prep8(dim3((unsigned)(prep_rows / 4)), s, m.rot8 ? m.sp8.as<int>() : nullptr, m.rot_w8, dq, nq, (int64_t)prep_rows, (int)ix.dim_, m.d_pad8, m.mu8.as<float>(),
                        m.step8, ix.metric_, m.q8.as<signed char>(), m.qstat.as<float>(), px);
     if (fold)   // (16 bytes per row: 5 us at 1M rows, 40 us at 10M - where the pass itself takes 1.4 ms)
       hipLaunchKernelGGL(fold8_kernel, dim3((unsigned)std::min<int64_t>((m.n_pad8 + 255) / 256, 8192)), dim3(256), 0, s, m.acc0.as<int>(), m.erow.as<float>(),
@@ -1280,10 +1285,14 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
     else if (pieces == 3) EPS_S8_WIDE(3);
     else EPS_S8_WIDE(4);
 #undef EPS_S8_WIDE
+  } else if (mfma_form && nq > 16) {   // r6, 17..32 queries: two 16-query column blocks per row block
+    if (pieces == 2) hipLaunchKernelGGL((stream8m_kernel<2, 2>), grid, block, 0, s, a);
+    else if (pieces == 3) hipLaunchKernelGGL((stream8m_kernel<3, 2>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((stream8m_kernel<4, 2>), grid, block, 0, s, a);
   } else if (mfma_form) {   // 5..16 queries (and 3-4 with k > 16): the same pass on the matrix cores
-    if (pieces == 2) hipLaunchKernelGGL((stream8m_kernel<2>), grid, block, 0, s, a);
-    else if (pieces == 3) hipLaunchKernelGGL((stream8m_kernel<3>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((stream8m_kernel<4>), grid, block, 0, s, a);
+    if (pieces == 2) hipLaunchKernelGGL((stream8m_kernel<2, 1>), grid, block, 0, s, a);
+    else if (pieces == 3) hipLaunchKernelGGL((stream8m_kernel<3, 1>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((stream8m_kernel<4, 1>), grid, block, 0, s, a);
   } else if (pieces == 2) EPS_S8_LAUNCH(2);
   else if (pieces == 3) EPS_S8_LAUNCH(3);
   else EPS_S8_LAUNCH(4);

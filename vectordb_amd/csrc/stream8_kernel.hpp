@@ -78,7 +78,7 @@ constexpr int S8_FORCE_LIMIT = 0x30000000;   // (= TQ_MAX8: accumulators at or a
 constexpr int S8_EMPTY = -2147483647 - 1;
 constexpr int S8_SLOTS = 64, S8_SLOTS_WIDE = 128, S8_SLOT_STRIDE = 64;   // (stride in 4-byte words)
 constexpr int S8_MAX_K = 64;   // k of a one-pass call: <= 16 with 64 slots per query, 17..64 with 128 (r5)
-constexpr int S8_MAX_Q = 16;   // queries of a one-pass call: <= 4 on v_dot4 (stream8_kernel), 5..16 on the matrix cores (stream8m_kernel, r5)
+constexpr int S8_MAX_Q = 32;   // queries of a one-pass call: <= 4 on v_dot4 (stream8_kernel), 5..16 on the matrix cores (stream8m_kernel, r5), 17..32 on two column blocks (r6)
 constexpr int S8_TABLE_WORDS = S8_MAX_Q * S8_SLOTS_WIDE * S8_SLOT_STRIDE;
 constexpr int S8_WAVE_CAP = 32, S8_MAX_WAVES = 8192;   // (32: a run of identical rows - 16 of them in one chunk - must not fill a list by itself)
 
@@ -448,9 +448,14 @@ __global__ __launch_bounds__(256, 2) void stream8_kernel(Stream8Args a) {
 //   results   lane l holds rows base + 4 g + {0, 1, 2, 3} of column c, started from acc0[row]: one compare per value against the column's
 //             threshold (T_s[c]), the common block ends at one ballot.
 // Table, thresholds, private candidate lists and the selection + re-rank behind the pass are stream8_kernel's (above), per query.
-template <int PIECES>
+// NB (r6): 16-query column blocks per call - 1: 5..16 queries; 2: 17..32 queries, the row operand of a block feeds both column blocks (24 MFMAs per
+// 16 rows at d = 768: ~25 us of matrix pipe per 1M rows, the pass stays HBM-bound; the queries' operands 96 registers, two row blocks in flight 96).
+// (NB = 2 with both column blocks' operands in registers spills a few dwords at 256 - and ANY scratch costs every wavefront of the launch its
+// set-up; with ONE workgroup per CU - 512 registers - the pass ran at half its rate, 17 queries 0.300 ms against 0.217 for 16.  So the second column
+// block's operands live in LDS, [K-step][lane] x 16 bytes: conflict-free ds_read_b128, 12 per row block and wavefront, issued ahead of the MFMAs that use them)
+template <int PIECES, int NB = 1>
 __global__ __launch_bounds__(256, 2) void stream8m_kernel(Stream8Args a) {
-  constexpr int KS = PIECES * 4;   // MFMAs per 16-row block
+  constexpr int KS = PIECES * 4;   // MFMAs per 16-row block and column block
   __shared__ int T_s[S8_MAX_Q], gkth_s[S8_MAX_Q];
   __shared__ u32 mine_s[4][S8_MAX_Q];   // entries of each wavefront's private list, per query
   const int lane = lane_id();
@@ -460,9 +465,21 @@ __global__ __launch_bounds__(256, 2) void stream8m_kernel(Stream8Args a) {
   const int64_t W = (int64_t)gridDim.x * 4;
   if (lane < S8_MAX_Q) mine_s[wave][lane] = 0;
 
-  i32x4 qv[KS];
+  constexpr bool Q0_LDS = NB == 2 && PIECES == 4;   // (1024-byte rows: 16 + 16 + 16 operand registers per K-step leave no room for either column block's queries)
+  i32x4 qv[Q0_LDS ? 1 : KS];
+  __shared__ i32x4 q2_s[NB == 2 ? KS : 1][NB == 2 ? 64 : 1];   // (NB = 2: the second column block's operands, the same in every wavefront)
+  __shared__ i32x4 q1_s[Q0_LDS ? KS : 1][Q0_LDS ? 64 : 1];
+  if (!Q0_LDS) {
 #pragma unroll
-  for (int j = 0; j < KS; ++j) qv[j] = *reinterpret_cast<const i32x4*>(a.q8 + (int64_t)col * a.d_pad8 + j * 64 + kg * 16);
+    for (int j = 0; j < KS; ++j) qv[j] = *reinterpret_cast<const i32x4*>(a.q8 + (int64_t)col * a.d_pad8 + j * 64 + kg * 16);
+  }
+  if (NB == 2) {
+    for (int j = wave; j < KS; j += 4) {
+      q2_s[j][lane] = *reinterpret_cast<const i32x4*>(a.q8 + (int64_t)(col + 16) * a.d_pad8 + j * 64 + kg * 16);
+      if (Q0_LDS) q1_s[j][lane] = *reinterpret_cast<const i32x4*>(a.q8 + (int64_t)col * a.d_pad8 + j * 64 + kg * 16);
+    }
+    __syncthreads();
+  }
 
   auto load_block = [&](int64_t base, i32x4 (&xv)[KS], i32x4& c0) __attribute__((always_inline)) {
     int64_t r = base + col;
@@ -472,11 +489,15 @@ __global__ __launch_bounds__(256, 2) void stream8m_kernel(Stream8Args a) {
     for (int j = 0; j < KS; ++j) xv[j] = *reinterpret_cast<const i32x4*>(p0 + j * 64);
     c0 = *reinterpret_cast<const i32x4*>(a.acc0 + base + 4 * kg);   // (acc0 has n_pad8 >= n rounded up to 256 entries; base is a multiple of 16)
   };
-  auto dots = [&](const i32x4 (&xv)[KS], const i32x4& c0) __attribute__((always_inline)) {
-    i32x4 acc = c0;
+  auto dots = [&](const i32x4 (&xv)[KS], const i32x4& c0, i32x4 (&acc)[NB]) __attribute__((always_inline)) {
+    acc[0] = c0;
 #pragma unroll
-    for (int j = 0; j < KS; ++j) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(xv[j], qv[j], acc, 0, 0, 0);
-    return acc;
+    for (int j = 0; j < KS; ++j) acc[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(xv[j], Q0_LDS ? q1_s[j][lane] : qv[Q0_LDS ? 0 : j], acc[0], 0, 0, 0);
+    if (NB == 2) {
+      acc[NB - 1] = c0;
+#pragma unroll
+      for (int j = 0; j < KS; ++j) acc[NB - 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(xv[j], q2_s[j][lane], acc[NB - 1], 0, 0, 0);
+    }
   };
   // the table -> thresholds: wavefront w serves the queries q = w, w + 4, ... (a refresh of 16 queries by one wavefront would cost it ~2 k instructions)
   auto refresh = [&]() __attribute__((always_inline)) {
@@ -489,31 +510,36 @@ __global__ __launch_bounds__(256, 2) void stream8m_kernel(Stream8Args a) {
       }
     }
   };
-  auto test_block = [&](int64_t base, const i32x4& acc) __attribute__((always_inline)) {
-    const int T = col < a.nq ? *reinterpret_cast<volatile int*>(&T_s[col]) : 2147483647;
-    const int gk = col < a.nq ? *reinterpret_cast<volatile int*>(&gkth_s[col]) : 2147483647;
+  auto test_block = [&](int64_t base, const i32x4 (&accs)[NB]) __attribute__((always_inline)) {
     const int64_t row0 = base + 4 * kg;
-    bool any = false;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) any |= (acc[r] >= T || acc[r] > gk) && row0 + r < a.n;
-    if (!__ballot(any)) return;   // (the common block ends here)
+    for (int b = 0; b < NB; ++b) {
+      const int qc = col + 16 * b;
+      const i32x4 acc = accs[b];
+      const int T = qc < a.nq ? *reinterpret_cast<volatile int*>(&T_s[qc]) : 2147483647;
+      const int gk = qc < a.nq ? *reinterpret_cast<volatile int*>(&gkth_s[qc]) : 2147483647;
+      bool any = false;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int64_t row = row0 + r;
-      const int v = acc[r];
-      const bool live = row < a.n && col < a.nq;
-      unsigned long long m = __ballot(live && v >= T);
-      while (m) {   // (rare) one entry at a time: the lane it belongs to appends it to ITS query's list of this wavefront
-        const int i = __ffsll((long long)m) - 1;
-        m &= m - 1;
-        const int q = i & 15;
-        const u32 slot = *reinterpret_cast<volatile u32*>(&mine_s[wave][q]);
-        if (lane == i) {
-          if (slot < (u32)S8_WAVE_CAP) a.raw[((int64_t)q * a.waves + wid) * S8_WAVE_CAP + slot] = ((u64)(u32)v << 32) | (u32)row;
-          *reinterpret_cast<volatile u32*>(&mine_s[wave][q]) = slot + 1;
+      for (int r = 0; r < 4; ++r) any |= (acc[r] >= T || acc[r] > gk) && row0 + r < a.n;
+      if (!__ballot(any)) continue;   // (the common block ends here)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t row = row0 + r;
+        const int v = acc[r];
+        const bool live = row < a.n && qc < a.nq;
+        unsigned long long m = __ballot(live && v >= T);
+        while (m) {   // (rare) one entry at a time: the lane it belongs to appends it to ITS query's list of this wavefront
+          const int i = __ffsll((long long)m) - 1;
+          m &= m - 1;
+          const int q = (i & 15) + 16 * b;
+          const u32 slot = *reinterpret_cast<volatile u32*>(&mine_s[wave][q]);
+          if (lane == i) {
+            if (slot < (u32)S8_WAVE_CAP) a.raw[((int64_t)q * a.waves + wid) * S8_WAVE_CAP + slot] = ((u64)(u32)v << 32) | (u32)row;
+            *reinterpret_cast<volatile u32*>(&mine_s[wave][q]) = slot + 1;
+          }
         }
+        if (live && v > gk && v < S8_FORCE_LIMIT) stream8_offer(a, qc, stream8_offer_value(a, v, row), (u32)row);
       }
-      if (live && v > gk && v < S8_FORCE_LIMIT) stream8_offer(a, col, stream8_offer_value(a, v, row), (u32)row);
     }
   };
 
@@ -522,25 +548,31 @@ __global__ __launch_bounds__(256, 2) void stream8m_kernel(Stream8Args a) {
   i32x4 xa[KS], xb[KS], ca, cb;
   if (first < a.n) load_block(first, xa, ca);
   if (first + stride < a.n) load_block(first + stride, xb, cb);
-  i32x4 acc = {S8_EMPTY, S8_EMPTY, S8_EMPTY, S8_EMPTY};
+  i32x4 acc[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) acc[b] = i32x4{S8_EMPTY, S8_EMPTY, S8_EMPTY, S8_EMPTY};
   // ---- the first block feeds the empty table before anything is tested: per query the best of the wavefront's 16 rows is offered
   if (first < a.n) {
-    acc = dots(xa, ca);
-    int bv = S8_EMPTY, br = 0;
+    dots(xa, ca, acc);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const bool better = first + 4 * kg + r < a.n && acc[r] < S8_FORCE_LIMIT && acc[r] > bv;
-      br = better ? 4 * kg + r : br;
-      bv = better ? acc[r] : bv;
-    }
+    for (int b = 0; b < NB; ++b) {
+      int bv = S8_EMPTY, br = 0;
 #pragma unroll
-    for (int o = 16; o < 64; o <<= 1) {
-      const int ov = __shfl_xor(bv, o), orow = __shfl_xor(br, o);
-      const bool better = ov > bv;
-      br = better ? orow : br;
-      bv = better ? ov : bv;
+      for (int r = 0; r < 4; ++r) {
+        const bool better = first + 4 * kg + r < a.n && acc[b][r] < S8_FORCE_LIMIT && acc[b][r] > bv;
+        br = better ? 4 * kg + r : br;
+        bv = better ? acc[b][r] : bv;
+      }
+#pragma unroll
+      for (int o = 16; o < 64; o <<= 1) {
+        const int ov = __shfl_xor(bv, o), orow = __shfl_xor(br, o);
+        const bool better = ov > bv;
+        br = better ? orow : br;
+        bv = better ? ov : bv;
+      }
+      const int qc = col + 16 * b;
+      if (kg == 0 && qc < a.nq && bv != S8_EMPTY) stream8_offer(a, qc, stream8_offer_value(a, bv, first + br), (u32)(first + br));
     }
-    if (kg == 0 && col < a.nq && bv != S8_EMPTY) stream8_offer(a, col, stream8_offer_value(a, bv, first + br), (u32)(first + br));
   }
   __syncthreads();
   // (as in stream8_kernel: a workgroup that gets here before k slots of a query have been filled by anyone waits for them - bounded)
@@ -570,11 +602,11 @@ __global__ __launch_bounds__(256, 2) void stream8m_kernel(Stream8Args a) {
   for (int64_t base = first + stride; base < a.n; base += 2 * stride, it += 2) {
     if (base + stride < a.n) load_block(base + stride, xa, ca);
     if (it == 1 || it == 3 || (it & 7) == 7) refresh();   // (every wavefront its own queries; a stale threshold only loosens the test)
-    acc = dots(xb, cb);
+    dots(xb, cb, acc);
     test_block(base, acc);
     if (base + stride >= a.n) break;
     if (base + 2 * stride < a.n) load_block(base + 2 * stride, xb, cb);
-    acc = dots(xa, ca);
+    dots(xa, ca, acc);
     test_block(base + stride, acc);
   }
   if (lane < a.nq) a.raw_cnt[(int64_t)lane * a.waves + wid] = *reinterpret_cast<volatile u32*>(&mine_s[wave][lane]);
