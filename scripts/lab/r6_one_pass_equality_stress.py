@@ -1,5 +1,5 @@
 """r6: the one-pass search against the fp32 stream engine, call by call, on the three kinds of tables it now serves - homogeneous rows (table-wide margin),
-rows with outliers (margins folded per call; a forced row), embedding-like rows in the rotated frame (cut grid, folded margins) - for random query counts,
+rows with outliers (margins folded per call; a forced row), embedding-like rows in the rotated frame (cut grid, folded margins) - for random query counts (1..32),
 k, metrics, with and without a deleted bitset.  Prints the calls made, how many the one-pass form answered, and any call whose answer differs (none may)."""
 import os
 import sys
@@ -21,12 +21,12 @@ for kind in ("uniform", "outliers", "embedding"):
             X = rng.standard_normal((n, d), dtype=np.float32)
             X[:, :8] *= 4.0
             X /= np.linalg.norm(X, axis=1, keepdims=True)
-            Q = rng.standard_normal((16, d), dtype=np.float32)
+            Q = rng.standard_normal((32, d), dtype=np.float32)
             Q[:, :8] *= 4.0
             Q /= np.linalg.norm(Q, axis=1, keepdims=True)
         else:
             X = rng.random((n, d), dtype=np.float32)
-            Q = rng.random((16, d), dtype=np.float32)
+            Q = rng.random((32, d), dtype=np.float32)
             if kind == "outliers":
                 X[123, 5] = 90.0
                 X[n // 2, 7] = -35.0
@@ -40,10 +40,10 @@ for kind in ("uniform", "outliers", "embedding"):
         for r in range(5, n, 13):
             gone[r >> 3] |= 1 << (r & 7)
         for it in range(rounds):
-            nq = int(rng.choice([1, 1, 1, 2, 3, 4, 5, 8, 13, 16]))
+            nq = int(rng.choice([1, 1, 1, 2, 3, 4, 5, 8, 13, 16, 17, 24, 32]))
             k = int(rng.choice([1, 10, 10, 16, 17, 40, 64]))
             ix.set_deleted(gone if it % 3 == 2 else None)
-            qs = Q[rng.permutation(16)[:nq]]
+            qs = Q[rng.permutation(32)[:nq]]
             a = ix.search(qs, k, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
             st = ix.stats()
             b = ix.search(qs, k, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
