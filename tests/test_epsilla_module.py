@@ -191,3 +191,50 @@ def test_gfx950_module_insert_array_leaves_the_table_the_json_insert_leaves():
     assert out["upsert"] == [0, {"inserted": 2, "skipped": 0}]
     assert [r["Name"] for r in out["after_upsert"]] == ["upserted", "new"] or out["after_upsert"][0]["Name"] == "upserted"
     assert out["array_insert_s"] < 0.2 * out["json_insert_s"], (out["array_insert_s"], out["json_insert_s"])
+
+
+def test_gfx950_module_insert_array_argument_checks_on_cpu():
+    """CPU (ingest never touches the device): what insert_array accepts and refuses - every schema field needs a column of a matching shape, numeric columns
+    are C-contiguous buffers, STRING columns lists of str, all of one length; n = 0 is a no-op; float64 vectors and VECTOR_DOUBLE fields are stored as the
+    JSON path stores them (rounded to float32); a primary key repeated inside the call is skipped as `insert` skips it."""
+    if not _have(GPU_DIR):
+        pytest.skip("dropin/_build/epsilla.so not built (make -C dropin)")
+    code = r'''
+import sys, ctypes
+import numpy as np
+sys.path.insert(0, %r)
+import epsilla
+assert epsilla.load_db(db_name="db", db_path=sys.argv[1]) == 0
+epsilla.use_db(db_name="db")
+fields = [{"name": "ID", "dataType": "INT", "primaryKey": True}, {"name": "Name", "dataType": "STRING"}, {"name": "W", "dataType": "DOUBLE"},
+          {"name": "V", "dataType": "VECTOR_FLOAT", "dimensions": 4, "metricType": "COSINE"},
+          {"name": "D", "dataType": "VECTOR_DOUBLE", "dimensions": 3, "metricType": "EUCLIDEAN"}]
+ctypes.pythonapi.Py_IncRef(ctypes.py_object(fields))
+epsilla.create_table(table_name="T", table_fields=fields)
+n = 5
+good = {"ID": np.array([1, 2, 3, 2, 5], np.int64), "Name": ["a", "b", "c", "dup", "e"], "W": np.arange(n, dtype=np.float32),
+        "V": np.arange(4 * n, dtype=np.float64).reshape(n, 4) + 1.0, "D": np.ones((n, 3), np.float32)}
+def refused(cols, **kw):
+    try:
+        epsilla.insert_array(table_name="T", columns=cols, **kw)
+    except Exception as e:
+        return str(e)
+    return None
+bad = []
+bad.append(refused({k: v for k, v in good.items() if k != "W"}))                                  # a schema field without a column
+bad.append(refused({**good, "V": good["V"][:, :3]}))                                               # wrong width
+bad.append(refused({**good, "V": np.asfortranarray(good["V"])}))                                   # not C-contiguous
+bad.append(refused({**good, "Name": ["a", "b", "c"]}))                                             # lengths differ
+bad.append(refused({**good, "Name": np.arange(n)}))                                                # a STRING field wants a list of str
+bad.append(refused({**good, "ID": np.arange(n, dtype=np.float64)}))                                # an integer field wants an integer column
+bad.append(refused({**good, "ID": [1, 2, 3, 4, 5]}))                                               # numeric columns are buffers, not lists
+bad.append(refused("not a dict"))
+assert all(bad), bad
+assert epsilla.insert_array(table_name="T", columns={"ID": np.zeros(0, np.int64), "Name": [], "W": np.zeros(0), "V": np.zeros((0, 4), np.float32), "D": np.zeros((0, 3))}) == (0, {"inserted": 0, "skipped": 0})
+assert epsilla.insert_array(table_name="T", columns=good) == (0, {"inserted": 4, "skipped": 1})
+assert epsilla.insert_array(table_name="T", columns=good) == (0, {"inserted": 0, "skipped": 5})
+print("CHECKS OK", [b[:60] for b in bad])
+''' % GPU_DIR
+    db = os.path.join(tempfile.mkdtemp(), "db")
+    r = subprocess.run([sys.executable, "-c", code, db], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "CHECKS OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
