@@ -376,7 +376,9 @@ __global__ __launch_bounds__(512, 2) void mfma_filter_kernel_v3(FilterArgs a) {
 #undef EPS_DS_READ_B128
 #define EPS_DS_READ_B128(dst, addr, off) asm volatile("" : EPS_FRAG_RW(dst) : "v"(addr))   /* (read-write: the fragment keeps the random bytes it was given) */
 #endif
-#if defined(EPS_V7_ABL) && (EPS_V7_ABL & 64)
+//  128  no query-fragment loads only (the row operand's LDS-DMA ring stays): what a QUERY-STATIONARY tile could reach at best - a workgroup's 256
+//       queries never change, their fragments are the half of the global operand traffic that residency would remove
+#if defined(EPS_V7_ABL) && (EPS_V7_ABL & (64 | 128))
 #undef EPS_GLOAD_B128
 #define EPS_GLOAD_B128(dst, voff, sbase, off) asm volatile("" : EPS_FRAG_RW(dst) : "v"(voff), "s"(sbase))
 #endif
@@ -533,7 +535,7 @@ __global__ __launch_bounds__(256, NRB == 8 ? 1 : 2) void mfma_filter_kernel_v7(F
     for (int kk = 0; kk < 4; ++kk) faddr[kk] = lds_base + (u32)swz((int)(ln & 31), kk * 2 + (int)(ln >> 5)) * 16;
   };
   lane_values();
-#if defined(EPS_V7_ABL) && (EPS_V7_ABL & (32 | 64))
+#if defined(EPS_V7_ABL) && (EPS_V7_ABL & (32 | 64 | 128))
   {   // the ablated transports leave operands where they are: give fragments and ring bytes that toggle like data (a zero operand runs the pipe at 2.4 GHz)
     u32 h = (u32)tid * 2654435761u + (u32)blockIdx.x * 40503u + 12345u;
     auto nx = [&]() { h ^= h << 13; h ^= h >> 17; h ^= h << 5; return h; };
