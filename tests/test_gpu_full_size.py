@@ -119,7 +119,7 @@ def test_configs2_10M_x_768_L2_batch_1024_matches_the_reference_bruteforce(amd, 
     ix.close()
 
 
-def test_configs2_10M_x_768_graph_path_matches_the_reference_searchimpl(amd, ref, table, tmp_path):
+def test_configs2_10M_x_768_graph_path_matches_the_reference_searchimpl(amd, ref, oracle, table, tmp_path):
     """configs[2] on the path the north_star NAMES: the NSG of all 10M rows built on the device (~2 min), written in
     the reference's ann_graph file format, loaded by the reference's own ANNGraphSegment file constructor, walked by the reference's
     SearchImpl (vec_search_executor.cpp:518-715; IntraQueryThreads = 1 - the deterministic form - SearchQueueSize = 500) next to the
@@ -156,7 +156,18 @@ def test_configs2_10M_x_768_graph_path_matches_the_reference_searchimpl(amd, ref
     ids4, dd4, cnt4, st4 = _search(amd, t, ix, B, mode=amd.MODE_GRAPH, intra_threads=4, master_queue=L, local_queue=L)
     assert (cnt4 == K).all() and (ids4 >= 0).all() and (ids4 < N).all() and (np.diff(dd4, axis=1) >= 0).all()
     assert all(len(set(r.tolist())) == K for r in ids4)
+    # r6: IntraQueryThreads = 4 at SearchQueueSize 2000 - the worker queues laid out with their occupancy bound (ceil(L / T) + I x out-degree keys: LDS
+    # where the caller's capacity sent them to HBM), 8 wavefronts per query - against the oracle's lockstep schedule ON THIS GRAPH, which keeps the
+    # caller's LocalQueueSize: the same walk key for key (ids position-wise, distances to 1e-4) at the size the layout change is for
+    off, nbr, nav_ = ref.graph_arrays(gref)
     ref.L.ref_graph_free(gref)
+    L2 = 2000
+    init2 = oracle.prepare_init_ids(off, nbr, nav, L2)
+    ids2, dd2, cnt2, st2 = _search(amd, t, ix, 3, mode=amd.MODE_GRAPH, intra_threads=4, master_queue=L2, local_queue=L2)
+    for q in range(3):
+        oid, od, _ = oracle.search_impl(0, t["arr"], off, nbr, init2, Qh[q], T=4, L=L2, I=15, lockstep=True)
+        assert_topk_match(ids2[q], dd2[q], oid[:K], od[:K], what="configs[2] graph T=4 L=2000 q%d" % q)
+    del off, nbr
     ix.close()
     try:
         os.remove(str(tmp_path / "7" / "ann_graph_1.bin"))   # 4 GB
