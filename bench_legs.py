@@ -267,28 +267,32 @@ def config_c2(amd, torch, args, X, qlast, dev, stream, local_rank, cpu, graph_in
 
     # r5 (late): the one-pass form beyond configs[1]'s own shape - k = 64 (128 table slots per query) and a compiled filter program (evaluated once per
     # row into a bitset by one launch in front of the pass) - one query per call, each answer compared with the fp32 stream engine's under the same setting
-    def probe(kk, calls=100, check=10):
-        oo = (torch.empty((1, kk), dtype=torch.int64, device=dev), torch.empty((1, kk), dtype=torch.float32, device=dev), torch.empty((1,), dtype=torch.int32, device=dev))
+    def probe(kk, calls=100, check=10, per_call=1):
+        oo = (torch.empty((per_call, kk), dtype=torch.int64, device=dev), torch.empty((per_call, kk), dtype=torch.float32, device=dev), torch.empty((per_call,), dtype=torch.int32, device=dev))
         rr = (torch.empty_like(oo[0]), torch.empty_like(oo[1]), torch.empty_like(oo[2]))
+        span = max(1, qlast.shape[0] - per_call)
         for i in range(3):
-            ix.search(qlast[i:i + 1], kk, out=oo, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
+            ix.search(qlast[i:i + per_call], kk, out=oo, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
         torch.cuda.synchronize()
         lat, one, same = [], 0, 0
         for i in range(calls):
+            qs = qlast[i % span:i % span + per_call]
             t0 = time.perf_counter()
-            ix.search(qlast[i:i + 1], kk, out=oo, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
+            ix.search(qs, kk, out=oo, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_MFMA_I8)
             torch.cuda.synchronize()
             lat.append(time.perf_counter() - t0)
             one += int(ix.stats().get("one_pass", 0))
             if i < check:
-                ix.search(qlast[i:i + 1], kk, out=rr, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
+                ix.search(qs, kk, out=rr, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
                 torch.cuda.synchronize()
                 same += int(torch.equal(oo[0], rr[0]) and torch.equal(oo[1], rr[1]))
-        return {"k": kk, "p50_ms": 1e3 * float(np.median(lat)), "p99_ms": 1e3 * float(np.percentile(lat, 99)), "queries": calls, "one_pass_calls": one,
+        return {"k": kk, "queries_per_call": per_call, "p50_ms": 1e3 * float(np.median(lat)), "p99_ms": 1e3 * float(np.percentile(lat, 99)), "queries": calls, "one_pass_calls": one,
                 "answers_equal_to_the_stream_engine": "%d of %d" % (same, check)}
     try:
         wide = {"what": "one query per call on the one-pass form beyond k <= 16 / no filter program (r5); p50 issue -> sync, inputs in HBM"}
         wide["k64"] = probe(64)
+        for per_call in (8, 16, 32):   # (r5: up to 16 queries per call on the matrix cores; r6: 17..32 on two column blocks)
+            wide["%d_queries_per_call_k%d" % (per_call, k)] = probe(k, calls=60, check=6, per_call=per_call)
         attr = torch.arange(n1, dtype=torch.int32, device=dev).view(torch.uint8).reshape(n1, 4)
         ix.set_filter_program([("i32", 0), ("const", 3), ("%",), ("const", 1), ("=",)], attr, stride=4)
         wide["filter_program_id_mod_3_eq_1_k%d" % k] = probe(k)
@@ -454,11 +458,25 @@ def config_embedding_like(amd, torch, args, X, dev, stream, local_rank):
     g2 = (torch.empty((nrec, k), dtype=torch.int64, device=dev), torch.empty((nrec, k), dtype=torch.float32, device=dev), torch.empty((nrec,), dtype=torch.int32, device=dev))
     ix.search(Q[:nrec], k, out=g2, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_STREAM)
     torch.cuda.synchronize()
+    # r6: ONE query per call on the same table (the one-pass search under folded margins: the pass is 7.7 GB of mirror at this size)
+    single = None
+    try:
+        o1 = (torch.empty((1, k), dtype=torch.int64, device=dev), torch.empty((1, k), dtype=torch.float32, device=dev), torch.empty((1,), dtype=torch.int32, device=dev))
+        lat, one = [], 0
+        for i in range(24):
+            t0 = time.perf_counter()
+            ix.search(Q[i:i + 1], k, out=o1, mode=amd.MODE_FLAT)
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t0)
+            one += int(ix.stats().get("one_pass", 0))
+        single = {"p50_ms": 1e3 * float(np.median(lat[4:])), "calls": 20, "one_pass_calls_of_24": one, "last_answer_equals_the_batch": bool(torch.equal(o1[0][0].cpu(), torch.from_numpy(got[23])))}
+    except Exception as e:  # noqa: BLE001
+        single = {"failed": repr(e)}
     out = {"workload": "%dM x %d COSINE, unit-norm rows with Gaussian coordinates, 8 dominant dimensions (4 x scale), k=%d, batch=%d, exact flat scan (the library's engine choice)"
                        % (n // 1_000_000, d, k, b),
            "qps": b / sec, "ms_per_step": 1e3 * sec, "recall_at_10": recall_of(got[:nrec], g2[0].cpu().numpy()), "recall_check": "%d queries vs the fp32 stream scan" % nrec,
            "operand_bits": int(st.get("main_kernel_bits", 0)), "rerank_rows_per_query": st["rerank_rows"] / float(b), "overflow_queries": st["overflow_queries"],
-           "main_kernel_ms": float(np.median(km)) if km else None}
+           "main_kernel_ms": float(np.median(km)) if km else None, "one_query_per_call": single}
     ix.close()
     return out
 
