@@ -1159,6 +1159,10 @@ static int32_t flat_stream8_slice(Index& ix, const float* dq, int64_t nq, int k,
   // queries 0.235 / 0.254 / 0.281 ms against 0.38 - and loses where it leaves several times that: the same table of embedding-like rows 0.433 /
   // 0.465 / 0.505 against 0.432 / 0.443 / 0.443 (profiles/r6_one_pass_17_to_32_queries.txt).  Tables with folded margins are the looser ones.)
   if (nq > 16 && m.fold8 && tune_int("EPS_S8_MAX_Q", 0) == 0) return EPS_OK;
+  // (... and on LARGE tables: with two column blocks the pass is no longer purely HBM-bound - 24 MFMAs and 12 LDS operand reads per 16-row block - and its
+  // time grows with the queries, while the chain's 128-query tiles stream the mirror at the HBM rate whatever nq: 10M x 768, 17 / 24 / 32 queries: 1.46 /
+  // 1.54 / 1.73 ms against the chain's 1.53; 4M: 0.66 / 0.70 / 0.79 against 0.78; 2M: 0.38 / 0.40 / 0.45 against 0.51)
+  if (nq > 16 && (double)(nq - 16) * (double)n > 64e6 && tune_int("EPS_S8_MAX_Q", 0) == 0) return EPS_OK;
   // (r6: ... and per kernel form - five or more queries share one list budget per query and overflow on tables where one query does not:
   // an 8-query batch must not talk the table out of the form for single-query traffic)
   const int kclass = (k <= 16 ? 0 : 1) + (nq <= 4 ? 0 : (nq <= 16 ? 2 : 4));   // (r6: 17..32 queries - two column blocks - are a form of their own)
