@@ -228,6 +228,17 @@ if what in ("ingest", "ingest_big"):
                                                  with_distance=True)
                 ans["batch|%s|%s" % (field, flt)] = [code, [[[r["ID"] for r in rr], [r["@distance"] for r in rr]] for rr in resp]]
         out["answers"][t] = ans
+    # after rebuild() (graphs built on the device mirror of both tables; the build is deterministic): the graph path answers both tables alike
+    t0 = time.perf_counter()
+    out["rebuild_code"] = epsilla.rebuild()
+    out["rebuild_s"] = time.perf_counter() - t0
+    out["answers_after_rebuild"] = {}
+    for t in ("J", "A"):
+        ans = {}
+        for field in ("VL2", "VIP", "VCOS"):
+            code, resp = epsilla.query_batch(table_name=t, query_field=field, query_vectors=Q[:16], response_fields=["ID"], limit=10, filter="", with_distance=True)
+            ans[field] = [code, [[[r["ID"] for r in rr], [r["@distance"] for r in rr]] for rr in resp]]
+        out["answers_after_rebuild"][t] = ans
     # beyond the capacity (the binding loads databases with 150000 rows per table): both paths refuse, with the same text
     over = 150001 - rows + 2                                         # (two records were skipped as duplicates: rows - 2 are stored)
     try:

@@ -186,6 +186,11 @@ def test_gfx950_module_insert_array_leaves_the_table_the_json_insert_leaves():
         assert J[key] == A[key], key                     # (JSON round trip of the SAME floats on both sides: equality, not closeness)
     some = J["query|VCOS|"][0][1]
     assert len(some) == 10 and abs(sum(v * v for v in some[0]["VCOS"]) - 1.0) < 1e-5
+    # ... and after rebuild() (both tables' graphs built on their device mirrors): the graph path answers them alike too
+    assert out["rebuild_code"] == 0
+    RJ, RA = out["answers_after_rebuild"]["J"], out["answers_after_rebuild"]["A"]
+    for field in ("VL2", "VIP", "VCOS"):
+        assert RJ[field][0] == 0 and RJ[field] == RA[field], field
     assert out["capacity_error"] and "can hold up to 150000 records" in out["capacity_error"]
     assert out["missing_field_error"] and "missing field: Tag" in out["missing_field_error"]
     assert out["upsert"] == [0, {"inserted": 2, "skipped": 0}]
