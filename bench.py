@@ -32,8 +32,10 @@ sys.path.insert(0, ROOT)
 
 # HBM traffic of the dominant kernel is a PMC measurement (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, corrected as
 # MI355X_MICROARCH.md prescribes: gfx950 FETCH_SIZE counts 128-B requests at 64 B -> x2; KiB units) and cannot be taken inside this
-# run: `roofline.traffic` is null here and `roofline.traffic_reference` names the committed profile of the same launch shape (file,
-# sha256 of the file as it lies in this tree, the bytes it shows, and which round's kernel it was taken on).
+# process.  r6: at N = 1 on the headline shape the run measures it LIVE by re-running its headline step in two child processes under rocprofv3
+# (pmc_traffic below; --no-pmc skips it): `roofline.traffic` carries the bytes of the largest dispatch, `roofline.traffic_measurement` how they were
+# taken.  Where that is not possible (no rocprofv3, the graph mode, N > 1) `traffic` stays null; `roofline.traffic_reference` names the committed
+# profile of the same launch shape either way (file, sha256 of the file as it lies in this tree, the bytes it shows, the round's kernel it was taken on).
 TRAFFIC_REF = {
     "mfma8": {"file": "profiles/r6_pmc_10Mx768_b1024.csv", "bytes_per_launch": (2 * 2752675 + 3866) * 1024.0, "algorithmic_bytes": 7280256 * 768.0,
               "launch": "mfma_filter_kernel_v7<2, FM_IDS, int8, 8>, 7,280,256 rows x 1024 queries (last of 6 stages), occurrence 5 of the PMC passes (library kernels' rows only)",
@@ -115,6 +117,56 @@ def power_leg(torch, step, queries, seconds, device_index):
     return out
 
 
+def pmc_traffic(args, kernel_substr, want_rows_hint):
+    """HBM traffic of the dominant launch, measured LIVE: this script re-runs itself under `rocprofv3 --pmc` in two child processes (FETCH_SIZE; WRITE_SIZE -
+    separate passes, as MI355X_MICROARCH.md prescribes), headline step only, and reads the largest dispatch of the dominant kernel out of the profiler's
+    database.  gfx950: FETCH_SIZE counts 128-byte requests at 64 -> x 2; both counters are in KiB.  Returns {"bytes": ..} or {"failed": reason} - a
+    failure here never fails the bench (roofline.traffic stays null and the committed reference stands)."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return {"failed": "rocprofv3 not found"}
+    out = {"how": "two child runs of this script under rocprofv3 --pmc (FETCH_SIZE | WRITE_SIZE), headline step only; the largest dispatch of the dominant kernel; FETCH_SIZE x 2 (gfx950), KiB"}
+    vals = {}
+    t0 = time.time()
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        td = tempfile.mkdtemp(prefix="eps_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "-d", td, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--graph-rows", "0",
+               "--configs", "none", "--recall-queries", "64", "--power-seconds", "0", "--no-e2e", "--no-pmc", "--rows", str(args.rows), "--dim", str(args.dim), "--batch", str(args.batch),
+               "--k", str(args.k), "--metric", args.metric, "--engine", args.engine]
+        env = dict(os.environ, TMPDIR="/tmp")
+        for k_ in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k_, None)
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=420)
+            dbs = glob.glob(os.path.join(td, "**", "*.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return {"failed": "%s pass: rc %d, %d database(s): %s" % (counter, r.returncode, len(dbs), (r.stderr or r.stdout)[-300:])}
+            c = sqlite3.connect(dbs[0])
+            best = None
+            for did, kn, val, dur in c.execute("select dispatch_id, kernel_name, sum(value), max(duration) from counters_collection where counter_name = ? group by dispatch_id", (counter,)):
+                if kernel_substr in kn and (best is None or dur > best[1]):
+                    best = (val, dur, kn)
+            c.close()
+            if best is None:
+                return {"failed": "%s pass: no dispatch of %s in the profile" % (counter, kernel_substr)}
+            vals[counter] = best
+        except Exception as e:  # noqa: BLE001
+            return {"failed": "%s pass: %r" % (counter, e)}
+        finally:
+            shutil.rmtree(td, ignore_errors=True)
+    out["FETCH_SIZE_KiB"], out["WRITE_SIZE_KiB"] = float(vals["FETCH_SIZE"][0]), float(vals["WRITE_SIZE"][0])
+    out["bytes"] = (2.0 * out["FETCH_SIZE_KiB"] + out["WRITE_SIZE_KiB"]) * 1024.0
+    out["dispatch_us_under_the_profiler"] = float(vals["FETCH_SIZE"][1]) / 1e3
+    out["kernel"] = vals["FETCH_SIZE"][2][:120]
+    out["seconds"] = time.time() - t0
+    return out
+
+
 def traffic_ref(key):
     import hashlib
     r = dict(TRAFFIC_REF[key])
@@ -152,6 +204,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline legs (0 = skip)")
     ap.add_argument("--power-seconds", type=float, default=2.0, help="N = 1: after the timed region the same step runs back to back for this long while the shader clock and "
                     "socket power are sampled (roofline.under_load; 0 = skip)")
+    ap.add_argument("--no-pmc", dest="pmc", action="store_false", help="N = 1, flat mode, >= 5M rows: skip the two child runs under rocprofv3 --pmc that measure the dominant launch's HBM "
+                                                                         "traffic live (roofline.traffic)")
     ap.add_argument("--no-e2e", dest="e2e", action="store_false", help="skip the end-to-end (host -> host, pipelined) repetition of the timed steps")
     ap.add_argument("--scale", default="rows", choices=["queries", "rows"])
     ap.add_argument("--inproc", action="store_true", help="N > 1 in ONE process: eps_index_create_sharded over devices 0..N-1 (the form the single-process "
@@ -640,6 +694,13 @@ def main():
             roof = {"bound": "hbm", "kernel": "flat_scan_kernel", "achieved": alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms else None,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
         roof["frac"] = (roof["achieved"] / roof["peak"]) if roof["achieved"] else None
+        if used_mfma and args.mode == "flat" and world == 1 and args.pmc and n >= 5_000_000 and not args.inproc:
+            # r6: the HBM traffic of the dominant launch measured by this very run (two child processes under rocprofv3 --pmc), per launch like `achieved`
+            live = pmc_traffic(args, "mfma_filter_kernel_v7", krows)
+            roof["traffic_measurement"] = live
+            if "bytes" in live:
+                roof["traffic"] = live["bytes"]
+                roof["traffic_over_algorithmic"] = live["bytes"] / roof["algorithmic_bytes"] if roof.get("algorithmic_bytes") else None
         if args.mode == "graph" and roof["achieved"]:
             roof["gather_ceiling_measured"] = HBM_GATHER_CEILING_GBS
             roof["frac_of_gather_ceiling"] = roof["achieved"] / HBM_GATHER_CEILING_GBS

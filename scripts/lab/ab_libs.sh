@@ -9,7 +9,7 @@ rounds=$1; shift
 for r in $(seq 1 $rounds); do
   for v in "$@"; do
     cp scripts/lab/_ab/$v.so vectordb_amd/lib/libepsilla_gfx950.so
-    timeout 600 python bench.py --steps 20 --warmup 5 --cpu-seconds 0 --graph-rows 0 --configs none --recall-queries 128 2> gpurun_out/ab/$v.$r.err | python -c "
+    timeout 600 python bench.py --steps 20 --warmup 5 --cpu-seconds 0 --graph-rows 0 --configs none --recall-queries 128 --no-pmc 2> gpurun_out/ab/$v.$r.err | python -c "
 import sys, json
 j = json.loads(sys.stdin.readline())
 print('$v', $r, 'ms/step %.3f' % j['ms_per_step'], 'kernel %.3f' % j['roofline']['kernel_ms_per_launch'], 'frac %.4f' % j['roofline']['frac'], 'recall', j['recall_at_10'], 'rerank', j['stats']['rerank_rows_per_query'], 'ovf', j['stats']['overflow_queries'])"

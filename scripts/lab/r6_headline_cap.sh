@@ -15,7 +15,7 @@ cp vectordb_amd/lib/libepsilla_gfx950.so /tmp/cur.so
 for r in 1 2; do
   for v in cur noepi nolds noglobal mfmaonly; do
     cp scripts/lab/_ab/$v.so vectordb_amd/lib/libepsilla_gfx950.so
-    timeout 600 python bench.py --steps 20 --warmup 5 --cpu-seconds 0 --graph-rows 0 --configs none --recall-queries 64 --power-seconds 4 --no-e2e 2> $O/$v.$r.err | python -c "
+    timeout 600 python bench.py --steps 20 --warmup 5 --cpu-seconds 0 --graph-rows 0 --configs none --recall-queries 64 --power-seconds 4 --no-e2e --no-pmc 2> $O/$v.$r.err | python -c "
 import sys, json
 j = json.loads(sys.stdin.readline())
 p = j['roofline'].get('under_load', {}) or {}
