@@ -142,7 +142,7 @@ def pmc_traffic(args, kernel_substr, want_rows_hint):
         for k_ in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
             env.pop(k_, None)
         try:
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=420)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=150)
             dbs = glob.glob(os.path.join(td, "**", "*.db"), recursive=True)
             if r.returncode != 0 or not dbs:
                 return {"failed": "%s pass: rc %d, %d database(s): %s" % (counter, r.returncode, len(dbs), (r.stderr or r.stdout)[-300:])}
