@@ -118,53 +118,12 @@ def power_leg(torch, step, queries, seconds, device_index):
 
 
 def pmc_traffic(args, kernel_substr, want_rows_hint):
-    """HBM traffic of the dominant launch, measured LIVE: this script re-runs itself under `rocprofv3 --pmc` in two child processes (FETCH_SIZE; WRITE_SIZE -
-    separate passes, as MI355X_MICROARCH.md prescribes), headline step only, and reads the largest dispatch of the dominant kernel out of the profiler's
-    database.  gfx950: FETCH_SIZE counts 128-byte requests at 64 -> x 2; both counters are in KiB.  Returns {"bytes": ..} or {"failed": reason} - a
-    failure here never fails the bench (roofline.traffic stays null and the committed reference stands)."""
-    import glob
-    import shutil
-    import sqlite3
-    import subprocess
-    import tempfile
-    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
-    if not exe:
-        return {"failed": "rocprofv3 not found"}
-    out = {"how": "two child runs of this script under rocprofv3 --pmc (FETCH_SIZE | WRITE_SIZE), headline step only; the largest dispatch of the dominant kernel; FETCH_SIZE x 2 (gfx950), KiB"}
-    vals = {}
-    t0 = time.time()
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        td = tempfile.mkdtemp(prefix="eps_pmc_", dir="/tmp")
-        cmd = [exe, "--pmc", counter, "-d", td, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--graph-rows", "0",
-               "--configs", "none", "--recall-queries", "64", "--power-seconds", "0", "--no-e2e", "--no-pmc", "--rows", str(args.rows), "--dim", str(args.dim), "--batch", str(args.batch),
-               "--k", str(args.k), "--metric", args.metric, "--engine", args.engine]
-        env = dict(os.environ, TMPDIR="/tmp")
-        for k_ in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
-            env.pop(k_, None)
-        try:
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=150)
-            dbs = glob.glob(os.path.join(td, "**", "*.db"), recursive=True)
-            if r.returncode != 0 or not dbs:
-                return {"failed": "%s pass: rc %d, %d database(s): %s" % (counter, r.returncode, len(dbs), (r.stderr or r.stdout)[-300:])}
-            c = sqlite3.connect(dbs[0])
-            best = None
-            for did, kn, val, dur in c.execute("select dispatch_id, kernel_name, sum(value), max(duration) from counters_collection where counter_name = ? group by dispatch_id", (counter,)):
-                if kernel_substr in kn and (best is None or dur > best[1]):
-                    best = (val, dur, kn)
-            c.close()
-            if best is None:
-                return {"failed": "%s pass: no dispatch of %s in the profile" % (counter, kernel_substr)}
-            vals[counter] = best
-        except Exception as e:  # noqa: BLE001
-            return {"failed": "%s pass: %r" % (counter, e)}
-        finally:
-            shutil.rmtree(td, ignore_errors=True)
-    out["FETCH_SIZE_KiB"], out["WRITE_SIZE_KiB"] = float(vals["FETCH_SIZE"][0]), float(vals["WRITE_SIZE"][0])
-    out["bytes"] = (2.0 * out["FETCH_SIZE_KiB"] + out["WRITE_SIZE_KiB"]) * 1024.0
-    out["dispatch_us_under_the_profiler"] = float(vals["FETCH_SIZE"][1]) / 1e3
-    out["kernel"] = vals["FETCH_SIZE"][2][:120]
-    out["seconds"] = time.time() - t0
-    return out
+    """HBM traffic of the dominant launch, measured LIVE: this script re-runs its headline step in two child processes under `rocprofv3 --pmc`
+    (bench_legs.pmc_bytes).  A failure here never fails the bench (roofline.traffic stays null and the committed reference stands)."""
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--graph-rows", "0", "--configs", "none", "--recall-queries", "64",
+             "--power-seconds", "0", "--no-e2e", "--no-pmc", "--rows", str(args.rows), "--dim", str(args.dim), "--batch", str(args.batch), "--k", str(args.k), "--metric", args.metric,
+             "--engine", args.engine]
+    return pmc_bytes(child, kernel_substr)
 
 
 def traffic_ref(key):
@@ -176,7 +135,7 @@ def traffic_ref(key):
 
 
 from bench_legs import (HBM_PEAK_GBS, HBM_GATHER_CEILING_GBS, MFMA_F16_PEAK_TF, MFMA_F16_SUSTAINED_TF, MFMA_I8_PEAK_TOPS, MFMA_I8_SUSTAINED_TOPS,  # noqa: E402
-                        CpuBaseline, config_c1, config_c2, config_c4, config_embedding_like, config_secondary, cpu_baseline, exact_topk_torch, gen_rows, recall_of)
+                        CpuBaseline, config_c1, config_c2, config_c4, config_embedding_like, config_secondary, cpu_baseline, exact_topk_torch, gen_rows, pmc_bytes, recall_of)
 
 
 def parse():

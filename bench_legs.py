@@ -29,6 +29,52 @@ MFMA_I8_PEAK_TOPS = 5000.0      # dense 8-bit MFMA peak: twice the fp16 rate (MI
 MFMA_I8_SUSTAINED_TOPS = 3424.0  # measured: v_mfma_i32_32x32x32_i8 alone on bytes in [-127, 127], 1.74 GHz (profiles/r3_mfma_peak_i8_vs_fp16.txt)
 
 
+def pmc_bytes(child_argv, kernel_substr):
+    """HBM bytes of ONE launch measured live: `child_argv` (a python command that runs the launch a few times) is run twice under `rocprofv3 --pmc` - FETCH_SIZE,
+    then WRITE_SIZE: separate passes, as MI355X_MICROARCH.md prescribes - and the LONGEST dispatch whose kernel name contains `kernel_substr` is read out of the
+    profiler's database.  gfx950: FETCH_SIZE counts 128-byte requests at 64 -> x 2; both counters are in KiB.  Returns {"bytes": ..} or {"failed": reason}."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return {"failed": "rocprofv3 not found"}
+    out = {"how": "two child runs under rocprofv3 --pmc (FETCH_SIZE | WRITE_SIZE); the longest dispatch of the kernel; FETCH_SIZE x 2 (gfx950), KiB"}
+    vals = {}
+    t0 = time.time()
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        td = tempfile.mkdtemp(prefix="eps_pmc_", dir="/tmp")
+        env = dict(os.environ, TMPDIR="/tmp")
+        for k_ in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k_, None)
+        try:
+            r = subprocess.run([exe, "--pmc", counter, "-d", td, "-o", "pmc", "--"] + list(child_argv), cwd="/tmp", env=env, capture_output=True, text=True, timeout=150)
+            dbs = glob.glob(os.path.join(td, "**", "*.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return {"failed": "%s pass: rc %d, %d database(s): %s" % (counter, r.returncode, len(dbs), (r.stderr or r.stdout)[-300:])}
+            c = sqlite3.connect(dbs[0])
+            best = None
+            for did, kn, val, dur in c.execute("select dispatch_id, kernel_name, sum(value), max(duration) from counters_collection where counter_name = ? group by dispatch_id", (counter,)):
+                if kernel_substr in kn and (best is None or dur > best[1]):
+                    best = (val, dur, kn)
+            c.close()
+            if best is None:
+                return {"failed": "%s pass: no dispatch of %s in the profile" % (counter, kernel_substr)}
+            vals[counter] = best
+        except Exception as e:  # noqa: BLE001
+            return {"failed": "%s pass: %r" % (counter, e)}
+        finally:
+            shutil.rmtree(td, ignore_errors=True)
+    out["FETCH_SIZE_KiB"], out["WRITE_SIZE_KiB"] = float(vals["FETCH_SIZE"][0]), float(vals["WRITE_SIZE"][0])
+    out["bytes"] = (2.0 * out["FETCH_SIZE_KiB"] + out["WRITE_SIZE_KiB"]) * 1024.0
+    out["dispatch_us_under_the_profiler"] = float(vals["FETCH_SIZE"][1]) / 1e3
+    out["kernel"] = vals["FETCH_SIZE"][2][:120]
+    out["seconds"] = time.time() - t0
+    return out
+
+
 def gen_rows(torch, n, d, seed, device, kind="uniform", centres=None):
     """synthetic fp32 rows generated on the device in slabs (seeded per rank): i.i.d. U[0,1), or the clustered mixture"""
     g = torch.Generator(device=device).manual_seed(seed)
@@ -258,7 +304,15 @@ def config_c2(amd, torch, args, X, qlast, dev, stream, local_rank, cpu, graph_in
             ach = n1 * row_bytes / (timed["main_kernel_ms"] * 1e-3) / 1e9
             gpu["mfma_i8"]["roofline"] = {"bound": "hbm", "kernel": "stream8_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                           "kernel_ms": timed["main_kernel_ms"], "algorithmic_bytes": n1 * row_bytes,
-                                          "note": "one pass over the 8-bit mirror (%d bytes per row) + 4 bytes of start value per row; timed run p50 %.3f ms" % (row_bytes - 4, timed["p50_ms"])}
+                                          "note": "one pass over the 8-bit mirror (%d bytes per row) + 4 bytes of start value per row; timed run p50 %.3f ms" % (row_bytes - 4, timed["p50_ms"]),
+                                          "traffic": None}
+            if getattr(args, "pmc", False) and n1 == 1_000_000 and d == 768:
+                # r6: the pass's HBM bytes measured live (40 single-query calls of scripts/prof_single_query.py under rocprofv3 --pmc, the longest stream8 dispatch)
+                live = pmc_bytes([sys.executable, os.path.join(ROOT, "scripts", "prof_single_query.py"), str(n1), str(d)], "stream8_kernel")
+                gpu["mfma_i8"]["roofline"]["traffic_measurement"] = live
+                if "bytes" in live:
+                    gpu["mfma_i8"]["roofline"]["traffic"] = live["bytes"]
+                    gpu["mfma_i8"]["roofline"]["traffic_over_algorithmic"] = live["bytes"] / float(n1 * row_bytes)
     gpu["auto"], ra = latency(ix, mode=amd.MODE_FLAT, flat_engine=amd.FLAT_AUTO)
     gpu["auto"]["recall_at_10"] = recall_of(ra, gt1)
     if graph_index is not None:
