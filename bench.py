@@ -123,7 +123,10 @@ def pmc_traffic(args, kernel_substr, want_rows_hint):
     child = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--graph-rows", "0", "--configs", "none", "--recall-queries", "64",
              "--power-seconds", "0", "--no-e2e", "--no-pmc", "--rows", str(args.rows), "--dim", str(args.dim), "--batch", str(args.batch), "--k", str(args.k), "--metric", args.metric,
              "--engine", args.engine]
-    return pmc_bytes(child, kernel_substr)
+    out = pmc_bytes(child, kernel_substr)
+    child[child.index("--steps") + 1] = "6"   # (more launches for the trace's median)
+    out["kernel_trace"] = profiler_kernel_us(child, kernel_substr + "<2, 0")
+    return out
 
 
 def traffic_ref(key):
@@ -135,7 +138,7 @@ def traffic_ref(key):
 
 
 from bench_legs import (HBM_PEAK_GBS, HBM_GATHER_CEILING_GBS, MFMA_F16_PEAK_TF, MFMA_F16_SUSTAINED_TF, MFMA_I8_PEAK_TOPS, MFMA_I8_SUSTAINED_TOPS,  # noqa: E402
-                        CpuBaseline, config_c1, config_c2, config_c4, config_embedding_like, config_secondary, cpu_baseline, exact_topk_torch, gen_rows, pmc_bytes, recall_of)
+                        CpuBaseline, config_c1, config_c2, config_c4, config_embedding_like, config_secondary, cpu_baseline, exact_topk_torch, gen_rows, pmc_bytes, profiler_kernel_us, recall_of)
 
 
 def parse():
@@ -660,6 +663,10 @@ def main():
             if "bytes" in live:
                 roof["traffic"] = live["bytes"]
                 roof["traffic_over_algorithmic"] = live["bytes"] / roof["algorithmic_bytes"] if roof.get("algorithmic_bytes") else None
+            kt = live.get("kernel_trace") or {}
+            if "median_us" in kt and kernel_ms:   # (the profiler's view of the same launch: serialised dispatches, a few per cent above the hipEvent time of the timed region)
+                roof["rocprofv3_kernel_ms"] = kt["median_us"] / 1e3
+                roof["rocprofv3_over_hipevents"] = kt["median_us"] / 1e3 / kernel_ms
         if args.mode == "graph" and roof["achieved"]:
             roof["gather_ceiling_measured"] = HBM_GATHER_CEILING_GBS
             roof["frac_of_gather_ceiling"] = roof["achieved"] / HBM_GATHER_CEILING_GBS

@@ -75,6 +75,41 @@ def pmc_bytes(child_argv, kernel_substr):
     return out
 
 
+def profiler_kernel_us(child_argv, kernel_substr, top_fraction=0.85):
+    """The dominant kernel's launch duration as `rocprofv3 --kernel-trace --stats` sees it, live: one child run; the median duration of the dispatches of the kernel
+    within `top_fraction` of its longest one (= the largest stage's launches) - what the hipEvent figure of the roofline must agree with."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return {"failed": "rocprofv3 not found"}
+    td = tempfile.mkdtemp(prefix="eps_kt_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k_ in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k_, None)
+    t0 = time.time()
+    try:
+        r = subprocess.run([exe, "--kernel-trace", "--stats", "-d", td, "-o", "kt", "--"] + list(child_argv), cwd="/tmp", env=env, capture_output=True, text=True, timeout=150)
+        dbs = glob.glob(os.path.join(td, "**", "*.db"), recursive=True)
+        if r.returncode != 0 or not dbs:
+            return {"failed": "rc %d, %d database(s): %s" % (r.returncode, len(dbs), (r.stderr or r.stdout)[-300:])}
+        c = sqlite3.connect(dbs[0])
+        dur = sorted(float(d) / 1e3 for (d,) in c.execute("select duration from kernels where name like ?", ("%" + kernel_substr + "%",)))
+        c.close()
+        if not dur:
+            return {"failed": "no dispatch of %s in the trace" % kernel_substr}
+        big = [d for d in dur if d >= top_fraction * dur[-1]]
+        return {"how": "one child run under rocprofv3 --kernel-trace --stats; median of the kernel's dispatches within %.0f %% of its longest" % (100 * top_fraction),
+                "median_us": float(np.median(big)), "dispatches": len(big), "of": len(dur), "seconds": time.time() - t0}
+    except Exception as e:  # noqa: BLE001
+        return {"failed": repr(e)}
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
+
+
 def gen_rows(torch, n, d, seed, device, kind="uniform", centres=None):
     """synthetic fp32 rows generated on the device in slabs (seeded per rank): i.i.d. U[0,1), or the clustered mixture"""
     g = torch.Generator(device=device).manual_seed(seed)
