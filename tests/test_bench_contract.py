@@ -141,3 +141,22 @@ def test_bench_inproc_shard_group():
     assert d["n_gpus"] == 2 and "rows_total=240000" in d["config"]["workload"] and d["recall_at_10"] == 1.0
     for key in ("metric", "value", "unit", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
         assert key in d, key
+
+
+@pytest.mark.gpu
+def test_live_pmc_traffic_and_kernel_trace_of_a_child_run():
+    """r6: bench.py measures `roofline.traffic` itself - child runs of the launch under `rocprofv3 --pmc` (FETCH_SIZE, then WRITE_SIZE), the longest dispatch of the
+    kernel, gfx950's FETCH_SIZE x 2 - and the profiler's view of the launch duration under `--kernel-trace --stats`.  Here on a launch whose bytes are known: the
+    one-pass search over a 300 000 x 768 mirror streams 300 000 x (768 + 4) bytes."""
+    import shutil
+    if not (shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3")):
+        pytest.skip("rocprofv3 not installed")
+    sys.path.insert(0, ROOT)
+    from bench_legs import pmc_bytes, profiler_kernel_us
+    child = [sys.executable, os.path.join(ROOT, "scripts", "prof_single_query.py"), "300000", "768"]
+    t = pmc_bytes(child, "stream8_kernel")
+    assert "bytes" in t, t
+    alg = 300000 * 772.0
+    assert 0.98 * alg <= t["bytes"] <= 1.10 * alg, (t, alg)
+    kt = profiler_kernel_us(child, "stream8_kernel")
+    assert "median_us" in kt and 20.0 < kt["median_us"] < 200.0 and kt["dispatches"] >= 10, kt
