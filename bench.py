@@ -124,6 +124,7 @@ def pmc_traffic(args, kernel_substr, want_rows_hint):
              "--power-seconds", "0", "--no-e2e", "--no-pmc", "--rows", str(args.rows), "--dim", str(args.dim), "--batch", str(args.batch), "--k", str(args.k), "--metric", args.metric,
              "--engine", args.engine]
     out = pmc_bytes(child, kernel_substr)
+    out["matrix_pipe"] = pmc_counters(child, kernel_substr, ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"])
     child[child.index("--steps") + 1] = "6"   # (more launches for the trace's median)
     out["kernel_trace"] = profiler_kernel_us(child, kernel_substr + "<2, 0")
     return out
@@ -138,7 +139,7 @@ def traffic_ref(key):
 
 
 from bench_legs import (HBM_PEAK_GBS, HBM_GATHER_CEILING_GBS, MFMA_F16_PEAK_TF, MFMA_F16_SUSTAINED_TF, MFMA_I8_PEAK_TOPS, MFMA_I8_SUSTAINED_TOPS,  # noqa: E402
-                        CpuBaseline, config_c1, config_c2, config_c4, config_embedding_like, config_secondary, cpu_baseline, exact_topk_torch, gen_rows, pmc_bytes, profiler_kernel_us, recall_of)
+                        CpuBaseline, config_c1, config_c2, config_c4, config_embedding_like, config_secondary, cpu_baseline, exact_topk_torch, gen_rows, pmc_bytes, pmc_counters, profiler_kernel_us, recall_of)
 
 
 def parse():
@@ -663,6 +664,12 @@ def main():
             if "bytes" in live:
                 roof["traffic"] = live["bytes"]
                 roof["traffic_over_algorithmic"] = live["bytes"] / roof["algorithmic_bytes"] if roof.get("algorithmic_bytes") else None
+            mp = (live.get("matrix_pipe") or {}).get("values") or {}
+            if mp.get("GRBM_GUI_ACTIVE") and mp.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+                # busy cycles summed over the chip's SIMDs against the active cycles summed over its XCDs: the fraction of a clock the matrix pipe of a SIMD works
+                prop = torch.cuda.get_device_properties(local_rank)
+                simds, xcds = 4 * int(prop.multi_processor_count), 8
+                roof["matrix_pipe_busy"] = (mp["SQ_VALU_MFMA_BUSY_CYCLES"] / simds) / (mp["GRBM_GUI_ACTIVE"] / xcds)
             kt = live.get("kernel_trace") or {}
             if "median_us" in kt and kernel_ms:   # (the profiler's view of the same launch: serialised dispatches, a few per cent above the hipEvent time of the timed region)
                 roof["rocprofv3_kernel_ms"] = kt["median_us"] / 1e3

@@ -75,6 +75,41 @@ def pmc_bytes(child_argv, kernel_substr):
     return out
 
 
+def pmc_counters(child_argv, kernel_substr, counters):
+    """`counters` (one rocprofv3 --pmc pass) of the LONGEST dispatch whose kernel name contains `kernel_substr`: {"values": {name: sum over the device}} or {"failed": ..}"""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return {"failed": "rocprofv3 not found"}
+    td = tempfile.mkdtemp(prefix="eps_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k_ in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k_, None)
+    try:
+        r = subprocess.run([exe, "--pmc"] + list(counters) + ["-d", td, "-o", "pmc", "--"] + list(child_argv), cwd="/tmp", env=env, capture_output=True, text=True, timeout=150)
+        dbs = glob.glob(os.path.join(td, "**", "*.db"), recursive=True)
+        if r.returncode != 0 or not dbs:
+            return {"failed": "rc %d, %d database(s): %s" % (r.returncode, len(dbs), (r.stderr or r.stdout)[-300:])}
+        c = sqlite3.connect(dbs[0])
+        per = {}
+        for did, kn, cn, val, dur in c.execute("select dispatch_id, kernel_name, counter_name, sum(value), max(duration) from counters_collection group by dispatch_id, counter_name"):
+            if kernel_substr in kn:
+                per.setdefault(did, {"_dur": dur})[cn] = val
+        c.close()
+        if not per:
+            return {"failed": "no dispatch of %s in the profile" % kernel_substr}
+        best = max(per.values(), key=lambda v: v["_dur"])
+        return {"values": {k_: float(v) for k_, v in best.items() if k_ != "_dur"}, "dispatch_us_under_the_profiler": float(best["_dur"]) / 1e3}
+    except Exception as e:  # noqa: BLE001
+        return {"failed": repr(e)}
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
+
+
 def profiler_kernel_us(child_argv, kernel_substr, top_fraction=0.85):
     """The dominant kernel's launch duration as `rocprofv3 --kernel-trace --stats` sees it, live: one child run; the median duration of the dispatches of the kernel
     within `top_fraction` of its longest one (= the largest stage's launches) - what the hipEvent figure of the roofline must agree with."""
